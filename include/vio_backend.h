@@ -1,0 +1,196 @@
+/*
+ * vio_backend.h — C ABI of the MI355X sliding-window VIO backend.
+ *
+ * This is the drop-in boundary for the hot path of the reference's hand-written
+ * Eigen LM/Schur solver `myslam::backend::Problem` as it is driven by
+ * `Estimator::problemSolve / MargOldFrame / MargNewFrame`.
+ *
+ * Reference shorthands (read-only tree, cited as file:line):
+ *   VM/ = workspace/assignments/17-vins-initialization/vins-mono/
+ *
+ * Three shared libraries export this same surface with different prefixes, so the
+ * parity tests call all of them with identical arguments:
+ *   vio_*   libvio_hip.so      HIP/gfx950 product path (this header's prototypes)
+ *   vioo_*  liboracle.so       plain-C CPU restatement (test infrastructure only)
+ *   vior_*  oracle/_ref/...    harness around the compiled reference Problem (tests, this container)
+ *
+ * Conventions
+ *   - plain pointers and sizes; every input is copied at the call, every output is written
+ *     into caller-provided buffers; no pointer is retained after return.
+ *   - all floating point is IEEE fp64; all matrices are dense ROW-MAJOR.
+ *   - pose layout  (x,y,z,qx,qy,qz,qw)            VM/src/estimator.cpp:505-547 (vector2double)
+ *     speed-bias   (vx,vy,vz,bax,bay,baz,bgx,bgy,bgz)
+ *   - pose-block ordering of the reduced system (dimension VIO_POSE_DIM = 171):
+ *       [ ext(6) | pose_0(6) sb_0(9) | ... | pose_10(6) sb_10(9) ]
+ *     VM/src/backend/problem.cc:256-285 (SetOrdering) with the vertex creation order of
+ *     VM/src/estimator.cpp:915-953.  Landmark k has ordering id 171 + k.
+ *   - one context = one HIP stream = one caller thread at a time (the reference backend is not
+ *     re-entrant either: VM/src/System.cpp:358-441).
+ *   - every function returns a vio_status; nothing throws or aborts across the ABI.
+ */
+#ifndef VIO_BACKEND_H
+#define VIO_BACKEND_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIO_WINDOW_SIZE 10                      /* VM/include/parameters.h:35 */
+#define VIO_NUM_FRAMES (VIO_WINDOW_SIZE + 1)    /* 11 poses + 11 speed-biases */
+#define VIO_POSE_DIM (6 + 15 * VIO_NUM_FRAMES)  /* 171, VM/src/estimator.cpp:931,942,952 */
+#define VIO_PRIOR_DIM (VIO_POSE_DIM - 15)       /* 156, output of Problem::Marginalize */
+#define VIO_CAM_DIM (6 + 6 * VIO_NUM_FRAMES)    /* 72: ext + 11 poses, the columns visual factors touch */
+
+struct vio_ctx;                                 /* opaque; owns all device memory behind the handle */
+typedef struct vio_ctx vio_ctx;
+
+typedef enum {
+    VIO_OK = 0,
+    VIO_ERR_BAD_ARG = -1,
+    VIO_ERR_HIP = -2,          /* a HIP runtime call failed; see vio_last_error() */
+    VIO_ERR_NOT_FINITE = -3,   /* chi2 or the linear solve produced a non-finite value */
+    VIO_ERR_EMPTY = -4,        /* Problem::Solve returns false on an empty graph, problem.cc:172-175 */
+    VIO_ERR_UNSUPPORTED = -5,  /* graph shape outside what the window layout can express */
+    VIO_ERR_NO_DEVICE = -6
+} vio_status;
+
+typedef enum {                 /* VM/include/backend/loss_function.h:23-91 */
+    VIO_LOSS_TRIVIAL = 0,
+    VIO_LOSS_HUBER = 1,
+    VIO_LOSS_CAUCHY = 2,       /* the one Estimator uses, delta = 1.0 (estimator.cpp:905) */
+    VIO_LOSS_TUKEY = 3
+} vio_loss_type;
+
+typedef enum {
+    VIO_MARG_OLD = 0,          /* Estimator::MargOldFrame  estimator.cpp:693-829 */
+    VIO_MARG_SECOND_NEW = 1    /* Estimator::MargNewFrame  estimator.cpp:830-901 */
+} vio_marg_kind;
+
+typedef struct vio_config {
+    int32_t device;            /* HIP device ordinal (ignored by the CPU libraries) */
+    int32_t ext_fixed;         /* 1 == vertexExt->SetFixed(), i.e. ESTIMATE_EXTRINSIC == 0 (estimator.cpp:921-926) */
+    int32_t loss_type;         /* vio_loss_type applied to every reprojection edge */
+    int32_t reserved0;
+    double loss_delta;         /* CauchyLoss(1.0) in the reference */
+    double reproj_sqrt_info;   /* s in project_sqrt_info_ = s*I2, reference s = 460/1.5; the edge information is
+                                  s^2*I2 (estimator.cpp:42,1012) */
+    double gravity[3];         /* global G read by IntegrationBase::evaluate (integration_base.h:178-180) */
+    void *stream;              /* optional hipStream_t to enqueue on (NULL: the library creates its own) */
+    int32_t shard_rank;        /* landmark shard index of this context (multi-GPU), 0 when unsharded */
+    int32_t shard_count;       /* number of shards; IMU + prior terms are added by rank 0 only */
+} vio_config;
+
+/* State of one IntegrationBase as EdgeImu consumes it (VM/include/factor/integration_base.h:160-208,
+ * VM/src/backend/edge_imu.cc:13-156).  Offsets inside jacobian/covariance follow StateOrder
+ * O_P=0,O_R=3,O_V=6,O_BA=9,O_BG=12 (VM/include/parameters.h:75-82). */
+typedef struct vio_preint {
+    double sum_dt;
+    double delta_p[3];
+    double delta_q[4];         /* x,y,z,w */
+    double delta_v[3];
+    double linearized_ba[3];
+    double linearized_bg[3];
+    double jacobian[225];      /* 15x15 row-major */
+    double covariance[225];    /* 15x15 row-major; information = covariance^-1 (edge_imu.cc:35) */
+} vio_preint;
+
+typedef struct vio_solve_report {
+    int32_t iterations;        /* outer LM iterations executed (problem.cc:188) */
+    int32_t trials;            /* SolveLinearSystem calls (accepted + rejected) */
+    int32_t accepted;          /* accepted steps */
+    int32_t stop_reason;       /* 0: iteration cap, 1: chi2 decrease < 1e-5 (problem.cc:239) */
+    double initial_chi2;
+    double final_chi2;         /* currentChi_ */
+    double final_lambda;       /* currentLambda_ */
+    double solve_ms;           /* wall clock of the whole call, "problem solve cost" (problem.cc:246) */
+    double hessian_ms;         /* device time spent linearising, "makeHessian cost" (problem.cc:247) */
+    double chi2_trace[128];    /* currentChi_ at the top of each outer iteration */
+    double lambda_trace[128];
+} vio_solve_report;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+vio_status vio_create(const vio_config *cfg, struct vio_ctx **out);
+void vio_destroy(struct vio_ctx *ctx);
+const char *vio_last_error(const struct vio_ctx *ctx);   /* valid until the next call on ctx */
+void vio_default_config(vio_config *cfg);                /* the reference's constants */
+
+/* ---- graph construction: replaces AddVertex/AddEdge in estimator.cpp:909-1034 ----------- */
+/* para_Pose[11][7], para_SpeedBias[11][9], para_Ex_Pose[0][7]  (estimator.h:113-119) */
+vio_status vio_set_window(struct vio_ctx *ctx, const double *poses, const double *speed_bias,
+                          const double *ext);
+/* VertexInverseDepth x N, in creation order (estimator.cpp:988-993); N is bounded by device memory only */
+vio_status vio_set_landmarks(struct vio_ctx *ctx, int64_t n, const double *inv_depth);
+/* EdgeReprojection x M (estimator.cpp:996-1016): edge e connects landmark lm[e], host frame host[e],
+ * target frame target[e] and the extrinsic; pts_i/pts_j are the normalised (x,y) of the two
+ * observations (z == 1 is implied, feature_manager.h).  All edges of one landmark must share
+ * host[e] and pts_i (they do in the reference: one host observation per feature). */
+vio_status vio_set_observations(struct vio_ctx *ctx, int64_t m, const int32_t *lm,
+                                const int32_t *host, const int32_t *target,
+                                const double *pts_i_xy, const double *pts_j_xy);
+/* EdgeImu between frames k and k+1, k in [0,10) (estimator.cpp:956-970).  pre == NULL removes the
+ * edge (the reference skips it when sum_dt > 10). */
+vio_status vio_set_imu(struct vio_ctx *ctx, int32_t k, const vio_preint *pre);
+/* SetHessianPrior/SetbPrior/SetErrPrior/SetJtPrior + ExtendHessiansPriorSize(15)
+ * (estimator.cpp:1023-1034, problem.cc:82-91).  dim is 0 (no prior yet) or VIO_PRIOR_DIM;
+ * H is dim x dim, b and err have dim entries, jt_inv is dim x dim. */
+vio_status vio_set_prior(struct vio_ctx *ctx, int32_t dim, const double *H, const double *b,
+                         const double *err, const double *jt_inv);
+
+/* ---- the solve: Problem::Solve(iterations)  problem.cc:169-250 ---------------------------- */
+vio_status vio_solve(struct vio_ctx *ctx, int32_t iterations, vio_solve_report *report);
+
+/* ---- single steps of the LM loop (the reference's private methods), for parity tests,
+ *      the multi-GPU driver and the benchmark ------------------------------------------------- */
+vio_status vio_linearize(struct vio_ctx *ctx);                      /* SetOrdering + MakeHessian  problem.cc:303-389 */
+vio_status vio_init_lm(struct vio_ctx *ctx, double *chi2, double *lambda); /* ComputeLambdaInitLM  :497-522 */
+vio_status vio_solve_linear(struct vio_ctx *ctx, double lambda);    /* SolveLinearSystem          :394-451 */
+vio_status vio_update_states(struct vio_ctx *ctx);                  /* UpdateStates               :453-480 */
+vio_status vio_rollback_states(struct vio_ctx *ctx);                /* RollbackStates             :482-494 */
+/* 0.5*(sum RobustChi2 + ||err_prior||) at the current states (problem.cc:549-556) */
+vio_status vio_chi2(struct vio_ctx *ctx, double *chi2);
+/* IsGoodStepInLM (problem.cc:541-573) with the context's own currentChi_/currentLambda_/ni_ */
+vio_status vio_eval_step(struct vio_ctx *ctx, int32_t *accepted, double *chi2, double *lambda);
+/* One fixed-lambda Gauss-Newton iteration, fully enqueued with no host round trip:
+ * linearise -> reduce -> IMU + prior -> damped LDLT -> back-substitute -> update -> chi2.
+ * This is BASELINE.json's "GN iteration" (SURVEY.md section 8d). */
+vio_status vio_gn_iteration(struct vio_ctx *ctx, double lambda);
+vio_status vio_synchronize(struct vio_ctx *ctx);
+
+/* ---- marginalisation: Marg{Old,New}Frame + Problem::Marginalize  problem.cc:617-795 ------ */
+/* Uses the window/landmarks/observations/IMU/prior currently set.  Outputs the new prior
+ * (VIO_PRIOR_DIM): H dim x dim, b, err, jt_inv dim x dim. */
+vio_status vio_marginalize(struct vio_ctx *ctx, int32_t kind, double *H, double *b, double *err,
+                           double *jt_inv);
+
+/* ---- read back ------------------------------------------------------------------------------ */
+vio_status vio_get_window(struct vio_ctx *ctx, double *poses, double *speed_bias, double *ext);
+vio_status vio_get_landmarks(struct vio_ctx *ctx, int64_t n, double *inv_depth);
+/* b_prior_ (VIO_POSE_DIM entries) and err_prior_ (VIO_PRIOR_DIM) after the first-order updates
+ * (estimator.cpp:1040-1049) */
+vio_status vio_get_prior(struct vio_ctx *ctx, double *b, double *err);
+/* delta_x_: pose part (171) and landmark part (n) of the last SolveLinearSystem */
+vio_status vio_get_delta(struct vio_ctx *ctx, double *dx_pose, int64_t n, double *dx_landmarks);
+/* H_pp_schur_ WITHOUT the lambda of problem.cc:434-436, and b_pp_schur_ (171x171, 171) */
+vio_status vio_get_schur_system(struct vio_ctx *ctx, double *H, double *b);
+/* Hmm diagonal and bmm (n entries each), and the pose part of b_ / diag(Hessian_) (171 each) */
+vio_status vio_get_landmark_system(struct vio_ctx *ctx, int64_t n, double *hll, double *bl);
+vio_status vio_get_pose_gradient(struct vio_ctx *ctx, double *b_pose, double *diag_pose);
+
+/* ---- multi-GPU exchange ------------------------------------------- */
+/* Device pointer + element count of the packed fp64 buffer that must be summed over all shards
+ * between vio_linearize and vio_solve_linear (one RCCL all-reduce), and of the scalar buffer
+ * summed after vio_update_states (chi2 + gain-ratio scale). */
+vio_status vio_exchange_buffers(struct vio_ctx *ctx, void **reduced_system, int64_t *reduced_count,
+                                void **step_scalars, int64_t *scalar_count);
+/* Hook called on the host, stream-ordered, wherever the LM loop needs an exchange
+ * (which == 0: reduced system, 1: step scalars).  NULL (default) = unsharded. */
+typedef int (*vio_exchange_fn)(void *user, int which);
+vio_status vio_set_exchange_hook(struct vio_ctx *ctx, vio_exchange_fn fn, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIO_BACKEND_H */

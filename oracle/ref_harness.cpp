@@ -1,0 +1,574 @@
+/*
+ * ref_harness.cpp — drives the REFERENCE's own backend sources (compiled where they lie under
+ * /root/reference by oracle/Makefile; outputs only into oracle/_ref/) through the C ABI of
+ * include/vio_backend.h, under the prefix `vior_`.
+ *
+ * TEST INFRASTRUCTURE ONLY (validates oracle/vio_oracle.c and generates tests/golden/).
+ * It is built only in the container that has /root/reference; the resulting oracle/_ref/*.so is
+ * git-ignored.  No reference source text lives in this file: it only *calls* the reference's
+ * classes the way Estimator::problemSolve / MargOldFrame / MargNewFrame do
+ * (VM/src/estimator.cpp:693-1073).
+ *
+ * What is the reference here, and what is not:
+ *   reference code   Problem, Vertex, VertexPose, VertexSpeedBias, VertexInverseDepth, Edge,
+ *                    EdgeReprojection, CauchyLoss/HuberLoss/TukeyLoss, vendored Eigen 3.3.4, Sophus
+ *   NOT reference    the IMU edge.  VM/include/backend/edge_imu.h pulls in
+ *                    VM/include/factor/integration_base.h, whose line 6 includes <ceres/ceres.h>;
+ *                    the image has no Ceres and a stand-in header is not allowed, so EdgeImu is
+ *                    unbuildable here.  The harness therefore plugs `EdgeImuPort` — an Edge subclass
+ *                    whose residual/Jacobians come from oracle/vio_oracle.c (vioo_imu_edge) and whose
+ *                    information is covariance.inverse() evaluated with the reference's Eigen exactly
+ *                    as edge_imu.cc:35 does — into the reference Problem.  Everything the Problem
+ *                    does with that edge (robust info, Hessian blocks, Schur, LDLT, update, chi2,
+ *                    marginalisation) is reference code.
+ */
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <eigen3/Eigen/Dense>
+
+#define private public
+#define protected public
+#include "backend/problem.h"
+#include "backend/edge_reprojection.h"
+#include "backend/vertex_inverse_depth.h"
+#include "backend/vertex_pose.h"
+#include "backend/vertex_speedbias.h"
+#include "backend/loss_function.h"
+#undef private
+#undef protected
+
+#include "vio_oracle.h" /* vioo_imu_edge for EdgeImuPort */
+#undef vio_ctx
+#undef vio_create
+#undef vio_destroy
+#undef vio_last_error
+#undef vio_default_config
+#undef vio_set_window
+#undef vio_set_landmarks
+#undef vio_set_observations
+#undef vio_set_imu
+#undef vio_set_prior
+#undef vio_solve
+#undef vio_linearize
+#undef vio_init_lm
+#undef vio_solve_linear
+#undef vio_update_states
+#undef vio_rollback_states
+#undef vio_chi2
+#undef vio_eval_step
+#undef vio_gn_iteration
+#undef vio_synchronize
+#undef vio_marginalize
+#undef vio_get_window
+#undef vio_get_landmarks
+#undef vio_get_prior
+#undef vio_get_delta
+#undef vio_get_schur_system
+#undef vio_get_landmark_system
+#undef vio_get_pose_gradient
+#undef vio_exchange_buffers
+#undef vio_set_exchange_hook
+
+using namespace myslam::backend;
+typedef Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> RowMat;
+
+namespace {
+
+const int NF = VIO_NUM_FRAMES, PD = VIO_POSE_DIM, PRD = VIO_PRIOR_DIM;
+
+class EdgeImuPort : public Edge {
+public:
+    EIGEN_MAKE_ALIGNED_OPERATOR_NEW;
+    EdgeImuPort(const vio_preint &pre, const double *g)
+        : Edge(15, 4, std::vector<std::string>{"VertexPose", "VertexSpeedBias", "VertexPose", "VertexSpeedBias"}),
+          pre_(pre) {
+        g_[0] = g[0]; g_[1] = g[1]; g_[2] = g[2];
+        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) cov_(i, j) = pre.covariance[15 * i + j];
+    }
+    std::string TypeInfo() const override { return "EdgeImu"; }
+    void gather(double *pi, double *si, double *pj, double *sj) {
+        for (int k = 0; k < 7; ++k) { pi[k] = verticies_[0]->Parameters()[k]; pj[k] = verticies_[2]->Parameters()[k]; }
+        for (int k = 0; k < 9; ++k) { si[k] = verticies_[1]->Parameters()[k]; sj[k] = verticies_[3]->Parameters()[k]; }
+    }
+    void ComputeResidual() override {
+        double pi[7], si[9], pj[7], sj[9], r[15];
+        gather(pi, si, pj, sj);
+        vioo_imu_edge(&pre_, g_, pi, si, pj, sj, r, NULL, NULL, NULL, NULL);
+        for (int k = 0; k < 15; ++k) residual_[k] = r[k];
+        SetInformation(cov_.inverse());     /* as edge_imu.cc:35, with the reference's Eigen */
+    }
+    void ComputeJacobians() override {
+        double pi[7], si[9], pj[7], sj[9], J0[90], J1[135], J2[90], J3[135];
+        gather(pi, si, pj, sj);
+        vioo_imu_edge(&pre_, g_, pi, si, pj, sj, NULL, J0, J1, J2, J3);
+        jacobians_[0] = Eigen::Map<Eigen::Matrix<double, 15, 6, Eigen::RowMajor>>(J0);
+        jacobians_[1] = Eigen::Map<Eigen::Matrix<double, 15, 9, Eigen::RowMajor>>(J1);
+        jacobians_[2] = Eigen::Map<Eigen::Matrix<double, 15, 6, Eigen::RowMajor>>(J2);
+        jacobians_[3] = Eigen::Map<Eigen::Matrix<double, 15, 9, Eigen::RowMajor>>(J3);
+    }
+    vio_preint pre_;
+    double g_[3];
+    Eigen::Matrix<double, 15, 15> cov_;
+};
+
+struct Graph {
+    std::unique_ptr<Problem> problem;
+    std::shared_ptr<VertexPose> ext;
+    std::vector<std::shared_ptr<VertexPose>> cams;
+    std::vector<std::shared_ptr<VertexSpeedBias>> vbs;
+    std::vector<std::shared_ptr<VertexInverseDepth>> pts;      /* indexed by landmark id, may be null */
+    std::vector<std::shared_ptr<Edge>> edges;
+    std::unique_ptr<LossFunction> loss;
+};
+
+}  // namespace
+
+struct vior_ctx {
+    vio_config cfg;
+    std::string err;
+    double pose[NF * 7], sb[NF * 9], ext[7];
+    std::vector<double> invd;
+    std::vector<int32_t> lm, host, target;
+    std::vector<double> pts_i, pts_j;
+    bool imu_valid[VIO_WINDOW_SIZE];
+    vio_preint pre[VIO_WINDOW_SIZE];
+    int prior_dim;
+    MatXX Hprior, Jtinv;
+    VecX bprior, errprior;
+    std::unique_ptr<Graph> g;       /* the live solve graph */
+    MatXX Hs;                       /* H_pp_schur_ evaluated with lambda = 0 */
+    VecX bs;
+    bool silent;
+};
+
+static LossFunction *make_loss(const vio_config &cfg) {
+    switch (cfg.loss_type) {
+    case VIO_LOSS_HUBER: return new HuberLoss(cfg.loss_delta);
+    case VIO_LOSS_CAUCHY: return new CauchyLoss(cfg.loss_delta);
+    case VIO_LOSS_TUKEY: return new TukeyLoss(cfg.loss_delta);
+    default: return nullptr;
+    }
+}
+
+/* Graph construction in the order of Estimator::problemSolve (estimator.cpp:909-1034);
+ * marg = 0 solve graph, 1 MargOldFrame graph (:699-810), 2 MargNewFrame graph (:834-885). */
+static std::unique_ptr<Graph> build_graph(vior_ctx *c, int marg) {
+    std::unique_ptr<Graph> g(new Graph);
+    g->loss.reset(make_loss(c->cfg));
+    g->problem.reset(new Problem(Problem::ProblemType::SLAM_PROBLEM));
+    Problem &problem = *g->problem;
+    g->ext.reset(new VertexPose());
+    {
+        Eigen::VectorXd p(7);
+        for (int k = 0; k < 7; ++k) p[k] = c->ext[k];
+        g->ext->SetParameters(p);
+        if (marg == 0 && c->cfg.ext_fixed) g->ext->SetFixed();
+        problem.AddVertex(g->ext);
+    }
+    for (int i = 0; i < NF; ++i) {
+        std::shared_ptr<VertexPose> cam(new VertexPose());
+        Eigen::VectorXd p(7);
+        for (int k = 0; k < 7; ++k) p[k] = c->pose[7 * i + k];
+        cam->SetParameters(p);
+        g->cams.push_back(cam);
+        problem.AddVertex(cam);
+        std::shared_ptr<VertexSpeedBias> vb(new VertexSpeedBias());
+        Eigen::VectorXd v(9);
+        for (int k = 0; k < 9; ++k) v[k] = c->sb[9 * i + k];
+        vb->SetParameters(v);
+        g->vbs.push_back(vb);
+        problem.AddVertex(vb);
+    }
+    if (marg != 2) {
+        for (int k = 0; k < VIO_WINDOW_SIZE; ++k) {
+            if (!c->imu_valid[k]) continue;
+            if (marg == 1 && k != 0) continue;
+            std::shared_ptr<EdgeImuPort> e(new EdgeImuPort(c->pre[k], c->cfg.gravity));
+            std::vector<std::shared_ptr<Vertex>> ev{g->cams[k], g->vbs[k], g->cams[k + 1], g->vbs[k + 1]};
+            e->SetVertex(ev);
+            problem.AddEdge(e);
+            g->edges.push_back(e);
+        }
+        const double s = c->cfg.reproj_sqrt_info;
+        Eigen::Matrix2d sqrt_info = s * Eigen::Matrix2d::Identity();
+        g->pts.assign(c->invd.size(), nullptr);
+        /* landmarks are created on first use so that the vertex-id order equals estimator.cpp:988-1016
+         * when the caller lists observations grouped by landmark, as the reference does */
+        for (size_t e = 0; e < c->lm.size(); ++e) {
+            int l = c->lm[e];
+            if (marg == 1 && c->host[e] != 0) continue;
+            if (!g->pts[l]) {
+                std::shared_ptr<VertexInverseDepth> v(new VertexInverseDepth());
+                VecX inv_d(1);
+                inv_d << c->invd[l];
+                v->SetParameters(inv_d);
+                problem.AddVertex(v);
+                g->pts[l] = v;
+            }
+            Vec3 pi(c->pts_i[2 * e], c->pts_i[2 * e + 1], 1.0), pj(c->pts_j[2 * e], c->pts_j[2 * e + 1], 1.0);
+            std::shared_ptr<EdgeReprojection> edge(new EdgeReprojection(pi, pj));
+            std::vector<std::shared_ptr<Vertex>> ev{g->pts[l], g->cams[c->host[e]], g->cams[c->target[e]], g->ext};
+            edge->SetVertex(ev);
+            edge->SetInformation(sqrt_info.transpose() * sqrt_info);
+            if (g->loss) edge->SetLossFunction(g->loss.get());
+            problem.AddEdge(edge);
+            g->edges.push_back(edge);
+        }
+        if (marg == 0) {
+            /* problemSolve adds every selected landmark even though all of them have edges; a landmark
+             * without any observation cannot occur there, so nothing else to add */
+        }
+    }
+    if (c->prior_dim > 0) {
+        problem.SetHessianPrior(c->Hprior);
+        problem.SetbPrior(c->bprior);
+        problem.SetErrPrior(c->errprior);
+        problem.SetJtPrior(c->Jtinv);
+        problem.ExtendHessiansPriorSize(15);
+    } else if (marg == 1) {
+        MatXX H(PD, PD); H.setZero();
+        VecX b(PD); b.setZero();
+        problem.SetHessianPrior(H);
+        problem.SetbPrior(b);
+    }
+    return g;
+}
+
+static void pull_states(vior_ctx *c) {
+    Graph &g = *c->g;
+    for (int k = 0; k < 7; ++k) c->ext[k] = g.ext->Parameters()[k];
+    for (int i = 0; i < NF; ++i) {
+        for (int k = 0; k < 7; ++k) c->pose[7 * i + k] = g.cams[i]->Parameters()[k];
+        for (int k = 0; k < 9; ++k) c->sb[9 * i + k] = g.vbs[i]->Parameters()[k];
+    }
+    for (size_t l = 0; l < c->invd.size(); ++l) if (g.pts[l]) c->invd[l] = g.pts[l]->Parameters()[0];
+}
+
+struct CoutSilencer {
+    std::streambuf *old;
+    std::ostringstream sink;
+    CoutSilencer() { old = std::cout.rdbuf(sink.rdbuf()); }
+    ~CoutSilencer() { std::cout.rdbuf(old); }
+};
+
+extern "C" {
+
+void vior_default_config(vio_config *cfg) { vioo_default_config(cfg); }
+
+vio_status vior_create(const vio_config *cfg, vior_ctx **out) {
+    if (!cfg || !out) return VIO_ERR_BAD_ARG;
+    vior_ctx *c = new vior_ctx();
+    c->cfg = *cfg;
+    std::memset(c->pose, 0, sizeof(c->pose)); std::memset(c->sb, 0, sizeof(c->sb)); std::memset(c->ext, 0, sizeof(c->ext));
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) c->imu_valid[k] = false;
+    c->prior_dim = 0;
+    c->silent = true;
+    *out = c;
+    return VIO_OK;
+}
+void vior_destroy(vior_ctx *c) { delete c; }
+const char *vior_last_error(const vior_ctx *c) { return c ? c->err.c_str() : "null"; }
+
+vio_status vior_set_window(vior_ctx *c, const double *poses, const double *sb, const double *ext) {
+    std::memcpy(c->pose, poses, sizeof(c->pose)); std::memcpy(c->sb, sb, sizeof(c->sb)); std::memcpy(c->ext, ext, sizeof(c->ext));
+    c->g.reset();
+    return VIO_OK;
+}
+vio_status vior_set_landmarks(vior_ctx *c, int64_t n, const double *invd) {
+    c->invd.assign(invd, invd + n);
+    c->g.reset();
+    return VIO_OK;
+}
+vio_status vior_set_observations(vior_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target,
+                                 const double *pi, const double *pj) {
+    c->lm.assign(lm, lm + m); c->host.assign(host, host + m); c->target.assign(target, target + m);
+    c->pts_i.assign(pi, pi + 2 * m); c->pts_j.assign(pj, pj + 2 * m);
+    c->g.reset();
+    return VIO_OK;
+}
+vio_status vior_set_imu(vior_ctx *c, int32_t k, const vio_preint *pre) {
+    if (k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
+    c->imu_valid[k] = pre != NULL;
+    if (pre) c->pre[k] = *pre;
+    c->g.reset();
+    return VIO_OK;
+}
+vio_status vior_set_prior(vior_ctx *c, int32_t dim, const double *H, const double *b, const double *err, const double *jt) {
+    if (dim != 0 && dim != PRD) return VIO_ERR_BAD_ARG;
+    c->prior_dim = dim;
+    if (dim) {
+        c->Hprior = Eigen::Map<const RowMat>(H, dim, dim);
+        c->bprior = Eigen::Map<const VecX>(b, dim);
+        c->errprior = Eigen::Map<const VecX>(err, dim);
+        c->Jtinv = Eigen::Map<const RowMat>(jt, dim, dim);
+    }
+    c->g.reset();
+    return VIO_OK;
+}
+
+static void ensure_graph(vior_ctx *c) { if (!c->g) c->g = build_graph(c, 0); }
+
+vio_status vior_linearize(vior_ctx *c) {
+    ensure_graph(c);
+    CoutSilencer s;
+    Problem &p = *c->g->problem;
+    p.SetOrdering();
+    p.MakeHessian();
+    /* evaluate the reference's own Schur complement once with lambda = 0 so that H_pp_schur_/b_pp_schur_
+     * can be read back without the damping term (the LDLT result of this call is discarded) */
+    double keep = p.currentLambda_;
+    p.currentLambda_ = 0.0;
+    p.SolveLinearSystem();
+    c->Hs = p.H_pp_schur_;
+    c->bs = p.b_pp_schur_;
+    p.currentLambda_ = keep;
+    p.delta_x_.setZero();
+    return VIO_OK;
+}
+vio_status vior_init_lm(vior_ctx *c, double *chi2, double *lambda) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    c->g->problem->ComputeLambdaInitLM();
+    if (chi2) *chi2 = c->g->problem->currentChi_;
+    if (lambda) *lambda = c->g->problem->currentLambda_;
+    return VIO_OK;
+}
+vio_status vior_solve_linear(vior_ctx *c, double lambda) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    c->g->problem->currentLambda_ = lambda;
+    c->g->problem->SolveLinearSystem();
+    return VIO_OK;
+}
+vio_status vior_update_states(vior_ctx *c) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    c->g->problem->UpdateStates();
+    pull_states(c);
+    return VIO_OK;
+}
+vio_status vior_rollback_states(vior_ctx *c) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    c->g->problem->RollbackStates();
+    pull_states(c);
+    return VIO_OK;
+}
+vio_status vior_chi2(vior_ctx *c, double *chi2) {
+    ensure_graph(c);
+    Problem &p = *c->g->problem;
+    double t = 0;
+    for (auto &e : p.edges_) { e.second->ComputeResidual(); t += e.second->RobustChi2(); }
+    if (p.err_prior_.size() > 0) t += p.err_prior_.norm();
+    *chi2 = 0.5 * t;
+    return VIO_OK;
+}
+vio_status vior_eval_step(vior_ctx *c, int32_t *accepted, double *chi2, double *lambda) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    bool ok = c->g->problem->IsGoodStepInLM();
+    if (accepted) *accepted = ok ? 1 : 0;
+    if (chi2) *chi2 = c->g->problem->currentChi_;
+    if (lambda) *lambda = c->g->problem->currentLambda_;
+    return VIO_OK;
+}
+vio_status vior_solve(vior_ctx *c, int32_t iterations, vio_solve_report *rep) {
+    c->g = build_graph(c, 0);
+    std::string log;
+    bool ok;
+    {
+        CoutSilencer s;
+        ok = c->g->problem->Solve(iterations);
+        log = s.sink.str();
+    }
+    if (!ok) return VIO_ERR_EMPTY;
+    pull_states(c);
+    if (rep) {
+        std::memset(rep, 0, sizeof(*rep));
+        std::istringstream in(log);
+        std::string line;
+        int it = 0;
+        while (std::getline(in, line)) {
+            int k; double chi, lam;
+            if (std::sscanf(line.c_str(), "iter: %d , chi= %lf , Lambda= %lf", &k, &chi, &lam) == 3 && it < 128) {
+                rep->chi2_trace[it] = chi; rep->lambda_trace[it] = lam; ++it;   /* 6 significant digits only */
+            }
+        }
+        rep->iterations = it;
+        rep->final_chi2 = c->g->problem->currentChi_;
+        rep->final_lambda = c->g->problem->currentLambda_;
+    }
+    return VIO_OK;
+}
+vio_status vior_gn_iteration(vior_ctx *c, double lambda) {
+    vior_linearize(c);
+    vior_solve_linear(c, lambda);
+    return vior_update_states(c);
+}
+vio_status vior_synchronize(vior_ctx *) { return VIO_OK; }
+
+vio_status vior_marginalize(vior_ctx *c, int32_t kind, double *H, double *b, double *err, double *jt) {
+    std::unique_ptr<Graph> g = build_graph(c, kind == VIO_MARG_OLD ? 1 : 2);
+    std::vector<std::shared_ptr<Vertex>> marg;
+    int f = kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1;
+    marg.push_back(g->cams[f]);
+    marg.push_back(g->vbs[f]);
+    {
+        CoutSilencer s;
+        g->problem->Marginalize(marg, PD);
+    }
+    MatXX Hp = g->problem->GetHessianPrior();
+    VecX bp = g->problem->GetbPrior(), ep = g->problem->GetErrPrior();
+    MatXX Jp = g->problem->GetJtPrior();
+    if (Hp.rows() != PRD) return VIO_ERR_UNSUPPORTED;
+    Eigen::Map<RowMat>(H, PRD, PRD) = Hp;
+    Eigen::Map<VecX>(b, PRD) = bp;
+    Eigen::Map<VecX>(err, PRD) = ep;
+    Eigen::Map<RowMat>(jt, PRD, PRD) = Jp;
+    return VIO_OK;
+}
+
+vio_status vior_get_window(vior_ctx *c, double *poses, double *sb, double *ext) {
+    if (poses) std::memcpy(poses, c->pose, sizeof(c->pose));
+    if (sb) std::memcpy(sb, c->sb, sizeof(c->sb));
+    if (ext) std::memcpy(ext, c->ext, sizeof(c->ext));
+    return VIO_OK;
+}
+vio_status vior_get_landmarks(vior_ctx *c, int64_t n, double *invd) {
+    if ((size_t)n != c->invd.size()) return VIO_ERR_BAD_ARG;
+    std::memcpy(invd, c->invd.data(), sizeof(double) * n);
+    return VIO_OK;
+}
+vio_status vior_get_prior(vior_ctx *c, double *b, double *err) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    Problem &p = *c->g->problem;
+    if (b) { for (int i = 0; i < PD; ++i) b[i] = i < p.b_prior_.size() ? p.b_prior_[i] : 0.0; }
+    if (err) { for (int i = 0; i < PRD; ++i) err[i] = i < p.err_prior_.size() ? p.err_prior_[i] : 0.0; }
+    return VIO_OK;
+}
+vio_status vior_get_delta(vior_ctx *c, double *dxp, int64_t n, double *dxl) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    Problem &p = *c->g->problem;
+    if (dxp) for (int i = 0; i < PD; ++i) dxp[i] = p.delta_x_[i];
+    if (dxl) for (int64_t l = 0; l < n; ++l) dxl[l] = c->g->pts[l] ? p.delta_x_[c->g->pts[l]->OrderingId()] : 0.0;
+    return VIO_OK;
+}
+vio_status vior_get_schur_system(vior_ctx *c, double *H, double *b) {
+    if (!c->g || c->Hs.rows() != PD) return VIO_ERR_BAD_ARG;
+    if (H) Eigen::Map<RowMat>(H, PD, PD) = c->Hs;
+    if (b) Eigen::Map<VecX>(b, PD) = c->bs;
+    return VIO_OK;
+}
+vio_status vior_get_landmark_system(vior_ctx *c, int64_t n, double *hll, double *bl) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    Problem &p = *c->g->problem;
+    for (int64_t l = 0; l < n; ++l) {
+        int id = c->g->pts[l] ? (int)c->g->pts[l]->OrderingId() : -1;
+        if (hll) hll[l] = id >= 0 ? p.Hessian_(id, id) : 0.0;
+        if (bl) bl[l] = id >= 0 ? p.b_[id] : 0.0;
+    }
+    return VIO_OK;
+}
+vio_status vior_get_pose_gradient(vior_ctx *c, double *b, double *diag) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    Problem &p = *c->g->problem;
+    for (int i = 0; i < PD; ++i) { if (b) b[i] = p.b_[i]; if (diag) diag[i] = p.Hessian_(i, i); }
+    return VIO_OK;
+}
+vio_status vior_get_pose_hessian(vior_ctx *c, double *Hpp) {
+    if (!c->g) return VIO_ERR_BAD_ARG;
+    Eigen::Map<RowMat>(Hpp, PD, PD) = c->g->problem->Hessian_.topLeftCorner(PD, PD);
+    return VIO_OK;
+}
+vio_status vior_exchange_buffers(vior_ctx *, void **, int64_t *, void **, int64_t *) { return VIO_ERR_UNSUPPORTED; }
+vio_status vior_set_exchange_hook(vior_ctx *, vio_exchange_fn, void *) { return VIO_ERR_UNSUPPORTED; }
+
+/* ---- single pieces of the reference, for the per-function golden vectors -------------------- */
+
+/* EdgeReprojection::ComputeResidual/ComputeJacobians on one edge */
+void vior_reproj_edge(const double *pose_i, const double *pose_j, const double *ext, double inv_depth, const double *pi,
+                      const double *pj, double *residual, double *J_l, double *J_i, double *J_j, double *J_e) {
+    std::shared_ptr<VertexInverseDepth> vl(new VertexInverseDepth());
+    std::shared_ptr<VertexPose> vi(new VertexPose()), vj(new VertexPose()), ve(new VertexPose());
+    VecX d(1); d << inv_depth; vl->SetParameters(d);
+    Eigen::VectorXd a(7), b(7), e(7);
+    for (int k = 0; k < 7; ++k) { a[k] = pose_i[k]; b[k] = pose_j[k]; e[k] = ext[k]; }
+    vi->SetParameters(a); vj->SetParameters(b); ve->SetParameters(e);
+    EdgeReprojection edge(Vec3(pi[0], pi[1], 1.0), Vec3(pj[0], pj[1], 1.0));
+    edge.SetVertex(std::vector<std::shared_ptr<Vertex>>{vl, vi, vj, ve});
+    edge.ComputeResidual();
+    edge.ComputeJacobians();
+    residual[0] = edge.residual_[0]; residual[1] = edge.residual_[1];
+    J_l[0] = edge.jacobians_[0](0, 0); J_l[1] = edge.jacobians_[0](1, 0);
+    for (int r = 0; r < 2; ++r) for (int k = 0; k < 6; ++k) {
+        J_i[6 * r + k] = edge.jacobians_[1](r, k); J_j[6 * r + k] = edge.jacobians_[2](r, k); J_e[6 * r + k] = edge.jacobians_[3](r, k);
+    }
+    global_vertex_id = 0;
+}
+
+/* LossFunction::Compute */
+void vior_loss(int type, double delta, double e2, double *rho) {
+    Eigen::Vector3d r(e2, 1, 0);
+    vio_config cfg; cfg.loss_type = type; cfg.loss_delta = delta;
+    std::unique_ptr<LossFunction> l(make_loss(cfg));
+    if (l) l->Compute(e2, r);
+    rho[0] = r[0]; rho[1] = r[1]; rho[2] = r[2];
+}
+
+/* Edge::RobustInfo on a reprojection edge with the given residual */
+void vior_robust_info2(int type, double delta, double s, const double *res, double *drho, double *W) {
+    EdgeReprojection edge(Vec3(0, 0, 1), Vec3(0, 0, 1));
+    Eigen::Matrix2d sq = s * Eigen::Matrix2d::Identity();
+    edge.SetInformation(sq.transpose() * sq);
+    vio_config cfg; cfg.loss_type = type; cfg.loss_delta = delta;
+    std::unique_ptr<LossFunction> l(make_loss(cfg));
+    if (l) edge.SetLossFunction(l.get());
+    edge.residual_[0] = res[0]; edge.residual_[1] = res[1];
+    MatXX info(2, 2);
+    edge.RobustInfo(*drho, info);
+    W[0] = info(0, 0); W[1] = info(0, 1); W[2] = info(1, 0); W[3] = info(1, 1);
+}
+
+/* VertexPose::Plus */
+void vior_pose_plus(double *pose, const double *delta) {
+    VertexPose v;
+    Eigen::VectorXd p(7), d(6);
+    for (int k = 0; k < 7; ++k) p[k] = pose[k];
+    for (int k = 0; k < 6; ++k) d[k] = delta[k];
+    v.SetParameters(p);
+    v.Plus(d);
+    for (int k = 0; k < 7; ++k) pose[k] = v.Parameters()[k];
+    global_vertex_id = 0;
+}
+
+/* Eigen::LDLT solve as problem.cc:439 uses it */
+void vior_ldlt_solve(int n, const double *A, const double *b, double *x, int *tr) {
+    MatXX M = Eigen::Map<const RowMat>(A, n, n);
+    VecX rhs = Eigen::Map<const VecX>(b, n);
+    Eigen::LDLT<MatXX> ldlt(M);
+    VecX sol = ldlt.solve(rhs);
+    for (int i = 0; i < n; ++i) { x[i] = sol[i]; if (tr) tr[i] = ldlt.transpositionsP().indices()[i]; }
+}
+
+/* Eigen::SelfAdjointEigenSolver as problem.cc:752,766 use it */
+int vior_symmetric_eigen(int n, const double *A, double *evals, double *V) {
+    MatXX M = Eigen::Map<const RowMat>(A, n, n);
+    Eigen::SelfAdjointEigenSolver<Eigen::MatrixXd> saes(M);
+    for (int i = 0; i < n; ++i) evals[i] = saes.eigenvalues()[i];
+    Eigen::Map<RowMat>(V, n, n) = saes.eigenvectors();
+    return 0;
+}
+
+/* fixed-size 15x15 inverse as edge_imu.cc:35 evaluates covariance.inverse() */
+void vior_inverse15(const double *cov, double *info) {
+    Eigen::Matrix<double, 15, 15> C;
+    for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) C(i, j) = cov[15 * i + j];
+    Eigen::Matrix<double, 15, 15> I = C.inverse();
+    for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) info[15 * i + j] = I(i, j);
+}
+
+}  // extern "C"

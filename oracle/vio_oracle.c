@@ -1,0 +1,1440 @@
+/*
+ * vio_oracle.c — CPU restatement of the reference's sliding-window backend, in plain C.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP path and the
+ * `cpu_baseline` ("port") leg of bench.py.  Nothing in the product path may link, load or
+ * call it.
+ *
+ * Parity status: PINNED for the solver (Problem::{MakeHessian,SolveLinearSystem,UpdateStates,
+ * IsGoodStepInLM,Solve,Marginalize}), the reprojection factor, the vertices and the loss
+ * functions — checked against the reference's own sources compiled in oracle/_ref (see
+ * oracle/Makefile, tests/test_oracle_vs_reference.py, tests/golden/).
+ * UNPINNED for the IMU factor arithmetic (IntegrationBase::evaluate/midPointIntegration,
+ * EdgeImu::ComputeJacobians): integration_base.h:6 includes <ceres/ceres.h>, which this image
+ * lacks, so that translation unit cannot be built here; those functions are restated from the
+ * source text and checked by central finite differences and algebraic identities only.
+ *
+ * What it restates (VM/ = workspace/assignments/17-vins-initialization/vins-mono/):
+ *   VM/src/backend/edge_reprojection.cc:18-109   reprojection residual + Jacobians
+ *   VM/include/factor/integration_base.h:14-186  mid-point pre-integration, evaluate
+ *   VM/src/backend/edge_imu.cc:13-156            IMU residual + Jacobians
+ *   VM/src/backend/edge.cc:33-74                 Chi2 / RobustChi2 / RobustInfo
+ *   VM/src/backend/loss_function.cc:9-47         Huber / Cauchy / Tukey
+ *   VM/src/backend/vertex_pose.cc:7-19           pose Plus (Sophus exp, so3.hpp:393-419)
+ *   VM/src/backend/problem.cc:169-573            LM loop, Hessian, Schur, LDLT, update, chi2
+ *   VM/src/backend/problem.cc:617-795            Marginalize
+ *   VM/src/estimator.cpp:693-1073                graph construction of problemSolve/Marg*Frame
+ *
+ * The one deliberate difference from the reference: the landmark Schur complement is formed in
+ * O(M) from the per-landmark 1x1 blocks instead of dense (171+N)^2 products.  The arithmetic per
+ * entry is the same (Hpp - (Hpm*Hmm^-1)*Hmp), only zero terms are skipped.
+ */
+#define _POSIX_C_SOURCE 200809L
+#include "vio_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define NF VIO_NUM_FRAMES
+#define PD VIO_POSE_DIM
+#define PRD VIO_PRIOR_DIM
+#define CD VIO_CAM_DIM
+
+/* ------------------------------------------------------------------------------------------ */
+/* small math, written the way Eigen 3.3 evaluates the same expressions                        */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct { double x, y, z, w; } quat;
+
+static quat q_from_pose(const double *p) { quat q = {p[3], p[4], p[5], p[6]}; return q; }
+
+/* Eigen::QuaternionBase::operator* */
+static quat q_mul(quat a, quat b) {
+    quat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    return r;
+}
+
+/* Eigen::QuaternionBase::inverse(): conjugate / squaredNorm */
+static quat q_inv(quat q) {
+    double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    quat r = {0, 0, 0, 0};
+    if (n2 > 0) { r.x = -q.x / n2; r.y = -q.y / n2; r.z = -q.z / n2; r.w = q.w / n2; }
+    return r;
+}
+
+/* Eigen::QuaternionBase::_transformVector */
+static void q_rot(quat q, const double *v, double *out) {
+    double ux = q.y * v[2] - q.z * v[1];
+    double uy = q.z * v[0] - q.x * v[2];
+    double uz = q.x * v[1] - q.y * v[0];
+    ux += ux; uy += uy; uz += uz;
+    double cx = q.y * uz - q.z * uy;
+    double cy = q.z * ux - q.x * uz;
+    double cz = q.x * uy - q.y * ux;
+    out[0] = v[0] + q.w * ux + cx;
+    out[1] = v[1] + q.w * uy + cy;
+    out[2] = v[2] + q.w * uz + cz;
+}
+
+/* Eigen::QuaternionBase::toRotationMatrix, row-major 3x3 */
+static void q_to_R(quat q, double *R) {
+    double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+static void m3_mul(const double *A, const double *B, double *C) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+static void m3_T(const double *A, double *T) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * j + i];
+}
+static void m3_vec(const double *A, const double *v, double *o) {
+    for (int i = 0; i < 3; ++i) o[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+/* Utility::skewSymmetric == Sophus::SO3::hat (utility.h:27-35) */
+static void skew(const double *v, double *S) {
+    S[0] = 0;     S[1] = -v[2]; S[2] = v[1];
+    S[3] = v[2];  S[4] = 0;     S[5] = -v[0];
+    S[6] = -v[1]; S[7] = v[0];  S[8] = 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* loss functions: loss_function.cc:9-47, trivial loss loss_function.h:40-50                   */
+/* ------------------------------------------------------------------------------------------ */
+void vioo_loss(int type, double delta, double e2, double *rho) {
+    switch (type) {
+    case VIO_LOSS_HUBER: {
+        double dsqr = delta * delta;
+        if (e2 <= dsqr) { rho[0] = e2; rho[1] = 1.; rho[2] = 0.; }
+        else {
+            double sqrte = sqrt(e2);
+            rho[0] = 2 * sqrte * delta - dsqr;
+            rho[1] = delta / sqrte;
+            rho[2] = -0.5 * rho[1] / e2;
+        }
+        break;
+    }
+    case VIO_LOSS_CAUCHY: {
+        double dsqr = delta * delta;
+        double dsqrReci = 1. / dsqr;
+        double aux = dsqrReci * e2 + 1.0;
+        rho[0] = dsqr * log(aux);
+        rho[1] = 1. / aux;
+        rho[2] = -dsqrReci * (rho[1] * rho[1]);
+        break;
+    }
+    case VIO_LOSS_TUKEY: {
+        double e = sqrt(e2);
+        double delta2 = delta * delta;
+        if (e <= delta) {
+            double aux = e2 / delta2;
+            rho[0] = delta2 * (1. - (1. - aux) * (1. - aux) * (1. - aux)) / 3.;
+            rho[1] = (1. - aux) * (1. - aux);
+            rho[2] = -2. * (1. - aux) / delta2;
+        } else { rho[0] = delta2 / 3.; rho[1] = 0; rho[2] = 0; }
+        break;
+    }
+    default: rho[0] = e2; rho[1] = 1; rho[2] = 0; break;
+    }
+}
+
+/* Edge::RobustInfo (edge.cc:48-74) for information = s^2*I2, sqrt_information = s*I2.
+ * With the trivial loss the reference still goes through the lossfunction_ branch only when a
+ * loss object is set; VIO_LOSS_TRIVIAL here means "no loss object" (drho = 1, W = information). */
+void vioo_robust_info2(int type, double delta, double s, const double *r, double *drho, double *W) {
+    double info = s * s;
+    if (type == VIO_LOSS_TRIVIAL) {
+        *drho = 1.0; W[0] = info; W[1] = 0; W[2] = 0; W[3] = info; return;
+    }
+    double e2 = r[0] * (info * r[0]) + r[1] * (info * r[1]);   /* Edge::Chi2, edge.cc:33-37 */
+    double rho[3];
+    vioo_loss(type, delta, e2, rho);
+    double w0 = s * r[0], w1 = s * r[1];                        /* sqrt_information_ * residual_ */
+    double ri[4] = {rho[1], 0, 0, rho[1]};
+    if (rho[1] + 2 * rho[2] * e2 > 0.) {
+        double c = 2 * rho[2];
+        ri[0] += c * w0 * w0; ri[1] += c * w0 * w1; ri[2] += c * w1 * w0; ri[3] += c * w1 * w1;
+    }
+    W[0] = ri[0] * info; W[1] = ri[1] * info; W[2] = ri[2] * info; W[3] = ri[3] * info;
+    *drho = rho[1];
+}
+
+static double robust_chi2_2(int type, double delta, double s, const double *r) {
+    double info = s * s;
+    double e2 = r[0] * (info * r[0]) + r[1] * (info * r[1]);
+    if (type == VIO_LOSS_TRIVIAL) return e2;
+    double rho[3];
+    vioo_loss(type, delta, e2, rho);
+    return rho[0];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* EdgeReprojection: edge_reprojection.cc:18-109                                               */
+/* ------------------------------------------------------------------------------------------ */
+void vioo_reproj_edge(const double *pose_i, const double *pose_j, const double *ext, double inv_dep_i,
+                      const double *pi_xy, const double *pj_xy, double *residual, double *J_l,
+                      double *J_i, double *J_j, double *J_e) {
+    quat Qi = q_from_pose(pose_i), Qj = q_from_pose(pose_j), qic = q_from_pose(ext);
+    const double *Pi = pose_i, *Pj = pose_j, *tic = ext;
+    double pts_i[3] = {pi_xy[0], pi_xy[1], 1.0};
+
+    double pc_i[3] = {pts_i[0] / inv_dep_i, pts_i[1] / inv_dep_i, pts_i[2] / inv_dep_i};
+    double pb_i[3], pw[3], d[3], pb_j[3], e[3], pc_j[3];
+    q_rot(qic, pc_i, pb_i);
+    for (int k = 0; k < 3; ++k) pb_i[k] += tic[k];
+    q_rot(Qi, pb_i, pw);
+    for (int k = 0; k < 3; ++k) pw[k] += Pi[k];
+    for (int k = 0; k < 3; ++k) d[k] = pw[k] - Pj[k];
+    q_rot(q_inv(Qj), d, pb_j);
+    for (int k = 0; k < 3; ++k) e[k] = pb_j[k] - tic[k];
+    q_rot(q_inv(qic), e, pc_j);
+
+    double dep_j = pc_j[2];
+    if (residual) {
+        residual[0] = pc_j[0] / dep_j - pj_xy[0];
+        residual[1] = pc_j[1] / dep_j - pj_xy[1];
+    }
+    if (!J_l && !J_i && !J_j && !J_e) return;
+
+    double Ri[9], Rj[9], ric[9], ricT[9], RjT[9];
+    q_to_R(Qi, Ri); q_to_R(Qj, Rj); q_to_R(qic, ric);
+    m3_T(ric, ricT); m3_T(Rj, RjT);
+    double reduce[6] = {1. / dep_j, 0, -pc_j[0] / (dep_j * dep_j),
+                        0, 1. / dep_j, -pc_j[1] / (dep_j * dep_j)};
+    double A[9];            /* ric^T * Rj^T */
+    m3_mul(ricT, RjT, A);
+    double ARi[9];          /* ric^T * Rj^T * Ri */
+    m3_mul(A, Ri, ARi);
+
+    if (J_i) {
+        double H[9], nH[9], right[9];
+        skew(pb_i, H);
+        for (int k = 0; k < 9; ++k) nH[k] = -H[k];
+        m3_mul(ARi, nH, right);
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c) {
+                J_i[6 * r + c] = reduce[3 * r] * A[c] + reduce[3 * r + 1] * A[3 + c] + reduce[3 * r + 2] * A[6 + c];
+                J_i[6 * r + 3 + c] = reduce[3 * r] * right[c] + reduce[3 * r + 1] * right[3 + c] + reduce[3 * r + 2] * right[6 + c];
+            }
+    }
+    if (J_j) {
+        double H[9], right[9], left[9];
+        skew(pb_j, H);
+        m3_mul(ricT, H, right);
+        for (int k = 0; k < 9; ++k) left[k] = -A[k];
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c) {
+                J_j[6 * r + c] = reduce[3 * r] * left[c] + reduce[3 * r + 1] * left[3 + c] + reduce[3 * r + 2] * left[6 + c];
+                J_j[6 * r + 3 + c] = reduce[3 * r] * right[c] + reduce[3 * r + 1] * right[3 + c] + reduce[3 * r + 2] * right[6 + c];
+            }
+    }
+    if (J_l) {
+        /* reduce * ric^T * Rj^T * Ri * ric * pts_i * -1.0 / (inv_dep_i * inv_dep_i) */
+        double T[9], v[3];
+        m3_mul(ARi, ric, T);
+        m3_vec(T, pts_i, v);
+        for (int r = 0; r < 2; ++r) {
+            double s = reduce[3 * r] * v[0] + reduce[3 * r + 1] * v[1] + reduce[3 * r + 2] * v[2];
+            J_l[r] = s * -1.0 / (inv_dep_i * inv_dep_i);
+        }
+    }
+    if (J_e) {
+        double RjTRi[9], M[9], left[9];
+        m3_mul(RjT, Ri, RjTRi);
+        for (int k = 0; k < 9; ++k) M[k] = RjTRi[k];
+        M[0] -= 1; M[4] -= 1; M[8] -= 1;
+        m3_mul(ricT, M, left);
+        double tmp_r[9];
+        m3_mul(ARi, ric, tmp_r);
+        double S1[9], t1[9], v2[3], S2[9], u[3], w[3], x[3], S3[9], right[9];
+        skew(pc_i, S1);
+        m3_mul(tmp_r, S1, t1);
+        m3_vec(tmp_r, pc_i, v2);
+        skew(v2, S2);
+        /* ric^T * (Rj^T * (Ri * tic + Pi - Pj) - tic) */
+        m3_vec(Ri, tic, u);
+        for (int k = 0; k < 3; ++k) u[k] = u[k] + Pi[k] - Pj[k];
+        m3_vec(RjT, u, w);
+        for (int k = 0; k < 3; ++k) w[k] -= tic[k];
+        m3_vec(ricT, w, x);
+        skew(x, S3);
+        for (int k = 0; k < 9; ++k) right[k] = -t1[k] + S2[k] + S3[k];
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c) {
+                J_e[6 * r + c] = reduce[3 * r] * left[c] + reduce[3 * r + 1] * left[3 + c] + reduce[3 * r + 2] * left[6 + c];
+                J_e[6 * r + 3 + c] = reduce[3 * r] * right[c] + reduce[3 * r + 1] * right[3 + c] + reduce[3 * r + 2] * right[6 + c];
+            }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* IMU factor: integration_base.h:160-186 (evaluate), edge_imu.cc:38-156 (Jacobians)           */
+/* ------------------------------------------------------------------------------------------ */
+#define O_P 0
+#define O_R 3
+#define O_V 6
+#define O_BA 9
+#define O_BG 12
+
+static void jac_block(const double *J15, int r0, int c0, double *B) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = J15[15 * (r0 + i) + c0 + j];
+}
+/* Utility::deltaQ (utility.h:11-24): (1, theta/2), NOT normalised */
+static quat delta_q(const double *theta) {
+    quat q = {theta[0] / 2.0, theta[1] / 2.0, theta[2] / 2.0, 1.0};
+    return q;
+}
+/* bottom-right 3x3 of Utility::Qleft(q): w*I + skew(vec)  (utility.h:48-56) */
+static void qleft_br(quat q, double *B) {
+    double v[3] = {q.x, q.y, q.z}, S[9];
+    skew(v, S);
+    for (int k = 0; k < 9; ++k) B[k] = S[k];
+    B[0] += q.w; B[4] += q.w; B[8] += q.w;
+}
+/* bottom-right 3x3 of Utility::Qright(p): w*I - skew(vec)  (utility.h:58-66) */
+static void qright_br(quat q, double *B) {
+    double v[3] = {q.x, q.y, q.z}, S[9];
+    skew(v, S);
+    for (int k = 0; k < 9; ++k) B[k] = -S[k];
+    B[0] += q.w; B[4] += q.w; B[8] += q.w;
+}
+/* bottom-right 3x3 of Qleft(a)*Qright(b): rows 1..3 of Qleft times cols 1..3 of Qright */
+static void qleft_qright_br(quat a, quat b, double *B) {
+    /* Qleft(a) = [w, -v^T; v, w I + [v]x],  Qright(b) = [w, -v^T; v, w I - [v]x]
+       bottom-right of product = v_a * (-v_b^T) + (w_a I + [v_a]x)(w_b I - [v_b]x) */
+    double La[9], Rb[9], P[9];
+    qleft_br(a, La); qright_br(b, Rb);
+    m3_mul(La, Rb, P);
+    double va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = va[i] * (-vb[j]) + P[3 * i + j];
+}
+
+void vioo_imu_edge(const vio_preint *pre, const double *G, const double *pose_i, const double *sb_i,
+                   const double *pose_j, const double *sb_j, double *res, double *Jpi, double *Jsi,
+                   double *Jpj, double *Jsj) {
+    quat Qi = q_from_pose(pose_i), Qj = q_from_pose(pose_j);
+    const double *Pi = pose_i, *Pj = pose_j;
+    const double *Vi = sb_i, *Bai = sb_i + 3, *Bgi = sb_i + 6;
+    const double *Vj = sb_j, *Baj = sb_j + 3, *Bgj = sb_j + 6;
+    double sum_dt = pre->sum_dt;
+    quat dq = {pre->delta_q[0], pre->delta_q[1], pre->delta_q[2], pre->delta_q[3]};
+
+    double dp_dba[9], dp_dbg[9], dq_dbg[9], dv_dba[9], dv_dbg[9];
+    jac_block(pre->jacobian, O_P, O_BA, dp_dba);
+    jac_block(pre->jacobian, O_P, O_BG, dp_dbg);
+    jac_block(pre->jacobian, O_R, O_BG, dq_dbg);
+    jac_block(pre->jacobian, O_V, O_BA, dv_dba);
+    jac_block(pre->jacobian, O_V, O_BG, dv_dbg);
+
+    double dba[3], dbg[3];
+    for (int k = 0; k < 3; ++k) { dba[k] = Bai[k] - pre->linearized_ba[k]; dbg[k] = Bgi[k] - pre->linearized_bg[k]; }
+    double th[3];
+    m3_vec(dq_dbg, dbg, th);
+    quat corrected_dq = q_mul(dq, delta_q(th));
+    quat Qi_inv = q_inv(Qi);
+
+    if (res) {
+        double a[3], b[3], t[3], u[3];
+        m3_vec(dv_dba, dba, a); m3_vec(dv_dbg, dbg, b);
+        double cdv[3] = {pre->delta_v[0] + a[0] + b[0], pre->delta_v[1] + a[1] + b[1], pre->delta_v[2] + a[2] + b[2]};
+        m3_vec(dp_dba, dba, a); m3_vec(dp_dbg, dbg, b);
+        double cdp[3] = {pre->delta_p[0] + a[0] + b[0], pre->delta_p[1] + a[1] + b[1], pre->delta_p[2] + a[2] + b[2]};
+        for (int k = 0; k < 3; ++k) t[k] = 0.5 * G[k] * sum_dt * sum_dt + Pj[k] - Pi[k] - Vi[k] * sum_dt;
+        q_rot(Qi_inv, t, u);
+        for (int k = 0; k < 3; ++k) res[O_P + k] = u[k] - cdp[k];
+        quat qe = q_mul(q_inv(corrected_dq), q_mul(Qi_inv, Qj));
+        res[O_R + 0] = 2 * qe.x; res[O_R + 1] = 2 * qe.y; res[O_R + 2] = 2 * qe.z;
+        for (int k = 0; k < 3; ++k) t[k] = G[k] * sum_dt + Vj[k] - Vi[k];
+        q_rot(Qi_inv, t, u);
+        for (int k = 0; k < 3; ++k) res[O_V + k] = u[k] - cdv[k];
+        for (int k = 0; k < 3; ++k) { res[O_BA + k] = Baj[k] - Bai[k]; res[O_BG + k] = Bgj[k] - Bgi[k]; }
+    }
+
+    double RiT[9];              /* Qi.inverse().toRotationMatrix() */
+    q_to_R(Qi_inv, RiT);
+    if (Jpi) {
+        memset(Jpi, 0, sizeof(double) * 15 * 6);
+        double t[3], u[3], S[9], B[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Jpi[6 * (O_P + i) + O_P + j] = -RiT[3 * i + j];
+        for (int k = 0; k < 3; ++k) t[k] = 0.5 * G[k] * sum_dt * sum_dt + Pj[k] - Pi[k] - Vi[k] * sum_dt;
+        q_rot(Qi_inv, t, u); skew(u, S);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Jpi[6 * (O_P + i) + O_R + j] = S[3 * i + j];
+        qleft_qright_br(q_mul(q_inv(Qj), Qi), corrected_dq, B);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Jpi[6 * (O_R + i) + O_R + j] = -B[3 * i + j];
+        for (int k = 0; k < 3; ++k) t[k] = G[k] * sum_dt + Vj[k] - Vi[k];
+        q_rot(Qi_inv, t, u); skew(u, S);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Jpi[6 * (O_V + i) + O_R + j] = S[3 * i + j];
+    }
+    if (Jsi) {
+        memset(Jsi, 0, sizeof(double) * 15 * 9);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            Jsi[9 * (O_P + i) + (O_V - O_V) + j] = -RiT[3 * i + j] * sum_dt;
+            Jsi[9 * (O_P + i) + (O_BA - O_V) + j] = -dp_dba[3 * i + j];
+            Jsi[9 * (O_P + i) + (O_BG - O_V) + j] = -dp_dbg[3 * i + j];
+        }
+        /* -Qleft(Qj^-1 * Qi * delta_q).bottomRight * dq_dbg  — delta_q, not corrected_delta_q (edge_imu.cc:107-109) */
+        double L[9], nL[9], B[9];
+        qleft_br(q_mul(q_mul(q_inv(Qj), Qi), dq), L);
+        for (int k = 0; k < 9; ++k) nL[k] = -L[k];
+        m3_mul(nL, dq_dbg, B);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+            Jsi[9 * (O_R + i) + (O_BG - O_V) + j] = B[3 * i + j];
+            Jsi[9 * (O_V + i) + (O_V - O_V) + j] = -RiT[3 * i + j];
+            Jsi[9 * (O_V + i) + (O_BA - O_V) + j] = -dv_dba[3 * i + j];
+            Jsi[9 * (O_V + i) + (O_BG - O_V) + j] = -dv_dbg[3 * i + j];
+        }
+        for (int i = 0; i < 3; ++i) {
+            Jsi[9 * (O_BA + i) + (O_BA - O_V) + i] = -1.0;
+            Jsi[9 * (O_BG + i) + (O_BG - O_V) + i] = -1.0;
+        }
+    }
+    if (Jpj) {
+        memset(Jpj, 0, sizeof(double) * 15 * 6);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Jpj[6 * (O_P + i) + O_P + j] = RiT[3 * i + j];
+        double L[9];
+        qleft_br(q_mul(q_mul(q_inv(corrected_dq), Qi_inv), Qj), L);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Jpj[6 * (O_R + i) + O_R + j] = L[3 * i + j];
+    }
+    if (Jsj) {
+        memset(Jsj, 0, sizeof(double) * 15 * 9);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Jsj[9 * (O_V + i) + (O_V - O_V) + j] = RiT[3 * i + j];
+        for (int i = 0; i < 3; ++i) {
+            Jsj[9 * (O_BA + i) + (O_BA - O_V) + i] = 1.0;
+            Jsj[9 * (O_BG + i) + (O_BG - O_V) + i] = 1.0;
+        }
+    }
+}
+
+/* covariance.inverse() on a fixed 15x15: Eigen routes sizes > 4 through PartialPivLU
+ * (LU/InverseImpl.h, LU/PartialPivLU.h unblocked_lu for rows <= 16), then solves against I. */
+void vioo_inverse15(const double *cov, double *info) {
+    enum { n = 15 };
+    double lu[n * n];
+    int piv[n];
+    memcpy(lu, cov, sizeof(lu));
+    for (int k = 0; k < n; ++k) {
+        int row = k; double big = fabs(lu[n * k + k]);
+        for (int i = k + 1; i < n; ++i) if (fabs(lu[n * i + k]) > big) { big = fabs(lu[n * i + k]); row = i; }
+        piv[k] = row;
+        if (big != 0) {
+            if (row != k) for (int j = 0; j < n; ++j) { double t = lu[n * k + j]; lu[n * k + j] = lu[n * row + j]; lu[n * row + j] = t; }
+            for (int i = k + 1; i < n; ++i) lu[n * i + k] /= lu[n * k + k];
+        }
+        for (int i = k + 1; i < n; ++i)
+            for (int j = k + 1; j < n; ++j) lu[n * i + j] -= lu[n * i + k] * lu[n * k + j];
+    }
+    for (int c = 0; c < n; ++c) {
+        double x[n];
+        for (int i = 0; i < n; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+        for (int k = 0; k < n; ++k) if (piv[k] != k) { double t = x[k]; x[k] = x[piv[k]]; x[piv[k]] = t; }
+        for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) x[i] -= lu[n * i + j] * x[j];
+        for (int i = n - 1; i >= 0; --i) {
+            for (int j = i + 1; j < n; ++j) x[i] -= lu[n * i + j] * x[j];
+            x[i] /= lu[n * i + i];
+        }
+        for (int i = 0; i < n; ++i) info[n * i + c] = x[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* vertices: vertex.cc:28-30, vertex_pose.cc:7-19, Sophus so3.hpp:393-419,683-685              */
+/* ------------------------------------------------------------------------------------------ */
+void vioo_pose_plus(double *p, const double *d) {
+    p[0] += d[0]; p[1] += d[1]; p[2] += d[2];
+    double ox = d[3], oy = d[4], oz = d[5];
+    double theta_sq = ox * ox + oy * oy + oz * oz;
+    double theta = sqrt(theta_sq);
+    double half_theta = 0.5 * theta;
+    double imag, real;
+    if (theta < 1e-10) {
+        double theta_po4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+        real = 1.0 - 0.5 * theta_sq + (1.0 / 384.0) * theta_po4;
+    } else {
+        double s = sin(half_theta);
+        imag = s / theta;
+        real = cos(half_theta);
+    }
+    quat e = {imag * ox, imag * oy, imag * oz, real};
+    /* SO3Group(const Quaternion&) normalises: Eigen normalize() = coeffs /= norm() */
+    double n = sqrt(e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w);
+    e.x /= n; e.y /= n; e.z /= n; e.w /= n;
+    quat q = {p[3], p[4], p[5], p[6]};
+    q = q_mul(q, e);          /* q.normalized() result is discarded in the reference (vertex_pose.cc:12) */
+    p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Eigen::LDLT<MatrixXd,Lower>: Cholesky/LDLT.h:291-400 (unblocked), :558-600 (solve)          */
+/* ------------------------------------------------------------------------------------------ */
+void vioo_ldlt_solve(int n, const double *Ain, const double *b, double *x, int *tr_out) {
+    double *A = (double *)malloc(sizeof(double) * n * n);
+    double *temp = (double *)malloc(sizeof(double) * n);
+    int *tr = (int *)malloc(sizeof(int) * n);
+    memcpy(A, Ain, sizeof(double) * n * n);
+#define M(i, j) A[(size_t)(i) * n + (j)]
+    if (n <= 1) {
+        tr[0] = 0;
+    } else {
+        int zero_all = 0;
+        for (int k = 0; k < n && !zero_all; ++k) {
+            int big = k; double bv = fabs(M(k, k));
+            for (int i = k + 1; i < n; ++i) if (fabs(M(i, i)) > bv) { bv = fabs(M(i, i)); big = i; }
+            tr[k] = big;
+            if (k != big) {
+                int s = n - big - 1;
+                for (int j = 0; j < k; ++j) { double t = M(k, j); M(k, j) = M(big, j); M(big, j) = t; }
+                for (int i = 0; i < s; ++i) { double t = M(n - s + i, k); M(n - s + i, k) = M(n - s + i, big); M(n - s + i, big) = t; }
+                { double t = M(k, k); M(k, k) = M(big, big); M(big, big) = t; }
+                for (int i = k + 1; i < big; ++i) { double t = M(i, k); M(i, k) = M(big, i); M(big, i) = t; }
+            }
+            int rs = n - k - 1;
+            if (k > 0) {
+                for (int j = 0; j < k; ++j) temp[j] = M(j, j) * M(k, j);
+                double s = 0;
+                for (int j = 0; j < k; ++j) s += M(k, j) * temp[j];
+                M(k, k) -= s;
+                for (int i = 0; i < rs; ++i) {
+                    double t = 0;
+                    for (int j = 0; j < k; ++j) t += M(k + 1 + i, j) * temp[j];
+                    M(k + 1 + i, k) -= t;
+                }
+            }
+            double akk = M(k, k);
+            int valid = fabs(akk) > 0;
+            if (k == 0 && !valid) {
+                for (int j = 0; j < n; ++j) tr[j] = j;
+                zero_all = 1;
+                break;
+            }
+            if (rs > 0 && valid) for (int i = 0; i < rs; ++i) M(k + 1 + i, k) /= akk;
+        }
+    }
+    /* solve: dst = P b; L^-1; D^+; L^-T; P^-1 */
+    for (int i = 0; i < n; ++i) x[i] = b[i];
+    for (int k = 0; k < n; ++k) if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+    for (int i = 0; i < n; ++i) { double s = x[i]; for (int j = 0; j < i; ++j) s -= M(i, j) * x[j]; x[i] = s; }
+    double tol = 1.0 / DBL_MAX;
+    for (int i = 0; i < n; ++i) { if (fabs(M(i, i)) > tol) x[i] /= M(i, i); else x[i] = 0; }
+    for (int i = n - 1; i >= 0; --i) { double s = x[i]; for (int j = i + 1; j < n; ++j) s -= M(j, i) * x[j]; x[i] = s; }
+    for (int k = n - 1; k >= 0; --k) if (tr[k] != k) { double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+#undef M
+    if (tr_out) memcpy(tr_out, tr, sizeof(int) * n);
+    free(A); free(temp); free(tr);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* symmetric eigen-decomposition: Householder tridiagonalisation + implicit QL (the classical   */
+/* tred2/tql2 pair).  Stands where problem.cc:752,766 call Eigen::SelfAdjointEigenSolver.        */
+/* ------------------------------------------------------------------------------------------ */
+int vioo_symmetric_eigen(int n, const double *Ain, double *d, double *Vout) {
+    double *V = (double *)malloc(sizeof(double) * n * n);
+    double *e = (double *)malloc(sizeof(double) * n);
+#define V_(i, j) V[(size_t)(i) * n + (j)]
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { V_(i, j) = Ain[(size_t)i * n + j]; V_(j, i) = V_(i, j); }
+    /* tred2 */
+    for (int j = 0; j < n; ++j) d[j] = V_(n - 1, j);
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) { d[j] = V_(i - 1, j); V_(i, j) = 0.0; V_(j, i) = 0.0; }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1];
+            double g = sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h -= f * g;
+            d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j];
+                V_(j, i) = f;
+                g = e[j] + V_(j, j) * f;
+                for (int k = j + 1; k <= i - 1; ++k) { g += V_(k, j) * d[k]; e[k] += V_(k, j) * f; }
+                e[j] = g;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; g = e[j];
+                for (int k = j; k <= i - 1; ++k) V_(k, j) -= (f * e[k] + g * d[k]);
+                d[j] = V_(i - 1, j);
+                V_(i, j) = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        V_(n - 1, i) = V_(i, i);
+        V_(i, i) = 1.0;
+        double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) d[k] = V_(k, i + 1) / h;
+            for (int j = 0; j <= i; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= i; ++k) g += V_(k, i + 1) * V_(k, j);
+                for (int k = 0; k <= i; ++k) V_(k, j) -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; ++k) V_(k, i + 1) = 0.0;
+    }
+    for (int j = 0; j < n; ++j) { d[j] = V_(n - 1, j); V_(n - 1, j) = 0.0; }
+    V_(n - 1, n - 1) = 1.0;
+    e[0] = 0.0;
+    /* tql2 */
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0, eps = ldexp(1.0, -52);
+    int ok = 1;
+    for (int l = 0; l < n; ++l) {
+        double t = fabs(d[l]) + fabs(e[l]);
+        if (t > tst1) tst1 = t;
+        int m = l;
+        while (m < n) { if (fabs(e[m]) <= eps * tst1) break; ++m; }
+        if (m == n) m = n - 1;
+        if (m > l) {
+            int iter = 0;
+            do {
+                if (++iter > 200) { ok = 0; break; }
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, el1 = e[l + 1], s = 0.0, s2 = 0.0;
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; ++k) {
+                        h = V_(k, i + 1);
+                        V_(k, i + 1) = s * V_(k, i) + c * h;
+                        V_(k, i) = c * V_(k, i) - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (fabs(e[l]) > eps * tst1);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    /* sort ascending */
+    for (int i = 0; i < n - 1; ++i) {
+        int k = i; double p = d[i];
+        for (int j = i + 1; j < n; ++j) if (d[j] < p) { k = j; p = d[j]; }
+        if (k != i) {
+            d[k] = d[i]; d[i] = p;
+            for (int j = 0; j < n; ++j) { double t = V_(j, i); V_(j, i) = V_(j, k); V_(j, k) = t; }
+        }
+    }
+    memcpy(Vout, V, sizeof(double) * n * n);
+#undef V_
+    free(V); free(e);
+    return ok ? 0 : -1;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* IntegrationBase: integration_base.h:14-158                                                  */
+/* ------------------------------------------------------------------------------------------ */
+static void mat_mul(int m, int k, int n, const double *A, const double *B, double *C) {
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0;
+            for (int l = 0; l < k; ++l) s += A[i * k + l] * B[l * n + j];
+            C[i * n + j] = s;
+        }
+}
+static void set_block3(double *M, int ld, int r0, int c0, const double *B, double scale) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[(r0 + i) * ld + c0 + j] = B[3 * i + j] * scale;
+}
+
+void vioo_preintegrate(const double *acc_first, const double *gyr_first, const double *ba, const double *bg,
+                       int count, const double *dts, const double *accs, const double *gyrs, double ACC_N,
+                       double GYR_N, double ACC_W, double GYR_W, vio_preint *out) {
+    double acc_0[3], gyr_0[3];
+    memcpy(acc_0, acc_first, sizeof(acc_0)); memcpy(gyr_0, gyr_first, sizeof(gyr_0));
+    double jac[225], cov[225], noise[18 * 18];
+    memset(jac, 0, sizeof(jac)); memset(cov, 0, sizeof(cov)); memset(noise, 0, sizeof(noise));
+    for (int i = 0; i < 15; ++i) jac[16 * i] = 1.0;
+    for (int i = 0; i < 3; ++i) {
+        noise[19 * (0 + i)] = ACC_N * ACC_N; noise[19 * (3 + i)] = GYR_N * GYR_N;
+        noise[19 * (6 + i)] = ACC_N * ACC_N; noise[19 * (9 + i)] = GYR_N * GYR_N;
+        noise[19 * (12 + i)] = ACC_W * ACC_W; noise[19 * (15 + i)] = GYR_W * GYR_W;
+    }
+    double sum_dt = 0, dp[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+    quat dq = {0, 0, 0, 1};
+    for (int s = 0; s < count; ++s) {
+        double _dt = dts[s];
+        const double *acc_1 = accs + 3 * s, *gyr_1 = gyrs + 3 * s;
+        double a0[3], a1[3], un_gyr[3], un_acc_0[3], un_acc_1[3], un_acc[3];
+        for (int k = 0; k < 3; ++k) { a0[k] = acc_0[k] - ba[k]; a1[k] = acc_1[k] - ba[k]; }
+        q_rot(dq, a0, un_acc_0);
+        for (int k = 0; k < 3; ++k) un_gyr[k] = 0.5 * (gyr_0[k] + gyr_1[k]) - bg[k];
+        quat inc = {un_gyr[0] * _dt / 2, un_gyr[1] * _dt / 2, un_gyr[2] * _dt / 2, 1};
+        quat rq = q_mul(dq, inc);
+        q_rot(rq, a1, un_acc_1);
+        for (int k = 0; k < 3; ++k) un_acc[k] = 0.5 * (un_acc_0[k] + un_acc_1[k]);
+        double rp[3], rv[3];
+        for (int k = 0; k < 3; ++k) {
+            rp[k] = dp[k] + dv[k] * _dt + 0.5 * un_acc[k] * _dt * _dt;
+            rv[k] = dv[k] + un_acc[k] * _dt;
+        }
+        /* jacobian / covariance propagation, integration_base.h:75-127 */
+        double R_w_x[9], R_a_0_x[9], R_a_1_x[9], Rd[9], Rr[9];
+        skew(un_gyr, R_w_x); skew(a0, R_a_0_x); skew(a1, R_a_1_x);
+        q_to_R(dq, Rd); q_to_R(rq, Rr);
+        double ImW[9];          /* I - R_w_x*dt */
+        for (int k = 0; k < 9; ++k) ImW[k] = -R_w_x[k] * _dt;
+        ImW[0] += 1; ImW[4] += 1; ImW[8] += 1;
+        double RdA0[9], RrA1[9], RrA1I[9];
+        m3_mul(Rd, R_a_0_x, RdA0); m3_mul(Rr, R_a_1_x, RrA1); m3_mul(RrA1, ImW, RrA1I);
+        double F[225], Vm[15 * 18];
+        memset(F, 0, sizeof(F)); memset(Vm, 0, sizeof(Vm));
+        double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, B[9];
+        set_block3(F, 15, 0, 0, I3, 1.0);
+        for (int k = 0; k < 9; ++k) B[k] = -0.25 * RdA0[k] * _dt * _dt + -0.25 * RrA1I[k] * _dt * _dt;
+        set_block3(F, 15, 0, 3, B, 1.0);
+        set_block3(F, 15, 0, 6, I3, _dt);
+        for (int k = 0; k < 9; ++k) B[k] = -0.25 * (Rd[k] + Rr[k]) * _dt * _dt;
+        set_block3(F, 15, 0, 9, B, 1.0);
+        for (int k = 0; k < 9; ++k) B[k] = -0.25 * RrA1[k] * _dt * _dt * -_dt;
+        set_block3(F, 15, 0, 12, B, 1.0);
+        set_block3(F, 15, 3, 3, ImW, 1.0);
+        set_block3(F, 15, 3, 12, I3, -1.0 * _dt);
+        for (int k = 0; k < 9; ++k) B[k] = -0.5 * RdA0[k] * _dt + -0.5 * RrA1I[k] * _dt;
+        set_block3(F, 15, 6, 3, B, 1.0);
+        set_block3(F, 15, 6, 6, I3, 1.0);
+        for (int k = 0; k < 9; ++k) B[k] = -0.5 * (Rd[k] + Rr[k]) * _dt;
+        set_block3(F, 15, 6, 9, B, 1.0);
+        for (int k = 0; k < 9; ++k) B[k] = -0.5 * RrA1[k] * _dt * -_dt;
+        set_block3(F, 15, 6, 12, B, 1.0);
+        set_block3(F, 15, 9, 9, I3, 1.0);
+        set_block3(F, 15, 12, 12, I3, 1.0);
+
+        set_block3(Vm, 18, 0, 0, Rd, 0.25 * _dt * _dt);
+        for (int k = 0; k < 9; ++k) B[k] = 0.25 * -RrA1[k] * _dt * _dt * 0.5 * _dt;
+        set_block3(Vm, 18, 0, 3, B, 1.0);
+        set_block3(Vm, 18, 0, 6, Rr, 0.25 * _dt * _dt);
+        set_block3(Vm, 18, 0, 9, B, 1.0);
+        set_block3(Vm, 18, 3, 3, I3, 0.5 * _dt);
+        set_block3(Vm, 18, 3, 9, I3, 0.5 * _dt);
+        set_block3(Vm, 18, 6, 0, Rd, 0.5 * _dt);
+        for (int k = 0; k < 9; ++k) B[k] = 0.5 * -RrA1[k] * _dt * 0.5 * _dt;
+        set_block3(Vm, 18, 6, 3, B, 1.0);
+        set_block3(Vm, 18, 6, 6, Rr, 0.5 * _dt);
+        set_block3(Vm, 18, 6, 9, B, 1.0);
+        set_block3(Vm, 18, 9, 12, I3, _dt);
+        set_block3(Vm, 18, 12, 15, I3, _dt);
+
+        double T1[225], T2[225], FT[225], VN[15 * 18], VT[18 * 15], T3[225];
+        mat_mul(15, 15, 15, F, jac, T1);
+        memcpy(jac, T1, sizeof(jac));
+        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) FT[15 * i + j] = F[15 * j + i];
+        mat_mul(15, 15, 15, F, cov, T1);
+        mat_mul(15, 15, 15, T1, FT, T2);
+        mat_mul(15, 18, 18, Vm, noise, VN);
+        for (int i = 0; i < 18; ++i) for (int j = 0; j < 15; ++j) VT[15 * i + j] = Vm[18 * j + i];
+        mat_mul(15, 18, 15, VN, VT, T3);
+        for (int k = 0; k < 225; ++k) cov[k] = T2[k] + T3[k];
+
+        memcpy(dp, rp, sizeof(dp)); memcpy(dv, rv, sizeof(dv));
+        dq = rq;
+        double nq = sqrt(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w);   /* delta_q.normalize() */
+        dq.x /= nq; dq.y /= nq; dq.z /= nq; dq.w /= nq;
+        sum_dt += _dt;
+        memcpy(acc_0, acc_1, sizeof(acc_0)); memcpy(gyr_0, gyr_1, sizeof(gyr_0));
+    }
+    out->sum_dt = sum_dt;
+    memcpy(out->delta_p, dp, sizeof(dp)); memcpy(out->delta_v, dv, sizeof(dv));
+    out->delta_q[0] = dq.x; out->delta_q[1] = dq.y; out->delta_q[2] = dq.z; out->delta_q[3] = dq.w;
+    memcpy(out->linearized_ba, ba, sizeof(double) * 3); memcpy(out->linearized_bg, bg, sizeof(double) * 3);
+    memcpy(out->jacobian, jac, sizeof(jac)); memcpy(out->covariance, cov, sizeof(cov));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the Problem                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+struct vioo_ctx {
+    vio_config cfg;
+    char err[256];
+    double pose[NF * 7], sb[NF * 9], ext[7];
+    double pose_bak[NF * 7], sb_bak[NF * 9], ext_bak[7];
+    int64_t N, M;
+    double *invd, *invd_bak;
+    int32_t *lm, *host, *target;
+    double *pts_i, *pts_j;
+    int imu_valid[VIO_WINDOW_SIZE];
+    vio_preint pre[VIO_WINDOW_SIZE];
+    double imu_info[VIO_WINDOW_SIZE][225];
+    /* prior */
+    int has_prior;              /* err_prior_.rows() > 0 */
+    double Hprior[PD * PD], bprior[PD], bprior_bak[PD];
+    double errprior[PRD], errprior_bak[PRD], Jtinv[PRD * PRD];
+    /* linearisation */
+    int linearized;
+    double Hpp[PD * PD], bpp[PD];       /* Hessian_ pose block (+prior), b_ pose part */
+    double *hll, *bl, *Hpl;             /* Hmm diagonal, bmm, Hpm column per landmark (CD entries) */
+    double Hs[PD * PD], bs[PD];         /* H_pp_schur_ (before lambda), b_pp_schur_ */
+    double dx_pose[PD], *dx_lm;
+    double lambda, chi, ni;
+    double t_hessian_ms;
+};
+
+static int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
+
+static double now_ms(void) {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+void vio_default_config(vio_config *cfg) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->device = 0;
+    cfg->ext_fixed = 1;                         /* estimate_extrinsic: 0, vio_simulation.yaml:25 */
+    cfg->loss_type = VIO_LOSS_CAUCHY;
+    cfg->loss_delta = 1.0;
+    cfg->reproj_sqrt_info = 460.0 / 1.5;        /* estimator.cpp:42, parameters.cpp:70 */
+    cfg->gravity[0] = 0; cfg->gravity[1] = 0; cfg->gravity[2] = 9.81;   /* g_norm, vio_simulation.yaml:79 */
+    cfg->stream = NULL;
+    cfg->shard_rank = 0; cfg->shard_count = 1;
+}
+
+vio_status vio_create(const vio_config *cfg, struct vioo_ctx **out) {
+    if (!cfg || !out) return VIO_ERR_BAD_ARG;
+    struct vioo_ctx *c = (struct vioo_ctx *)calloc(1, sizeof(*c));
+    if (!c) return VIO_ERR_BAD_ARG;
+    c->cfg = *cfg;
+    if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
+    c->ni = 2; c->lambda = -1;
+    for (int i = 0; i < NF; ++i) c->pose[7 * i + 6] = 1.0;
+    c->ext[6] = 1.0;
+    *out = c;
+    return VIO_OK;
+}
+
+void vio_destroy(struct vioo_ctx *c) {
+    if (!c) return;
+    free(c->invd); free(c->invd_bak); free(c->lm); free(c->host); free(c->target);
+    free(c->pts_i); free(c->pts_j); free(c->hll); free(c->bl); free(c->Hpl); free(c->dx_lm);
+    free(c);
+}
+
+const char *vio_last_error(const struct vioo_ctx *c) { return c ? c->err : "null context"; }
+
+vio_status vio_set_window(struct vioo_ctx *c, const double *poses, const double *sb, const double *ext) {
+    if (!c || !poses || !sb || !ext) return VIO_ERR_BAD_ARG;
+    memcpy(c->pose, poses, sizeof(c->pose)); memcpy(c->sb, sb, sizeof(c->sb)); memcpy(c->ext, ext, sizeof(c->ext));
+    c->linearized = 0;
+    return VIO_OK;
+}
+
+vio_status vio_set_landmarks(struct vioo_ctx *c, int64_t n, const double *invd) {
+    if (!c || n < 0 || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+    free(c->invd); free(c->invd_bak); free(c->hll); free(c->bl); free(c->Hpl); free(c->dx_lm);
+    c->N = n;
+    size_t nn = (size_t)(n > 0 ? n : 1);
+    c->invd = (double *)malloc(sizeof(double) * nn);
+    c->invd_bak = (double *)malloc(sizeof(double) * nn);
+    c->hll = (double *)calloc(nn, sizeof(double));
+    c->bl = (double *)calloc(nn, sizeof(double));
+    c->Hpl = (double *)calloc(nn * CD, sizeof(double));
+    c->dx_lm = (double *)calloc(nn, sizeof(double));
+    if (n > 0) memcpy(c->invd, invd, sizeof(double) * n);
+    c->linearized = 0;
+    return VIO_OK;
+}
+
+vio_status vio_set_observations(struct vioo_ctx *c, int64_t m, const int32_t *lm, const int32_t *host,
+                                const int32_t *target, const double *pi, const double *pj) {
+    if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
+    for (int64_t e = 0; e < m; ++e) {
+        if (lm[e] < 0 || lm[e] >= c->N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF ||
+            host[e] == target[e]) {
+            snprintf(c->err, sizeof(c->err), "observation %lld out of range", (long long)e);
+            return VIO_ERR_BAD_ARG;
+        }
+    }
+    free(c->lm); free(c->host); free(c->target); free(c->pts_i); free(c->pts_j);
+    c->M = m;
+    size_t mm = (size_t)(m > 0 ? m : 1);
+    c->lm = (int32_t *)malloc(sizeof(int32_t) * mm); c->host = (int32_t *)malloc(sizeof(int32_t) * mm);
+    c->target = (int32_t *)malloc(sizeof(int32_t) * mm);
+    c->pts_i = (double *)malloc(sizeof(double) * 2 * mm); c->pts_j = (double *)malloc(sizeof(double) * 2 * mm);
+    if (m > 0) {
+        memcpy(c->lm, lm, sizeof(int32_t) * m); memcpy(c->host, host, sizeof(int32_t) * m);
+        memcpy(c->target, target, sizeof(int32_t) * m);
+        memcpy(c->pts_i, pi, sizeof(double) * 2 * m); memcpy(c->pts_j, pj, sizeof(double) * 2 * m);
+    }
+    c->linearized = 0;
+    return VIO_OK;
+}
+
+vio_status vio_set_imu(struct vioo_ctx *c, int32_t k, const vio_preint *pre) {
+    if (!c || k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
+    if (!pre) { c->imu_valid[k] = 0; return VIO_OK; }
+    c->pre[k] = *pre;
+    vioo_inverse15(pre->covariance, c->imu_info[k]);    /* SetInformation(covariance.inverse()), edge_imu.cc:35 */
+    c->imu_valid[k] = 1;
+    c->linearized = 0;
+    return VIO_OK;
+}
+
+vio_status vio_set_prior(struct vioo_ctx *c, int32_t dim, const double *H, const double *b, const double *err,
+                         const double *jt) {
+    if (!c || (dim != 0 && dim != PRD)) return VIO_ERR_BAD_ARG;
+    memset(c->Hprior, 0, sizeof(c->Hprior)); memset(c->bprior, 0, sizeof(c->bprior));
+    memset(c->errprior, 0, sizeof(c->errprior)); memset(c->Jtinv, 0, sizeof(c->Jtinv));
+    c->has_prior = 0;
+    if (dim == PRD) {
+        if (!H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
+        /* ExtendHessiansPriorSize(15): zero rows/cols appended (problem.cc:82-91) */
+        for (int i = 0; i < PRD; ++i) { memcpy(&c->Hprior[i * PD], &H[i * PRD], sizeof(double) * PRD); c->bprior[i] = b[i]; }
+        memcpy(c->errprior, err, sizeof(double) * PRD);
+        memcpy(c->Jtinv, jt, sizeof(double) * PRD * PRD);
+        c->has_prior = 1;
+    }
+    c->linearized = 0;
+    return VIO_OK;
+}
+
+/* add J_a^T * W * J_b (6x6, J row-major 2x6) into the 171x171 pose block at (ia, ib), and mirror it
+ * (problem.cc:347-355) */
+static void add_pose_block(double *H, int ia, int ib, const double *Ja, const double *W, const double *Jb, int same) {
+    for (int r = 0; r < 6; ++r) {
+        double t0 = Ja[r] * W[0] + Ja[6 + r] * W[2];    /* (Ja^T W) row r */
+        double t1 = Ja[r] * W[1] + Ja[6 + r] * W[3];
+        for (int cc = 0; cc < 6; ++cc) {
+            double h = t0 * Jb[cc] + t1 * Jb[6 + cc];
+            H[(ia + r) * PD + ib + cc] += h;
+            if (!same) H[(ib + cc) * PD + ia + r] += h;
+        }
+    }
+}
+
+static void linearize_impl(struct vioo_ctx *c, int marg_mode, double *Hpp, double *bpp) {
+    /* marg_mode: Problem::Marginalize's assembly (problem.cc:641-681): no IsFixed test, only the edges
+     * connected to frame 0; the caller has already restricted the edge set. */
+    const int fixed = marg_mode ? 0 : c->cfg.ext_fixed;
+    const double s = c->cfg.reproj_sqrt_info, info = s * s;
+    memset(Hpp, 0, sizeof(double) * PD * PD); memset(bpp, 0, sizeof(double) * PD);
+    for (int64_t l = 0; l < c->N; ++l) { c->hll[l] = 0; c->bl[l] = 0; }
+    memset(c->Hpl, 0, sizeof(double) * (size_t)(c->N > 0 ? c->N : 1) * CD);
+
+    for (int64_t e = 0; e < c->M; ++e) {
+        int l = c->lm[e], fi = c->host[e], fj = c->target[e];
+        if (marg_mode && fi != 0) continue;     /* MargOldFrame adds only landmarks hosted in frame 0 (estimator.cpp:762-764) */
+        double r[2], Jl[2], Ji[12], Jj[12], Je[12], W[4], drho;
+        vioo_reproj_edge(&c->pose[7 * fi], &c->pose[7 * fj], c->ext, c->invd[l], &c->pts_i[2 * e], &c->pts_j[2 * e],
+                         r, Jl, Ji, Jj, Je);
+        vioo_robust_info2(c->cfg.loss_type, c->cfg.loss_delta, s, r, &drho, W);
+        int ii = 6 + 15 * fi, ij = 6 + 15 * fj;
+        /* landmark-landmark */
+        c->hll[l] += (Jl[0] * W[0] + Jl[1] * W[2]) * Jl[0] + (Jl[0] * W[1] + Jl[1] * W[3]) * Jl[1];
+        /* landmark-pose (Hmp row == Hpm column since W is symmetric) */
+        double t0 = Jl[0] * W[0] + Jl[1] * W[2], t1 = Jl[0] * W[1] + Jl[1] * W[3];
+        double *w = &c->Hpl[(size_t)l * CD];
+        for (int k = 0; k < 6; ++k) {
+            w[6 + 6 * fi + k] += t0 * Ji[k] + t1 * Ji[6 + k];
+            w[6 + 6 * fj + k] += t0 * Jj[k] + t1 * Jj[6 + k];
+            if (!fixed) w[k] += t0 * Je[k] + t1 * Je[6 + k];
+        }
+        /* pose-pose in the edge's vertex order (landmark, pose_i, pose_j, ext), j >= i */
+        add_pose_block(Hpp, ii, ii, Ji, W, Ji, 1);
+        add_pose_block(Hpp, ii, ij, Ji, W, Jj, 0);
+        if (!fixed) add_pose_block(Hpp, ii, 0, Ji, W, Je, 0);
+        add_pose_block(Hpp, ij, ij, Jj, W, Jj, 1);
+        if (!fixed) add_pose_block(Hpp, ij, 0, Jj, W, Je, 0);
+        if (!fixed) add_pose_block(Hpp, 0, 0, Je, W, Je, 1);
+        /* b -= drho * J^T * Information * r  (problem.cc:357) */
+        double ir0 = info * r[0], ir1 = info * r[1];
+        c->bl[l] -= drho * (Jl[0] * ir0 + Jl[1] * ir1);
+        for (int k = 0; k < 6; ++k) {
+            bpp[ii + k] -= drho * (Ji[k] * ir0 + Ji[6 + k] * ir1);
+            bpp[ij + k] -= drho * (Jj[k] * ir0 + Jj[6 + k] * ir1);
+            if (!fixed) bpp[k] -= drho * (Je[k] * ir0 + Je[6 + k] * ir1);
+        }
+    }
+    /* IMU edges: vertex order (pose_i, sb_i, pose_j, sb_j) = 30 contiguous columns from 6+15*i */
+    if (c->cfg.shard_rank == 0) {
+        for (int k = 0; k < VIO_WINDOW_SIZE; ++k) {
+            if (!c->imu_valid[k]) continue;
+            if (marg_mode && k != 0) continue;  /* only pre_integrations[1] (estimator.cpp:735-747) */
+            double r[15], Jpi[90], Jsi[135], Jpj[90], Jsj[135], J[15 * 30];
+            vioo_imu_edge(&c->pre[k], c->cfg.gravity, &c->pose[7 * k], &c->sb[9 * k], &c->pose[7 * (k + 1)],
+                          &c->sb[9 * (k + 1)], r, Jpi, Jsi, Jpj, Jsj);
+            for (int i = 0; i < 15; ++i) {
+                for (int j = 0; j < 6; ++j) { J[30 * i + j] = Jpi[6 * i + j]; J[30 * i + 15 + j] = Jpj[6 * i + j]; }
+                for (int j = 0; j < 9; ++j) { J[30 * i + 6 + j] = Jsi[9 * i + j]; J[30 * i + 21 + j] = Jsj[9 * i + j]; }
+            }
+            const double *I = c->imu_info[k];
+            double JtI[30 * 15], T[30 * 30], Ir[15];
+            for (int a = 0; a < 30; ++a)
+                for (int j = 0; j < 15; ++j) {
+                    double sum = 0;
+                    for (int i = 0; i < 15; ++i) sum += J[30 * i + a] * I[15 * i + j];
+                    JtI[15 * a + j] = sum;
+                }
+            for (int a = 0; a < 30; ++a)
+                for (int b2 = 0; b2 < 30; ++b2) {
+                    double sum = 0;
+                    for (int j = 0; j < 15; ++j) sum += JtI[15 * a + j] * J[30 * j + b2];
+                    T[30 * a + b2] = sum;
+                }
+            /* vertex blocks: [0,6) [6,15) [15,21) [21,30): upper blocks computed, lower mirrored (problem.cc:347-355) */
+            static const int bs[5] = {0, 6, 15, 21, 30};
+            int base = 6 + 15 * k;
+            for (int bi = 0; bi < 4; ++bi)
+                for (int bj = bi; bj < 4; ++bj)
+                    for (int a = bs[bi]; a < bs[bi + 1]; ++a)
+                        for (int b2 = bs[bj]; b2 < bs[bj + 1]; ++b2) {
+                            Hpp[(base + a) * PD + base + b2] += T[30 * a + b2];
+                            if (bi != bj) Hpp[(base + b2) * PD + base + a] += T[30 * a + b2];
+                        }
+            for (int i = 0; i < 15; ++i) { double sum = 0; for (int j = 0; j < 15; ++j) sum += I[15 * i + j] * r[j]; Ir[i] = sum; }
+            for (int a = 0; a < 30; ++a) {
+                double sum = 0;
+                for (int i = 0; i < 15; ++i) sum += J[30 * i + a] * Ir[i];
+                bpp[base + a] -= 1.0 * sum;
+            }
+        }
+    }
+}
+
+/* SetOrdering + MakeHessian, problem.cc:256-285,303-389 */
+vio_status vio_linearize(struct vioo_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    double t0 = now_ms();
+    linearize_impl(c, 0, c->Hpp, c->bpp);
+    c->t_hessian_ms += now_ms() - t0;
+    /* prior, with the rows/cols of fixed pose vertices zeroed (problem.cc:365-384) */
+    if (c->cfg.shard_rank == 0) {
+        for (int i = 0; i < PD; ++i) {
+            int fi = c->cfg.ext_fixed && i < 6;
+            for (int j = 0; j < PD; ++j) {
+                int fj = c->cfg.ext_fixed && j < 6;
+                c->Hpp[i * PD + j] += (fi || fj) ? 0.0 : c->Hprior[i * PD + j];
+            }
+            c->bpp[i] += fi ? 0.0 : c->bprior[i];
+        }
+    }
+    /* Schur system without lambda: Hpp - (Hpm*Hmm^-1)*Hmp, bpp - (Hpm*Hmm^-1)*bmm  (problem.cc:412-429) */
+    memcpy(c->Hs, c->Hpp, sizeof(c->Hs)); memcpy(c->bs, c->bpp, sizeof(c->bs));
+    {
+        double *S = (double *)calloc(CD * CD, sizeof(double));
+        double sb[CD];
+        memset(sb, 0, sizeof(sb));
+        for (int64_t l = 0; l < c->N; ++l) {
+            const double *w = &c->Hpl[(size_t)l * CD];
+            double hinv = 1.0 / c->hll[l];
+            int nzc[CD], nn = 0;
+            for (int a = 0; a < CD; ++a) if (w[a] != 0.0) nzc[nn++] = a;
+            for (int x = 0; x < nn; ++x) {
+                double ta = w[nzc[x]] * hinv;                     /* tempH entry */
+                for (int y = 0; y < nn; ++y) S[nzc[x] * CD + nzc[y]] += ta * w[nzc[y]];
+                sb[nzc[x]] += ta * c->bl[l];
+            }
+        }
+        for (int a = 0; a < CD; ++a) {
+            int fa = cam_to_full(a);
+            for (int b2 = 0; b2 < CD; ++b2) c->Hs[fa * PD + cam_to_full(b2)] -= S[a * CD + b2];
+            c->bs[fa] -= sb[a];
+        }
+        free(S);
+    }
+    memset(c->dx_pose, 0, sizeof(c->dx_pose));
+    for (int64_t l = 0; l < c->N; ++l) c->dx_lm[l] = 0;
+    c->linearized = 1;
+    return VIO_OK;
+}
+
+static double chi2_now(struct vioo_ctx *c) {
+    const double s = c->cfg.reproj_sqrt_info;
+    double chi = 0;
+    for (int64_t e = 0; e < c->M; ++e) {
+        double r[2];
+        vioo_reproj_edge(&c->pose[7 * c->host[e]], &c->pose[7 * c->target[e]], c->ext, c->invd[c->lm[e]],
+                         &c->pts_i[2 * e], &c->pts_j[2 * e], r, NULL, NULL, NULL, NULL);
+        chi += robust_chi2_2(c->cfg.loss_type, c->cfg.loss_delta, s, r);
+    }
+    if (c->cfg.shard_rank == 0) {
+        for (int k = 0; k < VIO_WINDOW_SIZE; ++k) {
+            if (!c->imu_valid[k]) continue;
+            double r[15];
+            vioo_imu_edge(&c->pre[k], c->cfg.gravity, &c->pose[7 * k], &c->sb[9 * k], &c->pose[7 * (k + 1)],
+                          &c->sb[9 * (k + 1)], r, NULL, NULL, NULL, NULL);
+            const double *I = c->imu_info[k];
+            double e2 = 0;
+            for (int i = 0; i < 15; ++i) { double t = 0; for (int j = 0; j < 15; ++j) t += I[15 * i + j] * r[j]; e2 += r[i] * t; }
+            chi += e2;
+        }
+        if (c->has_prior) {
+            double n2 = 0;
+            for (int i = 0; i < PRD; ++i) n2 += c->errprior[i] * c->errprior[i];
+            chi += sqrt(n2);            /* err_prior_.norm(), NOT squared (problem.cc:505-507,554-556) */
+        }
+    }
+    return 0.5 * chi;
+}
+
+vio_status vio_chi2(struct vioo_ctx *c, double *chi2) {
+    if (!c || !chi2) return VIO_ERR_BAD_ARG;
+    *chi2 = chi2_now(c);
+    return VIO_OK;
+}
+
+/* ComputeLambdaInitLM, problem.cc:497-522 */
+vio_status vio_init_lm(struct vioo_ctx *c, double *chi2, double *lambda) {
+    if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    c->ni = 2.;
+    c->chi = chi2_now(c);
+    double maxd = 0;
+    for (int i = 0; i < PD; ++i) maxd = fmax(fabs(c->Hpp[i * PD + i]), maxd);
+    for (int64_t l = 0; l < c->N; ++l) maxd = fmax(fabs(c->hll[l]), maxd);
+    maxd = fmin(5e10, maxd);
+    c->lambda = 1e-5 * maxd;
+    if (chi2) *chi2 = c->chi;
+    if (lambda) *lambda = c->lambda;
+    return VIO_OK;
+}
+
+/* SolveLinearSystem (SLAM branch), problem.cc:406-449 */
+vio_status vio_solve_linear(struct vioo_ctx *c, double lambda) {
+    if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    double *H = (double *)malloc(sizeof(double) * PD * PD);
+    memcpy(H, c->Hs, sizeof(double) * PD * PD);
+    for (int i = 0; i < PD; ++i) H[i * PD + i] += lambda;
+    vioo_ldlt_solve(PD, H, c->bs, c->dx_pose, NULL);
+    free(H);
+    for (int64_t l = 0; l < c->N; ++l) {
+        const double *w = &c->Hpl[(size_t)l * CD];
+        double t = 0;
+        for (int a = 0; a < CD; ++a) if (w[a] != 0.0) t += w[a] * c->dx_pose[cam_to_full(a)];
+        c->dx_lm[l] = (1.0 / c->hll[l]) * (c->bl[l] - t);
+    }
+    c->lambda = lambda;
+    return VIO_OK;
+}
+
+/* UpdateStates, problem.cc:453-480 */
+vio_status vio_update_states(struct vioo_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    memcpy(c->pose_bak, c->pose, sizeof(c->pose)); memcpy(c->sb_bak, c->sb, sizeof(c->sb));
+    memcpy(c->ext_bak, c->ext, sizeof(c->ext));
+    if (c->N > 0) memcpy(c->invd_bak, c->invd, sizeof(double) * c->N);
+    vioo_pose_plus(c->ext, &c->dx_pose[0]);
+    for (int i = 0; i < NF; ++i) {
+        vioo_pose_plus(&c->pose[7 * i], &c->dx_pose[6 + 15 * i]);
+        for (int k = 0; k < 9; ++k) c->sb[9 * i + k] += c->dx_pose[12 + 15 * i + k];
+    }
+    for (int64_t l = 0; l < c->N; ++l) c->invd[l] += c->dx_lm[l];
+    if (c->has_prior) {
+        memcpy(c->bprior_bak, c->bprior, sizeof(c->bprior)); memcpy(c->errprior_bak, c->errprior, sizeof(c->errprior));
+        double tmp[PD];
+        for (int i = 0; i < PD; ++i) { double s = 0; for (int j = 0; j < PD; ++j) s += c->Hprior[i * PD + j] * c->dx_pose[j]; tmp[i] = s; }
+        for (int i = 0; i < PD; ++i) c->bprior[i] -= tmp[i];
+        for (int i = 0; i < PRD; ++i) {
+            double s = 0;
+            for (int j = 0; j < PRD; ++j) s += -c->Jtinv[i * PRD + j] * c->bprior[j];
+            c->errprior[i] = s;
+        }
+    }
+    return VIO_OK;
+}
+
+/* RollbackStates, problem.cc:482-494 */
+vio_status vio_rollback_states(struct vioo_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    memcpy(c->pose, c->pose_bak, sizeof(c->pose)); memcpy(c->sb, c->sb_bak, sizeof(c->sb));
+    memcpy(c->ext, c->ext_bak, sizeof(c->ext));
+    if (c->N > 0) memcpy(c->invd, c->invd_bak, sizeof(double) * c->N);
+    if (c->has_prior) { memcpy(c->bprior, c->bprior_bak, sizeof(c->bprior)); memcpy(c->errprior, c->errprior_bak, sizeof(c->errprior)); }
+    return VIO_OK;
+}
+
+/* IsGoodStepInLM, problem.cc:541-573 */
+vio_status vio_eval_step(struct vioo_ctx *c, int32_t *accepted, double *chi2, double *lambda) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    double scale = 0;
+    for (int i = 0; i < PD; ++i) scale += c->dx_pose[i] * (c->lambda * c->dx_pose[i] + c->bpp[i]);
+    for (int64_t l = 0; l < c->N; ++l) scale += c->dx_lm[l] * (c->lambda * c->dx_lm[l] + c->bl[l]);
+    scale = 0.5 * scale;
+    scale += 1e-6;
+    double tempChi = chi2_now(c);
+    double rho = (c->chi - tempChi) / scale;
+    int ok;
+    if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, 2. / 3.);
+        double scaleFactor = fmax(1. / 3., alpha);
+        c->lambda *= scaleFactor;
+        c->ni = 2;
+        c->chi = tempChi;
+        ok = 1;
+    } else {
+        c->lambda *= c->ni;
+        c->ni *= 2;
+        ok = 0;
+    }
+    if (accepted) *accepted = ok;
+    if (chi2) *chi2 = c->chi;
+    if (lambda) *lambda = c->lambda;
+    return VIO_OK;
+}
+
+/* Problem::Solve, problem.cc:169-250 */
+vio_status vio_solve(struct vioo_ctx *c, int32_t iterations, vio_solve_report *rep) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (c->M == 0 && c->N == 0) {
+        int any = 0;
+        for (int k = 0; k < VIO_WINDOW_SIZE; ++k) any |= c->imu_valid[k];
+        if (!any) return VIO_ERR_EMPTY;
+    }
+    double t0 = now_ms();
+    c->t_hessian_ms = 0;
+    vio_solve_report r;
+    memset(&r, 0, sizeof(r));
+    vio_linearize(c);
+    vio_init_lm(c, &r.initial_chi2, NULL);
+    int stop = 0, iter = 0;
+    double last_chi = 1e20;
+    while (!stop && iter < iterations) {
+        if (iter < 128) { r.chi2_trace[iter] = c->chi; r.lambda_trace[iter] = c->lambda; }
+        int success = 0, false_cnt = 0;
+        while (!success && false_cnt < 10) {
+            vio_solve_linear(c, c->lambda);
+            vio_update_states(c);
+            int32_t ok;
+            vio_eval_step(c, &ok, NULL, NULL);
+            r.trials++;
+            if (ok) { vio_linearize(c); false_cnt = 0; success = 1; r.accepted++; }
+            else { false_cnt++; vio_rollback_states(c); }
+        }
+        iter++;
+        if (last_chi - c->chi < 1e-5) { stop = 1; r.stop_reason = 1; }
+        last_chi = c->chi;
+    }
+    r.iterations = iter;
+    r.final_chi2 = c->chi; r.final_lambda = c->lambda;
+    r.solve_ms = now_ms() - t0; r.hessian_ms = c->t_hessian_ms;
+    if (rep) *rep = r;
+    return VIO_OK;
+}
+
+vio_status vio_gn_iteration(struct vioo_ctx *c, double lambda) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    vio_linearize(c);
+    vio_solve_linear(c, lambda);
+    vio_update_states(c);
+    c->chi = chi2_now(c);
+    return VIO_OK;
+}
+
+vio_status vio_synchronize(struct vioo_ctx *c) { return c ? VIO_OK : VIO_ERR_BAD_ARG; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Marginalize: estimator.cpp:693-901 + problem.cc:617-795                                     */
+/* ------------------------------------------------------------------------------------------ */
+static void move_to_bottom(double *H, double *b, int n, int idx, int dim) {
+    /* rows idx..idx+dim -> bottom, then cols (problem.cc:728-744) */
+    double *T = (double *)malloc(sizeof(double) * n * n);
+    int rest = n - idx - dim;
+    memcpy(T, H, sizeof(double) * n * n);
+    for (int i = 0; i < rest; ++i) memcpy(&H[(idx + i) * n], &T[(idx + dim + i) * n], sizeof(double) * n);
+    for (int i = 0; i < dim; ++i) memcpy(&H[(n - dim + i) * n], &T[(idx + i) * n], sizeof(double) * n);
+    memcpy(T, H, sizeof(double) * n * n);
+    for (int r = 0; r < n; ++r) {
+        for (int j = 0; j < rest; ++j) H[r * n + idx + j] = T[r * n + idx + dim + j];
+        for (int j = 0; j < dim; ++j) H[r * n + n - dim + j] = T[r * n + idx + j];
+    }
+    double tb[PD];
+    memcpy(tb, b, sizeof(double) * n);
+    for (int i = 0; i < rest; ++i) b[idx + i] = tb[idx + dim + i];
+    for (int i = 0; i < dim; ++i) b[n - dim + i] = tb[idx + i];
+    free(T);
+}
+
+vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, double *bout, double *errout, double *jtout) {
+    if (!c || !Hout || !bout || !errout || !jtout) return VIO_ERR_BAD_ARG;
+    if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
+    const int n = PD;
+    double *H = (double *)calloc(n * n, sizeof(double));
+    double b[PD];
+    memset(b, 0, sizeof(b));
+    if (kind == VIO_MARG_OLD) {
+        linearize_impl(c, 1, H, b);
+        /* Schur out the landmarks hosted in frame 0 (problem.cc:685-708) */
+        double *S = (double *)calloc(CD * CD, sizeof(double));
+        double sb[CD];
+        memset(sb, 0, sizeof(sb));
+        for (int64_t l = 0; l < c->N; ++l) {
+            const double *w = &c->Hpl[(size_t)l * CD];
+            if (c->hll[l] == 0.0) continue;     /* landmark not part of the marginalisation graph */
+            double hinv = 1.0 / c->hll[l];
+            for (int a = 0; a < CD; ++a) {
+                if (w[a] == 0.0) continue;
+                double ta = w[a] * hinv;
+                for (int b2 = 0; b2 < CD; ++b2) S[a * CD + b2] += ta * w[b2];
+                sb[a] += ta * c->bl[l];
+            }
+        }
+        for (int a = 0; a < CD; ++a) {
+            int fa = cam_to_full(a);
+            for (int b2 = 0; b2 < CD; ++b2) H[fa * n + cam_to_full(b2)] -= S[a * CD + b2];
+            b[fa] -= sb[a];
+        }
+        free(S);
+        c->linearized = 0;      /* hll/bl/Hpl now hold the marginalisation graph's values */
+    }
+    /* += prior (no fixed-vertex zeroing here, problem.cc:710-715) */
+    for (int i = 0; i < n * n; ++i) H[i] += c->Hprior[i];
+    for (int i = 0; i < n; ++i) b[i] += c->bprior[i];
+    /* move speed-bias then pose of the marginalised frame to the bottom (index-large first, :721-745) */
+    int f = (kind == VIO_MARG_OLD) ? 0 : VIO_WINDOW_SIZE - 1;
+    move_to_bottom(H, b, n, 12 + 15 * f, 9);
+    move_to_bottom(H, b, n, 6 + 15 * f, 6);
+    const int m2 = 15, n2 = n - 15;
+    double Amm[15 * 15], ev[15], V[15 * 15], Amm_inv[15 * 15];
+    for (int i = 0; i < m2; ++i) for (int j = 0; j < m2; ++j) Amm[i * m2 + j] = 0.5 * (H[(n2 + i) * n + n2 + j] + H[(n2 + j) * n + n2 + i]);
+    vioo_symmetric_eigen(m2, Amm, ev, V);
+    const double eps = 1e-8;
+    for (int i = 0; i < m2; ++i) for (int j = 0; j < m2; ++j) {
+        double s = 0;
+        for (int k = 0; k < m2; ++k) s += V[i * m2 + k] * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V[j * m2 + k];
+        Amm_inv[i * m2 + j] = s;
+    }
+    double *tempB = (double *)malloc(sizeof(double) * n2 * m2);
+    for (int i = 0; i < n2; ++i) for (int j = 0; j < m2; ++j) {
+        double s = 0;
+        for (int k = 0; k < m2; ++k) s += H[i * n + n2 + k] * Amm_inv[k * m2 + j];
+        tempB[i * m2 + j] = s;
+    }
+    double *Hp = (double *)malloc(sizeof(double) * n2 * n2);
+    double bp[PRD];
+    for (int i = 0; i < n2; ++i) {
+        for (int j = 0; j < n2; ++j) {
+            double s = 0;
+            for (int k = 0; k < m2; ++k) s += tempB[i * m2 + k] * H[(n2 + k) * n + j];
+            Hp[i * n2 + j] = H[i * n + j] - s;
+        }
+        double s = 0;
+        for (int k = 0; k < m2; ++k) s += tempB[i * m2 + k] * b[n2 + k];
+        bp[i] = b[i] - s;
+    }
+    double *ev2 = (double *)malloc(sizeof(double) * n2);
+    double *V2 = (double *)malloc(sizeof(double) * n2 * n2);
+    vioo_symmetric_eigen(n2, Hp, ev2, V2);
+    /* Jt_prior_inv = S_inv_sqrt.asDiagonal() * V^T ; err = -Jt_prior_inv * b ; H = J^T J with J = S_sqrt * V^T */
+    for (int i = 0; i < n2; ++i) {
+        double sinv = ev2[i] > eps ? sqrt(1.0 / ev2[i]) : 0.0;
+        for (int j = 0; j < n2; ++j) jtout[i * n2 + j] = sinv * V2[j * n2 + i];
+    }
+    for (int i = 0; i < n2; ++i) {
+        double s = 0;
+        for (int j = 0; j < n2; ++j) s += -jtout[i * n2 + j] * bp[j];
+        errout[i] = s;
+    }
+    for (int i = 0; i < n2; ++i) for (int j = 0; j < n2; ++j) {
+        double s = 0;
+        for (int k = 0; k < n2; ++k) {
+            double sk = ev2[k] > eps ? ev2[k] : 0.0;
+            s += V2[i * n2 + k] * sk * V2[j * n2 + k];      /* (sqrt(S) V^T)^T (sqrt(S) V^T) */
+        }
+        Hout[i * n2 + j] = fabs(s) > 1e-9 ? s : 0.0;
+    }
+    memcpy(bout, bp, sizeof(double) * n2);
+    free(H); free(tempB); free(Hp); free(ev2); free(V2);
+    return VIO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* getters                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+vio_status vio_get_window(struct vioo_ctx *c, double *poses, double *sb, double *ext) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (poses) memcpy(poses, c->pose, sizeof(c->pose));
+    if (sb) memcpy(sb, c->sb, sizeof(c->sb));
+    if (ext) memcpy(ext, c->ext, sizeof(c->ext));
+    return VIO_OK;
+}
+vio_status vio_get_landmarks(struct vioo_ctx *c, int64_t n, double *invd) {
+    if (!c || n != c->N || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+    if (n > 0) memcpy(invd, c->invd, sizeof(double) * n);
+    return VIO_OK;
+}
+vio_status vio_get_prior(struct vioo_ctx *c, double *b, double *err) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (b) memcpy(b, c->bprior, sizeof(c->bprior));
+    if (err) memcpy(err, c->errprior, sizeof(c->errprior));
+    return VIO_OK;
+}
+vio_status vio_get_delta(struct vioo_ctx *c, double *dxp, int64_t n, double *dxl) {
+    if (!c || (dxl && n != c->N)) return VIO_ERR_BAD_ARG;
+    if (dxp) memcpy(dxp, c->dx_pose, sizeof(c->dx_pose));
+    if (dxl && n > 0) memcpy(dxl, c->dx_lm, sizeof(double) * n);
+    return VIO_OK;
+}
+vio_status vio_get_schur_system(struct vioo_ctx *c, double *H, double *b) {
+    if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    if (H) memcpy(H, c->Hs, sizeof(c->Hs));
+    if (b) memcpy(b, c->bs, sizeof(c->bs));
+    return VIO_OK;
+}
+vio_status vio_get_landmark_system(struct vioo_ctx *c, int64_t n, double *hll, double *bl) {
+    if (!c || n != c->N) return VIO_ERR_BAD_ARG;
+    if (hll && n > 0) memcpy(hll, c->hll, sizeof(double) * n);
+    if (bl && n > 0) memcpy(bl, c->bl, sizeof(double) * n);
+    return VIO_OK;
+}
+vio_status vio_get_pose_gradient(struct vioo_ctx *c, double *b, double *diag) {
+    if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    if (b) memcpy(b, c->bpp, sizeof(c->bpp));
+    if (diag) for (int i = 0; i < PD; ++i) diag[i] = c->Hpp[i * PD + i];
+    return VIO_OK;
+}
+vio_status vioo_get_pose_hessian(struct vioo_ctx *c, double *Hpp) {
+    if (!c || !c->linearized || !Hpp) return VIO_ERR_BAD_ARG;
+    memcpy(Hpp, c->Hpp, sizeof(c->Hpp));
+    return VIO_OK;
+}
+vio_status vio_exchange_buffers(struct vioo_ctx *c, void **a, int64_t *na, void **b, int64_t *nb) {
+    (void)c; (void)a; (void)na; (void)b; (void)nb;
+    return VIO_ERR_UNSUPPORTED;
+}
+vio_status vio_set_exchange_hook(struct vioo_ctx *c, vio_exchange_fn fn, void *user) {
+    (void)c; (void)fn; (void)user;
+    return VIO_ERR_UNSUPPORTED;
+}

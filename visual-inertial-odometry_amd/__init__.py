@@ -1,0 +1,24 @@
+"""MI355X-native sliding-window VIO backend: host-side Python surface.
+
+The product path is `csrc/libvio_hip.so` (hand-written HIP for gfx950 behind the C ABI of
+include/vio_backend.h).  There is no CPU fallback: `load_hip()` raises if the library is missing.
+"""
+import os
+
+from . import capi, synth
+from .capi import (CAM_DIM, LOSS_CAUCHY, LOSS_HUBER, LOSS_TRIVIAL, LOSS_TUKEY, MARG_OLD, MARG_SECOND_NEW,
+                   NUM_FRAMES, POSE_DIM, PRIOR_DIM, WINDOW_SIZE, VioConfig, VioContext, VioError, VioLib,
+                   VioPreint, VioSolveReport)
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(PKG_DIR, "csrc", "libvio_hip.so")
+
+_hip = None
+
+
+def load_hip():
+    """Load the HIP product library.  Raises (never falls back) when it has not been built."""
+    global _hip
+    if _hip is None:
+        _hip = VioLib(HIP_LIB, "vio_")
+    return _hip

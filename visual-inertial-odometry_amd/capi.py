@@ -1,0 +1,289 @@
+"""ctypes binding of the C ABI declared in include/vio_backend.h.
+
+The product library is `csrc/libvio_hip.so` (prefix ``vio_``).  The same binding class is
+parametrised by (path, prefix) so that the tests can drive the CPU oracle (``vioo_``) and the
+compiled reference harness (``vior_``) through the identical surface; nothing in this package loads
+those two libraries.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+WINDOW_SIZE = 10          # VM/include/parameters.h:35
+NUM_FRAMES = WINDOW_SIZE + 1
+POSE_DIM = 6 + 15 * NUM_FRAMES     # 171
+PRIOR_DIM = POSE_DIM - 15          # 156
+CAM_DIM = 6 + 6 * NUM_FRAMES       # 72
+
+LOSS_TRIVIAL, LOSS_HUBER, LOSS_CAUCHY, LOSS_TUKEY = 0, 1, 2, 3
+MARG_OLD, MARG_SECOND_NEW = 0, 1
+
+STATUS = {0: "VIO_OK", -1: "VIO_ERR_BAD_ARG", -2: "VIO_ERR_HIP", -3: "VIO_ERR_NOT_FINITE",
+          -4: "VIO_ERR_EMPTY", -5: "VIO_ERR_UNSUPPORTED", -6: "VIO_ERR_NO_DEVICE"}
+
+
+class VioConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("ext_fixed", C.c_int32), ("loss_type", C.c_int32),
+                ("reserved0", C.c_int32), ("loss_delta", C.c_double), ("reproj_sqrt_info", C.c_double),
+                ("gravity", C.c_double * 3), ("stream", C.c_void_p), ("shard_rank", C.c_int32),
+                ("shard_count", C.c_int32)]
+
+
+class VioPreint(C.Structure):
+    _fields_ = [("sum_dt", C.c_double), ("delta_p", C.c_double * 3), ("delta_q", C.c_double * 4),
+                ("delta_v", C.c_double * 3), ("linearized_ba", C.c_double * 3),
+                ("linearized_bg", C.c_double * 3), ("jacobian", C.c_double * 225),
+                ("covariance", C.c_double * 225)]
+
+    @classmethod
+    def from_dict(cls, d):
+        p = cls()
+        p.sum_dt = float(d["sum_dt"])
+        for name, n in (("delta_p", 3), ("delta_q", 4), ("delta_v", 3), ("linearized_ba", 3),
+                        ("linearized_bg", 3), ("jacobian", 225), ("covariance", 225)):
+            arr = np.ascontiguousarray(d[name], dtype=np.float64).reshape(-1)
+            assert arr.size == n, name
+            getattr(p, name)[:] = arr.tolist()
+        return p
+
+
+class VioSolveReport(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("accepted", C.c_int32),
+                ("stop_reason", C.c_int32), ("initial_chi2", C.c_double), ("final_chi2", C.c_double),
+                ("final_lambda", C.c_double), ("solve_ms", C.c_double), ("hessian_ms", C.c_double),
+                ("chi2_trace", C.c_double * 128), ("lambda_trace", C.c_double * 128)]
+
+
+class VioError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        super().__init__("%s failed: %s %s" % (where, STATUS.get(status, status), detail))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+class VioLib:
+    """One shared library exporting the vio_backend.h surface under `prefix`."""
+
+    SYMBOLS = ["create", "destroy", "last_error", "default_config", "set_window", "set_landmarks",
+               "set_observations", "set_imu", "set_prior", "solve", "linearize", "init_lm",
+               "solve_linear", "update_states", "rollback_states", "chi2", "eval_step", "gn_iteration",
+               "synchronize", "marginalize", "get_window", "get_landmarks", "get_prior", "get_delta",
+               "get_schur_system", "get_landmark_system", "get_pose_gradient", "exchange_buffers",
+               "set_exchange_hook"]
+
+    def __init__(self, path, prefix="vio_"):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                "%s not found — build it first (python -c 'import __graft_entry__ as g; g.build()')" % path)
+        self.path = path
+        self.prefix = prefix
+        self.dll = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
+        self.fn = {}
+        for s in self.SYMBOLS:
+            self.fn[s] = getattr(self.dll, prefix + s)     # raises AttributeError on a missing export
+        self.fn["last_error"].restype = C.c_char_p
+        self.fn["destroy"].restype = None
+        self.fn["default_config"].restype = None
+        for s in self.SYMBOLS:
+            if s not in ("last_error", "destroy", "default_config"):
+                self.fn[s].restype = C.c_int
+
+    def has(self, name):
+        return hasattr(self.dll, self.prefix + name)
+
+    def raw(self, name):
+        return getattr(self.dll, self.prefix + name)
+
+    def default_config(self):
+        cfg = VioConfig()
+        self.fn["default_config"](C.byref(cfg))
+        return cfg
+
+    def context(self, cfg=None, **overrides):
+        cfg = cfg or self.default_config()
+        for k, v in overrides.items():
+            if k == "gravity":
+                cfg.gravity[:] = list(v)
+            else:
+                setattr(cfg, k, v)
+        return VioContext(self, cfg)
+
+
+class VioContext:
+    """Owns one vio_ctx handle.  Methods mirror the reference's Problem call sequence."""
+
+    def __init__(self, lib, cfg):
+        self.lib = lib
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        self.n = 0
+        self.m = 0
+        st = lib.fn["create"](C.byref(cfg), C.byref(self.h))
+        if st != 0:
+            raise VioError(st, lib.prefix + "create")
+
+    def close(self):
+        if self.h:
+            self.lib.fn["destroy"](self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st, where):
+        if st != 0:
+            msg = self.lib.fn["last_error"](self.h)
+            raise VioError(st, self.lib.prefix + where, (msg or b"").decode(errors="replace"))
+
+    # ---- graph construction ---------------------------------------------------------------
+    def set_window(self, poses, speed_bias, ext):
+        p, s, e = _f64(poses, (NUM_FRAMES, 7)), _f64(speed_bias, (NUM_FRAMES, 9)), _f64(ext, (7,))
+        self._ck(self.lib.fn["set_window"](self.h, _dp(p), _dp(s), _dp(e)), "set_window")
+
+    def set_landmarks(self, inv_depth):
+        d = _f64(inv_depth).reshape(-1)
+        self.n = d.size
+        self._ck(self.lib.fn["set_landmarks"](self.h, C.c_int64(d.size), _dp(d)), "set_landmarks")
+
+    def set_observations(self, lm, host, target, pts_i, pts_j):
+        lm = np.ascontiguousarray(lm, dtype=np.int32)
+        host = np.ascontiguousarray(host, dtype=np.int32)
+        target = np.ascontiguousarray(target, dtype=np.int32)
+        self.m = lm.size
+        pi, pj = _f64(pts_i, (self.m, 2)), _f64(pts_j, (self.m, 2))
+        self._ck(self.lib.fn["set_observations"](self.h, C.c_int64(self.m), _ip(lm), _ip(host), _ip(target),
+                                                 _dp(pi), _dp(pj)), "set_observations")
+
+    def set_imu(self, k, pre):
+        if pre is None:
+            self._ck(self.lib.fn["set_imu"](self.h, C.c_int32(k), None), "set_imu")
+        else:
+            p = pre if isinstance(pre, VioPreint) else VioPreint.from_dict(pre)
+            self._ck(self.lib.fn["set_imu"](self.h, C.c_int32(k), C.byref(p)), "set_imu")
+
+    def set_prior(self, prior):
+        if prior is None:
+            self._ck(self.lib.fn["set_prior"](self.h, C.c_int32(0), None, None, None, None), "set_prior")
+            return
+        H, b = _f64(prior["H"], (PRIOR_DIM, PRIOR_DIM)), _f64(prior["b"], (PRIOR_DIM,))
+        err, jt = _f64(prior["err"], (PRIOR_DIM,)), _f64(prior["jt_inv"], (PRIOR_DIM, PRIOR_DIM))
+        self._ck(self.lib.fn["set_prior"](self.h, C.c_int32(PRIOR_DIM), _dp(H), _dp(b), _dp(err), _dp(jt)),
+                 "set_prior")
+
+    def load(self, w):
+        """Upload a synth.Window (or any object/dict with the same fields)."""
+        g = (lambda k: w[k]) if isinstance(w, dict) else (lambda k: getattr(w, k))
+        self.set_window(g("poses"), g("speed_bias"), g("ext"))
+        self.set_landmarks(g("inv_depth"))
+        self.set_observations(g("lm"), g("host"), g("target"), g("pts_i"), g("pts_j"))
+        for k, pre in enumerate(g("preint")):
+            self.set_imu(k, pre)
+        self.set_prior(g("prior"))
+
+    # ---- solve ----------------------------------------------------------------------------
+    def solve(self, iterations=10):
+        rep = VioSolveReport()
+        self._ck(self.lib.fn["solve"](self.h, C.c_int32(iterations), C.byref(rep)), "solve")
+        return rep
+
+    def linearize(self):
+        self._ck(self.lib.fn["linearize"](self.h), "linearize")
+
+    def init_lm(self):
+        chi, lam = C.c_double(), C.c_double()
+        self._ck(self.lib.fn["init_lm"](self.h, C.byref(chi), C.byref(lam)), "init_lm")
+        return chi.value, lam.value
+
+    def solve_linear(self, lam):
+        self._ck(self.lib.fn["solve_linear"](self.h, C.c_double(lam)), "solve_linear")
+
+    def update_states(self):
+        self._ck(self.lib.fn["update_states"](self.h), "update_states")
+
+    def rollback_states(self):
+        self._ck(self.lib.fn["rollback_states"](self.h), "rollback_states")
+
+    def chi2(self):
+        chi = C.c_double()
+        self._ck(self.lib.fn["chi2"](self.h, C.byref(chi)), "chi2")
+        return chi.value
+
+    def eval_step(self):
+        ok, chi, lam = C.c_int32(), C.c_double(), C.c_double()
+        self._ck(self.lib.fn["eval_step"](self.h, C.byref(ok), C.byref(chi), C.byref(lam)), "eval_step")
+        return bool(ok.value), chi.value, lam.value
+
+    def gn_iteration(self, lam):
+        self._ck(self.lib.fn["gn_iteration"](self.h, C.c_double(lam)), "gn_iteration")
+
+    def synchronize(self):
+        self._ck(self.lib.fn["synchronize"](self.h), "synchronize")
+
+    def marginalize(self, kind):
+        H = np.zeros((PRIOR_DIM, PRIOR_DIM))
+        b, err = np.zeros(PRIOR_DIM), np.zeros(PRIOR_DIM)
+        jt = np.zeros((PRIOR_DIM, PRIOR_DIM))
+        self._ck(self.lib.fn["marginalize"](self.h, C.c_int32(kind), _dp(H), _dp(b), _dp(err), _dp(jt)),
+                 "marginalize")
+        return {"H": H, "b": b, "err": err, "jt_inv": jt}
+
+    # ---- read back ------------------------------------------------------------------------
+    def get_window(self):
+        p, s, e = np.zeros((NUM_FRAMES, 7)), np.zeros((NUM_FRAMES, 9)), np.zeros(7)
+        self._ck(self.lib.fn["get_window"](self.h, _dp(p), _dp(s), _dp(e)), "get_window")
+        return p, s, e
+
+    def get_landmarks(self):
+        d = np.zeros(max(self.n, 1))
+        self._ck(self.lib.fn["get_landmarks"](self.h, C.c_int64(self.n), _dp(d)), "get_landmarks")
+        return d[:self.n]
+
+    def get_prior(self):
+        b, err = np.zeros(POSE_DIM), np.zeros(PRIOR_DIM)
+        self._ck(self.lib.fn["get_prior"](self.h, _dp(b), _dp(err)), "get_prior")
+        return b, err
+
+    def get_delta(self):
+        dp, dl = np.zeros(POSE_DIM), np.zeros(max(self.n, 1))
+        self._ck(self.lib.fn["get_delta"](self.h, _dp(dp), C.c_int64(self.n), _dp(dl)), "get_delta")
+        return dp, dl[:self.n]
+
+    def get_schur_system(self):
+        H, b = np.zeros((POSE_DIM, POSE_DIM)), np.zeros(POSE_DIM)
+        self._ck(self.lib.fn["get_schur_system"](self.h, _dp(H), _dp(b)), "get_schur_system")
+        return H, b
+
+    def get_landmark_system(self):
+        h, b = np.zeros(max(self.n, 1)), np.zeros(max(self.n, 1))
+        self._ck(self.lib.fn["get_landmark_system"](self.h, C.c_int64(self.n), _dp(h), _dp(b)),
+                 "get_landmark_system")
+        return h[:self.n], b[:self.n]
+
+    def get_pose_gradient(self):
+        b, d = np.zeros(POSE_DIM), np.zeros(POSE_DIM)
+        self._ck(self.lib.fn["get_pose_gradient"](self.h, _dp(b), _dp(d)), "get_pose_gradient")
+        return b, d
+
+    def exchange_buffers(self):
+        p0, n0, p1, n1 = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        self._ck(self.lib.fn["exchange_buffers"](self.h, C.byref(p0), C.byref(n0), C.byref(p1), C.byref(n1)),
+                 "exchange_buffers")
+        return (p0.value, n0.value), (p1.value, n1.value)
