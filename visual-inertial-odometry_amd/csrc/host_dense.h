@@ -1,0 +1,21 @@
+// host_dense.h — small dense host routines of the product path (C++).
+//   inverse15        covariance.inverse() of an IMU edge, done once per upload (edge_imu.cc:35 does it per evaluation)
+//   marginalize_tail the dense tail of Problem::Marginalize (problem.cc:717-779): move the marginalised frame
+//                    to the bottom, eigen-decomposition pseudo-inverse Schur complement, re-factor the new prior
+#ifndef VIO_HOST_DENSE_H
+#define VIO_HOST_DENSE_H
+
+namespace vio_host {
+
+void inverse15(const double *cov, double *info);
+
+// Symmetric eigen-decomposition (lower triangle is read). evals ascending, V row-major, column k = k-th vector.
+bool symmetric_eigen(int n, const double *A, double *evals, double *V);
+
+// H (171x171 row-major) and b (171) hold H_marg/b_marg AFTER the landmark Schur complement and AFTER the old
+// prior has been added.  frame = index of the frame whose pose (6) and speed-bias (9) are marginalised.
+// Outputs: Hout 156x156, bout 156, errout 156, jtout 156x156.
+void marginalize_tail(double *H, double *b, int frame, double *Hout, double *bout, double *errout, double *jtout);
+
+}  // namespace vio_host
+#endif

@@ -1,0 +1,868 @@
+// vio_api.cpp — host side of libvio_hip.so: the C ABI of include/vio_backend.h over the gfx950 kernels.
+//
+// Mirrors the call sequence of the reference's Estimator::problemSolve / MargOldFrame / MargNewFrame
+// (VM/src/estimator.cpp:693-1073) against Problem (VM/src/backend/problem.cc); see the header for the
+// per-function citations.  No CPU fallback: every compute entry point launches HIP kernels and fails with
+// VIO_ERR_HIP / VIO_ERR_NO_DEVICE when it cannot.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vio_backend.h"
+#include "host_dense.h"
+#include "vio_types.h"
+
+struct ReduceTables {
+    const int32_t *list_off;
+    const int32_t *list;
+    const double *slab;
+    double *vis;
+};
+void vio_launch_prepare(const DeviceTables &T, hipStream_t s);
+void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s);
+void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
+void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
+void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s);
+void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
+void vio_launch_step_sum(const DeviceTables &T, hipStream_t s);
+void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s);
+void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s);
+void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
+void vio_launch_flip(LmState *lm, hipStream_t s);
+int vio_set_kernel_attributes();
+
+namespace {
+
+constexpr int NF = VIO_NUM_FRAMES, PD = VIO_POSE_DIM, PRD = VIO_PRIOR_DIM;
+constexpr int LDS_BUDGET_DOUBLES = 150 * 1024 / 8;     // per linearize workgroup (160 KiB per CU on gfx950)
+constexpr int POSE_SOLVE_LDS = (14880 + 5 * 176 + 112 + 176) * 8 + 176 * 4 + 64;
+constexpr int IMU_ITEM_LDS_DOUBLES = 450 + 225 + 450 + 32;
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t resize(size_t count) {
+        if (count == 0) count = 1;
+        if (count <= n) return hipSuccess;
+        if (p) hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+};
+
+struct Pattern {
+    int use_ext, host, K, nb, host_slot, nsplit, G;
+    int8_t target[VIO_MAXK], tslot[VIO_MAXK], cam_block[VIO_MAXNB];
+    int strip_off, n_strips, row_off, n_rows, lds_doubles;
+};
+
+// Everything that depends on the graph topology (which landmark is seen from where).
+struct Plan {
+    bool valid = false;
+    int marg = 0, use_ext = 0;
+    int64_t Ns = 0, Ms = 0;
+    std::vector<int32_t> sorted_to_orig;       // landmark permutation
+    std::vector<ItemDesc> items;
+    std::vector<Pattern> patterns;
+    std::vector<uint32_t> strips, rows;
+    std::vector<int32_t> list_off, list;
+    size_t slab_doubles = 0, lw_doubles = 0;
+    int max_lds_doubles = 0;
+    DevBuf<ItemDesc> d_items;
+    DevBuf<uint32_t> d_strips, d_rows;
+    DevBuf<int32_t> d_list_off, d_list;
+    DevBuf<double> d_pts_i, d_pts_j, d_invd, d_slab, d_lw, d_dxl, d_step_part;
+    void release() {
+        d_items.release(); d_strips.release(); d_rows.release(); d_list_off.release(); d_list.release();
+        d_pts_i.release(); d_pts_j.release(); d_invd.release(); d_slab.release(); d_lw.release(); d_dxl.release();
+        d_step_part.release();
+        valid = false;
+    }
+};
+
+}  // namespace
+
+struct vio_ctx {
+    vio_config cfg;
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // host mirrors of the inputs (original landmark order)
+    double h_state[STATE_STRIDE];
+    std::vector<double> h_invd, h_pts_i, h_pts_j;
+    std::vector<int32_t> h_olm, h_ohost, h_otarget;   // observation -> landmark / host frame / target frame
+    bool imu_valid[VIO_WINDOW_SIZE];
+    std::vector<double> h_pre;                 // [10][PRE_STRIDE]
+    int has_prior = 0;
+    std::vector<double> h_Hprior, h_bprior, h_errprior, h_Jtinv;
+    // dirty tracking
+    bool dirty_inputs = true;                  // host mirrors newer than the device
+    bool device_ahead = false;                 // device states newer than the host mirrors
+    bool topo_dirty = true;
+    bool linearized = false;
+    bool pairtab_valid = false;
+    bool stepwise_updated = false;
+    double gn_lambda = -1.0;
+    Plan solve_plan, marg_plan;
+    Plan *active = nullptr;
+    // device buffers independent of the topology
+    DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
+        d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi;
+    DevBuf<int32_t> d_imu_valid;
+    DevBuf<LmState> d_lm;
+    LmState h_lm;
+    vio_exchange_fn hook = nullptr;
+    void *hook_user = nullptr;
+    double hessian_ms = 0;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            c->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                 \
+            return VIO_ERR_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+#define VIOCHK(expr)                                    \
+    do {                                                \
+        vio_status s__ = (expr);                        \
+        if (s__ != VIO_OK) return s__;                  \
+    } while (0)
+
+vio_status fail(vio_ctx *c, vio_status s, const std::string &msg) {
+    c->err = msg;
+    return s;
+}
+
+// ---- topology preprocessing ----------------------------------------------------------------------------
+void build_pattern_tables(Pattern &pt, std::vector<uint32_t> &strips, std::vector<uint32_t> &rows) {
+    const int nb = pt.nb, K = pt.K;
+    int type[VIO_MAXNB], kof[VIO_MAXNB];
+    for (int p = 0; p < nb; ++p) {
+        type[p] = (pt.use_ext && p == 0) ? 0 : (p == pt.host_slot ? 1 : 2);
+        kof[p] = 15;
+    }
+    for (int k = 0; k < K; ++k) kof[pt.tslot[k]] = k;
+    pt.strip_off = (int)strips.size();
+    pt.row_off = (int)rows.size();
+    int ns = 0;
+    for (int p = 0; p < nb; ++p)
+        for (int q = p; q < nb; ++q)
+            for (int i = 0; i < 6; ++i) {
+                const int first = ns;
+                int ncopy = 1;
+                if (type[p] != 2 && type[q] != 2) {
+                    ncopy = K;
+                    for (int cpy = 0; cpy < K; ++cpy) { strips.push_back(STRIP_PACK(p, q, i, cpy, cpy == 0, 0, type[p], type[q])); ++ns; }
+                } else if (type[p] == 2 && type[q] == 2 && p != q) {
+                    strips.push_back(STRIP_PACK(p, q, i, 15, 1, 0, type[p], type[q])); ++ns;
+                } else {
+                    const int k = type[p] == 2 ? kof[p] : kof[q];
+                    strips.push_back(STRIP_PACK(p, q, i, k, 1, 0, type[p], type[q])); ++ns;
+                }
+                rows.push_back((uint32_t)first | ((uint32_t)ncopy << 16));
+            }
+    for (int kind = 1; kind <= 3; ++kind)
+        for (int p = 0; p < nb; ++p) {
+            const int k = type[p] == 2 ? kof[p] : 15;
+            rows.push_back((uint32_t)ns | (1u << 16));
+            strips.push_back(STRIP_PACK(p, 0, 0, k, 0, kind, type[p], 0)); ++ns;
+        }
+    pt.n_strips = ns;
+    pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
+    pt.nsplit = ns < 192 ? 4 : 1;
+    const int REC = pt.use_ext ? 59 : 41, LREC = (12 * nb + 3) | 1;
+    int G = std::max(1, std::min(64, 256 / K));
+    auto lds = [&](int g) { return VIO_MAXK * PAIR_STRIDE + 16 + 256 + g * K * REC + g * LREC + pt.nsplit * ns * 6; };
+    while (G > 1 && lds(G) > LDS_BUDGET_DOUBLES) --G;
+    pt.G = G;
+    pt.lds_doubles = lds(G);
+}
+
+vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
+    pl.valid = false;
+    pl.marg = marg;
+    pl.use_ext = marg ? 1 : (c->cfg.ext_fixed ? 0 : 1);
+    const int64_t N = (int64_t)c->h_invd.size(), M = (int64_t)c->h_olm.size();
+    std::vector<std::vector<int32_t>> obs_of(N);
+    for (int64_t e = 0; e < M; ++e) obs_of[c->h_olm[e]].push_back((int32_t)e);
+    // pattern of each landmark
+    std::map<std::vector<int8_t>, int> pattern_id;
+    pl.patterns.clear(); pl.strips.clear(); pl.rows.clear();
+    std::vector<int32_t> lm_pattern(N, -1);
+    for (int64_t l = 0; l < N; ++l) {
+        const auto &ob = obs_of[l];
+        if (ob.empty()) {
+            if (marg) continue;
+            return fail(c, VIO_ERR_UNSUPPORTED, "landmark without observations (its 1x1 Hessian block would be singular)");
+        }
+        const int h = c->h_ohost[ob[0]];
+        if (marg && h != 0) continue;          // MargOldFrame keeps landmarks hosted in frame 0 only (estimator.cpp:762-764)
+        if ((int)ob.size() > VIO_MAXK) return fail(c, VIO_ERR_UNSUPPORTED, "more than 10 observations of one landmark");
+        std::vector<int8_t> key;
+        key.push_back((int8_t)h);
+        bool seen[NF] = {false};
+        seen[h] = true;
+        for (int32_t e : ob) {
+            if (c->h_ohost[e] != h || c->h_pts_i[2 * e] != c->h_pts_i[2 * ob[0]] || c->h_pts_i[2 * e + 1] != c->h_pts_i[2 * ob[0] + 1])
+                return fail(c, VIO_ERR_UNSUPPORTED, "edges of one landmark must share host frame and host observation");
+            const int t = c->h_otarget[e];
+            if (seen[t]) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
+            seen[t] = true;
+            key.push_back((int8_t)t);
+        }
+        auto itp = pattern_id.find(key);
+        int id;
+        if (itp == pattern_id.end()) {
+            id = (int)pl.patterns.size();
+            pattern_id[key] = id;
+            Pattern pt;
+            std::memset(&pt, 0, sizeof(pt));
+            pt.use_ext = pl.use_ext; pt.host = h; pt.K = (int)ob.size();
+            std::vector<int> frames;
+            for (int f = 0; f < NF; ++f) if (seen[f]) frames.push_back(f);
+            pt.nb = (int)frames.size() + pt.use_ext;
+            int p = 0;
+            if (pt.use_ext) pt.cam_block[p++] = 0;
+            for (int f : frames) { if (f == h) pt.host_slot = p; pt.cam_block[p++] = (int8_t)(1 + f); }
+            for (int k = 0; k < pt.K; ++k) {
+                pt.target[k] = key[1 + k];
+                for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + key[1 + k]) pt.tslot[k] = (int8_t)q;
+            }
+            build_pattern_tables(pt, pl.strips, pl.rows);
+            pl.patterns.push_back(pt);
+        } else id = itp->second;
+        lm_pattern[l] = id;
+    }
+    // sort landmarks by pattern (stable in the original index)
+    pl.sorted_to_orig.clear();
+    for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) pl.sorted_to_orig.push_back((int32_t)l);
+    std::stable_sort(pl.sorted_to_orig.begin(), pl.sorted_to_orig.end(),
+                     [&](int32_t a, int32_t b) { return lm_pattern[a] < lm_pattern[b]; });
+    pl.Ns = (int64_t)pl.sorted_to_orig.size();
+    // items
+    pl.items.clear();
+    std::vector<double> pts_i(2 * std::max<int64_t>(pl.Ns, 1)), pts_j;
+    pl.slab_doubles = 0; pl.lw_doubles = 0; pl.max_lds_doubles = IMU_ITEM_LDS_DOUBLES;
+    int64_t s = 0, obs_base = 0;
+    while (s < pl.Ns) {
+        const int id = lm_pattern[pl.sorted_to_orig[s]];
+        const Pattern &pt = pl.patterns[id];
+        int64_t e = s;
+        while (e < pl.Ns && e - s < pt.G && lm_pattern[pl.sorted_to_orig[e]] == id) ++e;
+        ItemDesc it;
+        std::memset(&it, 0, sizeof(it));
+        it.lm_base = (int32_t)s; it.G = (int32_t)(e - s); it.K = pt.K; it.nb = pt.nb; it.host = pt.host;
+        it.host_slot = pt.host_slot; it.use_ext = pt.use_ext; it.obs_base = (int32_t)obs_base;
+        it.out_base = (int32_t)pl.slab_doubles; it.lw_base = (int32_t)pl.lw_doubles;
+        std::memcpy(it.target, pt.target, sizeof(it.target)); std::memcpy(it.tslot, pt.tslot, sizeof(it.tslot));
+        std::memcpy(it.cam_block, pt.cam_block, sizeof(it.cam_block));
+        it.strip_off = pt.strip_off; it.n_strips = pt.n_strips; it.row_off = pt.row_off; it.n_rows = pt.n_rows;
+        it.nsplit = pt.nsplit; it.lds_doubles = pt.lds_doubles;
+        pl.items.push_back(it);
+        pl.max_lds_doubles = std::max(pl.max_lds_doubles, pt.lds_doubles);
+        pl.slab_doubles += (size_t)item_out_count(pt.nb);
+        pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
+        pl.lw_doubles += (size_t)item_lw_fields(pt.nb) * it.G;
+        pts_j.resize(2 * (obs_base + (int64_t)it.G * it.K));
+        for (int g = 0; g < it.G; ++g) {
+            const int32_t l = pl.sorted_to_orig[s + g];
+            const auto &ob = obs_of[l];
+            pts_i[2 * (s + g)] = c->h_pts_i[2 * ob[0]]; pts_i[2 * (s + g) + 1] = c->h_pts_i[2 * ob[0] + 1];
+            for (int k = 0; k < it.K; ++k) {
+                const int64_t o = obs_base + (int64_t)k * it.G + g;
+                pts_j[2 * o] = c->h_pts_j[2 * ob[k]]; pts_j[2 * o + 1] = c->h_pts_j[2 * ob[k] + 1];
+            }
+        }
+        obs_base += (int64_t)it.G * it.K;
+        s = e;
+    }
+    pl.Ms = obs_base;
+    // inverted lists for k_reduce
+    const int n_lists = VIO_NPAIR + VIO_NCB + 1;
+    std::vector<std::vector<int32_t>> lists(n_lists);
+    for (const ItemDesc &it : pl.items) {
+        for (int p = 0; p < it.nb; ++p) {
+            const int P = it.cam_block[p];
+            for (int q = p; q < it.nb; ++q) {
+                const int Q = it.cam_block[q];
+                const int bidx = P * VIO_NCB - P * (P - 1) / 2 + (Q - P);
+                lists[bidx].push_back(it.out_base + item_pair_index(it.nb, p, q) * 36);
+            }
+            lists[VIO_NPAIR + P].push_back(it.out_base + item_nbp(it.nb) * 36 + p * 6);
+            lists[VIO_NPAIR + P].push_back(it.nb * 6);
+        }
+        lists[n_lists - 1].push_back(it.out_base + it.n_rows * 6);
+    }
+    pl.list_off.assign(n_lists + 1, 0);
+    pl.list.clear();
+    for (int b = 0; b < n_lists; ++b) {
+        pl.list_off[b] = (int32_t)pl.list.size();
+        pl.list.insert(pl.list.end(), lists[b].begin(), lists[b].end());
+    }
+    pl.list_off[n_lists] = (int32_t)pl.list.size();
+    // upload
+    const size_t ni = pl.items.size();
+    HIPCHK(pl.d_items.resize(ni)); HIPCHK(pl.d_strips.resize(pl.strips.size())); HIPCHK(pl.d_rows.resize(pl.rows.size()));
+    HIPCHK(pl.d_list_off.resize(pl.list_off.size())); HIPCHK(pl.d_list.resize(pl.list.size()));
+    HIPCHK(pl.d_pts_i.resize(2 * (size_t)pl.Ns)); HIPCHK(pl.d_pts_j.resize(2 * (size_t)pl.Ms));
+    HIPCHK(pl.d_invd.resize(2 * (size_t)std::max<int64_t>(pl.Ns, 1))); HIPCHK(pl.d_slab.resize(pl.slab_doubles));
+    HIPCHK(pl.d_lw.resize(pl.lw_doubles)); HIPCHK(pl.d_dxl.resize((size_t)pl.Ns));
+    HIPCHK(pl.d_step_part.resize(2 * (ni + VIO_WINDOW_SIZE)));
+    hipStream_t st = c->stream;
+    if (ni) HIPCHK(hipMemcpyAsync(pl.d_items.p, pl.items.data(), ni * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
+    if (!pl.strips.empty()) HIPCHK(hipMemcpyAsync(pl.d_strips.p, pl.strips.data(), pl.strips.size() * 4, hipMemcpyHostToDevice, st));
+    if (!pl.rows.empty()) HIPCHK(hipMemcpyAsync(pl.d_rows.p, pl.rows.data(), pl.rows.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(pl.d_list_off.p, pl.list_off.data(), pl.list_off.size() * 4, hipMemcpyHostToDevice, st));
+    if (!pl.list.empty()) HIPCHK(hipMemcpyAsync(pl.d_list.p, pl.list.data(), pl.list.size() * 4, hipMemcpyHostToDevice, st));
+    if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i.data(), 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
+    if (pl.Ms) HIPCHK(hipMemcpyAsync(pl.d_pts_j.p, pts_j.data(), 2 * (size_t)pl.Ms * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    pl.valid = true;
+    return VIO_OK;
+}
+
+// ---- device state management ---------------------------------------------------------------------------
+vio_status alloc_fixed(vio_ctx *c) {
+    HIPCHK(c->d_state.resize(2 * STATE_STRIDE)); HIPCHK(c->d_pairtab.resize(2 * PAIRTAB_STRIDE));
+    HIPCHK(c->d_vis.resize(VIS_COUNT)); HIPCHK(c->d_pre.resize(VIO_WINDOW_SIZE * PRE_STRIDE));
+    HIPCHK(c->d_imu_out.resize(VIO_WINDOW_SIZE * IMU_OUT)); HIPCHK(c->d_Hprior.resize(PD * PD));
+    HIPCHK(c->d_bprior.resize(2 * 176)); HIPCHK(c->d_errprior.resize(2 * 160)); HIPCHK(c->d_Jtinv.resize(PRD * PRD));
+    HIPCHK(c->d_Hs.resize(PD * PD)); HIPCHK(c->d_bs.resize(176)); HIPCHK(c->d_bfull.resize(176));
+    HIPCHK(c->d_diagfull.resize(176)); HIPCHK(c->d_dx.resize(176)); HIPCHK(c->d_step_tot.resize(8));
+    HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
+    HIPCHK(hipMemsetAsync(c->d_vis.p, 0, VIS_COUNT * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_step_tot.p, 0, 8 * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_dx.p, 0, 176 * 8, c->stream));
+    return VIO_OK;
+}
+
+DeviceTables make_tables(vio_ctx *c, Plan &pl) {
+    DeviceTables T;
+    std::memset(&T, 0, sizeof(T));
+    T.items = pl.d_items.p; T.n_items = (int32_t)pl.items.size(); T.n_imu_items = VIO_WINDOW_SIZE;
+    T.Ns = (int32_t)pl.Ns; T.ext_fixed = c->cfg.ext_fixed; T.loss_type = c->cfg.loss_type; T.marg_mode = pl.marg;
+    T.loss_delta = c->cfg.loss_delta; T.sqrt_info = c->cfg.reproj_sqrt_info;
+    for (int k = 0; k < 3; ++k) T.gravity[k] = c->cfg.gravity[k];
+    T.state = c->d_state.p; T.invd = pl.d_invd.p; T.pts_i = pl.d_pts_i.p; T.pts_j = pl.d_pts_j.p;
+    T.pairtab = c->d_pairtab.p; T.slab = pl.d_slab.p; T.lw = pl.d_lw.p; T.vis = c->d_vis.p; T.pre = c->d_pre.p;
+    T.imu_valid = c->d_imu_valid.p; T.imu_out = c->d_imu_out.p; T.imu_chi_try = c->d_imu_chi.p;
+    T.strips = pl.d_strips.p; T.rows = pl.d_rows.p; T.pair_slot = nullptr; T.blk_slot = nullptr;
+    T.Hprior = c->d_Hprior.p; T.bprior = c->d_bprior.p; T.errprior = c->d_errprior.p; T.Jtinv = c->d_Jtinv.p;
+    // Problem always carries a 171x171 prior block (zero before the first marginalisation); err_prior_ exists
+    // only once a prior has been set (problem.cc:466,505,554)
+    T.has_prior = c->has_prior; T.add_imu_prior = 1;
+    T.Hs = c->d_Hs.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
+    T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
+    T.step_tot = c->d_step_tot.p; T.lm = c->d_lm.p;
+    return T;
+}
+
+vio_status read_lm(vio_ctx *c) {
+    HIPCHK(hipMemcpyAsync(&c->h_lm, c->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VIO_OK;
+}
+
+// bring the host mirrors up to date with the device (states, inverse depths, prior vectors)
+vio_status pull_from_device(vio_ctx *c) {
+    if (!c->device_ahead) return VIO_OK;
+    VIOCHK(read_lm(c));
+    const int cur = c->h_lm.cur;
+    HIPCHK(hipMemcpyAsync(c->h_state, c->d_state.p + cur * STATE_STRIDE, STATE_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
+    Plan &pl = c->solve_plan;
+    std::vector<double> tmp((size_t)std::max<int64_t>(pl.Ns, 1));
+    if (pl.valid && pl.Ns)
+        HIPCHK(hipMemcpyAsync(tmp.data(), pl.d_invd.p + (size_t)cur * pl.Ns, (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
+    if (c->has_prior) {
+        HIPCHK(hipMemcpyAsync(c->h_bprior.data(), c->d_bprior.p + cur * 176, PD * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_errprior.data(), c->d_errprior.p + cur * 160, PRD * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (pl.valid)
+        for (int64_t s = 0; s < pl.Ns; ++s) c->h_invd[pl.sorted_to_orig[s]] = tmp[s];
+    c->device_ahead = false;
+    return VIO_OK;
+}
+
+// upload the host mirrors into copy 0 and reset the LM state
+vio_status push_to_device(vio_ctx *c, Plan &pl) {
+    hipStream_t st = c->stream;
+    HIPCHK(hipMemcpyAsync(c->d_state.p, c->h_state, STATE_STRIDE * 8, hipMemcpyHostToDevice, st));
+    std::vector<double> tmp((size_t)std::max<int64_t>(pl.Ns, 1));
+    for (int64_t s = 0; s < pl.Ns; ++s) tmp[s] = c->h_invd[pl.sorted_to_orig[s]];
+    if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_invd.p, tmp.data(), (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_pre.p, c->h_pre.data(), VIO_WINDOW_SIZE * PRE_STRIDE * 8, hipMemcpyHostToDevice, st));
+    int32_t iv[16] = {0};
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) iv[k] = c->imu_valid[k] ? 1 : 0;
+    HIPCHK(hipMemcpyAsync(c->d_imu_valid.p, iv, sizeof(iv), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_Hprior.p, c->h_Hprior.data(), PD * PD * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_bprior.p, c->h_bprior.data(), PD * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_errprior.p, c->h_errprior.data(), PRD * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_Jtinv.p, c->h_Jtinv.data(), PRD * PRD * 8, hipMemcpyHostToDevice, st));
+    std::memset(&c->h_lm, 0, sizeof(LmState));
+    c->h_lm.ni = 2; c->h_lm.lambda = -1; c->h_lm.finite = 1; c->h_lm.last_chi = 1e20;
+    HIPCHK(hipMemcpyAsync(c->d_lm.p, &c->h_lm, sizeof(LmState), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));      // the staging vectors above go out of scope
+    return VIO_OK;
+}
+
+// make `pl` the active plan with the host mirrors uploaded
+vio_status activate(vio_ctx *c, Plan &pl, int marg) {
+    const bool need_build = !pl.valid || c->topo_dirty;
+    const bool switching = c->active != &pl;
+    if (need_build || switching || c->dirty_inputs) {
+        VIOCHK(pull_from_device(c));
+        if (need_build) {
+            if (c->topo_dirty) { c->solve_plan.valid = false; c->marg_plan.valid = false; c->topo_dirty = false; }
+            VIOCHK(build_plan(c, pl, marg));
+        }
+        VIOCHK(push_to_device(c, pl));
+        c->active = &pl;
+        c->dirty_inputs = false;
+        c->linearized = false;
+        c->pairtab_valid = false;
+        c->stepwise_updated = false;
+        c->gn_lambda = -1.0;
+    }
+    return VIO_OK;
+}
+
+vio_status run_exchange(vio_ctx *c, int which) {
+    if (!c->hook) return VIO_OK;
+    if (c->hook(c->hook_user, which) != 0) return fail(c, VIO_ERR_HIP, "exchange hook failed");
+    return VIO_OK;
+}
+
+// prepare (if needed) + linearize + reduce + [exchange] + assemble at the current state
+vio_status enqueue_linearize(vio_ctx *c, Plan &pl) {
+    DeviceTables T = make_tables(c, pl);
+    if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
+    vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream);
+    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, c->d_vis.p};
+    vio_launch_reduce(R, c->stream);
+    VIOCHK(run_exchange(c, 0));
+    vio_launch_assemble(T, c->stream);
+    HIPCHK(hipGetLastError());
+    c->linearized = true;
+    return VIO_OK;
+}
+
+vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode) {
+    DeviceTables T = make_tables(c, pl);
+    vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream);
+    vio_launch_backsub(T, 0, c->stream);
+    if (c->hook) {
+        vio_launch_step_sum(T, c->stream);
+        VIOCHK(run_exchange(c, 1));
+        vio_launch_lm_decide(T, mode, 0, c->stream);
+    } else {
+        vio_launch_lm_decide(T, mode, 1, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    c->device_ahead = true;
+    return VIO_OK;
+}
+
+}  // namespace
+
+// =========================================================================================================
+extern "C" {
+
+void vio_default_config(vio_config *cfg) {
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->device = 0;
+    cfg->ext_fixed = 1;                        // estimate_extrinsic: 0 (VM/config/vio_simulation.yaml:25)
+    cfg->loss_type = VIO_LOSS_CAUCHY;          // CauchyLoss(1.0), estimator.cpp:905
+    cfg->loss_delta = 1.0;
+    cfg->reproj_sqrt_info = 460.0 / 1.5;       // estimator.cpp:42
+    cfg->gravity[2] = 9.81;                    // g_norm (vio_simulation.yaml:79)
+    cfg->shard_rank = 0;
+    cfg->shard_count = 1;
+}
+
+vio_status vio_create(const vio_config *cfg, vio_ctx **out) {
+    if (!cfg || !out) return VIO_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VIO_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return VIO_ERR_BAD_ARG;
+    if (hipSetDevice(cfg->device) != hipSuccess) return VIO_ERR_HIP;
+    vio_ctx *c = new vio_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
+    if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VIO_ERR_HIP; }
+        c->own_stream = true;
+    }
+    std::memset(c->h_state, 0, sizeof(c->h_state));
+    c->h_state[STATE_EXT + 6] = 1.0;
+    for (int i = 0; i < NF; ++i) c->h_state[STATE_POSE + 7 * i + 6] = 1.0;
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) c->imu_valid[k] = false;
+    c->h_pre.assign(VIO_WINDOW_SIZE * PRE_STRIDE, 0.0);
+    c->h_Hprior.assign(PD * PD, 0.0); c->h_bprior.assign(PD, 0.0); c->h_errprior.assign(PRD, 0.0); c->h_Jtinv.assign(PRD * PRD, 0.0);
+    if (vio_set_kernel_attributes() != 0) { c->err = "hipFuncSetAttribute failed"; }
+    vio_status s = alloc_fixed(c);
+    if (s != VIO_OK) { vio_destroy(c); return s; }
+    *out = c;
+    return VIO_OK;
+}
+
+void vio_destroy(vio_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    hipStreamSynchronize(c->stream);
+    c->solve_plan.release(); c->marg_plan.release();
+    c->d_state.release(); c->d_pairtab.release(); c->d_vis.release(); c->d_pre.release(); c->d_imu_out.release();
+    c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
+    c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
+    c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release();
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *vio_last_error(const vio_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+vio_status vio_set_window(vio_ctx *c, const double *poses, const double *sb, const double *ext) {
+    if (!c || !poses || !sb || !ext) return VIO_ERR_BAD_ARG;
+    VIOCHK(pull_from_device(c));
+    std::memcpy(c->h_state + STATE_EXT, ext, 7 * 8);
+    std::memcpy(c->h_state + STATE_POSE, poses, 77 * 8);
+    std::memcpy(c->h_state + STATE_SB, sb, 99 * 8);
+    c->dirty_inputs = true;
+    return VIO_OK;
+}
+
+vio_status vio_set_landmarks(vio_ctx *c, int64_t n, const double *invd) {
+    if (!c || n < 0 || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+    VIOCHK(pull_from_device(c));
+    const bool resized = (int64_t)c->h_invd.size() != n;
+    c->h_invd.assign(invd, invd + n);
+    if (resized) {      // the observation list refers to landmark indices: it must be set again
+        c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear();
+        c->topo_dirty = true;
+    }
+    c->dirty_inputs = true;
+    return VIO_OK;
+}
+
+vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target,
+                                const double *pi, const double *pj) {
+    if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
+    const int64_t N = (int64_t)c->h_invd.size();
+    for (int64_t e = 0; e < m; ++e)
+        if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
+            return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
+    VIOCHK(pull_from_device(c));
+    c->h_olm.assign(lm, lm + m); c->h_ohost.assign(host, host + m); c->h_otarget.assign(target, target + m);
+    c->h_pts_i.assign(pi, pi + 2 * m); c->h_pts_j.assign(pj, pj + 2 * m);
+    c->topo_dirty = true;
+    c->dirty_inputs = true;
+    return VIO_OK;
+}
+
+vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
+    if (!c || k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
+    VIOCHK(pull_from_device(c));
+    c->imu_valid[k] = pre != nullptr;
+    double *o = c->h_pre.data() + (size_t)k * PRE_STRIDE;
+    if (pre) {
+        o[PRE_SUMDT] = pre->sum_dt;
+        for (int i = 0; i < 3; ++i) { o[PRE_DP + i] = pre->delta_p[i]; o[PRE_DV + i] = pre->delta_v[i]; o[PRE_BA + i] = pre->linearized_ba[i]; o[PRE_BG + i] = pre->linearized_bg[i]; }
+        for (int i = 0; i < 4; ++i) o[PRE_DQ + i] = pre->delta_q[i];
+        std::memcpy(o + PRE_JAC, pre->jacobian, 225 * 8);
+        vio_host::inverse15(pre->covariance, o + PRE_INFO);     // SetInformation(covariance.inverse()), edge_imu.cc:35
+    }
+    c->dirty_inputs = true;
+    return VIO_OK;
+}
+
+vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double *b, const double *err, const double *jt) {
+    if (!c || (dim != 0 && dim != PRD)) return VIO_ERR_BAD_ARG;
+    if (dim && (!H || !b || !err || !jt)) return VIO_ERR_BAD_ARG;
+    VIOCHK(pull_from_device(c));
+    std::fill(c->h_Hprior.begin(), c->h_Hprior.end(), 0.0); std::fill(c->h_bprior.begin(), c->h_bprior.end(), 0.0);
+    std::fill(c->h_errprior.begin(), c->h_errprior.end(), 0.0); std::fill(c->h_Jtinv.begin(), c->h_Jtinv.end(), 0.0);
+    c->has_prior = dim ? 1 : 0;
+    if (dim) {      // ExtendHessiansPriorSize(15): 15 zero rows/cols appended (problem.cc:82-91)
+        for (int i = 0; i < PRD; ++i) { std::memcpy(&c->h_Hprior[(size_t)i * PD], &H[(size_t)i * PRD], PRD * 8); c->h_bprior[i] = b[i]; }
+        std::memcpy(c->h_errprior.data(), err, PRD * 8);
+        std::memcpy(c->h_Jtinv.data(), jt, (size_t)PRD * PRD * 8);
+    }
+    c->dirty_inputs = true;
+    return VIO_OK;
+}
+
+vio_status vio_linearize(vio_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
+    VIOCHK(activate(c, c->solve_plan, 0));
+    if (c->stepwise_updated) c->stepwise_updated = false;     // a new linearisation commits the step
+    VIOCHK(enqueue_linearize(c, c->solve_plan));
+    return VIO_OK;
+}
+
+vio_status vio_init_lm(vio_ctx *c, double *chi2, double *lambda) {
+    if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    DeviceTables T = make_tables(c, *c->active);
+    vio_launch_init_lm(T, 1 << 30, c->stream);
+    VIOCHK(read_lm(c));
+    if (chi2) *chi2 = c->h_lm.chi;
+    if (lambda) *lambda = c->h_lm.lambda;
+    return VIO_OK;
+}
+
+vio_status vio_solve_linear(vio_ctx *c, double lambda) {
+    if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    Plan &pl = *c->active;
+    DeviceTables T = make_tables(c, pl);
+    vio_launch_set_lambda(c->d_lm.p, lambda, c->stream);
+    vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream);
+    vio_launch_backsub(T, 0, c->stream);
+    if (c->hook) { vio_launch_step_sum(T, c->stream); VIOCHK(run_exchange(c, 1)); }
+    HIPCHK(hipGetLastError());
+    c->stepwise_updated = false;
+    return VIO_OK;
+}
+
+vio_status vio_update_states(vio_ctx *c) {
+    if (!c || !c->active) return VIO_ERR_BAD_ARG;
+    if (!c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = true; c->device_ahead = true; }
+    return VIO_OK;
+}
+
+vio_status vio_rollback_states(vio_ctx *c) {
+    if (!c || !c->active) return VIO_ERR_BAD_ARG;
+    if (c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = false; c->device_ahead = true; }
+    return VIO_OK;
+}
+
+vio_status vio_chi2(vio_ctx *c, double *chi2) {
+    if (!c || !chi2) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
+    VIOCHK(activate(c, c->solve_plan, 0));
+    Plan &pl = *c->active;
+    DeviceTables T = make_tables(c, pl);
+    // the chi2 kernels read the pair table of the current state; after a stepwise update it is the trial table
+    if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
+    vio_launch_backsub(T, 1, c->stream);
+    if (c->hook) { vio_launch_step_sum(T, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 2, 0, c->stream); }
+    else vio_launch_lm_decide(T, 2, 1, c->stream);
+    VIOCHK(read_lm(c));
+    *chi2 = c->h_lm.chi_try;
+    return VIO_OK;
+}
+
+vio_status vio_eval_step(vio_ctx *c, int32_t *accepted, double *chi2, double *lambda) {
+    if (!c || !c->active) return VIO_ERR_BAD_ARG;
+    Plan &pl = *c->active;
+    DeviceTables T = make_tables(c, pl);
+    // the decide kernel expects the trial copy to be "the other one"
+    if (c->stepwise_updated) vio_launch_flip(c->d_lm.p, c->stream);
+    if (c->hook) vio_launch_lm_decide(T, 0, 0, c->stream); else vio_launch_lm_decide(T, 0, 1, c->stream);
+    VIOCHK(read_lm(c));
+    const bool ok = c->h_lm.accepted != 0;
+    if (ok) {
+        c->stepwise_updated = false;           // the trial copy is current now; nothing left to roll back to
+    } else if (c->stepwise_updated) {
+        vio_launch_flip(c->d_lm.p, c->stream);  // stay on the updated states until the caller rolls back (problem.cc:228-231)
+    }
+    c->device_ahead = true;
+    if (accepted) *accepted = ok ? 1 : 0;
+    if (chi2) *chi2 = c->h_lm.chi;
+    if (lambda) *lambda = c->h_lm.lambda;
+    return VIO_OK;
+}
+
+vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
+    bool any_imu = false;
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) any_imu |= c->imu_valid[k];
+    if (c->h_olm.empty() && !any_imu) return fail(c, VIO_ERR_EMPTY, "Cannot solve problem without edges or verticies");
+    const auto t0 = std::chrono::steady_clock::now();
+    VIOCHK(activate(c, c->solve_plan, 0));
+    Plan &pl = c->solve_plan;
+    hipEvent_t ev0, ev1;
+    HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+    double hess_ms = 0;
+    auto timed_linearize = [&]() -> vio_status {
+        HIPCHK(hipEventRecord(ev0, c->stream));
+        VIOCHK(enqueue_linearize(c, pl));
+        HIPCHK(hipEventRecord(ev1, c->stream));
+        return VIO_OK;
+    };
+    VIOCHK(timed_linearize());
+    DeviceTables T = make_tables(c, pl);
+    vio_launch_init_lm(T, iterations, c->stream);
+    VIOCHK(read_lm(c));
+    { float ms = 0; hipEventElapsedTime(&ms, ev0, ev1); hess_ms += ms; }
+    vio_solve_report r;
+    std::memset(&r, 0, sizeof(r));
+    r.initial_chi2 = c->h_lm.chi;
+    vio_status status = VIO_OK;
+    while (!c->h_lm.stop && c->h_lm.iter < iterations) {
+        status = enqueue_trial(c, pl, 0);
+        if (status != VIO_OK) break;
+        status = read_lm(c);
+        if (status != VIO_OK) break;
+        if (c->h_lm.accepted && !c->h_lm.stop) {
+            status = timed_linearize();
+            if (status != VIO_OK) break;
+            HIPCHK(hipEventSynchronize(ev1));
+            float ms = 0; hipEventElapsedTime(&ms, ev0, ev1); hess_ms += ms;
+        }
+    }
+    hipEventDestroy(ev0); hipEventDestroy(ev1);
+    if (status != VIO_OK) return status;
+    if (c->h_lm.accepted && c->h_lm.stop) c->linearized = false;   // the reference re-linearises here; nobody reads it
+    r.iterations = c->h_lm.iter; r.trials = c->h_lm.trials; r.accepted = c->h_lm.naccepted;
+    r.stop_reason = c->h_lm.stop_reason;
+    r.final_chi2 = c->h_lm.chi; r.final_lambda = c->h_lm.lambda;
+    for (int i = 0; i < 128; ++i) { r.chi2_trace[i] = c->h_lm.chi_trace[i]; r.lambda_trace[i] = c->h_lm.lambda_trace[i]; }
+    r.hessian_ms = hess_ms;
+    r.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rep) *rep = r;
+    return c->h_lm.finite ? VIO_OK : VIO_ERR_NOT_FINITE;
+}
+
+vio_status vio_gn_iteration(vio_ctx *c, double lambda) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    VIOCHK(activate(c, c->solve_plan, 0));
+    Plan &pl = c->solve_plan;
+    if (lambda != c->gn_lambda) { vio_launch_set_lambda(c->d_lm.p, lambda, c->stream); c->gn_lambda = lambda; }
+    VIOCHK(enqueue_linearize(c, pl));
+    VIOCHK(enqueue_trial(c, pl, 1));
+    return VIO_OK;
+}
+
+vio_status vio_synchronize(vio_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VIO_OK;
+}
+
+vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, double *err, double *jt) {
+    if (!c || !H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
+    if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
+    std::vector<double> Hm((size_t)PD * PD), bm(PD);
+    if (kind == VIO_MARG_OLD) {
+        VIOCHK(activate(c, c->marg_plan, 1));
+        VIOCHK(enqueue_linearize(c, c->marg_plan));
+        HIPCHK(hipMemcpyAsync(Hm.data(), c->d_Hs.p, (size_t)PD * PD * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(bm.data(), c->d_bs.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        c->linearized = false;
+    } else {
+        // MargNewFrame builds a graph without edges (estimator.cpp:830-901): H_marg is the prior alone
+        VIOCHK(pull_from_device(c));
+        Hm = c->h_Hprior;
+        bm = c->h_bprior;
+    }
+    vio_host::marginalize_tail(Hm.data(), bm.data(), kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, H, b, err, jt);
+    return VIO_OK;
+}
+
+vio_status vio_get_window(vio_ctx *c, double *poses, double *sb, double *ext) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    VIOCHK(pull_from_device(c));
+    if (ext) std::memcpy(ext, c->h_state + STATE_EXT, 7 * 8);
+    if (poses) std::memcpy(poses, c->h_state + STATE_POSE, 77 * 8);
+    if (sb) std::memcpy(sb, c->h_state + STATE_SB, 99 * 8);
+    return VIO_OK;
+}
+
+vio_status vio_get_landmarks(vio_ctx *c, int64_t n, double *invd) {
+    if (!c || n != (int64_t)c->h_invd.size() || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+    VIOCHK(pull_from_device(c));
+    if (n) std::memcpy(invd, c->h_invd.data(), (size_t)n * 8);
+    return VIO_OK;
+}
+
+vio_status vio_get_prior(vio_ctx *c, double *b, double *err) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    VIOCHK(pull_from_device(c));
+    if (b) std::memcpy(b, c->h_bprior.data(), PD * 8);
+    if (err) std::memcpy(err, c->h_errprior.data(), PRD * 8);
+    return VIO_OK;
+}
+
+vio_status vio_get_delta(vio_ctx *c, double *dxp, int64_t n, double *dxl) {
+    if (!c || !c->active) return VIO_ERR_BAD_ARG;
+    if (dxl && n != (int64_t)c->h_invd.size()) return VIO_ERR_BAD_ARG;
+    Plan &pl = *c->active;
+    if (dxp) HIPCHK(hipMemcpyAsync(dxp, c->d_dx.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> tmp((size_t)std::max<int64_t>(pl.Ns, 1));
+    if (dxl && pl.Ns) HIPCHK(hipMemcpyAsync(tmp.data(), pl.d_dxl.p, (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (dxl) {
+        for (int64_t l = 0; l < n; ++l) dxl[l] = 0.0;
+        for (int64_t s = 0; s < pl.Ns; ++s) dxl[pl.sorted_to_orig[s]] = tmp[s];
+    }
+    return VIO_OK;
+}
+
+vio_status vio_get_schur_system(vio_ctx *c, double *H, double *b) {
+    if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    if (H) HIPCHK(hipMemcpyAsync(H, c->d_Hs.p, (size_t)PD * PD * 8, hipMemcpyDeviceToHost, c->stream));
+    if (b) HIPCHK(hipMemcpyAsync(b, c->d_bs.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VIO_OK;
+}
+
+vio_status vio_get_landmark_system(vio_ctx *c, int64_t n, double *hll, double *bl) {
+    if (!c || !c->linearized || n != (int64_t)c->h_invd.size()) return VIO_ERR_BAD_ARG;
+    Plan &pl = *c->active;
+    std::vector<double> lw(std::max<size_t>(pl.lw_doubles, 1));
+    if (pl.lw_doubles) HIPCHK(hipMemcpyAsync(lw.data(), pl.d_lw.p, pl.lw_doubles * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t l = 0; l < n; ++l) { if (hll) hll[l] = 0; if (bl) bl[l] = 0; }
+    for (const ItemDesc &it : pl.items)
+        for (int g = 0; g < it.G; ++g) {
+            const int32_t l = pl.sorted_to_orig[it.lm_base + g];
+            if (hll) hll[l] = lw[(size_t)it.lw_base + (size_t)(6 * it.nb) * it.G + g];
+            if (bl) bl[l] = lw[(size_t)it.lw_base + (size_t)(6 * it.nb + 1) * it.G + g];
+        }
+    return VIO_OK;
+}
+
+vio_status vio_get_pose_gradient(vio_ctx *c, double *b, double *diag) {
+    if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    if (b) HIPCHK(hipMemcpyAsync(b, c->d_bfull.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
+    if (diag) HIPCHK(hipMemcpyAsync(diag, c->d_diagfull.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return VIO_OK;
+}
+
+vio_status vio_exchange_buffers(vio_ctx *c, void **reduced, int64_t *n_reduced, void **scalars, int64_t *n_scalars) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (reduced) *reduced = c->d_vis.p;
+    if (n_reduced) *n_reduced = VIS_MAXH;       // everything before the max-|h_ll| slot is summed across shards
+    if (scalars) *scalars = c->d_step_tot.p;
+    if (n_scalars) *n_scalars = 2;
+    return VIO_OK;
+}
+
+vio_status vio_set_exchange_hook(vio_ctx *c, vio_exchange_fn fn, void *user) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    c->hook = fn;
+    c->hook_user = user;
+    return VIO_OK;
+}
+
+}  // extern "C"

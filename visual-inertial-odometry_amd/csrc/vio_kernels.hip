@@ -1,0 +1,1091 @@
+// vio_kernels.hip — hand-written gfx950 kernels of the sliding-window VIO backend.
+//
+// One Levenberg-Marquardt trial of the reference (Problem::Solve, VM/src/backend/problem.cc:169-250) maps to
+//
+//   k_linearize   MakeHessian (problem.cc:303-389) for all reprojection edges (edge_reprojection.cc:18-109,
+//                 edge.cc:48-74) + the per-landmark Schur terms of SolveLinearSystem (problem.cc:412-429),
+//                 one workgroup per item (<= 64 landmarks sharing a (host, targets) pattern); IMU edges
+//                 (edge_imu.cc:13-156, integration_base.h:160-186) ride in the same grid
+//   k_reduce      fixed-order sum of the per-item partial blocks -> 72x72 reduced visual system
+//   k_assemble    + IMU blocks + prior (problem.cc:365-384) -> H_pp_schur_, b_pp_schur_ (171)
+//   k_pose_solve  + lambda (problem.cc:434-436), pivoted LDLT (Eigen LDLT, problem.cc:439), pose update
+//                 (UpdateStates :453-480, vertex_pose.cc:7-19), prior first-order update (:473-474)
+//   k_backsub     landmark back-substitution (problem.cc:445), landmark update, chi2 of the trial state
+//                 (IsGoodStepInLM :549-556)
+//   k_lm_decide   gain ratio + Nielsen update + accept/rollback (IsGoodStepInLM :541-573, Solve :188-245)
+//
+// All arithmetic is fp64.  Every reduction has a fixed order (no float atomics), so results are bitwise
+// reproducible run to run.  wave = 64 lanes; workgroups of 256 threads (4 waves) except the 1024-thread
+// single-workgroup dense solve.
+#include <hip/hip_runtime.h>
+
+#include "vio_device_math.h"
+#include "vio_types.h"
+
+#define LIN_THREADS 256
+
+__device__ __forceinline__ int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
+// inverse: -1 when the full index is a speed-bias dimension
+__device__ __forceinline__ int full_to_cam(int i) {
+    if (i < 6) return i;
+    const int f = (i - 6) / 15, o = (i - 6) % 15;
+    return o < 6 ? 6 + 6 * f + o : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pair table: for every ordered frame pair (h,t) the composed maps of the reprojection chain
+//   p_cj = C * p_ci + d   with C = ric^T Rt^T Rh ric,  d = ric^T (Rt^T (Rh tic + Ph - Pt) - tic)
+// (edge_reprojection.cc:35-40 evaluated once per pair instead of once per edge)
+// ---------------------------------------------------------------------------------------------------------
+__device__ void d_build_pairtab(const double *st, double *tab, double *sR, int tid, int nt) {
+    if (tid < 12) {
+        const double *q = (tid == 0) ? st + STATE_EXT + 3 : st + STATE_POSE + 7 * (tid - 1) + 3;
+        d_quat_to_R(q, sR + 9 * tid);
+    }
+    __syncthreads();
+    const double *ric = sR;
+    const double *tic = st + STATE_EXT;
+    for (int pr = tid; pr < 121; pr += nt) {
+        const int h = pr / 11, t = pr % 11;
+        if (h == t) continue;
+        const double *Rh = sR + 9 * (1 + h), *Rt = sR + 9 * (1 + t);
+        const double *Ph = st + STATE_POSE + 7 * h, *Pt = st + STATE_POSE + 7 * t;
+        double M[9], A[9], B[9], C[9], u[3], w[3], d[3], RtRh[9], El[9];
+        d_m3_mul(Rt, ric, M);                   // A = ric^T Rt^T = (Rt ric)^T
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) A[3 * i + j] = M[3 * j + i];
+        d_m3_mul(A, Rh, B);
+        d_m3_mul(B, ric, C);
+        d_m3_vec(Rh, tic, u);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u[k] = u[k] + Ph[k] - Pt[k];
+        d_m3_tvec(Rt, u, w);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[k] -= tic[k];
+        d_m3_tvec(ric, w, d);
+        d_m3_tmul(Rt, Rh, RtRh);
+        RtRh[0] -= 1; RtRh[4] -= 1; RtRh[8] -= 1;
+        d_m3_tmul(ric, RtRh, El);
+        double *o = tab + pr * PAIR_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { o[PAIR_A + k] = A[k]; o[PAIR_B + k] = B[k]; o[PAIR_C + k] = C[k]; o[PAIR_EL + k] = El[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[PAIR_D + k] = d[k];
+    }
+    if (tid < 9) tab[121 * PAIR_STRIDE + CAMTAB_RIC + tid] = ric[tid];
+    if (tid < 3) tab[121 * PAIR_STRIDE + CAMTAB_TIC + tid] = tic[tid];
+}
+
+__global__ __launch_bounds__(128) void k_prepare(DeviceTables T) {
+    __shared__ double sR[12 * 9];
+    const int cur = T.lm->cur;
+    d_build_pairtab(T.state + cur * STATE_STRIDE, T.pairtab + cur * PAIRTAB_STRIDE, sR, threadIdx.x, blockDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// IMU factor (one workgroup per edge, appended to the linearize grid)
+// ---------------------------------------------------------------------------------------------------------
+#define O_P 0
+#define O_R 3
+#define O_V 6
+#define O_BA 9
+#define O_BG 12
+
+struct ImuCommon {
+    dquat Qi, Qj, Qi_inv, dq, cdq;
+    double sum_dt;
+    double dba[3], dbg[3];
+};
+
+__device__ __forceinline__ void d_skew(const double *v, double *S) {
+    S[0] = 0; S[1] = -v[2]; S[2] = v[1]; S[3] = v[2]; S[4] = 0; S[5] = -v[0]; S[6] = -v[1]; S[7] = v[0]; S[8] = 0;
+}
+__device__ __forceinline__ void d_qleft_br(dquat q, double *B) {      // Utility::Qleft bottom-right 3x3 (utility.h:48-56)
+    double v[3] = {q.x, q.y, q.z};
+    d_skew(v, B);
+    B[0] += q.w; B[4] += q.w; B[8] += q.w;
+}
+__device__ __forceinline__ void d_qright_br(dquat q, double *B) {     // Utility::Qright bottom-right 3x3 (utility.h:58-66)
+    double v[3] = {q.x, q.y, q.z}, S[9];
+    d_skew(v, S);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) B[k] = -S[k];
+    B[0] += q.w; B[4] += q.w; B[8] += q.w;
+}
+
+__device__ void d_imu_common(const double *pre, const double *pi, const double *si, const double *pj, ImuCommon &c) {
+    c.Qi = d_qload(pi); c.Qj = d_qload(pj);
+    c.Qi_inv = d_qinv(c.Qi);
+    c.sum_dt = pre[PRE_SUMDT];
+    c.dq.x = pre[PRE_DQ]; c.dq.y = pre[PRE_DQ + 1]; c.dq.z = pre[PRE_DQ + 2]; c.dq.w = pre[PRE_DQ + 3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { c.dba[k] = si[3 + k] - pre[PRE_BA + k]; c.dbg[k] = si[6 + k] - pre[PRE_BG + k]; }
+    const double *Jm = pre + PRE_JAC;
+    double th[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        th[i] = Jm[15 * (O_R + i) + O_BG] * c.dbg[0] + Jm[15 * (O_R + i) + O_BG + 1] * c.dbg[1] + Jm[15 * (O_R + i) + O_BG + 2] * c.dbg[2];
+    dquat dth = {th[0] / 2.0, th[1] / 2.0, th[2] / 2.0, 1.0};      // Utility::deltaQ, not normalised
+    c.cdq = d_qmul(c.dq, dth);
+}
+
+// IntegrationBase::evaluate (integration_base.h:160-186)
+__device__ void d_imu_residual(const double *pre, const double *G, const double *pi, const double *si, const double *pj,
+                               const double *sj, const ImuCommon &c, double *res) {
+    const double *Jm = pre + PRE_JAC;
+    const double sum_dt = c.sum_dt;
+    double cdp[3], cdv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double a = 0, b = 0, e = 0, f = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            a += Jm[15 * (O_V + i) + O_BA + j] * c.dba[j];
+            b += Jm[15 * (O_V + i) + O_BG + j] * c.dbg[j];
+            e += Jm[15 * (O_P + i) + O_BA + j] * c.dba[j];
+            f += Jm[15 * (O_P + i) + O_BG + j] * c.dbg[j];
+        }
+        cdv[i] = pre[PRE_DV + i] + a + b;
+        cdp[i] = pre[PRE_DP + i] + e + f;
+    }
+    double t[3], u[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = 0.5 * G[k] * sum_dt * sum_dt + pj[k] - pi[k] - si[k] * sum_dt;
+    d_qrot(c.Qi_inv, t, u);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) res[O_P + k] = u[k] - cdp[k];
+    dquat qe = d_qmul(d_qinv(c.cdq), d_qmul(c.Qi_inv, c.Qj));
+    res[O_R] = 2 * qe.x; res[O_R + 1] = 2 * qe.y; res[O_R + 2] = 2 * qe.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = G[k] * sum_dt + sj[k] - si[k];
+    d_qrot(c.Qi_inv, t, u);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) res[O_V + k] = u[k] - cdv[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { res[O_BA + k] = sj[3 + k] - si[3 + k]; res[O_BG + k] = sj[6 + k] - si[6 + k]; }
+}
+
+// One 3x3 block of the 15x30 Jacobian [J_pose_i | J_sb_i | J_pose_j | J_sb_j] (edge_imu.cc:74-153).
+// `blk` enumerates the 14 non-zero blocks; sJ is the 15x30 row-major LDS image (zero-initialised).
+__device__ void d_imu_jac_block(int blk, const double *pre, const double *G, const double *pi, const double *si,
+                                const double *pj, const double *sj, const ImuCommon &c, double *sJ) {
+    const double *Jm = pre + PRE_JAC;
+    const double sum_dt = c.sum_dt;
+    double B[9];
+    int r0 = 0, c0 = 0;
+    double RiT[9];
+    double qi[4] = {c.Qi_inv.x, c.Qi_inv.y, c.Qi_inv.z, c.Qi_inv.w};
+    d_quat_to_R(qi, RiT);                 // Qi.inverse().toRotationMatrix()
+    switch (blk) {
+    case 0: r0 = O_P; c0 = 0 + O_P;       // jacobian_pose_i(O_P,O_P) = -Ri^T
+        for (int k = 0; k < 9; ++k) B[k] = -RiT[k];
+        break;
+    case 1: { r0 = O_P; c0 = 0 + O_R;     // skew(Qi^-1 (0.5 G dt^2 + Pj - Pi - Vi dt))
+        double t[3], u[3];
+        for (int k = 0; k < 3; ++k) t[k] = 0.5 * G[k] * sum_dt * sum_dt + pj[k] - pi[k] - si[k] * sum_dt;
+        d_qrot(c.Qi_inv, t, u); d_skew(u, B);
+        break; }
+    case 2: { r0 = O_R; c0 = 0 + O_R;     // -(Qleft(Qj^-1 Qi) Qright(corrected_delta_q)).bottomRight
+        dquat a = d_qmul(d_qinv(c.Qj), c.Qi), b = c.cdq;
+        double La[9], Rb[9], P[9];
+        d_qleft_br(a, La); d_qright_br(b, Rb); d_m3_mul(La, Rb, P);
+        const double va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = -(va[i] * (-vb[j]) + P[3 * i + j]);
+        break; }
+    case 3: { r0 = O_V; c0 = 0 + O_R;     // skew(Qi^-1 (G dt + Vj - Vi))
+        double t[3], u[3];
+        for (int k = 0; k < 3; ++k) t[k] = G[k] * sum_dt + sj[k] - si[k];
+        d_qrot(c.Qi_inv, t, u); d_skew(u, B);
+        break; }
+    case 4: r0 = O_P; c0 = 6 + 0;         // speedbias_i(O_P, V) = -Ri^T dt
+        for (int k = 0; k < 9; ++k) B[k] = -RiT[k] * sum_dt;
+        break;
+    case 5: r0 = O_P; c0 = 6 + 3;         // -dp_dba
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = -Jm[15 * (O_P + i) + O_BA + j];
+        break;
+    case 6: r0 = O_P; c0 = 6 + 6;         // -dp_dbg
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = -Jm[15 * (O_P + i) + O_BG + j];
+        break;
+    case 7: { r0 = O_R; c0 = 6 + 6;       // -Qleft(Qj^-1 Qi delta_q).bottomRight * dq_dbg  (delta_q, not corrected: edge_imu.cc:107-109)
+        double L[9], nL[9], D[9];
+        d_qleft_br(d_qmul(d_qmul(d_qinv(c.Qj), c.Qi), c.dq), L);
+        for (int k = 0; k < 9; ++k) nL[k] = -L[k];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) D[3 * i + j] = Jm[15 * (O_R + i) + O_BG + j];
+        d_m3_mul(nL, D, B);
+        break; }
+    case 8: r0 = O_V; c0 = 6 + 0;         // -Ri^T
+        for (int k = 0; k < 9; ++k) B[k] = -RiT[k];
+        break;
+    case 9: r0 = O_V; c0 = 6 + 3;         // -dv_dba
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = -Jm[15 * (O_V + i) + O_BA + j];
+        break;
+    case 10: r0 = O_V; c0 = 6 + 6;        // -dv_dbg
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = -Jm[15 * (O_V + i) + O_BG + j];
+        break;
+    case 11: r0 = O_P; c0 = 15 + O_P;     // pose_j(O_P,O_P) = Ri^T
+        for (int k = 0; k < 9; ++k) B[k] = RiT[k];
+        break;
+    case 12: { r0 = O_R; c0 = 15 + O_R;   // Qleft(corrected_dq^-1 Qi^-1 Qj).bottomRight
+        d_qleft_br(d_qmul(d_qmul(d_qinv(c.cdq), c.Qi_inv), c.Qj), B);
+        break; }
+    case 13: r0 = O_V; c0 = 21 + 0;       // speedbias_j(O_V,V) = Ri^T
+        for (int k = 0; k < 9; ++k) B[k] = RiT[k];
+        break;
+    default: return;
+    }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) sJ[30 * (r0 + i) + c0 + j] = B[3 * i + j];
+}
+
+// T = J^T Info J (30x30), g = J^T Info r, chi = r^T Info r  for IMU edge k
+__device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
+    const int tid = threadIdx.x;
+    double *sJ = smem;               // 450
+    double *sI = sJ + 450;           // 225 information
+    double *sJtI = sI + 225;         // 30x15
+    double *sr = sJtI + 450;         // 15
+    double *sIr = sr + 16;           // 15
+    double *out = T.imu_out + k * IMU_OUT;
+    if (!T.imu_valid[k]) {
+        for (int e = tid; e < IMU_OUT; e += LIN_THREADS) out[e] = 0.0;
+        return;
+    }
+    const int cur = T.lm->cur;
+    const double *st = T.state + cur * STATE_STRIDE;
+    const double *pre = T.pre + k * PRE_STRIDE;
+    const double *pi = st + STATE_POSE + 7 * k, *pj = pi + 7, *si = st + STATE_SB + 9 * k, *sj = si + 9;
+    for (int e = tid; e < 450; e += LIN_THREADS) sJ[e] = 0.0;
+    for (int e = tid; e < 225; e += LIN_THREADS) sI[e] = pre[PRE_INFO + e];
+    __syncthreads();
+    if (tid < 16) {
+        ImuCommon c;
+        d_imu_common(pre, pi, si, pj, c);
+        if (tid < 14) d_imu_jac_block(tid, pre, T.gravity, pi, si, pj, sj, c, sJ);
+        else if (tid == 14) {
+            double r[15];
+            d_imu_residual(pre, T.gravity, pi, si, pj, sj, c, r);
+            for (int i = 0; i < 15; ++i) sr[i] = r[i];
+        } else {
+            for (int i = 0; i < 3; ++i) {       // identity blocks (edge_imu.cc:116-118,146-148)
+                sJ[30 * (O_BA + i) + 6 + 3 + i] = -1.0; sJ[30 * (O_BG + i) + 6 + 6 + i] = -1.0;
+                sJ[30 * (O_BA + i) + 21 + 3 + i] = 1.0; sJ[30 * (O_BG + i) + 21 + 6 + i] = 1.0;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 450; e += LIN_THREADS) {      // JtI[a][j] = sum_i J[i][a] * I[i][j]
+        const int a = e / 15, j = e % 15;
+        double s = 0;
+        for (int i = 0; i < 15; ++i) s += sJ[30 * i + a] * sI[15 * i + j];
+        sJtI[e] = s;
+    }
+    if (tid < 15) {
+        double s = 0;
+        for (int j = 0; j < 15; ++j) s += sI[15 * tid + j] * sr[j];
+        sIr[tid] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < 900; e += LIN_THREADS) {
+        const int a = e / 30, b = e % 30;
+        double s = 0;
+        for (int j = 0; j < 15; ++j) s += sJtI[15 * a + j] * sJ[30 * j + b];
+        out[IMU_T + e] = s;
+    }
+    if (tid < 30) {
+        double s = 0;
+        for (int i = 0; i < 15; ++i) s += sJ[30 * i + tid] * sIr[i];
+        out[IMU_G + tid] = s;
+    }
+    if (tid == 32) {
+        double s = 0;
+        for (int i = 0; i < 15; ++i) s += sr[i] * sIr[i];
+        out[IMU_CHI] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_linearize: one workgroup (256 threads) per item
+//   phase 1   thread per observation (k-major: a wave shares one target frame): residual, Jacobians, robust
+//             weight, whitened rows L*J into an LDS record per observation
+//   phase 1.5 thread per landmark: h_ll, b_l, Schur row w = Hpl, written to HBM for the back-substitution
+//   phase 2   lanes own 1x6 strips of the output blocks and stream the LDS records (4 waves split the
+//             landmarks or the strips); fixed summation order
+// ---------------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+
+__global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b >= T.n_items) {
+        d_imu_item(T, b - T.n_items, dyn_smem);
+        return;
+    }
+    __shared__ ItemDesc sIt;        // kept in LDS: its small arrays are indexed at run time
+    if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
+    __syncthreads();
+    const ItemDesc &it = sIt;
+    const int cur = T.lm->cur;
+    const int G = it.G, K = it.K, nb = it.nb, use_ext = it.use_ext;
+    const int REC = use_ext ? 59 : 41;
+    const int offH = 0, offT = 12, offE = 24;
+    const int offA = use_ext ? 36 : 24;
+    const int offBH = offA + 2, offBT = offBH + 6, offBE = offBT + 6;
+    const int offBL = use_ext ? 56 : 38;
+    const int LREC = (12 * nb + 3) | 1;
+
+    double *sPair = dyn_smem;                         // K * PAIR_STRIDE
+    double *sCam = sPair + VIO_MAXK * PAIR_STRIDE;    // ric, tic
+    double *sRed = sCam + 16;                         // LIN_THREADS
+    double *sRec = sRed + LIN_THREADS;                // G*K*REC
+    double *sLrec = sRec + G * K * REC;               // G*LREC
+    double *sPart = sLrec + G * LREC;                 // nsplit*n_strips*6
+
+    const double *ptab = T.pairtab + cur * PAIRTAB_STRIDE;
+    for (int e = tid; e < K * PAIR_STRIDE; e += LIN_THREADS) {
+        const int k = e / PAIR_STRIDE, o = e % PAIR_STRIDE;
+        sPair[e] = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + o];
+    }
+    if (tid < 12) sCam[tid] = ptab[121 * PAIR_STRIDE + tid];
+    __syncthreads();
+
+    const double *invd = T.invd + (size_t)cur * T.Ns + it.lm_base;
+    const double *pts_i = T.pts_i + 2 * (size_t)it.lm_base;
+    const double *pts_j = T.pts_j + 2 * (size_t)it.obs_base;
+    const double s_info = T.sqrt_info, info = s_info * s_info;
+    const double *ric = sCam, *tic = sCam + CAMTAB_TIC;
+
+    // ---------------- phase 1 ----------------
+    double chi_acc = 0.0;
+    for (int o = tid; o < G * K; o += LIN_THREADS) {
+        const int k = o / G, g = o - k * G;
+        const double *PA = sPair + k * PAIR_STRIDE;
+        const double lam = invd[g];
+        const double il = 1.0 / lam;
+        const double x = pts_i[2 * g], y = pts_i[2 * g + 1];
+        const double u = pts_j[2 * o], v = pts_j[2 * o + 1];
+        const double pci[3] = {x * il, y * il, il};
+        double Cp[3], pcj[3], pbi[3], pbj[3];
+        d_m3_vec(PA + PAIR_C, pci, Cp);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) pcj[m] = Cp[m] + PA[PAIR_D + m];
+        d_m3_vec(ric, pci, pbi);
+        d_m3_vec(ric, pcj, pbj);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { pbi[m] += tic[m]; pbj[m] += tic[m]; }
+        const double iz = 1.0 / pcj[2];
+        const double r0 = pcj[0] * iz - u, r1 = pcj[1] * iz - v;
+        const double ra = -pcj[0] * (iz * iz), rb = -pcj[1] * (iz * iz);     // reduce = [iz 0 ra; 0 iz rb]
+        // J_lambda = reduce * C*pts_i * (-1/lam^2) = reduce * (C*pc_i) * (-1/lam)
+        const double Jl0 = (iz * Cp[0] + ra * Cp[2]) * (-il), Jl1 = (iz * Cp[1] + rb * Cp[2]) * (-il);
+        // reduce*A, reduce*B, reduce*ric^T
+        double RA0[3], RA1[3], RB0[3], RB1[3], RR0[3], RR1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            RA0[c] = iz * PA[PAIR_A + c] + ra * PA[PAIR_A + 6 + c];
+            RA1[c] = iz * PA[PAIR_A + 3 + c] + rb * PA[PAIR_A + 6 + c];
+            RB0[c] = iz * PA[PAIR_B + c] + ra * PA[PAIR_B + 6 + c];
+            RB1[c] = iz * PA[PAIR_B + 3 + c] + rb * PA[PAIR_B + 6 + c];
+            RR0[c] = iz * ric[3 * c] + ra * ric[3 * c + 2];
+            RR1[c] = iz * ric[3 * c + 1] + rb * ric[3 * c + 2];
+        }
+        // J_pose_i = [reduce*A | pb_i x (reduce*B)rows]   (row * hat(v) = row x v; -row x v = v x row)
+        double Jh0[6], Jh1[6], Jt0[6], Jt1[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { Jh0[c] = RA0[c]; Jh1[c] = RA1[c]; Jt0[c] = -RA0[c]; Jt1[c] = -RA1[c]; }
+        Jh0[3] = pbi[1] * RB0[2] - pbi[2] * RB0[1]; Jh0[4] = pbi[2] * RB0[0] - pbi[0] * RB0[2]; Jh0[5] = pbi[0] * RB0[1] - pbi[1] * RB0[0];
+        Jh1[3] = pbi[1] * RB1[2] - pbi[2] * RB1[1]; Jh1[4] = pbi[2] * RB1[0] - pbi[0] * RB1[2]; Jh1[5] = pbi[0] * RB1[1] - pbi[1] * RB1[0];
+        // J_pose_j = [-reduce*A | (reduce*ric^T)rows x pb_j]
+        Jt0[3] = RR0[1] * pbj[2] - RR0[2] * pbj[1]; Jt0[4] = RR0[2] * pbj[0] - RR0[0] * pbj[2]; Jt0[5] = RR0[0] * pbj[1] - RR0[1] * pbj[0];
+        Jt1[3] = RR1[1] * pbj[2] - RR1[2] * pbj[1]; Jt1[4] = RR1[2] * pbj[0] - RR1[0] * pbj[2]; Jt1[5] = RR1[0] * pbj[1] - RR1[1] * pbj[0];
+
+        // robust weight: Edge::RobustInfo (edge.cc:48-74) with information = s^2 I
+        const double e2 = r0 * (info * r0) + r1 * (info * r1);
+        double rho0, rho1, rho2;
+        d_loss(T.loss_type, T.loss_delta, e2, rho0, rho1, rho2);
+        chi_acc += (T.loss_type == 0) ? e2 : rho0;
+        double lam2 = rho1;
+        if (T.loss_type != 0 && rho1 + 2 * rho2 * e2 > 0.) lam2 = rho1 + 2 * rho2 * e2;
+        // symmetric square root L of W = s^2 (rho1 I + 2 rho2 (s r)(s r)^T): L = s (al I + (be-al) rhat rhat^T)
+        const double al = sqrt(rho1), be = sqrt(fmax(lam2, 0.0));
+        const double rn2 = r0 * r0 + r1 * r1;
+        const double irn2 = rn2 > 0 ? 1.0 / rn2 : 0.0;
+        const double gm = (be - al) * irn2;
+        const double L00 = s_info * (al + gm * r0 * r0), L01 = s_info * (gm * r0 * r1), L11 = s_info * (al + gm * r1 * r1);
+        const double c0 = rho1 * (info * r0), c1 = rho1 * (info * r1);         // drho * Information * residual
+
+        double *rec = sRec + (size_t)o * REC;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            rec[offH + c] = L00 * Jh0[c] + L01 * Jh1[c];
+            rec[offH + 6 + c] = L01 * Jh0[c] + L11 * Jh1[c];
+            rec[offT + c] = L00 * Jt0[c] + L01 * Jt1[c];
+            rec[offT + 6 + c] = L01 * Jt0[c] + L11 * Jt1[c];
+            rec[offBH + c] = Jh0[c] * c0 + Jh1[c] * c1;
+            rec[offBT + c] = Jt0[c] * c0 + Jt1[c] * c1;
+        }
+        rec[offA] = L00 * Jl0 + L01 * Jl1;
+        rec[offA + 1] = L01 * Jl0 + L11 * Jl1;
+        rec[offBL] = Jl0 * c0 + Jl1 * c1;
+        if (use_ext) {
+            // J_ext = reduce * [El | -C hat(pc_i) + hat(C pc_i) + hat(d)] = [reduce*El | pc_i x (reduce*C)rows + red_rows x pc_j]
+            double Je0[6], Je1[6], RC0[3], RC1[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Je0[c] = iz * PA[PAIR_EL + c] + ra * PA[PAIR_EL + 6 + c];
+                Je1[c] = iz * PA[PAIR_EL + 3 + c] + rb * PA[PAIR_EL + 6 + c];
+                RC0[c] = iz * PA[PAIR_C + c] + ra * PA[PAIR_C + 6 + c];
+                RC1[c] = iz * PA[PAIR_C + 3 + c] + rb * PA[PAIR_C + 6 + c];
+            }
+            // red0 = (iz,0,ra), red1 = (0,iz,rb);  red x pcj
+            const double x0[3] = {0 * pcj[2] - ra * pcj[1], ra * pcj[0] - iz * pcj[2], iz * pcj[1] - 0 * pcj[0]};
+            const double x1[3] = {iz * pcj[2] - rb * pcj[1], rb * pcj[0] - 0 * pcj[2], 0 * pcj[1] - iz * pcj[0]};
+            Je0[3] = pci[1] * RC0[2] - pci[2] * RC0[1] + x0[0]; Je0[4] = pci[2] * RC0[0] - pci[0] * RC0[2] + x0[1]; Je0[5] = pci[0] * RC0[1] - pci[1] * RC0[0] + x0[2];
+            Je1[3] = pci[1] * RC1[2] - pci[2] * RC1[1] + x1[0]; Je1[4] = pci[2] * RC1[0] - pci[0] * RC1[2] + x1[1]; Je1[5] = pci[0] * RC1[1] - pci[1] * RC1[0] + x1[2];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                rec[offE + c] = L00 * Je0[c] + L01 * Je1[c];
+                rec[offE + 6 + c] = L01 * Je0[c] + L11 * Je1[c];
+                rec[offBE + c] = Je0[c] * c0 + Je1[c] * c1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 1.5: per landmark ----------------
+    double maxh = 0.0;
+    for (int g = tid; g < G; g += LIN_THREADS) {
+        double h = 0, bl = 0;
+        double wH[6] = {0, 0, 0, 0, 0, 0}, wE[6] = {0, 0, 0, 0, 0, 0};
+        double *L = sLrec + (size_t)g * LREC;
+        for (int k = 0; k < K; ++k) {
+            const double *rec = sRec + (size_t)(k * G + g) * REC;
+            const double a0 = rec[offA], a1 = rec[offA + 1];
+            h += a0 * a0 + a1 * a1;
+            bl -= rec[offBL];
+            const int ts = it.tslot[k];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                wH[c] += rec[offH + c] * a0 + rec[offH + 6 + c] * a1;
+                L[6 * ts + c] = rec[offT + c] * a0 + rec[offT + 6 + c] * a1;
+            }
+            if (use_ext) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) wE[c] += rec[offE + c] * a0 + rec[offE + 6 + c] * a1;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) L[6 * it.host_slot + c] = wH[c];
+        if (use_ext) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) L[c] = wE[c];
+        }
+        const double hinv = 1.0 / h;                // Hmm_inv (problem.cc:419-425)
+        for (int c = 0; c < 6 * nb; ++c) L[6 * nb + c] = L[c] * hinv;     // tempH = Hpm * Hmm_inv (problem.cc:427)
+        L[12 * nb] = hinv;
+        L[12 * nb + 1] = bl;
+        maxh = fmax(maxh, fabs(h));
+        double *lw = T.lw + it.lw_base;
+        for (int c = 0; c < 6 * nb; ++c) lw[(size_t)c * G + g] = L[c];
+        lw[(size_t)(6 * nb) * G + g] = h;
+        lw[(size_t)(6 * nb + 1) * G + g] = bl;
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: strips ----------------
+    const int n_strips = it.n_strips, nsplit = it.nsplit;
+    const int wave = tid >> 6, lane = tid & 63;
+    const uint32_t *strips = T.strips + it.strip_off;
+    const int s_first = (nsplit == 4) ? lane : tid;
+    const int s_step = (nsplit == 4) ? 64 : LIN_THREADS;
+    const int g_first = (nsplit == 4) ? wave : 0;
+    const int g_step = (nsplit == 4) ? 4 : 1;
+    const int split = (nsplit == 4) ? wave : 0;
+    for (int s = s_first; s < n_strips; s += s_step) {
+        const uint32_t w = strips[s];
+        const int p = STRIP_P(w), q = STRIP_Q(w), i = STRIP_I(w), ks = STRIP_K(w), kind = STRIP_KIND(w);
+        const int sp = STRIP_SRCP(w), sq = STRIP_SRCQ(w);
+        const int offp = sp == 0 ? offE : (sp == 1 ? offH : offT);
+        const int offq = sq == 0 ? offE : (sq == 1 ? offH : offT);
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        if (kind == 0) {
+            const int schur = STRIP_SCHUR(w);
+            for (int g = g_first; g < G; g += g_step) {
+                if (schur) {
+                    const double *L = sLrec + (size_t)g * LREC;
+                    const double ai = L[6 * nb + 6 * p + i];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[j] -= ai * L[6 * q + j];
+                }
+                if (ks != 15) {
+                    const double *rec = sRec + (size_t)(ks * G + g) * REC;
+                    const double p0 = rec[offp + i], p1 = rec[offp + 6 + i];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) acc[j] += p0 * rec[offq + j] + p1 * rec[offq + 6 + j];
+                }
+            }
+        } else if (kind == 2) {         // Schur correction of b: (Hpm*Hmm^-1) * bmm
+            for (int g = g_first; g < G; g += g_step) {
+                const double *L = sLrec + (size_t)g * LREC;
+                const double bl = L[12 * nb + 1];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[j] += L[6 * nb + 6 * p + j] * bl;
+            }
+        } else {                        // kind 1: direct b, kind 3: direct diagonal
+            const int offb = sp == 0 ? offBE : (sp == 1 ? offBH : offBT);
+            const int k0 = ks == 15 ? 0 : ks, k1 = ks == 15 ? K : ks + 1;
+            for (int g = g_first; g < G; g += g_step) {
+                for (int k = k0; k < k1; ++k) {
+                    const double *rec = sRec + (size_t)(k * G + g) * REC;
+                    if (kind == 1) {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] -= rec[offb + j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) acc[j] += rec[offp + j] * rec[offp + j] + rec[offp + 6 + j] * rec[offp + 6 + j];
+                    }
+                }
+            }
+        }
+        double *o = sPart + ((size_t)split * n_strips + s) * 6;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) o[j] = acc[j];
+    }
+    __syncthreads();
+
+    // ---------------- combine and write the item's slab ----------------
+    const uint32_t *rows = T.rows + it.row_off;
+    double *out = T.slab + it.out_base;
+    for (int r = tid; r < it.n_rows; r += LIN_THREADS) {
+        const uint32_t w = rows[r];
+        const int first = ROW_FIRST(w), ncopy = ROW_NCOPY(w);
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        for (int c = 0; c < ncopy; ++c)
+            for (int v = 0; v < nsplit; ++v) {
+                const double *o = sPart + ((size_t)v * n_strips + first + c) * 6;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) sum[j] += o[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) out[(size_t)r * 6 + j] = sum[j];
+    }
+    const double chi = d_block_sum<LIN_THREADS>(chi_acc, sRed, tid);
+    const double mh = d_block_max<LIN_THREADS>(maxh, sRed, tid);
+    if (tid == 0) { out[(size_t)it.n_rows * 6] = chi; out[(size_t)it.n_rows * 6 + 1] = mh; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_reduce: fixed-order sum of the item slabs through inverted lists built at upload time.
+//   list b < 78           camera block pair (P,Q): entries = slab offset of that 6x6 block
+//   list 78 + P           camera block P vectors: entries = (offset of b_dir block, 6*nb)
+//   list 90               chi / max h: entries = offset
+// ---------------------------------------------------------------------------------------------------------
+struct ReduceTables {
+    const int32_t *list_off;     // [92]
+    const int32_t *list;         // offsets (pairs: 1 int per entry; vectors: 2 ints per entry)
+    const double *slab;
+    double *vis;
+};
+
+__global__ __launch_bounds__(64) void k_reduce(ReduceTables R) {
+    __shared__ int32_t sOff[128];
+    __shared__ double sV[24];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int lo = R.list_off[b], hi = R.list_off[b + 1];
+    if (b < VIO_NPAIR) {
+        double acc = 0.0;
+        for (int base = lo; base < hi; base += 64) {
+            const int n = min(64, hi - base);
+            __syncthreads();
+            if (t < n) sOff[t] = R.list[base + t];
+            __syncthreads();
+            if (t < 36) {
+#pragma unroll 8
+                for (int e = 0; e < n; ++e) acc += R.slab[(size_t)sOff[e] + t];
+            }
+        }
+        if (t < 36) {
+            int P = 0, rem = b;
+            while (rem >= VIO_NCB - P) { rem -= VIO_NCB - P; ++P; }
+            const int Q = P + rem, i = t / 6, j = t % 6;
+            R.vis[VIS_H + (6 * P + i) * VIO_CD + 6 * Q + j] = acc;
+            if (P != Q) R.vis[VIS_H + (6 * Q + j) * VIO_CD + 6 * P + i] = acc;
+        }
+    } else if (b < VIO_NPAIR + VIO_NCB) {
+        const int P = b - VIO_NPAIR;
+        double acc = 0.0;
+        const int kind = t / 6, i = t % 6;
+        for (int base = lo; base < hi; base += 2 * 32) {
+            const int n = min(32, (hi - base) / 2);
+            __syncthreads();
+            if (t < 2 * n) sOff[t] = R.list[base + t];
+            __syncthreads();
+            if (t < 18) {
+#pragma unroll 4
+                for (int e = 0; e < n; ++e) acc += R.slab[(size_t)sOff[2 * e] + kind * sOff[2 * e + 1] + i];
+            }
+        }
+        if (t < 18) sV[t] = acc;
+        __syncthreads();
+        if (t < 6) {
+            R.vis[VIS_BDIR + 6 * P + t] = sV[t];
+            R.vis[VIS_BRED + 6 * P + t] = sV[t] - sV[6 + t];     // bpp - (Hpm*Hmm^-1)*bmm (problem.cc:429)
+            R.vis[VIS_DIAG + 6 * P + t] = sV[12 + t];
+        }
+    } else {
+        double chi = 0.0, mh = 0.0;
+        if (t == 0) {
+            for (int e = lo; e < hi; ++e) { chi += R.slab[(size_t)R.list[e]]; mh = fmax(mh, R.slab[(size_t)R.list[e] + 1]); }
+            R.vis[VIS_CHI] = chi;
+            R.vis[VIS_MAXH] = mh;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_assemble: row i of H_pp_schur_ (without lambda) = reduced visual (72 -> 171) + IMU blocks + prior
+//   (problem.cc:365-384: prior rows/cols of a fixed extrinsic are zeroed; Marginalize adds it unmasked)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int imu_vblock(int a) { return a < 6 ? 0 : (a < 15 ? 1 : (a < 21 ? 2 : 3)); }
+
+__global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
+    const int i = blockIdx.x, j = threadIdx.x;
+    const int cur = T.lm->cur;
+    const int ci = full_to_cam(i);
+    const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
+    if (j < VIO_PD) {
+        double vv = 0.0, vr = 0.0;      // reduced visual part, IMU + prior part
+        const int cj = full_to_cam(j);
+        if (ci >= 0 && cj >= 0) vv = T.vis[VIS_H + ci * VIO_CD + cj];
+        if (i >= 6 && j >= 6) {
+            const int fi = (i - 6) / 15;
+            for (int k = fi - 1; k <= fi; ++k) {
+                if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
+                if (T.marg_mode && k != 0) continue;
+                const int a = i - (6 + 15 * k), bb = j - (6 + 15 * k);
+                if (bb < 0 || bb >= 30) continue;
+                const double *Tk = T.imu_out + k * IMU_OUT + IMU_T;
+                // upper vertex blocks are computed, lower ones mirrored (problem.cc:347-355)
+                vr += (imu_vblock(a) <= imu_vblock(bb)) ? Tk[a * 30 + bb] : Tk[bb * 30 + a];
+            }
+        }
+        if (T.has_prior) {
+            const bool mask_j = T.ext_fixed && !T.marg_mode && j < 6;
+            if (!mask_i && !mask_j) vr += T.Hprior[i * VIO_PD + j];
+        }
+        T.Hs[i * VIO_PD + j] = vv + vr;
+        if (j == i)     // diag(Hessian_) before the Schur complement, for ComputeLambdaInitLM (problem.cc:511-516)
+            T.diagfull[i] = ((ci >= 0) ? T.vis[VIS_DIAG + ci] : 0.0) + vr;
+    } else if (j == VIO_PD) {
+        double bred = 0.0, bdir = 0.0;
+        if (ci >= 0) { bred = T.vis[VIS_BRED + ci]; bdir = T.vis[VIS_BDIR + ci]; }
+        double extra = 0.0;
+        if (i >= 6) {
+            const int fi = (i - 6) / 15;
+            for (int k = fi - 1; k <= fi; ++k) {
+                if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
+                if (T.marg_mode && k != 0) continue;
+                const int a = i - (6 + 15 * k);
+                if (a < 0 || a >= 30) continue;
+                extra -= T.imu_out[k * IMU_OUT + IMU_G + a];
+            }
+        }
+        if (T.has_prior && !mask_i) extra += T.bprior[cur * 176 + i];
+        T.bs[i] = bred + extra;
+        T.bfull[i] = bdir + extra;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_pose_solve: single workgroup, 1024 threads.  (H_pp_schur_ + lambda I) dx = b_pp_schur_ with the pivot order
+// Eigen's LDLT would pick (largest |diagonal| first; Eigen pivots on the not-yet-updated diagonal,
+// Cholesky/LDLT.h:317-320, so the order is known before the factorisation starts), packed lower triangle in LDS,
+// right-hand side carried as an extra row so the forward substitution comes for free; back-substitution by
+// one wave; then the trial pose states, their pair table and the first-order prior update.
+// ---------------------------------------------------------------------------------------------------------
+#define PS_THREADS 1024
+#define PS_N VIO_PD
+__device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }
+
+__global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
+    double *P = dyn_smem;                          // (PS_N+1)(PS_N+2)/2 = 14878
+    double *sDg = P + 14880;                       // 176 diag (+lambda)
+    double *sDinv = sDg + 176;                     // 176
+    double *sX = sDinv + 176;                      // 176 solution in pivot order
+    double *sDx = sX + 176;                        // 176 solution in natural order
+    double *sR = sDx + 176;                        // 108 rotations
+    double *sB = sR + 112;                         // 176 trial b_prior
+    int *sPerm = (int *)(sB + 176);                // 176
+    const int tid = threadIdx.x;
+    LmState *lm = T.lm;
+    const int cur = lm->cur, trial = cur ^ 1;
+    const double lambda = lm->lambda;
+    const int n = PS_N;
+
+    for (int i = tid; i < n; i += PS_THREADS) sDg[i] = T.Hs[i * n + i] + lambda;
+    __syncthreads();
+    for (int i = tid; i < n; i += PS_THREADS) {
+        const double di = fabs(sDg[i]);
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double dj = fabs(sDg[j]);
+            rank += (dj > di || (dj == di && j < i)) ? 1 : 0;
+        }
+        sPerm[rank] = i;
+    }
+    __syncthreads();
+    {
+        const int ty = tid >> 5, tx = tid & 31;
+        for (int r = ty; r <= n; r += 32) {
+            for (int c = tx; c <= r && c < n + 1; c += 32) {
+                double v;
+                if (r < n) {
+                    const int i = sPerm[r], j = sPerm[c];
+                    const int hi = max(i, j), lo = min(i, j);
+                    v = T.Hs[hi * n + lo];
+                    if (r == c) v += lambda;
+                } else {
+                    v = (c < n) ? T.bs[sPerm[c]] : 0.0;
+                }
+                P[tri(r, c)] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    {   // right-looking LDL^T, columns kept unscaled (P(r,k) = L(r,k)*d_k), one barrier per pivot
+        const int ty = tid >> 5, tx = tid & 31;
+        for (int k = 0; k < n; ++k) {
+            const double d = P[tri(k, k)];
+            const double dinv = (fabs(d) > 0.0) ? 1.0 / d : 0.0;
+            if (tid == 0) sDinv[k] = dinv;
+            for (int r = k + 1 + ty; r <= n; r += 32) {
+                const double lrk = P[tri(r, k)] * dinv;
+                const int cmax = min(r, n - 1);
+                for (int c = k + 1 + tx; c <= cmax; c += 32) P[tri(r, c)] -= lrk * P[tri(c, k)];
+            }
+            __syncthreads();
+        }
+    }
+
+    if (tid < 64) {     // D^+ and L^-T by one wave: lane owns k = lane, lane+64, lane+128
+        const double tol = 1.0 / 1.7976931348623157e308;
+        double acc0 = 0, acc1 = 0, acc2 = 0;
+        const int lane = tid;
+        double z0 = 0, z1 = 0, z2 = 0;
+        {
+            const int k0 = lane, k1 = lane + 64, k2 = lane + 128;
+            const double d0 = P[tri(k0, k0)], d1 = P[tri(k1, k1)];
+            z0 = (fabs(d0) > tol) ? P[tri(n, k0)] / d0 : 0.0;
+            z1 = (fabs(d1) > tol) ? P[tri(n, k1)] / d1 : 0.0;
+            if (k2 < n) { const double d2 = P[tri(k2, k2)]; z2 = (fabs(d2) > tol) ? P[tri(n, k2)] / d2 : 0.0; }
+        }
+        const double i0 = sDinv[lane], i1 = sDinv[lane + 64], i2 = (lane + 128 < n) ? sDinv[lane + 128] : 0.0;
+        for (int r = n - 1; r >= 128; --r) {
+            const double cand = z2 - i2 * acc2;
+            const double xr = __shfl(cand, r - 128);
+            if (lane == r - 128) sX[r] = xr;
+            const double *row = P + tri(r, 0);
+            acc0 += row[lane] * xr;
+            acc1 += row[lane + 64] * xr;
+            if (lane + 128 < r) acc2 += row[lane + 128] * xr;
+        }
+        for (int r = 127; r >= 64; --r) {
+            const double cand = z1 - i1 * acc1;
+            const double xr = __shfl(cand, r - 64);
+            if (lane == r - 64) sX[r] = xr;
+            const double *row = P + tri(r, 0);
+            acc0 += row[lane] * xr;
+            if (lane + 64 < r) acc1 += row[lane + 64] * xr;
+        }
+        for (int r = 63; r >= 0; --r) {
+            const double cand = z0 - i0 * acc0;
+            const double xr = __shfl(cand, r);
+            if (lane == r) sX[r] = xr;
+            if (lane < r) acc0 += P[tri(r, 0) + lane] * xr;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += PS_THREADS) {
+        const double v = sX[r];
+        sDx[sPerm[r]] = v;
+        T.dx[sPerm[r]] = v;
+    }
+    __syncthreads();
+
+    // trial states = current (+) dx   (UpdateStates, problem.cc:456-463)
+    const double *sc = T.state + cur * STATE_STRIDE;
+    double *stt = T.state + trial * STATE_STRIDE;
+    if (tid < 12) {
+        const double *p = (tid == 0) ? sc + STATE_EXT : sc + STATE_POSE + 7 * (tid - 1);
+        double *o = (tid == 0) ? stt + STATE_EXT : stt + STATE_POSE + 7 * (tid - 1);
+        const double *d = (tid == 0) ? sDx : sDx + 6 + 15 * (tid - 1);
+        double tmp[7];
+        d_pose_plus(p, d, tmp);
+        for (int k = 0; k < 7; ++k) o[k] = tmp[k];
+    } else if (tid >= 32 && tid < 32 + 99) {
+        const int e = tid - 32, f = e / 9, k = e % 9;
+        stt[STATE_SB + e] = sc[STATE_SB + e] + sDx[12 + 15 * f + k];
+    }
+    __syncthreads();
+    d_build_pairtab(stt, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, PS_THREADS);
+
+    // prior: b' = b - H_prior*dx ; err' = -Jt_prior_inv * b'.head(156)   (problem.cc:466-475)
+    if (T.has_prior) {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int i = wave; i < n; i += PS_THREADS / 64) {
+            double s = 0;
+            for (int j = lane; j < n; j += 64) s += T.Hprior[i * n + j] * sDx[j];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) { const double v = T.bprior[cur * 176 + i] - s; sB[i] = v; T.bprior[trial * 176 + i] = v; }
+        }
+        __syncthreads();
+        for (int i = wave; i < VIO_PRD; i += PS_THREADS / 64) {
+            double s = 0;
+            for (int j = lane; j < VIO_PRD; j += 64) s += -T.Jtinv[i * VIO_PRD + j] * sB[j];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) T.errprior[trial * 160 + i] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_backsub: one wave per item.  delta_lambda = Hmm^-1 (bmm - Hmp dx_p) (problem.cc:445), trial inverse depth,
+// chi2 of the trial state, landmark part of the gain-ratio denominator.  mode 1: chi2 of the CURRENT state only.
+// Blocks >= n_items evaluate the IMU chi2.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_backsub(DeviceTables T, int mode) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const LmState *lm = T.lm;
+    const int cur = lm->cur;
+    const int which = (mode == 1) ? cur : (cur ^ 1);
+    if (b >= T.n_items) {
+        const int k = b - T.n_items;
+        if (lane == 0) {
+            double chi = 0.0;
+            if (T.imu_valid[k]) {
+                const double *st = T.state + which * STATE_STRIDE;
+                const double *pre = T.pre + k * PRE_STRIDE;
+                const double *pi = st + STATE_POSE + 7 * k, *pj = pi + 7, *si = st + STATE_SB + 9 * k, *sj = si + 9;
+                ImuCommon c;
+                d_imu_common(pre, pi, si, pj, c);
+                double r[15];
+                d_imu_residual(pre, T.gravity, pi, si, pj, sj, c, r);
+                for (int i = 0; i < 15; ++i) {
+                    double t = 0;
+                    for (int j = 0; j < 15; ++j) t += pre[PRE_INFO + 15 * i + j] * r[j];
+                    chi += r[i] * t;
+                }
+            }
+            T.step_part[2 * b + STEP_CHI] = chi;
+            T.step_part[2 * b + STEP_SCALE] = 0.0;
+        }
+        return;
+    }
+    __shared__ double sPairCD[VIO_MAXK * 12];
+    __shared__ ItemDesc sIt;
+    if (lane < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[lane] = ((const int32_t *)(T.items + b))[lane];
+    __syncthreads();
+    const ItemDesc &it = sIt;
+    const int G = it.G, K = it.K, nb = it.nb;
+    const double *ptab = T.pairtab + which * PAIRTAB_STRIDE;
+    for (int e = lane; e < K * 12; e += 64) {
+        const int k = e / 12, o = e % 12;
+        sPairCD[e] = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + PAIR_C + o];     // C (9) then d (3) are adjacent
+    }
+    __syncthreads();
+    double chi = 0.0, scale = 0.0;
+    if (lane < G) {
+        const int g = lane;
+        const size_t li = (size_t)it.lm_base + g;
+        double lam = T.invd[(size_t)cur * T.Ns + li];
+        if (mode == 0) {
+            const double *lw = T.lw + it.lw_base;
+            double t = 0.0;
+            for (int p = 0; p < nb; ++p) {
+                const int cb = it.cam_block[p];
+                const int base = cb == 0 ? 0 : 6 + 15 * (cb - 1);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) t += lw[(size_t)(6 * p + i) * G + g] * T.dx[base + i];
+            }
+            const double h = lw[(size_t)(6 * nb) * G + g], bl = lw[(size_t)(6 * nb + 1) * G + g];
+            const double dl = (1.0 / h) * (bl - t);
+            T.dxl[li] = dl;
+            lam = lam + dl;
+            T.invd[(size_t)(cur ^ 1) * T.Ns + li] = lam;
+            scale = dl * (lm->lambda * dl + bl);
+        }
+        const double il = 1.0 / lam;
+        const double x = T.pts_i[2 * li], y = T.pts_i[2 * li + 1];
+        const double pci[3] = {x * il, y * il, il};
+        const double s_info = T.sqrt_info, info = s_info * s_info;
+        for (int k = 0; k < K; ++k) {
+            const double *C = sPairCD + 12 * k;
+            const size_t o = (size_t)it.obs_base + (size_t)k * G + g;
+            double pcj[3];
+            d_m3_vec(C, pci, pcj);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) pcj[m] += C[9 + m];
+            const double iz = 1.0 / pcj[2];
+            const double r0 = pcj[0] * iz - T.pts_j[2 * o], r1 = pcj[1] * iz - T.pts_j[2 * o + 1];
+            const double e2 = r0 * (info * r0) + r1 * (info * r1);
+            double rho0, rho1, rho2;
+            d_loss(T.loss_type, T.loss_delta, e2, rho0, rho1, rho2);
+            chi += (T.loss_type == 0) ? e2 : rho0;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { chi += __shfl_xor(chi, o); scale += __shfl_xor(scale, o); }
+    if (lane == 0) { T.step_part[2 * b + STEP_CHI] = chi; T.step_part[2 * b + STEP_SCALE] = scale; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_step_sum: fixed-order sum of the visual per-item partials -> step_tot[0..1] (the second exchange buffer)
+// k_lm_decide: IsGoodStepInLM (problem.cc:541-573) + the loop bookkeeping of Problem::Solve (:188-245)
+//   mode 0: LM trial   mode 1: fixed-lambda GN step (always accept)   mode 2: chi2 only (no state change)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_step_sum(DeviceTables T) {
+    __shared__ double s0[256];
+    const int tid = threadIdx.x;
+    double c = 0, s = 0;
+    for (int e = tid; e < T.n_items; e += 256) { c += T.step_part[2 * e + STEP_CHI]; s += T.step_part[2 * e + STEP_SCALE]; }
+    const double ct = d_block_sum<256>(c, s0, tid);
+    const double st = d_block_sum<256>(s, s0, tid);
+    if (tid == 0) { T.step_tot[0] = ct; T.step_tot[1] = st; }
+}
+
+__global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int sum_local) {
+    __shared__ double s0[256];
+    const int tid = threadIdx.x;
+    LmState *lm = T.lm;
+    if (sum_local) {        // unsharded: fold k_step_sum in (same fixed order)
+        double c = 0, s = 0;
+        for (int e = tid; e < T.n_items; e += 256) { c += T.step_part[2 * e + STEP_CHI]; s += T.step_part[2 * e + STEP_SCALE]; }
+        const double ct = d_block_sum<256>(c, s0, tid);
+        const double st = d_block_sum<256>(s, s0, tid);
+        if (tid == 0) { T.step_tot[0] = ct; T.step_tot[1] = st; }
+        __syncthreads();
+    }
+    const int cur = lm->cur;
+    const int which = (mode == 2) ? cur : (cur ^ 1);
+    double e = 0.0, sp = 0.0;
+    if (T.has_prior)
+        for (int i = tid; i < VIO_PRD; i += 256) { const double v = T.errprior[which * 160 + i]; e += v * v; }
+    const double lambda = lm->lambda;
+    if (mode != 2)
+        for (int i = tid; i < VIO_PD; i += 256) { const double d = T.dx[i]; sp += d * (lambda * d + T.bfull[i]); }
+    const double en2 = d_block_sum<256>(e, s0, tid);
+    const double scale_p = d_block_sum<256>(sp, s0, tid);
+    if (tid != 0) return;
+    double chi_imu = 0.0;
+    for (int k = 0; k < T.n_imu_items; ++k) chi_imu += T.step_part[2 * (T.n_items + k) + STEP_CHI];
+    double total = T.step_tot[0] + chi_imu;
+    if (T.has_prior) total += sqrt(en2);            // err_prior_.norm(), not squared (problem.cc:554-556)
+    const double tempChi = 0.5 * total;
+    lm->chi_try = tempChi;
+    if (mode == 2) return;
+    double scale = 0.5 * (T.step_tot[1] + scale_p);
+    scale += 1e-6;
+    const double rho = (lm->chi - tempChi) / scale;
+    lm->rho = rho; lm->scale = scale;
+    lm->trials += 1;
+    const bool finite = isfinite(tempChi);
+    if (mode == 1 || (rho > 0 && finite)) {
+        if (mode == 0) {
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            const double scaleFactor = fmax(1. / 3., alpha);
+            lm->lambda *= scaleFactor;
+            lm->ni = 2;
+        }
+        lm->chi = tempChi;
+        lm->cur = cur ^ 1;
+        lm->accepted = 1;
+        lm->naccepted += 1;
+        lm->need_linearize = 1;
+        lm->false_cnt = 0;
+    } else {
+        lm->lambda *= lm->ni;
+        lm->ni *= 2;
+        lm->accepted = 0;
+        lm->need_linearize = 0;
+        lm->false_cnt += 1;
+    }
+    if (!finite) lm->finite = 0;
+    if (mode == 0 && (lm->accepted || lm->false_cnt >= 10)) {     // the inner while of Problem::Solve ends
+        lm->iter += 1;
+        lm->false_cnt = 0;
+        if (lm->last_chi - lm->chi < 1e-5) { lm->stop = 1; lm->stop_reason = 1; }
+        lm->last_chi = lm->chi;
+        if (lm->iter >= lm->max_iter) lm->stop = 1;
+        if (!lm->stop && lm->iter < 128) { lm->chi_trace[lm->iter] = lm->chi; lm->lambda_trace[lm->iter] = lm->lambda; }
+    }
+}
+
+// ComputeLambdaInitLM (problem.cc:497-522)
+__global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter) {
+    __shared__ double s0[256];
+    const int tid = threadIdx.x;
+    LmState *lm = T.lm;
+    const int cur = lm->cur;
+    double e = 0.0, md = 0.0;
+    if (T.has_prior)
+        for (int i = tid; i < VIO_PRD; i += 256) { const double v = T.errprior[cur * 160 + i]; e += v * v; }
+    for (int i = tid; i < VIO_PD; i += 256) md = fmax(md, fabs(T.diagfull[i]));
+    const double en2 = d_block_sum<256>(e, s0, tid);
+    const double maxd = d_block_max<256>(md, s0, tid);
+    if (tid != 0) return;
+    double total = T.vis[VIS_CHI];
+    for (int k = 0; k < 10; ++k) if (T.imu_valid[k]) total += T.imu_out[k * IMU_OUT + IMU_CHI];
+    if (T.has_prior) total += sqrt(en2);
+    const double chi = 0.5 * total;
+    double maxDiagonal = fmax(maxd, T.vis[VIS_MAXH]);
+    maxDiagonal = fmin(5e10, maxDiagonal);
+    lm->ni = 2.;
+    lm->chi = chi;
+    lm->init_chi = chi;
+    lm->lambda = 1e-5 * maxDiagonal;
+    lm->last_chi = 1e20;
+    lm->iter = 0; lm->false_cnt = 0; lm->trials = 0; lm->naccepted = 0; lm->stop = 0; lm->stop_reason = 0;
+    lm->finite = 1; lm->max_iter = max_iter; lm->accepted = 0; lm->need_linearize = 0;
+    lm->chi_trace[0] = chi; lm->lambda_trace[0] = lm->lambda;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host-callable launchers (C++ linkage inside the library)
+// ---------------------------------------------------------------------------------------------------------
+void vio_launch_prepare(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(128), 0, s, T); }
+void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
+}
+void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1), dim3(64), 0, s, R);
+}
+void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(VIO_PD), dim3(192), 0, s, T); }
+void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
+}
+void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(64), 0, s, T, mode);
+}
+void vio_launch_step_sum(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_step_sum, dim3(1), dim3(256), 0, s, T); }
+void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s) {
+    hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(256), 0, s, T, mode, sum_local);
+}
+__global__ void k_set_lambda(LmState *lm, double lambda) {
+    if (threadIdx.x == 0) lm->lambda = lambda;
+}
+void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s) { hipLaunchKernelGGL(k_set_lambda, dim3(1), dim3(64), 0, s, lm, lambda); }
+// rollback after a rejected step is implicit (the trial copies are simply not made current); an explicit
+// RollbackStates after vio_update_states flips the current index back
+__global__ void k_flip(LmState *lm) {
+    if (threadIdx.x == 0) lm->cur ^= 1;
+}
+void vio_launch_flip(LmState *lm, hipStream_t s) { hipLaunchKernelGGL(k_flip, dim3(1), dim3(64), 0, s, lm); }
+void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter);
+}
+int vio_set_kernel_attributes() {
+    hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    hipError_t e2 = hipFuncSetAttribute((const void *)k_pose_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
+    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
+}

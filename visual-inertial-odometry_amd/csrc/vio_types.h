@@ -1,0 +1,191 @@
+// vio_types.h — device-side layouts shared by the HIP kernels and the C-ABI host code.
+//
+// Data layout in HBM (all fp64 unless noted):
+//   state[2][STATE_STRIDE]   ext(7) | pose(11x7) | speed-bias(11x9); two copies: "current" and "trial"
+//   invd[2][Ns]              inverse depths in PATTERN-SORTED landmark order, current / trial
+//   pts_i[Ns][2]             host observation of each landmark
+//   pts_j[M][2]              target observations, item-major, inside an item k-major: obs_base + k*G + g
+//   items[n_items]           ItemDesc: <= G_MAX landmarks sharing (host, targets) — the unit of work of a workgroup
+//   pairtab[2][121][PAIR_STRIDE]   per ordered frame pair (h,t): composed rotations of the reprojection chain
+//   slab[...]                per-item compact partial sums (deterministic two-pass reduction, no float atomics)
+//   lw[...]                  per-landmark Schur row w (Hpl), 1/h_ll, b_l kept for back-substitution
+//   vis[VIS_COUNT]           reduced visual system in the 72-dim camera space (the multi-GPU exchange buffer)
+//   imu_out[10][IMU_OUT]     J^T*Info*J (30x30), J^T*Info*r (30), r^T*Info*r per IMU edge
+//   Hs[171x171], bs[171]     H_pp_schur_ (no lambda) and b_pp_schur_ of Problem::SolveLinearSystem
+//   lm                       LmState: lambda, chi2, ni, which state copy is current, counters
+#ifndef VIO_TYPES_H
+#define VIO_TYPES_H
+
+#include <stdint.h>
+
+#define VIO_NF 11
+#define VIO_PD 171
+#define VIO_PRD 156
+#define VIO_CD 72
+#define VIO_NCB 12               // camera blocks: ext + 11 poses
+#define VIO_NPAIR 78             // 12*13/2 block pairs (P <= Q)
+#define VIO_MAXK 10              // a landmark hosted in frame h has at most 10 other frames
+#define VIO_MAXNB 12
+
+#define STATE_EXT 0
+#define STATE_POSE 7
+#define STATE_SB (7 + 77)
+#define STATE_STRIDE 184
+
+#define PAIR_A 0                 // ric^T * Rt^T
+#define PAIR_B 9                 // A * Rh
+#define PAIR_C 18                // B * ric
+#define PAIR_D 27                // ric^T * (Rt^T * (Rh*tic + Ph - Pt) - tic)
+#define PAIR_EL 30               // ric^T * (Rt^T*Rh - I)
+#define PAIR_STRIDE 40
+#define CAMTAB_RIC 0             // stored after the 121 pair entries: ric(9), tic(3)
+#define CAMTAB_TIC 9
+#define PAIRTAB_STRIDE (121 * PAIR_STRIDE + 16)
+
+#define VIS_H 0                              // 72x72 row-major, both triangles
+#define VIS_BRED (VIO_CD * VIO_CD)           // reduced b (after landmark Schur), 72
+#define VIS_BDIR (VIS_BRED + VIO_CD)         // direct b (pose part of b_), 72
+#define VIS_DIAG (VIS_BDIR + VIO_CD)         // direct diagonal of Hpp (visual part), 72
+#define VIS_CHI (VIS_DIAG + VIO_CD)          // sum of RobustChi2 over reprojection edges
+#define VIS_MAXH (VIS_CHI + 1)               // max |h_ll|
+#define VIS_COUNT (VIS_MAXH + 1 + 6)         // padded to a multiple of 8
+
+#define IMU_T 0
+#define IMU_G 900
+#define IMU_CHI 930
+#define IMU_OUT 936
+
+#define STEP_CHI 0               // per-workgroup partials of the trial step: chi2 and gain-ratio scale
+#define STEP_SCALE 1
+
+struct ItemDesc {
+    int32_t lm_base;             // first landmark (sorted order)
+    int32_t G;                   // landmarks in this item
+    int32_t K;                   // observations per landmark
+    int32_t nb;                  // pattern blocks: [ext] + frames, ascending camera-block id
+    int32_t host;                // host frame
+    int32_t host_slot;           // pattern-local index of the host block
+    int32_t use_ext;             // 1: pattern-local block 0 is the extrinsic
+    int32_t obs_base;            // first observation (item-major storage)
+    int32_t out_base;            // offset into slab (doubles)
+    int32_t lw_base;             // offset into lw (doubles)
+    int8_t target[VIO_MAXK];     // target frame of observation k
+    int8_t tslot[VIO_MAXK];      // pattern-local block of observation k's target
+    int8_t cam_block[VIO_MAXNB]; // camera block id (0 ext, 1+f pose f) of pattern-local block p
+    int32_t strip_off;           // first strip word of this item's pattern
+    int32_t n_strips;
+    int32_t row_off;             // first output-row word of this item's pattern
+    int32_t n_rows;              // 6*nbp pair rows + 3*nb vector rows
+    int32_t nsplit;              // 4: the four waves split the landmarks; 1: they split the strips
+    int32_t lds_doubles;         // dynamic LDS this item needs
+};
+
+// A "strip" is the unit of phase-2 work of one lane: six accumulators (j = 0..5) of one output row.
+//   bits 0-3 p | 4-7 q | 8-10 i | 11-14 ksel (15: none for pairs / all k for vectors) | 15 schur | 16-17 kind
+//   | 18-19 row source of p | 20-21 row source of q        (row source: 0 ext rows, 1 host rows, 2 target rows)
+//   kind 0: block pair (p,q) row i;  1: direct b of block p;  2: Schur correction of b;  3: direct diagonal
+#define STRIP_P(w) ((w) & 15u)
+#define STRIP_Q(w) (((w) >> 4) & 15u)
+#define STRIP_I(w) (((w) >> 8) & 7u)
+#define STRIP_K(w) (((w) >> 11) & 15u)
+#define STRIP_SCHUR(w) (((w) >> 15) & 1u)
+#define STRIP_KIND(w) (((w) >> 16) & 3u)
+#define STRIP_SRCP(w) (((w) >> 18) & 3u)
+#define STRIP_SRCQ(w) (((w) >> 20) & 3u)
+#define STRIP_PACK(p, q, i, k, schur, kind, sp, sq) \
+    ((uint32_t)(p) | ((uint32_t)(q) << 4) | ((uint32_t)(i) << 8) | ((uint32_t)(k) << 11) | ((uint32_t)(schur) << 15) | \
+     ((uint32_t)(kind) << 16) | ((uint32_t)(sp) << 18) | ((uint32_t)(sq) << 20))
+// output row word: first strip (16 bits) | number of consecutive strips summed into the row (8 bits)
+#define ROW_FIRST(w) ((w) & 0xffffu)
+#define ROW_NCOPY(w) (((w) >> 16) & 0xffu)
+
+// per-item slab layout (doubles): pair blocks [nbp][36] | b_dir[6nb] | b_corr[6nb] | diag_dir[6nb] | chi | maxh
+__host__ __device__ inline int item_nbp(int nb) { return nb * (nb + 1) / 2; }
+__host__ __device__ inline int item_pair_index(int nb, int p, int q) { return p * nb - p * (p - 1) / 2 + (q - p); }
+__host__ __device__ inline int item_out_count(int nb) { return item_nbp(nb) * 36 + 18 * nb + 2; }
+// per-landmark storage (doubles) kept for back-substitution: w[6nb] | hinv | bl ; field-major inside an item: [field][g]
+__host__ __device__ inline int item_lw_fields(int nb) { return 6 * nb + 2; }
+
+struct LmState {
+    double lambda;               // currentLambda_
+    double chi;                  // currentChi_
+    double ni;                   // ni_
+    double last_chi;             // last_chi_ of Problem::Solve
+    double chi_try;              // tempChi of the last trial
+    double rho;                  // gain ratio of the last trial
+    double scale;
+    double init_chi;
+    int32_t cur;                 // which copy of state/invd/prior is current
+    int32_t accepted;            // result of the last IsGoodStepInLM
+    int32_t stop;
+    int32_t iter;                // outer iterations finished
+    int32_t false_cnt;
+    int32_t trials;
+    int32_t naccepted;
+    int32_t need_linearize;      // 1: the reduced system is stale (a step was accepted)
+    int32_t finite;
+    int32_t max_iter;
+    int32_t stop_reason;
+    int32_t pad_;
+    double chi_trace[128];
+    double lambda_trace[128];
+};
+
+struct DeviceTables {            // everything a kernel needs, passed by value
+    const ItemDesc *items;
+    int32_t n_items;
+    int32_t n_imu_items;         // IMU edges appended to the linearize grid (0 on shards with rank > 0)
+    int32_t Ns;                  // landmarks in sorted order
+    int32_t ext_fixed;
+    int32_t loss_type;
+    int32_t marg_mode;           // 1: Problem::Marginalize assembly (ext free, no fixed masking)
+    double loss_delta;
+    double sqrt_info;
+    double gravity[3];
+    double *state;               // [2][STATE_STRIDE]
+    double *invd;                // [2][Ns]
+    const double *pts_i;         // [Ns][2]
+    const double *pts_j;         // [M][2]
+    double *pairtab;             // [2][PAIRTAB_STRIDE]
+    double *slab;
+    double *lw;
+    double *vis;                 // [VIS_COUNT]
+    const double *pre;           // [10][PRE_STRIDE] packed pre-integrations + information
+    const int32_t *imu_valid;    // [10]
+    double *imu_out;             // [10][IMU_OUT]
+    double *imu_chi_try;         // [10]
+    const uint32_t *strips;      // strip words of all patterns
+    const uint32_t *rows;        // output-row words of all patterns
+    const int16_t *pair_slot;    // [n_items][78]
+    const int8_t *blk_slot;      // [n_items][12]
+    const double *Hprior;        // [171x171]
+    double *bprior;              // [2][176]
+    double *errprior;            // [2][160]
+    const double *Jtinv;         // [156x156]
+    int32_t has_prior;
+    int32_t add_imu_prior;       // 1 on shard rank 0
+    double *Hs;                  // [171x171]
+    double *bs;                  // [171]
+    double *bfull;               // [171] pose part of b_ (direct + imu + prior), for the gain ratio
+    double *diagfull;            // [171] diag(Hessian_) pose part, for lambda_0
+    double *dx;                  // [176] pose part of delta_x_
+    double *dxl;                 // [Ns]  landmark part of delta_x_
+    double *step_part;           // [n_step_blocks][2]
+    int32_t n_step_blocks;
+    int32_t pad_;
+    double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
+    LmState *lm;
+};
+
+// packed pre-integration record (doubles)
+#define PRE_SUMDT 0
+#define PRE_DP 1
+#define PRE_DQ 4
+#define PRE_DV 8
+#define PRE_BA 11
+#define PRE_BG 14
+#define PRE_JAC 17               // 15x15
+#define PRE_INFO (17 + 225)      // 15x15 information = covariance^-1 (computed on the host at upload)
+#define PRE_STRIDE (17 + 450 + 5)
+
+#endif
