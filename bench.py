@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — GN iterations/s of the MI355X sliding-window VIO backend on BASELINE.json's headline config.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks L]
+
+One "step" = one Gauss-Newton iteration of the hot path: linearise all reprojection
++ IMU factors, reduce the landmark Schur complement, add the prior, damped pivoted LDLT of the 171x171 pose
+system, back-substitute the landmarks, update every state, re-evaluate chi2 — `vio_gn_iteration` of
+include/vio_backend.h, enqueued back to back with no host round trip.  Inputs are resident in HBM before the
+timed region starts.
+
+N = 1: the 11-frame / 20 000-landmark / 80 000-observation synthetic window (BASELINE.json configs[2]).
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); every rank holds a 20 000-landmark
+       shard of an (N x 20 000)-landmark window; one all-reduce of the 72x72 reduced visual system per
+       iteration plus one 2-scalar all-reduce per step test.  Weak scaling: `value`
+       counts shard-iterations per second over all ranks.
+
+The JSON line also carries
+  roofline      achieved = algorithmic bytes per launch / measured launch duration of the dominant kernel
+                (HIP events on the library's stream during the timed steps), peak = 8 TB/s HBM
+  cpu_baseline  the oracle's (oracle/vio_oracle.c, plain C, 1 thread) GN iteration on the same window,
+                timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.join(ROOT, "visual-inertial-odometry_amd")
+
+
+def load_package():
+    if "vio_amd" in sys.modules:
+        return sys.modules["vio_amd"]
+    spec = importlib.util.spec_from_file_location(
+        "vio_amd", os.path.join(PKG_DIR, "__init__.py"), submodule_search_locations=[PKG_DIR])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["vio_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# algorithmic bytes of one launch of each kernel, N landmarks / M observations on this GPU
+def kernel_algorithmic_bytes(name, n, m):
+    b_state = 1464
+    b_imu = 10 * (10 + 225 + 225 + 6 + 1) * 8
+    b_sys = (171 * 171 + 171) * 8
+    return {
+        # reads: 2 (x,y) fp64 per observation + per-landmark host (x,y) + inverse depth + 3 int32 of indices per
+        # observation (44 B/obs + 8 B/landmark); writes h_ll/b_l per landmark
+        "k_linearize": 44 * m + 16 * n + b_state + b_imu,
+        "k_reduce": 78 * 36 * 8 * 2,
+        "k_assemble": 2 * b_sys,
+        "k_pose_solve": 2 * b_sys + b_state + 171 * 8,
+        # reads pts (44 B/obs), inverse depth + writes the trial inverse depth and delta per landmark
+        "k_backsub": 44 * m + 24 * n + b_state,
+        "k_lm_decide": 4096,
+    }[name]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--landmarks", type=int, default=20000, help="landmarks per GPU")
+    ap.add_argument("--obs-per-landmark", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=0, help="0 = sized for about 10-20 s")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    vio = load_package()
+    hip = vio.load_hip()        # raises if csrc/libvio_hip.so is missing: no fallback path
+
+    n_per_gpu, k_obs = args.landmarks, args.obs_per_landmark
+    full = vio.synth.make_window(n_per_gpu * world, seed=42, obs_per_landmark=k_obs)
+
+    stream = torch.cuda.current_stream()
+    sb = vio.sharded.ShardedBackend(hip, full, rank, world, dist=dist, torch_device="cuda",
+                                    ctx_kwargs=dict(device=local_rank, stream=stream.cuda_stream))
+    ctx, w = sb.ctx, sb.shard
+    n, m = w.n_landmarks, w.n_observations
+
+    # lambda of the reference's LM start (ComputeLambdaInitLM): identical on every rank after the exchange
+    ctx.linearize()
+    _, lam = ctx.init_lm()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.gn_iteration(lam)
+    ctx.synchronize()
+
+    # which kernel dominates?  one short profiled pass per kernel (outside the timed region)
+    per_kernel = {}
+    for kid, name in enumerate(hip.KERNELS):
+        ctx.profile_begin(kid)
+        for _ in range(10):
+            ctx.gn_iteration(lam)
+        ms, cnt = ctx.profile_end()
+        per_kernel[name] = ms / max(cnt, 1)
+    dominant = max(per_kernel, key=per_kernel.get)
+
+    # timed region: exactly K steps, event pairs around the dominant kernel only
+    ctx.profile_begin(hip.KERNELS.index(dominant))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.gn_iteration(lam)
+    ctx.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    dom_ms, dom_cnt = ctx.profile_end()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    chi2 = ctx.chi2()
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * args.steps / elapsed
+
+    dom_launch_s = (dom_ms / max(dom_cnt, 1)) * 1e-3
+    alg_bytes = kernel_algorithmic_bytes(dominant, n, m)
+    achieved = alg_bytes / dom_launch_s / 1e9 if dom_launch_s > 0 else 0.0
+    traffic = None
+    tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr_path):
+        try:
+            traffic = json.load(open(tr_path)).get(dominant, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "launch_us": round(dom_launch_s * 1e6, 3),
+                "iteration_algorithmic_bytes": vio.synth.algorithmic_bytes(n, m),
+                "iteration_achieved_GBps": round(vio.synth.algorithmic_bytes(n, m) / (ms_per_step * 1e-3) / 1e9, 3),
+                "kernel_us": {k: round(v * 1e3, 3) for k, v in per_kernel.items()}}
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+        orc = vio.VioLib(os.path.join(ROOT, "oracle", "liboracle.so"), "vioo_")
+        co = orc.context()
+        co.load(full)
+        co.gn_iteration(lam)        # warm-up / first touch
+        t = time.perf_counter()
+        co.gn_iteration(lam)
+        one = time.perf_counter() - t
+        steps = args.cpu_baseline_steps or max(3, min(200, int(12.0 / max(one, 1e-3))))
+        t = time.perf_counter()
+        for _ in range(steps):
+            co.gn_iteration(lam)
+        dt = time.perf_counter() - t
+        cpu_baseline = {"value": steps / dt, "unit": "GN iter/s", "cores": 1, "kind": "port",
+                        "ms_per_iter": dt * 1e3 / steps,
+                        "sample": "%d GN iterations of the same %d-landmark / %d-observation window, oracle/vio_oracle.c "
+                                  "(plain C, -O2, 1 thread)" % (steps, n, m)}
+
+    if rank == 0:
+        out = {
+            "metric": "GN iterations/s, 11-frame (10-keyframe) window, 20k landmarks per GPU",
+            "value": value, "unit": "GN iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic 11-frame VIO window (SURVEY.md 8d): %d landmarks x %d observations per GPU, "
+                                   "10 IMU factors, Cauchy loss, extrinsic fixed, fixed-lambda GN iteration"
+                                   % (n_per_gpu, k_obs),
+                       "landmarks_per_gpu": n_per_gpu, "observations_per_gpu": m, "landmarks_total": n_per_gpu * world,
+                       "lambda": lam, "parallelism": "landmark-sharded x%d, all-reduce of the 72x72 reduced system" % world
+                       if world > 1 else "single GPU"},
+            "final_chi2": chi2,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -190,6 +190,22 @@ vio_status vio_exchange_buffers(struct vio_ctx *ctx, void **reduced_system, int6
 typedef int (*vio_exchange_fn)(void *user, int which);
 vio_status vio_set_exchange_hook(struct vio_ctx *ctx, vio_exchange_fn fn, void *user);
 
+/* Optional: make the library use caller-owned device memory for the two exchange buffers (e.g. torch tensors,
+ * so that torch.distributed can all-reduce them in place).  reduced must hold >= the count reported by
+ * vio_exchange_buffers + 8 doubles, scalars >= 8 doubles.  NULL restores the library's own buffer. */
+vio_status vio_bind_exchange_buffers(struct vio_ctx *ctx, void *reduced_system, void *step_scalars);
+
+/* ---- measurement (HIP library only) ------------------------------------------------------------ */
+typedef enum {
+    VIO_K_LINEARIZE = 0, VIO_K_REDUCE = 1, VIO_K_ASSEMBLE = 2, VIO_K_POSE_SOLVE = 3, VIO_K_BACKSUB = 4,
+    VIO_K_LM_DECIDE = 5, VIO_K_COUNT = 6
+} vio_kernel_id;
+/* Wrap every launch of kernel `which` in a hipEvent pair recorded on the context's stream (which < 0: off). */
+vio_status vio_profile_begin(struct vio_ctx *ctx, int32_t which);
+/* Synchronise, sum the elapsed times of the recorded pairs, and stop profiling. */
+vio_status vio_profile_end(struct vio_ctx *ctx, double *total_ms, int64_t *launches);
+const char *vio_kernel_name(int32_t which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,10 @@
 #undef vio_get_pose_gradient
 #undef vio_exchange_buffers
 #undef vio_set_exchange_hook
+#undef vio_bind_exchange_buffers
+#undef vio_profile_begin
+#undef vio_profile_end
+#undef vio_kernel_name
 
 using namespace myslam::backend;
 typedef Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> RowMat;
@@ -486,6 +490,7 @@ vio_status vior_get_pose_hessian(vior_ctx *c, double *Hpp) {
 }
 vio_status vior_exchange_buffers(vior_ctx *, void **, int64_t *, void **, int64_t *) { return VIO_ERR_UNSUPPORTED; }
 vio_status vior_set_exchange_hook(vior_ctx *, vio_exchange_fn, void *) { return VIO_ERR_UNSUPPORTED; }
+vio_status vior_bind_exchange_buffers(vior_ctx *, void *, void *) { return VIO_ERR_UNSUPPORTED; }
 
 /* ---- single pieces of the reference, for the per-function golden vectors -------------------- */
 

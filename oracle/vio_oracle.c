@@ -39,6 +39,15 @@
 #include <string.h>
 #include <time.h>
 
+/* layout of the exchange buffer, identical to the HIP library's (csrc/vio_types.h VIS_*) */
+#define VIS_H 0
+#define VIS_BRED (VIO_CAM_DIM * VIO_CAM_DIM)
+#define VIS_BDIR (VIS_BRED + VIO_CAM_DIM)
+#define VIS_DIAG (VIS_BDIR + VIO_CAM_DIM)
+#define VIS_CHI (VIS_DIAG + VIO_CAM_DIM)
+#define VIS_MAXH (VIS_CHI + 1)
+#define VIS_N (VIS_MAXH + 1 + 6)
+
 #define NF VIO_NUM_FRAMES
 #define PD VIO_POSE_DIM
 #define PRD VIO_PRIOR_DIM
@@ -807,11 +816,19 @@ struct vioo_ctx {
     /* linearisation */
     int linearized;
     double Hpp[PD * PD], bpp[PD];       /* Hessian_ pose block (+prior), b_ pose part */
+    double diagfull[PD];                /* diag(Hessian_) pose part */
     double *hll, *bl, *Hpl;             /* Hmm diagonal, bmm, Hpm column per landmark (CD entries) */
     double Hs[PD * PD], bs[PD];         /* H_pp_schur_ (before lambda), b_pp_schur_ */
     double dx_pose[PD], *dx_lm;
     double lambda, chi, ni;
     double t_hessian_ms;
+    /* multi-shard exchange: the reduced visual system in camera space and the step
+     * scalars are summed over all shards through the caller's hook; IMU + prior terms are replicated */
+    double vis_own[VIS_N], step_own[8];
+    double *vis, *step;
+    double Hv_dir[CD * CD];              /* un-Schur'd visual part (local shard only), for vioo_get_pose_hessian */
+    vio_exchange_fn hook;
+    void *hook_user;
 };
 
 static int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
@@ -840,6 +857,7 @@ vio_status vio_create(const vio_config *cfg, struct vioo_ctx **out) {
     c->cfg = *cfg;
     if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
     c->ni = 2; c->lambda = -1;
+    c->vis = c->vis_own; c->step = c->step_own;
     for (int i = 0; i < NF; ++i) c->pose[7 * i + 6] = 1.0;
     c->ext[6] = 1.0;
     *out = c;
@@ -931,157 +949,198 @@ vio_status vio_set_prior(struct vioo_ctx *c, int32_t dim, const double *H, const
     return VIO_OK;
 }
 
-/* add J_a^T * W * J_b (6x6, J row-major 2x6) into the 171x171 pose block at (ia, ib), and mirror it
+/* add J_a^T * W * J_b (6x6, J row-major 2x6) into the 72x72 camera-space block at (ia, ib), and mirror it
  * (problem.cc:347-355) */
-static void add_pose_block(double *H, int ia, int ib, const double *Ja, const double *W, const double *Jb, int same) {
+static void add_cam_block(double *H, int ia, int ib, const double *Ja, const double *W, const double *Jb, int same) {
     for (int r = 0; r < 6; ++r) {
         double t0 = Ja[r] * W[0] + Ja[6 + r] * W[2];    /* (Ja^T W) row r */
         double t1 = Ja[r] * W[1] + Ja[6 + r] * W[3];
         for (int cc = 0; cc < 6; ++cc) {
             double h = t0 * Jb[cc] + t1 * Jb[6 + cc];
-            H[(ia + r) * PD + ib + cc] += h;
-            if (!same) H[(ib + cc) * PD + ia + r] += h;
+            H[(ia + r) * CD + ib + cc] += h;
+            if (!same) H[(ib + cc) * CD + ia + r] += h;
         }
     }
 }
 
-static void linearize_impl(struct vioo_ctx *c, int marg_mode, double *Hpp, double *bpp) {
-    /* marg_mode: Problem::Marginalize's assembly (problem.cc:641-681): no IsFixed test, only the edges
-     * connected to frame 0; the caller has already restricted the edge set. */
+/* Reprojection edges of this shard (MakeHessian's edge sweep, problem.cc:314-360, restricted to the camera
+ * columns the visual factors touch) followed by the landmark Schur complement (problem.cc:412-429):
+ *   vis.H = Hv - (Hpm*Hmm^-1)*Hmp,  vis.bred = bv - (Hpm*Hmm^-1)*bmm,  vis.bdir = bv,  vis.diag = diag(Hv)
+ * marg_mode: Problem::Marginalize's assembly (problem.cc:641-681): no IsFixed test, only the landmarks hosted
+ * in frame 0 (estimator.cpp:762-764). */
+static void linearize_visual(struct vioo_ctx *c, int marg_mode) {
     const int fixed = marg_mode ? 0 : c->cfg.ext_fixed;
     const double s = c->cfg.reproj_sqrt_info, info = s * s;
-    memset(Hpp, 0, sizeof(double) * PD * PD); memset(bpp, 0, sizeof(double) * PD);
+    double *Hv = c->Hv_dir;
+    double bv[CD];
+    memset(Hv, 0, sizeof(double) * CD * CD); memset(bv, 0, sizeof(bv));
     for (int64_t l = 0; l < c->N; ++l) { c->hll[l] = 0; c->bl[l] = 0; }
     memset(c->Hpl, 0, sizeof(double) * (size_t)(c->N > 0 ? c->N : 1) * CD);
-
+    double chi = 0, maxh = 0;
     for (int64_t e = 0; e < c->M; ++e) {
         int l = c->lm[e], fi = c->host[e], fj = c->target[e];
-        if (marg_mode && fi != 0) continue;     /* MargOldFrame adds only landmarks hosted in frame 0 (estimator.cpp:762-764) */
+        if (marg_mode && fi != 0) continue;
         double r[2], Jl[2], Ji[12], Jj[12], Je[12], W[4], drho;
         vioo_reproj_edge(&c->pose[7 * fi], &c->pose[7 * fj], c->ext, c->invd[l], &c->pts_i[2 * e], &c->pts_j[2 * e],
                          r, Jl, Ji, Jj, Je);
         vioo_robust_info2(c->cfg.loss_type, c->cfg.loss_delta, s, r, &drho, W);
-        int ii = 6 + 15 * fi, ij = 6 + 15 * fj;
-        /* landmark-landmark */
+        chi += robust_chi2_2(c->cfg.loss_type, c->cfg.loss_delta, s, r);
+        int ii = 6 + 6 * fi, ij = 6 + 6 * fj;
         c->hll[l] += (Jl[0] * W[0] + Jl[1] * W[2]) * Jl[0] + (Jl[0] * W[1] + Jl[1] * W[3]) * Jl[1];
-        /* landmark-pose (Hmp row == Hpm column since W is symmetric) */
         double t0 = Jl[0] * W[0] + Jl[1] * W[2], t1 = Jl[0] * W[1] + Jl[1] * W[3];
-        double *w = &c->Hpl[(size_t)l * CD];
+        double *w = &c->Hpl[(size_t)l * CD];       /* Hmp row == Hpm column (W symmetric) */
         for (int k = 0; k < 6; ++k) {
-            w[6 + 6 * fi + k] += t0 * Ji[k] + t1 * Ji[6 + k];
-            w[6 + 6 * fj + k] += t0 * Jj[k] + t1 * Jj[6 + k];
+            w[ii + k] += t0 * Ji[k] + t1 * Ji[6 + k];
+            w[ij + k] += t0 * Jj[k] + t1 * Jj[6 + k];
             if (!fixed) w[k] += t0 * Je[k] + t1 * Je[6 + k];
         }
-        /* pose-pose in the edge's vertex order (landmark, pose_i, pose_j, ext), j >= i */
-        add_pose_block(Hpp, ii, ii, Ji, W, Ji, 1);
-        add_pose_block(Hpp, ii, ij, Ji, W, Jj, 0);
-        if (!fixed) add_pose_block(Hpp, ii, 0, Ji, W, Je, 0);
-        add_pose_block(Hpp, ij, ij, Jj, W, Jj, 1);
-        if (!fixed) add_pose_block(Hpp, ij, 0, Jj, W, Je, 0);
-        if (!fixed) add_pose_block(Hpp, 0, 0, Je, W, Je, 1);
+        /* pose-pose blocks in the edge's vertex order (landmark, pose_i, pose_j, ext), j >= i */
+        add_cam_block(Hv, ii, ii, Ji, W, Ji, 1);
+        add_cam_block(Hv, ii, ij, Ji, W, Jj, 0);
+        if (!fixed) add_cam_block(Hv, ii, 0, Ji, W, Je, 0);
+        add_cam_block(Hv, ij, ij, Jj, W, Jj, 1);
+        if (!fixed) add_cam_block(Hv, ij, 0, Jj, W, Je, 0);
+        if (!fixed) add_cam_block(Hv, 0, 0, Je, W, Je, 1);
         /* b -= drho * J^T * Information * r  (problem.cc:357) */
         double ir0 = info * r[0], ir1 = info * r[1];
         c->bl[l] -= drho * (Jl[0] * ir0 + Jl[1] * ir1);
         for (int k = 0; k < 6; ++k) {
-            bpp[ii + k] -= drho * (Ji[k] * ir0 + Ji[6 + k] * ir1);
-            bpp[ij + k] -= drho * (Jj[k] * ir0 + Jj[6 + k] * ir1);
-            if (!fixed) bpp[k] -= drho * (Je[k] * ir0 + Je[6 + k] * ir1);
+            bv[ii + k] -= drho * (Ji[k] * ir0 + Ji[6 + k] * ir1);
+            bv[ij + k] -= drho * (Jj[k] * ir0 + Jj[6 + k] * ir1);
+            if (!fixed) bv[k] -= drho * (Je[k] * ir0 + Je[6 + k] * ir1);
         }
     }
-    /* IMU edges: vertex order (pose_i, sb_i, pose_j, sb_j) = 30 contiguous columns from 6+15*i */
-    if (c->cfg.shard_rank == 0) {
-        for (int k = 0; k < VIO_WINDOW_SIZE; ++k) {
-            if (!c->imu_valid[k]) continue;
-            if (marg_mode && k != 0) continue;  /* only pre_integrations[1] (estimator.cpp:735-747) */
-            double r[15], Jpi[90], Jsi[135], Jpj[90], Jsj[135], J[15 * 30];
-            vioo_imu_edge(&c->pre[k], c->cfg.gravity, &c->pose[7 * k], &c->sb[9 * k], &c->pose[7 * (k + 1)],
-                          &c->sb[9 * (k + 1)], r, Jpi, Jsi, Jpj, Jsj);
-            for (int i = 0; i < 15; ++i) {
-                for (int j = 0; j < 6; ++j) { J[30 * i + j] = Jpi[6 * i + j]; J[30 * i + 15 + j] = Jpj[6 * i + j]; }
-                for (int j = 0; j < 9; ++j) { J[30 * i + 6 + j] = Jsi[9 * i + j]; J[30 * i + 21 + j] = Jsj[9 * i + j]; }
-            }
-            const double *I = c->imu_info[k];
-            double JtI[30 * 15], T[30 * 30], Ir[15];
-            for (int a = 0; a < 30; ++a)
-                for (int j = 0; j < 15; ++j) {
-                    double sum = 0;
-                    for (int i = 0; i < 15; ++i) sum += J[30 * i + a] * I[15 * i + j];
-                    JtI[15 * a + j] = sum;
-                }
-            for (int a = 0; a < 30; ++a)
-                for (int b2 = 0; b2 < 30; ++b2) {
-                    double sum = 0;
-                    for (int j = 0; j < 15; ++j) sum += JtI[15 * a + j] * J[30 * j + b2];
-                    T[30 * a + b2] = sum;
-                }
-            /* vertex blocks: [0,6) [6,15) [15,21) [21,30): upper blocks computed, lower mirrored (problem.cc:347-355) */
-            static const int bs[5] = {0, 6, 15, 21, 30};
-            int base = 6 + 15 * k;
-            for (int bi = 0; bi < 4; ++bi)
-                for (int bj = bi; bj < 4; ++bj)
-                    for (int a = bs[bi]; a < bs[bi + 1]; ++a)
-                        for (int b2 = bs[bj]; b2 < bs[bj + 1]; ++b2) {
-                            Hpp[(base + a) * PD + base + b2] += T[30 * a + b2];
-                            if (bi != bj) Hpp[(base + b2) * PD + base + a] += T[30 * a + b2];
-                        }
-            for (int i = 0; i < 15; ++i) { double sum = 0; for (int j = 0; j < 15; ++j) sum += I[15 * i + j] * r[j]; Ir[i] = sum; }
-            for (int a = 0; a < 30; ++a) {
+    /* Schur terms, landmarks in index order */
+    double *S = (double *)calloc(CD * CD, sizeof(double));
+    double sb[CD];
+    memset(sb, 0, sizeof(sb));
+    for (int64_t l = 0; l < c->N; ++l) {
+        const double *w = &c->Hpl[(size_t)l * CD];
+        if (marg_mode && c->hll[l] == 0.0) continue;       /* landmark not in the marginalisation graph */
+        maxh = fmax(maxh, fabs(c->hll[l]));
+        double hinv = 1.0 / c->hll[l];                      /* Hmm_inv (problem.cc:419-425) */
+        int nzc[CD], nn = 0;
+        for (int a = 0; a < CD; ++a) if (w[a] != 0.0) nzc[nn++] = a;
+        for (int x = 0; x < nn; ++x) {
+            double ta = w[nzc[x]] * hinv;                   /* tempH = Hpm * Hmm_inv (problem.cc:427) */
+            for (int y = 0; y < nn; ++y) S[nzc[x] * CD + nzc[y]] += ta * w[nzc[y]];
+            sb[nzc[x]] += ta * c->bl[l];
+        }
+    }
+    for (int a = 0; a < CD; ++a) {
+        for (int b2 = 0; b2 < CD; ++b2) c->vis[VIS_H + a * CD + b2] = Hv[a * CD + b2] - S[a * CD + b2];
+        c->vis[VIS_BRED + a] = bv[a] - sb[a];
+        c->vis[VIS_BDIR + a] = bv[a];
+        c->vis[VIS_DIAG + a] = Hv[a * CD + a];
+    }
+    c->vis[VIS_CHI] = chi;
+    c->vis[VIS_MAXH] = maxh;
+    free(S);
+}
+
+/* IMU edges (replicated on every shard): vertex order (pose_i, sb_i, pose_j, sb_j) = 30 contiguous columns from
+ * 6+15*i.  Adds J^T Info J into H (upper vertex blocks computed, lower mirrored: problem.cc:347-355) and
+ * -J^T Info r into b. */
+static void add_imu_terms(struct vioo_ctx *c, int marg_mode, double *H, double *b1, double *b2, double *diag) {
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) {
+        if (!c->imu_valid[k]) continue;
+        if (marg_mode && k != 0) continue;  /* only pre_integrations[1] (estimator.cpp:735-747) */
+        double r[15], Jpi[90], Jsi[135], Jpj[90], Jsj[135], J[15 * 30];
+        vioo_imu_edge(&c->pre[k], c->cfg.gravity, &c->pose[7 * k], &c->sb[9 * k], &c->pose[7 * (k + 1)],
+                      &c->sb[9 * (k + 1)], r, Jpi, Jsi, Jpj, Jsj);
+        for (int i = 0; i < 15; ++i) {
+            for (int j = 0; j < 6; ++j) { J[30 * i + j] = Jpi[6 * i + j]; J[30 * i + 15 + j] = Jpj[6 * i + j]; }
+            for (int j = 0; j < 9; ++j) { J[30 * i + 6 + j] = Jsi[9 * i + j]; J[30 * i + 21 + j] = Jsj[9 * i + j]; }
+        }
+        const double *I = c->imu_info[k];
+        double JtI[30 * 15], T[30 * 30], Ir[15];
+        for (int a = 0; a < 30; ++a)
+            for (int j = 0; j < 15; ++j) {
                 double sum = 0;
-                for (int i = 0; i < 15; ++i) sum += J[30 * i + a] * Ir[i];
-                bpp[base + a] -= 1.0 * sum;
+                for (int i = 0; i < 15; ++i) sum += J[30 * i + a] * I[15 * i + j];
+                JtI[15 * a + j] = sum;
             }
+        for (int a = 0; a < 30; ++a)
+            for (int b = 0; b < 30; ++b) {
+                double sum = 0;
+                for (int j = 0; j < 15; ++j) sum += JtI[15 * a + j] * J[30 * j + b];
+                T[30 * a + b] = sum;
+            }
+        static const int bs[5] = {0, 6, 15, 21, 30};
+        int base = 6 + 15 * k;
+        for (int bi = 0; bi < 4; ++bi)
+            for (int bj = bi; bj < 4; ++bj)
+                for (int a = bs[bi]; a < bs[bi + 1]; ++a)
+                    for (int b = bs[bj]; b < bs[bj + 1]; ++b) {
+                        H[(base + a) * PD + base + b] += T[30 * a + b];
+                        if (bi != bj) H[(base + b) * PD + base + a] += T[30 * a + b];
+                        if (diag && a == b) diag[base + a] += T[30 * a + b];
+                    }
+        for (int i = 0; i < 15; ++i) { double sum = 0; for (int j = 0; j < 15; ++j) sum += I[15 * i + j] * r[j]; Ir[i] = sum; }
+        for (int a = 0; a < 30; ++a) {
+            double sum = 0;
+            for (int i = 0; i < 15; ++i) sum += J[30 * i + a] * Ir[i];
+            b1[base + a] -= 1.0 * sum;
+            if (b2) b2[base + a] -= 1.0 * sum;
         }
     }
 }
 
-/* SetOrdering + MakeHessian, problem.cc:256-285,303-389 */
+static int run_hook(struct vioo_ctx *c, int which) {
+    return c->hook ? c->hook(c->hook_user, which) : 0;
+}
+
+/* SetOrdering + MakeHessian (problem.cc:256-285,303-389) + the lambda-free part of SolveLinearSystem (:412-429) */
 vio_status vio_linearize(struct vioo_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
     double t0 = now_ms();
-    linearize_impl(c, 0, c->Hpp, c->bpp);
+    linearize_visual(c, 0);
+    if (run_hook(c, 0) != 0) return VIO_ERR_HIP;        /* sum of vis[0 .. VIS_MAXH) over the shards */
+    /* H_pp_schur_ (no lambda) = reduced visual + IMU + prior; b_pp_schur_; pose part of b_; diag(Hessian_) */
+    memset(c->Hs, 0, sizeof(c->Hs)); memset(c->bs, 0, sizeof(c->bs)); memset(c->bpp, 0, sizeof(c->bpp));
+    double diag[PD];
+    memset(diag, 0, sizeof(diag));
+    for (int a = 0; a < CD; ++a) {
+        int fa = cam_to_full(a);
+        for (int b2 = 0; b2 < CD; ++b2) c->Hs[fa * PD + cam_to_full(b2)] = c->vis[VIS_H + a * CD + b2];
+        c->bs[fa] = c->vis[VIS_BRED + a];
+        c->bpp[fa] = c->vis[VIS_BDIR + a];
+        diag[fa] = c->vis[VIS_DIAG + a];
+    }
+    double *R = (double *)calloc(PD * PD, sizeof(double));      /* IMU + prior part */
+    double rb[PD];
+    memset(rb, 0, sizeof(rb));
+    add_imu_terms(c, 0, R, rb, NULL, NULL);
     c->t_hessian_ms += now_ms() - t0;
     /* prior, with the rows/cols of fixed pose vertices zeroed (problem.cc:365-384) */
-    if (c->cfg.shard_rank == 0) {
-        for (int i = 0; i < PD; ++i) {
-            int fi = c->cfg.ext_fixed && i < 6;
-            for (int j = 0; j < PD; ++j) {
-                int fj = c->cfg.ext_fixed && j < 6;
-                c->Hpp[i * PD + j] += (fi || fj) ? 0.0 : c->Hprior[i * PD + j];
-            }
-            c->bpp[i] += fi ? 0.0 : c->bprior[i];
+    for (int i = 0; i < PD; ++i) {
+        int fi = c->cfg.ext_fixed && i < 6;
+        for (int j = 0; j < PD; ++j) {
+            int fj = c->cfg.ext_fixed && j < 6;
+            R[i * PD + j] += (fi || fj) ? 0.0 : c->Hprior[i * PD + j];
         }
+        rb[i] += fi ? 0.0 : c->bprior[i];
     }
-    /* Schur system without lambda: Hpp - (Hpm*Hmm^-1)*Hmp, bpp - (Hpm*Hmm^-1)*bmm  (problem.cc:412-429) */
-    memcpy(c->Hs, c->Hpp, sizeof(c->Hs)); memcpy(c->bs, c->bpp, sizeof(c->bs));
-    {
-        double *S = (double *)calloc(CD * CD, sizeof(double));
-        double sb[CD];
-        memset(sb, 0, sizeof(sb));
-        for (int64_t l = 0; l < c->N; ++l) {
-            const double *w = &c->Hpl[(size_t)l * CD];
-            double hinv = 1.0 / c->hll[l];
-            int nzc[CD], nn = 0;
-            for (int a = 0; a < CD; ++a) if (w[a] != 0.0) nzc[nn++] = a;
-            for (int x = 0; x < nn; ++x) {
-                double ta = w[nzc[x]] * hinv;                     /* tempH entry */
-                for (int y = 0; y < nn; ++y) S[nzc[x] * CD + nzc[y]] += ta * w[nzc[y]];
-                sb[nzc[x]] += ta * c->bl[l];
-            }
-        }
-        for (int a = 0; a < CD; ++a) {
-            int fa = cam_to_full(a);
-            for (int b2 = 0; b2 < CD; ++b2) c->Hs[fa * PD + cam_to_full(b2)] -= S[a * CD + b2];
-            c->bs[fa] -= sb[a];
-        }
-        free(S);
+    for (int i = 0; i < PD; ++i) {
+        for (int j = 0; j < PD; ++j) c->Hs[i * PD + j] += R[i * PD + j];
+        c->bs[i] += rb[i];
+        c->bpp[i] += rb[i];
+        diag[i] += R[i * PD + i];
     }
+    /* Hpp is only its diagonal plus the local shard's un-Schur'd visual blocks; see vioo_get_pose_hessian */
+    memcpy(c->Hpp, R, sizeof(c->Hpp));
+    for (int a = 0; a < CD; ++a)
+        for (int b2 = 0; b2 < CD; ++b2) c->Hpp[cam_to_full(a) * PD + cam_to_full(b2)] += c->Hv_dir[a * CD + b2];
+    memcpy(c->diagfull, diag, sizeof(diag));
+    free(R);
     memset(c->dx_pose, 0, sizeof(c->dx_pose));
     for (int64_t l = 0; l < c->N; ++l) c->dx_lm[l] = 0;
     c->linearized = 1;
     return VIO_OK;
 }
 
-static double chi2_now(struct vioo_ctx *c) {
+/* sum of RobustChi2 over this shard's reprojection edges */
+static double chi2_visual(struct vioo_ctx *c) {
     const double s = c->cfg.reproj_sqrt_info;
     double chi = 0;
     for (int64_t e = 0; e < c->M; ++e) {
@@ -1090,40 +1149,55 @@ static double chi2_now(struct vioo_ctx *c) {
                          &c->pts_i[2 * e], &c->pts_j[2 * e], r, NULL, NULL, NULL, NULL);
         chi += robust_chi2_2(c->cfg.loss_type, c->cfg.loss_delta, s, r);
     }
-    if (c->cfg.shard_rank == 0) {
-        for (int k = 0; k < VIO_WINDOW_SIZE; ++k) {
-            if (!c->imu_valid[k]) continue;
-            double r[15];
-            vioo_imu_edge(&c->pre[k], c->cfg.gravity, &c->pose[7 * k], &c->sb[9 * k], &c->pose[7 * (k + 1)],
-                          &c->sb[9 * (k + 1)], r, NULL, NULL, NULL, NULL);
-            const double *I = c->imu_info[k];
-            double e2 = 0;
-            for (int i = 0; i < 15; ++i) { double t = 0; for (int j = 0; j < 15; ++j) t += I[15 * i + j] * r[j]; e2 += r[i] * t; }
-            chi += e2;
-        }
-        if (c->has_prior) {
-            double n2 = 0;
-            for (int i = 0; i < PRD; ++i) n2 += c->errprior[i] * c->errprior[i];
-            chi += sqrt(n2);            /* err_prior_.norm(), NOT squared (problem.cc:505-507,554-556) */
-        }
+    return chi;
+}
+
+/* IMU + prior part of chi2 (replicated) */
+static double chi2_imu_prior(struct vioo_ctx *c) {
+    double chi = 0;
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) {
+        if (!c->imu_valid[k]) continue;
+        double r[15];
+        vioo_imu_edge(&c->pre[k], c->cfg.gravity, &c->pose[7 * k], &c->sb[9 * k], &c->pose[7 * (k + 1)],
+                      &c->sb[9 * (k + 1)], r, NULL, NULL, NULL, NULL);
+        const double *I = c->imu_info[k];
+        double e2 = 0;
+        for (int i = 0; i < 15; ++i) { double t = 0; for (int j = 0; j < 15; ++j) t += I[15 * i + j] * r[j]; e2 += r[i] * t; }
+        chi += e2;
     }
-    return 0.5 * chi;
+    if (c->has_prior) {
+        double n2 = 0;
+        for (int i = 0; i < PRD; ++i) n2 += c->errprior[i] * c->errprior[i];
+        chi += sqrt(n2);            /* err_prior_.norm(), NOT squared (problem.cc:505-507,554-556) */
+    }
+    return chi;
+}
+
+/* 0.5*(sum RobustChi2 + ||err_prior||) at the current states; scale_lm rides along in the second slot */
+static vio_status chi2_exchange(struct vioo_ctx *c, double scale_lm, double *chi_out, double *scale_out) {
+    c->step[0] = chi2_visual(c);
+    c->step[1] = scale_lm;
+    if (run_hook(c, 1) != 0) return VIO_ERR_HIP;
+    *chi_out = 0.5 * (c->step[0] + chi2_imu_prior(c));
+    if (scale_out) *scale_out = c->step[1];
+    return VIO_OK;
 }
 
 vio_status vio_chi2(struct vioo_ctx *c, double *chi2) {
     if (!c || !chi2) return VIO_ERR_BAD_ARG;
-    *chi2 = chi2_now(c);
-    return VIO_OK;
+    return chi2_exchange(c, 0.0, chi2, NULL);
 }
 
 /* ComputeLambdaInitLM, problem.cc:497-522 */
 vio_status vio_init_lm(struct vioo_ctx *c, double *chi2, double *lambda) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
     c->ni = 2.;
-    c->chi = chi2_now(c);
-    double maxd = 0;
-    for (int i = 0; i < PD; ++i) maxd = fmax(fabs(c->Hpp[i * PD + i]), maxd);
-    for (int64_t l = 0; l < c->N; ++l) maxd = fmax(fabs(c->hll[l]), maxd);
+    /* chi2 at the linearisation point: the visual sum travelled with the reduced system */
+    c->chi = 0.5 * (c->vis[VIS_CHI] + chi2_imu_prior(c));
+    c->step[2] = c->vis[VIS_MAXH];
+    if (run_hook(c, 2) != 0) return VIO_ERR_HIP;        /* max of step[2] over the shards */
+    double maxd = c->step[2];
+    for (int i = 0; i < PD; ++i) maxd = fmax(fabs(c->diagfull[i]), maxd);
     maxd = fmin(5e10, maxd);
     c->lambda = 1e-5 * maxd;
     if (chi2) *chi2 = c->chi;
@@ -1188,12 +1262,14 @@ vio_status vio_rollback_states(struct vioo_ctx *c) {
 /* IsGoodStepInLM, problem.cc:541-573 */
 vio_status vio_eval_step(struct vioo_ctx *c, int32_t *accepted, double *chi2, double *lambda) {
     if (!c) return VIO_ERR_BAD_ARG;
-    double scale = 0;
+    double scale_lm = 0, scale = 0;
+    for (int64_t l = 0; l < c->N; ++l) scale_lm += c->dx_lm[l] * (c->lambda * c->dx_lm[l] + c->bl[l]);
+    double tempChi;
+    vio_status st = chi2_exchange(c, scale_lm, &tempChi, &scale_lm);
+    if (st != VIO_OK) return st;
     for (int i = 0; i < PD; ++i) scale += c->dx_pose[i] * (c->lambda * c->dx_pose[i] + c->bpp[i]);
-    for (int64_t l = 0; l < c->N; ++l) scale += c->dx_lm[l] * (c->lambda * c->dx_lm[l] + c->bl[l]);
-    scale = 0.5 * scale;
+    scale = 0.5 * (scale + scale_lm);
     scale += 1e-6;
-    double tempChi = chi2_now(c);
     double rho = (c->chi - tempChi) / scale;
     int ok;
     if (rho > 0 && isfinite(tempChi)) {
@@ -1259,8 +1335,7 @@ vio_status vio_gn_iteration(struct vioo_ctx *c, double lambda) {
     vio_linearize(c);
     vio_solve_linear(c, lambda);
     vio_update_states(c);
-    c->chi = chi2_now(c);
-    return VIO_OK;
+    return chi2_exchange(c, 0.0, &c->chi, NULL);
 }
 
 vio_status vio_synchronize(struct vioo_ctx *c) { return c ? VIO_OK : VIO_ERR_BAD_ARG; }
@@ -1287,6 +1362,42 @@ static void move_to_bottom(double *H, double *b, int n, int idx, int dim) {
     free(T);
 }
 
+/* Schur complement of the trailing m2 x m2 block through an eigen-decomposition pseudo-inverse with the 1e-8
+ * cut (problem.cc:747-764; the same lines in A/15-vio-backend's TestMarginalize): H is n x n row-major,
+ * Hp (n-m2)x(n-m2), bp n-m2.  b may be NULL. */
+void vioo_schur_pinv(int n, int m2, const double *H, const double *b, double *Hp, double *bp) {
+    const int n2 = n - m2;
+    const double eps = 1e-8;
+    double *Amm = (double *)malloc(sizeof(double) * m2 * m2), *ev = (double *)malloc(sizeof(double) * m2);
+    double *V = (double *)malloc(sizeof(double) * m2 * m2), *Ainv = (double *)malloc(sizeof(double) * m2 * m2);
+    double *tempB = (double *)malloc(sizeof(double) * (n2 > 0 ? n2 : 1) * m2);
+    for (int i = 0; i < m2; ++i) for (int j = 0; j < m2; ++j) Amm[i * m2 + j] = 0.5 * (H[(n2 + i) * n + n2 + j] + H[(n2 + j) * n + n2 + i]);
+    vioo_symmetric_eigen(m2, Amm, ev, V);
+    for (int i = 0; i < m2; ++i) for (int j = 0; j < m2; ++j) {
+        double s = 0;
+        for (int k = 0; k < m2; ++k) s += V[i * m2 + k] * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V[j * m2 + k];
+        Ainv[i * m2 + j] = s;
+    }
+    for (int i = 0; i < n2; ++i) for (int j = 0; j < m2; ++j) {
+        double s = 0;
+        for (int k = 0; k < m2; ++k) s += H[i * n + n2 + k] * Ainv[k * m2 + j];
+        tempB[i * m2 + j] = s;
+    }
+    for (int i = 0; i < n2; ++i) {
+        for (int j = 0; j < n2; ++j) {
+            double s = 0;
+            for (int k = 0; k < m2; ++k) s += tempB[i * m2 + k] * H[(n2 + k) * n + j];
+            Hp[i * n2 + j] = H[i * n + j] - s;
+        }
+        if (b && bp) {
+            double s = 0;
+            for (int k = 0; k < m2; ++k) s += tempB[i * m2 + k] * b[n2 + k];
+            bp[i] = b[i] - s;
+        }
+    }
+    free(Amm); free(ev); free(V); free(Ainv); free(tempB);
+}
+
 vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, double *bout, double *errout, double *jtout) {
     if (!c || !Hout || !bout || !errout || !jtout) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
@@ -1295,28 +1406,15 @@ vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, doubl
     double b[PD];
     memset(b, 0, sizeof(b));
     if (kind == VIO_MARG_OLD) {
-        linearize_impl(c, 1, H, b);
-        /* Schur out the landmarks hosted in frame 0 (problem.cc:685-708) */
-        double *S = (double *)calloc(CD * CD, sizeof(double));
-        double sb[CD];
-        memset(sb, 0, sizeof(sb));
-        for (int64_t l = 0; l < c->N; ++l) {
-            const double *w = &c->Hpl[(size_t)l * CD];
-            if (c->hll[l] == 0.0) continue;     /* landmark not part of the marginalisation graph */
-            double hinv = 1.0 / c->hll[l];
-            for (int a = 0; a < CD; ++a) {
-                if (w[a] == 0.0) continue;
-                double ta = w[a] * hinv;
-                for (int b2 = 0; b2 < CD; ++b2) S[a * CD + b2] += ta * w[b2];
-                sb[a] += ta * c->bl[l];
-            }
-        }
+        /* edges connected to frame 0 (problem.cc:621-681), landmarks Schur-ed out (:685-708) */
+        linearize_visual(c, 1);
+        if (run_hook(c, 0) != 0) { free(H); return VIO_ERR_HIP; }      /* shards: sum the partial Schur systems */
         for (int a = 0; a < CD; ++a) {
             int fa = cam_to_full(a);
-            for (int b2 = 0; b2 < CD; ++b2) H[fa * n + cam_to_full(b2)] -= S[a * CD + b2];
-            b[fa] -= sb[a];
+            for (int b2 = 0; b2 < CD; ++b2) H[fa * n + cam_to_full(b2)] = c->vis[VIS_H + a * CD + b2];
+            b[fa] = c->vis[VIS_BRED + a];
         }
-        free(S);
+        add_imu_terms(c, 1, H, b, NULL, NULL);
         c->linearized = 0;      /* hll/bl/Hpl now hold the marginalisation graph's values */
     }
     /* += prior (no fixed-vertex zeroing here, problem.cc:710-715) */
@@ -1327,33 +1425,10 @@ vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, doubl
     move_to_bottom(H, b, n, 12 + 15 * f, 9);
     move_to_bottom(H, b, n, 6 + 15 * f, 6);
     const int m2 = 15, n2 = n - 15;
-    double Amm[15 * 15], ev[15], V[15 * 15], Amm_inv[15 * 15];
-    for (int i = 0; i < m2; ++i) for (int j = 0; j < m2; ++j) Amm[i * m2 + j] = 0.5 * (H[(n2 + i) * n + n2 + j] + H[(n2 + j) * n + n2 + i]);
-    vioo_symmetric_eigen(m2, Amm, ev, V);
-    const double eps = 1e-8;
-    for (int i = 0; i < m2; ++i) for (int j = 0; j < m2; ++j) {
-        double s = 0;
-        for (int k = 0; k < m2; ++k) s += V[i * m2 + k] * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V[j * m2 + k];
-        Amm_inv[i * m2 + j] = s;
-    }
-    double *tempB = (double *)malloc(sizeof(double) * n2 * m2);
-    for (int i = 0; i < n2; ++i) for (int j = 0; j < m2; ++j) {
-        double s = 0;
-        for (int k = 0; k < m2; ++k) s += H[i * n + n2 + k] * Amm_inv[k * m2 + j];
-        tempB[i * m2 + j] = s;
-    }
     double *Hp = (double *)malloc(sizeof(double) * n2 * n2);
     double bp[PRD];
-    for (int i = 0; i < n2; ++i) {
-        for (int j = 0; j < n2; ++j) {
-            double s = 0;
-            for (int k = 0; k < m2; ++k) s += tempB[i * m2 + k] * H[(n2 + k) * n + j];
-            Hp[i * n2 + j] = H[i * n + j] - s;
-        }
-        double s = 0;
-        for (int k = 0; k < m2; ++k) s += tempB[i * m2 + k] * b[n2 + k];
-        bp[i] = b[i] - s;
-    }
+    const double eps = 1e-8;
+    vioo_schur_pinv(n, m2, H, b, Hp, bp);
     double *ev2 = (double *)malloc(sizeof(double) * n2);
     double *V2 = (double *)malloc(sizeof(double) * n2 * n2);
     vioo_symmetric_eigen(n2, Hp, ev2, V2);
@@ -1376,7 +1451,7 @@ vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, doubl
         Hout[i * n2 + j] = fabs(s) > 1e-9 ? s : 0.0;
     }
     memcpy(bout, bp, sizeof(double) * n2);
-    free(H); free(tempB); free(Hp); free(ev2); free(V2);
+    free(H); free(Hp); free(ev2); free(V2);
     return VIO_OK;
 }
 
@@ -1422,7 +1497,7 @@ vio_status vio_get_landmark_system(struct vioo_ctx *c, int64_t n, double *hll, d
 vio_status vio_get_pose_gradient(struct vioo_ctx *c, double *b, double *diag) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
     if (b) memcpy(b, c->bpp, sizeof(c->bpp));
-    if (diag) for (int i = 0; i < PD; ++i) diag[i] = c->Hpp[i * PD + i];
+    if (diag) memcpy(diag, c->diagfull, sizeof(c->diagfull));
     return VIO_OK;
 }
 vio_status vioo_get_pose_hessian(struct vioo_ctx *c, double *Hpp) {
@@ -1431,10 +1506,22 @@ vio_status vioo_get_pose_hessian(struct vioo_ctx *c, double *Hpp) {
     return VIO_OK;
 }
 vio_status vio_exchange_buffers(struct vioo_ctx *c, void **a, int64_t *na, void **b, int64_t *nb) {
-    (void)c; (void)a; (void)na; (void)b; (void)nb;
-    return VIO_ERR_UNSUPPORTED;
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (a) *a = c->vis;
+    if (na) *na = VIS_MAXH;
+    if (b) *b = c->step;
+    if (nb) *nb = 2;
+    return VIO_OK;
 }
 vio_status vio_set_exchange_hook(struct vioo_ctx *c, vio_exchange_fn fn, void *user) {
-    (void)c; (void)fn; (void)user;
-    return VIO_ERR_UNSUPPORTED;
+    if (!c) return VIO_ERR_BAD_ARG;
+    c->hook = fn; c->hook_user = user;
+    return VIO_OK;
+}
+vio_status vio_bind_exchange_buffers(struct vioo_ctx *c, void *reduced, void *scalars) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    c->vis = reduced ? (double *)reduced : c->vis_own;
+    c->step = scalars ? (double *)scalars : c->step_own;
+    c->linearized = 0;
+    return VIO_OK;
 }

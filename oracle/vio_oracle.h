@@ -39,6 +39,10 @@
 #define vio_get_pose_gradient vioo_get_pose_gradient
 #define vio_exchange_buffers vioo_exchange_buffers
 #define vio_set_exchange_hook vioo_set_exchange_hook
+#define vio_bind_exchange_buffers vioo_bind_exchange_buffers
+#define vio_profile_begin vioo_profile_begin
+#define vio_profile_end vioo_profile_end
+#define vio_kernel_name vioo_kernel_name
 #include "../include/vio_backend.h"
 
 #ifdef __cplusplus
@@ -84,6 +88,9 @@ int vioo_symmetric_eigen(int n, const double *A, double *evals, double *V);
 void vioo_preintegrate(const double *acc0, const double *gyr0, const double *ba, const double *bg,
                        int count, const double *dt, const double *acc, const double *gyr,
                        double acc_n, double gyr_n, double acc_w, double gyr_w, vio_preint *out);
+
+/* Schur complement of the trailing m2 x m2 block with the eigen pseudo-inverse of problem.cc:747-764 */
+void vioo_schur_pinv(int n, int m2, const double *H, const double *b, double *Hp, double *bp);
 
 /* dense pose block of Hessian_ incl. prior (171x171) — oracle only, the HIP path never forms it */
 vio_status vioo_get_pose_hessian(struct vioo_ctx *ctx, double *Hpp);

@@ -1,0 +1,108 @@
+"""CPU tests of the boundary and the host logic: the C-ABI library loads and exports every symbol the header
+declares, the synthetic generator produces what the ABI takes, sharding partitions the landmarks."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "vio_backend.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(vio_[a-z0-9_]+)\s*\(", txt))
+    names.discard("vio_exchange_fn")
+    return sorted(names)
+
+
+def test_header_declares_the_reference_call_sequence():
+    fns = header_functions()
+    for need in ("vio_create", "vio_set_window", "vio_set_landmarks", "vio_set_observations", "vio_set_imu",
+                 "vio_set_prior", "vio_solve", "vio_marginalize", "vio_get_window", "vio_get_prior", "vio_destroy"):
+        assert need in fns
+
+
+def test_hip_library_exports_every_declared_symbol(vio):
+    """No compute call here (there is no GPU in the CPU tier): only that the product library exists, loads and
+    resolves each prototype of include/vio_backend.h."""
+    lib = C.CDLL(vio.HIP_LIB)
+    missing = [f for f in header_functions() if not hasattr(lib, f)]
+    assert not missing, missing
+
+
+def test_hip_library_fails_loudly_without_a_gpu(vio):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = vio.load_hip()
+    with pytest.raises(vio.VioError) as e:
+        lib.context()
+    assert e.value.status in (-6, -2)      # VIO_ERR_NO_DEVICE / VIO_ERR_HIP, never a silent CPU path
+
+
+def test_oracle_exports_the_same_surface(vio, oracle_lib):
+    for f in header_functions():
+        if f in ("vio_profile_begin", "vio_profile_end", "vio_kernel_name"):
+            continue        # measurement hooks exist on the HIP library only
+        assert oracle_lib.has(f[len("vio_"):]), f
+
+
+def test_synthetic_window_shapes(vio):
+    w = vio.synth.make_window(70, seed=3)
+    assert w.poses.shape == (11, 7) and w.speed_bias.shape == (11, 9) and w.ext.shape == (7,)
+    assert w.inv_depth.shape == (70,) and w.lm.shape == (280,) and w.pts_j.shape == (280, 2)
+    assert len(w.preint) == 10 and abs(w.preint[0]["sum_dt"] - 0.1) < 1e-12
+    assert np.all(w.host != w.target) and w.target.max() <= 10
+    np.testing.assert_allclose(np.linalg.norm(w.poses[:, 3:7], axis=1), 1.0, atol=1e-12)
+    # observations are grouped by landmark, as estimator.cpp:975-1016 emits them
+    assert np.all(np.diff(w.lm) >= 0)
+    r = vio.synth.make_window(200, seed=5, ragged=True)
+    counts = np.bincount(r.lm, minlength=200)
+    assert counts.min() >= 1 and counts.max() <= 10 and len(set(counts)) > 3
+
+
+def test_shard_window_partitions_landmarks(vio):
+    w = vio.synth.make_window(101, seed=1, ragged=True)
+    seen_obs, seen_lm = 0, 0
+    for r in range(3):
+        s = vio.synth.shard_window(w, r, 3)
+        lo, hi = s.landmark_range
+        assert s.n_landmarks == hi - lo and s.lm.max() < s.n_landmarks and s.lm.min() >= 0
+        np.testing.assert_array_equal(s.inv_depth, w.inv_depth[lo:hi])
+        np.testing.assert_array_equal(s.poses, w.poses)
+        seen_obs += s.n_observations
+        seen_lm += s.n_landmarks
+    assert seen_obs == w.n_observations and seen_lm == 101
+
+
+def test_algorithmic_bytes_formula(vio):
+    # 4.1 MB at N = 20k, M = 80k
+    b = vio.synth.algorithmic_bytes(20000, 80000)
+    assert 4.0e6 < b < 4.2e6
+
+
+def test_numpy_preintegration_matches_oracle_c(vio, oracle_lib):
+    """The generator's numpy restatement of IntegrationBase (integration_base.h:54-158) against the oracle's C one."""
+    rng = np.random.RandomState(0)
+    n = 20
+    acc = rng.normal(0, 1, (n + 1, 3)) + [0, 0, 9.8]
+    gyr = rng.normal(0, 0.3, (n + 1, 3))
+    ba, bg = rng.normal(0, 0.02, 3), rng.normal(0, 0.002, 3)
+    dts = np.full(n, 0.005)
+    py = vio.synth.preintegrate(acc[0], gyr[0], ba, bg, dts, acc[1:], gyr[1:])
+    out = vio.VioPreint()
+    f = oracle_lib.dll.vioo_preintegrate
+    f.restype = None
+    dp = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    a0, g0, a1, g1 = (np.ascontiguousarray(x) for x in (acc[0], gyr[0], acc[1:], gyr[1:]))
+    f(dp(a0), dp(g0), dp(ba), dp(bg), C.c_int(n), dp(dts), dp(a1), dp(g1), C.c_double(vio.synth.ACC_N),
+      C.c_double(vio.synth.GYR_N), C.c_double(vio.synth.ACC_W), C.c_double(vio.synth.GYR_W), C.byref(out))
+    assert abs(out.sum_dt - py["sum_dt"]) < 1e-15
+    np.testing.assert_allclose(np.array(out.delta_p[:]), py["delta_p"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(np.array(out.delta_q[:]), py["delta_q"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(np.array(out.delta_v[:]), py["delta_v"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(np.array(out.jacobian[:]).reshape(15, 15), py["jacobian"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(np.array(out.covariance[:]).reshape(15, 15), py["covariance"], rtol=1e-11, atol=1e-30)

@@ -1,0 +1,68 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  Each process runs the sharded LM loop of
+visual-inertial-odometry_amd/sharded.py with the CPU oracle standing in for the GPU library (same C ABI, same
+exchange hooks), and the result must equal the unsharded solve."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, n, ragged):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from conftest import ORACLE_DIR, load_package
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    vio = load_package()
+    orc = vio.VioLib(os.path.join(ORACLE_DIR, "liboracle.so"), "vioo_")
+    w = vio.synth.make_window(n, seed=21, ragged=ragged)
+    sb = vio.sharded.ShardedBackend(orc, w, rank, world, dist=dist, torch_device="cpu")
+    sb.ctx.linearize()
+    chi0, lam0 = sb.ctx.init_lm()
+    Hs, bs = sb.ctx.get_schur_system()
+    rep = sb.solve(10)
+    poses, sbias, ext = sb.ctx.get_window()
+    invd = sb.gather_landmarks()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), chi0=chi0, lam0=lam0, Hs=Hs, bs=bs, poses=poses, sb=sbias,
+             invd=invd, final_chi2=rep.final_chi2, iterations=rep.iterations, trials=rep.trials)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,ragged", [(90, False), (61, True)])
+def test_sharded_solve_equals_unsharded(vio, oracle_lib, tmp_path, n, ragged):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), n, ragged), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    w = vio.synth.make_window(n, seed=21, ragged=ragged)
+    ctx = oracle_lib.context()
+    ctx.load(w)
+    ctx.linearize()
+    chi0, lam0 = ctx.init_lm()
+    Hs, bs = ctx.get_schur_system()
+    rep = ctx.solve(10)
+    poses, sbias, _ = ctx.get_window()
+    invd = ctx.get_landmarks()
+    for r in (r0, r1):
+        # every rank holds the identical reduced system after the all-reduce
+        assert abs(float(r["chi0"]) - chi0) <= 1e-12 * abs(chi0) and float(r["lam0"]) == lam0
+        d = np.sqrt(np.abs(np.diag(Hs)) + 1e-300)
+        assert (np.abs(r["Hs"] - Hs) / np.outer(d, d)).max() <= 1e-12
+        assert int(r["iterations"]) == rep.iterations and int(r["trials"]) == rep.trials
+        assert abs(float(r["final_chi2"]) - rep.final_chi2) <= 1e-7 * rep.final_chi2
+        assert np.abs(r["poses"] - poses).max() <= 1e-7 and np.abs(r["sb"] - sbias).max() <= 1e-6
+        assert np.abs(r["invd"] - invd).max() <= 1e-7
+    np.testing.assert_array_equal(r0["Hs"], r1["Hs"])      # bitwise identical on both ranks
+    np.testing.assert_array_equal(r0["poses"], r1["poses"])

@@ -1,0 +1,237 @@
+"""The CPU oracle against the golden vectors dumped from the COMPILED REFERENCE (tests/golden/make_golden.py).
+This is what pins the oracle; the GPU tests then compare the HIP path with the oracle.
+
+Tolerances (all fp64):
+  per-function values      relative 1e-12 (same formulas, different evaluation order)
+  H_pp_schur_              1e-9 in the metric |dH_ij| / sqrt(H_ii H_jj) (the matrix spans 1e5 .. 1e16)
+  delta_x at the reference's own lambda: 1e-9 absolute (expected <= 1e-9, required <= 1e-6)
+  Solve(10) end state      1e-6 absolute: ten LM steps walk lambda down to ~10 where cond(H) ~ 1e15
+  marginalisation          compared through invariants (the entries are ill-posed)
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import vio_testutil as tu
+from conftest import GOLDEN_DIR
+
+dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+WINDOW_FILES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "window_*.npz")))
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+
+
+def cfg_of(z):
+    kw = {}
+    if "cfg_ext_fixed" in z:
+        kw["ext_fixed"] = int(z["cfg_ext_fixed"])
+    if "cfg_loss_type" in z:
+        kw["loss_type"] = int(z["cfg_loss_type"])
+    return kw
+
+
+def test_golden_files_present():
+    assert len(WINDOW_FILES) >= 8
+    for f in ("reproj_edges", "loss_and_robust", "pose_plus", "ldlt", "symmetric_eigen", "inverse15"):
+        assert os.path.exists(os.path.join(GOLDEN_DIR, f + ".npz"))
+
+
+def test_reprojection_edge(oracle_lib):
+    z = load("reproj_edges")
+    f = oracle_lib.dll.vioo_reproj_edge
+    f.restype = None
+    for e in range(z["residual"].shape[0]):
+        r, Jl, Ji, Jj, Je = np.zeros(2), np.zeros(2), np.zeros(12), np.zeros(12), np.zeros(12)
+        a = [np.ascontiguousarray(z[k][e]) for k in ("pose_i", "pose_j", "ext", "pts_i", "pts_j")]
+        f(dp(a[0]), dp(a[1]), dp(a[2]), C.c_double(z["inv_depth"][e]), dp(a[3]), dp(a[4]), dp(r), dp(Jl), dp(Ji), dp(Jj), dp(Je))
+        for got, key in ((r, "residual"), (Jl, "J_lambda"), (Ji, "J_pose_i"), (Jj, "J_pose_j"), (Je, "J_ext")):
+            want = z[key][e]
+            assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (e, key)
+
+
+def test_loss_functions_and_robust_info(oracle_lib):
+    z = load("loss_and_robust")
+    fl = oracle_lib.dll.vioo_loss
+    fl.restype = None
+    for t, nm in ((1, "huber"), (2, "cauchy"), (3, "tukey")):
+        for delta in (1.0, 2.5):
+            want = z["%s_%g" % (nm, delta)]
+            for i, e2 in enumerate(z["e2"]):
+                out = np.zeros(3)
+                fl(C.c_int(t), C.c_double(delta), C.c_double(e2), dp(out))
+                np.testing.assert_allclose(out, want[i], rtol=1e-14, atol=1e-300)
+    fr = oracle_lib.dll.vioo_robust_info2
+    fr.restype = None
+    for t, nm in ((0, "trivial"), (1, "huber"), (2, "cauchy"), (3, "tukey")):
+        for i, r in enumerate(z["residuals"]):
+            W, d = np.zeros(4), C.c_double()
+            fr(C.c_int(t), C.c_double(1.0), C.c_double(460 / 1.5), dp(np.ascontiguousarray(r)), C.byref(d), dp(W))
+            np.testing.assert_allclose(W, z["W_" + nm][i], rtol=1e-13, atol=1e-9)
+            assert abs(d.value - z["drho_" + nm][i]) <= 1e-14
+
+
+def test_pose_plus(oracle_lib):
+    z = load("pose_plus")
+    f = oracle_lib.dll.vioo_pose_plus
+    f.restype = None
+    for i in range(z["poses"].shape[0]):
+        p = z["poses"][i].copy()
+        f(dp(p), dp(np.ascontiguousarray(z["deltas"][i])))
+        np.testing.assert_allclose(p, z["result"][i], rtol=0, atol=1e-15)
+
+
+def test_ldlt_solve_matches_eigen(oracle_lib):
+    z = load("ldlt")
+    f = oracle_lib.dll.vioo_ldlt_solve
+    f.restype = None
+    x, tr = np.zeros(24), np.zeros(24, dtype=np.int32)
+    f(C.c_int(24), dp(np.ascontiguousarray(z["A_small"])), dp(np.ascontiguousarray(z["b_small"])), dp(x),
+      tr.ctypes.data_as(C.POINTER(C.c_int)))
+    np.testing.assert_array_equal(tr, z["tr_small"])       # same transpositions as Eigen, zero pivot included
+    np.testing.assert_allclose(x, z["x_small"], rtol=1e-11, atol=1e-13)
+    for i in range(3):
+        lam = float(z["lambda_%d" % i])
+        A = np.ascontiguousarray(z["Hs"] + lam * np.eye(171))
+        x, tr = np.zeros(171), np.zeros(171, dtype=np.int32)
+        f(C.c_int(171), dp(A), dp(np.ascontiguousarray(z["bs"])), dp(x), tr.ctypes.data_as(C.POINTER(C.c_int)))
+        np.testing.assert_array_equal(tr, z["tr_%d" % i])
+        # the allowed error grows with cond(H + lambda I): 3e10 / 1.6e13 / 2.7e16
+        tol = (1e-11, 1e-8, 1e-4)[i]
+        assert np.abs(x - z["x_%d" % i]).max() <= tol, (i, np.abs(x - z["x_%d" % i]).max())
+
+
+def test_symmetric_eigen(oracle_lib):
+    z = load("symmetric_eigen")
+    f = oracle_lib.dll.vioo_symmetric_eigen
+    for key, n in (("small", 24), ("prior", 156)):
+        A = np.ascontiguousarray(z["A_" + key])
+        ev, V = np.zeros(n), np.zeros((n, n))
+        assert f(C.c_int(n), dp(A), dp(ev), dp(V)) == 0
+        scale = np.abs(z["evals_" + key]).max()
+        assert np.abs(ev - z["evals_" + key]).max() <= 1e-12 * scale
+        As = np.tril(A) + np.tril(A, -1).T
+        assert np.abs(V @ np.diag(ev) @ V.T - As).max() <= 1e-11 * scale
+        assert np.abs(V.T @ V - np.eye(n)).max() <= 1e-12
+
+
+def test_inverse15(oracle_lib):
+    z = load("inverse15")
+    f = oracle_lib.dll.vioo_inverse15
+    f.restype = None
+    for k in range(z["cov"].shape[0]):
+        out = np.zeros((15, 15))
+        f(dp(np.ascontiguousarray(z["cov"][k])), dp(out))
+        # element-wise, scaled by the diagonal: information spans 1e4 .. 4e15
+        assert tu.scaled_sym_err(out, z["info"][k]) <= 1e-9
+
+
+@pytest.mark.parametrize("path", WINDOW_FILES, ids=[os.path.basename(p)[:-4] for p in WINDOW_FILES])
+def test_window_against_reference(vio, oracle_lib, path):
+    check_window_against_golden(vio, oracle_lib, path)
+
+
+def check_window_against_golden(vio, lib, path, dx_tol=1e-9, state_tol=1e-6, lambda_rtol=2e-5):
+    """Shared with the GPU tests: `lib` is the oracle here and the HIP library there."""
+    z = dict(np.load(path))
+    w = tu.arrays_to_window(vio, z)
+    kw = cfg_of(z)
+    ctx = lib.context(**kw)
+    ctx.load(w)
+    if "step_dx_pose" in z and "step_bs" not in z:          # the N = 2000 file: delta_x only
+        ctx.linearize()
+        chi0, lam0 = ctx.init_lm()
+        assert abs(chi0 - float(z["step_chi0"])) <= 1e-10 * abs(float(z["step_chi0"]))
+        assert lam0 == float(z["step_lambda0"])
+        ctx.solve_linear(lam0)
+        dxp, dxl = ctx.get_delta()
+        assert np.abs(dxp - z["step_dx_pose"]).max() <= dx_tol
+        assert np.abs(dxl - z["step_dx_lm"]).max() <= dx_tol
+        return
+    got = tu.run_stepwise(ctx)
+    g = lambda k: z["step_" + k]
+    if kw.get("loss_type") == vio.LOSS_HUBER:
+        # Knife edge in the reference itself: for a Huber outlier rho' + 2 rho'' e2 is 0 in exact arithmetic
+        # (loss_function.cc:16-20), so the `> 0` test of Edge::RobustInfo (edge.cc:62) is decided by the last bit
+        # of e2 and the edge's weight along the residual is either rho' or 0.  Any two evaluation orders of the
+        # residual disagree on some edges, so only W-independent quantities are comparable at window level; the
+        # branch itself is pinned with identical inputs in test_loss_functions_and_robust_info.
+        assert abs(got["chi0"] - g("chi0")) <= 1e-11 * abs(g("chi0"))
+        assert got["lambda0"] == g("lambda0")
+        return
+    if "step_Hs" in z:
+        assert tu.scaled_sym_err(got["Hs"], g("Hs")) <= 1e-9
+    scale_b = np.abs(g("bs")).max()
+    assert np.abs(got["bs"] - g("bs")).max() <= 1e-11 * scale_b
+    assert np.abs(got["bpp"] - g("bpp")).max() <= 1e-11 * np.abs(g("bpp")).max()
+    assert tu.rel_max(got["diag"], g("diag")) <= 1e-12
+    assert tu.rel_max(got["hll"], g("hll")) <= 1e-11 and tu.rel_max(got["bl"], g("bl")) <= 1e-10
+    assert abs(got["chi0"] - g("chi0")) <= 1e-11 * abs(g("chi0"))
+    assert got["lambda0"] == g("lambda0")
+    assert np.abs(got["dx_pose"] - g("dx_pose")).max() <= dx_tol
+    assert np.abs(got["dx_lm"] - g("dx_lm")).max() <= dx_tol
+    for k in ("poses1", "sb1", "ext1", "invd1"):
+        assert np.abs(got[k] - g(k)).max() <= dx_tol, k
+    if "in_prior_H" in z:
+        assert tu.rel_max(got["bprior1"], g("bprior1")) <= 1e-9
+        assert tu.rel_max(got["errprior1"], g("errprior1")) <= 1e-8
+    assert abs(got["chi1"] - g("chi1")) <= 1e-8 * abs(g("chi1"))
+    assert int(got["accepted"]) == int(g("accepted"))
+    assert abs(got["lambda1"] - g("lambda1")) <= 1e-9 * abs(g("lambda1"))
+    if "solve_posesF" in z:
+        ctx2 = lib.context(**kw)
+        ctx2.load(w)
+        sol, rep = tu.run_solve(ctx2, 10)
+        assert int(sol["iterations"]) == int(z["solve_iterations"])
+        assert abs(sol["final_chi2"] - z["solve_final_chi2"]) <= 1e-6 * abs(z["solve_final_chi2"])
+        # the reference prints chi/lambda with 6 significant digits: that is what its trace pins
+        n = len(z["solve_chi2_trace"])
+        np.testing.assert_allclose(sol["chi2_trace"][:n], z["solve_chi2_trace"], rtol=2e-5)
+        # lambda_{k+1}/lambda_k = 1-(2 rho-1)^3 with rho = (chi-chi_new)/scale: close to convergence chi-chi_new is a
+        # difference of nearly equal numbers, so the schedule amplifies rounding (a 1e-9 state difference shows up
+        # in the 4th digit of lambda after six steps)
+        np.testing.assert_allclose(sol["lambda_trace"][:n], z["solve_lambda_trace"], rtol=lambda_rtol)
+        for k in ("posesF", "sbF", "extF", "invdF"):
+            assert np.abs(sol[k] - z["solve_" + k]).max() <= state_tol, k
+    for kind in (0, 1):
+        if "marg%d_H" % kind not in z:
+            continue
+        wm = tu.arrays_to_window(vio, z, prefix="marg%d_in_" % kind)
+        ctx3 = lib.context(**kw)
+        ctx3.load(wm)
+        m = ctx3.marginalize(kind)
+        check_prior(m, {k: z["marg%d_%s" % (kind, k)] for k in tu.PRIOR_FIELDS})
+
+
+def check_prior(m, ref):
+    """Marginalisation outputs are compared through invariants: the Schur complement subtracts O(1e16) terms
+    whose difference is O(1e5), the eps = 1e-8 eigenvalue cut and the 1e-9 zeroing are discontinuous, and
+    eigenvector signs are arbitrary ('Marginalisation parity is ill-posed entry-wise')."""
+    Hs = np.abs(ref["H"]).max()
+    assert np.abs(m["H"] - ref["H"]).max() <= 2e-5 * Hs
+    assert np.abs(m["b"] - ref["b"]).max() <= 1e-6 * max(np.abs(ref["b"]).max(), 1.0)
+    ev, evr = np.linalg.eigvalsh(m["H"]), np.linalg.eigvalsh(ref["H"])
+    # spectrum: absolute agreement relative to the largest eigenvalue.  (The count of eigenvalues above the 1e-8
+    # cut is NOT an invariant: with the extrinsic free the smallest ones are O(1e-3..1) = 1e-7 of the largest,
+    # i.e. inside the rounding of the 1e16-sized terms the Schur complement cancels.)
+    assert np.abs(ev - evr).max() <= 2e-5 * evr.max()
+    # err_prior = -Jt_inv b (problem.cc:774).  Its components along eigenvectors whose eigenvalue lies between the
+    # 1e-8 cut and the rounding noise of H (~1e-6 of the largest) are amplified noise in the reference itself, so
+    # across implementations only the well-conditioned part is comparable; the full vector is checked for
+    # consistency with the implementation's own Jt_inv and b.
+    assert np.abs(m["err"] + m["jt_inv"] @ m["b"]).max() <= 1e-9 * max(np.abs(m["err"]).max(), 1e-12)
+
+    def damped_energy(H, b):
+        # b^T (H + mu I)^-1 b, mu = 1e-4 of the largest eigenvalue: what ||err_prior||^2 would be with a smooth cut
+        Hs_ = 0.5 * (H + H.T)
+        mu = 1e-4 * np.linalg.eigvalsh(Hs_).max()
+        return float(b @ np.linalg.solve(Hs_ + mu * np.eye(H.shape[0]), b))
+    qa, qb = damped_energy(m["H"], m["b"]), damped_energy(ref["H"], ref["b"])
+    assert abs(qa - qb) <= 1e-3 * max(qb, 1e-9)
+    # Jt_inv^T Jt_inv is the pseudo-inverse of H_prior restricted to the kept eigenspace: H P H == H
+    P = m["jt_inv"].T @ m["jt_inv"]
+    assert np.abs(m["H"] @ P @ m["H"] - m["H"]).max() <= 1e-5 * Hs

@@ -5,7 +5,7 @@ include/vio_backend.h).  There is no CPU fallback: `load_hip()` raises if the li
 """
 import os
 
-from . import capi, synth
+from . import capi, sharded, synth
 from .capi import (CAM_DIM, LOSS_CAUCHY, LOSS_HUBER, LOSS_TRIVIAL, LOSS_TUKEY, MARG_OLD, MARG_SECOND_NEW,
                    NUM_FRAMES, POSE_DIM, PRIOR_DIM, WINDOW_SIZE, VioConfig, VioContext, VioError, VioLib,
                    VioPreint, VioSolveReport)

@@ -84,7 +84,11 @@ class VioLib:
                "solve_linear", "update_states", "rollback_states", "chi2", "eval_step", "gn_iteration",
                "synchronize", "marginalize", "get_window", "get_landmarks", "get_prior", "get_delta",
                "get_schur_system", "get_landmark_system", "get_pose_gradient", "exchange_buffers",
-               "set_exchange_hook"]
+               "set_exchange_hook", "bind_exchange_buffers"]
+
+    # exported by the HIP library only (measurement, caller-owned exchange buffers)
+    HIP_ONLY = ["profile_begin", "profile_end", "kernel_name"]
+    KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
         if not os.path.exists(path):
@@ -96,6 +100,11 @@ class VioLib:
         self.fn = {}
         for s in self.SYMBOLS:
             self.fn[s] = getattr(self.dll, prefix + s)     # raises AttributeError on a missing export
+        if prefix == "vio_":
+            for s in self.HIP_ONLY:
+                self.fn[s] = getattr(self.dll, prefix + s)
+                self.fn[s].restype = C.c_int
+            self.fn["kernel_name"].restype = C.c_char_p
         self.fn["last_error"].restype = C.c_char_p
         self.fn["destroy"].restype = None
         self.fn["default_config"].restype = None
@@ -281,6 +290,25 @@ class VioContext:
         b, d = np.zeros(POSE_DIM), np.zeros(POSE_DIM)
         self._ck(self.lib.fn["get_pose_gradient"](self.h, _dp(b), _dp(d)), "get_pose_gradient")
         return b, d
+
+    def bind_exchange_buffers(self, reduced_ptr, scalars_ptr):
+        self._ck(self.lib.fn["bind_exchange_buffers"](self.h, C.c_void_p(reduced_ptr), C.c_void_p(scalars_ptr)),
+                 "bind_exchange_buffers")
+
+    def set_exchange_hook(self, fn):
+        """fn(which) -> 0 on success; kept alive on the context."""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+        self._hook = proto(lambda user, which: int(fn(which))) if fn is not None else None
+        self._ck(self.lib.fn["set_exchange_hook"](self.h, self._hook if self._hook else C.cast(None, proto), None),
+                 "set_exchange_hook")
+
+    def profile_begin(self, which):
+        self._ck(self.lib.fn["profile_begin"](self.h, C.c_int32(which)), "profile_begin")
+
+    def profile_end(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self.lib.fn["profile_end"](self.h, C.byref(ms), C.byref(n)), "profile_end")
+        return ms.value, n.value
 
     def exchange_buffers(self):
         p0, n0, p1, n1 = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()

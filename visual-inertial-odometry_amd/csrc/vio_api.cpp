@@ -31,9 +31,9 @@ void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s);
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
-void vio_launch_step_sum(const DeviceTables &T, hipStream_t s);
+void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s);
-void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s);
+void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
 int vio_set_kernel_attributes();
@@ -125,6 +125,10 @@ struct vio_ctx {
     vio_exchange_fn hook = nullptr;
     void *hook_user = nullptr;
     double hessian_ms = 0;
+    double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
+    int prof_which = -1;
+    std::vector<hipEvent_t> prof_events;               // pairs
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -322,7 +326,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     HIPCHK(pl.d_pts_i.resize(2 * (size_t)pl.Ns)); HIPCHK(pl.d_pts_j.resize(2 * (size_t)pl.Ms));
     HIPCHK(pl.d_invd.resize(2 * (size_t)std::max<int64_t>(pl.Ns, 1))); HIPCHK(pl.d_slab.resize(pl.slab_doubles));
     HIPCHK(pl.d_lw.resize(pl.lw_doubles)); HIPCHK(pl.d_dxl.resize((size_t)pl.Ns));
-    HIPCHK(pl.d_step_part.resize(2 * (ni + VIO_WINDOW_SIZE)));
+    HIPCHK(pl.d_step_part.resize(4 * (ni + VIO_WINDOW_SIZE)));
     hipStream_t st = c->stream;
     if (ni) HIPCHK(hipMemcpyAsync(pl.d_items.p, pl.items.data(), ni * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
     if (!pl.strips.empty()) HIPCHK(hipMemcpyAsync(pl.d_strips.p, pl.strips.data(), pl.strips.size() * 4, hipMemcpyHostToDevice, st));
@@ -359,7 +363,7 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     T.loss_delta = c->cfg.loss_delta; T.sqrt_info = c->cfg.reproj_sqrt_info;
     for (int k = 0; k < 3; ++k) T.gravity[k] = c->cfg.gravity[k];
     T.state = c->d_state.p; T.invd = pl.d_invd.p; T.pts_i = pl.d_pts_i.p; T.pts_j = pl.d_pts_j.p;
-    T.pairtab = c->d_pairtab.p; T.slab = pl.d_slab.p; T.lw = pl.d_lw.p; T.vis = c->d_vis.p; T.pre = c->d_pre.p;
+    T.pairtab = c->d_pairtab.p; T.slab = pl.d_slab.p; T.lw = pl.d_lw.p; T.vis = c->ext_vis ? c->ext_vis : c->d_vis.p; T.pre = c->d_pre.p;
     T.imu_valid = c->d_imu_valid.p; T.imu_out = c->d_imu_out.p; T.imu_chi_try = c->d_imu_chi.p;
     T.strips = pl.d_strips.p; T.rows = pl.d_rows.p; T.pair_slot = nullptr; T.blk_slot = nullptr;
     T.Hprior = c->d_Hprior.p; T.bprior = c->d_bprior.p; T.errprior = c->d_errprior.p; T.Jtinv = c->d_Jtinv.p;
@@ -368,7 +372,8 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     T.has_prior = c->has_prior; T.add_imu_prior = 1;
     T.Hs = c->d_Hs.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
-    T.step_tot = c->d_step_tot.p; T.lm = c->d_lm.p;
+    T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
+    T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
     return T;
 }
 
@@ -442,6 +447,23 @@ vio_status activate(vio_ctx *c, Plan &pl, int marg) {
     return VIO_OK;
 }
 
+struct ProfScope {       // records an event pair around one kernel launch when that kernel is being profiled
+    vio_ctx *c;
+    bool on;
+    ProfScope(vio_ctx *ctx, int id) : c(ctx), on(ctx->prof_which == id) {
+        if (!on) return;
+        if (c->prof_used + 2 > c->prof_events.size()) {
+            for (int k = 0; k < 2; ++k) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } c->prof_events.push_back(e); }
+        }
+        (void)hipEventRecord(c->prof_events[c->prof_used], c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(c->prof_events[c->prof_used + 1], c->stream);
+        c->prof_used += 2;
+    }
+};
+
 vio_status run_exchange(vio_ctx *c, int which) {
     if (!c->hook) return VIO_OK;
     if (c->hook(c->hook_user, which) != 0) return fail(c, VIO_ERR_HIP, "exchange hook failed");
@@ -452,25 +474,40 @@ vio_status run_exchange(vio_ctx *c, int which) {
 vio_status enqueue_linearize(vio_ctx *c, Plan &pl) {
     DeviceTables T = make_tables(c, pl);
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
-    vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream);
-    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, c->d_vis.p};
-    vio_launch_reduce(R, c->stream);
+    { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
+    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis};
+    { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
     VIOCHK(run_exchange(c, 0));
-    vio_launch_assemble(T, c->stream);
+    { ProfScope ps(c, VIO_K_ASSEMBLE); vio_launch_assemble(T, c->stream); }
     HIPCHK(hipGetLastError());
     c->linearized = true;
     return VIO_OK;
 }
 
+// ComputeLambdaInitLM; with shards, max |h_ll| is max-reduced through the hook (which == 2) in step_scalars[2]
+vio_status enqueue_init_lm(vio_ctx *c, const DeviceTables &T, int max_iter) {
+    const double *src = T.vis + VIS_MAXH;
+    if (c->hook) {
+        HIPCHK(hipMemcpyAsync(T.step_tot + 2, T.vis + VIS_MAXH, 8, hipMemcpyDeviceToDevice, c->stream));
+        VIOCHK(run_exchange(c, 2));
+        src = T.step_tot + 2;
+    }
+    vio_launch_init_lm(T, max_iter, src, c->stream);
+    HIPCHK(hipGetLastError());
+    return VIO_OK;
+}
+
 vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode) {
     DeviceTables T = make_tables(c, pl);
-    vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream);
-    vio_launch_backsub(T, 0, c->stream);
+    { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
+    { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, c->stream); }
     if (c->hook) {
-        vio_launch_step_sum(T, c->stream);
+        vio_launch_step_sum(T, 0, c->stream);
         VIOCHK(run_exchange(c, 1));
+        ProfScope ps(c, VIO_K_LM_DECIDE);
         vio_launch_lm_decide(T, mode, 0, c->stream);
     } else {
+        ProfScope ps(c, VIO_K_LM_DECIDE);
         vio_launch_lm_decide(T, mode, 1, c->stream);
     }
     HIPCHK(hipGetLastError());
@@ -531,6 +568,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release();
+    for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -619,7 +657,7 @@ vio_status vio_linearize(vio_ctx *c) {
 vio_status vio_init_lm(vio_ctx *c, double *chi2, double *lambda) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
     DeviceTables T = make_tables(c, *c->active);
-    vio_launch_init_lm(T, 1 << 30, c->stream);
+    VIOCHK(enqueue_init_lm(c, T, 1 << 30));
     VIOCHK(read_lm(c));
     if (chi2) *chi2 = c->h_lm.chi;
     if (lambda) *lambda = c->h_lm.lambda;
@@ -633,7 +671,6 @@ vio_status vio_solve_linear(vio_ctx *c, double lambda) {
     vio_launch_set_lambda(c->d_lm.p, lambda, c->stream);
     vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream);
     vio_launch_backsub(T, 0, c->stream);
-    if (c->hook) { vio_launch_step_sum(T, c->stream); VIOCHK(run_exchange(c, 1)); }
     HIPCHK(hipGetLastError());
     c->stepwise_updated = false;
     return VIO_OK;
@@ -660,7 +697,7 @@ vio_status vio_chi2(vio_ctx *c, double *chi2) {
     // the chi2 kernels read the pair table of the current state; after a stepwise update it is the trial table
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
     vio_launch_backsub(T, 1, c->stream);
-    if (c->hook) { vio_launch_step_sum(T, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 2, 0, c->stream); }
+    if (c->hook) { vio_launch_step_sum(T, 2, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 2, 0, c->stream); }
     else vio_launch_lm_decide(T, 2, 1, c->stream);
     VIOCHK(read_lm(c));
     *chi2 = c->h_lm.chi_try;
@@ -673,7 +710,8 @@ vio_status vio_eval_step(vio_ctx *c, int32_t *accepted, double *chi2, double *la
     DeviceTables T = make_tables(c, pl);
     // the decide kernel expects the trial copy to be "the other one"
     if (c->stepwise_updated) vio_launch_flip(c->d_lm.p, c->stream);
-    if (c->hook) vio_launch_lm_decide(T, 0, 0, c->stream); else vio_launch_lm_decide(T, 0, 1, c->stream);
+    if (c->hook) { vio_launch_step_sum(T, 0, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 0, 0, c->stream); }
+    else vio_launch_lm_decide(T, 0, 1, c->stream);
     VIOCHK(read_lm(c));
     const bool ok = c->h_lm.accepted != 0;
     if (ok) {
@@ -708,7 +746,7 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
     };
     VIOCHK(timed_linearize());
     DeviceTables T = make_tables(c, pl);
-    vio_launch_init_lm(T, iterations, c->stream);
+    VIOCHK(enqueue_init_lm(c, T, iterations));
     VIOCHK(read_lm(c));
     { float ms = 0; hipEventElapsedTime(&ms, ev0, ev1); hess_ms += ms; }
     vio_solve_report r;
@@ -851,9 +889,9 @@ vio_status vio_get_pose_gradient(vio_ctx *c, double *b, double *diag) {
 
 vio_status vio_exchange_buffers(vio_ctx *c, void **reduced, int64_t *n_reduced, void **scalars, int64_t *n_scalars) {
     if (!c) return VIO_ERR_BAD_ARG;
-    if (reduced) *reduced = c->d_vis.p;
+    if (reduced) *reduced = c->ext_vis ? c->ext_vis : c->d_vis.p;
     if (n_reduced) *n_reduced = VIS_MAXH;       // everything before the max-|h_ll| slot is summed across shards
-    if (scalars) *scalars = c->d_step_tot.p;
+    if (scalars) *scalars = c->ext_step ? c->ext_step : c->d_step_tot.p;
     if (n_scalars) *n_scalars = 2;
     return VIO_OK;
 }
@@ -862,6 +900,42 @@ vio_status vio_set_exchange_hook(vio_ctx *c, vio_exchange_fn fn, void *user) {
     if (!c) return VIO_ERR_BAD_ARG;
     c->hook = fn;
     c->hook_user = user;
+    return VIO_OK;
+}
+
+vio_status vio_bind_exchange_buffers(vio_ctx *c, void *reduced, void *scalars) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    c->ext_vis = (double *)reduced;
+    c->ext_step = (double *)scalars;
+    c->linearized = false;
+    return VIO_OK;
+}
+
+const char *vio_kernel_name(int32_t which) {
+    static const char *names[VIO_K_COUNT] = {"k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"};
+    return (which >= 0 && which < VIO_K_COUNT) ? names[which] : "";
+}
+
+vio_status vio_profile_begin(vio_ctx *c, int32_t which) {
+    if (!c || which >= VIO_K_COUNT) return VIO_ERR_BAD_ARG;
+    c->prof_which = which;
+    c->prof_used = 0;
+    return VIO_OK;
+}
+
+vio_status vio_profile_end(vio_ctx *c, double *total_ms, int64_t *launches) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double tot = 0;
+    for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i], c->prof_events[i + 1]));
+        tot += ms;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = (int64_t)(c->prof_used / 2);
+    c->prof_which = -1;
+    c->prof_used = 0;
     return VIO_OK;
 }
 

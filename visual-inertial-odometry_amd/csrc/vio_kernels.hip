@@ -633,12 +633,15 @@ __global__ __launch_bounds__(64) void k_reduce(ReduceTables R) {
             R.vis[VIS_DIAG + 6 * P + t] = sV[12 + t];
         }
     } else {
+        // chi2 and max|h_ll| over the items: lanes stride the list, then a fixed shuffle tree
         double chi = 0.0, mh = 0.0;
-        if (t == 0) {
-            for (int e = lo; e < hi; ++e) { chi += R.slab[(size_t)R.list[e]]; mh = fmax(mh, R.slab[(size_t)R.list[e] + 1]); }
-            R.vis[VIS_CHI] = chi;
-            R.vis[VIS_MAXH] = mh;
+        for (int e = lo + t; e < hi; e += 64) {
+            const size_t o = (size_t)R.list[e];
+            chi += R.slab[o];
+            mh = fmax(mh, R.slab[o + 1]);
         }
+        for (int o = 32; o > 0; o >>= 1) { chi += __shfl_xor(chi, o); mh = fmax(mh, __shfl_xor(mh, o)); }
+        if (t == 0) { R.vis[VIS_CHI] = chi; R.vis[VIS_MAXH] = mh; }
     }
 }
 
@@ -877,8 +880,9 @@ __global__ __launch_bounds__(64) void k_backsub(DeviceTables T, int mode) {
                     chi += r[i] * t;
                 }
             }
-            T.step_part[2 * b + STEP_CHI] = chi;
-            T.step_part[2 * b + STEP_SCALE] = 0.0;
+            double *part = (mode == 1) ? T.chi_part : T.step_part;
+            part[2 * b + STEP_CHI] = chi;
+            part[2 * b + STEP_SCALE] = 0.0;
         }
         return;
     }
@@ -935,7 +939,11 @@ __global__ __launch_bounds__(64) void k_backsub(DeviceTables T, int mode) {
         }
     }
     for (int o = 32; o > 0; o >>= 1) { chi += __shfl_xor(chi, o); scale += __shfl_xor(scale, o); }
-    if (lane == 0) { T.step_part[2 * b + STEP_CHI] = chi; T.step_part[2 * b + STEP_SCALE] = scale; }
+    if (lane == 0) {
+        // vio_chi2 (mode 1) has partials of its own so that it never disturbs a pending step test
+        double *part = (mode == 1) ? T.chi_part : T.step_part;
+        part[2 * b + STEP_CHI] = chi; part[2 * b + STEP_SCALE] = scale;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -943,11 +951,12 @@ __global__ __launch_bounds__(64) void k_backsub(DeviceTables T, int mode) {
 // k_lm_decide: IsGoodStepInLM (problem.cc:541-573) + the loop bookkeeping of Problem::Solve (:188-245)
 //   mode 0: LM trial   mode 1: fixed-lambda GN step (always accept)   mode 2: chi2 only (no state change)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_step_sum(DeviceTables T) {
+__global__ __launch_bounds__(256) void k_step_sum(DeviceTables T, int mode) {
     __shared__ double s0[256];
     const int tid = threadIdx.x;
+    const double *part = (mode == 2) ? T.chi_part : T.step_part;
     double c = 0, s = 0;
-    for (int e = tid; e < T.n_items; e += 256) { c += T.step_part[2 * e + STEP_CHI]; s += T.step_part[2 * e + STEP_SCALE]; }
+    for (int e = tid; e < T.n_items; e += 256) { c += part[2 * e + STEP_CHI]; s += part[2 * e + STEP_SCALE]; }
     const double ct = d_block_sum<256>(c, s0, tid);
     const double st = d_block_sum<256>(s, s0, tid);
     if (tid == 0) { T.step_tot[0] = ct; T.step_tot[1] = st; }
@@ -957,9 +966,10 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int
     __shared__ double s0[256];
     const int tid = threadIdx.x;
     LmState *lm = T.lm;
+    const double *part = (mode == 2) ? T.chi_part : T.step_part;
     if (sum_local) {        // unsharded: fold k_step_sum in (same fixed order)
         double c = 0, s = 0;
-        for (int e = tid; e < T.n_items; e += 256) { c += T.step_part[2 * e + STEP_CHI]; s += T.step_part[2 * e + STEP_SCALE]; }
+        for (int e = tid; e < T.n_items; e += 256) { c += part[2 * e + STEP_CHI]; s += part[2 * e + STEP_SCALE]; }
         const double ct = d_block_sum<256>(c, s0, tid);
         const double st = d_block_sum<256>(s, s0, tid);
         if (tid == 0) { T.step_tot[0] = ct; T.step_tot[1] = st; }
@@ -977,7 +987,7 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int
     const double scale_p = d_block_sum<256>(sp, s0, tid);
     if (tid != 0) return;
     double chi_imu = 0.0;
-    for (int k = 0; k < T.n_imu_items; ++k) chi_imu += T.step_part[2 * (T.n_items + k) + STEP_CHI];
+    for (int k = 0; k < T.n_imu_items; ++k) chi_imu += part[2 * (T.n_items + k) + STEP_CHI];
     double total = T.step_tot[0] + chi_imu;
     if (T.has_prior) total += sqrt(en2);            // err_prior_.norm(), not squared (problem.cc:554-556)
     const double tempChi = 0.5 * total;
@@ -1022,7 +1032,7 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int
 }
 
 // ComputeLambdaInitLM (problem.cc:497-522)
-__global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter) {
+__global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter, const double *maxh_src) {
     __shared__ double s0[256];
     const int tid = threadIdx.x;
     LmState *lm = T.lm;
@@ -1038,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter) {
     for (int k = 0; k < 10; ++k) if (T.imu_valid[k]) total += T.imu_out[k * IMU_OUT + IMU_CHI];
     if (T.has_prior) total += sqrt(en2);
     const double chi = 0.5 * total;
-    double maxDiagonal = fmax(maxd, T.vis[VIS_MAXH]);
+    double maxDiagonal = fmax(maxd, *maxh_src);     // max |h_ll| over all shards
     maxDiagonal = fmin(5e10, maxDiagonal);
     lm->ni = 2.;
     lm->chi = chi;
@@ -1067,7 +1077,7 @@ void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t 
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s) {
     hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(64), 0, s, T, mode);
 }
-void vio_launch_step_sum(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_step_sum, dim3(1), dim3(256), 0, s, T); }
+void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s) { hipLaunchKernelGGL(k_step_sum, dim3(1), dim3(256), 0, s, T, mode); }
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(256), 0, s, T, mode, sum_local);
 }
@@ -1081,8 +1091,8 @@ __global__ void k_flip(LmState *lm) {
     if (threadIdx.x == 0) lm->cur ^= 1;
 }
 void vio_launch_flip(LmState *lm, hipStream_t s) { hipLaunchKernelGGL(k_flip, dim3(1), dim3(64), 0, s, lm); }
-void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter);
+void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter, maxh_src);
 }
 int vio_set_kernel_attributes() {
     hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);

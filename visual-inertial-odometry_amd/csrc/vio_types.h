@@ -171,6 +171,7 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     double *dx;                  // [176] pose part of delta_x_
     double *dxl;                 // [Ns]  landmark part of delta_x_
     double *step_part;           // [n_step_blocks][2]
+    double *chi_part;            // [n_step_blocks][2] partials of vio_chi2 (kept apart from a pending step test)
     int32_t n_step_blocks;
     int32_t pad_;
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale

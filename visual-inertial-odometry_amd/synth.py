@@ -198,28 +198,22 @@ def make_window(n_landmarks, seed=42, obs_per_landmark=4, t0=1.0, imu_rate=200, 
         k_of = np.full(N, int(obs_per_landmark))
     px = rng.uniform(-0.5, 0.5, size=(N, 2))
     depth = rng.uniform(4.0, 10.0, size=N)
-    Rg = [m.Rwb for m in gt]
-    Pg = [m.twb for m in gt]
-    lm, host, target, pts_i, pts_j = [], [], [], [], []
-    for l in range(N):
-        h = int(host_of[l])
-        pc = np.array([px[l, 0], px[l, 1], 1.0]) * depth[l]
-        pw = Rg[h] @ (R_IC @ pc + T_IC) + Pg[h]
-        for j in range(h + 1, h + 1 + int(k_of[l])):
-            pcj = R_IC.T @ (Rg[j].T @ (pw - Pg[j]) - T_IC)
-            if pcj[2] < 0.5:        # behind / too close: keep the edge count deterministic, clamp the geometry
-                pcj[2] = 0.5
-            obs = pcj[0:2] / pcj[2] + rng.normal(0.0, pixel_noise, size=2)
-            lm.append(l)
-            host.append(h)
-            target.append(j)
-            pts_i.append(px[l])
-            pts_j.append(obs)
-    lm = np.array(lm, dtype=np.int32)
-    host = np.array(host, dtype=np.int32)
-    target = np.array(target, dtype=np.int32)
-    pts_i = np.array(pts_i, dtype=np.float64).reshape(-1, 2)
-    pts_j = np.array(pts_j, dtype=np.float64).reshape(-1, 2)
+    Rg = np.stack([m.Rwb for m in gt])
+    Pg = np.stack([m.twb for m in gt])
+    # vectorised over landmarks; observation order = landmark-major, then target frame (estimator.cpp:975-1016)
+    pc = np.concatenate([px, np.ones((N, 1))], axis=1) * depth[:, None]
+    pb = pc @ R_IC.T + T_IC
+    pw = np.einsum("nij,nj->ni", Rg[host_of], pb) + Pg[host_of]
+    lm = np.repeat(np.arange(N, dtype=np.int32), k_of)
+    first = np.concatenate([[0], np.cumsum(k_of)[:-1]]) if N else np.zeros(0, dtype=np.int64)
+    within = np.arange(lm.size) - np.repeat(first, k_of)
+    host = host_of[lm].astype(np.int32)
+    target = (host + 1 + within).astype(np.int32)
+    pbj = np.einsum("nji,nj->ni", Rg[target], pw[lm] - Pg[target])
+    pcj = (pbj - T_IC) @ R_IC
+    pcj[:, 2] = np.maximum(pcj[:, 2], 0.5)      # behind / too close: keep the edge count deterministic
+    pts_j = pcj[:, 0:2] / pcj[:, 2:3] + rng.normal(0.0, pixel_noise, size=(lm.size, 2))
+    pts_i = px[lm].copy()
     if outlier_fraction > 0 and lm.size:
         bad = rng.rand(lm.size) < outlier_fraction
         pts_j[bad] += rng.normal(0.0, 0.05, size=(int(bad.sum()), 2))
