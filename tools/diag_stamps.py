@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Diagnostic only: phase shares of k_linearize from the -DVIO_STAMPS build (csrc/diag/libvio_hip_stamps.so).
+Never used for timing claims: stamps change the schedule; read the SHARES."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package  # noqa: E402
+
+vio = load_package()
+lib = vio.VioLib(os.path.join(ROOT, "visual-inertial-odometry_amd", "csrc", "diag", "libvio_hip_stamps.so"), "vio_")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+w = vio.synth.make_window(n, seed=42)
+ctx = lib.context()
+ctx.load(w)
+for _ in range(3):
+    ctx.linearize()
+ctx.synchronize()
+nb = (n + 63) // 64 + 20
+buf = np.zeros((nb, 16), dtype=np.uint64)
+f = lib.dll.vio_debug_stamps
+f.restype = C.c_int
+assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(nb)) == 0
+st = buf.astype(np.int64)
+valid = st[:, 5] > 0
+vis = valid & (st[:, 1] > 0)
+imu = valid & (st[:, 1] == 0)
+names = ["load pair table", "phase 1 (per observation)", "phase 1.5 (per landmark)", "phase 2 (strips)", "combine + store"]
+d = np.diff(st[vis][:, :6], axis=1)
+print("visual workgroups: %d   (s_memtime ticks = 100 MHz?  constant clock; shares are what matters)" % vis.sum())
+for k, nm in enumerate(names):
+    print("  %-28s mean %8.1f  max %8.1f" % (nm, d[:, k].mean(), d[:, k].max()))
+print("  total                        mean %8.1f  max %8.1f" % ((st[vis][:, 5] - st[vis][:, 0]).mean(), (st[vis][:, 5] - st[vis][:, 0]).max()))
+if imu.any():
+    t = st[imu][:, 5] - st[imu][:, 0]
+    print("IMU workgroups: %d  total mean %.1f max %.1f" % (imu.sum(), t.mean(), t.max()))
+t0, t1 = st[valid][:, 0].min(), st[valid][:, 5].max()
+print("kernel span (first start -> last end): %d ticks; start spread %d" % (t1 - t0, st[valid][:, 0].max() - t0))
+
+# ---- k_pose_solve (stamps are cumulative ticks since kernel start; slots 8/9 are sums over the 22 panels)
+ctx.linearize()
+_, lam = ctx.init_lm()
+for _ in range(3):
+    ctx.solve_linear(lam)
+ctx.synchronize()
+assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(2)) == 0
+st = buf.astype(np.int64)[0]
+print("k_pose_solve: load+permute %d | factorisation done %d (panels %d, trailing %d) | back-substitution done %d | end %d"
+      % (st[0], st[1], st[8], st[9], st[2], st[3]))

@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -37,12 +38,13 @@ void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
 int vio_set_kernel_attributes();
+int lin_lds_doubles_host(int G, int K, int nb, int use_ext, int nsplit, int n_strips);
 
 namespace {
 
 constexpr int NF = VIO_NUM_FRAMES, PD = VIO_POSE_DIM, PRD = VIO_PRIOR_DIM;
 constexpr int LDS_BUDGET_DOUBLES = 150 * 1024 / 8;     // per linearize workgroup (160 KiB per CU on gfx950)
-constexpr int POSE_SOLVE_LDS = (14880 + 5 * 176 + 112 + 176) * 8 + 176 * 4 + 64;
+constexpr int POSE_SOLVE_LDS = (15754 + 177 * 10 + 5 * 176 + 112 + 176) * 8 + 176 * 4 + 64;
 constexpr int IMU_ITEM_LDS_DOUBLES = 450 + 225 + 450 + 32;
 
 template <typename T>
@@ -63,6 +65,7 @@ struct DevBuf {
 
 struct Pattern {
     int use_ext, host, K, nb, host_slot, nsplit, G;
+    int btype_i[VIO_MAXNB], bk_i[VIO_MAXNB];
     int8_t target[VIO_MAXK], tslot[VIO_MAXK], cam_block[VIO_MAXNB];
     int strip_off, n_strips, row_off, n_rows, lds_doubles;
 };
@@ -114,6 +117,7 @@ struct vio_ctx {
     bool pairtab_valid = false;
     bool stepwise_updated = false;
     double gn_lambda = -1.0;
+    int g_max = 64;                            // landmarks per item (tunable: VIO_G_MAX)
     Plan solve_plan, marg_plan;
     Plan *active = nullptr;
     // device buffers independent of the topology
@@ -126,6 +130,7 @@ struct vio_ctx {
     void *hook_user = nullptr;
     double hessian_ms = 0;
     double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
+    DevBuf<unsigned long long> d_dbg;                  // diagnostic builds only
     int prof_which = -1;
     std::vector<hipEvent_t> prof_events;               // pairs
     size_t prof_used = 0;
@@ -153,48 +158,50 @@ vio_status fail(vio_ctx *c, vio_status s, const std::string &msg) {
 }
 
 // ---- topology preprocessing ----------------------------------------------------------------------------
-void build_pattern_tables(Pattern &pt, std::vector<uint32_t> &strips, std::vector<uint32_t> &rows) {
+void build_pattern_tables(Pattern &pt, std::vector<uint32_t> &strips, std::vector<uint32_t> &elems, int g_max) {
     const int nb = pt.nb, K = pt.K;
-    int type[VIO_MAXNB], kof[VIO_MAXNB];
+    int *type = pt.btype_i, *kof = pt.bk_i;
     for (int p = 0; p < nb; ++p) {
         type[p] = (pt.use_ext && p == 0) ? 0 : (p == pt.host_slot ? 1 : 2);
         kof[p] = 15;
     }
     for (int k = 0; k < K; ++k) kof[pt.tslot[k]] = k;
     pt.strip_off = (int)strips.size();
-    pt.row_off = (int)rows.size();
+    pt.row_off = (int)elems.size();
     int ns = 0;
+    std::vector<uint32_t> diag_elems;           // direct diagonal: slot 6 of the (p,p,i) strips
     for (int p = 0; p < nb; ++p)
         for (int q = p; q < nb; ++q)
             for (int i = 0; i < 6; ++i) {
                 const int first = ns;
                 int ncopy = 1;
-                if (type[p] != 2 && type[q] != 2) {
+                const int dflag = p == q;
+                if (type[p] != 2 && type[q] != 2) {          // both touched by every observation: one copy per k
                     ncopy = K;
-                    for (int cpy = 0; cpy < K; ++cpy) { strips.push_back(STRIP_PACK(p, q, i, cpy, cpy == 0, 0, type[p], type[q])); ++ns; }
-                } else if (type[p] == 2 && type[q] == 2 && p != q) {
+                    for (int cpy = 0; cpy < K; ++cpy) { strips.push_back(STRIP_PACK(p, q, i, cpy, cpy == 0 ? 1 : 0, dflag, type[p], type[q])); ++ns; }
+                } else if (type[p] == 2 && type[q] == 2 && p != q) {     // two different targets: Schur term only
                     strips.push_back(STRIP_PACK(p, q, i, 15, 1, 0, type[p], type[q])); ++ns;
                 } else {
                     const int k = type[p] == 2 ? kof[p] : kof[q];
-                    strips.push_back(STRIP_PACK(p, q, i, k, 1, 0, type[p], type[q])); ++ns;
+                    strips.push_back(STRIP_PACK(p, q, i, k, 1, dflag, type[p], type[q])); ++ns;
                 }
-                rows.push_back((uint32_t)first | ((uint32_t)ncopy << 16));
+                for (int j = 0; j < 6; ++j) elems.push_back(ELEM_PACK(first, ncopy, j));
+                if (dflag) diag_elems.push_back(ELEM_PACK(first, ncopy, 6));
             }
-    for (int kind = 1; kind <= 3; ++kind)
+    // vector rows: direct b (landmark term 3), Schur correction of b (landmark term 2), then the direct diagonal
+    for (int sel = 3; sel >= 2; --sel)
         for (int p = 0; p < nb; ++p) {
-            const int k = type[p] == 2 ? kof[p] : 15;
-            rows.push_back((uint32_t)ns | (1u << 16));
-            strips.push_back(STRIP_PACK(p, 0, 0, k, 0, kind, type[p], 0)); ++ns;
+            for (int j = 0; j < 6; ++j) elems.push_back(ELEM_PACK(ns, 1, j));
+            strips.push_back(STRIP_PACK(p, 0, 0, 15, sel, 0, type[p], 0)); ++ns;
         }
+    elems.insert(elems.end(), diag_elems.begin(), diag_elems.end());
     pt.n_strips = ns;
     pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
     pt.nsplit = ns < 192 ? 4 : 1;
-    const int REC = pt.use_ext ? 59 : 41, LREC = (12 * nb + 3) | 1;
-    int G = std::max(1, std::min(64, 256 / K));
-    auto lds = [&](int g) { return VIO_MAXK * PAIR_STRIDE + 16 + 256 + g * K * REC + g * LREC + pt.nsplit * ns * 6; };
-    while (G > 1 && lds(G) > LDS_BUDGET_DOUBLES) --G;
+    int G = std::max(1, std::min(g_max, 256 / K));
+    while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext, pt.nsplit, ns) > LDS_BUDGET_DOUBLES) --G;
     pt.G = G;
-    pt.lds_doubles = lds(G);
+    pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext, pt.nsplit, ns);
 }
 
 vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
@@ -247,7 +254,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
                 pt.target[k] = key[1 + k];
                 for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + key[1 + k]) pt.tslot[k] = (int8_t)q;
             }
-            build_pattern_tables(pt, pl.strips, pl.rows);
+            build_pattern_tables(pt, pl.strips, pl.rows, c->g_max);
             pl.patterns.push_back(pt);
         } else id = itp->second;
         lm_pattern[l] = id;
@@ -275,6 +282,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         it.out_base = (int32_t)pl.slab_doubles; it.lw_base = (int32_t)pl.lw_doubles;
         std::memcpy(it.target, pt.target, sizeof(it.target)); std::memcpy(it.tslot, pt.tslot, sizeof(it.tslot));
         std::memcpy(it.cam_block, pt.cam_block, sizeof(it.cam_block));
+        for (int p = 0; p < pt.nb; ++p) { it.btype[p] = (int8_t)pt.btype_i[p]; it.bk[p] = (int8_t)pt.bk_i[p]; }
         it.strip_off = pt.strip_off; it.n_strips = pt.n_strips; it.row_off = pt.row_off; it.n_rows = pt.n_rows;
         it.nsplit = pt.nsplit; it.lds_doubles = pt.lds_doubles;
         pl.items.push_back(it);
@@ -374,6 +382,10 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
+#ifdef VIO_STAMPS
+    (void)c->d_dbg.resize(16 * (size_t)(T.n_items + T.n_imu_items + 16));
+    T.dbg = c->d_dbg.p;
+#endif
     return T;
 }
 
@@ -552,6 +564,7 @@ vio_status vio_create(const vio_config *cfg, vio_ctx **out) {
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) c->imu_valid[k] = false;
     c->h_pre.assign(VIO_WINDOW_SIZE * PRE_STRIDE, 0.0);
     c->h_Hprior.assign(PD * PD, 0.0); c->h_bprior.assign(PD, 0.0); c->h_errprior.assign(PRD, 0.0); c->h_Jtinv.assign(PRD * PRD, 0.0);
+    if (const char *e = std::getenv("VIO_G_MAX")) { int v = std::atoi(e); if (v >= 1 && v <= 64) c->g_max = v; }
     if (vio_set_kernel_attributes() != 0) { c->err = "hipFuncSetAttribute failed"; }
     vio_status s = alloc_fixed(c);
     if (s != VIO_OK) { vio_destroy(c); return s; }
@@ -910,6 +923,16 @@ vio_status vio_bind_exchange_buffers(vio_ctx *c, void *reduced, void *scalars) {
     c->linearized = false;
     return VIO_OK;
 }
+
+#ifdef VIO_STAMPS
+// diagnostic build: copy out the s_memtime stamps of the last k_linearize launch ([block][16])
+vio_status vio_debug_stamps(vio_ctx *c, unsigned long long *out, int64_t n_blocks) {
+    if (!c || !c->d_dbg.p) return VIO_ERR_BAD_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->d_dbg.p, (size_t)n_blocks * 16 * 8, hipMemcpyDeviceToHost));
+    return VIO_OK;
+}
+#endif
 
 const char *vio_kernel_name(int32_t which) {
     static const char *names[VIO_K_COUNT] = {"k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"};

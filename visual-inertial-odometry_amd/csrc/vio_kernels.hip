@@ -24,6 +24,16 @@
 
 #define LIN_THREADS 256
 
+// In-kernel stamps exist only in the diagnostic build (-DVIO_STAMPS -> libvio_hip_stamps.so, never shipped or timed)
+#ifdef VIO_STAMPS
+#define STAMP(T, slot)                                                                                   \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && (T).dbg) (T).dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STAMP(T, slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
 // inverse: -1 when the full index is a speed-bias dimension
 __device__ __forceinline__ int full_to_cam(int i) {
@@ -307,39 +317,58 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
 // ---------------------------------------------------------------------------------------------------------
 // k_linearize: one workgroup (256 threads) per item
 //   phase 1   thread per observation (k-major: a wave shares one target frame): residual, Jacobians, robust
-//             weight, whitened rows L*J into an LDS record per observation
-//   phase 1.5 thread per landmark: h_ll, b_l, Schur row w = Hpl, written to HBM for the back-substitution
-//   phase 2   lanes own 1x6 strips of the output blocks and stream the LDS records (4 waves split the
-//             landmarks or the strips); fixed summation order
+//             weight; the whitened rows L*J go to sRows (one plane per k, planes skewed by 6 doubles so that the
+//             strips of different k hit different LDS banks), the scalars phase 1.5 needs go to sAux
+//   phase 1.5 (landmark, block-subset) threads: h_ll, b_l, Schur row w = Hpl, direct b; w/h/b_l also go to HBM for
+//             the back-substitution
+//   phase 2   lanes own 1x6 strips of the output blocks and stream the LDS rows of the item's landmarks
+//             (the 4 waves split the landmarks, or the strips when there are many); every strip runs the same
+//             loop body: an optional "landmark term" coef * X[0..5] (Schur / b correction / direct b) and an
+//             optional "direct term" p0*q0[0..5] + p1*q1[0..5]; fixed summation order
+//   combine   thread per output element sums the wave partials and the per-k copies, coalesced store to the slab
+// LDS rows are read as 16-byte pairs (ds_read_b128); all region sizes and strides are even numbers of doubles.
 // ---------------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+
+__host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles)
+__host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 23 : 17; }      // aux record stride (odd)
+__host__ __device__ inline int lin_plane(int G, int use_ext) { return G * lin_rrow(use_ext) + 6; }
+__host__ __device__ inline int lin_lrec(int nb) { return 12 * nb + 4; }
+// total dynamic LDS of an item (doubles); must match the carve-up in k_linearize
+__host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext, int nsplit, int n_strips) {
+    int aux = G * K * lin_raux(use_ext), part = nsplit * n_strips * 8;
+    int shared = aux > part ? aux : part;
+    shared = (shared + 1) & ~1;
+    return VIO_MAXK * PAIR_STRIDE + 16 + LIN_THREADS + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
+}
 
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (b >= T.n_items) {
+        STAMP(T, 0);
         d_imu_item(T, b - T.n_items, dyn_smem);
+        STAMP(T, 5);
         return;
     }
     __shared__ ItemDesc sIt;        // kept in LDS: its small arrays are indexed at run time
     if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
     __syncthreads();
     const ItemDesc &it = sIt;
+    STAMP(T, 0);
     const int cur = T.lm->cur;
     const int G = it.G, K = it.K, nb = it.nb, use_ext = it.use_ext;
-    const int REC = use_ext ? 59 : 41;
-    const int offH = 0, offT = 12, offE = 24;
-    const int offA = use_ext ? 36 : 24;
-    const int offBH = offA + 2, offBT = offBH + 6, offBE = offBT + 6;
-    const int offBL = use_ext ? 56 : 38;
-    const int LREC = (12 * nb + 3) | 1;
+    const int RROW = lin_rrow(use_ext), RAUX = lin_raux(use_ext), PLANE = lin_plane(G, use_ext), LREC = lin_lrec(nb);
+    const int offH = 0, offT = 12, offE = 24;                       // inside a row record
+    const int auxA = 0, auxBH = 2, auxBT = 8, auxBL = 14, auxBE = 15;   // inside an aux record
 
-    double *sPair = dyn_smem;                         // K * PAIR_STRIDE
+    double *sPair = dyn_smem;                         // VIO_MAXK * PAIR_STRIDE
     double *sCam = sPair + VIO_MAXK * PAIR_STRIDE;    // ric, tic
     double *sRed = sCam + 16;                         // LIN_THREADS
-    double *sRec = sRed + LIN_THREADS;                // G*K*REC
-    double *sLrec = sRec + G * K * REC;               // G*LREC
-    double *sPart = sLrec + G * LREC;                 // nsplit*n_strips*6
+    double *sRows = sRed + LIN_THREADS;               // K * PLANE
+    double *sL = sRows + K * PLANE;                   // G * LREC
+    double *sAux = sL + G * LREC;                     // G*K*RAUX, dead after phase 1.5 ...
+    double *sPart = sAux;                             // ... then nsplit*n_strips*8
 
     const double *ptab = T.pairtab + cur * PAIRTAB_STRIDE;
     for (int e = tid; e < K * PAIR_STRIDE; e += LIN_THREADS) {
@@ -356,6 +385,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     const double *ric = sCam, *tic = sCam + CAMTAB_TIC;
 
     // ---------------- phase 1 ----------------
+    STAMP(T, 1);
     double chi_acc = 0.0;
     for (int o = tid; o < G * K; o += LIN_THREADS) {
         const int k = o / G, g = o - k * G;
@@ -414,19 +444,20 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         const double L00 = s_info * (al + gm * r0 * r0), L01 = s_info * (gm * r0 * r1), L11 = s_info * (al + gm * r1 * r1);
         const double c0 = rho1 * (info * r0), c1 = rho1 * (info * r1);         // drho * Information * residual
 
-        double *rec = sRec + (size_t)o * REC;
+        double *rec = sRows + k * PLANE + g * RROW;
+        double *aux = sAux + (size_t)o * RAUX;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             rec[offH + c] = L00 * Jh0[c] + L01 * Jh1[c];
             rec[offH + 6 + c] = L01 * Jh0[c] + L11 * Jh1[c];
             rec[offT + c] = L00 * Jt0[c] + L01 * Jt1[c];
             rec[offT + 6 + c] = L01 * Jt0[c] + L11 * Jt1[c];
-            rec[offBH + c] = Jh0[c] * c0 + Jh1[c] * c1;
-            rec[offBT + c] = Jt0[c] * c0 + Jt1[c] * c1;
+            aux[auxBH + c] = Jh0[c] * c0 + Jh1[c] * c1;
+            aux[auxBT + c] = Jt0[c] * c0 + Jt1[c] * c1;
         }
-        rec[offA] = L00 * Jl0 + L01 * Jl1;
-        rec[offA + 1] = L01 * Jl0 + L11 * Jl1;
-        rec[offBL] = Jl0 * c0 + Jl1 * c1;
+        aux[auxA] = L00 * Jl0 + L01 * Jl1;
+        aux[auxA + 1] = L01 * Jl0 + L11 * Jl1;
+        aux[auxBL] = Jl0 * c0 + Jl1 * c1;
         if (use_ext) {
             // J_ext = reduce * [El | -C hat(pc_i) + hat(C pc_i) + hat(d)] = [reduce*El | pc_i x (reduce*C)rows + red_rows x pc_j]
             double Je0[6], Je1[6], RC0[3], RC1[3];
@@ -446,132 +477,135 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             for (int c = 0; c < 6; ++c) {
                 rec[offE + c] = L00 * Je0[c] + L01 * Je1[c];
                 rec[offE + 6 + c] = L01 * Je0[c] + L11 * Je1[c];
-                rec[offBE + c] = Je0[c] * c0 + Je1[c] * c1;
+                aux[auxBE + c] = Je0[c] * c0 + Je1[c] * c1;
             }
         }
     }
     __syncthreads();
 
-    // ---------------- phase 1.5: per landmark ----------------
+    // ---------------- phase 1.5: (landmark, block subset) ----------------
+    STAMP(T, 2);
     double maxh = 0.0;
-    for (int g = tid; g < G; g += LIN_THREADS) {
-        double h = 0, bl = 0;
-        double wH[6] = {0, 0, 0, 0, 0, 0}, wE[6] = {0, 0, 0, 0, 0, 0};
-        double *L = sLrec + (size_t)g * LREC;
-        for (int k = 0; k < K; ++k) {
-            const double *rec = sRec + (size_t)(k * G + g) * REC;
-            const double a0 = rec[offA], a1 = rec[offA + 1];
-            h += a0 * a0 + a1 * a1;
-            bl -= rec[offBL];
-            const int ts = it.tslot[k];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                wH[c] += rec[offH + c] * a0 + rec[offH + 6 + c] * a1;
-                L[6 * ts + c] = rec[offT + c] * a0 + rec[offT + 6 + c] * a1;
+    {
+        const int parts = LIN_THREADS / G > 0 ? LIN_THREADS / G : 1;
+        const int g = tid % G, part = tid / G;
+        if (part < parts) {
+            double h = 0;
+            for (int k = 0; k < K; ++k) {
+                const double *aux = sAux + (size_t)(k * G + g) * RAUX;
+                h += aux[auxA] * aux[auxA] + aux[auxA + 1] * aux[auxA + 1];
             }
-            if (use_ext) {
+            const double hinv = 1.0 / h;                // Hmm_inv (problem.cc:419-425)
+            double *L = sL + (size_t)g * LREC;
+            double *lw = T.lw + it.lw_base;
+            for (int p = part; p < nb; p += parts) {
+                const int ty = it.btype[p];             // 0 ext, 1 host, 2 target
+                const int k0 = ty == 2 ? it.bk[p] : 0, k1 = ty == 2 ? it.bk[p] + 1 : K;
+                const int offR = ty == 0 ? offE : (ty == 1 ? offH : offT);
+                const int offB = ty == 0 ? auxBE : (ty == 1 ? auxBH : auxBT);
+                double w[6] = {0, 0, 0, 0, 0, 0}, bv[6] = {0, 0, 0, 0, 0, 0};
+                for (int k = k0; k < k1; ++k) {
+                    const double *rec = sRows + k * PLANE + g * RROW + offR;
+                    const double *aux = sAux + (size_t)(k * G + g) * RAUX;
+                    const double a0 = aux[auxA], a1 = aux[auxA + 1];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) wE[c] += rec[offE + c] * a0 + rec[offE + 6 + c] * a1;
+                    for (int c = 0; c < 6; ++c) { w[c] += rec[c] * a0 + rec[6 + c] * a1; bv[c] += aux[offB + c]; }
+                }
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    L[6 * p + c] = w[c];                // Hpm column of this landmark
+                    L[6 * nb + 6 * p + c] = bv[c];      // sum_k drho J^T Info r  (b gets the minus sign in phase 2)
+                    lw[(size_t)(6 * p + c) * G + g] = w[c];
+                }
+            }
+            if (part == 0) {
+                double bl = 0;
+                for (int k = 0; k < K; ++k) bl -= sAux[(size_t)(k * G + g) * RAUX + auxBL];
+                L[12 * nb] = hinv;
+                L[12 * nb + 1] = bl;
+                maxh = fabs(h);
+                lw[(size_t)(6 * nb) * G + g] = h;
+                lw[(size_t)(6 * nb + 1) * G + g] = bl;
             }
         }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) L[6 * it.host_slot + c] = wH[c];
-        if (use_ext) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) L[c] = wE[c];
-        }
-        const double hinv = 1.0 / h;                // Hmm_inv (problem.cc:419-425)
-        for (int c = 0; c < 6 * nb; ++c) L[6 * nb + c] = L[c] * hinv;     // tempH = Hpm * Hmm_inv (problem.cc:427)
-        L[12 * nb] = hinv;
-        L[12 * nb + 1] = bl;
-        maxh = fmax(maxh, fabs(h));
-        double *lw = T.lw + it.lw_base;
-        for (int c = 0; c < 6 * nb; ++c) lw[(size_t)c * G + g] = L[c];
-        lw[(size_t)(6 * nb) * G + g] = h;
-        lw[(size_t)(6 * nb + 1) * G + g] = bl;
     }
     __syncthreads();
 
     // ---------------- phase 2: strips ----------------
+    STAMP(T, 3);
     const int n_strips = it.n_strips, nsplit = it.nsplit;
-    const int wave = tid >> 6, lane = tid & 63;
-    const uint32_t *strips = T.strips + it.strip_off;
-    const int s_first = (nsplit == 4) ? lane : tid;
-    const int s_step = (nsplit == 4) ? 64 : LIN_THREADS;
-    const int g_first = (nsplit == 4) ? wave : 0;
-    const int g_step = (nsplit == 4) ? 4 : 1;
-    const int split = (nsplit == 4) ? wave : 0;
-    for (int s = s_first; s < n_strips; s += s_step) {
-        const uint32_t w = strips[s];
-        const int p = STRIP_P(w), q = STRIP_Q(w), i = STRIP_I(w), ks = STRIP_K(w), kind = STRIP_KIND(w);
-        const int sp = STRIP_SRCP(w), sq = STRIP_SRCQ(w);
-        const int offp = sp == 0 ? offE : (sp == 1 ? offH : offT);
-        const int offq = sq == 0 ? offE : (sq == 1 ? offH : offT);
-        double acc[6] = {0, 0, 0, 0, 0, 0};
-        if (kind == 0) {
-            const int schur = STRIP_SCHUR(w);
-            for (int g = g_first; g < G; g += g_step) {
-                if (schur) {
-                    const double *L = sLrec + (size_t)g * LREC;
-                    const double ai = L[6 * nb + 6 * p + i];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[j] -= ai * L[6 * q + j];
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const uint32_t *strips = T.strips + it.strip_off;
+        const int s_first = (nsplit == 4) ? lane : tid;
+        const int s_step = (nsplit == 4) ? 64 : LIN_THREADS;
+        const int g_first = (nsplit == 4) ? wave : 0;
+        const int g_step = (nsplit == 4) ? 4 : 1;
+        const int split = (nsplit == 4) ? wave : 0;
+        for (int s = s_first; s < n_strips; s += s_step) {
+            const uint32_t w = strips[s];
+            const int p = STRIP_P(w), q = STRIP_Q(w), i = STRIP_I(w), ks = STRIP_K(w), selL = STRIP_SELL(w);
+            const int sp = STRIP_SRCP(w), sq = STRIP_SRCQ(w), dflag = STRIP_DIAG(w);
+            const int offp = (sp == 0 ? offE : (sp == 1 ? offH : offT)) + i;
+            const int offq = sq == 0 ? offE : (sq == 1 ? offH : offT);
+            // landmark term: acc += coef * X[0..5]
+            const int offX = selL == 3 ? 6 * nb + 6 * p : (selL == 1 ? 6 * q : 6 * p);
+            const int offC = 6 * p + i;
+            const bool direct = ks != 15;
+            double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, acc5 = 0, dd = 0;
+            const double *Lg = sL + (size_t)g_first * LREC;
+            const double *rec = sRows + (direct ? ks : 0) * PLANE + g_first * RROW;
+            for (int g = g_first; g < G; g += g_step, Lg += g_step * LREC, rec += g_step * RROW) {
+                if (selL) {
+                    const double hinv = Lg[12 * nb];
+                    double coef = -1.0;
+                    if (selL == 1) coef = -(Lg[offC] * hinv);          // -(Hpm * Hmm^-1) entry (problem.cc:427)
+                    else if (selL == 2) coef = hinv * Lg[12 * nb + 1];
+                    const double2 x01 = *reinterpret_cast<const double2 *>(Lg + offX);
+                    const double2 x23 = *reinterpret_cast<const double2 *>(Lg + offX + 2);
+                    const double2 x45 = *reinterpret_cast<const double2 *>(Lg + offX + 4);
+                    acc0 += coef * x01.x; acc1 += coef * x01.y; acc2 += coef * x23.x;
+                    acc3 += coef * x23.y; acc4 += coef * x45.x; acc5 += coef * x45.y;
                 }
-                if (ks != 15) {
-                    const double *rec = sRec + (size_t)(ks * G + g) * REC;
-                    const double p0 = rec[offp + i], p1 = rec[offp + 6 + i];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[j] += p0 * rec[offq + j] + p1 * rec[offq + 6 + j];
-                }
-            }
-        } else if (kind == 2) {         // Schur correction of b: (Hpm*Hmm^-1) * bmm
-            for (int g = g_first; g < G; g += g_step) {
-                const double *L = sLrec + (size_t)g * LREC;
-                const double bl = L[12 * nb + 1];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[j] += L[6 * nb + 6 * p + j] * bl;
-            }
-        } else {                        // kind 1: direct b, kind 3: direct diagonal
-            const int offb = sp == 0 ? offBE : (sp == 1 ? offBH : offBT);
-            const int k0 = ks == 15 ? 0 : ks, k1 = ks == 15 ? K : ks + 1;
-            for (int g = g_first; g < G; g += g_step) {
-                for (int k = k0; k < k1; ++k) {
-                    const double *rec = sRec + (size_t)(k * G + g) * REC;
-                    if (kind == 1) {
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) acc[j] -= rec[offb + j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) acc[j] += rec[offp + j] * rec[offp + j] + rec[offp + 6 + j] * rec[offp + 6 + j];
-                    }
+                if (direct) {
+                    const double p0 = rec[offp], p1 = rec[offp + 6];
+                    const double2 a01 = *reinterpret_cast<const double2 *>(rec + offq);
+                    const double2 a23 = *reinterpret_cast<const double2 *>(rec + offq + 2);
+                    const double2 a45 = *reinterpret_cast<const double2 *>(rec + offq + 4);
+                    const double2 b01 = *reinterpret_cast<const double2 *>(rec + offq + 6);
+                    const double2 b23 = *reinterpret_cast<const double2 *>(rec + offq + 8);
+                    const double2 b45 = *reinterpret_cast<const double2 *>(rec + offq + 10);
+                    acc0 += p0 * a01.x + p1 * b01.x; acc1 += p0 * a01.y + p1 * b01.y;
+                    acc2 += p0 * a23.x + p1 * b23.x; acc3 += p0 * a23.y + p1 * b23.y;
+                    acc4 += p0 * a45.x + p1 * b45.x; acc5 += p0 * a45.y + p1 * b45.y;
+                    if (dflag) dd += p0 * p0 + p1 * p1;
                 }
             }
+            double *o = sPart + ((size_t)split * n_strips + s) * 8;
+            o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; o[4] = acc4; o[5] = acc5; o[6] = dd;
         }
-        double *o = sPart + ((size_t)split * n_strips + s) * 6;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) o[j] = acc[j];
     }
     __syncthreads();
 
     // ---------------- combine and write the item's slab ----------------
-    const uint32_t *rows = T.rows + it.row_off;
-    double *out = T.slab + it.out_base;
-    for (int r = tid; r < it.n_rows; r += LIN_THREADS) {
-        const uint32_t w = rows[r];
-        const int first = ROW_FIRST(w), ncopy = ROW_NCOPY(w);
-        double sum[6] = {0, 0, 0, 0, 0, 0};
-        for (int c = 0; c < ncopy; ++c)
-            for (int v = 0; v < nsplit; ++v) {
-                const double *o = sPart + ((size_t)v * n_strips + first + c) * 6;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) sum[j] += o[j];
-            }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) out[(size_t)r * 6 + j] = sum[j];
+    STAMP(T, 4);
+    {
+        const uint32_t *elems = T.rows + it.row_off;
+        double *out = T.slab + it.out_base;
+        const int n_out = it.n_rows * 6;
+        for (int e = tid; e < n_out; e += LIN_THREADS) {
+            const uint32_t w = elems[e];
+            const int first = ELEM_FIRST(w), ncopy = ELEM_NCOPY(w), slot = ELEM_SLOT(w);
+            double sum = 0;
+            for (int c = 0; c < ncopy; ++c)
+                for (int v = 0; v < nsplit; ++v) sum += sPart[((size_t)v * n_strips + first + c) * 8 + slot];
+            out[e] = sum;
+        }
+        const double chi = d_block_sum<LIN_THREADS>(chi_acc, sRed, tid);
+        const double mh = d_block_max<LIN_THREADS>(maxh, sRed, tid);
+        if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
     }
-    const double chi = d_block_sum<LIN_THREADS>(chi_acc, sRed, tid);
-    const double mh = d_block_max<LIN_THREADS>(maxh, sRed, tid);
-    if (tid == 0) { out[(size_t)it.n_rows * 6] = chi; out[(size_t)it.n_rows * 6 + 1] = mh; }
+    STAMP(T, 5);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -700,19 +734,49 @@ __global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_pose_solve: single workgroup, 1024 threads.  (H_pp_schur_ + lambda I) dx = b_pp_schur_ with the pivot order
-// Eigen's LDLT would pick (largest |diagonal| first; Eigen pivots on the not-yet-updated diagonal,
-// Cholesky/LDLT.h:317-320, so the order is known before the factorisation starts), packed lower triangle in LDS,
-// right-hand side carried as an extra row so the forward substitution comes for free; back-substitution by
-// one wave; then the trial pose states, their pair table and the first-order prior update.
+// k_pose_solve: single workgroup, 1024 threads.  (H_pp_schur_ + lambda I) dx = b_pp_schur_ (problem.cc:434-439).
+//
+// Pivoting: Eigen's LDLT picks, at step k, the largest |diagonal| among the NOT YET UPDATED trailing diagonal
+// (it is a left-looking algorithm, Cholesky/LDLT.h:317-320), so the whole pivot order is a sort of |diag(A)| and is
+// known before the factorisation starts: rank-sort the diagonal, gather the permuted lower triangle into LDS
+// (packed, 119 KB of the CU's 160 KB), then run an unpivoted blocked right-looking LDL^T on it:
+//   panel (8 columns)  one wave, rows in registers, pivot row entries broadcast with v_readlane, reciprocal by
+//                      v_rcp_f64 + Newton; columns stay unscaled (P(r,k) = L(r,k) d_k)
+//   trailing update    all 16 waves, 4x4 register tiles, A22 -= L21 D^-1 L21^T from LDS
+// The right-hand side rides along as row n of the packed triangle, so the forward substitution is free; the
+// back-substitution with L^T is done by one wave panel by panel.  Then: trial pose states (UpdateStates :453-480,
+// vertex_pose.cc:7-19), their pair table, and the first-order prior update (:473-474).
 // ---------------------------------------------------------------------------------------------------------
-#define PS_THREADS 1024
+#define PS_THREADS 512
+#define PS_TY (PS_THREADS / 32)
 #define PS_N VIO_PD
+#define PS_NB 8
 __device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }
 
+__device__ __forceinline__ double d_readlane(double x, int lane) {      // lane is wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double d_fast_rcp(double d) {                // 1/d to within an ulp; 0 for d == 0
+    if (d == 0.0) return 0.0;
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+
+// The 171x171 system is padded to NP = 176 = 22 panels of 8 with identity pivots (zero right-hand side), the
+// right-hand side is row NP of the packed triangle.
+#define PS_NP 176
+#define PS_SROW 10      // row stride of the scaled panel (doubles): 16-byte aligned and bank-conflict free for b128
+
 __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
-    double *P = dyn_smem;                          // (PS_N+1)(PS_N+2)/2 = 14878
-    double *sDg = P + 14880;                       // 176 diag (+lambda)
+    double *P = dyn_smem;                          // (NP+1)(NP+2)/2 = 15753
+    double *sS = P + 15754;                        // scaled panel L21 D^-1: (NP+1) rows x PS_SROW
+    double *sDg = sS + (PS_NP + 1) * PS_SROW;      // 176 diag (+lambda)
     double *sDinv = sDg + 176;                     // 176
     double *sX = sDinv + 176;                      // 176 solution in pivot order
     double *sDx = sX + 176;                        // 176 solution in natural order
@@ -723,7 +787,17 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     LmState *lm = T.lm;
     const int cur = lm->cur, trial = cur ^ 1;
     const double lambda = lm->lambda;
-    const int n = PS_N;
+    const int n = PS_N, NP = PS_NP;
+#ifdef VIO_STAMPS
+    unsigned long long t_panel = 0, t_trail = 0, t_mark = 0, t_start = __builtin_amdgcn_s_memtime();
+#define PS_MARK() (t_mark = __builtin_amdgcn_s_memtime())
+#define PS_ADD(acc) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); acc += now__ - t_mark; t_mark = now__; } while (0)
+#define PS_OUT(slot) do { if (tid == 0 && T.dbg) T.dbg[slot] = __builtin_amdgcn_s_memtime() - t_start; } while (0)
+#else
+#define PS_MARK() do { } while (0)
+#define PS_ADD(acc) do { } while (0)
+#define PS_OUT(slot) do { } while (0)
+#endif
 
     for (int i = tid; i < n; i += PS_THREADS) sDg[i] = T.Hs[i * n + i] + lambda;
     __syncthreads();
@@ -737,78 +811,200 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
         sPerm[rank] = i;
     }
     __syncthreads();
-    {
-        const int ty = tid >> 5, tx = tid & 31;
-        for (int r = ty; r <= n; r += 32) {
-            for (int c = tx; c <= r && c < n + 1; c += 32) {
-                double v;
-                if (r < n) {
-                    const int i = sPerm[r], j = sPerm[c];
-                    const int hi = max(i, j), lo = min(i, j);
-                    v = T.Hs[hi * n + lo];
-                    if (r == c) v += lambda;
-                } else {
-                    v = (c < n) ? T.bs[sPerm[c]] : 0.0;
+    {   // gather the permuted lower triangle (+ identity padding + rhs row): flat index -> (r,c), loads batched by 4
+        const int total = (NP + 1) * (NP + 2) / 2;
+        for (int e0 = tid; e0 < total; e0 += 4 * PS_THREADS) {
+            double v[4];
+            int idx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * PS_THREADS;
+                idx[u] = e;
+                v[u] = 0.0;
+                if (e < total) {
+                    int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+                    while (tri(r + 1, 0) <= e) ++r;
+                    while (tri(r, 0) > e) --r;
+                    const int c = e - tri(r, 0);
+                    if (r < n) {
+                        const int i = sPerm[r], j = sPerm[c];
+                        v[u] = T.Hs[max(i, j) * n + min(i, j)];
+                        if (r == c) v[u] += lambda;
+                    } else if (r < NP) {
+                        v[u] = (r == c) ? 1.0 : 0.0;
+                    } else {
+                        v[u] = (c < n) ? T.bs[sPerm[c]] : 0.0;
+                    }
                 }
-                P[tri(r, c)] = v;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (idx[u] < total) P[idx[u]] = v[u];
         }
     }
     __syncthreads();
 
-    {   // right-looking LDL^T, columns kept unscaled (P(r,k) = L(r,k)*d_k), one barrier per pivot
-        const int ty = tid >> 5, tx = tid & 31;
-        for (int k = 0; k < n; ++k) {
-            const double d = P[tri(k, k)];
-            const double dinv = (fabs(d) > 0.0) ? 1.0 / d : 0.0;
-            if (tid == 0) sDinv[k] = dinv;
-            for (int r = k + 1 + ty; r <= n; r += 32) {
-                const double lrk = P[tri(r, k)] * dinv;
-                const int cmax = min(r, n - 1);
-                for (int c = k + 1 + tx; c <= cmax; c += 32) P[tri(r, c)] -= lrk * P[tri(c, k)];
+    PS_OUT(0);
+    for (int k0 = 0; k0 < NP; k0 += PS_NB) {
+        PS_MARK();
+        // ---- panel: wave 0, lane owns rows k0 + lane + 64 s.  Entries above the diagonal of the 8x8 block are
+        //      whatever the packed triangle holds there: they are computed on but never read back or stored ----
+        if (tid < 64) {
+            const int lane = tid;
+            double a[3][PS_NB];
+            int base[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int r = min(k0 + lane + 64 * s, NP);
+                base[s] = tri(r, k0);
+#pragma unroll
+                for (int j = 0; j < PS_NB; ++j) a[s][j] = P[base[s] + j];
             }
-            __syncthreads();
+            double dinv[PS_NB];
+#pragma unroll
+            for (int j = 0; j < PS_NB; ++j) {
+                const double d = d_readlane(a[0][j], j);            // A(k0+j, k0+j): row k0+j is lane j, slot 0
+                dinv[j] = d_fast_rcp(d);
+                double l[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) l[s] = a[s][j] * dinv[j];
+#pragma unroll
+                for (int c = j + 1; c < PS_NB; ++c) {
+                    const double u = d_readlane(a[0][j], c);        // A(k0+c, k0+j)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) a[s][c] -= l[s] * u;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int r = k0 + lane + 64 * s;
+                if (r <= NP) {
+                    double *srow = sS + r * PS_SROW;
+#pragma unroll
+                    for (int j = 0; j < PS_NB; ++j) {
+                        if (s > 0 || j <= lane) P[base[s] + j] = a[s][j];
+                        srow[j] = a[s][j] * dinv[j];
+                    }
+                }
+            }
+            if (lane < PS_NB) {
+                double dv = dinv[0];
+#pragma unroll
+                for (int j = 1; j < PS_NB; ++j) if (lane == j) dv = dinv[j];
+                sDinv[k0 + lane] = dv;
+            }
         }
+        __syncthreads();
+        PS_ADD(t_panel);
+        // ---- trailing update A22 -= L21 D^-1 L21^T: thread (ty,tx) owns rows k1+ty+32a, columns k1+tx+32b
+        //      (interleaved, so that a wave's column reads and its read-modify-writes are bank-conflict free) ----
+        const int k1 = k0 + PS_NB;
+        if (k1 <= NP) {
+            const int ty = tid >> 5, tx = tid & 31;
+            const int m = NP + 1 - k1;                              // trailing rows (incl. the rhs row)
+            const int RB = 4 * PS_TY;                               // rows per pass
+            for (int rb = 0; rb * RB < m; ++rb) {
+                if (rb * RB + ty >= m) continue;
+                for (int cb = 0; cb * 128 <= rb * RB + RB - 1; ++cb) {
+                    if (cb * 128 + tx >= m - 1) continue;           // the rhs row has no column of its own
+                    double acc[4][4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = 0.0;
+                    int rbase[4], crow[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) rbase[rr] = tri(min(k1 + rb * RB + ty + PS_TY * rr, NP), k0);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) crow[cc] = min(k1 + cb * 128 + tx + 32 * cc, NP) * PS_SROW;
+#pragma unroll
+                    for (int jj = 0; jj < PS_NB; jj += 2) {
+                        double l0[4], l1[4];
+                        double2 sc[4];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) { l0[rr] = P[rbase[rr] + jj]; l1[rr] = P[rbase[rr] + jj + 1]; }
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) sc[cc] = *reinterpret_cast<const double2 *>(sS + crow[cc] + jj);
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                            for (int cc = 0; cc < 4; ++cc) acc[rr][cc] += l0[rr] * sc[cc].x + l1[rr] * sc[cc].y;
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = k1 + rb * RB + ty + PS_TY * rr;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            const int c = k1 + cb * 128 + tx + 32 * cc;
+                            if (r <= NP && c <= r && c < NP) P[tri(r, c)] -= acc[rr][cc];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        PS_ADD(t_trail);
     }
+    PS_OUT(1);
+#ifdef VIO_STAMPS
+    if (tid == 0 && T.dbg) { T.dbg[8] = t_panel; T.dbg[9] = t_trail; }
+#endif
 
-    if (tid < 64) {     // D^+ and L^-T by one wave: lane owns k = lane, lane+64, lane+128
+    if (tid < 64) {     // z = D^+ y, then x = L^-T z panel by panel from the bottom: lane owns columns lane + 64 s
         const double tol = 1.0 / 1.7976931348623157e308;
-        double acc0 = 0, acc1 = 0, acc2 = 0;
         const int lane = tid;
-        double z0 = 0, z1 = 0, z2 = 0;
-        {
-            const int k0 = lane, k1 = lane + 64, k2 = lane + 128;
-            const double d0 = P[tri(k0, k0)], d1 = P[tri(k1, k1)];
-            z0 = (fabs(d0) > tol) ? P[tri(n, k0)] / d0 : 0.0;
-            z1 = (fabs(d1) > tol) ? P[tri(n, k1)] / d1 : 0.0;
-            if (k2 < n) { const double d2 = P[tri(k2, k2)]; z2 = (fabs(d2) > tol) ? P[tri(n, k2)] / d2 : 0.0; }
+        double z[3], di[3], acc[3] = {0, 0, 0}, x[3] = {0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int k = lane + 64 * s;
+            if (k < NP) {
+                const double d = P[tri(k, k)];
+                z[s] = (fabs(d) > tol) ? P[tri(NP, k)] / d : 0.0;    // row NP holds y = L^-1 b (unscaled)
+                di[s] = sDinv[k];
+            } else { z[s] = 0; di[s] = 0; }
         }
-        const double i0 = sDinv[lane], i1 = sDinv[lane + 64], i2 = (lane + 128 < n) ? sDinv[lane + 128] : 0.0;
-        for (int r = n - 1; r >= 128; --r) {
-            const double cand = z2 - i2 * acc2;
-            const double xr = __shfl(cand, r - 128);
-            if (lane == r - 128) sX[r] = xr;
-            const double *row = P + tri(r, 0);
-            acc0 += row[lane] * xr;
-            acc1 += row[lane + 64] * xr;
-            if (lane + 128 < r) acc2 += row[lane + 128] * xr;
+        for (int k0 = NP - PS_NB; k0 >= 0; k0 -= PS_NB) {
+            const int s0 = k0 >> 6;                 // a panel never straddles a 64 boundary (64 % 8 == 0)
+            const int l0 = k0 & 63;
+            double xs[PS_NB], blk[PS_NB];
+            {   // entries of the 8x8 diagonal block in this lane's column, fetched before the dependent chain starts
+                const int c = lane + 64 * s0;
+#pragma unroll
+                for (int j = 0; j < PS_NB; ++j) blk[j] = (c >= k0 && c < k0 + j) ? P[tri(k0 + j, c)] : 0.0;
+            }
+#pragma unroll
+            for (int j = PS_NB - 1; j >= 0; --j) {
+                double cand = 0.0;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) if (s == s0) cand = z[s] - di[s] * acc[s];
+                const double xr = d_readlane(cand, l0 + j);
+                xs[j] = xr;
+                {                                   // columns of this panel left of k0+j get L(k0+j, c) * xr
+                    const double v = blk[j] * xr;
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) if (s == s0) acc[s] += v;
+                }
+                if (lane == l0 + j) {
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) if (s == s0) x[s] = xr;
+                }
+            }
+            // all columns left of the panel: acc_c += sum_j P(k0+j, c) * x_{k0+j}
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int c = lane + 64 * s;
+                if (c < k0) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < PS_NB; ++j) t += P[tri(k0 + j, c)] * xs[j];
+                    acc[s] += t;
+                }
+            }
         }
-        for (int r = 127; r >= 64; --r) {
-            const double cand = z1 - i1 * acc1;
-            const double xr = __shfl(cand, r - 64);
-            if (lane == r - 64) sX[r] = xr;
-            const double *row = P + tri(r, 0);
-            acc0 += row[lane] * xr;
-            if (lane + 64 < r) acc1 += row[lane + 64] * xr;
-        }
-        for (int r = 63; r >= 0; --r) {
-            const double cand = z0 - i0 * acc0;
-            const double xr = __shfl(cand, r);
-            if (lane == r) sX[r] = xr;
-            if (lane < r) acc0 += P[tri(r, 0) + lane] * xr;
-        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { const int k = lane + 64 * s; if (k < n) sX[k] = x[s]; }
     }
     __syncthreads();
+    PS_OUT(2);
     for (int r = tid; r < n; r += PS_THREADS) {
         const double v = sX[r];
         sDx[sPerm[r]] = v;
@@ -850,6 +1046,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
             if (lane == 0) T.errprior[trial * 160 + i] = s;
         }
     }
+    PS_OUT(3);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1094,8 +1291,11 @@ void vio_launch_flip(LmState *lm, hipStream_t s) { hipLaunchKernelGGL(k_flip, di
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter, maxh_src);
 }
+int lin_lds_doubles_host(int G, int K, int nb, int use_ext, int nsplit, int n_strips) {
+    return lin_lds_doubles(G, K, nb, use_ext, nsplit, n_strips);
+}
 int vio_set_kernel_attributes() {
     hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-    hipError_t e2 = hipFuncSetAttribute((const void *)k_pose_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
+    hipError_t e2 = hipFuncSetAttribute((const void *)k_pose_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
 }
