@@ -621,61 +621,85 @@ struct ReduceTables {
     double *vis;
 };
 
-__global__ __launch_bounds__(64) void k_reduce(ReduceTables R) {
-    __shared__ int32_t sOff[128];
-    __shared__ double sV[24];
-    const int b = blockIdx.x, t = threadIdx.x;
+#define RED_THREADS 256
+#define RED_PARTS (RED_THREADS / 64)
+
+__global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
+    // each of the 4 waves sums a contiguous quarter of the list (loads kept 8 deep in flight), then the quarters
+    // are added in order: the summation order is fixed by the list, not by timing
+    __shared__ double sV[RED_PARTS][40];
+    const int b = blockIdx.x, tid = threadIdx.x, part = tid >> 6, t = tid & 63;
     const int lo = R.list_off[b], hi = R.list_off[b + 1];
     if (b < VIO_NPAIR) {
+        const int n = hi - lo, per = (n + RED_PARTS - 1) / RED_PARTS;
+        const int e0 = lo + part * per, e1 = min(hi, e0 + per);
         double acc = 0.0;
-        for (int base = lo; base < hi; base += 64) {
-            const int n = min(64, hi - base);
-            __syncthreads();
-            if (t < n) sOff[t] = R.list[base + t];
-            __syncthreads();
-            if (t < 36) {
-#pragma unroll 8
-                for (int e = 0; e < n; ++e) acc += R.slab[(size_t)sOff[e] + t];
-            }
-        }
         if (t < 36) {
+            int e = e0;
+            for (; e + 8 <= e1; e += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = R.slab[(size_t)R.list[e + u] + t];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; e < e1; ++e) acc += R.slab[(size_t)R.list[e] + t];
+            sV[part][t] = acc;
+        }
+        __syncthreads();
+        if (tid < 36) {
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < RED_PARTS; ++q) tot += sV[q][tid];
             int P = 0, rem = b;
             while (rem >= VIO_NCB - P) { rem -= VIO_NCB - P; ++P; }
-            const int Q = P + rem, i = t / 6, j = t % 6;
-            R.vis[VIS_H + (6 * P + i) * VIO_CD + 6 * Q + j] = acc;
-            if (P != Q) R.vis[VIS_H + (6 * Q + j) * VIO_CD + 6 * P + i] = acc;
+            const int Q = P + rem, i = tid / 6, j = tid % 6;
+            R.vis[VIS_H + (6 * P + i) * VIO_CD + 6 * Q + j] = tot;
+            if (P != Q) R.vis[VIS_H + (6 * Q + j) * VIO_CD + 6 * P + i] = tot;
         }
     } else if (b < VIO_NPAIR + VIO_NCB) {
         const int P = b - VIO_NPAIR;
-        double acc = 0.0;
+        const int n = (hi - lo) / 2, per = (n + RED_PARTS - 1) / RED_PARTS;
+        const int e0 = part * per, e1 = min(n, e0 + per);
         const int kind = t / 6, i = t % 6;
-        for (int base = lo; base < hi; base += 2 * 32) {
-            const int n = min(32, (hi - base) / 2);
-            __syncthreads();
-            if (t < 2 * n) sOff[t] = R.list[base + t];
-            __syncthreads();
-            if (t < 18) {
-#pragma unroll 4
-                for (int e = 0; e < n; ++e) acc += R.slab[(size_t)sOff[2 * e] + kind * sOff[2 * e + 1] + i];
+        double acc = 0.0;
+        if (t < 18) {
+            int e = e0;
+            for (; e + 8 <= e1; e += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = R.slab[(size_t)R.list[lo + 2 * (e + u)] + kind * R.list[lo + 2 * (e + u) + 1] + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
             }
+            for (; e < e1; ++e) acc += R.slab[(size_t)R.list[lo + 2 * e] + kind * R.list[lo + 2 * e + 1] + i];
+            sV[part][t] = acc;
         }
-        if (t < 18) sV[t] = acc;
         __syncthreads();
-        if (t < 6) {
-            R.vis[VIS_BDIR + 6 * P + t] = sV[t];
-            R.vis[VIS_BRED + 6 * P + t] = sV[t] - sV[6 + t];     // bpp - (Hpm*Hmm^-1)*bmm (problem.cc:429)
-            R.vis[VIS_DIAG + 6 * P + t] = sV[12 + t];
+        if (tid < 6) {
+            double bd = 0.0, bc = 0.0, dg = 0.0;
+#pragma unroll
+            for (int q = 0; q < RED_PARTS; ++q) { bd += sV[q][tid]; bc += sV[q][6 + tid]; dg += sV[q][12 + tid]; }
+            R.vis[VIS_BDIR + 6 * P + tid] = bd;
+            R.vis[VIS_BRED + 6 * P + tid] = bd - bc;     // bpp - (Hpm*Hmm^-1)*bmm (problem.cc:429)
+            R.vis[VIS_DIAG + 6 * P + tid] = dg;
         }
     } else {
-        // chi2 and max|h_ll| over the items: lanes stride the list, then a fixed shuffle tree
+        // chi2 and max|h_ll| over the items: threads stride the list, then a fixed tree
+        __shared__ double sC[RED_THREADS], sM[RED_THREADS];
         double chi = 0.0, mh = 0.0;
-        for (int e = lo + t; e < hi; e += 64) {
+        for (int e = lo + tid; e < hi; e += RED_THREADS) {
             const size_t o = (size_t)R.list[e];
             chi += R.slab[o];
             mh = fmax(mh, R.slab[o + 1]);
         }
-        for (int o = 32; o > 0; o >>= 1) { chi += __shfl_xor(chi, o); mh = fmax(mh, __shfl_xor(mh, o)); }
-        if (t == 0) { R.vis[VIS_CHI] = chi; R.vis[VIS_MAXH] = mh; }
+        sC[tid] = chi; sM[tid] = mh;
+        __syncthreads();
+        for (int s2 = RED_THREADS / 2; s2 > 0; s2 >>= 1) {
+            if (tid < s2) { sC[tid] += sC[tid + s2]; sM[tid] = fmax(sM[tid], sM[tid + s2]); }
+            __syncthreads();
+        }
+        if (tid == 0) { R.vis[VIS_CHI] = sC[0]; R.vis[VIS_MAXH] = sM[0]; }
     }
 }
 
@@ -1265,7 +1289,7 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
     hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1), dim3(64), 0, s, R);
+    hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1), dim3(RED_THREADS), 0, s, R);
 }
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(VIO_PD), dim3(192), 0, s, T); }
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
