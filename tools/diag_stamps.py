@@ -48,6 +48,8 @@ for _ in range(3):
     ctx.solve_linear(lam)
 ctx.synchronize()
 assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(2)) == 0
+st2 = buf.astype(np.int64)[1]
+print("trailing loop alone (sum over panels): wave0 %d, wave5 %d" % (st2[0], st2[1]))
 st = buf.astype(np.int64)[0]
 print("k_pose_solve: load+permute %d | factorisation done %d (panels %d, trailing %d) | back-substitution done %d | end %d"
       % (st[0], st[1], st[8], st[9], st[2], st[3]))

@@ -123,7 +123,8 @@ struct vio_ctx {
     // device buffers independent of the topology
     DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
         d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi;
-    DevBuf<int32_t> d_imu_valid;
+    DevBuf<int32_t> d_imu_valid, d_perm;
+    DevBuf<double> d_Pg;
     DevBuf<LmState> d_lm;
     LmState h_lm;
     vio_exchange_fn hook = nullptr;
@@ -357,6 +358,7 @@ vio_status alloc_fixed(vio_ctx *c) {
     HIPCHK(c->d_Hs.resize(PD * PD)); HIPCHK(c->d_bs.resize(176)); HIPCHK(c->d_bfull.resize(176));
     HIPCHK(c->d_diagfull.resize(176)); HIPCHK(c->d_dx.resize(176)); HIPCHK(c->d_step_tot.resize(8));
     HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
+    HIPCHK(c->d_perm.resize(176)); HIPCHK(c->d_Pg.resize(15760));
     HIPCHK(hipMemsetAsync(c->d_vis.p, 0, VIS_COUNT * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_step_tot.p, 0, 8 * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_dx.p, 0, 176 * 8, c->stream));
@@ -378,7 +380,7 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     // Problem always carries a 171x171 prior block (zero before the first marginalisation); err_prior_ exists
     // only once a prior has been set (problem.cc:466,505,554)
     T.has_prior = c->has_prior; T.add_imu_prior = 1;
-    T.Hs = c->d_Hs.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
+    T.Hs = c->d_Hs.p; T.Pg = c->d_Pg.p; T.perm = c->d_perm.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
@@ -580,7 +582,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_state.release(); c->d_pairtab.release(); c->d_vis.release(); c->d_pre.release(); c->d_imu_out.release();
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
-    c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release();
+    c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;

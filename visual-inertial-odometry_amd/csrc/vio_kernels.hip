@@ -709,52 +709,100 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int imu_vblock(int a) { return a < 6 ? 0 : (a < 15 ? 1 : (a < 21 ? 2 : 3)); }
 
-__global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
-    const int i = blockIdx.x, j = threadIdx.x;
-    const int cur = T.lm->cur;
-    const int ci = full_to_cam(i);
-    const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
-    if (j < VIO_PD) {
-        double vv = 0.0, vr = 0.0;      // reduced visual part, IMU + prior part
-        const int cj = full_to_cam(j);
-        if (ci >= 0 && cj >= 0) vv = T.vis[VIS_H + ci * VIO_CD + cj];
-        if (i >= 6 && j >= 6) {
-            const int fi = (i - 6) / 15;
-            for (int k = fi - 1; k <= fi; ++k) {
-                if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
-                if (T.marg_mode && k != 0) continue;
-                const int a = i - (6 + 15 * k), bb = j - (6 + 15 * k);
-                if (bb < 0 || bb >= 30) continue;
-                const double *Tk = T.imu_out + k * IMU_OUT + IMU_T;
-                // upper vertex blocks are computed, lower ones mirrored (problem.cc:347-355)
-                vr += (imu_vblock(a) <= imu_vblock(bb)) ? Tk[a * 30 + bb] : Tk[bb * 30 + a];
-            }
+#define PS_N VIO_PD
+#define PS_NP 176       // 171 padded to 22 panels of 8 with identity pivots; the right-hand side is row PS_NP
+#define PS_PACKED ((PS_NP + 1) * (PS_NP + 2) / 2)
+__device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }
+
+// entry (i,j), i >= j, of H_pp_schur_ without lambda: the lower triangle as Eigen's LDLT reads it
+__device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int i, int j, double &vv, double &vr) {
+    vv = 0.0; vr = 0.0;                 // reduced visual part, IMU + prior part
+    const int ci = full_to_cam(i), cj = full_to_cam(j);
+    if (ci >= 0 && cj >= 0) vv = T.vis[VIS_H + ci * VIO_CD + cj];
+    if (i >= 6 && j >= 6) {
+        const int fi = (i - 6) / 15;
+        for (int k = fi - 1; k <= fi; ++k) {
+            if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
+            if (T.marg_mode && k != 0) continue;
+            const int a = i - (6 + 15 * k), bb = j - (6 + 15 * k);
+            if (bb < 0 || bb >= 30) continue;
+            const double *Tk = T.imu_out + k * IMU_OUT + IMU_T;
+            // upper vertex blocks are computed, lower ones mirrored (problem.cc:347-355)
+            vr += (imu_vblock(a) <= imu_vblock(bb)) ? Tk[a * 30 + bb] : Tk[bb * 30 + a];
         }
-        if (T.has_prior) {
-            const bool mask_j = T.ext_fixed && !T.marg_mode && j < 6;
-            if (!mask_i && !mask_j) vr += T.Hprior[i * VIO_PD + j];
-        }
-        T.Hs[i * VIO_PD + j] = vv + vr;
-        if (j == i)     // diag(Hessian_) before the Schur complement, for ComputeLambdaInitLM (problem.cc:511-516)
-            T.diagfull[i] = ((ci >= 0) ? T.vis[VIS_DIAG + ci] : 0.0) + vr;
-    } else if (j == VIO_PD) {
-        double bred = 0.0, bdir = 0.0;
-        if (ci >= 0) { bred = T.vis[VIS_BRED + ci]; bdir = T.vis[VIS_BDIR + ci]; }
-        double extra = 0.0;
-        if (i >= 6) {
-            const int fi = (i - 6) / 15;
-            for (int k = fi - 1; k <= fi; ++k) {
-                if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
-                if (T.marg_mode && k != 0) continue;
-                const int a = i - (6 + 15 * k);
-                if (a < 0 || a >= 30) continue;
-                extra -= T.imu_out[k * IMU_OUT + IMU_G + a];
-            }
-        }
-        if (T.has_prior && !mask_i) extra += T.bprior[cur * 176 + i];
-        T.bs[i] = bred + extra;
-        T.bfull[i] = bdir + extra;
     }
+    if (T.has_prior) {
+        const bool mask = T.ext_fixed && !T.marg_mode && (i < 6 || j < 6);
+        if (!mask) vr += T.Hprior[i * VIO_PD + j];
+    }
+}
+
+// Workgroup b < 171: row b of H_pp_schur_ in natural order (getters, marginalisation) and, for the solve, row b of
+// the PERMUTED packed lower triangle Pg: the pivot order of Eigen's LDLT is the order of |diag + lambda|, which for
+// lambda >= 0 and a non-negative diagonal does not depend on lambda, so it is fixed here once per linearisation
+// (every workgroup recomputes the 171 ranks: cheaper than one more launch).  Workgroups 171..175: identity padding.
+// Workgroup 176: right-hand side row, b_pp_schur_, pose part of b_, diag(Hessian_).
+__global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
+    __shared__ double sDg[176];
+    __shared__ int sPerm[176];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int cur = T.lm->cur;
+    if (t < VIO_PD) { double vv, vr; d_hs_entry(T, t, t, vv, vr); sDg[t] = vv + vr; }
+    __syncthreads();
+    if (t < VIO_PD) {
+        const double di = fabs(sDg[t]);
+        int rank = 0;
+        for (int j = 0; j < VIO_PD; ++j) {
+            const double dj = fabs(sDg[j]);
+            rank += (dj > di || (dj == di && j < t)) ? 1 : 0;
+        }
+        sPerm[rank] = t;
+    }
+    __syncthreads();
+    if (b < VIO_PD) {
+        const int i = b;
+        if (t < VIO_PD) {
+            double vv, vr;
+            d_hs_entry(T, max(i, t), min(i, t), vv, vr);
+            T.Hs[i * VIO_PD + t] = vv + vr;
+            if (t <= i) {                       // permuted row i of the packed triangle
+                const int pi = sPerm[i], pj = sPerm[t];
+                double wv, wr;
+                d_hs_entry(T, max(pi, pj), min(pi, pj), wv, wr);
+                T.Pg[tri(i, t)] = wv + wr;
+            }
+        }
+    } else if (b < PS_NP) {
+        if (t <= b) T.Pg[tri(b, t)] = (t == b) ? 1.0 : 0.0;
+    } else {
+        if (t < VIO_PD) {
+            const int i = t, ci = full_to_cam(i);
+            const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
+            double bred = 0.0, bdir = 0.0, dv, dr;
+            if (ci >= 0) { bred = T.vis[VIS_BRED + ci]; bdir = T.vis[VIS_BDIR + ci]; }
+            double extra = 0.0;
+            if (i >= 6) {
+                const int fi = (i - 6) / 15;
+                for (int k = fi - 1; k <= fi; ++k) {
+                    if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
+                    if (T.marg_mode && k != 0) continue;
+                    const int a = i - (6 + 15 * k);
+                    if (a < 0 || a >= 30) continue;
+                    extra -= T.imu_out[k * IMU_OUT + IMU_G + a];
+                }
+            }
+            if (T.has_prior && !mask_i) extra += T.bprior[cur * 176 + i];
+            T.bs[i] = bred + extra;
+            T.bfull[i] = bdir + extra;
+            // diag(Hessian_) before the Schur complement, for ComputeLambdaInitLM (problem.cc:511-516)
+            d_hs_entry(T, i, i, dv, dr);
+            T.diagfull[i] = ((ci >= 0) ? T.vis[VIS_DIAG + ci] : 0.0) + dr;
+            sDg[i] = bred + extra;
+            T.perm[i] = sPerm[i];
+        }
+    }
+    __syncthreads();
+    if (b == PS_NP && t <= PS_NP) T.Pg[tri(PS_NP, t)] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -771,11 +819,9 @@ __global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
 // back-substitution with L^T is done by one wave panel by panel.  Then: trial pose states (UpdateStates :453-480,
 // vertex_pose.cc:7-19), their pair table, and the first-order prior update (:473-474).
 // ---------------------------------------------------------------------------------------------------------
-#define PS_THREADS 512
+#define PS_THREADS 1024
 #define PS_TY (PS_THREADS / 32)
-#define PS_N VIO_PD
 #define PS_NB 8
-__device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }
 
 __device__ __forceinline__ double d_readlane(double x, int lane) {      // lane is wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
@@ -794,7 +840,6 @@ __device__ __forceinline__ double d_fast_rcp(double d) {                // 1/d t
 
 // The 171x171 system is padded to NP = 176 = 22 panels of 8 with identity pivots (zero right-hand side), the
 // right-hand side is row NP of the packed triangle.
-#define PS_NP 176
 #define PS_SROW 10      // row stride of the scaled panel (doubles): 16-byte aligned and bank-conflict free for b128
 
 __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
@@ -814,6 +859,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     const int n = PS_N, NP = PS_NP;
 #ifdef VIO_STAMPS
     unsigned long long t_panel = 0, t_trail = 0, t_mark = 0, t_start = __builtin_amdgcn_s_memtime();
+    if (tid == 0 && T.dbg) { T.dbg[16] = 0; T.dbg[17] = 0; }
 #define PS_MARK() (t_mark = __builtin_amdgcn_s_memtime())
 #define PS_ADD(acc) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); acc += now__ - t_mark; t_mark = now__; } while (0)
 #define PS_OUT(slot) do { if (tid == 0 && T.dbg) T.dbg[slot] = __builtin_amdgcn_s_memtime() - t_start; } while (0)
@@ -823,46 +869,53 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 #define PS_OUT(slot) do { } while (0)
 #endif
 
-    for (int i = tid; i < n; i += PS_THREADS) sDg[i] = T.Hs[i * n + i] + lambda;
-    __syncthreads();
-    for (int i = tid; i < n; i += PS_THREADS) {
-        const double di = fabs(sDg[i]);
-        int rank = 0;
-        for (int j = 0; j < n; ++j) {
-            const double dj = fabs(sDg[j]);
-            rank += (dj > di || (dj == di && j < i)) ? 1 : 0;
-        }
-        sPerm[rank] = i;
+    // Fast path: the packed, permuted triangle k_assemble wrote (pivot order fixed with lambda = 0) is valid as
+    // long as |diag + lambda| is still non-increasing along it — always the case for lambda >= 0 on a
+    // non-negative diagonal.  Coalesced 16-byte loads; lambda goes on the 171 real pivots.
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(T.Pg);
+        double2 *dst = reinterpret_cast<double2 *>(P);
+        for (int e = tid; e < (PS_PACKED + 1) / 2; e += PS_THREADS) dst[e] = src[e];
+        for (int i = tid; i < n; i += PS_THREADS) sPerm[i] = T.perm[i];
     }
     __syncthreads();
-    {   // gather the permuted lower triangle (+ identity padding + rhs row): flat index -> (r,c), loads batched by 4
-        const int total = (NP + 1) * (NP + 2) / 2;
-        for (int e0 = tid; e0 < total; e0 += 4 * PS_THREADS) {
-            double v[4];
-            int idx[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * PS_THREADS;
-                idx[u] = e;
-                v[u] = 0.0;
-                if (e < total) {
-                    int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-                    while (tri(r + 1, 0) <= e) ++r;
-                    while (tri(r, 0) > e) --r;
-                    const int c = e - tri(r, 0);
-                    if (r < n) {
-                        const int i = sPerm[r], j = sPerm[c];
-                        v[u] = T.Hs[max(i, j) * n + min(i, j)];
-                        if (r == c) v[u] += lambda;
-                    } else if (r < NP) {
-                        v[u] = (r == c) ? 1.0 : 0.0;
-                    } else {
-                        v[u] = (c < n) ? T.bs[sPerm[c]] : 0.0;
-                    }
-                }
+    int same = 1;
+    for (int k = tid; k + 1 < n; k += PS_THREADS)
+        same &= (fabs(P[tri(k, k)] + lambda) >= fabs(P[tri(k + 1, k + 1)] + lambda)) ? 1 : 0;
+    same = __syncthreads_and(same);
+    if (same) {
+        for (int k = tid; k < n; k += PS_THREADS) P[tri(k, k)] += lambda;
+    } else {
+        // slow path (e.g. a negative lambda): rank-sort |diag + lambda| here and gather entry by entry
+        for (int i = tid; i < n; i += PS_THREADS) { double vv, vr; d_hs_entry(T, i, i, vv, vr); sDg[i] = vv + vr + lambda; }
+        __syncthreads();
+        for (int i = tid; i < n; i += PS_THREADS) {
+            const double di = fabs(sDg[i]);
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const double dj = fabs(sDg[j]);
+                rank += (dj > di || (dj == di && j < i)) ? 1 : 0;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (idx[u] < total) P[idx[u]] = v[u];
+            sPerm[rank] = i;
+        }
+        __syncthreads();
+        for (int e = tid; e < PS_PACKED; e += PS_THREADS) {
+            int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
+            while (tri(r + 1, 0) <= e) ++r;
+            while (tri(r, 0) > e) --r;
+            const int c = e - tri(r, 0);
+            double v = 0.0;
+            if (r < n) {
+                const int i = sPerm[r], j = sPerm[c];
+                double vv, vr;
+                d_hs_entry(T, max(i, j), min(i, j), vv, vr);
+                v = vv + vr + ((r == c) ? lambda : 0.0);
+            } else if (r < NP) {
+                v = (r == c) ? 1.0 : 0.0;
+            } else {
+                v = (c < n) ? T.bs[sPerm[c]] : 0.0;
+            }
+            P[e] = v;
         }
     }
     __syncthreads();
@@ -919,51 +972,69 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
         }
         __syncthreads();
         PS_ADD(t_panel);
-        // ---- trailing update A22 -= L21 D^-1 L21^T: thread (ty,tx) owns rows k1+ty+32a, columns k1+tx+32b
-        //      (interleaved, so that a wave's column reads and its read-modify-writes are bank-conflict free) ----
+        // ---- trailing update A22 -= L21 D^-1 L21^T.  The LDS pipe is one per CU, so the update is laid out to
+        //      touch it as little as possible: a wave owns whole rows (r = k1 + wave + 8a), its lanes own columns
+        //      c = k1 + lane + 64b.  The scaled panel rows of a lane's (up to 3) columns live in registers for the
+        //      whole update; a row's 8 panel values are fetched by 8 lanes in one LDS read and handed to the wave
+        //      as scalar operands with v_readlane, so per row the wave spends LDS cycles only on the entries it
+        //      modifies. ----
         const int k1 = k0 + PS_NB;
         if (k1 <= NP) {
-            const int ty = tid >> 5, tx = tid & 31;
+            const int wave = tid >> 6, lane = tid & 63;
             const int m = NP + 1 - k1;                              // trailing rows (incl. the rhs row)
-            const int RB = 4 * PS_TY;                               // rows per pass
-            for (int rb = 0; rb * RB < m; ++rb) {
-                if (rb * RB + ty >= m) continue;
-                for (int cb = 0; cb * 128 <= rb * RB + RB - 1; ++cb) {
-                    if (cb * 128 + tx >= m - 1) continue;           // the rhs row has no column of its own
-                    double acc[4][4];
+            const int nbc = (m - 1 + 63) >> 6;                      // column groups in use (wave-uniform)
+            double sc[3][PS_NB];
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
+            for (int bb = 0; bb < 3; ++bb) {
+                const int c = min(k1 + lane + 64 * bb, NP);
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = 0.0;
-                    int rbase[4], crow[4];
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) rbase[rr] = tri(min(k1 + rb * RB + ty + PS_TY * rr, NP), k0);
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) crow[cc] = min(k1 + cb * 128 + tx + 32 * cc, NP) * PS_SROW;
-#pragma unroll
-                    for (int jj = 0; jj < PS_NB; jj += 2) {
-                        double l0[4], l1[4];
-                        double2 sc[4];
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) { l0[rr] = P[rbase[rr] + jj]; l1[rr] = P[rbase[rr] + jj + 1]; }
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) sc[cc] = *reinterpret_cast<const double2 *>(sS + crow[cc] + jj);
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                            for (int cc = 0; cc < 4; ++cc) acc[rr][cc] += l0[rr] * sc[cc].x + l1[rr] * sc[cc].y;
-                    }
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int r = k1 + rb * RB + ty + PS_TY * rr;
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
-                            const int c = k1 + cb * 128 + tx + 32 * cc;
-                            if (r <= NP && c <= r && c < NP) P[tri(r, c)] -= acc[rr][cc];
-                        }
-                    }
+                for (int jj = 0; jj < PS_NB / 2; ++jj) {
+                    const double2 v = (bb < nbc) ? *reinterpret_cast<const double2 *>(sS + c * PS_SROW + 2 * jj) : make_double2(0.0, 0.0);
+                    sc[bb][2 * jj] = v.x; sc[bb][2 * jj + 1] = v.y;
                 }
             }
+            const int dump = (int)(sX - P) + lane;
+            const int waves = PS_THREADS / 64;
+#ifdef VIO_STAMPS
+            const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+#endif
+            for (int a = wave; a < m; a += 2 * waves) {
+                // two rows per trip: rows ra and rb = ra + 8
+                const int ra = k1 + a, rb = min(ra + waves, NP);
+                const bool hasb = a + waves < m;
+                const int ta = tri(ra, 0), tb = tri(rb, 0);
+                // lanes 0..7 fetch row a's panel values, lanes 8..15 row b's
+                const double lv = P[((lane & 8) ? tb : ta) + k0 + (lane & 7)];
+                int ia[3], ib[3];
+                double oa[3], ob[3];
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    const int c = k1 + lane + 64 * bb;
+                    ia[bb] = (c <= ra && c < NP) ? ta + c : dump;
+                    ib[bb] = (hasb && c <= rb && c < NP) ? tb + c : dump;
+                    oa[bb] = P[ia[bb]];
+                    ob[bb] = P[ib[bb]];
+                }
+                double la[PS_NB], lb[PS_NB];
+#pragma unroll
+                for (int j = 0; j < PS_NB; ++j) { la[j] = d_readlane(lv, j); lb[j] = d_readlane(lv, 8 + j); }
+                const int bmax = (rb - k1) >> 6;                    // column groups row b reaches (>= row a's)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    if (bb <= bmax) {
+                        double acca = 0.0, accb = 0.0;
+#pragma unroll
+                        for (int j = 0; j < PS_NB; ++j) { acca += la[j] * sc[bb][j]; accb += lb[j] * sc[bb][j]; }
+                        oa[bb] -= acca;
+                        ob[bb] -= accb;
+                    }
+                }
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) { P[ia[bb]] = oa[bb]; P[ib[bb]] = ob[bb]; }
+            }
+#ifdef VIO_STAMPS
+            if (lane == 0 && T.dbg && (wave == 0 || wave == 5)) T.dbg[16 + (wave ? 1 : 0)] += __builtin_amdgcn_s_memtime() - tl0;
+#endif
         }
         __syncthreads();
         PS_ADD(t_trail);
@@ -1291,7 +1362,7 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1), dim3(RED_THREADS), 0, s, R);
 }
-void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(VIO_PD), dim3(192), 0, s, T); }
+void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(PS_NP + 1), dim3(192), 0, s, T); }
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
 }

@@ -170,6 +170,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     int32_t has_prior;
     int32_t add_imu_prior;       // 1 on shard rank 0
     double *Hs;                  // [171x171]
+    double *Pg;                  // permuted, padded, packed lower triangle + rhs row, written by k_assemble
+    int32_t *perm;               // [176] pivot order found by k_assemble
     double *bs;                  // [171]
     double *bfull;               // [171] pose part of b_ (direct + imu + prior), for the gain ratio
     double *diagfull;            // [171] diag(Hessian_) pose part, for lambda_0
