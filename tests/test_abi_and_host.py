@@ -28,7 +28,7 @@ def test_header_declares_the_reference_call_sequence():
 def test_hip_library_exports_every_declared_symbol(vio):
     """No compute call here (there is no GPU in the CPU tier): only that the product library exists, loads and
     resolves each prototype of include/vio_backend.h."""
-    lib = C.CDLL(vio.HIP_LIB)
+    lib = vio.load_hip().dll
     missing = [f for f in header_functions() if not hasattr(lib, f)]
     assert not missing, missing
 

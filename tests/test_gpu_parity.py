@@ -286,3 +286,41 @@ def test_gn_iteration_is_the_same_arithmetic_as_the_steps(vio, hip_lib):
     np.testing.assert_array_equal(sa, sb)
     np.testing.assert_array_equal(a.get_landmarks(), b.get_landmarks())
     assert a.chi2() == b.chi2()
+
+
+def test_exchange_hook_path_with_rccl_on_one_rank(vio, hip_lib):
+    """The multi-GPU path end to end on the one GPU available here: a world_size-1 RCCL group, caller-owned torch
+    exchange buffers bound into the library, the all-reduce issued from the library's hook on torch's current
+    stream.  With one rank the sums are identities, so the result must equal the unsharded solve bit for bit."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        w = vio.synth.make_window(700, seed=23, ragged=True)
+        sb = vio.sharded.ShardedBackend(hip_lib, w, 0, 1, dist=dist, torch_device="cuda", force_hook=True,
+                                        ctx_kwargs=dict(stream=torch.cuda.current_stream().cuda_stream))
+        rep = sb.solve(10)
+        ps, ss, _ = sb.ctx.get_window()
+        ls = sb.gather_landmarks()
+        ref = hip_lib.context()
+        ref.load(w)
+        rr = ref.solve(10)
+        pr, sr, _ = ref.get_window()
+        assert rep.iterations == rr.iterations and rep.trials == rr.trials and rep.final_chi2 == rr.final_chi2
+        np.testing.assert_array_equal(ps, pr)
+        np.testing.assert_array_equal(ss, sr)
+        np.testing.assert_array_equal(ls, ref.get_landmarks())
+        for _ in range(5):
+            sb.gn_iteration(5e5)
+        sb.ctx.synchronize()
+        assert np.isfinite(sb.ctx.chi2())
+    finally:
+        dist.destroy_process_group()

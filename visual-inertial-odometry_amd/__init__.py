@@ -5,7 +5,7 @@ include/vio_backend.h).  There is no CPU fallback: `load_hip()` raises if the li
 """
 import os
 
-from . import capi, sharded, synth
+from . import capi, sharded, stream, synth
 from .capi import (CAM_DIM, LOSS_CAUCHY, LOSS_HUBER, LOSS_TRIVIAL, LOSS_TUKEY, MARG_OLD, MARG_SECOND_NEW,
                    NUM_FRAMES, POSE_DIM, PRIOR_DIM, WINDOW_SIZE, VioConfig, VioContext, VioError, VioLib,
                    VioPreint, VioSolveReport)
@@ -20,5 +20,13 @@ def load_hip():
     """Load the HIP product library.  Raises (never falls back) when it has not been built."""
     global _hip
     if _hip is None:
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64/libhsa-runtime64.  If this library were
+        # loaded first it would pull in /opt/rocm's copies, and a later `import torch` would bring a second runtime
+        # that finds no GPU (and RCCL would sit on the other one).  Importing torch first makes the dynamic loader
+        # resolve our libamdhip64.so.7 to the copy torch already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _hip = VioLib(HIP_LIB, "vio_")
     return _hip

@@ -14,7 +14,7 @@ from . import synth
 
 
 class ShardedBackend:
-    def __init__(self, lib, window, rank, world, dist=None, torch_device="cuda", ctx_kwargs=None):
+    def __init__(self, lib, window, rank, world, dist=None, torch_device="cuda", ctx_kwargs=None, force_hook=False):
         import torch
         self.torch = torch
         self.dist = dist
@@ -31,7 +31,7 @@ class ShardedBackend:
         self.sca = torch.zeros(8, dtype=torch.float64, device=torch_device)
         self.ctx.bind_exchange_buffers(self.red.data_ptr(), self.sca.data_ptr())
         self._views = (self.red[:self.n_red], self.sca[:self.n_sc], self.sca[2:3])
-        if world > 1:
+        if world > 1 or force_hook:       # force_hook: exercise the exchange path on a single rank (tests)
             self.ctx.set_exchange_hook(self._exchange)
 
     def _exchange(self, which):
