@@ -159,6 +159,14 @@ vio_status vio_eval_step(struct vio_ctx *ctx, int32_t *accepted, double *chi2, d
 vio_status vio_gn_iteration(struct vio_ctx *ctx, double lambda);
 vio_status vio_synchronize(struct vio_ctx *ctx);
 
+/* ---- IMU pre-integration (host side, as in the reference: Estimator::processIMU -> IntegrationBase::push_back ->
+ *      propagate -> midPointIntegration, integration_base.h:30-36,54-158).  Starts from (acc0, gyr0) — the sample the
+ *      IntegrationBase constructor takes — and folds in `count` further samples; noise densities as ACC_N, GYR_N,
+ *      ACC_W, GYR_W of the YAML (vio_simulation.yaml:60-63).  No context needed. --------------------------------- */
+vio_status vio_preintegrate(const double *acc0, const double *gyr0, const double *ba, const double *bg, int32_t count,
+                            const double *dt, const double *acc, const double *gyr, double acc_n, double gyr_n,
+                            double acc_w, double gyr_w, vio_preint *out);
+
 /* ---- marginalisation: Marg{Old,New}Frame + Problem::Marginalize  problem.cc:617-795 ------ */
 /* Uses the window/landmarks/observations/IMU/prior currently set.  Outputs the new prior
  * (VIO_PRIOR_DIM): H dim x dim, b, err, jt_inv dim x dim. */

@@ -81,6 +81,7 @@
 #undef vio_profile_begin
 #undef vio_profile_end
 #undef vio_kernel_name
+#undef vio_preintegrate
 
 using namespace myslam::backend;
 typedef Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> RowMat;

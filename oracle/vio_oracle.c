@@ -1505,6 +1505,13 @@ vio_status vioo_get_pose_hessian(struct vioo_ctx *c, double *Hpp) {
     memcpy(Hpp, c->Hpp, sizeof(c->Hpp));
     return VIO_OK;
 }
+vio_status vio_preintegrate(const double *acc0, const double *gyr0, const double *ba, const double *bg, int32_t count,
+                            const double *dt, const double *acc, const double *gyr, double acc_n, double gyr_n,
+                            double acc_w, double gyr_w, vio_preint *out) {
+    if (!acc0 || !gyr0 || !ba || !bg || !out || count < 0) return VIO_ERR_BAD_ARG;
+    vioo_preintegrate(acc0, gyr0, ba, bg, count, dt, acc, gyr, acc_n, gyr_n, acc_w, gyr_w, out);
+    return VIO_OK;
+}
 vio_status vio_exchange_buffers(struct vioo_ctx *c, void **a, int64_t *na, void **b, int64_t *nb) {
     if (!c) return VIO_ERR_BAD_ARG;
     if (a) *a = c->vis;

@@ -43,6 +43,7 @@
 #define vio_profile_begin vioo_profile_begin
 #define vio_profile_end vioo_profile_end
 #define vio_kernel_name vioo_kernel_name
+#define vio_preintegrate vioo_preintegrate_abi
 #include "../include/vio_backend.h"
 
 #ifdef __cplusplus

@@ -45,6 +45,9 @@ def test_hip_library_fails_loudly_without_a_gpu(vio):
 
 def test_oracle_exports_the_same_surface(vio, oracle_lib):
     for f in header_functions():
+        if f == "vio_preintegrate":
+            assert oracle_lib.has("preintegrate_abi")
+            continue
         if f in ("vio_profile_begin", "vio_profile_end", "vio_kernel_name"):
             continue        # measurement hooks exist on the HIP library only
         assert oracle_lib.has(f[len("vio_"):]), f
@@ -106,3 +109,27 @@ def test_numpy_preintegration_matches_oracle_c(vio, oracle_lib):
     np.testing.assert_allclose(np.array(out.delta_v[:]), py["delta_v"], rtol=0, atol=1e-14)
     np.testing.assert_allclose(np.array(out.jacobian[:]).reshape(15, 15), py["jacobian"], rtol=1e-12, atol=1e-15)
     np.testing.assert_allclose(np.array(out.covariance[:]).reshape(15, 15), py["covariance"], rtol=1e-11, atol=1e-30)
+
+
+def test_abi_preintegration_matches_numpy_and_oracle(vio, oracle_lib):
+    """vio_preintegrate is host code inside the product library (as IntegrationBase is host code in the reference), so
+    it can be exercised without a GPU: product C++ vs the generator's numpy vs the oracle's C."""
+    lib = vio.load_hip()
+    rng = np.random.RandomState(1)
+    n = 20
+    acc = rng.normal(0, 1, (n + 1, 3)) + [0, 0, 9.8]
+    gyr = rng.normal(0, 0.3, (n + 1, 3))
+    ba, bg = rng.normal(0, 0.02, 3), rng.normal(0, 0.002, 3)
+    dts = np.full(n, 0.005)
+    s = vio.synth
+    got = lib.preintegrate(acc[0], gyr[0], ba, bg, dts, acc[1:], gyr[1:], s.ACC_N, s.GYR_N, s.ACC_W, s.GYR_W)
+    py = s.preintegrate(acc[0], gyr[0], ba, bg, dts, acc[1:], gyr[1:])
+    orc = oracle_lib.preintegrate(acc[0], gyr[0], ba, bg, dts, acc[1:], gyr[1:], s.ACC_N, s.GYR_N, s.ACC_W, s.GYR_W)
+    for ref in (py, {k: np.array(getattr(orc, k)[:]) if k != "sum_dt" else orc.sum_dt for k in
+                     ("sum_dt", "delta_p", "delta_q", "delta_v", "jacobian", "covariance")}):
+        assert abs(got.sum_dt - ref["sum_dt"]) < 1e-15
+        np.testing.assert_allclose(np.array(got.delta_p[:]), np.asarray(ref["delta_p"]).reshape(-1), rtol=0, atol=1e-15)
+        np.testing.assert_allclose(np.array(got.delta_q[:]), np.asarray(ref["delta_q"]).reshape(-1), rtol=0, atol=1e-15)
+        np.testing.assert_allclose(np.array(got.delta_v[:]), np.asarray(ref["delta_v"]).reshape(-1), rtol=0, atol=1e-14)
+        np.testing.assert_allclose(np.array(got.jacobian[:]), np.asarray(ref["jacobian"]).reshape(-1), rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(np.array(got.covariance[:]), np.asarray(ref["covariance"]).reshape(-1), rtol=1e-11, atol=1e-30)

@@ -87,7 +87,7 @@ class VioLib:
                "set_exchange_hook", "bind_exchange_buffers"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
-    HIP_ONLY = ["profile_begin", "profile_end", "kernel_name"]
+    HIP_ONLY = ["profile_begin", "profile_end", "kernel_name", "preintegrate"]
     KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
@@ -111,6 +111,18 @@ class VioLib:
         for s in self.SYMBOLS:
             if s not in ("last_error", "destroy", "default_config"):
                 self.fn[s].restype = C.c_int
+
+    def preintegrate(self, acc0, gyr0, ba, bg, dts, accs, gyrs, acc_n, gyr_n, acc_w, gyr_w):
+        """IntegrationBase on the host through the ABI (vio_preintegrate); returns a VioPreint."""
+        out = VioPreint()
+        a = [_f64(x).reshape(-1) for x in (acc0, gyr0, ba, bg, dts, accs, gyrs)]
+        fn = self.raw("preintegrate") if "preintegrate" not in self.fn else self.fn["preintegrate"]
+        fn.restype = C.c_int
+        st = fn(_dp(a[0]), _dp(a[1]), _dp(a[2]), _dp(a[3]), C.c_int32(a[4].size), _dp(a[4]), _dp(a[5]), _dp(a[6]),
+                C.c_double(acc_n), C.c_double(gyr_n), C.c_double(acc_w), C.c_double(gyr_w), C.byref(out))
+        if st != 0:
+            raise VioError(st, self.prefix + "preintegrate")
+        return out
 
     def has(self, name):
         return hasattr(self.dll, self.prefix + name)

@@ -240,4 +240,134 @@ void marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double 
     std::memcpy(bout, bp.data(), sizeof(double) * n2);
 }
 
+// ---- IntegrationBase ---------------------------------------------------------------------------------------
+namespace {
+struct M3 { double m[9]; };
+inline M3 mul(const M3 &a, const M3 &b) {
+    M3 c;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
+    return c;
+}
+inline M3 hat(const double *v) { return M3{{0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}}; }
+inline M3 rot_of(const double *q) {          // Eigen toRotationMatrix on (x,y,z,w), no normalisation
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    return M3{{1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)}};
+}
+inline void apply(const M3 &R, const double *v, double *o) {
+    for (int i = 0; i < 3; ++i) o[i] = R.m[3 * i] * v[0] + R.m[3 * i + 1] * v[1] + R.m[3 * i + 2] * v[2];
+}
+inline void put(double *M, int ld, int r0, int c0, const M3 &B, double s) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[(r0 + i) * ld + c0 + j] = B.m[3 * i + j] * s;
+}
+void matmul(int m, int k, int n, const double *A, const double *B, double *C) {
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0;
+            for (int l = 0; l < k; ++l) s += A[i * k + l] * B[l * n + j];
+            C[i * n + j] = s;
+        }
+}
+}  // namespace
+
+void preintegrate(const double *acc_first, const double *gyr_first, const double *ba, const double *bg, int count,
+                  const double *dts, const double *accs, const double *gyrs, double acc_n, double gyr_n, double acc_w,
+                  double gyr_w, double *sum_dt_out, double *dp_out, double *dq_out, double *dv_out, double *jac,
+                  double *cov) {
+    double a0[3] = {acc_first[0], acc_first[1], acc_first[2]}, g0[3] = {gyr_first[0], gyr_first[1], gyr_first[2]};
+    double noise[18 * 18] = {0};
+    for (int i = 0; i < 3; ++i) {
+        noise[19 * i] = acc_n * acc_n; noise[19 * (3 + i)] = gyr_n * gyr_n; noise[19 * (6 + i)] = acc_n * acc_n;
+        noise[19 * (9 + i)] = gyr_n * gyr_n; noise[19 * (12 + i)] = acc_w * acc_w; noise[19 * (15 + i)] = gyr_w * gyr_w;
+    }
+    std::fill(jac, jac + 225, 0.0);
+    std::fill(cov, cov + 225, 0.0);
+    for (int i = 0; i < 15; ++i) jac[16 * i] = 1.0;
+    double dp[3] = {0, 0, 0}, dv[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 1}, sum_dt = 0;
+    const M3 I3{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+    for (int s = 0; s < count; ++s) {
+        const double h = dts[s];
+        const double *a1 = accs + 3 * s, *g1 = gyrs + 3 * s;
+        double ua0[3], ua1[3], w[3], x0[3], x1[3];
+        for (int k = 0; k < 3; ++k) { x0[k] = a0[k] - ba[k]; x1[k] = a1[k] - ba[k]; w[k] = 0.5 * (g0[k] + g1[k]) - bg[k]; }
+        const M3 Rd = rot_of(dq);
+        apply(Rd, x0, ua0);
+        // result_delta_q = delta_q * Quaterniond(1, w*dt/2): rotated with BEFORE the normalize() of propagate()
+        const double iq[4] = {w[0] * h / 2, w[1] * h / 2, w[2] * h / 2, 1.0};
+        const double rq[4] = {dq[3] * iq[0] + dq[0] * iq[3] + dq[1] * iq[2] - dq[2] * iq[1],
+                              dq[3] * iq[1] + dq[1] * iq[3] + dq[2] * iq[0] - dq[0] * iq[2],
+                              dq[3] * iq[2] + dq[2] * iq[3] + dq[0] * iq[1] - dq[1] * iq[0],
+                              dq[3] * iq[3] - dq[0] * iq[0] - dq[1] * iq[1] - dq[2] * iq[2]};
+        const M3 Rr = rot_of(rq);
+        apply(Rr, x1, ua1);
+        double rp[3], rv[3];
+        for (int k = 0; k < 3; ++k) {
+            const double ua = 0.5 * (ua0[k] + ua1[k]);
+            rp[k] = dp[k] + dv[k] * h + 0.5 * ua * h * h;
+            rv[k] = dv[k] + ua * h;
+        }
+        const M3 Rw = hat(w), Ra0 = hat(x0), Ra1 = hat(x1);
+        M3 ImW;
+        for (int k = 0; k < 9; ++k) ImW.m[k] = I3.m[k] - Rw.m[k] * h;
+        const M3 RdA0 = mul(Rd, Ra0), RrA1 = mul(Rr, Ra1), RrA1I = mul(RrA1, ImW);
+        double F[225] = {0}, V[15 * 18] = {0};
+        M3 B;
+        put(F, 15, 0, 0, I3, 1.0);
+        for (int k = 0; k < 9; ++k) B.m[k] = -0.25 * RdA0.m[k] * h * h + -0.25 * RrA1I.m[k] * h * h;
+        put(F, 15, 0, 3, B, 1.0);
+        put(F, 15, 0, 6, I3, h);
+        for (int k = 0; k < 9; ++k) B.m[k] = -0.25 * (Rd.m[k] + Rr.m[k]) * h * h;
+        put(F, 15, 0, 9, B, 1.0);
+        for (int k = 0; k < 9; ++k) B.m[k] = -0.25 * RrA1.m[k] * h * h * -h;
+        put(F, 15, 0, 12, B, 1.0);
+        put(F, 15, 3, 3, ImW, 1.0);
+        put(F, 15, 3, 12, I3, -1.0 * h);
+        for (int k = 0; k < 9; ++k) B.m[k] = -0.5 * RdA0.m[k] * h + -0.5 * RrA1I.m[k] * h;
+        put(F, 15, 6, 3, B, 1.0);
+        put(F, 15, 6, 6, I3, 1.0);
+        for (int k = 0; k < 9; ++k) B.m[k] = -0.5 * (Rd.m[k] + Rr.m[k]) * h;
+        put(F, 15, 6, 9, B, 1.0);
+        for (int k = 0; k < 9; ++k) B.m[k] = -0.5 * RrA1.m[k] * h * -h;
+        put(F, 15, 6, 12, B, 1.0);
+        put(F, 15, 9, 9, I3, 1.0);
+        put(F, 15, 12, 12, I3, 1.0);
+        put(V, 18, 0, 0, Rd, 0.25 * h * h);
+        for (int k = 0; k < 9; ++k) B.m[k] = 0.25 * -RrA1.m[k] * h * h * 0.5 * h;
+        put(V, 18, 0, 3, B, 1.0);
+        put(V, 18, 0, 6, Rr, 0.25 * h * h);
+        put(V, 18, 0, 9, B, 1.0);
+        put(V, 18, 3, 3, I3, 0.5 * h);
+        put(V, 18, 3, 9, I3, 0.5 * h);
+        put(V, 18, 6, 0, Rd, 0.5 * h);
+        for (int k = 0; k < 9; ++k) B.m[k] = 0.5 * -RrA1.m[k] * h * 0.5 * h;
+        put(V, 18, 6, 3, B, 1.0);
+        put(V, 18, 6, 6, Rr, 0.5 * h);
+        put(V, 18, 6, 9, B, 1.0);
+        put(V, 18, 9, 12, I3, h);
+        put(V, 18, 12, 15, I3, h);
+        double T1[225], T2[225], FT[225], VN[15 * 18], VT[18 * 15], T3[225];
+        matmul(15, 15, 15, F, jac, T1);
+        std::memcpy(jac, T1, sizeof(T1));
+        for (int i = 0; i < 15; ++i)
+            for (int j = 0; j < 15; ++j) FT[15 * i + j] = F[15 * j + i];
+        matmul(15, 15, 15, F, cov, T1);
+        matmul(15, 15, 15, T1, FT, T2);
+        matmul(15, 18, 18, V, noise, VN);
+        for (int i = 0; i < 18; ++i)
+            for (int j = 0; j < 15; ++j) VT[15 * i + j] = V[18 * j + i];
+        matmul(15, 18, 15, VN, VT, T3);
+        for (int k = 0; k < 225; ++k) cov[k] = T2[k] + T3[k];
+        const double nq = std::sqrt(rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3]);
+        for (int k = 0; k < 4; ++k) dq[k] = rq[k] / nq;
+        for (int k = 0; k < 3; ++k) { dp[k] = rp[k]; dv[k] = rv[k]; a0[k] = a1[k]; g0[k] = g1[k]; }
+        sum_dt += h;
+    }
+    *sum_dt_out = sum_dt;
+    for (int k = 0; k < 3; ++k) { dp_out[k] = dp[k]; dv_out[k] = dv[k]; }
+    for (int k = 0; k < 4; ++k) dq_out[k] = dq[k];
+}
+
 }  // namespace vio_host

@@ -17,5 +17,11 @@ bool symmetric_eigen(int n, const double *A, double *evals, double *V);
 // Outputs: Hout 156x156, bout 156, errout 156, jtout 156x156.
 void marginalize_tail(double *H, double *b, int frame, double *Hout, double *bout, double *errout, double *jtout);
 
+// IntegrationBase mid-point propagation (integration_base.h:54-158): count samples after (acc0, gyr0).
+// out_* : sum_dt, delta_p[3], delta_q[4] (xyzw), delta_v[3], jacobian[225], covariance[225] (row-major)
+void preintegrate(const double *acc0, const double *gyr0, const double *ba, const double *bg, int count, const double *dt,
+                  const double *acc, const double *gyr, double acc_n, double gyr_n, double acc_w, double gyr_w,
+                  double *sum_dt, double *delta_p, double *delta_q, double *delta_v, double *jacobian, double *covariance);
+
 }  // namespace vio_host
 #endif

@@ -918,6 +918,16 @@ vio_status vio_set_exchange_hook(vio_ctx *c, vio_exchange_fn fn, void *user) {
     return VIO_OK;
 }
 
+vio_status vio_preintegrate(const double *acc0, const double *gyr0, const double *ba, const double *bg, int32_t count,
+                            const double *dt, const double *acc, const double *gyr, double acc_n, double gyr_n,
+                            double acc_w, double gyr_w, vio_preint *out) {
+    if (!acc0 || !gyr0 || !ba || !bg || !out || count < 0 || (count > 0 && (!dt || !acc || !gyr))) return VIO_ERR_BAD_ARG;
+    vio_host::preintegrate(acc0, gyr0, ba, bg, count, dt, acc, gyr, acc_n, gyr_n, acc_w, gyr_w, &out->sum_dt, out->delta_p,
+                           out->delta_q, out->delta_v, out->jacobian, out->covariance);
+    for (int k = 0; k < 3; ++k) { out->linearized_ba[k] = ba[k]; out->linearized_bg[k] = bg[k]; }
+    return VIO_OK;
+}
+
 vio_status vio_bind_exchange_buffers(vio_ctx *c, void *reduced, void *scalars) {
     if (!c) return VIO_ERR_BAD_ARG;
     c->ext_vis = (double *)reduced;
