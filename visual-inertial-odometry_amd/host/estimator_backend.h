@@ -1,0 +1,64 @@
+// estimator_backend.h — C++ host mirror of the three Estimator methods that talk to the backend
+// (SURVEY.md section 8f-1).  Same names, same data members, same call order as
+//   Estimator::problemSolve          VM/src/estimator.cpp:902-1073
+//   Estimator::MargOldFrame          VM/src/estimator.cpp:693-829
+//   Estimator::MargNewFrame          VM/src/estimator.cpp:830-901
+//   Estimator::backendOptimization   VM/src/estimator.cpp:1075-1141
+// but over plain arrays instead of Eigen objects, and with the graph handed to the C ABI of include/vio_backend.h
+// instead of being built from heap-allocated Vertex/Edge objects.  A maintainer of the reference replaces the
+// bodies of those methods with calls to this class (or copies its ~100 lines into estimator.cpp).
+#ifndef VIO_ESTIMATOR_BACKEND_H
+#define VIO_ESTIMATOR_BACKEND_H
+
+#include <array>
+#include <string>
+#include <vector>
+
+#include "../../include/vio_backend.h"
+
+namespace vio {
+
+constexpr int WINDOW_SIZE = VIO_WINDOW_SIZE;   // parameters.h:35
+
+// FeaturePerId / FeaturePerFrame (VM/include/feature_manager.h): one track = consecutive frames from start_frame
+struct FeaturePerId {
+    int start_frame = 0;
+    std::vector<std::array<double, 2>> feature_per_frame;   // normalised (x, y), z == 1
+    double inv_depth = 0.0;                                  // what getDepthVector()/setDepth() exchange (feature_manager.cpp:184-200)
+    int used_num = 0;
+};
+
+enum MarginalizationFlag { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };   // estimator.h:52-56
+
+class EstimatorBackend {
+public:
+    explicit EstimatorBackend(const vio_config &cfg);
+    ~EstimatorBackend();
+    EstimatorBackend(const EstimatorBackend &) = delete;
+    EstimatorBackend &operator=(const EstimatorBackend &) = delete;
+
+    // ---- the members Estimator keeps (estimator.h:66-69,113-119) ----
+    double para_Pose[WINDOW_SIZE + 1][7];
+    double para_SpeedBias[WINDOW_SIZE + 1][9];
+    double para_Ex_Pose[1][7];
+    std::vector<double> para_Feature;                 // [feature_index] (the reference caps this at NUM_OF_F = 1000)
+    std::vector<FeaturePerId> feature;                // f_manager.feature
+    const vio_preint *pre_integrations[WINDOW_SIZE + 1];   // [j] = between frames j-1 and j; nullptr or sum_dt > 10 skips the edge
+    std::vector<double> Hprior_, bprior_, errprior_, Jprior_inv_;   // empty until the first marginalisation
+    vio_solve_report last_report;
+
+    // ---- the methods ----
+    bool problemSolve();
+    bool MargOldFrame();
+    bool MargNewFrame();
+    void backendOptimization(MarginalizationFlag marginalization_flag);
+    const char *last_error() const;
+
+private:
+    bool uploadWindow();
+    vio_ctx *ctx_ = nullptr;
+    std::string err_;
+};
+
+}  // namespace vio
+#endif
