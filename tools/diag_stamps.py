@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_package  # noqa: E402
 
 vio = load_package()
-lib = vio.VioLib(os.path.join(ROOT, "visual-inertial-odometry_amd", "csrc", "diag", "libvio_hip_stamps.so"), "vio_")
+lib = vio.VioLib(os.path.join(ROOT, "visual-inertial-odometry_amd", "csrc", "diag", os.environ.get("VIO_DIAG_LIB", "libvio_hip_stamps.so")), "vio_")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 w = vio.synth.make_window(n, seed=42)
 ctx = lib.context()
@@ -47,8 +47,11 @@ _, lam = ctx.init_lm()
 for _ in range(3):
     ctx.solve_linear(lam)
 ctx.synchronize()
-assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(2)) == 0
+assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(4)) == 0
 st2 = buf.astype(np.int64)[1]
+st3 = buf.astype(np.int64)[2]; st4 = buf.astype(np.int64)[3]
+print("pre-loop (sc loads) sum: wave0 %d wave5 %d wave15 %d | barrier wait after loop: wave0 %d wave5 %d wave15 %d" % (st3[0], st3[5], st3[15], st4[0], st4[5], st4[15]))
+print("64 back-to-back __syncthreads with 16 waves: %d ticks" % st2[2])
 print("trailing loop alone (sum over panels): wave0 %d, wave5 %d" % (st2[0], st2[1]))
 st = buf.astype(np.int64)[0]
 print("k_pose_solve: load+permute %d | factorisation done %d (panels %d, trailing %d) | back-substitution done %d | end %d"

@@ -117,6 +117,8 @@ struct vio_ctx {
     bool pairtab_valid = false;
     bool stepwise_updated = false;
     double gn_lambda = -1.0;
+    bool want_natural_hs = false;              // set by vio_get_schur_system: re-run k_assemble with the natural-order copy
+    bool natural_hs_valid = false;
     int g_max = 64;                            // landmarks per item (tunable: VIO_G_MAX)
     Plan solve_plan, marg_plan;
     Plan *active = nullptr;
@@ -379,7 +381,7 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     T.Hprior = c->d_Hprior.p; T.bprior = c->d_bprior.p; T.errprior = c->d_errprior.p; T.Jtinv = c->d_Jtinv.p;
     // Problem always carries a 171x171 prior block (zero before the first marginalisation); err_prior_ exists
     // only once a prior has been set (problem.cc:466,505,554)
-    T.has_prior = c->has_prior; T.add_imu_prior = 1;
+    T.has_prior = c->has_prior; T.add_imu_prior = 1; T.natural_hs = (pl.marg || c->want_natural_hs) ? 1 : 0;
     T.Hs = c->d_Hs.p; T.Pg = c->d_Pg.p; T.perm = c->d_perm.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
@@ -495,6 +497,7 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl) {
     { ProfScope ps(c, VIO_K_ASSEMBLE); vio_launch_assemble(T, c->stream); }
     HIPCHK(hipGetLastError());
     c->linearized = true;
+    c->natural_hs_valid = T.natural_hs != 0;
     return VIO_OK;
 }
 
@@ -872,6 +875,13 @@ vio_status vio_get_delta(vio_ctx *c, double *dxp, int64_t n, double *dxl) {
 
 vio_status vio_get_schur_system(vio_ctx *c, double *H, double *b) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    if (H && !c->natural_hs_valid) {            // the solve path keeps only the permuted packed copy: assemble once more
+        c->want_natural_hs = true;
+        DeviceTables T = make_tables(c, *c->active);
+        vio_launch_assemble(T, c->stream);
+        c->want_natural_hs = false;
+        c->natural_hs_valid = true;
+    }
     if (H) HIPCHK(hipMemcpyAsync(H, c->d_Hs.p, (size_t)PD * PD * 8, hipMemcpyDeviceToHost, c->stream));
     if (b) HIPCHK(hipMemcpyAsync(b, c->d_bs.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -107,6 +107,25 @@ DEV void d_loss(int type, double delta, double e2, double &r0, double &r1, doubl
     } else { r0 = e2; r1 = 1; r2 = 0; }
 }
 
+// Wave-wide (64 lanes) sum of a double with DPP moves: quad swaps, half-row and row mirrors, then the two row
+// broadcasts gfx9 has (row_bcast:15 / row_bcast:31).  Six steps of (2 x v_mov_dpp + v_add_f64) instead of the
+// ds_bpermute round trips __shfl_xor costs for 64-bit values.  The total ends up in lane 63; fixed order.
+template <int CTRL, int ROW_MASK = 0xf>
+DEV double d_dpp_mov(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+DEV double d_wave_sum_to_lane63(double v) {
+    v += d_dpp_mov<0xB1>(v);            // quad_perm:[1,0,3,2]
+    v += d_dpp_mov<0x4E>(v);            // quad_perm:[2,3,0,1]
+    v += d_dpp_mov<0x141>(v);           // row_half_mirror
+    v += d_dpp_mov<0x140>(v);           // row_mirror: every lane of a row of 16 now holds the row's sum
+    v += d_dpp_mov<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v += d_dpp_mov<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
+    return v;                           // lane 63 holds the wave's sum
+}
+
 // deterministic block reductions (fixed tree), all threads must call
 template <int NT>
 DEV double d_block_sum(double v, double *scratch, int tid) {

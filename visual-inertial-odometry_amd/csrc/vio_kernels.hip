@@ -762,9 +762,11 @@ __global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
     if (b < VIO_PD) {
         const int i = b;
         if (t < VIO_PD) {
-            double vv, vr;
-            d_hs_entry(T, max(i, t), min(i, t), vv, vr);
-            T.Hs[i * VIO_PD + t] = vv + vr;
+            if (T.natural_hs) {                 // natural-order H_pp_schur_: only the getters and Marginalize read it
+                double vv, vr;
+                d_hs_entry(T, max(i, t), min(i, t), vv, vr);
+                T.Hs[i * VIO_PD + t] = vv + vr;
+            }
             if (t <= i) {                       // permuted row i of the packed triangle
                 const int pi = sPerm[i], pj = sPerm[t];
                 double wv, wr;
@@ -859,7 +861,8 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     const int n = PS_N, NP = PS_NP;
 #ifdef VIO_STAMPS
     unsigned long long t_panel = 0, t_trail = 0, t_mark = 0, t_start = __builtin_amdgcn_s_memtime();
-    if (tid == 0 && T.dbg) { T.dbg[16] = 0; T.dbg[17] = 0; }
+    if (tid < 64 && T.dbg) { T.dbg[16 + tid] = 0; }
+    __syncthreads();
 #define PS_MARK() (t_mark = __builtin_amdgcn_s_memtime())
 #define PS_ADD(acc) do { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); acc += now__ - t_mark; t_mark = now__; } while (0)
 #define PS_OUT(slot) do { if (tid == 0 && T.dbg) T.dbg[slot] = __builtin_amdgcn_s_memtime() - t_start; } while (0)
@@ -921,6 +924,13 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     __syncthreads();
 
     PS_OUT(0);
+#ifdef VIO_STAMPS
+    {   // barrier micro-benchmark (diagnostic build only)
+        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
+        for (int q = 0; q < 64; ++q) __syncthreads();
+        if (tid == 0 && T.dbg) T.dbg[18] = __builtin_amdgcn_s_memtime() - tb0;
+    }
+#endif
     for (int k0 = 0; k0 < NP; k0 += PS_NB) {
         PS_MARK();
         // ---- panel: wave 0, lane owns rows k0 + lane + 64 s.  Entries above the diagonal of the 8x8 block are
@@ -988,55 +998,68 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
             for (int bb = 0; bb < 3; ++bb) {
                 const int c = min(k1 + lane + 64 * bb, NP);
 #pragma unroll
-                for (int jj = 0; jj < PS_NB / 2; ++jj) {
-                    const double2 v = (bb < nbc) ? *reinterpret_cast<const double2 *>(sS + c * PS_SROW + 2 * jj) : make_double2(0.0, 0.0);
+                for (int jj = 0; jj < PS_NB / 2; ++jj) {     // unconditional (clamped row): unused groups are never applied
+                    const double2 v = *reinterpret_cast<const double2 *>(sS + c * PS_SROW + 2 * jj);
                     sc[bb][2 * jj] = v.x; sc[bb][2 * jj + 1] = v.y;
                 }
             }
             const int dump = (int)(sX - P) + lane;
             const int waves = PS_THREADS / 64;
+            const int uwave = __builtin_amdgcn_readfirstlane(wave);    // row arithmetic stays on the scalar unit
 #ifdef VIO_STAMPS
             const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && T.dbg && (wave == 0 || wave == 5 || wave == 15)) T.dbg[32 + wave] += tl0 - t_mark;   // pre-loop
 #endif
-            for (int a = wave; a < m; a += 2 * waves) {
-                // two rows per trip: rows ra and rb = ra + 8
+            int cofs[3];
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) cofs[bb] = k1 + lane + 64 * bb;
+            for (int a = uwave; a < m; a += 2 * waves) {
+                // two rows per trip (ra and rb = ra + 16) so that one trip pays the LDS latency once; a row reaches
+                // column group b iff b <= (r - k1) / 64, so only those groups are loaded, updated and stored
                 const int ra = k1 + a, rb = min(ra + waves, NP);
                 const bool hasb = a + waves < m;
                 const int ta = tri(ra, 0), tb = tri(rb, 0);
-                // lanes 0..7 fetch row a's panel values, lanes 8..15 row b's
-                const double lv = P[((lane & 8) ? tb : ta) + k0 + (lane & 7)];
+                const int ga = (a >> 6) + 1, gb = hasb ? ((a + waves) >> 6) + 1 : 0;
+                const double lv = P[((lane & 8) ? tb : ta) + k0 + (lane & 7)];     // lanes 0..7: row a, 8..15: row b
                 int ia[3], ib[3];
                 double oa[3], ob[3];
 #pragma unroll
                 for (int bb = 0; bb < 3; ++bb) {
-                    const int c = k1 + lane + 64 * bb;
-                    ia[bb] = (c <= ra && c < NP) ? ta + c : dump;
-                    ib[bb] = (hasb && c <= rb && c < NP) ? tb + c : dump;
-                    oa[bb] = P[ia[bb]];
-                    ob[bb] = P[ib[bb]];
+                    if (bb < ga) { ia[bb] = (cofs[bb] <= ra && cofs[bb] < NP) ? ta + cofs[bb] : dump; oa[bb] = P[ia[bb]]; }
+                    if (bb < gb) { ib[bb] = (cofs[bb] <= rb && cofs[bb] < NP) ? tb + cofs[bb] : dump; ob[bb] = P[ib[bb]]; }
                 }
                 double la[PS_NB], lb[PS_NB];
 #pragma unroll
-                for (int j = 0; j < PS_NB; ++j) { la[j] = d_readlane(lv, j); lb[j] = d_readlane(lv, 8 + j); }
-                const int bmax = (rb - k1) >> 6;                    // column groups row b reaches (>= row a's)
+                for (int j = 0; j < PS_NB; ++j) la[j] = d_readlane(lv, j);
+                if (gb) {
 #pragma unroll
-                for (int bb = 0; bb < 3; ++bb) {
-                    if (bb <= bmax) {
-                        double acca = 0.0, accb = 0.0;
-#pragma unroll
-                        for (int j = 0; j < PS_NB; ++j) { acca += la[j] * sc[bb][j]; accb += lb[j] * sc[bb][j]; }
-                        oa[bb] -= acca;
-                        ob[bb] -= accb;
-                    }
+                    for (int j = 0; j < PS_NB; ++j) lb[j] = d_readlane(lv, 8 + j);
                 }
 #pragma unroll
-                for (int bb = 0; bb < 3; ++bb) { P[ia[bb]] = oa[bb]; P[ib[bb]] = ob[bb]; }
+                for (int bb = 0; bb < 3; ++bb) {
+                    if (bb < ga) {
+#pragma unroll
+                        for (int j = 0; j < PS_NB; ++j) oa[bb] = fma(-la[j], sc[bb][j], oa[bb]);
+                        P[ia[bb]] = oa[bb];
+                    }
+                    if (bb < gb) {
+#pragma unroll
+                        for (int j = 0; j < PS_NB; ++j) ob[bb] = fma(-lb[j], sc[bb][j], ob[bb]);
+                        P[ib[bb]] = ob[bb];
+                    }
+                }
             }
 #ifdef VIO_STAMPS
             if (lane == 0 && T.dbg && (wave == 0 || wave == 5)) T.dbg[16 + (wave ? 1 : 0)] += __builtin_amdgcn_s_memtime() - tl0;
 #endif
         }
+#ifdef VIO_STAMPS
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef VIO_STAMPS
+        if ((tid & 63) == 0 && T.dbg && ((tid >> 6) == 0 || (tid >> 6) == 5 || (tid >> 6) == 15)) T.dbg[48 + (tid >> 6)] += __builtin_amdgcn_s_memtime() - tw0;
+#endif
         PS_ADD(t_trail);
     }
     PS_OUT(1);
@@ -1044,61 +1067,51 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     if (tid == 0 && T.dbg) { T.dbg[8] = t_panel; T.dbg[9] = t_trail; }
 #endif
 
-    if (tid < 64) {     // z = D^+ y, then x = L^-T z panel by panel from the bottom: lane owns columns lane + 64 s
+    // ---- z = D^+ y, then x = L^-T z panel by panel from the bottom (solve of Cholesky/LDLT.h:558-600).
+    //      Per panel: (A) the 16 waves form, two per column, the dot products of the panel's 8 columns with the part
+    //      of x already known (rows below the panel); (B) eight lanes of wave 0 run the 8-step chain inside the
+    //      panel with the pivot-row entries prefetched and x broadcast by v_readlane. ----
+    {
         const double tol = 1.0 / 1.7976931348623157e308;
-        const int lane = tid;
-        double z[3], di[3], acc[3] = {0, 0, 0}, x[3] = {0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int k = lane + 64 * s;
-            if (k < NP) {
-                const double d = P[tri(k, k)];
-                z[s] = (fabs(d) > tol) ? P[tri(NP, k)] / d : 0.0;    // row NP holds y = L^-1 b (unscaled)
-                di[s] = sDinv[k];
-            } else { z[s] = 0; di[s] = 0; }
-        }
+        double *sAcc = sDg;                         // 16 partial dot products (sDg is free after the permutation)
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int k = tid; k < NP; k += PS_THREADS) sX[k] = 0.0;
+        __syncthreads();
         for (int k0 = NP - PS_NB; k0 >= 0; k0 -= PS_NB) {
-            const int s0 = k0 >> 6;                 // a panel never straddles a 64 boundary (64 % 8 == 0)
-            const int l0 = k0 & 63;
-            double xs[PS_NB], blk[PS_NB];
-            {   // entries of the 8x8 diagonal block in this lane's column, fetched before the dependent chain starts
-                const int c = lane + 64 * s0;
-#pragma unroll
-                for (int j = 0; j < PS_NB; ++j) blk[j] = (c >= k0 && c < k0 + j) ? P[tri(k0 + j, c)] : 0.0;
+            {   // (A) column c = k0 + (wave & 7), rows k0+8 .. NP-1 split in two halves by wave >> 3
+                const int c = k0 + (wave & 7);
+                const int r0 = k0 + PS_NB, nrows = NP - r0;
+                const int half = (nrows + 1) >> 1;
+                const int lo = r0 + (wave >> 3) * half, hi = min(NP, lo + half);
+                double part = 0.0;
+                for (int r = lo + lane; r < hi; r += 64) part += P[tri(r, c)] * sX[r];
+                part = d_wave_sum_to_lane63(part);
+                if (lane == 63) sAcc[wave] = part;
             }
+            __syncthreads();
+            if (tid < 64) {                         // (B) lane j < 8 owns column k0 + j
+                const int j = lane & 7;
+                const int c = k0 + j;
+                const double d = P[tri(c, c)];
+                const double z = (fabs(d) > tol) ? P[tri(NP, c)] / d : 0.0;      // row NP holds y = L^-1 b (unscaled)
+                const double dinv = sDinv[c];
+                double acc = sAcc[j] + sAcc[8 + j];
+                double blk[PS_NB];                  // P(k0+jj, c) for jj > j: the rest of this column inside the panel
 #pragma unroll
-            for (int j = PS_NB - 1; j >= 0; --j) {
-                double cand = 0.0;
+                for (int jj = 0; jj < PS_NB; ++jj) blk[jj] = (jj > j) ? P[tri(k0 + jj, c)] : 0.0;
+                double xmine = 0.0;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) if (s == s0) cand = z[s] - di[s] * acc[s];
-                const double xr = d_readlane(cand, l0 + j);
-                xs[j] = xr;
-                {                                   // columns of this panel left of k0+j get L(k0+j, c) * xr
-                    const double v = blk[j] * xr;
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) if (s == s0) acc[s] += v;
+                for (int jj = PS_NB - 1; jj >= 0; --jj) {
+                    const double cand = z - dinv * acc;
+                    const double xr = d_readlane(cand, jj);
+                    if (j == jj) xmine = xr;
+                    acc += blk[jj] * xr;
                 }
-                if (lane == l0 + j) {
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) if (s == s0) x[s] = xr;
-                }
+                if (lane < PS_NB) sX[c] = xmine;
             }
-            // all columns left of the panel: acc_c += sum_j P(k0+j, c) * x_{k0+j}
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int c = lane + 64 * s;
-                if (c < k0) {
-                    double t = 0.0;
-#pragma unroll
-                    for (int j = 0; j < PS_NB; ++j) t += P[tri(k0 + j, c)] * xs[j];
-                    acc[s] += t;
-                }
-            }
+            __syncthreads();
         }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) { const int k = lane + 64 * s; if (k < n) sX[k] = x[s]; }
     }
-    __syncthreads();
     PS_OUT(2);
     for (int r = tid; r < n; r += PS_THREADS) {
         const double v = sX[r];

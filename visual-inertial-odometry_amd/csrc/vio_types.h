@@ -168,6 +168,7 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     double *errprior;            // [2][160]
     const double *Jtinv;         // [156x156]
     int32_t has_prior;
+    int32_t natural_hs;          // 1: k_assemble also writes H_pp_schur_ in natural order (getters, marginalisation)
     int32_t add_imu_prior;       // 1 on shard rank 0
     double *Hs;                  // [171x171]
     double *Pg;                  // permuted, padded, packed lower triangle + rhs row, written by k_assemble
