@@ -555,6 +555,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, acc5 = 0, dd = 0;
             const double *Lg = sL + (size_t)g_first * LREC;
             const double *rec = sRows + (direct ? ks : 0) * PLANE + g_first * RROW;
+#pragma unroll 4
             for (int g = g_first; g < G; g += g_step, Lg += g_step * LREC, rec += g_step * RROW) {
                 if (selL) {
                     const double hinv = Lg[12 * nb];
