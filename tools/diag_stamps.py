@@ -50,9 +50,9 @@ ctx.synchronize()
 assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(4)) == 0
 st2 = buf.astype(np.int64)[1]
 st3 = buf.astype(np.int64)[2]; st4 = buf.astype(np.int64)[3]
-print("pre-loop (sc loads) sum: wave0 %d wave5 %d wave15 %d | barrier wait after loop: wave0 %d wave5 %d wave15 %d" % (st3[0], st3[5], st3[15], st4[0], st4[5], st4[15]))
-print("64 back-to-back __syncthreads with 16 waves: %d ticks" % st2[2])
-print("trailing loop alone (sum over panels): wave0 %d, wave5 %d" % (st2[0], st2[1]))
+print("per step K: wave-1 update loop      ", list(st2[:10]))
+print("per step K: wave-0 update tile (K+1) ", list(st3[:10]))
+print("per step K: wave-0 F(K+1)            ", list(st4[:10]))
 st = buf.astype(np.int64)[0]
-print("k_pose_solve: load+permute %d | factorisation done %d (panels %d, trailing %d) | back-substitution done %d | end %d"
+print("k_pose_solve: load+permute %d | factorisation done %d (F+U phases %d, S phases %d) | back-substitution done %d | end %d"
       % (st[0], st[1], st[8], st[9], st[2], st[3]))

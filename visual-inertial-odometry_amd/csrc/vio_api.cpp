@@ -44,7 +44,8 @@ namespace {
 
 constexpr int NF = VIO_NUM_FRAMES, PD = VIO_POSE_DIM, PRD = VIO_PRIOR_DIM;
 constexpr int LDS_BUDGET_DOUBLES = 150 * 1024 / 8;     // per linearize workgroup (160 KiB per CU on gfx950)
-constexpr int POSE_SOLVE_LDS = (15754 + 177 * 10 + 5 * 176 + 112 + 176) * 8 + 176 * 4 + 64;
+constexpr int POSE_SOLVE_TILED = 66 * 272 + 192;   // PS_PACKED of vio_kernels.hip: 66 tiles of 16x17 + the rhs row
+constexpr int POSE_SOLVE_LDS = (POSE_SOLVE_TILED + 176 + 272 + 272 + 192 + 176 + 112 + 176) * 8 + 176 * 4 + 64;
 constexpr int IMU_ITEM_LDS_DOUBLES = 450 + 225 + 450 + 32;
 
 template <typename T>
@@ -360,7 +361,8 @@ vio_status alloc_fixed(vio_ctx *c) {
     HIPCHK(c->d_Hs.resize(PD * PD)); HIPCHK(c->d_bs.resize(176)); HIPCHK(c->d_bfull.resize(176));
     HIPCHK(c->d_diagfull.resize(176)); HIPCHK(c->d_dx.resize(176)); HIPCHK(c->d_step_tot.resize(8));
     HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
-    HIPCHK(c->d_perm.resize(176)); HIPCHK(c->d_Pg.resize(15760));
+    HIPCHK(c->d_perm.resize(176)); HIPCHK(c->d_Pg.resize(POSE_SOLVE_TILED));
+    HIPCHK(hipMemset(c->d_Pg.p, 0, POSE_SOLVE_TILED * sizeof(double)));   // tile padding (17th column) is never written again
     HIPCHK(hipMemsetAsync(c->d_vis.p, 0, VIS_COUNT * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_step_tot.p, 0, 8 * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_dx.p, 0, 176 * 8, c->stream));

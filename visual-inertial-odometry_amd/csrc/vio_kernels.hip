@@ -711,9 +711,21 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
 __device__ __forceinline__ int imu_vblock(int a) { return a < 6 ? 0 : (a < 15 ? 1 : (a < 21 ? 2 : 3)); }
 
 #define PS_N VIO_PD
-#define PS_NP 176       // 171 padded to 22 panels of 8 with identity pivots; the right-hand side is row PS_NP
-#define PS_PACKED ((PS_NP + 1) * (PS_NP + 2) / 2)
-__device__ __forceinline__ int tri(int r, int c) { return r * (r + 1) / 2 + c; }
+#define PS_NP 176       // 171 padded to 11 block rows of 16 with identity pivots
+// The permuted lower triangle is kept as 16x16 tiles (block row I >= block column J), each tile row-major with a row
+// stride of 17 doubles: with that stride both the C/D image of v_mfma_f64_16x16x4_f64 (lane -> row (l>>4)+4v,
+// column l&15) and its A/B image (lane -> row l&15, k = (l>>4)+4s) read and write LDS without bank conflicts.
+// The right-hand side is a 177th row kept apart (192 doubles after the tiles).
+#define PS_NB 16
+#define PS_NT (PS_NP / PS_NB)
+#define PS_TROW 17
+#define PS_TS (PS_NB * PS_TROW)
+#define PS_TILES (PS_NT * (PS_NT + 1) / 2)
+#define PS_YOFF (PS_TILES * PS_TS)
+#define PS_PACKED (PS_YOFF + 192)
+__device__ __forceinline__ int tix(int I, int J) { return (I * (I + 1) / 2 + J) * PS_TS; }
+// element (r, c) with c's block <= r's block (for a diagonal tile both halves exist)
+__device__ __forceinline__ int telem(int r, int c) { return tix(r >> 4, c >> 4) + (r & 15) * PS_TROW + (c & 15); }
 
 // entry (i,j), i >= j, of H_pp_schur_ without lambda: the lower triangle as Eigen's LDLT reads it
 __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int i, int j, double &vv, double &vr) {
@@ -739,7 +751,7 @@ __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int i, int j, 
 }
 
 // Workgroup b < 171: row b of H_pp_schur_ in natural order (getters, marginalisation) and, for the solve, row b of
-// the PERMUTED packed lower triangle Pg: the pivot order of Eigen's LDLT is the order of |diag + lambda|, which for
+// the PERMUTED, tiled lower triangle Pg: the pivot order of Eigen's LDLT is the order of |diag + lambda|, which for
 // lambda >= 0 and a non-negative diagonal does not depend on lambda, so it is fixed here once per linearisation
 // (every workgroup recomputes the 171 ranks: cheaper than one more launch).  Workgroups 171..175: identity padding.
 // Workgroup 176: right-hand side row, b_pp_schur_, pose part of b_, diag(Hessian_).
@@ -772,11 +784,15 @@ __global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
                 const int pi = sPerm[i], pj = sPerm[t];
                 double wv, wr;
                 d_hs_entry(T, max(pi, pj), min(pi, pj), wv, wr);
-                T.Pg[tri(i, t)] = wv + wr;
+                T.Pg[telem(i, t)] = wv + wr;
+                if (t < i && (t >> 4) == (i >> 4)) T.Pg[telem(t, i)] = wv + wr;      // upper half of a diagonal tile
             }
         }
     } else if (b < PS_NP) {
-        if (t <= b) T.Pg[tri(b, t)] = (t == b) ? 1.0 : 0.0;
+        if (t <= b) {
+            T.Pg[telem(b, t)] = (t == b) ? 1.0 : 0.0;
+            if (t < b && (t >> 4) == (b >> 4)) T.Pg[telem(t, b)] = 0.0;
+        }
     } else {
         if (t < VIO_PD) {
             const int i = t, ci = full_to_cam(i);
@@ -805,7 +821,7 @@ __global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
         }
     }
     __syncthreads();
-    if (b == PS_NP && t <= PS_NP) T.Pg[tri(PS_NP, t)] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
+    if (b == PS_NP && t < PS_NP) T.Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -813,18 +829,23 @@ __global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
 //
 // Pivoting: Eigen's LDLT picks, at step k, the largest |diagonal| among the NOT YET UPDATED trailing diagonal
 // (it is a left-looking algorithm, Cholesky/LDLT.h:317-320), so the whole pivot order is a sort of |diag(A)| and is
-// known before the factorisation starts: rank-sort the diagonal, gather the permuted lower triangle into LDS
-// (packed, 119 KB of the CU's 160 KB), then run an unpivoted blocked right-looking LDL^T on it:
-//   panel (8 columns)  one wave, rows in registers, pivot row entries broadcast with v_readlane, reciprocal by
-//                      v_rcp_f64 + Newton; columns stay unscaled (P(r,k) = L(r,k) d_k)
-//   trailing update    all 16 waves, 4x4 register tiles, A22 -= L21 D^-1 L21^T from LDS
-// The right-hand side rides along as row n of the packed triangle, so the forward substitution is free; the
-// back-substitution with L^T is done by one wave panel by panel.  Then: trial pose states (UpdateStates :453-480,
-// vertex_pose.cc:7-19), their pair table, and the first-order prior update (:473-474).
+// known before the factorisation starts: k_assemble rank-sorts the diagonal and writes the permuted lower triangle
+// as 16x16 tiles; this kernel copies them into LDS (140 KB of the CU's 160 KB) and runs an unpivoted blocked
+// right-looking LDL^T, 11 block columns of 16:
+//   panel            up to three waves, one lane per sub-diagonal row (16 columns in registers) plus a copy of the
+//                    diagonal tile's row (lane & 15) in every lane, so pivot-row entries are v_readlane broadcasts;
+//                    reciprocal by v_rcp_f64 + Newton; columns stay unscaled (U(r,k) = L(r,k) d_k)
+//   trailing update  all 16 waves, one 16x16 tile at a time: C -= U_ik (D^-1 U_jk^T) as four chained
+//                    v_mfma_f64_16x16x4_f64 with both operands read straight from the panel's tiles
+// The right-hand side rides along as row 176, so the forward substitution is free; the back-substitution with L^T
+// runs block by block from the bottom: a 16-step chain inside the diagonal tile, then every column left of it
+// accumulates that block's contribution (outer-product form, one barrier per block).  Then: trial pose states
+// (UpdateStates :453-480, vertex_pose.cc:7-19), their pair table, and the first-order prior update (:473-474).
 // ---------------------------------------------------------------------------------------------------------
 #define PS_THREADS 1024
 #define PS_TY (PS_THREADS / 32)
-#define PS_NB 8
+
+typedef double ps_v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double d_readlane(double x, int lane) {      // lane is wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
@@ -841,21 +862,75 @@ __device__ __forceinline__ double d_fast_rcp(double d) {                // 1/d t
     return x;
 }
 
-// The 171x171 system is padded to NP = 176 = 22 panels of 8 with identity pivots (zero right-hand side), the
-// right-hand side is row NP of the packed triangle.
-#define PS_SROW 10      // row stride of the scaled panel (doubles): 16-byte aligned and bank-conflict free for b128
+// F(K) of k_pose_solve: factor the 16x16 diagonal tile `tile` (row stride 17) in place, one wave.
+// Lanes 16..31 hold the rows of the identity (read from sI) and end up with M = the tile's column operations
+// applied to I (sM, 16 x 17); every other lane holds row (lane & 15) of the tile.
+// A lone wave issues one instruction of any kind every 4 cycles and dependent fp64 FMAs do not stall it, so the cost
+// is the instruction count plus whatever an s_waitcnt really waits.  Hence:
+//   * the pivot column is not broadcast with v_readlane (two per value plus a hazard nop) but published to LDS —
+//     lane c stores U(c,j) as soon as it is final — and read back as uniform loads, two values per instruction;
+//   * it is published INTO the tile, transposed (U(c,j) at [17 j + c]): that is the factored tile's final place,
+//     no copy-back; the back-substitution reads the diagonal tiles in that transposed form;
+//   * the sched_barriers pin the order publish -> (4 updates, 2 refills) groups, which gives every load a full
+//     reciprocal chain of slack; the reciprocals themselves are recomputed from the stored pivots by another
+//     wave (sDinv), off this chain.
+// Out of line: inlined into the kernel it pushes wave 0 over the 128 registers a 1024-thread workgroup allows.
+typedef __attribute__((address_space(3))) double lds_double;   // generic pointers would become flat_load here
+__device__ __noinline__ void ps_factor_diag(lds_double *tile, lds_double *sI, lds_double *sM, int lane) {
+    asm volatile("" : "+v"(tile));       // one base register + immediate offsets for the uniform loads below
+    const bool ident = (lane >> 4) == 1;
+    lds_double *p0 = (ident ? sI : tile) + (lane & 15) * PS_TROW;
+    double a0[PS_NB], u[PS_NB];
+#pragma unroll
+    for (int j = 0; j < PS_NB; ++j) a0[j] = p0[j];
+    // where a lane publishes its a0[j]: tile rows at tile[17 j + row] (all copies of a row store the same value),
+    // identity rows straight into their final place M[row][j]
+    lds_double *wp = ident ? sM + (lane & 15) * PS_TROW : tile + (lane & 15);
+    const int ws = ident ? 1 : PS_TROW;
+    __builtin_amdgcn_sched_barrier(0);   // every row is in registers before the first publish overwrites the tile
+    wp[0] = a0[0];
+    double d = d_readlane(a0[0], 0);
+#pragma unroll
+    for (int c = 1; c < PS_NB; ++c) u[c] = tile[c];
+#pragma unroll
+    for (int j = 0; j < PS_NB; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        const double l0 = a0[j] * d_fast_rcp(d);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0): one wait per column instead of one per update; by now
+        if (j + 1 < PS_NB) {                    // the previous column's loads have had the whole reciprocal to land
+            a0[j + 1] = fma(-l0, u[j + 1], a0[j + 1]);
+            wp += ws;
+            wp[0] = a0[j + 1];
+            d = d_readlane(a0[j + 1], j + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = j + 2; c < PS_NB; ++c) {
+            a0[c] = fma(-l0, u[c], a0[c]);
+            if (((c - j - 2) & 3) == 3 || c + 1 == PS_NB) {     // after every 4th update: refill what was just used
+#pragma unroll
+                for (int e = c - ((c - j - 2) & 3); e <= c; ++e) u[e] = tile[(j + 1) * PS_TROW + e];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
-    double *P = dyn_smem;                          // (NP+1)(NP+2)/2 = 15753
-    double *sS = P + 15754;                        // scaled panel L21 D^-1: (NP+1) rows x PS_SROW
-    double *sDg = sS + (PS_NP + 1) * PS_SROW;      // 176 diag (+lambda)
-    double *sDinv = sDg + 176;                     // 176
-    double *sX = sDinv + 176;                      // 176 solution in pivot order
-    double *sDx = sX + 176;                        // 176 solution in natural order
+    double *P = dyn_smem;                          // 66 tiles of 16x17, then the rhs row (192)
+    double *sY = P + PS_YOFF;
+    double *sDinv = P + PS_PACKED;                 // 176
+    double *sM = sDinv + 176;                      // 16 x 17: the panel's column operations applied to the identity
+    double *sI = sM + PS_TS;                       // 16 x 17 identity
+    double *sX = sI + PS_TS;                       // 192 solution in pivot order
+    double *sDx = sX + 192;                        // 176 solution in natural order
     double *sR = sDx + 176;                        // 108 rotations
     double *sB = sR + 112;                         // 176 trial b_prior
     int *sPerm = (int *)(sB + 176);                // 176
     const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
     LmState *lm = T.lm;
     const int cur = lm->cur, trial = cur ^ 1;
     const double lambda = lm->lambda;
@@ -873,24 +948,26 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 #define PS_OUT(slot) do { } while (0)
 #endif
 
-    // Fast path: the packed, permuted triangle k_assemble wrote (pivot order fixed with lambda = 0) is valid as
-    // long as |diag + lambda| is still non-increasing along it — always the case for lambda >= 0 on a
+    // Fast path: the permuted tiles k_assemble wrote (pivot order fixed with lambda = 0) are valid as long as
+    // |diag + lambda| is still non-increasing along the diagonal — always the case for lambda >= 0 on a
     // non-negative diagonal.  Coalesced 16-byte loads; lambda goes on the 171 real pivots.
     {
         const double2 *src = reinterpret_cast<const double2 *>(T.Pg);
         double2 *dst = reinterpret_cast<double2 *>(P);
-        for (int e = tid; e < (PS_PACKED + 1) / 2; e += PS_THREADS) dst[e] = src[e];
+        for (int e = tid; e < PS_PACKED / 2; e += PS_THREADS) dst[e] = src[e];
         for (int i = tid; i < n; i += PS_THREADS) sPerm[i] = T.perm[i];
+        if (tid < PS_TS) sI[tid] = (tid / PS_TROW == tid % PS_TROW) ? 1.0 : 0.0;
     }
     __syncthreads();
     int same = 1;
     for (int k = tid; k + 1 < n; k += PS_THREADS)
-        same &= (fabs(P[tri(k, k)] + lambda) >= fabs(P[tri(k + 1, k + 1)] + lambda)) ? 1 : 0;
+        same &= (fabs(P[telem(k, k)] + lambda) >= fabs(P[telem(k + 1, k + 1)] + lambda)) ? 1 : 0;
     same = __syncthreads_and(same);
     if (same) {
-        for (int k = tid; k < n; k += PS_THREADS) P[tri(k, k)] += lambda;
+        for (int k = tid; k < n; k += PS_THREADS) P[telem(k, k)] += lambda;
     } else {
         // slow path (e.g. a negative lambda): rank-sort |diag + lambda| here and gather entry by entry
+        double *sDg = sX;
         for (int i = tid; i < n; i += PS_THREADS) { double vv, vr; d_hs_entry(T, i, i, vv, vr); sDg[i] = vv + vr + lambda; }
         __syncthreads();
         for (int i = tid; i < n; i += PS_THREADS) {
@@ -904,213 +981,184 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
         }
         __syncthreads();
         for (int e = tid; e < PS_PACKED; e += PS_THREADS) {
-            int r = (int)((sqrt(8.0 * (double)e + 1.0) - 1.0) * 0.5);
-            while (tri(r + 1, 0) <= e) ++r;
-            while (tri(r, 0) > e) --r;
-            const int c = e - tri(r, 0);
             double v = 0.0;
-            if (r < n) {
-                const int i = sPerm[r], j = sPerm[c];
-                double vv, vr;
-                d_hs_entry(T, max(i, j), min(i, j), vv, vr);
-                v = vv + vr + ((r == c) ? lambda : 0.0);
-            } else if (r < NP) {
-                v = (r == c) ? 1.0 : 0.0;
+            if (e < PS_YOFF) {
+                const int ti = e / PS_TS, rem = e - ti * PS_TS, rr = rem / PS_TROW, cc = rem - rr * PS_TROW;
+                int I = 0;
+                while ((I + 1) * (I + 2) / 2 <= ti) ++I;
+                const int J = ti - I * (I + 1) / 2;
+                const int r0 = 16 * I + rr, c0 = 16 * J + cc;
+                const int r = max(r0, c0), c = min(r0, c0);          // upper half of a diagonal tile: mirrored
+                if (cc < 16) {
+                    if (r < n) {
+                        const int i = sPerm[r], j = sPerm[c];
+                        double vv, vr;
+                        d_hs_entry(T, max(i, j), min(i, j), vv, vr);
+                        v = vv + vr + ((r == c) ? lambda : 0.0);
+                    } else {
+                        v = (r == c) ? 1.0 : 0.0;
+                    }
+                }
             } else {
+                const int c = e - PS_YOFF;
                 v = (c < n) ? T.bs[sPerm[c]] : 0.0;
             }
             P[e] = v;
         }
     }
     __syncthreads();
-
     PS_OUT(0);
+
+    // Task graph of the blocked factorisation, with look-ahead:
+    //   F(K)      factor the diagonal tile (K,K): the serial chain of 16 pivots, wave 0 only
+    //   S(I,K)    U_IK = A_IK M_K for the tiles below it, one MFMA product per tile; M_K = the column operations of
+    //             F(K) applied to the identity (the rows of I ride along in lanes 16..31 of F's wave)
+    //   U(I,J,K)  A_IJ -= U_IK D_K^-1 U_JK^T
+    // F(K+1) only needs U(K+1,K+1,K), so wave 0 does that one update and goes straight on to F(K+1) while the
+    // other 15 waves do the rest of step K's updates.  Two barriers per step.
+    const int lofs = (lane & 15) * PS_TROW + (lane >> 4);      // A image: row l&15, k = (l>>4) + 4s (+4 per s)
+    const int cofs = (lane >> 4) * PS_TROW + (lane & 15);      // C/D and B image: row (l>>4) + 4v (+68 per v), col l&15
+    auto update_tile = [&](int I, int J, int K, const double *nd) {
+        const double *ta = P + tix(I, K) + lofs, *tb = P + tix(J, K) + lofs;
+        double *tc = P + tix(I, J) + cofs;
+        double av[4], bv[4];
+        ps_v4d acc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[q] = ta[4 * q]; bv[q] = tb[4 * q]; acc[q] = tc[4 * PS_TROW * q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q] * nd[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tc[4 * PS_TROW * q] = acc[q];
+    };
+
+    PS_MARK();
+    if (uwave == 0) ps_factor_diag((lds_double *)(P + tix(0, 0)), (lds_double *)sI, (lds_double *)sM, lane);
+    __syncthreads();
+    PS_ADD(t_panel);
+    for (int K = 0; K < PS_NT; ++K) {
+        const int k0 = K * PS_NB, k1 = k0 + PS_NB;
+        const int nk = PS_NT - 1 - K;                           // block rows below the panel
+        // ---- S: one tile per wave; the rhs row's 16 entries by wave 15 ----
+        if (uwave < nk) {
+            double *tt = P + tix(K + 1 + uwave, K);
+            double av[4], bv[4];
+            ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = tt[lofs + 4 * q]; bv[q] = sM[cofs + 4 * PS_TROW * q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tt[cofs + 4 * PS_TROW * q] = acc[q];
+        } else if (uwave == PS_THREADS / 64 - 2) {
+            if (lane < PS_NB) sDinv[k0 + lane] = d_fast_rcp(P[tix(K, K) + lane * (PS_TROW + 1)]);
+        } else if (uwave == PS_THREADS / 64 - 1) {
+            double y = 0.0;
+            if (lane < PS_NB) {
+#pragma unroll
+                for (int j = 0; j < PS_NB; ++j) y = fma(sY[k0 + j], sM[j * PS_TROW + lane], y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < PS_NB) sY[k0 + lane] = y;
+        }
+        __syncthreads();
+        PS_ADD(t_trail);
+        if (nk == 0) break;
+        // ---- U (+ F(K+1) on wave 0).  Items of the other waves: tiles 1 .. ntile-1 in row-major order of the
+        //      trailing triangle (tile 0 = (K+1,K+1) is wave 0's), then the rhs row in chunks of 64 columns ----
+        {
+            const int ntile = nk * (nk + 1) / 2;
+            const int nitem = ntile + ((nk * PS_NB + 63) >> 6);
+            double nd[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nd[q] = -sDinv[k0 + (lane >> 4) + 4 * q];
+            if (uwave == 0) {
 #ifdef VIO_STAMPS
-    {   // barrier micro-benchmark (diagnostic build only)
-        const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
-        for (int q = 0; q < 64; ++q) __syncthreads();
-        if (tid == 0 && T.dbg) T.dbg[18] = __builtin_amdgcn_s_memtime() - tb0;
-    }
+                const unsigned long long f0 = __builtin_amdgcn_s_memtime();
 #endif
-    for (int k0 = 0; k0 < NP; k0 += PS_NB) {
-        PS_MARK();
-        // ---- panel: wave 0, lane owns rows k0 + lane + 64 s.  Entries above the diagonal of the 8x8 block are
-        //      whatever the packed triangle holds there: they are computed on but never read back or stored ----
-        if (tid < 64) {
-            const int lane = tid;
-            double a[3][PS_NB];
-            int base[3];
+                update_tile(K + 1, K + 1, K, nd);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef VIO_STAMPS
+                const unsigned long long f1 = __builtin_amdgcn_s_memtime();
+#endif
+                ps_factor_diag((lds_double *)(P + tix(K + 1, K + 1)), (lds_double *)sI, (lds_double *)sM, lane);
+#ifdef VIO_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0 && T.dbg) { T.dbg[32 + K] = f1 - f0; T.dbg[48 + K] = __builtin_amdgcn_s_memtime() - f1; }
+#endif
+            } else {
+#ifdef VIO_STAMPS
+                const unsigned long long f0 = __builtin_amdgcn_s_memtime();
+#endif
+                for (int t = uwave; t < nitem; t += PS_THREADS / 64 - 1) {
+                    if (t < ntile) {
+                        int ii = 0;
+                        while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                        const int jj = t - ii * (ii + 1) / 2;
+                        update_tile(K + 1 + ii, K + 1 + jj, K, nd);
+                    } else {
+                        const int c = k1 + 64 * (t - ntile) + lane;
+                        if (c < NP) {
+                            const double *u = P + tix(c >> 4, K) + (c & 15) * PS_TROW;
+                            double y = sY[c];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int r = min(k0 + lane + 64 * s, NP);
-                base[s] = tri(r, k0);
-#pragma unroll
-                for (int j = 0; j < PS_NB; ++j) a[s][j] = P[base[s] + j];
-            }
-            double dinv[PS_NB];
-#pragma unroll
-            for (int j = 0; j < PS_NB; ++j) {
-                const double d = d_readlane(a[0][j], j);            // A(k0+j, k0+j): row k0+j is lane j, slot 0
-                dinv[j] = d_fast_rcp(d);
-                double l[3];
-#pragma unroll
-                for (int s = 0; s < 3; ++s) l[s] = a[s][j] * dinv[j];
-#pragma unroll
-                for (int c = j + 1; c < PS_NB; ++c) {
-                    const double u = d_readlane(a[0][j], c);        // A(k0+c, k0+j)
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) a[s][c] -= l[s] * u;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int r = k0 + lane + 64 * s;
-                if (r <= NP) {
-                    double *srow = sS + r * PS_SROW;
-#pragma unroll
-                    for (int j = 0; j < PS_NB; ++j) {
-                        if (s > 0 || j <= lane) P[base[s] + j] = a[s][j];
-                        srow[j] = a[s][j] * dinv[j];
+                            for (int kk = 0; kk < PS_NB; ++kk) y = fma(-(sY[k0 + kk] * sDinv[k0 + kk]), u[kk], y);
+                            sY[c] = y;
+                        }
                     }
                 }
-            }
-            if (lane < PS_NB) {
-                double dv = dinv[0];
-#pragma unroll
-                for (int j = 1; j < PS_NB; ++j) if (lane == j) dv = dinv[j];
-                sDinv[k0 + lane] = dv;
+#ifdef VIO_STAMPS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0 && T.dbg && uwave == 1) T.dbg[16 + K] = __builtin_amdgcn_s_memtime() - f0;
+#endif
             }
         }
         __syncthreads();
         PS_ADD(t_panel);
-        // ---- trailing update A22 -= L21 D^-1 L21^T.  The LDS pipe is one per CU, so the update is laid out to
-        //      touch it as little as possible: a wave owns whole rows (r = k1 + wave + 8a), its lanes own columns
-        //      c = k1 + lane + 64b.  The scaled panel rows of a lane's (up to 3) columns live in registers for the
-        //      whole update; a row's 8 panel values are fetched by 8 lanes in one LDS read and handed to the wave
-        //      as scalar operands with v_readlane, so per row the wave spends LDS cycles only on the entries it
-        //      modifies. ----
-        const int k1 = k0 + PS_NB;
-        if (k1 <= NP) {
-            const int wave = tid >> 6, lane = tid & 63;
-            const int m = NP + 1 - k1;                              // trailing rows (incl. the rhs row)
-            const int nbc = (m - 1 + 63) >> 6;                      // column groups in use (wave-uniform)
-            double sc[3][PS_NB];
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb) {
-                const int c = min(k1 + lane + 64 * bb, NP);
-#pragma unroll
-                for (int jj = 0; jj < PS_NB / 2; ++jj) {     // unconditional (clamped row): unused groups are never applied
-                    const double2 v = *reinterpret_cast<const double2 *>(sS + c * PS_SROW + 2 * jj);
-                    sc[bb][2 * jj] = v.x; sc[bb][2 * jj + 1] = v.y;
-                }
-            }
-            const int dump = (int)(sX - P) + lane;
-            const int waves = PS_THREADS / 64;
-            const int uwave = __builtin_amdgcn_readfirstlane(wave);    // row arithmetic stays on the scalar unit
-#ifdef VIO_STAMPS
-            const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
-            if (lane == 0 && T.dbg && (wave == 0 || wave == 5 || wave == 15)) T.dbg[32 + wave] += tl0 - t_mark;   // pre-loop
-#endif
-            int cofs[3];
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb) cofs[bb] = k1 + lane + 64 * bb;
-            for (int a = uwave; a < m; a += 2 * waves) {
-                // two rows per trip (ra and rb = ra + 16) so that one trip pays the LDS latency once; a row reaches
-                // column group b iff b <= (r - k1) / 64, so only those groups are loaded, updated and stored
-                const int ra = k1 + a, rb = min(ra + waves, NP);
-                const bool hasb = a + waves < m;
-                const int ta = tri(ra, 0), tb = tri(rb, 0);
-                const int ga = (a >> 6) + 1, gb = hasb ? ((a + waves) >> 6) + 1 : 0;
-                const double lv = P[((lane & 8) ? tb : ta) + k0 + (lane & 7)];     // lanes 0..7: row a, 8..15: row b
-                int ia[3], ib[3];
-                double oa[3], ob[3];
-#pragma unroll
-                for (int bb = 0; bb < 3; ++bb) {
-                    if (bb < ga) { ia[bb] = (cofs[bb] <= ra && cofs[bb] < NP) ? ta + cofs[bb] : dump; oa[bb] = P[ia[bb]]; }
-                    if (bb < gb) { ib[bb] = (cofs[bb] <= rb && cofs[bb] < NP) ? tb + cofs[bb] : dump; ob[bb] = P[ib[bb]]; }
-                }
-                double la[PS_NB], lb[PS_NB];
-#pragma unroll
-                for (int j = 0; j < PS_NB; ++j) la[j] = d_readlane(lv, j);
-                if (gb) {
-#pragma unroll
-                    for (int j = 0; j < PS_NB; ++j) lb[j] = d_readlane(lv, 8 + j);
-                }
-#pragma unroll
-                for (int bb = 0; bb < 3; ++bb) {
-                    if (bb < ga) {
-#pragma unroll
-                        for (int j = 0; j < PS_NB; ++j) oa[bb] = fma(-la[j], sc[bb][j], oa[bb]);
-                        P[ia[bb]] = oa[bb];
-                    }
-                    if (bb < gb) {
-#pragma unroll
-                        for (int j = 0; j < PS_NB; ++j) ob[bb] = fma(-lb[j], sc[bb][j], ob[bb]);
-                        P[ib[bb]] = ob[bb];
-                    }
-                }
-            }
-#ifdef VIO_STAMPS
-            if (lane == 0 && T.dbg && (wave == 0 || wave == 5)) T.dbg[16 + (wave ? 1 : 0)] += __builtin_amdgcn_s_memtime() - tl0;
-#endif
-        }
-#ifdef VIO_STAMPS
-        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
-#endif
-        __syncthreads();
-#ifdef VIO_STAMPS
-        if ((tid & 63) == 0 && T.dbg && ((tid >> 6) == 0 || (tid >> 6) == 5 || (tid >> 6) == 15)) T.dbg[48 + (tid >> 6)] += __builtin_amdgcn_s_memtime() - tw0;
-#endif
-        PS_ADD(t_trail);
     }
     PS_OUT(1);
 #ifdef VIO_STAMPS
     if (tid == 0 && T.dbg) { T.dbg[8] = t_panel; T.dbg[9] = t_trail; }
 #endif
 
-    // ---- z = D^+ y, then x = L^-T z panel by panel from the bottom (solve of Cholesky/LDLT.h:558-600).
-    //      Per panel: (A) the 16 waves form, two per column, the dot products of the panel's 8 columns with the part
-    //      of x already known (rows below the panel); (B) eight lanes of wave 0 run the 8-step chain inside the
-    //      panel with the pivot-row entries prefetched and x broadcast by v_readlane. ----
+    // ---- z = D^+ y, then x = L^-T z block by block from the bottom (solve of Cholesky/LDLT.h:558-600).
+    //      Thread c < 176 owns column c and keeps acc_c = sum over the rows below its block of U(r,c) x_r.
+    //      Per block I: (1) the 16 owners of its columns run the 16-step chain inside the diagonal tile, x broadcast
+    //      by v_readlane; (2) after one barrier every column left of the block adds the block's 16 terms. ----
     {
         const double tol = 1.0 / 1.7976931348623157e308;
-        double *sAcc = sDg;                         // 16 partial dot products (sDg is free after the permutation)
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int k = tid; k < NP; k += PS_THREADS) sX[k] = 0.0;
-        __syncthreads();
-        for (int k0 = NP - PS_NB; k0 >= 0; k0 -= PS_NB) {
-            {   // (A) column c = k0 + (wave & 7), rows k0+8 .. NP-1 split in two halves by wave >> 3
-                const int c = k0 + (wave & 7);
-                const int r0 = k0 + PS_NB, nrows = NP - r0;
-                const int half = (nrows + 1) >> 1;
-                const int lo = r0 + (wave >> 3) * half, hi = min(NP, lo + half);
-                double part = 0.0;
-                for (int r = lo + lane; r < hi; r += 64) part += P[tri(r, c)] * sX[r];
-                part = d_wave_sum_to_lane63(part);
-                if (lane == 63) sAcc[wave] = part;
-            }
-            __syncthreads();
-            if (tid < 64) {                         // (B) lane j < 8 owns column k0 + j
-                const int j = lane & 7;
-                const int c = k0 + j;
-                const double d = P[tri(c, c)];
-                const double z = (fabs(d) > tol) ? P[tri(NP, c)] / d : 0.0;      // row NP holds y = L^-1 b (unscaled)
-                const double dinv = sDinv[c];
-                double acc = sAcc[j] + sAcc[8 + j];
-                double blk[PS_NB];                  // P(k0+jj, c) for jj > j: the rest of this column inside the panel
+        const int c = tid;
+        double acc = 0.0;
+        for (int I = PS_NT - 1; I >= 0; --I) {
+            const int wI = (I * PS_NB) >> 6, lb = (I * PS_NB) & 63;
+            if (uwave == wI) {
+                const int j = (lane - lb) & 15;                 // lanes outside the block compute on junk, store nothing
+                const int cc = I * PS_NB + j;
+                const double *dt = P + tix(I, I);
+                const double d = dt[j * PS_TROW + j];
+                const double z = (fabs(d) > tol) ? sY[cc] / d : 0.0;      // sY holds y = L^-1 b (unscaled)
+                const double dinv = sDinv[cc];
+                double blk[PS_NB];                              // U(16I+jj, cc) for jj > j
 #pragma unroll
-                for (int jj = 0; jj < PS_NB; ++jj) blk[jj] = (jj > j) ? P[tri(k0 + jj, c)] : 0.0;
+                for (int jj = 0; jj < PS_NB; ++jj) blk[jj] = (jj > j) ? dt[j * PS_TROW + jj] : 0.0;   // stored transposed by F
+                const bool mine = (lane >= lb) && (lane < lb + PS_NB);
+                double a = mine ? acc : 0.0;
                 double xmine = 0.0;
 #pragma unroll
                 for (int jj = PS_NB - 1; jj >= 0; --jj) {
-                    const double cand = z - dinv * acc;
-                    const double xr = d_readlane(cand, jj);
+                    const double cand = z - dinv * a;
+                    const double xr = d_readlane(cand, lb + jj);
                     if (j == jj) xmine = xr;
-                    acc += blk[jj] * xr;
+                    a += blk[jj] * xr;
                 }
-                if (lane < PS_NB) sX[c] = xmine;
+                if (mine) sX[cc] = xmine;
             }
             __syncthreads();
+            if (c < I * PS_NB) {
+                const double *ut = P + tix(I, c >> 4) + (c & 15);
+                const double *xb = sX + I * PS_NB;
+#pragma unroll
+                for (int jj = 0; jj < PS_NB; ++jj) acc = fma(ut[jj * PS_TROW], xb[jj], acc);
+            }
         }
     }
     PS_OUT(2);
@@ -1144,15 +1192,15 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
         for (int i = wave; i < n; i += PS_THREADS / 64) {
             double s = 0;
             for (int j = lane; j < n; j += 64) s += T.Hprior[i * n + j] * sDx[j];
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) { const double v = T.bprior[cur * 176 + i] - s; sB[i] = v; T.bprior[trial * 176 + i] = v; }
+            s = d_wave_sum_to_lane63(s);
+            if (lane == 63) { const double v = T.bprior[cur * 176 + i] - s; sB[i] = v; T.bprior[trial * 176 + i] = v; }
         }
         __syncthreads();
         for (int i = wave; i < VIO_PRD; i += PS_THREADS / 64) {
             double s = 0;
             for (int j = lane; j < VIO_PRD; j += 64) s += -T.Jtinv[i * VIO_PRD + j] * sB[j];
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) T.errprior[trial * 160 + i] = s;
+            s = d_wave_sum_to_lane63(s);
+            if (lane == 63) T.errprior[trial * 160 + i] = s;
         }
     }
     PS_OUT(3);
