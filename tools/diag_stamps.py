@@ -54,5 +54,6 @@ print("per step K: wave-1 update loop      ", list(st2[:10]))
 print("per step K: wave-0 update tile (K+1) ", list(st3[:10]))
 print("per step K: wave-0 F(K+1)            ", list(st4[:10]))
 st = buf.astype(np.int64)[0]
+print("k_pose_solve prologue: diag+rhs loaded %d | pivot order known %d" % (st[4], st[5]))
 print("k_pose_solve: load+permute %d | factorisation done %d (F+U phases %d, S phases %d) | back-substitution done %d | end %d"
       % (st[0], st[1], st[8], st[9], st[2], st[3]))

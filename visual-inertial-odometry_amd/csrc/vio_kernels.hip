@@ -622,7 +622,7 @@ struct ReduceTables {
     double *vis;
 };
 
-#define RED_THREADS 256
+#define RED_THREADS 1024
 #define RED_PARTS (RED_THREADS / 64)
 
 __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
@@ -750,28 +750,61 @@ __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int i, int j, 
     }
 }
 
+// Row i of the right-hand sides: b_pp_schur_ (returned and stored in T.bs), the pose part of b_ (T.bfull, for the
+// gain ratio) and diag(Hessian_) before the Schur complement (T.diagfull, for ComputeLambdaInitLM, problem.cc:511-516)
+__device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int i, int cur) {
+    const int ci = full_to_cam(i);
+    const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
+    double bred = 0.0, bdir = 0.0, dv, dr;
+    if (ci >= 0) { bred = T.vis[VIS_BRED + ci]; bdir = T.vis[VIS_BDIR + ci]; }
+    double extra = 0.0;
+    if (i >= 6) {
+        const int fi = (i - 6) / 15;
+        for (int k = fi - 1; k <= fi; ++k) {
+            if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
+            if (T.marg_mode && k != 0) continue;
+            const int a = i - (6 + 15 * k);
+            if (a < 0 || a >= 30) continue;
+            extra -= T.imu_out[k * IMU_OUT + IMU_G + a];
+        }
+    }
+    if (T.has_prior && !mask_i) extra += T.bprior[cur * 176 + i];
+    T.bs[i] = bred + extra;
+    T.bfull[i] = bdir + extra;
+    d_hs_entry(T, i, i, dv, dr);
+    T.diagfull[i] = ((ci >= 0) ? T.vis[VIS_DIAG + ci] : 0.0) + dr;
+    return bred + extra;
+}
+
 // Workgroup b < 171: row b of H_pp_schur_ in natural order (getters, marginalisation) and, for the solve, row b of
 // the PERMUTED, tiled lower triangle Pg: the pivot order of Eigen's LDLT is the order of |diag + lambda|, which for
 // lambda >= 0 and a non-negative diagonal does not depend on lambda, so it is fixed here once per linearisation
-// (every workgroup recomputes the 171 ranks: cheaper than one more launch).  Workgroups 171..175: identity padding.
+// (every workgroup recomputes the 171 ranks, 5 threads per entry: cheaper than one more launch).  Workgroups 171..175: identity padding.
 // Workgroup 176: right-hand side row, b_pp_schur_, pose part of b_, diag(Hessian_).
-__global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
+#define ASM_THREADS 896        // 5 x 171 threads rank-sort, then 171 write the row
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
     __shared__ double sDg[176];
     __shared__ int sPerm[176];
+    __shared__ int sCnt[5 * 176];
     const int b = blockIdx.x, t = threadIdx.x;
     const int cur = T.lm->cur;
-    if (t < VIO_PD) { double vv, vr; d_hs_entry(T, t, t, vv, vr); sDg[t] = vv + vr; }
+    if (t < VIO_PD) { double vv, vr; d_hs_entry(T, t, t, vv, vr); sDg[t] = fabs(vv + vr); }
     __syncthreads();
-    if (t < VIO_PD) {
-        const double di = fabs(sDg[t]);
+    if (t < 5 * VIO_PD) {           // rank_i = #{j : d_j > d_i or (d_j == d_i and j < i)}, 5 threads per entry
+        const int i = t % VIO_PD, part = t / VIO_PD;
+        const int j0 = part * 35, j1 = min(VIO_PD, j0 + 35);
+        const double di = sDg[i];
         int rank = 0;
-        for (int j = 0; j < VIO_PD; ++j) {
-            const double dj = fabs(sDg[j]);
-            rank += (dj > di || (dj == di && j < t)) ? 1 : 0;
+        for (int j = j0; j < j1; ++j) {
+            const double dj = sDg[j];
+            rank += (dj > di || (dj == di && j < i)) ? 1 : 0;
         }
-        sPerm[rank] = t;
+        sCnt[part * 176 + i] = rank;
     }
     __syncthreads();
+    if (t < VIO_PD) sPerm[sCnt[t] + sCnt[176 + t] + sCnt[352 + t] + sCnt[528 + t] + sCnt[704 + t]] = t;
+    __syncthreads();
+    if (t >= 192) return;
     if (b < VIO_PD) {
         const int i = b;
         if (t < VIO_PD) {
@@ -780,7 +813,7 @@ __global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
                 d_hs_entry(T, max(i, t), min(i, t), vv, vr);
                 T.Hs[i * VIO_PD + t] = vv + vr;
             }
-            if (t <= i) {                       // permuted row i of the packed triangle
+            if (t <= i) {                       // permuted row i of the tiled triangle
                 const int pi = sPerm[i], pj = sPerm[t];
                 double wv, wr;
                 d_hs_entry(T, max(pi, pj), min(pi, pj), wv, wr);
@@ -795,33 +828,12 @@ __global__ __launch_bounds__(192) void k_assemble(DeviceTables T) {
         }
     } else {
         if (t < VIO_PD) {
-            const int i = t, ci = full_to_cam(i);
-            const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
-            double bred = 0.0, bdir = 0.0, dv, dr;
-            if (ci >= 0) { bred = T.vis[VIS_BRED + ci]; bdir = T.vis[VIS_BDIR + ci]; }
-            double extra = 0.0;
-            if (i >= 6) {
-                const int fi = (i - 6) / 15;
-                for (int k = fi - 1; k <= fi; ++k) {
-                    if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
-                    if (T.marg_mode && k != 0) continue;
-                    const int a = i - (6 + 15 * k);
-                    if (a < 0 || a >= 30) continue;
-                    extra -= T.imu_out[k * IMU_OUT + IMU_G + a];
-                }
-            }
-            if (T.has_prior && !mask_i) extra += T.bprior[cur * 176 + i];
-            T.bs[i] = bred + extra;
-            T.bfull[i] = bdir + extra;
-            // diag(Hessian_) before the Schur complement, for ComputeLambdaInitLM (problem.cc:511-516)
-            d_hs_entry(T, i, i, dv, dr);
-            T.diagfull[i] = ((ci >= 0) ? T.vis[VIS_DIAG + ci] : 0.0) + dr;
-            sDg[i] = bred + extra;
-            T.perm[i] = sPerm[i];
+            sDg[t] = d_rhs_entries(T, t, cur);
+            T.perm[t] = sPerm[t];
         }
+        __syncthreads();                        // the 192 remaining threads, all of them
+        if (t < PS_NP) T.Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
     }
-    __syncthreads();
-    if (b == PS_NP && t < PS_NP) T.Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -915,6 +927,50 @@ __device__ __noinline__ void ps_factor_diag(lds_double *tile, lds_double *sI, ld
             }
         }
     }
+}
+
+// Back-substitution of k_pose_solve, one wave.  Lane l owns columns l, l+64, l+128 (slots) and keeps
+// acc = sum over the rows below the column's block of U(r,c) x_r for each.  Per block I, from the bottom:
+//   chain   the 16 lanes of the block's slot: x_j = z_j - dinv_j (acc_j + sum_{jj>j} U(16I+jj, c_j) x_jj), 16 steps,
+//           x_jj broadcast by v_readlane; the diagonal tile is stored transposed and zero on/left of the diagonal,
+//           so a lane's 16 multipliers are one unmasked row
+//   spread  every column left of the block adds the block's 16 terms, the x_jj still in scalar registers
+// No LDS round trip for x, no barrier; the z = y / d of Eigen is y * (1/d) with the factorisation's reciprocal.
+__device__ __noinline__ void ps_backsub(lds_double *P, int lane) {
+    lds_double *sY = P + PS_YOFF, *sDinv = P + PS_PACKED, *sX = sDinv + 176 + 2 * PS_TS;
+    double acc[3] = {0.0, 0.0, 0.0}, xs[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int I = PS_NT - 1; I >= 0; --I) {
+        const int slot = (I * PS_NB) >> 6, lb = (I * PS_NB) & 63;
+        const int j = (lane - lb) & 15;                 // lanes outside the block compute on junk, never read back
+        const int cc = I * PS_NB + j;
+        lds_double *dt = P + tix(I, I) + j * PS_TROW;
+        const double dinv = sDinv[cc];
+        const double z = sY[cc] * dinv;                 // sY holds y = L^-1 b (unscaled)
+        double blk[PS_NB];
+#pragma unroll
+        for (int jj = 0; jj < PS_NB; ++jj) blk[jj] = dt[jj];
+        double a = acc[slot];
+        double xr[PS_NB];
+#pragma unroll
+        for (int jj = PS_NB - 1; jj >= 0; --jj) {
+            xr[jj] = d_readlane(fma(-dinv, a, z), lb + jj);
+            a = fma(blk[jj], xr[jj], a);
+        }
+        const double xmine = fma(-dinv, a, z);          // blk[jj] = 0 for jj <= j: a stopped changing after step j+1
+        xs[slot] = (lane >= lb && lane < lb + PS_NB) ? xmine : xs[slot];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            if (sl * 64 < I * PS_NB) {                  // the slot still has columns left of the block
+                const int c = min(lane + 64 * sl, I * PS_NB - 1);      // clamped lanes redo a neighbour's sum: unused
+                lds_double *ut = P + tix(I, c >> 4) + (c & 15);
+#pragma unroll
+                for (int jj = 0; jj < PS_NB; ++jj) acc[sl] = fma(ut[jj * PS_TROW], xr[jj], acc[sl]);
+            }
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) sX[lane + 64 * sl] = xs[sl];
 }
 
 __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
@@ -1089,7 +1145,13 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 #ifdef VIO_STAMPS
                 const unsigned long long f0 = __builtin_amdgcn_s_memtime();
 #endif
-                for (int t = uwave; t < nitem; t += PS_THREADS / 64 - 1) {
+                // Waves 4, 8 and 12 share wave 0's SIMD and slow F down by taking its issue slots: they sit the
+                // update out whenever 12 waves need no more rounds than 15 would.
+                const int rounds15 = (nitem - 1 + 14) / 15, rounds12 = (nitem - 1 + 11) / 12;
+                const bool spare = rounds12 == rounds15;
+                const int nw = spare ? 12 : 15;
+                const int slot = spare ? ((uwave & 3) ? uwave - 1 - (uwave >> 2) : -1) : uwave - 1;   // 0 .. nw-1
+                for (int t = 1 + slot; slot >= 0 && t < nitem; t += nw) {
                     if (t < ntile) {
                         int ii = 0;
                         while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
@@ -1120,47 +1182,16 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     if (tid == 0 && T.dbg) { T.dbg[8] = t_panel; T.dbg[9] = t_trail; }
 #endif
 
-    // ---- z = D^+ y, then x = L^-T z block by block from the bottom (solve of Cholesky/LDLT.h:558-600).
-    //      Thread c < 176 owns column c and keeps acc_c = sum over the rows below its block of U(r,c) x_r.
-    //      Per block I: (1) the 16 owners of its columns run the 16-step chain inside the diagonal tile, x broadcast
-    //      by v_readlane; (2) after one barrier every column left of the block adds the block's 16 terms. ----
-    {
-        const double tol = 1.0 / 1.7976931348623157e308;
-        const int c = tid;
-        double acc = 0.0;
-        for (int I = PS_NT - 1; I >= 0; --I) {
-            const int wI = (I * PS_NB) >> 6, lb = (I * PS_NB) & 63;
-            if (uwave == wI) {
-                const int j = (lane - lb) & 15;                 // lanes outside the block compute on junk, store nothing
-                const int cc = I * PS_NB + j;
-                const double *dt = P + tix(I, I);
-                const double d = dt[j * PS_TROW + j];
-                const double z = (fabs(d) > tol) ? sY[cc] / d : 0.0;      // sY holds y = L^-1 b (unscaled)
-                const double dinv = sDinv[cc];
-                double blk[PS_NB];                              // U(16I+jj, cc) for jj > j
-#pragma unroll
-                for (int jj = 0; jj < PS_NB; ++jj) blk[jj] = (jj > j) ? dt[j * PS_TROW + jj] : 0.0;   // stored transposed by F
-                const bool mine = (lane >= lb) && (lane < lb + PS_NB);
-                double a = mine ? acc : 0.0;
-                double xmine = 0.0;
-#pragma unroll
-                for (int jj = PS_NB - 1; jj >= 0; --jj) {
-                    const double cand = z - dinv * a;
-                    const double xr = d_readlane(cand, lb + jj);
-                    if (j == jj) xmine = xr;
-                    a += blk[jj] * xr;
-                }
-                if (mine) sX[cc] = xmine;
-            }
-            __syncthreads();
-            if (c < I * PS_NB) {
-                const double *ut = P + tix(I, c >> 4) + (c & 15);
-                const double *xb = sX + I * PS_NB;
-#pragma unroll
-                for (int jj = 0; jj < PS_NB; ++jj) acc = fma(ut[jj * PS_TROW], xb[jj], acc);
-            }
-        }
+    // ---- z = D^+ y, then x = L^-T z (solve of Cholesky/LDLT.h:558-600): one wave, no barriers (ps_backsub).
+    //      First the diagonal tiles are cleaned: F left them transposed with junk on and left of the diagonal;
+    //      zeros there let the chain read whole rows unmasked. ----
+    for (int e = tid; e < PS_NT * PS_NB * PS_NB; e += PS_THREADS) {
+        const int I = e >> 8, j = (e >> 4) & 15, cc = e & 15;
+        if (cc <= j) P[tix(I, I) + j * PS_TROW + cc] = 0.0;
     }
+    __syncthreads();
+    if (uwave == 0) ps_backsub((lds_double *)P, lane);
+    __syncthreads();
     PS_OUT(2);
     for (int r = tid; r < n; r += PS_THREADS) {
         const double v = sX[r];
@@ -1424,7 +1455,7 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1), dim3(RED_THREADS), 0, s, R);
 }
-void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(PS_NP + 1), dim3(192), 0, s, T); }
+void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(PS_NP + 1), dim3(ASM_THREADS), 0, s, T); }
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
 }
