@@ -22,16 +22,18 @@
 #include "vio_device_math.h"
 #include "vio_types.h"
 
-#define LIN_THREADS 256
+#define LIN_THREADS 1024
 
 // In-kernel stamps exist only in the diagnostic build (-DVIO_STAMPS -> libvio_hip_stamps.so, never shipped or timed)
 #ifdef VIO_STAMPS
-#define STAMP(T, slot)                                                                                   \
-    do {                                                                                                 \
-        if (threadIdx.x == 0 && (T).dbg) (T).dbg[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
+// Stamps go to LDS and are flushed once at the end: a global store in front of a barrier would add its own round
+// trip to the phase it is meant to time.
+__shared__ unsigned long long g_stamps[8];
+#define STAMP(T, slot) do { if (threadIdx.x == 0) g_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_FLUSH(T) do { if (threadIdx.x == 0 && (T).dbg) for (int q__ = 0; q__ < 8; ++q__) (T).dbg[(size_t)blockIdx.x * 16 + q__] = g_stamps[q__]; } while (0)
 #else
 #define STAMP(T, slot) do { } while (0)
+#define STAMP_FLUSH(T) do { } while (0)
 #endif
 
 __device__ __forceinline__ int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
@@ -331,7 +333,7 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
 extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
 
 __host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles)
-__host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 23 : 17; }      // aux record stride (odd)
+__host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 27 : 15; }      // per-observation partials (odd stride)
 __host__ __device__ inline int lin_plane(int G, int use_ext) { return G * lin_rrow(use_ext) + 6; }
 __host__ __device__ inline int lin_lrec(int nb) { return 12 * nb + 4; }
 // total dynamic LDS of an item (doubles); must match the carve-up in k_linearize
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         STAMP(T, 0);
         d_imu_item(T, b - T.n_items, dyn_smem);
         STAMP(T, 5);
+        STAMP_FLUSH(T);
         return;
     }
     __shared__ ItemDesc sIt;        // kept in LDS: its small arrays are indexed at run time
@@ -360,7 +363,8 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     const int G = it.G, K = it.K, nb = it.nb, use_ext = it.use_ext;
     const int RROW = lin_rrow(use_ext), RAUX = lin_raux(use_ext), PLANE = lin_plane(G, use_ext), LREC = lin_lrec(nb);
     const int offH = 0, offT = 12, offE = 24;                       // inside a row record
-    const int auxA = 0, auxBH = 2, auxBT = 8, auxBL = 14, auxBE = 15;   // inside an aux record
+    // per-observation partials of the landmark quantities (sAux record): host w (6), host b (6), h, b_l, [ext w (6), ext b (6)]
+    const int pkWH = 0, pkBH = 6, pkH = 12, pkBL = 13, pkWE = 14, pkBE = 20;
 
     double *sPair = dyn_smem;                         // VIO_MAXK * PAIR_STRIDE
     double *sCam = sPair + VIO_MAXK * PAIR_STRIDE;    // ric, tic
@@ -370,6 +374,16 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     double *sAux = sL + G * LREC;                     // G*K*RAUX, dead after phase 1.5 ...
     double *sPart = sAux;                             // ... then nsplit*n_strips*8
 
+    const double *invd = T.invd + (size_t)cur * T.Ns + it.lm_base;
+    const double *pts_i = T.pts_i + 2 * (size_t)it.lm_base;
+    const double *pts_j = T.pts_j + 2 * (size_t)it.obs_base;
+    // the first observation's inputs and the table words of the later phases are requested before the pair table's
+    // barrier: every global latency of the workgroup overlaps this one
+    double pf_lam = 1.0, pf_x = 0.0, pf_y = 0.0, pf_u = 0.0, pf_v = 0.0;
+    if (tid < G * K) {
+        const int k0 = tid / G, g0 = tid - k0 * G;
+        pf_lam = invd[g0]; pf_x = pts_i[2 * g0]; pf_y = pts_i[2 * g0 + 1]; pf_u = pts_j[2 * tid]; pf_v = pts_j[2 * tid + 1];
+    }
     const double *ptab = T.pairtab + cur * PAIRTAB_STRIDE;
     for (int e = tid; e < K * PAIR_STRIDE; e += LIN_THREADS) {
         const int k = e / PAIR_STRIDE, o = e % PAIR_STRIDE;
@@ -378,9 +392,6 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     if (tid < 12) sCam[tid] = ptab[121 * PAIR_STRIDE + tid];
     __syncthreads();
 
-    const double *invd = T.invd + (size_t)cur * T.Ns + it.lm_base;
-    const double *pts_i = T.pts_i + 2 * (size_t)it.lm_base;
-    const double *pts_j = T.pts_j + 2 * (size_t)it.obs_base;
     const double s_info = T.sqrt_info, info = s_info * s_info;
     const double *ric = sCam, *tic = sCam + CAMTAB_TIC;
 
@@ -390,10 +401,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     for (int o = tid; o < G * K; o += LIN_THREADS) {
         const int k = o / G, g = o - k * G;
         const double *PA = sPair + k * PAIR_STRIDE;
-        const double lam = invd[g];
+        const bool first = o == tid;
+        const double lam = first ? pf_lam : invd[g];
         const double il = 1.0 / lam;
-        const double x = pts_i[2 * g], y = pts_i[2 * g + 1];
-        const double u = pts_j[2 * o], v = pts_j[2 * o + 1];
+        const double x = first ? pf_x : pts_i[2 * g], y = first ? pf_y : pts_i[2 * g + 1];
+        const double u = first ? pf_u : pts_j[2 * o], v = first ? pf_v : pts_j[2 * o + 1];
         const double pci[3] = {x * il, y * il, il};
         double Cp[3], pcj[3], pbi[3], pbj[3];
         d_m3_vec(PA + PAIR_C, pci, Cp);
@@ -444,20 +456,27 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         const double L00 = s_info * (al + gm * r0 * r0), L01 = s_info * (gm * r0 * r1), L11 = s_info * (al + gm * r1 * r1);
         const double c0 = rho1 * (info * r0), c1 = rho1 * (info * r1);         // drho * Information * residual
 
+        // The landmark quantities of phase 1.5 are sums over the landmark's observations; this thread has its own
+        // term of each in registers.  Target-block terms have one contributor: they go straight to the landmark
+        // record; host (and extrinsic) terms go to the per-observation partials and are summed in phase 1.5.
         double *rec = sRows + k * PLANE + g * RROW;
-        double *aux = sAux + (size_t)o * RAUX;
+        double *pk = sAux + (size_t)o * RAUX;
+        double *Lg = sL + (size_t)g * LREC;
+        const int pT = it.tslot[k];
+        const double a0 = L00 * Jl0 + L01 * Jl1, a1 = L01 * Jl0 + L11 * Jl1;      // whitened d r / d lambda
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            rec[offH + c] = L00 * Jh0[c] + L01 * Jh1[c];
-            rec[offH + 6 + c] = L01 * Jh0[c] + L11 * Jh1[c];
-            rec[offT + c] = L00 * Jt0[c] + L01 * Jt1[c];
-            rec[offT + 6 + c] = L01 * Jt0[c] + L11 * Jt1[c];
-            aux[auxBH + c] = Jh0[c] * c0 + Jh1[c] * c1;
-            aux[auxBT + c] = Jt0[c] * c0 + Jt1[c] * c1;
+            const double lh0 = L00 * Jh0[c] + L01 * Jh1[c], lh1 = L01 * Jh0[c] + L11 * Jh1[c];
+            const double lt0 = L00 * Jt0[c] + L01 * Jt1[c], lt1 = L01 * Jt0[c] + L11 * Jt1[c];
+            rec[offH + c] = lh0; rec[offH + 6 + c] = lh1;
+            rec[offT + c] = lt0; rec[offT + 6 + c] = lt1;
+            pk[pkWH + c] = lh0 * a0 + lh1 * a1;                 // Hpm column of this landmark, host block
+            pk[pkBH + c] = Jh0[c] * c0 + Jh1[c] * c1;           // drho J^T Info r  (b gets the minus sign in phase 2)
+            Lg[6 * pT + c] = lt0 * a0 + lt1 * a1;
+            Lg[6 * nb + 6 * pT + c] = Jt0[c] * c0 + Jt1[c] * c1;
         }
-        aux[auxA] = L00 * Jl0 + L01 * Jl1;
-        aux[auxA + 1] = L01 * Jl0 + L11 * Jl1;
-        aux[auxBL] = Jl0 * c0 + Jl1 * c1;
+        pk[pkH] = a0 * a0 + a1 * a1;
+        pk[pkBL] = Jl0 * c0 + Jl1 * c1;
         if (use_ext) {
             // J_ext = reduce * [El | -C hat(pc_i) + hat(C pc_i) + hat(d)] = [reduce*El | pc_i x (reduce*C)rows + red_rows x pc_j]
             double Je0[6], Je1[6], RC0[3], RC1[3];
@@ -475,58 +494,32 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             Je1[3] = pci[1] * RC1[2] - pci[2] * RC1[1] + x1[0]; Je1[4] = pci[2] * RC1[0] - pci[0] * RC1[2] + x1[1]; Je1[5] = pci[0] * RC1[1] - pci[1] * RC1[0] + x1[2];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                rec[offE + c] = L00 * Je0[c] + L01 * Je1[c];
-                rec[offE + 6 + c] = L01 * Je0[c] + L11 * Je1[c];
-                aux[auxBE + c] = Je0[c] * c0 + Je1[c] * c1;
+                const double le0 = L00 * Je0[c] + L01 * Je1[c], le1 = L01 * Je0[c] + L11 * Je1[c];
+                rec[offE + c] = le0; rec[offE + 6 + c] = le1;
+                pk[pkWE + c] = le0 * a0 + le1 * a1;
+                pk[pkBE + c] = Je0[c] * c0 + Je1[c] * c1;
             }
         }
     }
     __syncthreads();
 
-    // ---------------- phase 1.5: (landmark, block subset) ----------------
+    // ---------------- phase 1.5: thread per (landmark, quantity): sum the K partials ----------------
     STAMP(T, 2);
     double maxh = 0.0;
     {
-        const int parts = LIN_THREADS / G > 0 ? LIN_THREADS / G : 1;
-        const int g = tid % G, part = tid / G;
-        if (part < parts) {
-            double h = 0;
-            for (int k = 0; k < K; ++k) {
-                const double *aux = sAux + (size_t)(k * G + g) * RAUX;
-                h += aux[auxA] * aux[auxA] + aux[auxA + 1] * aux[auxA + 1];
-            }
-            const double hinv = 1.0 / h;                // Hmm_inv (problem.cc:419-425)
+        const int Q = use_ext ? 26 : 14;
+        const int hs = it.host_slot;
+        for (int e = tid; e < G * Q; e += LIN_THREADS) {
+            const int g = e / Q, q = e - g * Q;
+            double sum = 0.0;
+            for (int k = 0; k < K; ++k) sum += sAux[(size_t)(k * G + g) * RAUX + q];
             double *L = sL + (size_t)g * LREC;
-            double *lw = T.lw + it.lw_base;
-            for (int p = part; p < nb; p += parts) {
-                const int ty = it.btype[p];             // 0 ext, 1 host, 2 target
-                const int k0 = ty == 2 ? it.bk[p] : 0, k1 = ty == 2 ? it.bk[p] + 1 : K;
-                const int offR = ty == 0 ? offE : (ty == 1 ? offH : offT);
-                const int offB = ty == 0 ? auxBE : (ty == 1 ? auxBH : auxBT);
-                double w[6] = {0, 0, 0, 0, 0, 0}, bv[6] = {0, 0, 0, 0, 0, 0};
-                for (int k = k0; k < k1; ++k) {
-                    const double *rec = sRows + k * PLANE + g * RROW + offR;
-                    const double *aux = sAux + (size_t)(k * G + g) * RAUX;
-                    const double a0 = aux[auxA], a1 = aux[auxA + 1];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) { w[c] += rec[c] * a0 + rec[6 + c] * a1; bv[c] += aux[offB + c]; }
-                }
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    L[6 * p + c] = w[c];                // Hpm column of this landmark
-                    L[6 * nb + 6 * p + c] = bv[c];      // sum_k drho J^T Info r  (b gets the minus sign in phase 2)
-                    lw[(size_t)(6 * p + c) * G + g] = w[c];
-                }
-            }
-            if (part == 0) {
-                double bl = 0;
-                for (int k = 0; k < K; ++k) bl -= sAux[(size_t)(k * G + g) * RAUX + auxBL];
-                L[12 * nb] = hinv;
-                L[12 * nb + 1] = bl;
-                maxh = fabs(h);
-                lw[(size_t)(6 * nb) * G + g] = h;
-                lw[(size_t)(6 * nb + 1) * G + g] = bl;
-            }
+            if (q < pkBH) L[6 * hs + q] = sum;
+            else if (q < pkH) L[6 * nb + 6 * hs + (q - pkBH)] = sum;
+            else if (q == pkH) { L[12 * nb] = 1.0 / sum; L[12 * nb + 2] = sum; maxh = fmax(maxh, fabs(sum)); }   // Hmm_inv (problem.cc:419-425)
+            else if (q == pkBL) L[12 * nb + 1] = -sum;
+            else if (q < pkBE) L[q - pkWE] = sum;                   // the extrinsic is pattern-local block 0
+            else L[6 * nb + (q - pkBE)] = sum;
         }
     }
     __syncthreads();
@@ -537,11 +530,12 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     {
         const int wave = tid >> 6, lane = tid & 63;
         const uint32_t *strips = T.strips + it.strip_off;
-        const int s_first = (nsplit == 4) ? lane : tid;
-        const int s_step = (nsplit == 4) ? 64 : LIN_THREADS;
-        const int g_first = (nsplit == 4) ? wave : 0;
-        const int g_step = (nsplit == 4) ? 4 : 1;
-        const int split = (nsplit == 4) ? wave : 0;
+        // nsplit (1 or 4) consecutive waves share a set of 64 strips and split its landmarks between them
+        const int split = wave & (nsplit - 1);
+        const int s_first = (wave / nsplit) * 64 + lane;
+        const int s_step = LIN_THREADS / nsplit;
+        const int g_first = split;
+        const int g_step = nsplit;
         for (int s = s_first; s < n_strips; s += s_step) {
             const uint32_t w = strips[s];
             const int p = STRIP_P(w), q = STRIP_Q(w), i = STRIP_I(w), ks = STRIP_K(w), selL = STRIP_SELL(w);
@@ -594,6 +588,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         const uint32_t *elems = T.rows + it.row_off;
         double *out = T.slab + it.out_base;
         const int n_out = it.n_rows * 6;
+        // block reductions first: a global store followed by a barrier costs the store's whole round trip
+        const double chi = d_block_sum<LIN_THREADS>(chi_acc, sRed, tid);
+        const double mh = d_block_max<LIN_THREADS>(maxh, sRed, tid);
         for (int e = tid; e < n_out; e += LIN_THREADS) {
             const uint32_t w = elems[e];
             const int first = ELEM_FIRST(w), ncopy = ELEM_NCOPY(w), slot = ELEM_SLOT(w);
@@ -602,11 +599,17 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
                 for (int v = 0; v < nsplit; ++v) sum += sPart[((size_t)v * n_strips + first + c) * 8 + slot];
             out[e] = sum;
         }
-        const double chi = d_block_sum<LIN_THREADS>(chi_acc, sRed, tid);
-        const double mh = d_block_max<LIN_THREADS>(maxh, sRed, tid);
         if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
+        // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
+        double *lw = T.lw + it.lw_base;
+        for (int e = tid; e < (6 * nb + 2) * G; e += LIN_THREADS) {
+            const int r = e / G, g = e - r * G;
+            const double *L = sL + (size_t)g * LREC;
+            lw[e] = (r < 6 * nb) ? L[r] : (r == 6 * nb ? L[12 * nb + 2] : L[12 * nb + 1]);
+        }
     }
     STAMP(T, 5);
+    STAMP_FLUSH(T);
 }
 
 // ---------------------------------------------------------------------------------------------------------
