@@ -126,6 +126,30 @@ DEV double d_wave_sum_to_lane63(double v) {
     return v;                           // lane 63 holds the wave's sum
 }
 
+DEV double d_wave_max_to_lane63(double v) {        // same network with fmax (inputs >= 0: the 0 a masked row reads is neutral)
+    v = fmax(v, d_dpp_mov<0xB1>(v));
+    v = fmax(v, d_dpp_mov<0x4E>(v));
+    v = fmax(v, d_dpp_mov<0x141>(v));
+    v = fmax(v, d_dpp_mov<0x140>(v));
+    v = fmax(v, d_dpp_mov<0x142, 0xa>(v));
+    v = fmax(v, d_dpp_mov<0x143, 0xc>(v));
+    return v;
+}
+
+// Sum and max over a workgroup of NT threads in one pass: DPP inside the wave, one LDS slot per wave, the wave
+// partials added in wave order by every thread (fixed order).  scratch: 2 * NT / 64 doubles.  All threads must call.
+template <int NT>
+DEV void d_block_sum_max(double &sum, double &mx, double *scratch, int tid) {
+    const double s = d_wave_sum_to_lane63(sum), m = d_wave_max_to_lane63(mx);
+    if ((tid & 63) == 63) { scratch[tid >> 6] = s; scratch[NT / 64 + (tid >> 6)] = m; }
+    __syncthreads();
+    double ts = 0.0, tm = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { ts += scratch[w]; tm = fmax(tm, scratch[NT / 64 + w]); }
+    __syncthreads();
+    sum = ts; mx = tm;
+}
+
 // deterministic block reductions (fixed tree), all threads must call
 template <int NT>
 DEV double d_block_sum(double v, double *scratch, int tid) {

@@ -331,17 +331,24 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
 // LDS rows are read as 16-byte pairs (ds_read_b128); all region sizes and strides are even numbers of doubles.
 // ---------------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+typedef double ps_v4d __attribute__((ext_vector_type(4)));      // accumulator of v_mfma_f64_16x16x4_f64
 
 __host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles)
 __host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 27 : 15; }      // per-observation partials (odd stride)
 __host__ __device__ inline int lin_plane(int G, int use_ext) { return G * lin_rrow(use_ext) + 6; }
-__host__ __device__ inline int lin_lrec(int nb) { return 12 * nb + 4; }
+__host__ __device__ inline int lin_lrec(int nb) { return 12 * nb + 5; }                 // landmark record stride (odd)
+#define LIN_VS 8            // landmark splits of the vector sums of phase 2
+// tiles of phase 2: K direct products (1 tile of 16x16, 3 with the extrinsic) + the lower tiles of the 6nb x 6nb Schur term
+__host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
+    const int ts = (6 * nb + 15) >> 4;
+    return K * (use_ext ? 3 : 1) + ts * (ts + 1) / 2;
+}
 // total dynamic LDS of an item (doubles); must match the carve-up in k_linearize
-__host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext, int nsplit, int n_strips) {
-    int aux = G * K * lin_raux(use_ext), part = nsplit * n_strips * 8;
+__host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext, int /*nsplit*/, int /*n_strips*/) {
+    int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256 + 2 * 6 * nb * LIN_VS;
     int shared = aux > part ? aux : part;
     shared = (shared + 1) & ~1;
-    return VIO_MAXK * PAIR_STRIDE + 16 + LIN_THREADS + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
+    return VIO_MAXK * PAIR_STRIDE + 16 + 2 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
 }
 
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
@@ -368,11 +375,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
 
     double *sPair = dyn_smem;                         // VIO_MAXK * PAIR_STRIDE
     double *sCam = sPair + VIO_MAXK * PAIR_STRIDE;    // ric, tic
-    double *sRed = sCam + 16;                         // LIN_THREADS
-    double *sRows = sRed + LIN_THREADS;               // K * PLANE
+    double *sRed = sCam + 16;                         // 2 * waves
+    double *sRows = sRed + 2 * (LIN_THREADS / 64);    // K * PLANE
     double *sL = sRows + K * PLANE;                   // G * LREC
     double *sAux = sL + G * LREC;                     // G*K*RAUX, dead after phase 1.5 ...
-    double *sPart = sAux;                             // ... then nsplit*n_strips*8
+    double *sTile = sAux;                             // ... then the 16x16 tiles of phase 2 and the vector partials
 
     const double *invd = T.invd + (size_t)cur * T.Ns + it.lm_base;
     const double *pts_i = T.pts_i + 2 * (size_t)it.lm_base;
@@ -524,80 +531,123 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     }
     __syncthreads();
 
-    // ---------------- phase 2: strips ----------------
+    // ---------------- phase 2: the item's contribution as 16x16 products on the matrix cores ----------------
+    // Streaming the LDS rows through VALU strips was bound by LDS bandwidth (9 bytes per FMA).  v_mfma_f64_16x16x4
+    // takes one operand element per lane, so the same sums cost two LDS reads per 1024 FMAs:
+    //   direct  for every observation index k: C_k = V_k^T V_k, V_k = the 2G whitened rows of the item's k-th
+    //           observations with columns [host 6 | target 6 | extrinsic 6]  (one tile; three with the extrinsic)
+    //   Schur   S = - sum_g w_g w_g^T / h_g over the 6nb pattern columns (lower tiles)
+    // One wave per product; the b vectors are plain sums over the landmarks (LIN_VS partials each).
     STAMP(T, 3);
-    const int n_strips = it.n_strips, nsplit = it.nsplit;
+    const int D = 6 * nb;
+    const int ntd = use_ext ? 3 : 1;
+    const int TS = (D + 15) >> 4, nts = TS * (TS + 1) / 2;
+    double *sVec = sTile + (size_t)(K * ntd + nts) * 256;
     {
-        const int wave = tid >> 6, lane = tid & 63;
-        const uint32_t *strips = T.strips + it.strip_off;
-        // nsplit (1 or 4) consecutive waves share a set of 64 strips and split its landmarks between them
-        const int split = wave & (nsplit - 1);
-        const int s_first = (wave / nsplit) * 64 + lane;
-        const int s_step = LIN_THREADS / nsplit;
-        const int g_first = split;
-        const int g_step = nsplit;
-        for (int s = s_first; s < n_strips; s += s_step) {
-            const uint32_t w = strips[s];
-            const int p = STRIP_P(w), q = STRIP_Q(w), i = STRIP_I(w), ks = STRIP_K(w), selL = STRIP_SELL(w);
-            const int sp = STRIP_SRCP(w), sq = STRIP_SRCQ(w), dflag = STRIP_DIAG(w);
-            const int offp = (sp == 0 ? offE : (sp == 1 ? offH : offT)) + i;
-            const int offq = sq == 0 ? offE : (sq == 1 ? offH : offT);
-            // landmark term: acc += coef * X[0..5]
-            const int offX = selL == 3 ? 6 * nb + 6 * p : (selL == 1 ? 6 * q : 6 * p);
-            const int offC = 6 * p + i;
-            const bool direct = ks != 15;
-            double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0, acc5 = 0, dd = 0;
-            const double *Lg = sL + (size_t)g_first * LREC;
-            const double *rec = sRows + (direct ? ks : 0) * PLANE + g_first * RROW;
+        const int wave = tid >> 6, lane = tid & 63, cl = lane & 15, rg = lane >> 4;
+        const int nwork = K * ntd + nts;
+        for (int wk = wave; wk < nwork; wk += LIN_THREADS / 64) {
+            ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            if (wk < K * ntd) {
+                const int k = wk / ntd, t = wk - k * ntd;          // t: 0 -> tile (0,0), 1 -> (1,0), 2 -> (1,1)
+                const int Dk = use_ext ? 18 : 12;
+                const int ca = 16 * (t == 0 ? 0 : 1) + cl, cb = 16 * (t == 2 ? 1 : 0) + cl;
+                const int cac = min(ca, Dk - 1), cbc = min(cb, Dk - 1);
+                // column -> offset inside a row record (host 0..5, target 6..11, extrinsic 12..17), + which of the 2 rows
+                const int oa = (cac < 6 ? offH + cac : (cac < 12 ? offT + cac - 6 : offE + cac - 12)) + (rg & 1) * 6;
+                const int ob = (cbc < 6 ? offH + cbc : (cbc < 12 ? offT + cbc - 6 : offE + cbc - 12)) + (rg & 1) * 6;
+                const double ma = ca < Dk ? 1.0 : 0.0, mb = cb < Dk ? 1.0 : 0.0;
+                const double *plane = sRows + k * PLANE;
+                const int steps = (G + 1) >> 1;                     // 4 rows = 2 landmarks per MFMA
 #pragma unroll 4
-            for (int g = g_first; g < G; g += g_step, Lg += g_step * LREC, rec += g_step * RROW) {
-                if (selL) {
-                    const double hinv = Lg[12 * nb];
-                    double coef = -1.0;
-                    if (selL == 1) coef = -(Lg[offC] * hinv);          // -(Hpm * Hmm^-1) entry (problem.cc:427)
-                    else if (selL == 2) coef = hinv * Lg[12 * nb + 1];
-                    const double2 x01 = *reinterpret_cast<const double2 *>(Lg + offX);
-                    const double2 x23 = *reinterpret_cast<const double2 *>(Lg + offX + 2);
-                    const double2 x45 = *reinterpret_cast<const double2 *>(Lg + offX + 4);
-                    acc0 += coef * x01.x; acc1 += coef * x01.y; acc2 += coef * x23.x;
-                    acc3 += coef * x23.y; acc4 += coef * x45.x; acc5 += coef * x45.y;
+                for (int st = 0; st < steps; ++st) {
+                    const int g = 2 * st + (rg >> 1);
+                    const double *r = plane + min(g, G - 1) * RROW;
+                    const double gm = g < G ? ma : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(r[oa] * gm, r[ob] * mb, acc, 0, 0, 0);
                 }
-                if (direct) {
-                    const double p0 = rec[offp], p1 = rec[offp + 6];
-                    const double2 a01 = *reinterpret_cast<const double2 *>(rec + offq);
-                    const double2 a23 = *reinterpret_cast<const double2 *>(rec + offq + 2);
-                    const double2 a45 = *reinterpret_cast<const double2 *>(rec + offq + 4);
-                    const double2 b01 = *reinterpret_cast<const double2 *>(rec + offq + 6);
-                    const double2 b23 = *reinterpret_cast<const double2 *>(rec + offq + 8);
-                    const double2 b45 = *reinterpret_cast<const double2 *>(rec + offq + 10);
-                    acc0 += p0 * a01.x + p1 * b01.x; acc1 += p0 * a01.y + p1 * b01.y;
-                    acc2 += p0 * a23.x + p1 * b23.x; acc3 += p0 * a23.y + p1 * b23.y;
-                    acc4 += p0 * a45.x + p1 * b45.x; acc5 += p0 * a45.y + p1 * b45.y;
-                    if (dflag) dd += p0 * p0 + p1 * p1;
+            } else {
+                const int ts = wk - K * ntd;
+                int ta = 0;
+                while ((ta + 1) * (ta + 2) / 2 <= ts) ++ta;
+                const int tb = ts - ta * (ta + 1) / 2;
+                const int a = 16 * ta + cl, bq = 16 * tb + cl;
+                const int ac = min(a, D - 1), bc = min(bq, D - 1);
+                const double ma = a < D ? 1.0 : 0.0, mb = bq < D ? -1.0 : 0.0;
+                const int steps = (G + 3) >> 2;                     // 4 landmarks per MFMA
+#pragma unroll 4
+                for (int st = 0; st < steps; ++st) {
+                    const int g = 4 * st + rg;
+                    const double *Lg = sL + (size_t)min(g, G - 1) * LREC;
+                    const double gm = g < G ? ma : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lg[ac] * gm, (Lg[bc] * Lg[12 * nb]) * mb, acc, 0, 0, 0);
                 }
             }
-            double *o = sPart + ((size_t)split * n_strips + s) * 8;
-            o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; o[4] = acc4; o[5] = acc5; o[6] = dd;
+            double *tl = sTile + (size_t)wk * 256 + rg * 16 + cl;   // C/D image: row rg + 4v, column cl
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tl[64 * v] = acc[v];
+        }
+        // b vectors: which 0: direct b = - sum_g bvec_g;  1: Schur correction = sum_g (b_l/h)_g w_g   (fixed order)
+        for (int e = tid; e < 2 * D * LIN_VS; e += LIN_THREADS) {
+            const int part = e % LIN_VS, a = (e / LIN_VS) % D, which = e / (LIN_VS * D);
+            double sum = 0.0;
+            for (int g = part; g < G; g += LIN_VS) {
+                const double *Lg = sL + (size_t)g * LREC;
+                sum += which == 0 ? -Lg[D + a] : (Lg[12 * nb] * Lg[12 * nb + 1]) * Lg[a];
+            }
+            sVec[e] = sum;
         }
     }
     __syncthreads();
 
-    // ---------------- combine and write the item's slab ----------------
+    // ---------------- combine: thread per slab element ----------------
     STAMP(T, 4);
     {
-        const uint32_t *elems = T.rows + it.row_off;
         double *out = T.slab + it.out_base;
         const int n_out = it.n_rows * 6;
+        const int n_pair = (nb * (nb + 1) / 2) * 36;
         // block reductions first: a global store followed by a barrier costs the store's whole round trip
-        const double chi = d_block_sum<LIN_THREADS>(chi_acc, sRed, tid);
-        const double mh = d_block_max<LIN_THREADS>(maxh, sRed, tid);
+        double chi = chi_acc, mh = maxh;
+        d_block_sum_max<LIN_THREADS>(chi, mh, sRed, tid);
+        // entry (x, y) of the k-th direct product; x, y: host 0..5, target 6..11, extrinsic 12..17
+        auto cdir = [&](int k, int x, int y) -> double {
+            const int hi = max(x, y), lo = min(x, y);
+            const int t = hi < 16 ? 0 : (lo < 16 ? 1 : 2);
+            return sTile[(size_t)(k * ntd + t) * 256 + (hi & 15) * 16 + (lo & 15)];
+        };
+        auto colof = [&](int ty, int i) { return ty == 1 ? i : (ty == 2 ? 6 + i : 12 + i); };
         for (int e = tid; e < n_out; e += LIN_THREADS) {
-            const uint32_t w = elems[e];
-            const int first = ELEM_FIRST(w), ncopy = ELEM_NCOPY(w), slot = ELEM_SLOT(w);
-            double sum = 0;
-            for (int c = 0; c < ncopy; ++c)
-                for (int v = 0; v < nsplit; ++v) sum += sPart[((size_t)v * n_strips + first + c) * 8 + slot];
-            out[e] = sum;
+            double v = 0.0;
+            if (e < n_pair) {
+                const int pi = e / 36, rem = e - 36 * pi, i = rem / 6, j = rem - 6 * i;
+                int p = 0, left = pi;
+                while (left >= nb - p) { left -= nb - p; ++p; }
+                const int q = p + left;
+                const int a = 6 * p + i, bq = 6 * q + j;
+                const int hi = (a >> 4) >= (bq >> 4) ? a : bq, lo = (a >> 4) >= (bq >> 4) ? bq : a;
+                const int ta = hi >> 4, tb = lo >> 4;
+                v = sTile[(size_t)(K * ntd + ta * (ta + 1) / 2 + tb) * 256 + (hi & 15) * 16 + (lo & 15)];
+                const int tp = it.btype[p], tq = it.btype[q];
+                if (tp != 2 && tq != 2) {                       // both touched by every observation
+                    for (int k = 0; k < K; ++k) v += cdir(k, colof(tp, i), colof(tq, j));
+                } else if (tp == 2 && tq == 2) {
+                    if (p == q) v += cdir(it.bk[p], 6 + i, 6 + j);
+                } else {
+                    v += cdir(tp == 2 ? it.bk[p] : it.bk[q], colof(tp, i), colof(tq, j));
+                }
+            } else {
+                const int ve = e - n_pair, which = ve / D, a = ve - which * D;
+                if (which < 2) {
+                    const double *pv = sVec + (size_t)(which * D + a) * LIN_VS;
+#pragma unroll
+                    for (int q = 0; q < LIN_VS; ++q) v += pv[q];
+                } else {                                        // direct diagonal (diag(Hessian_) before the Schur complement)
+                    const int p = a / 6, i = a - 6 * p, ty = it.btype[p];
+                    if (ty != 2) { for (int k = 0; k < K; ++k) v += cdir(k, colof(ty, i), colof(ty, i)); }
+                    else v = cdir(it.bk[p], 6 + i, 6 + i);
+                }
+            }
+            out[e] = v;
         }
         if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
         // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
@@ -860,7 +910,6 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
 #define PS_THREADS 1024
 #define PS_TY (PS_THREADS / 32)
 
-typedef double ps_v4d __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double d_readlane(double x, int lane) {      // lane is wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
