@@ -558,13 +558,25 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
                 const int ob = (cbc < 6 ? offH + cbc : (cbc < 12 ? offT + cbc - 6 : offE + cbc - 12)) + (rg & 1) * 6;
                 const double ma = ca < Dk ? 1.0 : 0.0, mb = cb < Dk ? 1.0 : 0.0;
                 const double *plane = sRows + k * PLANE;
-                const int steps = (G + 1) >> 1;                     // 4 rows = 2 landmarks per MFMA
-#pragma unroll 4
-                for (int st = 0; st < steps; ++st) {
-                    const int g = 2 * st + (rg >> 1);
-                    const double *r = plane + min(g, G - 1) * RROW;
-                    const double gm = g < G ? ma : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(r[oa] * gm, r[ob] * mb, acc, 0, 0, 0);
+                const int chunks = (((G + 1) >> 1) + 3) >> 2;       // 4 rows = 2 landmarks per MFMA, 4 MFMAs per chunk
+                // operands of the next chunk are in flight while the matrix core works on this one
+                double va[4], vb[4], xa[4], xb[4];
+                auto load = [&](int ch, double *pa, double *pb) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int g = 2 * (4 * ch + u) + (rg >> 1);
+                        const double *r = plane + min(g, G - 1) * RROW;
+                        pa[u] = r[oa] * (g < G ? ma : 0.0);
+                        pb[u] = r[ob] * mb;
+                    }
+                };
+                load(0, va, vb);
+                for (int ch = 0; ch < chunks; ++ch) {
+                    if (ch + 1 < chunks) load(ch + 1, xa, xb);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { va[u] = xa[u]; vb[u] = xb[u]; }
                 }
             } else {
                 const int ts = wk - K * ntd;
@@ -574,13 +586,24 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
                 const int a = 16 * ta + cl, bq = 16 * tb + cl;
                 const int ac = min(a, D - 1), bc = min(bq, D - 1);
                 const double ma = a < D ? 1.0 : 0.0, mb = bq < D ? -1.0 : 0.0;
-                const int steps = (G + 3) >> 2;                     // 4 landmarks per MFMA
-#pragma unroll 4
-                for (int st = 0; st < steps; ++st) {
-                    const int g = 4 * st + rg;
-                    const double *Lg = sL + (size_t)min(g, G - 1) * LREC;
-                    const double gm = g < G ? ma : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lg[ac] * gm, (Lg[bc] * Lg[12 * nb]) * mb, acc, 0, 0, 0);
+                const int chunks = (((G + 3) >> 2) + 3) >> 2;       // 4 landmarks per MFMA
+                double va[4], vb[4], xa[4], xb[4];
+                auto load = [&](int ch, double *pa, double *pb) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int g = 4 * (4 * ch + u) + rg;
+                        const double *Lg = sL + (size_t)min(g, G - 1) * LREC;
+                        pa[u] = Lg[ac] * (g < G ? ma : 0.0);
+                        pb[u] = (Lg[bc] * Lg[12 * nb]) * mb;
+                    }
+                };
+                load(0, va, vb);
+                for (int ch = 0; ch < chunks; ++ch) {
+                    if (ch + 1 < chunks) load(ch + 1, xa, xb);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { va[u] = xa[u]; vb[u] = xb[u]; }
                 }
             }
             double *tl = sTile + (size_t)wk * 256 + rg * 16 + cl;   // C/D image: row rg + 4v, column cl
@@ -588,7 +611,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             for (int v = 0; v < 4; ++v) tl[64 * v] = acc[v];
         }
         // b vectors: which 0: direct b = - sum_g bvec_g;  1: Schur correction = sum_g (b_l/h)_g w_g   (fixed order)
-        for (int e = tid; e < 2 * D * LIN_VS; e += LIN_THREADS) {
+        // (by the waves that had no product to form, when there are any)
+        const int v0 = min(nwork, LIN_THREADS / 64 - 1) * 64;
+        for (int e = tid - v0; e >= 0 && e < 2 * D * LIN_VS; e += LIN_THREADS - v0) {
             const int part = e % LIN_VS, a = (e / LIN_VS) % D, which = e / (LIN_VS * D);
             double sum = 0.0;
             for (int g = part; g < G; g += LIN_VS) {
