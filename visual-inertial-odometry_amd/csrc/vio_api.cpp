@@ -38,7 +38,7 @@ void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
 int vio_set_kernel_attributes();
-int lin_lds_doubles_host(int G, int K, int nb, int use_ext, int nsplit, int n_strips);
+int lin_lds_doubles_host(int G, int K, int nb, int use_ext);
 
 namespace {
 
@@ -65,10 +65,10 @@ struct DevBuf {
 };
 
 struct Pattern {
-    int use_ext, host, K, nb, host_slot, nsplit, G;
+    int use_ext, host, K, nb, host_slot, G;
     int btype_i[VIO_MAXNB], bk_i[VIO_MAXNB];
     int8_t target[VIO_MAXK], tslot[VIO_MAXK], cam_block[VIO_MAXNB];
-    int strip_off, n_strips, row_off, n_rows, lds_doubles;
+    int n_rows, lds_doubles;
 };
 
 // Everything that depends on the graph topology (which landmark is seen from where).
@@ -79,16 +79,14 @@ struct Plan {
     std::vector<int32_t> sorted_to_orig;       // landmark permutation
     std::vector<ItemDesc> items;
     std::vector<Pattern> patterns;
-    std::vector<uint32_t> strips, rows;
     std::vector<int32_t> list_off, list;
     size_t slab_doubles = 0, lw_doubles = 0;
     int max_lds_doubles = 0;
     DevBuf<ItemDesc> d_items;
-    DevBuf<uint32_t> d_strips, d_rows;
     DevBuf<int32_t> d_list_off, d_list;
     DevBuf<double> d_pts_i, d_pts_j, d_invd, d_slab, d_lw, d_dxl, d_step_part;
     void release() {
-        d_items.release(); d_strips.release(); d_rows.release(); d_list_off.release(); d_list.release();
+        d_items.release(); d_list_off.release(); d_list.release();
         d_pts_i.release(); d_pts_j.release(); d_invd.release(); d_slab.release(); d_lw.release(); d_dxl.release();
         d_step_part.release();
         valid = false;
@@ -120,7 +118,7 @@ struct vio_ctx {
     double gn_lambda = -1.0;
     bool want_natural_hs = false;              // set by vio_get_schur_system: re-run k_assemble with the natural-order copy
     bool natural_hs_valid = false;
-    int g_max = 48;                            // landmarks per item (tunable: VIO_G_MAX; 48 measured best at 20k landmarks)
+    int g_max = 48;                            // landmarks per item (tunable: VIO_G_MAX; 48 measured best at 20k landmarks, k_backsub needs <= 64)
     Plan solve_plan, marg_plan;
     Plan *active = nullptr;
     // device buffers independent of the topology
@@ -162,7 +160,10 @@ vio_status fail(vio_ctx *c, vio_status s, const std::string &msg) {
 }
 
 // ---- topology preprocessing ----------------------------------------------------------------------------
-void build_pattern_tables(Pattern &pt, std::vector<uint32_t> &strips, std::vector<uint32_t> &elems, int g_max) {
+// Block types of a pattern, its slab size and the largest G that fits the LDS budget.  The slab of an item holds,
+// in this order: the 6x6 blocks of the pattern-local pairs (p <= q, p-major), then per block the direct b, the Schur
+// correction of b and the direct diagonal, then chi2 and max h_ll (k_linearize writes it, k_reduce's lists index it).
+void build_pattern_tables(Pattern &pt, int g_max) {
     const int nb = pt.nb, K = pt.K;
     int *type = pt.btype_i, *kof = pt.bk_i;
     for (int p = 0; p < nb; ++p) {
@@ -170,42 +171,11 @@ void build_pattern_tables(Pattern &pt, std::vector<uint32_t> &strips, std::vecto
         kof[p] = 15;
     }
     for (int k = 0; k < K; ++k) kof[pt.tslot[k]] = k;
-    pt.strip_off = (int)strips.size();
-    pt.row_off = (int)elems.size();
-    int ns = 0;
-    std::vector<uint32_t> diag_elems;           // direct diagonal: slot 6 of the (p,p,i) strips
-    for (int p = 0; p < nb; ++p)
-        for (int q = p; q < nb; ++q)
-            for (int i = 0; i < 6; ++i) {
-                const int first = ns;
-                int ncopy = 1;
-                const int dflag = p == q;
-                if (type[p] != 2 && type[q] != 2) {          // both touched by every observation: one copy per k
-                    ncopy = K;
-                    for (int cpy = 0; cpy < K; ++cpy) { strips.push_back(STRIP_PACK(p, q, i, cpy, cpy == 0 ? 1 : 0, dflag, type[p], type[q])); ++ns; }
-                } else if (type[p] == 2 && type[q] == 2 && p != q) {     // two different targets: Schur term only
-                    strips.push_back(STRIP_PACK(p, q, i, 15, 1, 0, type[p], type[q])); ++ns;
-                } else {
-                    const int k = type[p] == 2 ? kof[p] : kof[q];
-                    strips.push_back(STRIP_PACK(p, q, i, k, 1, dflag, type[p], type[q])); ++ns;
-                }
-                for (int j = 0; j < 6; ++j) elems.push_back(ELEM_PACK(first, ncopy, j));
-                if (dflag) diag_elems.push_back(ELEM_PACK(first, ncopy, 6));
-            }
-    // vector rows: direct b (landmark term 3), Schur correction of b (landmark term 2), then the direct diagonal
-    for (int sel = 3; sel >= 2; --sel)
-        for (int p = 0; p < nb; ++p) {
-            for (int j = 0; j < 6; ++j) elems.push_back(ELEM_PACK(ns, 1, j));
-            strips.push_back(STRIP_PACK(p, 0, 0, 15, sel, 0, type[p], 0)); ++ns;
-        }
-    elems.insert(elems.end(), diag_elems.begin(), diag_elems.end());
-    pt.n_strips = ns;
     pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
-    pt.nsplit = ns < 192 ? 4 : 1;
     int G = std::max(1, std::min(g_max, 256 / K));
-    while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext, pt.nsplit, ns) > LDS_BUDGET_DOUBLES) --G;
+    while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext) > LDS_BUDGET_DOUBLES) --G;
     pt.G = G;
-    pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext, pt.nsplit, ns);
+    pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
 }
 
 vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
@@ -217,7 +187,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     for (int64_t e = 0; e < M; ++e) obs_of[c->h_olm[e]].push_back((int32_t)e);
     // pattern of each landmark
     std::map<std::vector<int8_t>, int> pattern_id;
-    pl.patterns.clear(); pl.strips.clear(); pl.rows.clear();
+    pl.patterns.clear();
     std::vector<int32_t> lm_pattern(N, -1);
     for (int64_t l = 0; l < N; ++l) {
         const auto &ob = obs_of[l];
@@ -258,7 +228,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
                 pt.target[k] = key[1 + k];
                 for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + key[1 + k]) pt.tslot[k] = (int8_t)q;
             }
-            build_pattern_tables(pt, pl.strips, pl.rows, c->g_max);
+            build_pattern_tables(pt, c->g_max);
             pl.patterns.push_back(pt);
         } else id = itp->second;
         lm_pattern[l] = id;
@@ -287,8 +257,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         std::memcpy(it.target, pt.target, sizeof(it.target)); std::memcpy(it.tslot, pt.tslot, sizeof(it.tslot));
         std::memcpy(it.cam_block, pt.cam_block, sizeof(it.cam_block));
         for (int p = 0; p < pt.nb; ++p) { it.btype[p] = (int8_t)pt.btype_i[p]; it.bk[p] = (int8_t)pt.bk_i[p]; }
-        it.strip_off = pt.strip_off; it.n_strips = pt.n_strips; it.row_off = pt.row_off; it.n_rows = pt.n_rows;
-        it.nsplit = pt.nsplit; it.lds_doubles = pt.lds_doubles;
+        it.n_rows = pt.n_rows; it.lds_doubles = pt.lds_doubles;
         pl.items.push_back(it);
         pl.max_lds_doubles = std::max(pl.max_lds_doubles, pt.lds_doubles);
         pl.slab_doubles += (size_t)item_out_count(pt.nb);
@@ -333,7 +302,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     pl.list_off[n_lists] = (int32_t)pl.list.size();
     // upload
     const size_t ni = pl.items.size();
-    HIPCHK(pl.d_items.resize(ni)); HIPCHK(pl.d_strips.resize(pl.strips.size())); HIPCHK(pl.d_rows.resize(pl.rows.size()));
+    HIPCHK(pl.d_items.resize(ni));
     HIPCHK(pl.d_list_off.resize(pl.list_off.size())); HIPCHK(pl.d_list.resize(pl.list.size()));
     HIPCHK(pl.d_pts_i.resize(2 * (size_t)pl.Ns)); HIPCHK(pl.d_pts_j.resize(2 * (size_t)pl.Ms));
     HIPCHK(pl.d_invd.resize(2 * (size_t)std::max<int64_t>(pl.Ns, 1))); HIPCHK(pl.d_slab.resize(pl.slab_doubles));
@@ -341,8 +310,6 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     HIPCHK(pl.d_step_part.resize(4 * (ni + VIO_WINDOW_SIZE)));
     hipStream_t st = c->stream;
     if (ni) HIPCHK(hipMemcpyAsync(pl.d_items.p, pl.items.data(), ni * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
-    if (!pl.strips.empty()) HIPCHK(hipMemcpyAsync(pl.d_strips.p, pl.strips.data(), pl.strips.size() * 4, hipMemcpyHostToDevice, st));
-    if (!pl.rows.empty()) HIPCHK(hipMemcpyAsync(pl.d_rows.p, pl.rows.data(), pl.rows.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(pl.d_list_off.p, pl.list_off.data(), pl.list_off.size() * 4, hipMemcpyHostToDevice, st));
     if (!pl.list.empty()) HIPCHK(hipMemcpyAsync(pl.d_list.p, pl.list.data(), pl.list.size() * 4, hipMemcpyHostToDevice, st));
     if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i.data(), 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
@@ -379,7 +346,7 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     T.state = c->d_state.p; T.invd = pl.d_invd.p; T.pts_i = pl.d_pts_i.p; T.pts_j = pl.d_pts_j.p;
     T.pairtab = c->d_pairtab.p; T.slab = pl.d_slab.p; T.lw = pl.d_lw.p; T.vis = c->ext_vis ? c->ext_vis : c->d_vis.p; T.pre = c->d_pre.p;
     T.imu_valid = c->d_imu_valid.p; T.imu_out = c->d_imu_out.p; T.imu_chi_try = c->d_imu_chi.p;
-    T.strips = pl.d_strips.p; T.rows = pl.d_rows.p; T.pair_slot = nullptr; T.blk_slot = nullptr;
+    T.pair_slot = nullptr; T.blk_slot = nullptr;
     T.Hprior = c->d_Hprior.p; T.bprior = c->d_bprior.p; T.errprior = c->d_errprior.p; T.Jtinv = c->d_Jtinv.p;
     // Problem always carries a 171x171 prior block (zero before the first marginalisation); err_prior_ exists
     // only once a prior has been set (problem.cc:466,505,554)

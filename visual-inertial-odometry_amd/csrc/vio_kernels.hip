@@ -317,18 +317,16 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_linearize: one workgroup (256 threads) per item
+// k_linearize: one workgroup (1024 threads) per item
 //   phase 1   thread per observation (k-major: a wave shares one target frame): residual, Jacobians, robust
-//             weight; the whitened rows L*J go to sRows (one plane per k, planes skewed by 6 doubles so that the
-//             strips of different k hit different LDS banks), the scalars phase 1.5 needs go to sAux
-//   phase 1.5 (landmark, block-subset) threads: h_ll, b_l, Schur row w = Hpl, direct b; w/h/b_l also go to HBM for
-//             the back-substitution
-//   phase 2   lanes own 1x6 strips of the output blocks and stream the LDS rows of the item's landmarks
-//             (the 4 waves split the landmarks, or the strips when there are many); every strip runs the same
-//             loop body: an optional "landmark term" coef * X[0..5] (Schur / b correction / direct b) and an
-//             optional "direct term" p0*q0[0..5] + p1*q1[0..5]; fixed summation order
-//   combine   thread per output element sums the wave partials and the per-k copies, coalesced store to the slab
-// LDS rows are read as 16-byte pairs (ds_read_b128); all region sizes and strides are even numbers of doubles.
+//             weight; the whitened rows L*J go to sRows (one plane per k), the thread's own terms of the
+//             per-landmark sums go to sAux (host/extrinsic blocks) or straight to the landmark record (target block)
+//   phase 1.5 thread per (landmark, quantity): sums the K per-observation terms: h_ll, b_l, Schur row w = Hpl, direct b
+//   phase 2   one wave per 16x16 product on the matrix cores (v_mfma_f64_16x16x4_f64): C_k = V_k^T V_k for the
+//             whitened rows of every observation index k, and the Schur term - sum_g w_g w_g^T / h_g; the b vectors
+//             are plain sums over the landmarks; fixed summation order
+//   combine   thread per slab element picks its direct and Schur entries out of the tiles; coalesced store to the
+//             slab; w/h/b_l go to HBM last (the back-substitution reads them)
 // ---------------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
 typedef double ps_v4d __attribute__((ext_vector_type(4)));      // accumulator of v_mfma_f64_16x16x4_f64
@@ -344,7 +342,7 @@ __host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
     return K * (use_ext ? 3 : 1) + ts * (ts + 1) / 2;
 }
 // total dynamic LDS of an item (doubles); must match the carve-up in k_linearize
-__host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext, int /*nsplit*/, int /*n_strips*/) {
+__host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext) {
     int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256 + 2 * 6 * nb * LIN_VS;
     int shared = aux > part ? aux : part;
     shared = (shared + 1) & ~1;
@@ -1556,8 +1554,8 @@ void vio_launch_flip(LmState *lm, hipStream_t s) { hipLaunchKernelGGL(k_flip, di
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter, maxh_src);
 }
-int lin_lds_doubles_host(int G, int K, int nb, int use_ext, int nsplit, int n_strips) {
-    return lin_lds_doubles(G, K, nb, use_ext, nsplit, n_strips);
+int lin_lds_doubles_host(int G, int K, int nb, int use_ext) {
+    return lin_lds_doubles(G, K, nb, use_ext);
 }
 int vio_set_kernel_attributes() {
     hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);

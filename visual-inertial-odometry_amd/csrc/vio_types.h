@@ -74,35 +74,10 @@ struct ItemDesc {
     int8_t cam_block[VIO_MAXNB]; // camera block id (0 ext, 1+f pose f) of pattern-local block p
     int8_t btype[VIO_MAXNB];     // 0 ext, 1 host, 2 target
     int8_t bk[VIO_MAXNB];        // observation index k of a target block
-    int32_t strip_off;           // first strip word of this item's pattern
-    int32_t n_strips;
-    int32_t row_off;             // first output-element word of this item's pattern (6 * n_rows of them)
     int32_t n_rows;              // 6*nbp pair rows + 3*nb vector rows
-    int32_t nsplit;              // 4: the four waves split the landmarks; 1: they split the strips
     int32_t lds_doubles;         // dynamic LDS this item needs
 };
 
-// A "strip" is the unit of phase-2 work of one lane: six accumulators (j = 0..5) of one output row plus one
-// scalar (the direct diagonal entry of a (p,p) row).
-//   bits 0-3 p | 4-7 q | 8-10 i | 11-14 ksel (15: no direct term) | 15-16 landmark term | 17 diag flag
-//   | 18-19 row source of p | 20-21 row source of q        (row source: 0 ext rows, 1 host rows, 2 target rows)
-//   landmark term 0 none, 1 Schur: -(w[6p+i]/h) * w[6q..], 2 b correction: (b_l/h) * w[6p..], 3 direct b: -bvec[6p..]
-#define STRIP_P(w) ((w) & 15u)
-#define STRIP_Q(w) (((w) >> 4) & 15u)
-#define STRIP_I(w) (((w) >> 8) & 7u)
-#define STRIP_K(w) (((w) >> 11) & 15u)
-#define STRIP_SELL(w) (((w) >> 15) & 3u)
-#define STRIP_DIAG(w) (((w) >> 17) & 1u)
-#define STRIP_SRCP(w) (((w) >> 18) & 3u)
-#define STRIP_SRCQ(w) (((w) >> 20) & 3u)
-#define STRIP_PACK(p, q, i, k, sell, diag, sp, sq) \
-    ((uint32_t)(p) | ((uint32_t)(q) << 4) | ((uint32_t)(i) << 8) | ((uint32_t)(k) << 11) | ((uint32_t)(sell) << 15) | \
-     ((uint32_t)(diag) << 17) | ((uint32_t)(sp) << 18) | ((uint32_t)(sq) << 20))
-// output element word: first strip (16 bits) | number of consecutive strips summed (8 bits) | slot 0..6 (3 bits)
-#define ELEM_FIRST(w) ((w) & 0xffffu)
-#define ELEM_NCOPY(w) (((w) >> 16) & 0xffu)
-#define ELEM_SLOT(w) (((w) >> 24) & 7u)
-#define ELEM_PACK(first, ncopy, slot) ((uint32_t)(first) | ((uint32_t)(ncopy) << 16) | ((uint32_t)(slot) << 24))
 
 // per-item slab layout (doubles): pair blocks [nbp][36] | b_dir[6nb] | b_corr[6nb] | diag_dir[6nb] | chi | maxh
 __host__ __device__ inline int item_nbp(int nb) { return nb * (nb + 1) / 2; }
@@ -159,8 +134,6 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     const int32_t *imu_valid;    // [10]
     double *imu_out;             // [10][IMU_OUT]
     double *imu_chi_try;         // [10]
-    const uint32_t *strips;      // strip words of all patterns
-    const uint32_t *rows;        // output-element words of all patterns
     const int16_t *pair_slot;    // [n_items][78]
     const int8_t *blk_slot;      // [n_items][12]
     const double *Hprior;        // [171x171]
