@@ -210,6 +210,9 @@ typedef enum {
 } vio_kernel_id;
 /* Wrap every launch of kernel `which` in a hipEvent pair recorded on the context's stream (which < 0: off). */
 vio_status vio_profile_begin(struct vio_ctx *ctx, int32_t which);
+/* The same, but only every `every`-th launch gets its event pair (every >= 1).  An event record drains the stream
+ * (about 7 us each on MI355X), so bench.py samples inside its timed region instead of bracketing every launch. */
+vio_status vio_profile_begin_sampled(struct vio_ctx *ctx, int32_t which, int32_t every);
 /* Synchronise, sum the elapsed times of the recorded pairs, and stop profiling. */
 vio_status vio_profile_end(struct vio_ctx *ctx, double *total_ms, int64_t *launches);
 const char *vio_kernel_name(int32_t which);

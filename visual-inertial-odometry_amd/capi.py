@@ -87,7 +87,7 @@ class VioLib:
                "set_exchange_hook", "bind_exchange_buffers"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
-    HIP_ONLY = ["profile_begin", "profile_end", "kernel_name", "preintegrate"]
+    HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate"]
     KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
@@ -316,6 +316,9 @@ class VioContext:
 
     def profile_begin(self, which):
         self._ck(self.lib.fn["profile_begin"](self.h, C.c_int32(which)), "profile_begin")
+
+    def profile_begin_sampled(self, which, every):
+        self._ck(self.lib.fn["profile_begin_sampled"](self.h, C.c_int32(which), C.c_int32(every)), "profile_begin_sampled")
 
     def profile_end(self):
         ms, n = C.c_double(), C.c_int64()

@@ -134,6 +134,7 @@ struct vio_ctx {
     double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
     DevBuf<unsigned long long> d_dbg;                  // diagnostic builds only
     int prof_which = -1;
+    int prof_every = 1, prof_seen = 0;                 // event pairs around every prof_every-th launch only
     std::vector<hipEvent_t> prof_events;               // pairs
     size_t prof_used = 0;
 };
@@ -437,6 +438,7 @@ struct ProfScope {       // records an event pair around one kernel launch when 
     bool on;
     ProfScope(vio_ctx *ctx, int id) : c(ctx), on(ctx->prof_which == id) {
         if (!on) return;
+        if (c->prof_seen++ % c->prof_every != 0) { on = false; return; }
         if (c->prof_used + 2 > c->prof_events.size()) {
             for (int k = 0; k < 2; ++k) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } c->prof_events.push_back(e); }
         }
@@ -930,10 +932,18 @@ const char *vio_kernel_name(int32_t which) {
     return (which >= 0 && which < VIO_K_COUNT) ? names[which] : "";
 }
 
+vio_status vio_profile_begin_sampled(vio_ctx *c, int32_t which, int32_t every) {
+    if (!c || every < 1) return VIO_ERR_BAD_ARG;
+    vio_status s = vio_profile_begin(c, which);
+    c->prof_every = every;
+    return s;
+}
+
 vio_status vio_profile_begin(vio_ctx *c, int32_t which) {
     if (!c || which >= VIO_K_COUNT) return VIO_ERR_BAD_ARG;
     c->prof_which = which;
     c->prof_used = 0;
+    c->prof_every = 1; c->prof_seen = 0;
     return VIO_OK;
 }
 
