@@ -45,7 +45,7 @@ namespace {
 constexpr int NF = VIO_NUM_FRAMES, PD = VIO_POSE_DIM, PRD = VIO_PRIOR_DIM;
 constexpr int LDS_BUDGET_DOUBLES = 150 * 1024 / 8;     // per linearize workgroup (160 KiB per CU on gfx950)
 constexpr int POSE_SOLVE_TILED = 66 * 272 + 192;   // PS_PACKED of vio_kernels.hip: 66 tiles of 16x17 + the rhs row
-constexpr int POSE_SOLVE_LDS = (POSE_SOLVE_TILED + 176 + 272 + 272 + 192 + 176 + 112 + 176) * 8 + 176 * 4 + 64;
+constexpr int POSE_SOLVE_LDS = (POSE_SOLVE_TILED + 176 + 272 + 272 + 192 + 176 + 112 + 176 + 184) * 8 + 176 * 4 + 64;
 constexpr int IMU_ITEM_LDS_DOUBLES = 450 + 225 + 450 + 32;
 
 template <typename T>

@@ -1059,6 +1059,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     double *sR = sDx + 176;                        // 108 rotations
     double *sB = sR + 112;                         // 176 trial b_prior
     int *sPerm = (int *)(sB + 176);                // 176
+    double *sState = sB + 176 + 88;                // 184: the current pose / speed-bias states
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
@@ -1085,8 +1086,18 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     {
         const double2 *src = reinterpret_cast<const double2 *>(T.Pg);
         double2 *dst = reinterpret_cast<double2 *>(P);
-        for (int e = tid; e < PS_PACKED / 2; e += PS_THREADS) dst[e] = src[e];
-        for (int i = tid; i < n; i += PS_THREADS) sPerm[i] = T.perm[i];
+        // 9 loads per thread, all in flight before the first store (named scalars: a local array ends up in scratch)
+        static_assert((PS_PACKED / 2 + PS_THREADS - 1) / PS_THREADS == 9, "copy below is written for 9 rounds");
+#define PS_LD(q) const double2 v##q = src[min(tid + q * PS_THREADS, PS_PACKED / 2 - 1)];
+#define PS_ST(q) dst[min(tid + q * PS_THREADS, PS_PACKED / 2 - 1)] = v##q;          /* clamped lanes rewrite the last pair */
+        PS_LD(0) PS_LD(1) PS_LD(2) PS_LD(3) PS_LD(4) PS_LD(5) PS_LD(6) PS_LD(7) PS_LD(8)
+        const int pm = (tid < n) ? T.perm[tid] : 0;
+        const double stv = (tid < STATE_STRIDE) ? T.state[cur * STATE_STRIDE + tid] : 0.0;    // for the update at the end
+        PS_ST(0) PS_ST(1) PS_ST(2) PS_ST(3) PS_ST(4) PS_ST(5) PS_ST(6) PS_ST(7) PS_ST(8)
+#undef PS_LD
+#undef PS_ST
+        if (tid < n) sPerm[tid] = pm;
+        if (tid < STATE_STRIDE) sState[tid] = stv;
         if (tid < PS_TS) sI[tid] = (tid / PS_TROW == tid % PS_TROW) ? 1.0 : 0.0;
     }
     __syncthreads();
@@ -1275,22 +1286,24 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     }
     __syncthreads();
 
-    // trial states = current (+) dx   (UpdateStates, problem.cc:456-463)
-    const double *sc = T.state + cur * STATE_STRIDE;
+    // trial states = current (+) dx   (UpdateStates, problem.cc:456-463): in place in the LDS copy of the states
+    // (the pair table below reads them from there, not back from HBM) and out to the trial slot
     double *stt = T.state + trial * STATE_STRIDE;
     if (tid < 12) {
-        const double *p = (tid == 0) ? sc + STATE_EXT : sc + STATE_POSE + 7 * (tid - 1);
+        double *p = (tid == 0) ? sState + STATE_EXT : sState + STATE_POSE + 7 * (tid - 1);
         double *o = (tid == 0) ? stt + STATE_EXT : stt + STATE_POSE + 7 * (tid - 1);
         const double *d = (tid == 0) ? sDx : sDx + 6 + 15 * (tid - 1);
         double tmp[7];
         d_pose_plus(p, d, tmp);
-        for (int k = 0; k < 7; ++k) o[k] = tmp[k];
+        for (int k = 0; k < 7; ++k) { p[k] = tmp[k]; o[k] = tmp[k]; }
     } else if (tid >= 32 && tid < 32 + 99) {
         const int e = tid - 32, f = e / 9, k = e % 9;
-        stt[STATE_SB + e] = sc[STATE_SB + e] + sDx[12 + 15 * f + k];
+        const double v = sState[STATE_SB + e] + sDx[12 + 15 * f + k];
+        sState[STATE_SB + e] = v;
+        stt[STATE_SB + e] = v;
     }
     __syncthreads();
-    d_build_pairtab(stt, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, PS_THREADS);
+    d_build_pairtab(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, PS_THREADS);
 
     // prior: b' = b - H_prior*dx ; err' = -Jt_prior_inv * b'.head(156)   (problem.cc:466-475)
     if (T.has_prior) {
