@@ -10,10 +10,11 @@ include/vio_backend.h, enqueued back to back with no host round trip.  Inputs ar
 timed region starts.
 
 N = 1: the 11-frame / 20 000-landmark / 80 000-observation synthetic window (BASELINE.json configs[2]).
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL); every rank holds a 20 000-landmark
-       shard of an (N x 20 000)-landmark window; one all-reduce of the 72x72 reduced visual system per
-       iteration plus one 2-scalar all-reduce per step test.  Weak scaling: `value`
-       counts shard-iterations per second over all ranks.
+N > 1: one process per GPU (torch.distributed, backend nccl == RCCL, for the rendezvous, the barriers and the
+       128-byte communicator id); every rank holds a 20 000-landmark shard of an (N x 20 000)-landmark window;
+       per iteration the library itself issues one RCCL all-reduce of the 72x72 reduced visual system and one
+       of the 2 step scalars on its stream.  Weak scaling: `value` counts
+       shard-iterations per second over all ranks.
 
 The JSON line also carries
   roofline      achieved = algorithmic bytes per launch / measured launch duration of the dominant kernel
@@ -98,9 +99,17 @@ def main():
     n_per_gpu, k_obs = args.landmarks, args.obs_per_landmark
     full = vio.synth.make_window(n_per_gpu * world, seed=42, obs_per_landmark=k_obs)
 
-    stream = torch.cuda.current_stream()
-    sb = vio.sharded.ShardedBackend(hip, full, rank, world, dist=dist, torch_device="cuda",
-                                    ctx_kwargs=dict(device=local_rank, stream=stream.cuda_stream))
+    # N > 1: the library all-reduces with RCCL itself on its own stream (VIO_EXCHANGE=hook selects the
+    # torch.distributed hook instead, which has to share torch's current stream)
+    kw = dict(device=local_rank)
+    if os.environ.get("VIO_EXCHANGE", "native") == "hook":
+        kw["stream"] = torch.cuda.current_stream().cuda_stream
+    force = os.environ.get("VIO_BENCH_FORCE_EXCHANGE") == "1"      # diagnostic: run the sharded kernel sequence on one rank
+    if force and dist is None and os.environ.get("VIO_EXCHANGE", "native") == "hook":
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    sb = vio.sharded.ShardedBackend(hip, full, rank, world, dist=dist, torch_device="cuda", ctx_kwargs=kw, force_hook=force)
     ctx, w = sb.ctx, sb.shard
     n, m = w.n_landmarks, w.n_observations
 
@@ -197,12 +206,14 @@ def main():
                                    % (n_per_gpu, k_obs),
                        "landmarks_per_gpu": n_per_gpu, "observations_per_gpu": m, "landmarks_total": n_per_gpu * world,
                        "lambda": lam, "parallelism": "landmark-sharded x%d, all-reduce of the 72x72 reduced system" % world
-                       if world > 1 else "single GPU"},
+                       if world > 1 else "single GPU", "exchange": sb.exchange},
             "final_chi2": chi2,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL's version banner sits in C stdio's buffer: keep the JSON line last
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -198,6 +198,17 @@ vio_status vio_exchange_buffers(struct vio_ctx *ctx, void **reduced_system, int6
 typedef int (*vio_exchange_fn)(void *user, int which);
 vio_status vio_set_exchange_hook(struct vio_ctx *ctx, vio_exchange_fn fn, void *user);
 
+/* Native exchange: the library all-reduces its exchange buffers itself with RCCL (xGMI inside a node), in stream order
+ * on its own stream, with no host callback in the loop.  RCCL is dlopen'ed (librccl.so of the process, e.g. the one
+ * PyTorch loaded); the caller only distributes the 128-byte id of rank 0 to all ranks (torch.distributed / MPI /
+ * a socket) and every rank calls vio_comm_init with it.  Replaces the hook when both are set.
+ *   vio_comm_unique_id   ncclGetUniqueId, rank 0 only: fills id128[128]
+ *   vio_comm_init        ncclCommInitRank on the context's device: collective over all `nranks` processes
+ *   vio_comm_destroy     ncclCommDestroy (also done by vio_destroy) */
+vio_status vio_comm_unique_id(void *id128);
+vio_status vio_comm_init(struct vio_ctx *ctx, const void *id128, int32_t rank, int32_t nranks);
+vio_status vio_comm_destroy(struct vio_ctx *ctx);
+
 /* Optional: make the library use caller-owned device memory for the two exchange buffers (e.g. torch tensors,
  * so that torch.distributed can all-reduce them in place).  reduced must hold >= the count reported by
  * vio_exchange_buffers + 8 doubles, scalars >= 8 doubles.  NULL restores the library's own buffer. */

@@ -48,8 +48,9 @@ def test_oracle_exports_the_same_surface(vio, oracle_lib):
         if f == "vio_preintegrate":
             assert oracle_lib.has("preintegrate_abi")
             continue
-        if f in ("vio_profile_begin", "vio_profile_begin_sampled", "vio_profile_end", "vio_kernel_name"):
-            continue        # measurement hooks exist on the HIP library only
+        if f in ("vio_profile_begin", "vio_profile_begin_sampled", "vio_profile_end", "vio_kernel_name",
+                 "vio_comm_unique_id", "vio_comm_init", "vio_comm_destroy"):
+            continue        # measurement hooks and the native RCCL exchange exist on the HIP library only
         assert oracle_lib.has(f[len("vio_"):]), f
 
 

@@ -305,8 +305,9 @@ def test_exchange_hook_path_with_rccl_on_one_rank(vio, hip_lib):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         w = vio.synth.make_window(700, seed=23, ragged=True)
-        sb = vio.sharded.ShardedBackend(hip_lib, w, 0, 1, dist=dist, torch_device="cuda", force_hook=True,
+        sb = vio.sharded.ShardedBackend(hip_lib, w, 0, 1, dist=dist, torch_device="cuda", force_hook=True, exchange="hook",
                                         ctx_kwargs=dict(stream=torch.cuda.current_stream().cuda_stream))
+        assert sb.exchange == "hook"
         rep = sb.solve(10)
         ps, ss, _ = sb.ctx.get_window()
         ls = sb.gather_landmarks()
@@ -324,3 +325,29 @@ def test_exchange_hook_path_with_rccl_on_one_rank(vio, hip_lib):
         assert np.isfinite(sb.ctx.chi2())
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_exchange_on_one_rank(vio, hip_lib):
+    """The default multi-GPU exchange: the library dlopens RCCL, builds its own communicator from a 128-byte id
+    (vio_comm_unique_id / vio_comm_init) and all-reduces the exchange buffers on its own stream.  One rank here, so
+    every sum is an identity and the LM solve must equal the unsharded one bit for bit; the sharded kernel sequence
+    (k_step_sum + exchange + k_lm_decide) is the one that runs."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    w = vio.synth.make_window(700, seed=29, ragged=True)
+    sb = vio.sharded.ShardedBackend(hip_lib, w, 0, 1, dist=None, torch_device="cuda", force_hook=True, exchange="native")
+    assert sb.exchange == "native"
+    rep = sb.solve(10)
+    ps, ss, _ = sb.ctx.get_window()
+    ref = hip_lib.context()
+    ref.load(w)
+    rr = ref.solve(10)
+    pr, sr, _ = ref.get_window()
+    assert rep.iterations == rr.iterations and rep.trials == rr.trials and rep.final_chi2 == rr.final_chi2
+    np.testing.assert_array_equal(ps, pr)
+    np.testing.assert_array_equal(ss, sr)
+    np.testing.assert_array_equal(sb.ctx.get_landmarks(), ref.get_landmarks())
+    for _ in range(5):
+        sb.gn_iteration(5e5)
+    sb.ctx.synchronize()
+    assert np.isfinite(sb.ctx.chi2())
+    sb.ctx.comm_destroy()

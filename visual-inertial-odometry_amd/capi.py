@@ -87,7 +87,8 @@ class VioLib:
                "set_exchange_hook", "bind_exchange_buffers"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
-    HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate"]
+    HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
+                "comm_unique_id", "comm_init", "comm_destroy"]
     KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
@@ -123,6 +124,14 @@ class VioLib:
         if st != 0:
             raise VioError(st, self.prefix + "preintegrate")
         return out
+
+    def comm_unique_id(self):
+        """ncclGetUniqueId through the ABI (rank 0): 128 bytes to hand to every rank's VioContext.comm_init."""
+        buf = (C.c_char * 128)()
+        st = self.fn["comm_unique_id"](buf)
+        if st != 0:
+            raise VioError(st, self.prefix + "comm_unique_id", "(is librccl.so loadable?)")
+        return bytes(buf.raw)
 
     def has(self, name):
         return hasattr(self.dll, self.prefix + name)
@@ -313,6 +322,14 @@ class VioContext:
         self._hook = proto(lambda user, which: int(fn(which))) if fn is not None else None
         self._ck(self.lib.fn["set_exchange_hook"](self.h, self._hook if self._hook else C.cast(None, proto), None),
                  "set_exchange_hook")
+
+    def comm_init(self, id128, rank, nranks):
+        """Native RCCL exchange: id128 = the 128 bytes of rank 0's VioLib.comm_unique_id(), same on every rank."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        self._ck(self.lib.fn["comm_init"](self.h, buf, C.c_int32(rank), C.c_int32(nranks)), "comm_init")
+
+    def comm_destroy(self):
+        self._ck(self.lib.fn["comm_destroy"](self.h), "comm_destroy")
 
     def profile_begin(self, which):
         self._ck(self.lib.fn["profile_begin"](self.h, C.c_int32(which)), "profile_begin")

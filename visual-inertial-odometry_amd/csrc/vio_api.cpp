@@ -4,6 +4,7 @@
 // (VM/src/estimator.cpp:693-1073) against Problem (VM/src/backend/problem.cc); see the header for the
 // per-function citations.  No CPU fallback: every compute entry point launches HIP kernels and fails with
 // VIO_ERR_HIP / VIO_ERR_NO_DEVICE when it cannot.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -129,6 +130,7 @@ struct vio_ctx {
     DevBuf<LmState> d_lm;
     LmState h_lm;
     vio_exchange_fn hook = nullptr;
+    void *comm = nullptr;                              // ncclComm_t of the native exchange (vio_comm_init)
     void *hook_user = nullptr;
     double hessian_ms = 0;
     double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
@@ -451,7 +453,56 @@ struct ProfScope {       // records an event pair around one kernel launch when 
     }
 };
 
+// ---- RCCL, resolved at run time: the library has no link-time dependency on it -------------------------------
+struct RcclId128 { char b[128]; };          // ncclUniqueId: passed by value to ncclCommInitRank
+struct RcclApi {
+    void *lib = nullptr;
+    int (*GetUniqueId)(RcclId128 *id) = nullptr;
+    int (*CommInitRank)(void **comm, int nranks, RcclId128 id, int rank) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+RcclApi *rccl_api(std::string &err) {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) { if (!api.lib) err = "librccl.so could not be loaded"; return api.lib ? &api : nullptr; }
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) { err = std::string("dlopen librccl.so: ") + dlerror(); return nullptr; }
+    *(void **)&api.GetUniqueId = dlsym(api.lib, "ncclGetUniqueId");
+    *(void **)&api.CommInitRank = dlsym(api.lib, "ncclCommInitRank");
+    *(void **)&api.CommDestroy = dlsym(api.lib, "ncclCommDestroy");
+    *(void **)&api.AllReduce = dlsym(api.lib, "ncclAllReduce");
+    *(void **)&api.GetErrorString = dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) {
+        err = "librccl.so lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllReduce";
+        dlclose(api.lib); api.lib = nullptr;
+        return nullptr;
+    }
+    return &api;
+}
+
+inline bool sharded(const vio_ctx *c) { return c->hook != nullptr || c->comm != nullptr; }
+
+// which == 0: reduced visual system (sum), 1: the two step scalars (sum), 2: max |h_ll| (max, step buffer slot 2)
 vio_status run_exchange(vio_ctx *c, int which) {
+    if (c->comm) {
+        std::string err;
+        RcclApi *api = rccl_api(err);
+        if (!api) return fail(c, VIO_ERR_HIP, err);
+        double *vis = c->ext_vis ? c->ext_vis : c->d_vis.p;
+        double *step = c->ext_step ? c->ext_step : c->d_step_tot.p;
+        double *buf = which == 0 ? vis : (which == 1 ? step : step + 2);
+        const size_t count = which == 0 ? (size_t)VIS_MAXH : (which == 1 ? 2 : 1);
+        const int rc = api->AllReduce(buf, buf, count, /*ncclDouble*/ 8, which == 2 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, c->comm, c->stream);
+        if (rc != 0) return fail(c, VIO_ERR_HIP, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
+        return VIO_OK;
+    }
     if (!c->hook) return VIO_OK;
     if (c->hook(c->hook_user, which) != 0) return fail(c, VIO_ERR_HIP, "exchange hook failed");
     return VIO_OK;
@@ -475,7 +526,7 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl) {
 // ComputeLambdaInitLM; with shards, max |h_ll| is max-reduced through the hook (which == 2) in step_scalars[2]
 vio_status enqueue_init_lm(vio_ctx *c, const DeviceTables &T, int max_iter) {
     const double *src = T.vis + VIS_MAXH;
-    if (c->hook) {
+    if (sharded(c)) {
         HIPCHK(hipMemcpyAsync(T.step_tot + 2, T.vis + VIS_MAXH, 8, hipMemcpyDeviceToDevice, c->stream));
         VIOCHK(run_exchange(c, 2));
         src = T.step_tot + 2;
@@ -489,7 +540,7 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode) {
     DeviceTables T = make_tables(c, pl);
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, c->stream); }
-    if (c->hook) {
+    if (sharded(c)) {
         vio_launch_step_sum(T, 0, c->stream);
         VIOCHK(run_exchange(c, 1));
         ProfScope ps(c, VIO_K_LM_DECIDE);
@@ -552,6 +603,7 @@ void vio_destroy(vio_ctx *c) {
     if (!c) return;
     hipSetDevice(c->cfg.device);
     hipStreamSynchronize(c->stream);
+    vio_comm_destroy(c);
     c->solve_plan.release(); c->marg_plan.release();
     c->d_state.release(); c->d_pairtab.release(); c->d_vis.release(); c->d_pre.release(); c->d_imu_out.release();
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
@@ -686,7 +738,7 @@ vio_status vio_chi2(vio_ctx *c, double *chi2) {
     // the chi2 kernels read the pair table of the current state; after a stepwise update it is the trial table
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
     vio_launch_backsub(T, 1, c->stream);
-    if (c->hook) { vio_launch_step_sum(T, 2, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 2, 0, c->stream); }
+    if (sharded(c)) { vio_launch_step_sum(T, 2, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 2, 0, c->stream); }
     else vio_launch_lm_decide(T, 2, 1, c->stream);
     VIOCHK(read_lm(c));
     *chi2 = c->h_lm.chi_try;
@@ -699,7 +751,7 @@ vio_status vio_eval_step(vio_ctx *c, int32_t *accepted, double *chi2, double *la
     DeviceTables T = make_tables(c, pl);
     // the decide kernel expects the trial copy to be "the other one"
     if (c->stepwise_updated) vio_launch_flip(c->d_lm.p, c->stream);
-    if (c->hook) { vio_launch_step_sum(T, 0, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 0, 0, c->stream); }
+    if (sharded(c)) { vio_launch_step_sum(T, 0, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 0, 0, c->stream); }
     else vio_launch_lm_decide(T, 0, 1, c->stream);
     VIOCHK(read_lm(c));
     const bool ok = c->h_lm.accepted != 0;
@@ -896,6 +948,40 @@ vio_status vio_set_exchange_hook(vio_ctx *c, vio_exchange_fn fn, void *user) {
     if (!c) return VIO_ERR_BAD_ARG;
     c->hook = fn;
     c->hook_user = user;
+    return VIO_OK;
+}
+
+vio_status vio_comm_unique_id(void *id128) {
+    if (!id128) return VIO_ERR_BAD_ARG;
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return VIO_ERR_HIP;
+    return api->GetUniqueId((RcclId128 *)id128) == 0 ? VIO_OK : VIO_ERR_HIP;
+}
+
+vio_status vio_comm_destroy(vio_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (c->comm) {
+        std::string err;
+        if (RcclApi *api = rccl_api(err)) { hipStreamSynchronize(c->stream); api->CommDestroy(c->comm); }
+        c->comm = nullptr;
+    }
+    return VIO_OK;
+}
+
+vio_status vio_comm_init(vio_ctx *c, const void *id128, int32_t rank, int32_t nranks) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return VIO_ERR_BAD_ARG;
+    if (rank != c->cfg.shard_rank || nranks != c->cfg.shard_count) return fail(c, VIO_ERR_BAD_ARG, "vio_comm_init: rank/nranks differ from the context's shard_rank/shard_count");
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(c, VIO_ERR_HIP, err);
+    vio_comm_destroy(c);
+    HIPCHK(hipSetDevice(c->cfg.device));
+    RcclId128 id;
+    std::memcpy(&id, id128, sizeof(id));
+    const int rc = api->CommInitRank(&c->comm, nranks, id, rank);
+    if (rc != 0) { c->comm = nullptr; return fail(c, VIO_ERR_HIP, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error")); }
+    c->linearized = false;
     return VIO_OK;
 }
 

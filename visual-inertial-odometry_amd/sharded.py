@@ -5,8 +5,10 @@ speed-biases, extrinsic, pre-integrations and prior are replicated.  Per lineari
 packed reduced visual system (72x72 H, reduced b, direct b, direct diagonal, chi2: 5401 fp64 = 43 KB) and per
 trial step one all-reduce of two scalars (chi2 of the trial state, landmark part of the gain-ratio
 denominator); every rank then runs the identical damped LDLT and updates its own landmarks.  The collective is
-torch.distributed (backend nccl == RCCL over xGMI on the GPU box, gloo in the CPU tests); the library calls back
-through vio_set_exchange_hook at the two points of the LM loop where the exchange belongs.
+RCCL over xGMI on the GPU box: by default the library calls ncclAllReduce itself on its own stream (vio_comm_init; the
+communicator id is broadcast once through torch.distributed).  The portable alternative — and the gloo path of the CPU
+tests — is vio_set_exchange_hook: the library calls back at the two points of the LM loop where the exchange belongs
+and the hook runs torch.distributed.all_reduce on the bound exchange buffers.
 """
 import numpy as np
 
@@ -14,7 +16,12 @@ from . import synth
 
 
 class ShardedBackend:
-    def __init__(self, lib, window, rank, world, dist=None, torch_device="cuda", ctx_kwargs=None, force_hook=False):
+    def __init__(self, lib, window, rank, world, dist=None, torch_device="cuda", ctx_kwargs=None, force_hook=False,
+                 exchange=None):
+        """exchange: "native" — the library all-reduces with RCCL itself, in stream order, no Python in the loop
+        (HIP library on GPUs; the 128-byte communicator id travels through torch.distributed once);
+        "hook" — torch.distributed.all_reduce from the library's exchange hook (any backend: gloo in the CPU tests).
+        Default: native when the library exports it and the device is a GPU, unless VIO_EXCHANGE=hook."""
         import torch
         self.torch = torch
         self.dist = dist
@@ -31,7 +38,18 @@ class ShardedBackend:
         self.sca = torch.zeros(8, dtype=torch.float64, device=torch_device)
         self.ctx.bind_exchange_buffers(self.red.data_ptr(), self.sca.data_ptr())
         self._views = (self.red[:self.n_red], self.sca[:self.n_sc], self.sca[2:3])
-        if world > 1 or force_hook:       # force_hook: exercise the exchange path on a single rank (tests)
+        if exchange is None:
+            import os
+            exchange = os.environ.get("VIO_EXCHANGE", "native" if (lib.has("comm_init") and str(torch_device).startswith("cuda")) else "hook")
+        self.exchange = exchange if (world > 1 or force_hook) else "none"
+        if self.exchange == "native":
+            idt = torch.zeros(128, dtype=torch.uint8, device=torch_device)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(lib.comm_unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(idt, src=0)
+            self.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        elif self.exchange == "hook":     # force_hook: exercise the exchange path on a single rank (tests)
             self.ctx.set_exchange_hook(self._exchange)
 
     def _exchange(self, which):
