@@ -45,8 +45,8 @@
 #define VIS_BDIR (VIS_BRED + VIO_CAM_DIM)
 #define VIS_DIAG (VIS_BDIR + VIO_CAM_DIM)
 #define VIS_CHI (VIS_DIAG + VIO_CAM_DIM)
-#define VIS_MAXH (VIS_CHI + 1)
-#define VIS_N (VIS_MAXH + 1 + 6)
+#define VIS_MAXH (VIS_CHI + 3)          /* two slots after VIS_CHI are reserved (the HIP library's GN step scalars) */
+#define VIS_N (VIS_MAXH + 1 + 4)
 
 #define NF VIO_NUM_FRAMES
 #define PD VIO_POSE_DIM

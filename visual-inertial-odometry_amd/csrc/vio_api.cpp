@@ -34,6 +34,7 @@ void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s);
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s);
+void vio_launch_gn_finish(const DeviceTables &T, hipStream_t s);
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s);
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
@@ -131,6 +132,7 @@ struct vio_ctx {
     LmState h_lm;
     vio_exchange_fn hook = nullptr;
     void *comm = nullptr;                              // ncclComm_t of the native exchange (vio_comm_init)
+    bool gn_pending = false;                           // sharded GN mode: the last step's landmark sums ride with the next all-reduce
     void *hook_user = nullptr;
     double hessian_ms = 0;
     double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
@@ -356,6 +358,7 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     T.has_prior = c->has_prior; T.add_imu_prior = 1; T.natural_hs = (pl.marg || c->want_natural_hs) ? 1 : 0;
     T.Hs = c->d_Hs.p; T.Pg = c->d_Pg.p; T.perm = c->d_perm.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
+    T.gn_flags = 0;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
 #ifdef VIO_STAMPS
@@ -365,7 +368,22 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     return T;
 }
 
+vio_status run_exchange(vio_ctx *c, int which);
+DeviceTables make_tables(vio_ctx *c, Plan &pl);
+
+// sharded GN mode leaves the last step's landmark sums un-reduced until the next linearisation's all-reduce; anyone
+// who wants LmState before that gets them reduced here (a collective: every rank reads at the same point)
+vio_status flush_gn_pending(vio_ctx *c) {
+    if (!c->gn_pending || !c->active) return VIO_OK;
+    VIOCHK(run_exchange(c, 3));
+    DeviceTables T = make_tables(c, *c->active);
+    vio_launch_gn_finish(T, c->stream);
+    c->gn_pending = false;
+    return VIO_OK;
+}
+
 vio_status read_lm(vio_ctx *c) {
+    VIOCHK(flush_gn_pending(c));
     HIPCHK(hipMemcpyAsync(&c->h_lm, c->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return VIO_OK;
@@ -489,7 +507,8 @@ RcclApi *rccl_api(std::string &err) {
 
 inline bool sharded(const vio_ctx *c) { return c->hook != nullptr || c->comm != nullptr; }
 
-// which == 0: reduced visual system (sum), 1: the two step scalars (sum), 2: max |h_ll| (max, step buffer slot 2)
+// which == 0: reduced visual system (sum), 1: the two step scalars (sum), 2: max |h_ll| (max, step buffer slot 2),
+// 3 (native only): the two deferred GN step scalars parked in vis[VIS_STEP..] (sum)
 vio_status run_exchange(vio_ctx *c, int which) {
     if (c->comm) {
         std::string err;
@@ -497,8 +516,8 @@ vio_status run_exchange(vio_ctx *c, int which) {
         if (!api) return fail(c, VIO_ERR_HIP, err);
         double *vis = c->ext_vis ? c->ext_vis : c->d_vis.p;
         double *step = c->ext_step ? c->ext_step : c->d_step_tot.p;
-        double *buf = which == 0 ? vis : (which == 1 ? step : step + 2);
-        const size_t count = which == 0 ? (size_t)VIS_MAXH : (which == 1 ? 2 : 1);
+        double *buf = which == 0 ? vis : (which == 1 ? step : (which == 2 ? step + 2 : vis + VIS_STEP));
+        const size_t count = which == 0 ? (size_t)VIS_MAXH : (which == 2 ? 1 : 2);
         const int rc = api->AllReduce(buf, buf, count, /*ncclDouble*/ 8, which == 2 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, c->comm, c->stream);
         if (rc != 0) return fail(c, VIO_ERR_HIP, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
         return VIO_OK;
@@ -516,6 +535,7 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl) {
     ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis};
     { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
     VIOCHK(run_exchange(c, 0));
+    if (c->gn_pending) { T.gn_flags = 2; c->gn_pending = false; }       // the previous GN step's sums just came back with vis
     { ProfScope ps(c, VIO_K_ASSEMBLE); vio_launch_assemble(T, c->stream); }
     HIPCHK(hipGetLastError());
     c->linearized = true;
@@ -541,10 +561,15 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode) {
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, c->stream); }
     if (sharded(c)) {
+        // GN mode with the native exchange: a step is always accepted, nothing downstream waits for chi2, so the two
+        // landmark sums are not all-reduced here but ride along with the next linearisation's all-reduce
+        const bool defer = mode == 1 && c->comm != nullptr;
+        if (defer) T.gn_flags = 1;
         vio_launch_step_sum(T, 0, c->stream);
-        VIOCHK(run_exchange(c, 1));
+        if (!defer) VIOCHK(run_exchange(c, 1));
         ProfScope ps(c, VIO_K_LM_DECIDE);
         vio_launch_lm_decide(T, mode, 0, c->stream);
+        if (defer) c->gn_pending = true;
     } else {
         ProfScope ps(c, VIO_K_LM_DECIDE);
         vio_launch_lm_decide(T, mode, 1, c->stream);

@@ -852,6 +852,18 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int i, in
     return bred + extra;
 }
 
+// Sharded GN mode: the landmark sums of the previous step (chi2, gain-ratio scale) have just come back summed over
+// the shards in vis[VIS_STEP..]; finish what k_lm_decide left open.
+__device__ __forceinline__ void d_gn_finish(const DeviceTables &T) {
+    LmState *lm = T.lm;
+    const double chi = 0.5 * ((T.vis[VIS_STEP] + lm->gn_chi_imu) + lm->gn_prior);
+    const double scale = 0.5 * (T.vis[VIS_STEP + 1] + lm->gn_scale_p) + 1e-6;
+    lm->chi_try = chi;
+    lm->chi = chi;
+    lm->scale = scale;
+    lm->rho = (lm->gn_chi_prev - chi) / scale;
+}
+
 // Workgroup b < 171: row b of H_pp_schur_ in natural order (getters, marginalisation) and, for the solve, row b of
 // the PERMUTED, tiled lower triangle Pg: the pivot order of Eigen's LDLT is the order of |diag + lambda|, which for
 // lambda >= 0 and a non-negative diagonal does not depend on lambda, so it is fixed here once per linearisation
@@ -907,6 +919,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
             sDg[t] = d_rhs_entries(T, t, cur);
             T.perm[t] = sPerm[t];
         }
+        if (t == 191 && (T.gn_flags & 2)) d_gn_finish(T);
         __syncthreads();                        // the 192 remaining threads, all of them
         if (t < PS_NP) T.Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
     }
@@ -1432,8 +1445,13 @@ __global__ __launch_bounds__(256) void k_step_sum(DeviceTables T, int mode) {
     for (int e = tid; e < T.n_items; e += 256) { c += part[2 * e + STEP_CHI]; s += part[2 * e + STEP_SCALE]; }
     const double ct = d_block_sum<256>(c, s0, tid);
     const double st = d_block_sum<256>(s, s0, tid);
-    if (tid == 0) { T.step_tot[0] = ct; T.step_tot[1] = st; }
+    if (tid == 0) {
+        T.step_tot[0] = ct; T.step_tot[1] = st;
+        if (T.gn_flags & 1) { T.vis[VIS_STEP] = ct; T.vis[VIS_STEP + 1] = st; }     // ride along with the next all-reduce
+    }
 }
+
+__global__ void k_gn_finish(DeviceTables T) { if (threadIdx.x == 0) d_gn_finish(T); }
 
 __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int sum_local) {
     __shared__ double s0[256];
@@ -1466,6 +1484,12 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int
     const double tempChi = 0.5 * total;
     lm->chi_try = tempChi;
     if (mode == 2) return;
+    if (T.gn_flags & 1) {           // sharded GN step: the landmark sums are still local; k_assemble finishes (d_gn_finish)
+        lm->gn_chi_imu = chi_imu;
+        lm->gn_prior = T.has_prior ? sqrt(en2) : 0.0;
+        lm->gn_scale_p = scale_p;
+        lm->gn_chi_prev = lm->chi;
+    }
     double scale = 0.5 * (T.step_tot[1] + scale_p);
     scale += 1e-6;
     const double rho = (lm->chi - tempChi) / scale;
@@ -1551,6 +1575,7 @@ void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s) {
     hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(64), 0, s, T, mode);
 }
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s) { hipLaunchKernelGGL(k_step_sum, dim3(1), dim3(256), 0, s, T, mode); }
+void vio_launch_gn_finish(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_gn_finish, dim3(1), dim3(64), 0, s, T); }
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(256), 0, s, T, mode, sum_local);
 }
