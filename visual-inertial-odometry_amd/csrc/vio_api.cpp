@@ -564,12 +564,17 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode) {
         // GN mode with the native exchange: a step is always accepted, nothing downstream waits for chi2, so the two
         // landmark sums are not all-reduced here but ride along with the next linearisation's all-reduce
         const bool defer = mode == 1 && c->comm != nullptr;
-        if (defer) T.gn_flags = 1;
-        vio_launch_step_sum(T, 0, c->stream);
-        if (!defer) VIOCHK(run_exchange(c, 1));
-        ProfScope ps(c, VIO_K_LM_DECIDE);
-        vio_launch_lm_decide(T, mode, 0, c->stream);
-        if (defer) c->gn_pending = true;
+        if (defer) {
+            T.gn_flags = 1;             // k_lm_decide sums the partials itself and parks the sums in vis[VIS_STEP..]
+            ProfScope ps(c, VIO_K_LM_DECIDE);
+            vio_launch_lm_decide(T, mode, 1, c->stream);
+            c->gn_pending = true;
+        } else {
+            vio_launch_step_sum(T, 0, c->stream);
+            VIOCHK(run_exchange(c, 1));
+            ProfScope ps(c, VIO_K_LM_DECIDE);
+            vio_launch_lm_decide(T, mode, 0, c->stream);
+        }
     } else {
         ProfScope ps(c, VIO_K_LM_DECIDE);
         vio_launch_lm_decide(T, mode, 1, c->stream);

@@ -1463,7 +1463,10 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int
         for (int e = tid; e < T.n_items; e += 256) { c += part[2 * e + STEP_CHI]; s += part[2 * e + STEP_SCALE]; }
         const double ct = d_block_sum<256>(c, s0, tid);
         const double st = d_block_sum<256>(s, s0, tid);
-        if (tid == 0) { T.step_tot[0] = ct; T.step_tot[1] = st; }
+        if (tid == 0) {
+            T.step_tot[0] = ct; T.step_tot[1] = st;
+            if (T.gn_flags & 1) { T.vis[VIS_STEP] = ct; T.vis[VIS_STEP + 1] = st; }     // ride along with the next all-reduce
+        }
         __syncthreads();
     }
     const int cur = lm->cur;
