@@ -120,7 +120,7 @@ struct vio_ctx {
     double gn_lambda = -1.0;
     bool want_natural_hs = false;              // set by vio_get_schur_system: re-run k_assemble with the natural-order copy
     bool natural_hs_valid = false;
-    int g_max = 48;                            // landmarks per item (tunable: VIO_G_MAX; 48 measured best at 20k landmarks, k_backsub needs <= 64)
+    int g_max = 0;                             // landmarks per item; 0 = automatic (VIO_G_MAX overrides; <= 128: k_backsub has one thread per landmark)
     Plan solve_plan, marg_plan;
     Plan *active = nullptr;
     // device buffers independent of the topology
@@ -177,7 +177,7 @@ void build_pattern_tables(Pattern &pt, int g_max) {
     }
     for (int k = 0; k < K; ++k) kof[pt.tslot[k]] = k;
     pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
-    int G = std::max(1, std::min(g_max, 256 / K));
+    int G = std::max(1, std::min(g_max, 1024 / K));          // one thread per observation in k_linearize's phase 1
     while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext) > LDS_BUDGET_DOUBLES) --G;
     pt.G = G;
     pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
@@ -233,7 +233,12 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
                 pt.target[k] = key[1 + k];
                 for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + key[1 + k]) pt.tslot[k] = (int8_t)q;
             }
-            build_pattern_tables(pt, c->g_max);
+            // Items per window: one k_linearize workgroup each, one workgroup per CU (LDS).  48 landmarks per item is
+            // the fastest workgroup; when that would need a second round on the 256 CUs, bigger items that still fit one
+            // round win (20 000 landmarks: 250 items of 80 instead of 417 of 48 - same kernel time, shorter k_reduce lists).
+            const int n_lm_total = (int)N;
+            const int g_auto = std::min(96, std::max(48, (n_lm_total + 247) / 248));
+            build_pattern_tables(pt, c->g_max > 0 ? c->g_max : g_auto);
             pl.patterns.push_back(pt);
         } else id = itp->second;
         lm_pattern[l] = id;
@@ -621,7 +626,7 @@ vio_status vio_create(const vio_config *cfg, vio_ctx **out) {
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) c->imu_valid[k] = false;
     c->h_pre.assign(VIO_WINDOW_SIZE * PRE_STRIDE, 0.0);
     c->h_Hprior.assign(PD * PD, 0.0); c->h_bprior.assign(PD, 0.0); c->h_errprior.assign(PRD, 0.0); c->h_Jtinv.assign(PRD * PRD, 0.0);
-    if (const char *e = std::getenv("VIO_G_MAX")) { int v = std::atoi(e); if (v >= 1 && v <= 64) c->g_max = v; }
+    if (const char *e = std::getenv("VIO_G_MAX")) { int v = std::atoi(e); if (v >= 1 && v <= 128) c->g_max = v; }
     if (vio_set_kernel_attributes() != 0) { c->err = "hipFuncSetAttribute failed"; }
     vio_status s = alloc_fixed(c);
     if (s != VIO_OK) { vio_destroy(c); return s; }

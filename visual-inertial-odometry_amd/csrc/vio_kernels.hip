@@ -1343,7 +1343,8 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 // chi2 of the trial state, landmark part of the gain-ratio denominator.  mode 1: chi2 of the CURRENT state only.
 // Blocks >= n_items evaluate the IMU chi2.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_backsub(DeviceTables T, int mode) {
+#define BS_THREADS 128      // one thread per landmark of the item (G <= 128)
+__global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const LmState *lm = T.lm;
     const int cur = lm->cur;
@@ -1379,7 +1380,7 @@ __global__ __launch_bounds__(64) void k_backsub(DeviceTables T, int mode) {
     const ItemDesc &it = sIt;
     const int G = it.G, K = it.K, nb = it.nb;
     const double *ptab = T.pairtab + which * PAIRTAB_STRIDE;
-    for (int e = lane; e < K * 12; e += 64) {
+    for (int e = lane; e < K * 12; e += BS_THREADS) {
         const int k = e / 12, o = e % 12;
         sPairCD[e] = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + PAIR_C + o];     // C (9) then d (3) are adjacent
     }
@@ -1424,11 +1425,19 @@ __global__ __launch_bounds__(64) void k_backsub(DeviceTables T, int mode) {
             chi += (T.loss_type == 0) ? e2 : rho0;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { chi += __shfl_xor(chi, o); scale += __shfl_xor(scale, o); }
+    // fixed order: DPP sum inside each wave, then wave 0 + wave 1
+    __shared__ double sSum[2 * (BS_THREADS / 64)];
+    chi = d_wave_sum_to_lane63(chi);
+    scale = d_wave_sum_to_lane63(scale);
+    if ((lane & 63) == 63) { sSum[2 * (lane >> 6)] = chi; sSum[2 * (lane >> 6) + 1] = scale; }
+    __syncthreads();
     if (lane == 0) {
+        double c = 0.0, sc = 0.0;
+#pragma unroll
+        for (int w = 0; w < BS_THREADS / 64; ++w) { c += sSum[2 * w]; sc += sSum[2 * w + 1]; }
         // vio_chi2 (mode 1) has partials of its own so that it never disturbs a pending step test
         double *part = (mode == 1) ? T.chi_part : T.step_part;
-        part[2 * b + STEP_CHI] = chi; part[2 * b + STEP_SCALE] = scale;
+        part[2 * b + STEP_CHI] = c; part[2 * b + STEP_SCALE] = sc;
     }
 }
 
@@ -1575,7 +1584,7 @@ void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t 
     hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
 }
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(64), 0, s, T, mode);
+    hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(BS_THREADS), 0, s, T, mode);
 }
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s) { hipLaunchKernelGGL(k_step_sum, dim3(1), dim3(256), 0, s, T, mode); }
 void vio_launch_gn_finish(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_gn_finish, dim3(1), dim3(64), 0, s, T); }
