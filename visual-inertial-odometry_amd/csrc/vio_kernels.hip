@@ -360,11 +360,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         return;
     }
     __shared__ ItemDesc sIt;        // kept in LDS: its small arrays are indexed at run time
+    const int cur = T.lm->cur;      // requested together with the descriptor: both are cold after the kernel boundary
     if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
     __syncthreads();
     const ItemDesc &it = sIt;
     STAMP(T, 0);
-    const int cur = T.lm->cur;
     const int G = it.G, K = it.K, nb = it.nb, use_ext = it.use_ext;
     const int RROW = lin_rrow(use_ext), RAUX = lin_raux(use_ext), PLANE = lin_plane(G, use_ext), LREC = lin_lrec(nb);
     const int offH = 0, offT = 12, offE = 24;                       // inside a row record
@@ -699,35 +699,48 @@ struct ReduceTables {
 };
 
 #define RED_THREADS 1024
-#define RED_PARTS (RED_THREADS / 64)
 
 __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
-    // each of the 4 waves sums a contiguous quarter of the list (loads kept 8 deep in flight), then the quarters
-    // are added in order: the summation order is fixed by the list, not by timing
-    __shared__ double sV[RED_PARTS][40];
-    const int b = blockIdx.x, tid = threadIdx.x, part = tid >> 6, t = tid & 63;
+    // A list is cut into interleaved slots (entry e belongs to slot e mod nslots); a group of 36 (18) threads owns a
+    // slot and sums its entries with 8 gathers in flight, then the slots are added in slot order: the summation order
+    // is fixed by the list, not by timing.  Three dependent round trips (offsets, list, slab) whatever the list length.
+    __shared__ double sV[56 * 18 + 8];
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int lo = R.list_off[b], hi = R.list_off[b + 1];
     if (b < VIO_NPAIR) {
-        const int n = hi - lo, per = (n + RED_PARTS - 1) / RED_PARTS;
-        const int e0 = lo + part * per, e1 = min(hi, e0 + per);
-        double acc = 0.0;
-        if (t < 36) {
-            int e = e0;
-            for (; e + 8 <= e1; e += 8) {
+        constexpr int W = 36, NS = RED_THREADS / W;           // 28 slots
+        const int s = tid / W, t = tid - s * W;
+        const int n = hi - lo;
+        if (s < NS) {
+            double acc = 0.0;
+            int e = s;
+            for (; e + 7 * NS < n; e += 8 * NS) {
+                int off[8];
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = R.slab[(size_t)R.list[e + u] + t];
+                for (int u = 0; u < 8; ++u) off[u] = R.list[lo + e + u * NS];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = R.slab[(size_t)off[u] + t];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += v[u];
             }
-            for (; e < e1; ++e) acc += R.slab[(size_t)R.list[e] + t];
-            sV[part][t] = acc;
+            {   // tail: up to 7 entries, still all in flight together
+                int off[7];
+                double v[7];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) off[u] = (e + u * NS < n) ? R.list[lo + e + u * NS] : -1;
+#pragma unroll
+                for (int u = 0; u < 7; ++u) v[u] = off[u] >= 0 ? R.slab[(size_t)off[u] + t] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 7; ++u) if (off[u] >= 0) acc += v[u];
+            }
+            sV[s * W + t] = acc;
         }
         __syncthreads();
-        if (tid < 36) {
+        if (tid < W) {
             double tot = 0.0;
 #pragma unroll
-            for (int q = 0; q < RED_PARTS; ++q) tot += sV[q][tid];
+            for (int q = 0; q < NS; ++q) tot += sV[q * W + tid];
             int P = 0, rem = b;
             while (rem >= VIO_NCB - P) { rem -= VIO_NCB - P; ++P; }
             const int Q = P + rem, i = tid / 6, j = tid % 6;
@@ -735,28 +748,34 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
             if (P != Q) R.vis[VIS_H + (6 * Q + j) * VIO_CD + 6 * P + i] = tot;
         }
     } else if (b < VIO_NPAIR + VIO_NCB) {
+        constexpr int W = 18, NS = RED_THREADS / W;           // 56 slots
         const int P = b - VIO_NPAIR;
-        const int n = (hi - lo) / 2, per = (n + RED_PARTS - 1) / RED_PARTS;
-        const int e0 = part * per, e1 = min(n, e0 + per);
+        const int s = tid / W, t = tid - s * W;
         const int kind = t / 6, i = t % 6;
-        double acc = 0.0;
-        if (t < 18) {
-            int e = e0;
-            for (; e + 8 <= e1; e += 8) {
-                double v[8];
+        const int n = (hi - lo) / 2;
+        if (s < NS) {
+            double acc = 0.0;
+            for (int e = s; e < n; e += 4 * NS) {
+                int off[4], str[4];
+                double v[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = R.slab[(size_t)R.list[lo + 2 * (e + u)] + kind * R.list[lo + 2 * (e + u) + 1] + i];
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = e + u * NS < n;
+                    off[u] = ok ? R.list[lo + 2 * (e + u * NS)] : -1;
+                    str[u] = ok ? R.list[lo + 2 * (e + u * NS) + 1] : 0;
+                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
+                for (int u = 0; u < 4; ++u) v[u] = off[u] >= 0 ? R.slab[(size_t)off[u] + kind * str[u] + i] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (off[u] >= 0) acc += v[u];
             }
-            for (; e < e1; ++e) acc += R.slab[(size_t)R.list[lo + 2 * e] + kind * R.list[lo + 2 * e + 1] + i];
-            sV[part][t] = acc;
+            sV[s * W + t] = acc;
         }
         __syncthreads();
         if (tid < 6) {
             double bd = 0.0, bc = 0.0, dg = 0.0;
 #pragma unroll
-            for (int q = 0; q < RED_PARTS; ++q) { bd += sV[q][tid]; bc += sV[q][6 + tid]; dg += sV[q][12 + tid]; }
+            for (int q = 0; q < NS; ++q) { bd += sV[q * W + tid]; bc += sV[q * W + 6 + tid]; dg += sV[q * W + 12 + tid]; }
             R.vis[VIS_BDIR + 6 * P + tid] = bd;
             R.vis[VIS_BRED + 6 * P + tid] = bd - bc;     // bpp - (Hpm*Hmm^-1)*bmm (problem.cc:429)
             R.vis[VIS_DIAG + 6 * P + tid] = dg;
