@@ -150,6 +150,20 @@ DEV void d_block_sum_max(double &sum, double &mx, double *scratch, int tid) {
     sum = ts; mx = tm;
 }
 
+// Two sums over a workgroup of NT threads in one pass (DPP inside the wave, wave partials added in wave order).
+// scratch: 2 * NT / 64 doubles.  All threads must call; every thread gets both totals.
+template <int NT>
+DEV void d_block_sum2(double &a, double &b, double *scratch, int tid) {
+    const double sa = d_wave_sum_to_lane63(a), sb = d_wave_sum_to_lane63(b);
+    if ((tid & 63) == 63) { scratch[tid >> 6] = sa; scratch[NT / 64 + (tid >> 6)] = sb; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { ta += scratch[w]; tb += scratch[NT / 64 + w]; }
+    __syncthreads();
+    a = ta; b = tb;
+}
+
 // deterministic block reductions (fixed tree), all threads must call
 template <int NT>
 DEV double d_block_sum(double v, double *scratch, int tid) {

@@ -1471,46 +1471,48 @@ __global__ __launch_bounds__(256) void k_step_sum(DeviceTables T, int mode) {
     const double *part = (mode == 2) ? T.chi_part : T.step_part;
     double c = 0, s = 0;
     for (int e = tid; e < T.n_items; e += 256) { c += part[2 * e + STEP_CHI]; s += part[2 * e + STEP_SCALE]; }
-    const double ct = d_block_sum<256>(c, s0, tid);
-    const double st = d_block_sum<256>(s, s0, tid);
+    d_block_sum2<256>(c, s, s0, tid);        // the same reduction as k_lm_decide's: sharded and unsharded runs agree bit for bit
     if (tid == 0) {
-        T.step_tot[0] = ct; T.step_tot[1] = st;
-        if (T.gn_flags & 1) { T.vis[VIS_STEP] = ct; T.vis[VIS_STEP + 1] = st; }     // ride along with the next all-reduce
+        T.step_tot[0] = c; T.step_tot[1] = s;
+        if (T.gn_flags & 1) { T.vis[VIS_STEP] = c; T.vis[VIS_STEP + 1] = s; }     // ride along with the next all-reduce
     }
 }
 
 __global__ void k_gn_finish(DeviceTables T) { if (threadIdx.x == 0) d_gn_finish(T); }
 
 __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int sum_local) {
-    __shared__ double s0[256];
+    __shared__ double s0[16];
+    __shared__ double sImu[16];
     const int tid = threadIdx.x;
     LmState *lm = T.lm;
     const double *part = (mode == 2) ? T.chi_part : T.step_part;
-    if (sum_local) {        // unsharded: fold k_step_sum in (same fixed order)
-        double c = 0, s = 0;
-        for (int e = tid; e < T.n_items; e += 256) { c += part[2 * e + STEP_CHI]; s += part[2 * e + STEP_SCALE]; }
-        const double ct = d_block_sum<256>(c, s0, tid);
-        const double st = d_block_sum<256>(s, s0, tid);
-        if (tid == 0) {
-            T.step_tot[0] = ct; T.step_tot[1] = st;
-            if (T.gn_flags & 1) { T.vis[VIS_STEP] = ct; T.vis[VIS_STEP + 1] = st; }     // ride along with the next all-reduce
-        }
-        __syncthreads();
-    }
+    // everything this kernel reads is requested before anything is waited for: one round trip, not five.  The prior
+    // error is read from both state copies because which one counts depends on lm->cur, itself still in flight.
     const int cur = lm->cur;
-    const int which = (mode == 2) ? cur : (cur ^ 1);
-    double e = 0.0, sp = 0.0;
-    if (T.has_prior)
-        for (int i = tid; i < VIO_PRD; i += 256) { const double v = T.errprior[which * 160 + i]; e += v * v; }
     const double lambda = lm->lambda;
+    double c = 0, s = 0, e0 = 0.0, e1 = 0.0, sp = 0.0;
+    if (sum_local)          // unsharded: fold k_step_sum in (same fixed order)
+        for (int e = tid; e < T.n_items; e += 256) { c += part[2 * e + STEP_CHI]; s += part[2 * e + STEP_SCALE]; }
+    if (T.has_prior)
+        for (int i = tid; i < VIO_PRD; i += 256) { const double v0 = T.errprior[i], v1 = T.errprior[160 + i]; e0 += v0 * v0; e1 += v1 * v1; }
     if (mode != 2)
         for (int i = tid; i < VIO_PD; i += 256) { const double d = T.dx[i]; sp += d * (lambda * d + T.bfull[i]); }
-    const double en2 = d_block_sum<256>(e, s0, tid);
-    const double scale_p = d_block_sum<256>(sp, s0, tid);
+    if (tid < T.n_imu_items) sImu[tid] = part[2 * (T.n_items + tid) + STEP_CHI];
+    const int which = (mode == 2) ? cur : (cur ^ 1);
+    double e = which ? e1 : e0;
+    if (sum_local) {
+        d_block_sum2<256>(c, s, s0, tid);
+        if (tid == 0) {
+            T.step_tot[0] = c; T.step_tot[1] = s;
+            if (T.gn_flags & 1) { T.vis[VIS_STEP] = c; T.vis[VIS_STEP + 1] = s; }     // ride along with the next all-reduce
+        }
+    }
+    d_block_sum2<256>(e, sp, s0, tid);
+    const double en2 = e, scale_p = sp;
     if (tid != 0) return;
     double chi_imu = 0.0;
-    for (int k = 0; k < T.n_imu_items; ++k) chi_imu += part[2 * (T.n_items + k) + STEP_CHI];
-    double total = T.step_tot[0] + chi_imu;
+    for (int k = 0; k < T.n_imu_items; ++k) chi_imu += sImu[k];
+    double total = (sum_local ? c : T.step_tot[0]) + chi_imu;
     if (T.has_prior) total += sqrt(en2);            // err_prior_.norm(), not squared (problem.cc:554-556)
     const double tempChi = 0.5 * total;
     lm->chi_try = tempChi;
@@ -1521,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int
         lm->gn_scale_p = scale_p;
         lm->gn_chi_prev = lm->chi;
     }
-    double scale = 0.5 * (T.step_tot[1] + scale_p);
+    double scale = 0.5 * ((sum_local ? s : T.step_tot[1]) + scale_p);
     scale += 1e-6;
     const double rho = (lm->chi - tempChi) / scale;
     lm->rho = rho; lm->scale = scale;
