@@ -823,14 +823,21 @@ __device__ __forceinline__ int tix(int I, int J) { return (I * (I + 1) / 2 + J) 
 __device__ __forceinline__ int telem(int r, int c) { return tix(r >> 4, c >> 4) + (r & 15) * PS_TROW + (c & 15); }
 
 // entry (i,j), i >= j, of H_pp_schur_ without lambda: the lower triangle as Eigen's LDLT reads it
-__device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int i, int j, double &vv, double &vr) {
+// valid: bit k set = IMU edge k exists (d_imu_mask: read once per kernel so that an entry costs one round trip, not two)
+__device__ __forceinline__ int d_imu_mask(const DeviceTables &T) {
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m |= (T.imu_valid[k] != 0) << k;
+    return m;
+}
+__device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int i, int j, double &vv, double &vr) {
     vv = 0.0; vr = 0.0;                 // reduced visual part, IMU + prior part
     const int ci = full_to_cam(i), cj = full_to_cam(j);
     if (ci >= 0 && cj >= 0) vv = T.vis[VIS_H + ci * VIO_CD + cj];
     if (i >= 6 && j >= 6) {
         const int fi = (i - 6) / 15;
         for (int k = fi - 1; k <= fi; ++k) {
-            if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
+            if (k < 0 || k >= 10 || !((valid >> k) & 1)) continue;
             if (T.marg_mode && k != 0) continue;
             const int a = i - (6 + 15 * k), bb = j - (6 + 15 * k);
             if (bb < 0 || bb >= 30) continue;
@@ -847,7 +854,7 @@ __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int i, int j, 
 
 // Row i of the right-hand sides: b_pp_schur_ (returned and stored in T.bs), the pose part of b_ (T.bfull, for the
 // gain ratio) and diag(Hessian_) before the Schur complement (T.diagfull, for ComputeLambdaInitLM, problem.cc:511-516)
-__device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int i, int cur) {
+__device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid, int i, int cur) {
     const int ci = full_to_cam(i);
     const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
     double bred = 0.0, bdir = 0.0, dv, dr;
@@ -856,7 +863,7 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int i, in
     if (i >= 6) {
         const int fi = (i - 6) / 15;
         for (int k = fi - 1; k <= fi; ++k) {
-            if (k < 0 || k >= 10 || !T.imu_valid[k]) continue;
+            if (k < 0 || k >= 10 || !((valid >> k) & 1)) continue;
             if (T.marg_mode && k != 0) continue;
             const int a = i - (6 + 15 * k);
             if (a < 0 || a >= 30) continue;
@@ -866,7 +873,7 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int i, in
     if (T.has_prior && !mask_i) extra += T.bprior[cur * 176 + i];
     T.bs[i] = bred + extra;
     T.bfull[i] = bdir + extra;
-    d_hs_entry(T, i, i, dv, dr);
+    d_hs_entry(T, valid, i, i, dv, dr);
     T.diagfull[i] = ((ci >= 0) ? T.vis[VIS_DIAG + ci] : 0.0) + dr;
     return bred + extra;
 }
@@ -895,7 +902,8 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
     __shared__ int sCnt[5 * 176];
     const int b = blockIdx.x, t = threadIdx.x;
     const int cur = T.lm->cur;
-    if (t < VIO_PD) { double vv, vr; d_hs_entry(T, t, t, vv, vr); sDg[t] = fabs(vv + vr); }
+    const int valid = d_imu_mask(T);
+    if (t < VIO_PD) { double vv, vr; d_hs_entry(T, valid, t, t, vv, vr); sDg[t] = fabs(vv + vr); }
     __syncthreads();
     if (t < 5 * VIO_PD) {           // rank_i = #{j : d_j > d_i or (d_j == d_i and j < i)}, 5 threads per entry
         const int i = t % VIO_PD, part = t / VIO_PD;
@@ -917,13 +925,13 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
         if (t < VIO_PD) {
             if (T.natural_hs) {                 // natural-order H_pp_schur_: only the getters and Marginalize read it
                 double vv, vr;
-                d_hs_entry(T, max(i, t), min(i, t), vv, vr);
+                d_hs_entry(T, valid, max(i, t), min(i, t), vv, vr);
                 T.Hs[i * VIO_PD + t] = vv + vr;
             }
             if (t <= i) {                       // permuted row i of the tiled triangle
                 const int pi = sPerm[i], pj = sPerm[t];
                 double wv, wr;
-                d_hs_entry(T, max(pi, pj), min(pi, pj), wv, wr);
+                d_hs_entry(T, valid, max(pi, pj), min(pi, pj), wv, wr);
                 T.Pg[telem(i, t)] = wv + wr;
                 if (t < i && (t >> 4) == (i >> 4)) T.Pg[telem(t, i)] = wv + wr;      // upper half of a diagonal tile
             }
@@ -935,7 +943,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
         }
     } else {
         if (t < VIO_PD) {
-            sDg[t] = d_rhs_entries(T, t, cur);
+            sDg[t] = d_rhs_entries(T, valid, t, cur);
             T.perm[t] = sPerm[t];
         }
         if (t == 191 && (T.gn_flags & 2)) d_gn_finish(T);
@@ -1142,7 +1150,8 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     } else {
         // slow path (e.g. a negative lambda): rank-sort |diag + lambda| here and gather entry by entry
         double *sDg = sX;
-        for (int i = tid; i < n; i += PS_THREADS) { double vv, vr; d_hs_entry(T, i, i, vv, vr); sDg[i] = vv + vr + lambda; }
+        const int valid = d_imu_mask(T);
+        for (int i = tid; i < n; i += PS_THREADS) { double vv, vr; d_hs_entry(T, valid, i, i, vv, vr); sDg[i] = vv + vr + lambda; }
         __syncthreads();
         for (int i = tid; i < n; i += PS_THREADS) {
             const double di = fabs(sDg[i]);
@@ -1167,7 +1176,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
                     if (r < n) {
                         const int i = sPerm[r], j = sPerm[c];
                         double vv, vr;
-                        d_hs_entry(T, max(i, j), min(i, j), vv, vr);
+                        d_hs_entry(T, d_imu_mask(T), max(i, j), min(i, j), vv, vr);
                         v = vv + vr + ((r == c) ? lambda : 0.0);
                     } else {
                         v = (r == c) ? 1.0 : 0.0;
@@ -1393,7 +1402,10 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
         return;
     }
     __shared__ double sPairCD[VIO_MAXK * 12];
+    __shared__ double sDxp[176];
     __shared__ ItemDesc sIt;
+    // the pose update is the same for every item: requested together with the descriptor (both cold after the boundary)
+    if (mode == 0) { sDxp[lane] = T.dx[lane]; if (lane + BS_THREADS < 176) sDxp[lane + BS_THREADS] = T.dx[lane + BS_THREADS]; }
     if (lane < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[lane] = ((const int32_t *)(T.items + b))[lane];
     __syncthreads();
     const ItemDesc &it = sIt;
@@ -1416,7 +1428,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
                 const int cb = it.cam_block[p];
                 const int base = cb == 0 ? 0 : 6 + 15 * (cb - 1);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) t += lw[(size_t)(6 * p + i) * G + g] * T.dx[base + i];
+                for (int i = 0; i < 6; ++i) t += lw[(size_t)(6 * p + i) * G + g] * sDxp[base + i];
             }
             const double h = lw[(size_t)(6 * nb) * G + g], bl = lw[(size_t)(6 * nb + 1) * G + g];
             const double dl = (1.0 / h) * (bl - t);
