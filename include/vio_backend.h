@@ -167,6 +167,20 @@ vio_status vio_preintegrate(const double *acc0, const double *gyr0, const double
                             const double *dt, const double *acc, const double *gyr, double acc_n, double gyr_n,
                             double acc_w, double gyr_w, vio_preint *out);
 
+/* ---- triangulation of new tracks: FeatureManager::triangulate  VM/src/feature_manager.cpp:203-257 ----
+ * Depth (in its first camera frame) of every track that has none yet (depth[i] <= 0 on entry): the smallest right
+ * singular vector v of the 2K x 4 DLT system built from its K observations (:228-240), depth = v[2] / v[3] (:245); a
+ * result below 0.1 becomes init_depth (INIT_DEPTH, parameters.cpp:126; :252-255).  Tracks the optimiser would not use
+ * (fewer than 2 observations, or start_frame >= VIO_WINDOW_SIZE - 2; :207-208) and tracks that already have a depth
+ * (:210-211) are left alone.
+ *   start_frame[i]                      frame of the track's first observation (its host frame)
+ *   obs_offset[i] .. obs_offset[i+1]    its observations, one per consecutive frame from start_frame on
+ *   pts[e][2]                           normalised image point (x, y), z = 1 (the reference normalises the 3-vector, :236)
+ *   poses[11][7], ext[7]                p, q(xyzw) of the IMU frames; camera-to-IMU extrinsic
+ * One GPU thread per track; depth[] is updated in place on the host. */
+vio_status vio_triangulate(struct vio_ctx *ctx, int64_t n_tracks, const int32_t *start_frame, const int64_t *obs_offset,
+                           const double *pts, const double *poses, const double *ext, double init_depth, double *depth);
+
 /* ---- marginalisation: Marg{Old,New}Frame + Problem::Marginalize  problem.cc:617-795 ------ */
 /* Uses the window/landmarks/observations/IMU/prior currently set.  Outputs the new prior
  * (VIO_PRIOR_DIM): H dim x dim, b, err, jt_inv dim x dim. */

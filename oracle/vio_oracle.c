@@ -677,6 +677,65 @@ int vioo_symmetric_eigen(int n, const double *Ain, double *d, double *Vout) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* FeatureManager::triangulate (VM/src/feature_manager.cpp:203-257), restated.                 */
+/* The reference takes the last column of V of Eigen::JacobiSVD of the 2K x 4 matrix svd_A     */
+/* (:243).  FeatureManager does not compile here (parameters.h pulls in OpenCV), so this part   */
+/* is PARITY UNPINNED against the reference itself; tests/test_triangulate.py pins it against   */
+/* numpy.linalg.svd of the same svd_A instead.  Here: eigenvector of the smallest eigenvalue of */
+/* svd_A^T svd_A through the tred2/tql2 solver above (the HIP kernel uses Jacobi rotations).    */
+/* ------------------------------------------------------------------------------------------ */
+vio_status vio_triangulate(struct vioo_ctx *c, int64_t n, const int32_t *start_frame, const int64_t *obs_offset,
+                           const double *pts, const double *poses, const double *ext, double init_depth, double *depth) {
+    (void)c;
+    if (n < 0 || (n > 0 && (!start_frame || !obs_offset || !depth)) || !poses || !ext) return VIO_ERR_BAD_ARG;
+    double Rc[VIO_NUM_FRAMES][9], tc[VIO_NUM_FRAMES][3], ric[9];
+    quat qe = {ext[3], ext[4], ext[5], ext[6]};
+    q_to_R(qe, ric);
+    for (int f = 0; f < VIO_NUM_FRAMES; ++f) {
+        quat q = {poses[7 * f + 3], poses[7 * f + 4], poses[7 * f + 5], poses[7 * f + 6]};
+        double Rf[9], t[3];
+        q_to_R(q, Rf);
+        m3_mul(Rf, ric, Rc[f]);                                   /* R1 = Rs[j] * ric[0]          (:225) */
+        m3_vec(Rf, ext, t);
+        for (int k = 0; k < 3; ++k) tc[f][k] = poses[7 * f + k] + t[k];   /* t1 = Ps[j] + Rs[j] * tic[0]  (:224) */
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const int sf = start_frame[i];
+        const int64_t e0 = obs_offset[i];
+        const int K = (int)(obs_offset[i + 1] - e0);
+        if (K < 0 || sf < 0 || sf + K > VIO_NUM_FRAMES) return VIO_ERR_BAD_ARG;
+        if (!(K >= 2 && sf < VIO_WINDOW_SIZE - 2)) continue;      /* :207 */
+        if (depth[i] > 0) continue;                               /* :210 */
+        double R0T[9], AtA[16], ev[4], V[16];
+        m3_T(Rc[sf], R0T);
+        memset(AtA, 0, sizeof(AtA));
+        for (int j = 0; j < K; ++j) {
+            const int f = sf + j;
+            double dt[3], t[3], R[9], RT[9], P[3][4];
+            for (int k = 0; k < 3; ++k) dt[k] = tc[f][k] - tc[sf][k];
+            m3_vec(R0T, dt, t);                                   /* t = R0^T (t1 - t0)           (:230) */
+            m3_mul(R0T, Rc[f], R);                                /* R = R0^T R1                  (:231) */
+            m3_T(R, RT);
+            for (int r = 0; r < 3; ++r) {                         /* P = [R^T | -R^T t]           (:233-234) */
+                for (int k = 0; k < 3; ++k) P[r][k] = RT[3 * r + k];
+                P[r][3] = -(RT[3 * r] * t[0] + RT[3 * r + 1] * t[1] + RT[3 * r + 2] * t[2]);
+            }
+            const double x = pts[2 * (e0 + j)], y = pts[2 * (e0 + j) + 1];
+            const double nn = sqrt(x * x + y * y + 1.0);          /* f = point.normalized()        (:235) */
+            const double f0 = x / nn, f1 = y / nn, f2 = 1.0 / nn;
+            double ra[4], rb[4];
+            for (int k = 0; k < 4; ++k) { ra[k] = f0 * P[2][k] - f2 * P[0][k]; rb[k] = f1 * P[2][k] - f2 * P[1][k]; }   /* :236-237 */
+            for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) AtA[4 * a + b] += ra[a] * ra[b] + rb[a] * rb[b];
+        }
+        vioo_symmetric_eigen(4, AtA, ev, V);                      /* ascending: column 0 <-> smallest singular value */
+        double dep = V[4 * 2 + 0] / V[4 * 3 + 0];                 /* svd_V[2] / svd_V[3]          (:245) */
+        if (dep < 0.1) dep = init_depth;                          /* :252-255 */
+        depth[i] = dep;
+    }
+    return VIO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* IntegrationBase: integration_base.h:14-158                                                  */
 /* ------------------------------------------------------------------------------------------ */
 static void mat_mul(int m, int k, int n, const double *A, const double *B, double *C) {

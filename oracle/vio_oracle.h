@@ -44,6 +44,7 @@
 #define vio_profile_end vioo_profile_end
 #define vio_kernel_name vioo_kernel_name
 #define vio_preintegrate vioo_preintegrate_abi
+#define vio_triangulate vioo_triangulate
 #include "../include/vio_backend.h"
 
 #ifdef __cplusplus

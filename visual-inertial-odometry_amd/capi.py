@@ -84,7 +84,7 @@ class VioLib:
                "solve_linear", "update_states", "rollback_states", "chi2", "eval_step", "gn_iteration",
                "synchronize", "marginalize", "get_window", "get_landmarks", "get_prior", "get_delta",
                "get_schur_system", "get_landmark_system", "get_pose_gradient", "exchange_buffers",
-               "set_exchange_hook", "bind_exchange_buffers"]
+               "set_exchange_hook", "bind_exchange_buffers", "triangulate"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
@@ -322,6 +322,18 @@ class VioContext:
         self._hook = proto(lambda user, which: int(fn(which))) if fn is not None else None
         self._ck(self.lib.fn["set_exchange_hook"](self.h, self._hook if self._hook else C.cast(None, proto), None),
                  "set_exchange_hook")
+
+    def triangulate(self, start_frame, obs_offset, pts, poses, ext, depth, init_depth=5.0):
+        """FeatureManager::triangulate for tracks in CSR form; returns the updated depth vector (entries > 0 are kept)."""
+        sf = np.ascontiguousarray(start_frame, dtype=np.int32)
+        off = np.ascontiguousarray(obs_offset, dtype=np.int64)
+        p = _f64(pts).reshape(-1, 2) if len(pts) else np.zeros((0, 2))
+        d = np.array(depth, dtype=np.float64).copy()
+        assert off.size == sf.size + 1 and d.size == sf.size and (sf.size == 0 or off[-1] == p.shape[0])
+        self._ck(self.lib.fn["triangulate"](self.h, C.c_int64(sf.size), _ip(sf), off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            _dp(p), _dp(_f64(poses, (NUM_FRAMES, 7))), _dp(_f64(ext, (7,))),
+                                            C.c_double(init_depth), _dp(d)), "triangulate")
+        return d
 
     def comm_init(self, id128, rank, nranks):
         """Native RCCL exchange: id128 = the 128 bytes of rank 0's VioLib.comm_unique_id(), same on every rank."""

@@ -35,6 +35,7 @@ void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t 
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_gn_finish(const DeviceTables &T, hipStream_t s);
+void vio_launch_triangulate(const TriTables &Q, hipStream_t s);
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s);
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
@@ -984,6 +985,40 @@ vio_status vio_set_exchange_hook(vio_ctx *c, vio_exchange_fn fn, void *user) {
     c->hook = fn;
     c->hook_user = user;
     return VIO_OK;
+}
+
+vio_status vio_triangulate(vio_ctx *c, int64_t n, const int32_t *start_frame, const int64_t *obs_offset, const double *pts,
+                           const double *poses, const double *ext, double init_depth, double *depth) {
+    if (!c || n < 0 || (n > 0 && (!start_frame || !obs_offset || !depth)) || !poses || !ext) return VIO_ERR_BAD_ARG;
+    if (n == 0) return VIO_OK;
+    const int64_t m = obs_offset[n];
+    if (m < 0 || (m > 0 && !pts)) return VIO_ERR_BAD_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t k = obs_offset[i + 1] - obs_offset[i];
+        if (k < 0 || start_frame[i] < 0 || start_frame[i] + k > VIO_NF) return fail(c, VIO_ERR_BAD_ARG, "vio_triangulate: a track leaves the window");
+    }
+    hipSetDevice(c->cfg.device);
+    DevBuf<int32_t> d_sf; DevBuf<int64_t> d_off; DevBuf<double> d_pts, d_pose, d_depth;
+    vio_status st = VIO_OK;
+    auto body = [&]() -> vio_status {
+        HIPCHK(d_sf.resize(n)); HIPCHK(d_off.resize(n + 1)); HIPCHK(d_pts.resize(2 * (size_t)m)); HIPCHK(d_pose.resize(7 * VIO_NF + 7));
+        HIPCHK(d_depth.resize(n));
+        HIPCHK(hipMemcpyAsync(d_sf.p, start_frame, n * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_off.p, obs_offset, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if (m) HIPCHK(hipMemcpyAsync(d_pts.p, pts, 2 * (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_pose.p, poses, 7 * VIO_NF * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_pose.p + 7 * VIO_NF, ext, 7 * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_depth.p, depth, n * 8, hipMemcpyHostToDevice, c->stream));
+        TriTables Q{n, d_sf.p, d_off.p, d_pts.p, d_pose.p, d_pose.p + 7 * VIO_NF, init_depth, d_depth.p};
+        vio_launch_triangulate(Q, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(depth, d_depth.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return VIO_OK;
+    };
+    st = body();
+    d_sf.release(); d_off.release(); d_pts.release(); d_pose.release(); d_depth.release();
+    return st;
 }
 
 vio_status vio_comm_unique_id(void *id128) {

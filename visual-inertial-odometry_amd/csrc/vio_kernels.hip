@@ -1603,6 +1603,84 @@ __global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// k_triangulate: FeatureManager::triangulate (feature_manager.cpp:203-257), one thread per track.
+//   The reference takes the last column of V of a JacobiSVD of the 2K x 4 matrix A (:243); that is the eigenvector of
+//   the smallest eigenvalue of A^T A, found here with cyclic Jacobi rotations on the 4x4 (10 accumulated entries
+//   instead of a 2K x 4 matrix per thread).  Camera poses R_f ric, P_f + R_f tic are staged once per workgroup.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_triangulate(TriTables Q) {
+    __shared__ double sRc[VIO_NF * 9], sTc[VIO_NF * 3];
+    const int tid = threadIdx.x;
+    if (tid < VIO_NF) {
+        double Rf[9], ric[9], tic[3], t[3];
+        d_quat_to_R(Q.poses + 7 * tid + 3, Rf);
+        d_quat_to_R(Q.ext + 3, ric);
+        for (int k = 0; k < 3; ++k) tic[k] = Q.ext[k];
+        d_m3_mul(Rf, ric, sRc + 9 * tid);                    // R1 = Rs[j] * ric   (:225)
+        d_m3_vec(Rf, tic, t);
+        for (int k = 0; k < 3; ++k) sTc[3 * tid + k] = Q.poses[7 * tid + k] + t[k];    // t1 = Ps[j] + Rs[j] * tic   (:224)
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + tid;
+    if (i >= Q.n) return;
+    const int sf = Q.start_frame[i];
+    const int64_t e0 = Q.obs_offset[i];
+    const int K = (int)(Q.obs_offset[i + 1] - e0);
+    if (!(K >= 2 && sf < VIO_NF - 1 - 2)) return;            // used_num >= 2 && start_frame < WINDOW_SIZE - 2   (:207)
+    if (Q.depth[i] > 0) return;                              // :210
+    const double *R0 = sRc + 9 * sf, *t0 = sTc + 3 * sf;
+    double M[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) M[a][b] = 0.0;
+    for (int j = 0; j < K; ++j) {
+        const int f = min(sf + j, VIO_NF - 1);
+        const double *R1 = sRc + 9 * f, *t1 = sTc + 3 * f;
+        double dt[3] = {t1[0] - t0[0], t1[1] - t0[1], t1[2] - t0[2]}, t[3], R[9];
+        d_m3_tvec(R0, dt, t);                                // t = R0^T (t1 - t0)
+        d_m3_tmul(R0, R1, R);                                // R = R0^T R1
+        double P[3][4];                                      // P = [R^T | -R^T t]
+        for (int r = 0; r < 3; ++r) {
+            P[r][0] = R[r]; P[r][1] = R[3 + r]; P[r][2] = R[6 + r];
+            P[r][3] = -(R[r] * t[0] + R[3 + r] * t[1] + R[6 + r] * t[2]);
+        }
+        const double x = Q.pts[2 * (e0 + j)], y = Q.pts[2 * (e0 + j) + 1];
+        const double nn = sqrt(x * x + y * y + 1.0);
+        const double f0 = x / nn, f1 = y / nn, f2 = 1.0 / nn;
+        double ra[4], rb[4];
+        for (int c = 0; c < 4; ++c) { ra[c] = f0 * P[2][c] - f2 * P[0][c]; rb[c] = f1 * P[2][c] - f2 * P[1][c]; }
+        for (int a = 0; a < 4; ++a) for (int b = 0; b <= a; ++b) M[a][b] += ra[a] * ra[b] + rb[a] * rb[b];
+    }
+    for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) M[a][b] = M[b][a];
+    // cyclic Jacobi: M -> diagonal, V accumulates the rotations (columns = eigenvectors)
+    double V[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) V[a][b] = a == b ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0.0;
+        for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) off += M[a][b] * M[a][b];
+        if (off == 0.0) break;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                const double apq = M[p][q];
+                if (apq == 0.0) continue;
+                const double theta = (M[q][q] - M[p][p]) / (2.0 * apq);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+                for (int k = 0; k < 4; ++k) { const double mkp = M[k][p], mkq = M[k][q]; M[k][p] = c * mkp - sn * mkq; M[k][q] = sn * mkp + c * mkq; }
+                for (int k = 0; k < 4; ++k) { const double mpk = M[p][k], mqk = M[q][k]; M[p][k] = c * mpk - sn * mqk; M[q][k] = sn * mpk + c * mqk; }
+                for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+            }
+    }
+    int m = 0;
+    for (int a = 1; a < 4; ++a) if (M[a][a] < M[m][m]) m = a;
+    double dep = V[2][m] / V[3][m];                          // svd_V[2] / svd_V[3]   (:245)
+    if (dep < 0.1) dep = Q.init_depth;                       // :252
+    Q.depth[i] = dep;
+}
+
+void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
+    hipLaunchKernelGGL(k_triangulate, dim3((unsigned)((Q.n + 255) / 256)), dim3(256), 0, s, Q);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host-callable launchers (C++ linkage inside the library)
 // ---------------------------------------------------------------------------------------------------------
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(128), 0, s, T); }

@@ -165,6 +165,17 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     unsigned long long *dbg;     // diagnostic builds only (-DVIO_STAMPS): [block][16] s_memtime stamps
 };
 
+struct TriTables {               // k_triangulate (FeatureManager::triangulate)
+    int64_t n;
+    const int32_t *start_frame;  // [n]
+    const int64_t *obs_offset;   // [n + 1]
+    const double *pts;           // [m][2]
+    const double *poses;         // [11][7]
+    const double *ext;           // [7]
+    double init_depth;
+    double *depth;               // [n] in/out
+};
+
 // packed pre-integration record (doubles)
 #define PRE_SUMDT 0
 #define PRE_DP 1
