@@ -1,0 +1,90 @@
+// Test driver for the C++ FeatureManager mirror: reads tracks + poses + a list of operations from a flat binary file
+// written by the pytest, applies the operations, writes the tracks back.
+// Input (little-endian): int64 n_tracks; per track: int32 id, int32 start, int32 n_obs, double estimated_depth, n_obs x (x,y);
+//   77 doubles poses[11][7]; 7 doubles ext; int32 n_ops; per op: int32 code [+ payload]
+//   codes: 1 triangulate (needs the GPU)  2 setDepth (int64 n, n doubles)  3 removeFailures  4 removeBackShiftDepth
+//          (9+3+9+3 doubles)  5 removeBack  6 removeFront (int32 frame_count)  7 clearDepth (int64 n, n doubles)
+// Output: int32 getFeatureCount; int64 n_dep, getDepthVector(); int64 n_tracks; per track: id, start, n_obs, depth,
+//   int32 solve_flag, points.
+#include <cstdio>
+#include <vector>
+
+#include "../../visual-inertial-odometry_amd/host/feature_manager.h"
+
+template <typename T>
+static bool rd(FILE *f, T *p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 2;
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f) return 3;
+    std::vector<vio::FeaturePerId> tracks;
+    int64_t nt;
+    if (!rd(f, &nt, 1)) return 4;
+    tracks.resize(nt);
+    for (auto &t : tracks) {
+        int32_t id, start, nobs;
+        if (!rd(f, &id, 1) || !rd(f, &start, 1) || !rd(f, &nobs, 1) || !rd(f, &t.estimated_depth, 1)) return 4;
+        t.feature_id = id; t.start_frame = start;
+        t.feature_per_frame.resize(nobs);
+        for (auto &p : t.feature_per_frame) if (!rd(f, p.data(), 2)) return 4;
+    }
+    double poses[11][7], ext[7];
+    if (!rd(f, &poses[0][0], 77) || !rd(f, ext, 7)) return 4;
+    vio::FeatureManager fm(tracks);
+    int32_t nops;
+    if (!rd(f, &nops, 1)) return 4;
+    vio_ctx *ctx = nullptr;
+    for (int32_t k = 0; k < nops; ++k) {
+        int32_t code;
+        if (!rd(f, &code, 1)) return 4;
+        if (code == 1) {
+            if (!ctx) {
+                vio_config cfg;
+                vio_default_config(&cfg);
+                if (vio_create(&cfg, &ctx) != VIO_OK) { std::fprintf(stderr, "vio_create failed (no GPU?)\n"); return 5; }
+            }
+            if (!fm.triangulate(ctx, poses, ext)) { std::fprintf(stderr, "triangulate failed: %s\n", vio_last_error(ctx)); return 6; }
+        } else if (code == 2 || code == 7) {
+            int64_t n;
+            if (!rd(f, &n, 1)) return 4;
+            std::vector<double> x(n);
+            if (n && !rd(f, x.data(), n)) return 4;
+            if ((int)n != fm.getFeatureCount()) return 7;
+            if (code == 2) fm.setDepth(x); else fm.clearDepth(x);
+        } else if (code == 3) {
+            fm.removeFailures();
+        } else if (code == 4) {
+            double a[24];
+            if (!rd(f, a, 24)) return 4;
+            fm.removeBackShiftDepth(a, a + 9, a + 12, a + 21);
+        } else if (code == 5) {
+            fm.removeBack();
+        } else if (code == 6) {
+            int32_t fc;
+            if (!rd(f, &fc, 1)) return 4;
+            fm.removeFront(fc);
+        } else return 8;
+    }
+    std::fclose(f);
+    if (ctx) vio_destroy(ctx);
+    FILE *o = std::fopen(argv[2], "wb");
+    int32_t cnt = fm.getFeatureCount();
+    std::fwrite(&cnt, 4, 1, o);
+    std::vector<double> dep = fm.getDepthVector();
+    int64_t nd = (int64_t)dep.size();
+    std::fwrite(&nd, 8, 1, o);
+    std::fwrite(dep.data(), 8, dep.size(), o);
+    int64_t n = (int64_t)tracks.size();
+    std::fwrite(&n, 8, 1, o);
+    for (auto &t : tracks) {
+        int32_t h[3] = {t.feature_id, t.start_frame, (int32_t)t.feature_per_frame.size()};
+        std::fwrite(h, 4, 3, o);
+        std::fwrite(&t.estimated_depth, 8, 1, o);
+        int32_t sfl = t.solve_flag;
+        std::fwrite(&sfl, 4, 1, o);
+        for (auto &p : t.feature_per_frame) std::fwrite(p.data(), 8, 2, o);
+    }
+    std::fclose(o);
+    return 0;
+}

@@ -84,7 +84,9 @@ class VioLib:
                "solve_linear", "update_states", "rollback_states", "chi2", "eval_step", "gn_iteration",
                "synchronize", "marginalize", "get_window", "get_landmarks", "get_prior", "get_delta",
                "get_schur_system", "get_landmark_system", "get_pose_gradient", "exchange_buffers",
-               "set_exchange_hook", "bind_exchange_buffers", "triangulate"]
+               "set_exchange_hook", "bind_exchange_buffers"]
+    # outside the backend proper: the compiled-reference harness (vior_) has no FeatureManager
+    OPTIONAL = ["triangulate"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
@@ -101,6 +103,10 @@ class VioLib:
         self.fn = {}
         for s in self.SYMBOLS:
             self.fn[s] = getattr(self.dll, prefix + s)     # raises AttributeError on a missing export
+        for s in self.OPTIONAL:
+            if hasattr(self.dll, prefix + s):
+                self.fn[s] = getattr(self.dll, prefix + s)
+                self.fn[s].restype = C.c_int
         if prefix == "vio_":
             for s in self.HIP_ONLY:
                 self.fn[s] = getattr(self.dll, prefix + s)

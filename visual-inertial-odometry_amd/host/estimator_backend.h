@@ -26,6 +26,10 @@ struct FeaturePerId {
     std::vector<std::array<double, 2>> feature_per_frame;   // normalised (x, y), z == 1
     double inv_depth = 0.0;                                  // what getDepthVector()/setDepth() exchange (feature_manager.cpp:184-200)
     int used_num = 0;
+    int feature_id = 0;
+    double estimated_depth = -1.0;                           // FeaturePerId::estimated_depth (feature_manager.h:62,74): <= 0 = not triangulated yet
+    int solve_flag = 0;                                      // 0 haven't solved yet, 1 solved, 2 solve failed (feature_manager.h:63)
+    int endFrame() const { return start_frame + (int)feature_per_frame.size() - 1; }
 };
 
 enum MarginalizationFlag { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };   // estimator.h:52-56
@@ -56,6 +60,9 @@ public:
 
 private:
     bool uploadWindow();
+public:
+    vio_ctx *context() { return ctx_; }               // for FeatureManager::triangulate
+private:
     vio_ctx *ctx_ = nullptr;
     std::string err_;
 };

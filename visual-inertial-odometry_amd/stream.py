@@ -97,7 +97,11 @@ class SyntheticStream:
 
 
 class StreamDriver:
-    def __init__(self, lib, stream, ctx_kwargs=None, pos_noise=0.02, rot_noise=0.005, depth_noise=0.05, seed=1):
+    def __init__(self, lib, stream, ctx_kwargs=None, pos_noise=0.02, rot_noise=0.005, depth_noise=0.05, seed=1,
+                 triangulate=False):
+        """triangulate=True: a landmark's first depth comes from FeatureManager::triangulate (vio_triangulate, on the
+        current pose estimates, feature_manager.cpp:203-257) the first time it enters a solve, as in
+        Estimator::solveOdometry (estimator.cpp:489-503), instead of from the perturbed ground truth."""
         self.lib, self.s = lib, stream
         self.ctx = lib.context(**(ctx_kwargs or {}))
         rng = np.random.RandomState(seed)
@@ -114,6 +118,8 @@ class StreamDriver:
             self.sb[i, 0:3] = st.V[i]
         self.ext = st.ext.copy()
         self.inv_depth = 1.0 / (np.array(st.lm_depth) * (1.0 + depth_noise * st.init_noise))
+        self.triangulate = triangulate
+        self.have_depth = np.zeros(len(st.lm_host), dtype=bool) if triangulate else np.ones(len(st.lm_host), dtype=bool)
         self.prior = None
         self.trajectory = []        # (stamp, pose[7]) of the newest frame after every solve
         self.reports = []
@@ -140,9 +146,30 @@ class StreamDriver:
                          n_landmarks=len(ids), n_observations=len(lm))
         return w, np.array(ids, dtype=np.int64)
 
+    def triangulate_new(self):
+        """f_manager.triangulate(Ps, tic, ric) of solveOdometry: depths of the tracks that have none yet."""
+        s, st = self.start, self.s
+        todo, sf, off, pts = [], [], [0], []
+        for l, h in enumerate(st.lm_host):
+            if self.have_depth[l] or h < s or h - s >= WINDOW_SIZE - 2:
+                continue
+            obs = [o for j, o in sorted(st.lm_obs[l].items()) if j <= s + WINDOW_SIZE]
+            if not obs:
+                continue
+            todo.append(l); sf.append(h - s); pts.append(st.lm_px[l]); pts.extend(obs); off.append(off[-1] + 1 + len(obs))
+        if not todo:
+            return 0
+        depth = self.ctx.triangulate(np.array(sf, dtype=np.int32), np.array(off, dtype=np.int64), np.array(pts).reshape(-1, 2),
+                                     self.poses, self.ext, -np.ones(len(todo)))
+        self.inv_depth[todo] = 1.0 / depth
+        self.have_depth[todo] = True
+        return len(todo)
+
     def step(self):
         """One keyframe: solve, re-anchor, marginalise the oldest frame, slide.  Returns False at the end."""
         st = self.s
+        if self.triangulate:
+            self.triangulate_new()
         w, ids = self.window_arrays()
         self.ctx.load(w)
         rep = self.ctx.solve(10)
