@@ -1629,8 +1629,12 @@ __global__ __launch_bounds__(256) void k_triangulate(TriTables Q) {
     if (!(K >= 2 && sf < VIO_NF - 1 - 2)) return;            // used_num >= 2 && start_frame < WINDOW_SIZE - 2   (:207)
     if (Q.depth[i] > 0) return;                              // :210
     const double *R0 = sRc + 9 * sf, *t0 = sTc + 3 * sf;
+    // every index below is a compile-time constant after unrolling: M and V live in registers, not in scratch
     double M[4][4];
-    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) M[a][b] = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) M[a][b] = 0.0;
     for (int j = 0; j < K; ++j) {
         const int f = min(sf + j, VIO_NF - 1);
         const double *R1 = sRc + 9 * f, *t1 = sTc + 3 * f;
@@ -1638,6 +1642,7 @@ __global__ __launch_bounds__(256) void k_triangulate(TriTables Q) {
         d_m3_tvec(R0, dt, t);                                // t = R0^T (t1 - t0)
         d_m3_tmul(R0, R1, R);                                // R = R0^T R1
         double P[3][4];                                      // P = [R^T | -R^T t]
+#pragma unroll
         for (int r = 0; r < 3; ++r) {
             P[r][0] = R[r]; P[r][1] = R[3 + r]; P[r][2] = R[6 + r];
             P[r][3] = -(R[r] * t[0] + R[3 + r] * t[1] + R[6 + r] * t[2]);
@@ -1646,32 +1651,50 @@ __global__ __launch_bounds__(256) void k_triangulate(TriTables Q) {
         const double nn = sqrt(x * x + y * y + 1.0);
         const double f0 = x / nn, f1 = y / nn, f2 = 1.0 / nn;
         double ra[4], rb[4];
+#pragma unroll
         for (int c = 0; c < 4; ++c) { ra[c] = f0 * P[2][c] - f2 * P[0][c]; rb[c] = f1 * P[2][c] - f2 * P[1][c]; }
-        for (int a = 0; a < 4; ++a) for (int b = 0; b <= a; ++b) M[a][b] += ra[a] * ra[b] + rb[a] * rb[b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) M[a][b] += ra[a] * ra[b] + rb[a] * rb[b];
     }
-    for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) M[a][b] = M[b][a];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) M[a][b] = M[b][a];
     // cyclic Jacobi: M -> diagonal, V accumulates the rotations (columns = eigenvectors)
     double V[4][4];
-    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) V[a][b] = a == b ? 1.0 : 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) V[a][b] = a == b ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 12; ++sweep) {
-        double off = 0.0;
-        for (int a = 0; a < 4; ++a) for (int b = a + 1; b < 4; ++b) off += M[a][b] * M[a][b];
-        if (off == 0.0) break;
+        const double off = M[0][1] * M[0][1] + M[0][2] * M[0][2] + M[0][3] * M[0][3] + M[1][2] * M[1][2] + M[1][3] * M[1][3] + M[2][3] * M[2][3];
+        const double dg = M[0][0] * M[0][0] + M[1][1] * M[1][1] + M[2][2] * M[2][2] + M[3][3] * M[3][3];
+        if (off <= 1e-36 * dg) break;                          // off-diagonal mass below rounding of the diagonal: converged
+#pragma unroll
         for (int p = 0; p < 3; ++p)
+#pragma unroll
             for (int q = p + 1; q < 4; ++q) {
                 const double apq = M[p][q];
-                if (apq == 0.0) continue;
-                const double theta = (M[q][q] - M[p][p]) / (2.0 * apq);
-                const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
-                for (int k = 0; k < 4; ++k) { const double mkp = M[k][p], mkq = M[k][q]; M[k][p] = c * mkp - sn * mkq; M[k][q] = sn * mkp + c * mkq; }
-                for (int k = 0; k < 4; ++k) { const double mpk = M[p][k], mqk = M[q][k]; M[p][k] = c * mpk - sn * mqk; M[q][k] = sn * mpk + c * mqk; }
-                for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+                if (apq != 0.0) {
+                    const double theta = (M[q][q] - M[p][p]) / (2.0 * apq);
+                    const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double mkp = M[k][p], mkq = M[k][q]; M[k][p] = c * mkp - sn * mkq; M[k][q] = sn * mkp + c * mkq; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double mpk = M[p][k], mqk = M[q][k]; M[p][k] = c * mpk - sn * mqk; M[q][k] = sn * mpk + c * mqk; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+                }
             }
     }
-    int m = 0;
-    for (int a = 1; a < 4; ++a) if (M[a][a] < M[m][m]) m = a;
-    double dep = V[2][m] / V[3][m];                          // svd_V[2] / svd_V[3]   (:245)
+    // eigenvector of the smallest eigenvalue, picked with selects (no run-time index into V)
+    double best = M[0][0], v2 = V[2][0], v3 = V[3][0];
+#pragma unroll
+    for (int a = 1; a < 4; ++a) if (M[a][a] < best) { best = M[a][a]; v2 = V[2][a]; v3 = V[3][a]; }
+    double dep = v2 / v3;                                    // svd_V[2] / svd_V[3]   (:245)
     if (dep < 0.1) dep = Q.init_depth;                       // :252
     Q.depth[i] = dep;
 }
