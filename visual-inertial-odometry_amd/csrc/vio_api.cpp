@@ -134,6 +134,8 @@ struct vio_ctx {
     vio_exchange_fn hook = nullptr;
     void *comm = nullptr;                              // ncclComm_t of the native exchange (vio_comm_init)
     bool gn_pending = false;                           // sharded GN mode: the last step's landmark sums ride with the next all-reduce
+    int cur_host = -1;                                 // LmState.cur as the host tracks it through GN iterations (-1: unknown)
+    bool decide_pending = false;                       // GN mode: the last step's k_lm_decide has not run yet (it rides in the next k_linearize)
     void *hook_user = nullptr;
     double hessian_ms = 0;
     double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
@@ -347,7 +349,7 @@ vio_status alloc_fixed(vio_ctx *c) {
     return VIO_OK;
 }
 
-DeviceTables make_tables(vio_ctx *c, Plan &pl) {
+DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     DeviceTables T;
     std::memset(&T, 0, sizeof(T));
     T.items = pl.d_items.p; T.n_items = (int32_t)pl.items.size(); T.n_imu_items = VIO_WINDOW_SIZE;
@@ -364,7 +366,7 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
     T.has_prior = c->has_prior; T.add_imu_prior = 1; T.natural_hs = (pl.marg || c->want_natural_hs) ? 1 : 0;
     T.Hs = c->d_Hs.p; T.Pg = c->d_Pg.p; T.perm = c->d_perm.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
-    T.gn_flags = 0;
+    T.gn_flags = 0; T.cur_hint = -1; T.decide_mode = -1;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
 #ifdef VIO_STAMPS
@@ -375,7 +377,24 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
 }
 
 vio_status run_exchange(vio_ctx *c, int which);
-DeviceTables make_tables(vio_ctx *c, Plan &pl);
+
+// GN mode folds the step test of iteration i into k_linearize of iteration i+1; whoever touches the device outside
+// that loop gets it run first, as its own launch.
+void flush_decide(vio_ctx *c) {
+    if (!c->decide_pending || !c->active) return;
+    DeviceTables T = make_tables_raw(c, *c->active);
+    if (c->comm) T.gn_flags = 1;
+    vio_launch_lm_decide(T, 1, 1, c->stream);
+    c->decide_pending = false;
+}
+
+// tables for every path but the GN loop: bring the device's LmState up to date first; the host's idea of `cur` is void
+// until the next read_lm
+DeviceTables make_tables(vio_ctx *c, Plan &pl) {
+    flush_decide(c);
+    c->cur_host = -1;
+    return make_tables_raw(c, pl);
+}
 
 // sharded GN mode leaves the last step's landmark sums un-reduced until the next linearisation's all-reduce; anyone
 // who wants LmState before that gets them reduced here (a collective: every rank reads at the same point)
@@ -389,9 +408,11 @@ vio_status flush_gn_pending(vio_ctx *c) {
 }
 
 vio_status read_lm(vio_ctx *c) {
+    flush_decide(c);
     VIOCHK(flush_gn_pending(c));
     HIPCHK(hipMemcpyAsync(&c->h_lm, c->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->cur_host = c->h_lm.cur;
     return VIO_OK;
 }
 
@@ -435,6 +456,7 @@ vio_status push_to_device(vio_ctx *c, Plan &pl) {
     c->h_lm.ni = 2; c->h_lm.lambda = -1; c->h_lm.finite = 1; c->h_lm.last_chi = 1e20;
     HIPCHK(hipMemcpyAsync(c->d_lm.p, &c->h_lm, sizeof(LmState), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));      // the staging vectors above go out of scope
+    c->decide_pending = false; c->gn_pending = false; c->cur_host = 0;      // a fresh LmState: nothing of the old one is owed
     return VIO_OK;
 }
 
@@ -534,10 +556,16 @@ vio_status run_exchange(vio_ctx *c, int which) {
 }
 
 // prepare (if needed) + linearize + reduce + [exchange] + assemble at the current state
-vio_status enqueue_linearize(vio_ctx *c, Plan &pl) {
-    DeviceTables T = make_tables(c, pl);
+// gn = true: the GN loop (vio_gn_iteration): `cur` comes from the host, the previous step's test rides in k_linearize
+vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false) {
+    DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
+    if (gn) {
+        T.cur_hint = c->cur_host;
+        if (c->decide_pending) { T.decide_mode = 1; if (c->comm) T.gn_flags = 1; }
+    }
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
     { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
+    if (T.decide_mode >= 0) { c->decide_pending = false; T.decide_mode = -1; T.gn_flags = 0; }
     ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis};
     { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
     VIOCHK(run_exchange(c, 0));
@@ -562,10 +590,22 @@ vio_status enqueue_init_lm(vio_ctx *c, const DeviceTables &T, int max_iter) {
     return VIO_OK;
 }
 
-vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode) {
-    DeviceTables T = make_tables(c, pl);
+vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false) {
+    DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
+    if (gn) T.cur_hint = c->cur_host;
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, c->stream); }
+    if (gn) {
+        // the step is accepted whatever chi2 turns out to be: its test (k_lm_decide, mode 1) is not launched here but
+        // rides in the next k_linearize (flush_decide runs it when anybody else asks first); with the native exchange
+        // its two landmark sums ride in the next all-reduce
+        c->decide_pending = true;
+        if (c->comm) c->gn_pending = true;
+        c->cur_host ^= 1;
+        HIPCHK(hipGetLastError());
+        c->device_ahead = true;
+        return VIO_OK;
+    }
     if (sharded(c)) {
         // GN mode with the native exchange: a step is always accepted, nothing downstream waits for chi2, so the two
         // landmark sums are not all-reduced here but ride along with the next linearisation's all-reduce
@@ -859,9 +899,12 @@ vio_status vio_gn_iteration(vio_ctx *c, double lambda) {
     if (!c) return VIO_ERR_BAD_ARG;
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = c->solve_plan;
+    // the fold needs the decide kernel to be free of an exchange in front of it: not with the host hook
+    const bool gn = c->hook == nullptr;
+    if (gn && c->cur_host < 0) VIOCHK(read_lm(c));      // once: from here on the host tracks LmState.cur itself
     if (lambda != c->gn_lambda) { vio_launch_set_lambda(c->d_lm.p, lambda, c->stream); c->gn_lambda = lambda; }
-    VIOCHK(enqueue_linearize(c, pl));
-    VIOCHK(enqueue_trial(c, pl, 1));
+    VIOCHK(enqueue_linearize(c, pl, gn));
+    VIOCHK(enqueue_trial(c, pl, 1, gn));
     return VIO_OK;
 }
 

@@ -36,6 +36,9 @@ __shared__ unsigned long long g_stamps[8];
 #define STAMP_FLUSH(T) do { } while (0)
 #endif
 
+// which copy of the double-buffered state is current: the host's hint when it tracks it (GN mode), else LmState
+__device__ __forceinline__ int d_cur(const DeviceTables &T) { return T.cur_hint >= 0 ? T.cur_hint : T.lm->cur; }
+
 __device__ __forceinline__ int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
 // inverse: -1 when the full index is a speed-bias dimension
 __device__ __forceinline__ int full_to_cam(int i) {
@@ -92,7 +95,7 @@ __device__ void d_build_pairtab(const double *st, double *tab, double *sR, int t
 
 __global__ __launch_bounds__(128) void k_prepare(DeviceTables T) {
     __shared__ double sR[12 * 9];
-    const int cur = T.lm->cur;
+    const int cur = d_cur(T);
     d_build_pairtab(T.state + cur * STATE_STRIDE, T.pairtab + cur * PAIRTAB_STRIDE, sR, threadIdx.x, blockDim.x);
 }
 
@@ -263,7 +266,7 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
         for (int e = tid; e < IMU_OUT; e += LIN_THREADS) out[e] = 0.0;
         return;
     }
-    const int cur = T.lm->cur;
+    const int cur = d_cur(T);
     const double *st = T.state + cur * STATE_STRIDE;
     const double *pre = T.pre + k * PRE_STRIDE;
     const double *pi = st + STATE_POSE + 7 * k, *pj = pi + 7, *si = st + STATE_SB + 9 * k, *sj = si + 9;
@@ -349,9 +352,18 @@ __host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext
     return VIO_MAXK * PAIR_STRIDE + 16 + 2 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
 }
 
+template <int NT> __device__ void d_lm_decide(const DeviceTables &T, int mode, int sum_local, double *s0, double *sImu, int tid);
+
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    if (b >= T.n_items + T.n_imu_items) {
+        // GN mode: the step test of the PREVIOUS iteration rides here as one more workgroup instead of a launch of
+        // its own (nothing in this kernel depends on it: every other workgroup takes `cur` from the host's hint)
+        __shared__ double sDec[2 * (LIN_THREADS / 64)], sDecImu[16];
+        d_lm_decide<LIN_THREADS>(T, T.decide_mode, 1, sDec, sDecImu, tid);
+        return;
+    }
     if (b >= T.n_items) {
         STAMP(T, 0);
         d_imu_item(T, b - T.n_items, dyn_smem);
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         return;
     }
     __shared__ ItemDesc sIt;        // kept in LDS: its small arrays are indexed at run time
-    const int cur = T.lm->cur;      // requested together with the descriptor: both are cold after the kernel boundary
+    const int cur = d_cur(T);      // requested together with the descriptor: both are cold after the kernel boundary
     if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
     __syncthreads();
     const ItemDesc &it = sIt;
@@ -901,7 +913,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
     __shared__ int sPerm[176];
     __shared__ int sCnt[5 * 176];
     const int b = blockIdx.x, t = threadIdx.x;
-    const int cur = T.lm->cur;
+    const int cur = d_cur(T);
     const int valid = d_imu_mask(T);
     if (t < VIO_PD) { double vv, vr; d_hs_entry(T, valid, t, t, vv, vr); sDg[t] = fabs(vv + vr); }
     __syncthreads();
@@ -1104,7 +1116,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     const int wave = tid >> 6, lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     LmState *lm = T.lm;
-    const int cur = lm->cur, trial = cur ^ 1;
+    const int cur = d_cur(T), trial = cur ^ 1;
     const double lambda = lm->lambda;
     const int n = PS_N, NP = PS_NP;
 #ifdef VIO_STAMPS
@@ -1375,7 +1387,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const LmState *lm = T.lm;
-    const int cur = lm->cur;
+    const int cur = d_cur(T);
     const int which = (mode == 1) ? cur : (cur ^ 1);
     if (b >= T.n_items) {
         const int k = b - T.n_items;
@@ -1492,34 +1504,36 @@ __global__ __launch_bounds__(256) void k_step_sum(DeviceTables T, int mode) {
 
 __global__ void k_gn_finish(DeviceTables T) { if (threadIdx.x == 0) d_gn_finish(T); }
 
-__global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int sum_local) {
-    __shared__ double s0[16];
-    __shared__ double sImu[16];
-    const int tid = threadIdx.x;
+// The body of k_lm_decide for a workgroup of NT threads (256: the kernel; 1024: the extra workgroup of k_linearize that
+// runs the previous GN step's test).  Only the first 256 threads carry data and the wave partials are added in wave
+// order, so both give the same bits.
+template <int NT>
+__device__ void d_lm_decide(const DeviceTables &T, int mode, int sum_local, double *s0, double *sImu, int tid) {
     LmState *lm = T.lm;
     const double *part = (mode == 2) ? T.chi_part : T.step_part;
     // everything this kernel reads is requested before anything is waited for: one round trip, not five.  The prior
     // error is read from both state copies because which one counts depends on lm->cur, itself still in flight.
     const int cur = lm->cur;
     const double lambda = lm->lambda;
+    const bool act = tid < 256;
     double c = 0, s = 0, e0 = 0.0, e1 = 0.0, sp = 0.0;
-    if (sum_local)          // unsharded: fold k_step_sum in (same fixed order)
+    if (sum_local && act)   // unsharded: fold k_step_sum in (same fixed order)
         for (int e = tid; e < T.n_items; e += 256) { c += part[2 * e + STEP_CHI]; s += part[2 * e + STEP_SCALE]; }
-    if (T.has_prior)
+    if (T.has_prior && act)
         for (int i = tid; i < VIO_PRD; i += 256) { const double v0 = T.errprior[i], v1 = T.errprior[160 + i]; e0 += v0 * v0; e1 += v1 * v1; }
-    if (mode != 2)
+    if (mode != 2 && act)
         for (int i = tid; i < VIO_PD; i += 256) { const double d = T.dx[i]; sp += d * (lambda * d + T.bfull[i]); }
     if (tid < T.n_imu_items) sImu[tid] = part[2 * (T.n_items + tid) + STEP_CHI];
     const int which = (mode == 2) ? cur : (cur ^ 1);
     double e = which ? e1 : e0;
     if (sum_local) {
-        d_block_sum2<256>(c, s, s0, tid);
+        d_block_sum2<NT>(c, s, s0, tid);
         if (tid == 0) {
             T.step_tot[0] = c; T.step_tot[1] = s;
             if (T.gn_flags & 1) { T.vis[VIS_STEP] = c; T.vis[VIS_STEP + 1] = s; }     // ride along with the next all-reduce
         }
     }
-    d_block_sum2<256>(e, sp, s0, tid);
+    d_block_sum2<NT>(e, sp, s0, tid);
     const double en2 = e, scale_p = sp;
     if (tid != 0) return;
     double chi_imu = 0.0;
@@ -1571,6 +1585,12 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int
         if (lm->iter >= lm->max_iter) lm->stop = 1;
         if (!lm->stop && lm->iter < 128) { lm->chi_trace[lm->iter] = lm->chi; lm->lambda_trace[lm->iter] = lm->lambda; }
     }
+}
+
+__global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int sum_local) {
+    __shared__ double s0[8];
+    __shared__ double sImu[16];
+    d_lm_decide<256>(T, mode, sum_local, s0, sImu, threadIdx.x);
 }
 
 // ComputeLambdaInitLM (problem.cc:497-522)
@@ -1708,7 +1728,7 @@ void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(128), 0, s, T); }
 void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
+    hipLaunchKernelGGL(k_linearize, dim3(n_blocks + (T.decide_mode >= 0 ? 1 : 0)), dim3(LIN_THREADS), lds_bytes, s, T);
 }
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1), dim3(RED_THREADS), 0, s, R);

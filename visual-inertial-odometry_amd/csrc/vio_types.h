@@ -160,6 +160,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     double *chi_part;            // [n_step_blocks][2] partials of vio_chi2 (kept apart from a pending step test)
     int32_t n_step_blocks;
     int32_t gn_flags;            // sharded GN mode: bit 0 k_step_sum/k_lm_decide defer the landmark sums, bit 1 k_assemble finishes the previous step
+    int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur
+    int32_t decide_mode;         // >= 0: k_linearize carries one extra workgroup that runs the PREVIOUS step's k_lm_decide(mode)
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
     LmState *lm;
     unsigned long long *dbg;     // diagnostic builds only (-DVIO_STAMPS): [block][16] s_memtime stamps
