@@ -28,13 +28,14 @@ f.restype = C.c_int
 assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(nb)) == 0
 st = buf.astype(np.int64)
 valid = st[:, 5] > 0
-vis = valid & (st[:, 1] > 0)
+vis = valid & (st[:, 1] > 0) & (np.arange(nb) < (n + gmax - 1) // gmax) & (st[:, 5] - st[:, 0] < 10**7)
 imu = valid & (st[:, 1] == 0)
 names = ["load pair table", "phase 1 (per observation)", "phase 1.5 (per landmark)", "phase 2 (strips)", "combine + store"]
 d = np.diff(st[vis][:, :6], axis=1)
 print("visual workgroups: %d   (s_memtime ticks = 100 MHz?  constant clock; shares are what matters)" % vis.sum())
 for k, nm in enumerate(names):
     print("  %-28s mean %8.1f  max %8.1f" % (nm, d[:, k].mean(), d[:, k].max()))
+print("  inside phase 2, wave 0: product done after %.0f, vector sums done after %.0f (of the phase)" % ((st[vis][:, 6] - st[vis][:, 3]).mean(), (st[vis][:, 7] - st[vis][:, 3]).mean()))
 print("  total                        mean %8.1f  max %8.1f" % ((st[vis][:, 5] - st[vis][:, 0]).mean(), (st[vis][:, 5] - st[vis][:, 0]).max()))
 if imu.any():
     t = st[imu][:, 5] - st[imu][:, 0]

@@ -385,6 +385,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
 
     double *sPair = dyn_smem;                         // VIO_MAXK * PAIR_STRIDE
     double *sCam = sPair + VIO_MAXK * PAIR_STRIDE;    // ric, tic
+    double *sZero = sCam + 12;                        // a zero for the padding lanes of phase 2 (sCam holds 12 values)
     double *sRed = sCam + 16;                         // 2 * waves
     double *sRows = sRed + 2 * (LIN_THREADS / 64);    // K * PLANE
     double *sL = sRows + K * PLANE;                   // G * LREC
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         sPair[e] = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + o];
     }
     if (tid < 12) sCam[tid] = ptab[121 * PAIR_STRIDE + tid];
+    if (tid >= 12 && tid < 16) sCam[tid] = 0.0;
     __syncthreads();
 
     const double s_info = T.sqrt_info, info = s_info * s_info;
@@ -566,27 +568,41 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
                 // column -> offset inside a row record (host 0..5, target 6..11, extrinsic 12..17), + which of the 2 rows
                 const int oa = (cac < 6 ? offH + cac : (cac < 12 ? offT + cac - 6 : offE + cac - 12)) + (rg & 1) * 6;
                 const int ob = (cbc < 6 ? offH + cbc : (cbc < 12 ? offT + cbc - 6 : offE + cbc - 12)) + (rg & 1) * 6;
-                const double ma = ca < Dk ? 1.0 : 0.0, mb = cb < Dk ? 1.0 : 0.0;
-                const double *plane = sRows + k * PLANE;
-                const int chunks = (((G + 1) >> 1) + 3) >> 2;       // 4 rows = 2 landmarks per MFMA, 4 MFMAs per chunk
-                // operands of the next chunk are in flight while the matrix core works on this one
+                // Per-lane operand stream: element (landmark g, this lane's row of the pair, this lane's column) sits at
+                // pa + g * sa.  A padding column (>= Dk) streams a zero with stride 0 instead of being masked, so the
+                // steady state is loads and MFMAs only; the loads of chunk ch+1 are issued before the MFMAs of chunk ch
+                // and nothing touches them until the next iteration (no s_waitcnt in front of the matrix core).
+                const double *plane = sRows + k * PLANE + (rg >> 1) * RROW;
+                const double *pa = ca < Dk ? plane + oa : sZero;
+                const double *pb = cb < Dk ? plane + ob : sZero;
+                const int sa = ca < Dk ? 2 * RROW : 0, sb = cb < Dk ? 2 * RROW : 0;      // 2 landmarks per MFMA step
+                const bool same = t != 1;                            // diagonal tiles: B is A
+                const int steps_full = G >> 1;                       // steps whose two landmarks both exist
+                const int chunks_full = steps_full >> 2;
                 double va[4], vb[4], xa[4], xb[4];
-                auto load = [&](int ch, double *pa, double *pb) {
+                if (chunks_full > 0) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int g = 2 * (4 * ch + u) + (rg >> 1);
-                        const double *r = plane + min(g, G - 1) * RROW;
-                        pa[u] = r[oa] * (g < G ? ma : 0.0);
-                        pb[u] = r[ob] * mb;
+                    for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = same ? va[u] : pb[u * sb]; }
+                }
+                for (int ch = 0; ch < chunks_full; ++ch) {
+                    pa += 4 * sa; pb += 4 * sb;
+                    if (ch + 1 < chunks_full) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; if (!same) xb[u] = pb[u * sb]; }
                     }
-                };
-                load(0, va, vb);
-                for (int ch = 0; ch < chunks; ++ch) {
-                    if (ch + 1 < chunks) load(ch + 1, xa, xb);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], same ? va[u] : vb[u], acc, 0, 0, 0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { va[u] = xa[u]; vb[u] = xb[u]; }
+                }
+                // the remaining steps (fewer than 4 full ones, plus the half step of an odd G), landmark by landmark masked
+                for (int st = 4 * chunks_full; 2 * st < G; ++st) {
+                    const int g = 2 * st + (rg >> 1);
+                    const double m = g < G ? 1.0 : 0.0;
+                    const int gc = min(g, G - 1) - (rg >> 1);        // pa already points at landmark (rg >> 1)
+                    const double *qa = ca < Dk ? sRows + k * PLANE + (rg >> 1) * RROW + oa + (size_t)gc * RROW : sZero;
+                    const double *qb = cb < Dk ? sRows + k * PLANE + (rg >> 1) * RROW + ob + (size_t)gc * RROW : sZero;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0] * m, qb[0], acc, 0, 0, 0);
                 }
             } else {
                 const int ts = wk - K * ntd;
@@ -595,31 +611,42 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
                 const int tb = ts - ta * (ta + 1) / 2;
                 const int a = 16 * ta + cl, bq = 16 * tb + cl;
                 const int ac = min(a, D - 1), bc = min(bq, D - 1);
-                const double ma = a < D ? 1.0 : 0.0, mb = bq < D ? -1.0 : 0.0;
-                const int chunks = (((G + 3) >> 2) + 3) >> 2;       // 4 landmarks per MFMA
-                double va[4], vb[4], xa[4], xb[4];
-                auto load = [&](int ch, double *pa, double *pb) {
+                // same streaming as above: element (landmark g, column) at pa + g * LREC, 4 landmarks per MFMA step;
+                // B carries the -1/h_g of the landmark
+                const double *pa = a < D ? sL + (size_t)rg * LREC + ac : sZero;
+                const double *pb = bq < D ? sL + (size_t)rg * LREC + bc : sZero;
+                const double *ph = sL + (size_t)rg * LREC + 12 * nb;
+                const int sa = a < D ? 4 * LREC : 0, sb = bq < D ? 4 * LREC : 0, sh = 4 * LREC;
+                const int chunks_full = (G >> 2) >> 2;               // chunks whose 16 landmarks all exist
+                double va[4], vb[4], vh[4], xa[4], xb[4], xh[4];
+                if (chunks_full > 0) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int g = 4 * (4 * ch + u) + rg;
-                        const double *Lg = sL + (size_t)min(g, G - 1) * LREC;
-                        pa[u] = Lg[ac] * (g < G ? ma : 0.0);
-                        pb[u] = (Lg[bc] * Lg[12 * nb]) * mb;
+                    for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; vh[u] = ph[u * sh]; }
+                }
+                for (int ch = 0; ch < chunks_full; ++ch) {
+                    pa += 4 * sa; pb += 4 * sb; ph += 4 * sh;
+                    if (ch + 1 < chunks_full) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; xb[u] = pb[u * sb]; xh[u] = ph[u * sh]; }
                     }
-                };
-                load(0, va, vb);
-                for (int ch = 0; ch < chunks; ++ch) {
-                    if (ch + 1 < chunks) load(ch + 1, xa, xb);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], -(vb[u] * vh[u]), acc, 0, 0, 0);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { va[u] = xa[u]; vb[u] = xb[u]; }
+                    for (int u = 0; u < 4; ++u) { va[u] = xa[u]; vb[u] = xb[u]; vh[u] = xh[u]; }
+                }
+                for (int st = 16 * chunks_full; st < G; st += 4) {   // the remaining landmarks, masked
+                    const int g = st + rg, gc = min(g, G - 1);
+                    const double m = g < G ? 1.0 : 0.0;
+                    const double *Lg = sL + (size_t)gc * LREC;
+                    const double wa = a < D ? Lg[ac] : 0.0, wb = bq < D ? Lg[bc] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa * m, -(wb * Lg[12 * nb]), acc, 0, 0, 0);
                 }
             }
             double *tl = sTile + (size_t)wk * 256 + rg * 16 + cl;   // C/D image: row rg + 4v, column cl
 #pragma unroll
             for (int v = 0; v < 4; ++v) tl[64 * v] = acc[v];
         }
+        STAMP(T, 6);
         // b vectors: which 0: direct b = - sum_g bvec_g;  1: Schur correction = sum_g (b_l/h)_g w_g   (fixed order)
         // (by the waves that had no product to form, when there are any)
         const int v0 = min(nwork, LIN_THREADS / 64 - 1) * 64;
@@ -632,6 +659,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             }
             sVec[e] = sum;
         }
+        STAMP(T, 7);
     }
     __syncthreads();
 
