@@ -195,6 +195,40 @@ def main():
                         "sample": "%d GN iterations of the same %d-landmark / %d-observation window, oracle/vio_oracle.c "
                                   "(plain C, -O2, 1 thread)" % (steps, n, m)}
 
+    # the reference's own backend (compiled from its sources where they lie, oracle/_ref, by the recipe in oracle/Makefile;
+    # present when the repo was built where /root/reference exists): its dense (171+N)^2 solver needs 18 s and 13 GB per
+    # iteration at N = 20 000, so it is timed on a 2 000-landmark window of the same generator and reported beside the port
+    cpu_reference = None
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libvio_ref.so")
+    if cpu_baseline is not None and os.path.exists(ref_so):
+        try:
+            rl = vio.VioLib(ref_so, "vior_")
+            wr = vio.synth.make_window(2000, seed=42, obs_per_landmark=k_obs)
+            cr = rl.context()
+            cr.load(wr)
+            cr.linearize()
+            _, lam_r = cr.init_lm()
+            cr.gn_iteration(lam_r)
+            t = time.perf_counter()
+            nref = 5
+            for _ in range(nref):
+                cr.gn_iteration(lam_r)
+            dt = time.perf_counter() - t
+            co2 = orc.context()
+            co2.load(wr)
+            co2.gn_iteration(lam_r)
+            t = time.perf_counter()
+            for _ in range(50):
+                co2.gn_iteration(lam_r)
+            dto = (time.perf_counter() - t) / 50
+            cpu_reference = {"value": nref / dt, "unit": "GN iter/s", "cores": 1, "kind": "reference",
+                             "ms_per_iter": dt * 1e3 / nref, "port_ms_per_iter_same_window": dto * 1e3,
+                             "sample": "%d GN iterations of a 2000-landmark / %d-observation window (the reference's dense "
+                                       "solver is O(N^2): 18 s per iteration at N = 20000, BASELINE.md section 2), "
+                                       "oracle/_ref/libvio_ref.so, 1 thread" % (nref, wr.n_observations)}
+        except Exception as exc:       # the reference library is optional test infrastructure
+            cpu_reference = {"error": str(exc)}
+
     if rank == 0:
         out = {
             "metric": "GN iterations/s, 11-frame (10-keyframe) window, 20k landmarks per GPU",
@@ -210,6 +244,7 @@ def main():
             "final_chi2": chi2,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "cpu_reference": cpu_reference,
         }
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL's version banner sits in C stdio's buffer: keep the JSON line last
