@@ -1,24 +1,28 @@
 """Sliding-window stream driver over synthetic data.
 
-Host-side control flow of `Estimator::processImage` -> `backendOptimization` -> `slideWindow` for a stream of
-keyframes, with any library that exports the C ABI as the backend:
+Host-side control flow of `Estimator::processImage` -> `solveOdometry` -> `slideWindow` for a stream of frames, with
+any library that exports the C ABI as the backend:
 
-    per new keyframe:   predict its state from the last one with the pre-integrated IMU (processIMU,
-                        VM/src/estimator.cpp:105-139), vector2double (:505-547), Solve(10) with the prior
-                        (problemSolve :902-1073), double2vector's yaw/position re-anchoring (:549-600),
-                        MargOldFrame (:693-829), slide the window by one frame (slideWindowOld :1144-1200).
+    per new frame:   predict its state from the last one with the pre-integrated IMU (processIMU,
+                     VM/src/estimator.cpp:105-139), [f_manager.triangulate], vector2double (:505-547), Solve(10) with the
+                     prior (problemSolve :902-1073), double2vector's yaw/position re-anchoring (:549-600), then
+      keyframe       MargOldFrame (:693-829), slideWindowOld (:1187-1199): the oldest frame leaves; landmarks hosted
+                     in it move to their next frame with the depth carried over (removeBackShiftDepth,
+                     feature_manager.cpp:276-312) or die with it
+      non-keyframe   MargNewFrame (:830-901), slideWindowNew (:1201-1206): the second-newest frame leaves, its
+                     observations are dropped (removeFront, feature_manager.cpp:331-350), its IMU samples are appended
+                     to the interval before it (pre_integrations[frame_count - 1]->push_back, :1163-1176)
 
-Simplifications against the reference (this is the "next" row, not the graded hot path): every frame is a keyframe
-(always MARGIN_OLD), and a landmark hosted in the marginalised frame leaves the window instead of being re-hosted
-(`removeBackShiftDepth`, feature_manager.cpp:276-312).  Poses are written in TUM format (`stamp px py pz qx qy qz qw`,
-System.cpp:438) so that `evo_ape tum` can be run on the output.
+Which frames are keyframes is the front-end's call (the parallax test of addFeatureCheckParallax); here it is a
+parameter (`nonkey_every`).  Poses are written in TUM format (`stamp px py pz qx qy qz qw`, System.cpp:438) so that
+`evo_ape tum` can be run on the output.
 """
 import math
 
 import numpy as np
 
 from . import synth
-from .capi import MARG_OLD, NUM_FRAMES, WINDOW_SIZE
+from .capi import MARG_OLD, MARG_SECOND_NEW, NUM_FRAMES, WINDOW_SIZE
 
 
 def r2ypr(R):
@@ -72,9 +76,11 @@ class SyntheticStream:
         self.ext = np.concatenate([synth.T_IC, synth.rot_to_quat(synth.R_IC)])
         n_sub = int(round(frame_dt * imu_rate))
         dt = frame_dt / n_sub
-        self.preint = []            # preint[k]: frame k -> k+1
+        self.preint, self.imu = [], []      # [k]: frame k -> k+1: pre-integration and the raw samples it was made of
         for k in range(n_frames - 1):
             ms = [synth.motion_model(self.times[k] + j * dt) for j in range(n_sub + 1)]
+            self.imu.append(dict(acc0=ms[0].acc, gyr0=ms[0].gyro, dt=[dt] * n_sub, acc=[m.acc for m in ms[1:]],
+                                 gyr=[m.gyro for m in ms[1:]]))
             self.preint.append(synth.preintegrate(ms[0].acc, ms[0].gyro, np.zeros(3), np.zeros(3), [dt] * n_sub,
                                                   [m.acc for m in ms[1:]], [m.gyro for m in ms[1:]]))
         # landmarks: hosted in frame h, seen in h+1 .. h+track_len
@@ -98,15 +104,21 @@ class SyntheticStream:
 
 class StreamDriver:
     def __init__(self, lib, stream, ctx_kwargs=None, pos_noise=0.02, rot_noise=0.005, depth_noise=0.05, seed=1,
-                 triangulate=False):
+                 triangulate=False, nonkey_every=0):
         """triangulate=True: a landmark's first depth comes from FeatureManager::triangulate (vio_triangulate, on the
         current pose estimates, feature_manager.cpp:203-257) the first time it enters a solve, as in
-        Estimator::solveOdometry (estimator.cpp:489-503), instead of from the perturbed ground truth."""
+        Estimator::solveOdometry (estimator.cpp:489-503), instead of from the perturbed ground truth.
+        nonkey_every=n > 0: every n-th frame is not a keyframe: when it is the second-newest frame of the window it is
+        marginalised (MARGIN_SECOND_NEW) instead of the oldest one."""
         self.lib, self.s = lib, stream
         self.ctx = lib.context(**(ctx_kwargs or {}))
         rng = np.random.RandomState(seed)
         st = stream
-        self.start = 0
+        self.frames = list(range(NUM_FRAMES))              # global index of the frame in each window slot
+        self.intervals = [dict(st.imu[k]) for k in range(WINDOW_SIZE)]     # raw IMU between consecutive window frames
+        self.preint = [st.preint[k] for k in range(WINDOW_SIZE)]
+        self.next_frame = NUM_FRAMES
+        self.nonkey_every = nonkey_every
         self.poses = np.zeros((NUM_FRAMES, 7))
         self.sb = np.zeros((NUM_FRAMES, 9))
         for i in range(NUM_FRAMES):
@@ -117,59 +129,98 @@ class StreamDriver:
             self.poses[i, 3:7] = synth.quat_mul(st.Q[i], dq)
             self.sb[i, 0:3] = st.V[i]
         self.ext = st.ext.copy()
-        self.inv_depth = 1.0 / (np.array(st.lm_depth) * (1.0 + depth_noise * st.init_noise))
+        # tracks (FeaturePerId): landmark -> list of (global frame, normalised point), the first one is the host
+        self.tracks = {}
+        for f in self.frames:
+            self.add_frame_observations(f)
+        self.depth = {}                                    # landmark -> estimated depth in its current host frame
+        self.init_depth = np.array(st.lm_depth) * (1.0 + depth_noise * st.init_noise)
         self.triangulate = triangulate
-        self.have_depth = np.zeros(len(st.lm_host), dtype=bool) if triangulate else np.ones(len(st.lm_host), dtype=bool)
         self.prior = None
         self.trajectory = []        # (stamp, pose[7]) of the newest frame after every solve
         self.reports = []
+        self.flags = []             # marginalisation flag of every step
+        self.n_triangulated = 0
+
+    # ---- feature bookkeeping (FeatureManager) ---------------------------------------------------------
+    def add_frame_observations(self, f):
+        st = self.s
+        for l, h in enumerate(st.lm_host):
+            if h == f:
+                self.tracks[l] = [(f, np.asarray(st.lm_px[l], dtype=np.float64))]
+            elif l in self.tracks and f in st.lm_obs[l] and self.tracks[l][-1][0] == self.prev_of(f):
+                self.tracks[l].append((f, np.asarray(st.lm_obs[l][f], dtype=np.float64)))
+
+    def prev_of(self, f):
+        """The window frame in front of global frame f (tracks are consecutive in window frames)."""
+        fr = self.frames if f in self.frames else self.frames + [f]
+        i = fr.index(f)
+        return fr[i - 1] if i > 0 else None
+
+    def usable(self):
+        """(landmark, window index of its host) of the tracks the optimiser takes: used_num >= 2 and
+        start_frame < WINDOW_SIZE - 2 (estimator.cpp:979-981)."""
+        out = []
+        for l, tr in self.tracks.items():
+            start = self.frames.index(tr[0][0])
+            if len(tr) >= 2 and start < WINDOW_SIZE - 2:
+                out.append((l, start))
+        return out
+
+    def ensure_depths(self):
+        """First depth of the tracks that have none: triangulation on the current poses, or perturbed ground truth."""
+        todo = [(l, start) for l, start in self.usable() if l not in self.depth]
+        if not todo:
+            return
+        if not self.triangulate:
+            for l, _ in todo:
+                self.depth[l] = float(self.init_depth[l])
+            return
+        sf, off, pts = [], [0], []
+        for l, start in todo:
+            sf.append(start); pts.extend(p for _, p in self.tracks[l]); off.append(off[-1] + len(self.tracks[l]))
+        d = self.ctx.triangulate(np.array(sf, dtype=np.int32), np.array(off, dtype=np.int64), np.array(pts).reshape(-1, 2),
+                                 self.poses, self.ext, -np.ones(len(todo)))
+        for (l, _), v in zip(todo, d):
+            self.depth[l] = float(v)
+        self.n_triangulated += len(todo)
 
     def window_arrays(self):
-        s, st = self.start, self.s
-        ids, lm, host, target, pi, pj = [], [], [], [], [], []
-        for l, h in enumerate(st.lm_host):
-            # estimator.cpp:979-981: used_num >= 2 and start_frame < WINDOW_SIZE - 2, restricted to this window
-            if h < s or h - s >= WINDOW_SIZE - 2:
-                continue
-            obs = [(j, o) for j, o in sorted(st.lm_obs[l].items()) if j <= s + WINDOW_SIZE]
-            if not obs:
-                continue
+        ids, lm, host, target, pi, pj, invd = [], [], [], [], [], [], []
+        for l, start in self.usable():
             k = len(ids)
             ids.append(l)
-            for j, o in obs:
-                lm.append(k); host.append(h - s); target.append(j - s); pi.append(st.lm_px[l]); pj.append(o)
+            invd.append(1.0 / self.depth[l])
+            tr = self.tracks[l]
+            for j in range(1, len(tr)):
+                lm.append(k); host.append(start); target.append(start + j); pi.append(tr[0][1]); pj.append(tr[j][1])
         w = synth.Window(poses=self.poses.copy(), speed_bias=self.sb.copy(), ext=self.ext.copy(),
-                         inv_depth=self.inv_depth[ids].copy(), lm=np.array(lm, dtype=np.int32),
+                         inv_depth=np.array(invd), lm=np.array(lm, dtype=np.int32),
                          host=np.array(host, dtype=np.int32), target=np.array(target, dtype=np.int32),
                          pts_i=np.array(pi).reshape(-1, 2), pts_j=np.array(pj).reshape(-1, 2),
-                         preint=[st.preint[s + k] for k in range(WINDOW_SIZE)], prior=self.prior,
+                         preint=list(self.preint), prior=self.prior,
                          n_landmarks=len(ids), n_observations=len(lm))
-        return w, np.array(ids, dtype=np.int64)
+        return w, ids
 
-    def triangulate_new(self):
-        """f_manager.triangulate(Ps, tic, ric) of solveOdometry: depths of the tracks that have none yet."""
-        s, st = self.start, self.s
-        todo, sf, off, pts = [], [], [0], []
-        for l, h in enumerate(st.lm_host):
-            if self.have_depth[l] or h < s or h - s >= WINDOW_SIZE - 2:
-                continue
-            obs = [o for j, o in sorted(st.lm_obs[l].items()) if j <= s + WINDOW_SIZE]
-            if not obs:
-                continue
-            todo.append(l); sf.append(h - s); pts.append(st.lm_px[l]); pts.extend(obs); off.append(off[-1] + 1 + len(obs))
-        if not todo:
-            return 0
-        depth = self.ctx.triangulate(np.array(sf, dtype=np.int32), np.array(off, dtype=np.int64), np.array(pts).reshape(-1, 2),
-                                     self.poses, self.ext, -np.ones(len(todo)))
-        self.inv_depth[todo] = 1.0 / depth
-        self.have_depth[todo] = True
-        return len(todo)
+    @property
+    def inv_depth(self):
+        """Inverse depths by landmark id (NaN where the landmark never got one) — what the tests compare."""
+        out = np.full(len(self.s.lm_host), np.nan)
+        for l, d in self.depth.items():
+            out[l] = 1.0 / d
+        return out
 
+    @property
+    def have_depth(self):
+        out = np.zeros(len(self.s.lm_host), dtype=bool)
+        out[list(self.depth.keys())] = True
+        return out
+
+    # ---- one frame ------------------------------------------------------------------------------------
     def step(self):
-        """One keyframe: solve, re-anchor, marginalise the oldest frame, slide.  Returns False at the end."""
+        """Solve the current window, marginalise, slide, take in the next frame.  Returns False at the end."""
         st = self.s
-        if self.triangulate:
-            self.triangulate_new()
+        self.ensure_depths()
         w, ids = self.window_arrays()
         self.ctx.load(w)
         rep = self.ctx.solve(10)
@@ -179,29 +230,92 @@ class StreamDriver:
             b, e = self.ctx.get_prior()
             self.prior = dict(self.prior, b=b[:156].copy(), err=e.copy())
         self.poses, self.sb = anchor_gauge(w.poses, poses, sb)
-        self.inv_depth[ids] = invd
-        newest = self.start + WINDOW_SIZE
+        for l, v in zip(ids, invd):
+            self.depth[l] = 1.0 / v
+        newest = self.frames[WINDOW_SIZE]
         self.trajectory.append((st.times[newest], self.poses[WINDOW_SIZE].copy()))
         self.reports.append(rep)
-        # MargOldFrame on the re-anchored states (backendOptimization, estimator.cpp:1086-1092)
+        second_new = self.frames[WINDOW_SIZE - 1]
+        margin_old = not (self.nonkey_every and second_new % self.nonkey_every == self.nonkey_every - 1)
+        self.flags.append(MARG_OLD if margin_old else MARG_SECOND_NEW)
+        # backendOptimization marginalises on the re-anchored states (estimator.cpp:1086-1102)
         w2, _ = self.window_arrays()
         self.ctx.load(w2)
-        self.prior = self.ctx.marginalize(MARG_OLD)
-        if newest + 1 >= st.n_frames:
+        self.prior = self.ctx.marginalize(MARG_OLD if margin_old else MARG_SECOND_NEW)
+        if self.next_frame >= st.n_frames:
             return False
-        # slideWindowOld + processIMU prediction of the new frame
-        self.poses[:-1], self.sb[:-1] = self.poses[1:].copy(), self.sb[1:].copy()
-        pre = st.preint[newest]
-        dt = pre["sum_dt"]
-        Ri = synth.quat_to_rot(self.poses[WINDOW_SIZE - 1, 3:7])
-        g = np.array([0.0, 0.0, synth.G_NORM])
-        Pi, Vi = self.poses[WINDOW_SIZE - 1, 0:3], self.sb[WINDOW_SIZE - 1, 0:3]
-        self.poses[WINDOW_SIZE, 0:3] = Pi + Vi * dt - 0.5 * g * dt * dt + Ri @ pre["delta_p"]
-        self.poses[WINDOW_SIZE, 3:7] = synth.quat_mul(self.poses[WINDOW_SIZE - 1, 3:7], pre["delta_q"])
-        self.sb[WINDOW_SIZE, 0:3] = Vi - g * dt + Ri @ pre["delta_v"]
-        self.sb[WINDOW_SIZE, 3:9] = self.sb[WINDOW_SIZE - 1, 3:9]
-        self.start += 1
+        if margin_old:
+            self.slide_window_old()
+        else:
+            self.slide_window_new()
+        self.take_next_frame()
         return True
+
+    def slide_window_old(self):
+        """slideWindowOld (estimator.cpp:1144-1199) + removeBackShiftDepth (feature_manager.cpp:276-312)."""
+        gone = self.frames[0]
+        R0 = synth.quat_to_rot(self.poses[0, 3:7]); R1 = synth.quat_to_rot(self.poses[1, 3:7])
+        ric, tic = synth.quat_to_rot(self.ext[3:7]), self.ext[0:3]
+        mR, mP, nR, nP = R0 @ ric, self.poses[0, 0:3] + R0 @ tic, R1 @ ric, self.poses[1, 0:3] + R1 @ tic
+        for l in list(self.tracks.keys()):
+            tr = self.tracks[l]
+            if tr[0][0] != gone:
+                continue
+            uv = np.array([tr[0][1][0], tr[0][1][1], 1.0])
+            del tr[0]
+            if len(tr) < 2:
+                del self.tracks[l]
+                self.depth.pop(l, None)
+                continue
+            if l in self.depth:
+                pj = nR.T @ (mR @ (uv * self.depth[l]) + mP - nP)
+                self.depth[l] = float(pj[2]) if pj[2] > 0 else 5.0       # INIT_DEPTH
+        self.frames.pop(0)
+        self.intervals.pop(0)
+        self.preint.pop(0)
+        self.poses[:-1], self.sb[:-1] = self.poses[1:].copy(), self.sb[1:].copy()
+
+    def slide_window_new(self):
+        """slideWindowNew (estimator.cpp:1201-1206, the frame_count - 1 branch of :1163-1186) + removeFront."""
+        gone = self.frames[WINDOW_SIZE - 1]
+        for l in list(self.tracks.keys()):
+            tr = [o for o in self.tracks[l] if o[0] != gone]
+            if not tr:
+                del self.tracks[l]
+                self.depth.pop(l, None)
+            else:
+                self.tracks[l] = tr
+        # the IMU samples of the newest interval are appended to the one before it
+        a, b = self.intervals[WINDOW_SIZE - 2], self.intervals[WINDOW_SIZE - 1]
+        merged = dict(acc0=a["acc0"], gyr0=a["gyr0"], dt=a["dt"] + b["dt"], acc=a["acc"] + b["acc"], gyr=a["gyr"] + b["gyr"])
+        self.intervals[WINDOW_SIZE - 2:] = [merged]
+        self.preint[WINDOW_SIZE - 2:] = [synth.preintegrate(merged["acc0"], merged["gyr0"], np.zeros(3), np.zeros(3),
+                                                           merged["dt"], merged["acc"], merged["gyr"])]
+        self.frames.pop(WINDOW_SIZE - 1)
+        self.poses[WINDOW_SIZE - 1], self.sb[WINDOW_SIZE - 1] = self.poses[WINDOW_SIZE].copy(), self.sb[WINDOW_SIZE].copy()
+
+    def take_next_frame(self):
+        """The next image: processIMU's propagation of the newest state, then the frame's observations."""
+        st = self.s
+        f = self.next_frame
+        self.next_frame += 1
+        last = self.frames[-1]
+        # raw samples from `last` to f (consecutive global frames unless frames were skipped: they never are here)
+        iv = dict(st.imu[last])
+        pre = st.preint[last]
+        self.frames.append(f)
+        self.intervals.append(iv)
+        self.preint.append(pre)
+        dt = pre["sum_dt"]
+        i = WINDOW_SIZE - 1
+        Ri = synth.quat_to_rot(self.poses[i, 3:7])
+        g = np.array([0.0, 0.0, synth.G_NORM])
+        Pi, Vi = self.poses[i, 0:3], self.sb[i, 0:3]
+        self.poses[WINDOW_SIZE, 0:3] = Pi + Vi * dt - 0.5 * g * dt * dt + Ri @ pre["delta_p"]
+        self.poses[WINDOW_SIZE, 3:7] = synth.quat_mul(self.poses[i, 3:7], pre["delta_q"])
+        self.sb[WINDOW_SIZE, 0:3] = Vi - g * dt + Ri @ pre["delta_v"]
+        self.sb[WINDOW_SIZE, 3:9] = self.sb[i, 3:9]
+        self.add_frame_observations(f)
 
     def run(self):
         while self.step():
