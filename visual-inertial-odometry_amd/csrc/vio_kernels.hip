@@ -4,19 +4,23 @@
 //
 //   k_linearize   MakeHessian (problem.cc:303-389) for all reprojection edges (edge_reprojection.cc:18-109,
 //                 edge.cc:48-74) + the per-landmark Schur terms of SolveLinearSystem (problem.cc:412-429),
-//                 one workgroup per item (<= 64 landmarks sharing a (host, targets) pattern); IMU edges
-//                 (edge_imu.cc:13-156, integration_base.h:160-186) ride in the same grid
+//                 one workgroup of 1024 threads per item (48..96 landmarks sharing a (host, targets) pattern), the
+//                 item's blocks formed as fp64 MFMA tiles; IMU edges (edge_imu.cc:13-156,
+//                 integration_base.h:160-186) ride in the same grid, and in GN mode so does the previous step's test
 //   k_reduce      fixed-order sum of the per-item partial blocks -> 72x72 reduced visual system
-//   k_assemble    + IMU blocks + prior (problem.cc:365-384) -> H_pp_schur_, b_pp_schur_ (171)
-//   k_pose_solve  + lambda (problem.cc:434-436), pivoted LDLT (Eigen LDLT, problem.cc:439), pose update
-//                 (UpdateStates :453-480, vertex_pose.cc:7-19), prior first-order update (:473-474)
+//   k_assemble    + IMU blocks + prior (problem.cc:365-384) -> H_pp_schur_, b_pp_schur_ (171), in Eigen's pivot
+//                 order, as 16x16 tiles
+//   k_pose_solve  + lambda (problem.cc:434-436), LDLT in that order (Eigen LDLT, problem.cc:439) blocked on fp64
+//                 MFMA tiles with look-ahead, pose update (UpdateStates :453-480, vertex_pose.cc:7-19), prior
+//                 first-order update (:473-474)
 //   k_backsub     landmark back-substitution (problem.cc:445), landmark update, chi2 of the trial state
 //                 (IsGoodStepInLM :549-556)
 //   k_lm_decide   gain ratio + Nielsen update + accept/rollback (IsGoodStepInLM :541-573, Solve :188-245)
+// and, either side of the solve:
+//   k_triangulate FeatureManager::triangulate (feature_manager.cpp:203-257), one thread per track
 //
 // All arithmetic is fp64.  Every reduction has a fixed order (no float atomics), so results are bitwise
-// reproducible run to run.  wave = 64 lanes; workgroups of 256 threads (4 waves) except the 1024-thread
-// single-workgroup dense solve.
+// reproducible run to run.  wave = 64 lanes.
 #include <hip/hip_runtime.h>
 
 #include "vio_device_math.h"
