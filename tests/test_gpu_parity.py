@@ -360,3 +360,28 @@ def test_native_rccl_exchange_on_one_rank(vio, hip_lib):
     np.testing.assert_array_equal(sb.ctx.get_landmarks(), ref.get_landmarks())
     assert sb.ctx.chi2() == ref.chi2()
     sb.ctx.comm_destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k_obs,ext_fixed,n", [(10, 0, 600), (10, 1, 3000), (7, 0, 1500), (1, 1, 200)])
+def test_long_tracks_and_free_extrinsic(vio, oracle_lib, hip_lib, k_obs, ext_fixed, n):
+    """The widest patterns a window can hold: up to 10 observations per landmark (12 pattern blocks with a free
+    extrinsic: 45 MFMA products per item in k_linearize, 15 Schur tiles), and the other end, one observation."""
+    w = vio.synth.make_window(n, seed=100 + k_obs, obs_per_landmark=k_obs)
+    ch, co = hip_lib.context(ext_fixed=ext_fixed), oracle_lib.context(ext_fixed=ext_fixed)
+    ch.load(w); co.load(w)
+    ch.linearize(); co.linearize()
+    Hh, bh = ch.get_schur_system()
+    Ho, bo = co.get_schur_system()
+    scale = np.abs(Ho).max()
+    assert np.abs(Hh - Ho).max() <= 1e-11 * scale
+    assert np.abs(bh - bo).max() <= 1e-11 * max(np.abs(bo).max(), 1.0)
+    chi_h, lam_h = ch.init_lm()
+    chi_o, lam_o = co.init_lm()
+    assert abs(chi_h - chi_o) <= 1e-11 * chi_o and abs(lam_h - lam_o) <= 1e-11 * lam_o
+    ch.solve_linear(lam_o); co.solve_linear(lam_o)
+    dh, _ = ch.get_delta()
+    do, _ = co.get_delta()
+    assert np.abs(dh - do).max() <= 1e-8 * max(np.abs(do).max(), 1e-12)
+    rh, ro = ch.solve(10), co.solve(10)
+    assert rh.final_chi2 <= 1.0001 * ro.final_chi2 + 1e-9

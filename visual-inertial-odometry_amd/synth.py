@@ -194,7 +194,7 @@ def make_window(n_landmarks, seed=42, obs_per_landmark=4, t0=1.0, imu_rate=200, 
         host_of = rng.randint(0, WINDOW_SIZE - 1, size=N)
         k_of = np.array([rng.randint(1, WINDOW_SIZE - h + 1) for h in host_of])
     else:
-        host_of = np.arange(N) % 7
+        host_of = np.arange(N) % max(1, min(7, WINDOW_SIZE + 1 - int(obs_per_landmark)))    # host + K <= 10
         k_of = np.full(N, int(obs_per_landmark))
     px = rng.uniform(-0.5, 0.5, size=(N, 2))
     depth = rng.uniform(4.0, 10.0, size=N)
