@@ -79,6 +79,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VIO_BENCH_ONE_DEVICE") == "1":      # diagnostic: all ranks on device 0 (if RCCL lets them)
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:

@@ -26,15 +26,16 @@ struct ReduceTables {
     const int32_t *list;
     const double *slab;
     double *vis;
+    const double *step_part;
+    int32_t n_step;
 };
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s);
 void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s);
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s);
-void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
+void vio_launch_backsub(const DeviceTables &T, int mode, int lite, hipStream_t s);
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s);
-void vio_launch_gn_finish(const DeviceTables &T, hipStream_t s);
 void vio_launch_triangulate(const TriTables &Q, hipStream_t s);
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s);
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s);
@@ -133,9 +134,8 @@ struct vio_ctx {
     LmState h_lm;
     vio_exchange_fn hook = nullptr;
     void *comm = nullptr;                              // ncclComm_t of the native exchange (vio_comm_init)
-    bool gn_pending = false;                           // sharded GN mode: the last step's landmark sums ride with the next all-reduce
     int cur_host = -1;                                 // LmState.cur as the host tracks it through GN iterations (-1: unknown)
-    bool decide_pending = false;                       // GN mode: the last step's k_lm_decide has not run yet (it rides in the next k_linearize)
+    bool decide_pending = false;                       // GN mode: the last step's test has not run yet (k_assemble of the next iteration does it)
     void *hook_user = nullptr;
     double hessian_ms = 0;
     double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
@@ -366,7 +366,7 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     T.has_prior = c->has_prior; T.add_imu_prior = 1; T.natural_hs = (pl.marg || c->want_natural_hs) ? 1 : 0;
     T.Hs = c->d_Hs.p; T.Pg = c->d_Pg.p; T.perm = c->d_perm.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
-    T.gn_flags = 0; T.cur_hint = -1; T.decide_mode = -1;
+    T.gn_flags = 0; T.cur_hint = -1;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
 #ifdef VIO_STAMPS
@@ -378,38 +378,34 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
 
 vio_status run_exchange(vio_ctx *c, int which);
 
-// GN mode folds the step test of iteration i into k_linearize of iteration i+1; whoever touches the device outside
-// that loop gets it run first, as its own launch.
-void flush_decide(vio_ctx *c) {
-    if (!c->decide_pending || !c->active) return;
-    DeviceTables T = make_tables_raw(c, *c->active);
-    if (c->comm) T.gn_flags = 1;
-    vio_launch_lm_decide(T, 1, 1, c->stream);
+// GN mode leaves the chi2 evaluation and the step test of iteration i to iteration i+1 (k_linearize computes that chi2
+// anyway, k_assemble runs the test); whoever touches the device outside that loop gets them done first, the classic
+// way: k_backsub once more in full (the landmark update it repeats is idempotent), then k_lm_decide.
+vio_status flush_decide(vio_ctx *c) {
+    if (!c->decide_pending || !c->active) return VIO_OK;
     c->decide_pending = false;
+    DeviceTables T = make_tables_raw(c, *c->active);
+    vio_launch_backsub(T, 0, 0, c->stream);
+    if (c->hook || c->comm) {
+        vio_launch_step_sum(T, 0, c->stream);
+        VIOCHK(run_exchange(c, 1));
+        vio_launch_lm_decide(T, 1, 0, c->stream);
+    } else {
+        vio_launch_lm_decide(T, 1, 1, c->stream);
+    }
+    return VIO_OK;
 }
 
 // tables for every path but the GN loop: bring the device's LmState up to date first; the host's idea of `cur` is void
 // until the next read_lm
 DeviceTables make_tables(vio_ctx *c, Plan &pl) {
-    flush_decide(c);
+    (void)flush_decide(c);
     c->cur_host = -1;
     return make_tables_raw(c, pl);
 }
 
-// sharded GN mode leaves the last step's landmark sums un-reduced until the next linearisation's all-reduce; anyone
-// who wants LmState before that gets them reduced here (a collective: every rank reads at the same point)
-vio_status flush_gn_pending(vio_ctx *c) {
-    if (!c->gn_pending || !c->active) return VIO_OK;
-    VIOCHK(run_exchange(c, 3));
-    DeviceTables T = make_tables(c, *c->active);
-    vio_launch_gn_finish(T, c->stream);
-    c->gn_pending = false;
-    return VIO_OK;
-}
-
 vio_status read_lm(vio_ctx *c) {
-    flush_decide(c);
-    VIOCHK(flush_gn_pending(c));
+    VIOCHK(flush_decide(c));
     HIPCHK(hipMemcpyAsync(&c->h_lm, c->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->cur_host = c->h_lm.cur;
@@ -456,7 +452,7 @@ vio_status push_to_device(vio_ctx *c, Plan &pl) {
     c->h_lm.ni = 2; c->h_lm.lambda = -1; c->h_lm.finite = 1; c->h_lm.last_chi = 1e20;
     HIPCHK(hipMemcpyAsync(c->d_lm.p, &c->h_lm, sizeof(LmState), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));      // the staging vectors above go out of scope
-    c->decide_pending = false; c->gn_pending = false; c->cur_host = 0;      // a fresh LmState: nothing of the old one is owed
+    c->decide_pending = false; c->cur_host = 0;      // a fresh LmState: nothing of the old one is owed
     return VIO_OK;
 }
 
@@ -535,8 +531,7 @@ RcclApi *rccl_api(std::string &err) {
 
 inline bool sharded(const vio_ctx *c) { return c->hook != nullptr || c->comm != nullptr; }
 
-// which == 0: reduced visual system (sum), 1: the two step scalars (sum), 2: max |h_ll| (max, step buffer slot 2),
-// 3 (native only): the two deferred GN step scalars parked in vis[VIS_STEP..] (sum)
+// which == 0: reduced visual system (sum), 1: the two step scalars (sum), 2: max |h_ll| (max, step buffer slot 2)
 vio_status run_exchange(vio_ctx *c, int which) {
     if (c->comm) {
         std::string err;
@@ -544,8 +539,8 @@ vio_status run_exchange(vio_ctx *c, int which) {
         if (!api) return fail(c, VIO_ERR_HIP, err);
         double *vis = c->ext_vis ? c->ext_vis : c->d_vis.p;
         double *step = c->ext_step ? c->ext_step : c->d_step_tot.p;
-        double *buf = which == 0 ? vis : (which == 1 ? step : (which == 2 ? step + 2 : vis + VIS_STEP));
-        const size_t count = which == 0 ? (size_t)VIS_MAXH : (which == 2 ? 1 : 2);
+        double *buf = which == 0 ? vis : (which == 1 ? step : step + 2);
+        const size_t count = which == 0 ? (size_t)VIS_MAXH : (which == 1 ? 2 : 1);
         const int rc = api->AllReduce(buf, buf, count, /*ncclDouble*/ 8, which == 2 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, c->comm, c->stream);
         if (rc != 0) return fail(c, VIO_ERR_HIP, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
         return VIO_OK;
@@ -556,20 +551,18 @@ vio_status run_exchange(vio_ctx *c, int which) {
 }
 
 // prepare (if needed) + linearize + reduce + [exchange] + assemble at the current state
-// gn = true: the GN loop (vio_gn_iteration): `cur` comes from the host, the previous step's test rides in k_linearize
+// gn = true: the GN loop (vio_gn_iteration): `cur` comes from the host; when a step is waiting for its test, k_reduce also
+// sums its gain-ratio partials and k_assemble runs the test on the chi2 this very linearisation computes
 vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false) {
     DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
-    if (gn) {
-        T.cur_hint = c->cur_host;
-        if (c->decide_pending) { T.decide_mode = 1; if (c->comm) T.gn_flags = 1; }
-    }
+    const bool test_prev = gn && c->decide_pending;
+    if (gn) T.cur_hint = c->cur_host;
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
     { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
-    if (T.decide_mode >= 0) { c->decide_pending = false; T.decide_mode = -1; T.gn_flags = 0; }
-    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis};
+    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items};
     { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
     VIOCHK(run_exchange(c, 0));
-    if (c->gn_pending) { T.gn_flags = 2; c->gn_pending = false; }       // the previous GN step's sums just came back with vis
+    if (test_prev) { T.gn_flags = 1; c->decide_pending = false; }
     { ProfScope ps(c, VIO_K_ASSEMBLE); vio_launch_assemble(T, c->stream); }
     HIPCHK(hipGetLastError());
     c->linearized = true;
@@ -594,33 +587,22 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false) {
     DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
     if (gn) T.cur_hint = c->cur_host;
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
-    { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, c->stream); }
     if (gn) {
-        // the step is accepted whatever chi2 turns out to be: its test (k_lm_decide, mode 1) is not launched here but
-        // rides in the next k_linearize (flush_decide runs it when anybody else asks first); with the native exchange
-        // its two landmark sums ride in the next all-reduce
+        // the step is accepted whatever chi2 turns out to be: only the landmark update runs here; the chi2 of the new
+        // state and the step test belong to the next iteration (flush_decide does them when anybody else asks first)
+        { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, 1, c->stream); }
         c->decide_pending = true;
-        if (c->comm) c->gn_pending = true;
         c->cur_host ^= 1;
         HIPCHK(hipGetLastError());
         c->device_ahead = true;
         return VIO_OK;
     }
+    { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, 0, c->stream); }
     if (sharded(c)) {
-        // GN mode with the native exchange: a step is always accepted, nothing downstream waits for chi2, so the two
-        // landmark sums are not all-reduced here but ride along with the next linearisation's all-reduce
-        const bool defer = mode == 1 && c->comm != nullptr;
-        if (defer) {
-            T.gn_flags = 1;             // k_lm_decide sums the partials itself and parks the sums in vis[VIS_STEP..]
-            ProfScope ps(c, VIO_K_LM_DECIDE);
-            vio_launch_lm_decide(T, mode, 1, c->stream);
-            c->gn_pending = true;
-        } else {
-            vio_launch_step_sum(T, 0, c->stream);
-            VIOCHK(run_exchange(c, 1));
-            ProfScope ps(c, VIO_K_LM_DECIDE);
-            vio_launch_lm_decide(T, mode, 0, c->stream);
-        }
+        vio_launch_step_sum(T, 0, c->stream);
+        VIOCHK(run_exchange(c, 1));
+        ProfScope ps(c, VIO_K_LM_DECIDE);
+        vio_launch_lm_decide(T, mode, 0, c->stream);
     } else {
         ProfScope ps(c, VIO_K_LM_DECIDE);
         vio_launch_lm_decide(T, mode, 1, c->stream);
@@ -787,7 +769,7 @@ vio_status vio_solve_linear(vio_ctx *c, double lambda) {
     DeviceTables T = make_tables(c, pl);
     vio_launch_set_lambda(c->d_lm.p, lambda, c->stream);
     vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream);
-    vio_launch_backsub(T, 0, c->stream);
+    vio_launch_backsub(T, 0, 0, c->stream);
     HIPCHK(hipGetLastError());
     c->stepwise_updated = false;
     return VIO_OK;
@@ -813,7 +795,7 @@ vio_status vio_chi2(vio_ctx *c, double *chi2) {
     DeviceTables T = make_tables(c, pl);
     // the chi2 kernels read the pair table of the current state; after a stepwise update it is the trial table
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
-    vio_launch_backsub(T, 1, c->stream);
+    vio_launch_backsub(T, 1, 0, c->stream);
     if (sharded(c)) { vio_launch_step_sum(T, 2, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 2, 0, c->stream); }
     else vio_launch_lm_decide(T, 2, 1, c->stream);
     VIOCHK(read_lm(c));
@@ -899,8 +881,7 @@ vio_status vio_gn_iteration(vio_ctx *c, double lambda) {
     if (!c) return VIO_ERR_BAD_ARG;
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = c->solve_plan;
-    // the fold needs the decide kernel to be free of an exchange in front of it: not with the host hook
-    const bool gn = c->hook == nullptr;
+    const bool gn = true;       // chi2 and the gain-ratio partial of a step reach its test through vis: one exchange per iteration
     if (gn && c->cur_host < 0) VIOCHK(read_lm(c));      // once: from here on the host tracks LmState.cur itself
     if (lambda != c->gn_lambda) { vio_launch_set_lambda(c->d_lm.p, lambda, c->stream); c->gn_lambda = lambda; }
     VIOCHK(enqueue_linearize(c, pl, gn));

@@ -356,18 +356,9 @@ __host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext
     return VIO_MAXK * PAIR_STRIDE + 16 + 2 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
 }
 
-template <int NT> __device__ void d_lm_decide(const DeviceTables &T, int mode, int sum_local, double *s0, double *sImu, int tid);
-
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    if (b >= T.n_items + T.n_imu_items) {
-        // GN mode: the step test of the PREVIOUS iteration rides here as one more workgroup instead of a launch of
-        // its own (nothing in this kernel depends on it: every other workgroup takes `cur` from the host's hint)
-        __shared__ double sDec[2 * (LIN_THREADS / 64)], sDecImu[16];
-        d_lm_decide<LIN_THREADS>(T, T.decide_mode, 1, sDec, sDecImu, tid);
-        return;
-    }
     if (b >= T.n_items) {
         STAMP(T, 0);
         d_imu_item(T, b - T.n_items, dyn_smem);
@@ -740,6 +731,8 @@ struct ReduceTables {
     const int32_t *list;         // offsets (pairs: 1 int per entry; vectors: 2 ints per entry)
     const double *slab;
     double *vis;
+    const double *step_part;     // GN mode: per-item partials of the previous step (k_backsub), or null
+    int32_t n_step;              // items
 };
 
 #define RED_THREADS 1024
@@ -840,6 +833,18 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
             __syncthreads();
         }
         if (tid == 0) { R.vis[VIS_CHI] = sC[0]; R.vis[VIS_MAXH] = sM[0]; }
+        if (R.step_part) {      // landmark part of the previous step's gain-ratio denominator: summed here so that it is in the
+            double sc = 0.0;    // exchange buffer when the shards all-reduce it (fixed order: strided partials, then the tree)
+            for (int e = tid; e < R.n_step; e += RED_THREADS) sc += R.step_part[2 * e + STEP_SCALE];
+            __syncthreads();
+            sC[tid] = sc;
+            __syncthreads();
+            for (int s2 = RED_THREADS / 2; s2 > 0; s2 >>= 1) {
+                if (tid < s2) sC[tid] += sC[tid + s2];
+                __syncthreads();
+            }
+            if (tid == 0) R.vis[VIS_STEP + 1] = sC[0];
+        }
     }
 }
 
@@ -922,18 +927,6 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid
     return bred + extra;
 }
 
-// Sharded GN mode: the landmark sums of the previous step (chi2, gain-ratio scale) have just come back summed over
-// the shards in vis[VIS_STEP..]; finish what k_lm_decide left open.
-__device__ __forceinline__ void d_gn_finish(const DeviceTables &T) {
-    LmState *lm = T.lm;
-    const double chi = 0.5 * ((T.vis[VIS_STEP] + lm->gn_chi_imu) + lm->gn_prior);
-    const double scale = 0.5 * (T.vis[VIS_STEP + 1] + lm->gn_scale_p) + 1e-6;
-    lm->chi_try = chi;
-    lm->chi = chi;
-    lm->scale = scale;
-    lm->rho = (lm->gn_chi_prev - chi) / scale;
-}
-
 // Workgroup b < 171: row b of H_pp_schur_ in natural order (getters, marginalisation) and, for the solve, row b of
 // the PERMUTED, tiled lower triangle Pg: the pivot order of Eigen's LDLT is the order of |diag + lambda|, which for
 // lambda >= 0 and a non-negative diagonal does not depend on lambda, so it is fixed here once per linearisation
@@ -986,11 +979,43 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
             if (t < b && (t >> 4) == (b >> 4)) T.Pg[telem(t, b)] = 0.0;
         }
     } else {
+        // GN mode: the step test of the PREVIOUS iteration (IsGoodStepInLM's bookkeeping, always accepted).  The chi2 of
+        // the state that step produced is the one this linearisation has just computed and k_reduce summed (all-reduced
+        // with the rest of vis when sharded), so nobody evaluates it twice.  b_ of the previous linearisation is read
+        // before d_rhs_entries replaces it.
+        double sp = 0.0, e2 = 0.0;
+        if (T.gn_flags & 1) {
+            if (t < VIO_PD) { const double d = T.dx[t]; sp = d * (T.lm->lambda * d + T.bfull[t]); }
+            if (T.has_prior && t < VIO_PRD) { const double v = T.errprior[cur * 160 + t]; e2 = v * v; }
+        }
         if (t < VIO_PD) {
             sDg[t] = d_rhs_entries(T, valid, t, cur);
             T.perm[t] = sPerm[t];
         }
-        if (t == 191 && (T.gn_flags & 2)) d_gn_finish(T);
+        if (T.gn_flags & 1) {
+            __shared__ double sSum[8];
+            d_block_sum2<192>(sp, e2, sSum, t);
+            if (t == 0) {
+                LmState *lm = T.lm;
+                double chi_imu = 0.0;
+                for (int k = 0; k < 10; ++k) if ((valid >> k) & 1) chi_imu += T.imu_out[k * IMU_OUT + IMU_CHI];
+                double total = T.vis[VIS_CHI] + chi_imu;
+                if (T.has_prior) total += sqrt(e2);             // err_prior_.norm(), not squared (problem.cc:554-556)
+                const double tempChi = 0.5 * total;
+                const double scale = 0.5 * (T.vis[VIS_STEP + 1] + sp) + 1e-6;
+                lm->chi_try = tempChi;
+                lm->rho = (lm->chi - tempChi) / scale;
+                lm->scale = scale;
+                lm->trials += 1;
+                lm->chi = tempChi;
+                lm->cur = cur;
+                lm->accepted = 1;
+                lm->naccepted += 1;
+                lm->need_linearize = 1;
+                lm->false_cnt = 0;
+                if (!isfinite(tempChi)) lm->finite = 0;
+            }
+        }
         __syncthreads();                        // the 192 remaining threads, all of them
         if (t < PS_NP) T.Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
     }
@@ -1416,7 +1441,9 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 // Blocks >= n_items evaluate the IMU chi2.
 // ---------------------------------------------------------------------------------------------------------
 #define BS_THREADS 128      // one thread per landmark of the item (G <= 128)
-__global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode) {
+// lite (GN mode): the landmark update and the gain-ratio partial only; the chi2 of the new state comes out of the next
+// linearisation anyway (k_assemble's step test reads it there) and the IMU blocks are not launched.
+__global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode, int lite) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const LmState *lm = T.lm;
     const int cur = d_cur(T);
@@ -1455,7 +1482,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
     const ItemDesc &it = sIt;
     const int G = it.G, K = it.K, nb = it.nb;
     const double *ptab = T.pairtab + which * PAIRTAB_STRIDE;
-    for (int e = lane; e < K * 12; e += BS_THREADS) {
+    for (int e = lane; e < K * 12 && !lite; e += BS_THREADS) {
         const int k = e / 12, o = e % 12;
         sPairCD[e] = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + PAIR_C + o];     // C (9) then d (3) are adjacent
     }
@@ -1481,6 +1508,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
             T.invd[(size_t)(cur ^ 1) * T.Ns + li] = lam;
             scale = dl * (lm->lambda * dl + bl);
         }
+        if (!lite) {
         const double il = 1.0 / lam;
         const double x = T.pts_i[2 * li], y = T.pts_i[2 * li + 1];
         const double pci[3] = {x * il, y * il, il};
@@ -1498,6 +1526,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
             double rho0, rho1, rho2;
             d_loss(T.loss_type, T.loss_delta, e2, rho0, rho1, rho2);
             chi += (T.loss_type == 0) ? e2 : rho0;
+        }
         }
     }
     // fixed order: DPP sum inside each wave, then wave 0 + wave 1
@@ -1530,11 +1559,8 @@ __global__ __launch_bounds__(256) void k_step_sum(DeviceTables T, int mode) {
     d_block_sum2<256>(c, s, s0, tid);        // the same reduction as k_lm_decide's: sharded and unsharded runs agree bit for bit
     if (tid == 0) {
         T.step_tot[0] = c; T.step_tot[1] = s;
-        if (T.gn_flags & 1) { T.vis[VIS_STEP] = c; T.vis[VIS_STEP + 1] = s; }     // ride along with the next all-reduce
     }
 }
-
-__global__ void k_gn_finish(DeviceTables T) { if (threadIdx.x == 0) d_gn_finish(T); }
 
 // The body of k_lm_decide for a workgroup of NT threads (256: the kernel; 1024: the extra workgroup of k_linearize that
 // runs the previous GN step's test).  Only the first 256 threads carry data and the wave partials are added in wave
@@ -1562,7 +1588,6 @@ __device__ void d_lm_decide(const DeviceTables &T, int mode, int sum_local, doub
         d_block_sum2<NT>(c, s, s0, tid);
         if (tid == 0) {
             T.step_tot[0] = c; T.step_tot[1] = s;
-            if (T.gn_flags & 1) { T.vis[VIS_STEP] = c; T.vis[VIS_STEP + 1] = s; }     // ride along with the next all-reduce
         }
     }
     d_block_sum2<NT>(e, sp, s0, tid);
@@ -1575,12 +1600,6 @@ __device__ void d_lm_decide(const DeviceTables &T, int mode, int sum_local, doub
     const double tempChi = 0.5 * total;
     lm->chi_try = tempChi;
     if (mode == 2) return;
-    if (T.gn_flags & 1) {           // sharded GN step: the landmark sums are still local; k_assemble finishes (d_gn_finish)
-        lm->gn_chi_imu = chi_imu;
-        lm->gn_prior = T.has_prior ? sqrt(en2) : 0.0;
-        lm->gn_scale_p = scale_p;
-        lm->gn_chi_prev = lm->chi;
-    }
     double scale = 0.5 * ((sum_local ? s : T.step_tot[1]) + scale_p);
     scale += 1e-6;
     const double rho = (lm->chi - tempChi) / scale;
@@ -1760,7 +1779,7 @@ void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(128), 0, s, T); }
 void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_linearize, dim3(n_blocks + (T.decide_mode >= 0 ? 1 : 0)), dim3(LIN_THREADS), lds_bytes, s, T);
+    hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1), dim3(RED_THREADS), 0, s, R);
@@ -1769,11 +1788,11 @@ void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernel
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
 }
-void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(BS_THREADS), 0, s, T, mode);
+void vio_launch_backsub(const DeviceTables &T, int mode, int lite, hipStream_t s) {
+    if (lite && T.n_items == 0) return;
+    hipLaunchKernelGGL(k_backsub, dim3(T.n_items + (lite ? 0 : T.n_imu_items)), dim3(BS_THREADS), 0, s, T, mode, lite);
 }
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s) { hipLaunchKernelGGL(k_step_sum, dim3(1), dim3(256), 0, s, T, mode); }
-void vio_launch_gn_finish(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_gn_finish, dim3(1), dim3(64), 0, s, T); }
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s) {
     hipLaunchKernelGGL(k_lm_decide, dim3(1), dim3(256), 0, s, T, mode, sum_local);
 }

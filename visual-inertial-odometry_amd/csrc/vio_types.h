@@ -47,7 +47,7 @@
 #define VIS_BDIR (VIS_BRED + VIO_CD)         // direct b (pose part of b_), 72
 #define VIS_DIAG (VIS_BDIR + VIO_CD)         // direct diagonal of Hpp (visual part), 72
 #define VIS_CHI (VIS_DIAG + VIO_CD)          // sum of RobustChi2 over reprojection edges
-#define VIS_STEP (VIS_CHI + 1)               // 2 slots: step scalars of the previous GN iteration riding along (sharded GN mode)
+#define VIS_STEP (VIS_CHI + 1)               // 2 slots; [1]: landmark part of the previous GN step's gain-ratio denominator (k_reduce)
 #define VIS_MAXH (VIS_STEP + 2)              // max |h_ll| — first slot that is NOT summed across shards
 #define VIS_COUNT (VIS_MAXH + 1 + 4)         // padded to a multiple of 8
 
@@ -108,10 +108,6 @@ struct LmState {
     int32_t max_iter;
     int32_t stop_reason;
     int32_t pad_;
-    double gn_chi_imu;           // sharded GN mode: the chi2 terms that are not sharded (IMU, prior norm), scale_p and the chi
-    double gn_prior;             //   before the step: what k_assemble needs to finish the step bookkeeping once the landmark
-    double gn_scale_p;           //   sums have come back from the all-reduce (same order of additions as k_lm_decide)
-    double gn_chi_prev;
     double chi_trace[128];
     double lambda_trace[128];
 };
@@ -159,9 +155,9 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     double *step_part;           // [n_step_blocks][2]
     double *chi_part;            // [n_step_blocks][2] partials of vio_chi2 (kept apart from a pending step test)
     int32_t n_step_blocks;
-    int32_t gn_flags;            // sharded GN mode: bit 0 k_step_sum/k_lm_decide defer the landmark sums, bit 1 k_assemble finishes the previous step
+    int32_t gn_flags;            // GN mode: bit 0: k_assemble runs the step test of the PREVIOUS iteration (its chi2 is the one this linearisation computed)
     int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur
-    int32_t decide_mode;         // >= 0: k_linearize carries one extra workgroup that runs the PREVIOUS step's k_lm_decide(mode)
+    int32_t pad2_;
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
     LmState *lm;
     unsigned long long *dbg;     // diagnostic builds only (-DVIO_STAMPS): [block][16] s_memtime stamps
