@@ -34,7 +34,7 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s);
-void vio_launch_backsub(const DeviceTables &T, int mode, int lite, hipStream_t s);
+void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_triangulate(const TriTables &Q, hipStream_t s);
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s);
@@ -385,7 +385,7 @@ vio_status flush_decide(vio_ctx *c) {
     if (!c->decide_pending || !c->active) return VIO_OK;
     c->decide_pending = false;
     DeviceTables T = make_tables_raw(c, *c->active);
-    vio_launch_backsub(T, 0, 0, c->stream);
+    vio_launch_backsub(T, 0, c->stream);
     if (c->hook || c->comm) {
         vio_launch_step_sum(T, 0, c->stream);
         VIOCHK(run_exchange(c, 1));
@@ -557,6 +557,7 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false) {
     DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
     const bool test_prev = gn && c->decide_pending;
     if (gn) T.cur_hint = c->cur_host;
+    if (test_prev) T.gn_flags = 2;
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
     { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
     ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items};
@@ -588,16 +589,16 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false) {
     if (gn) T.cur_hint = c->cur_host;
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     if (gn) {
-        // the step is accepted whatever chi2 turns out to be: only the landmark update runs here; the chi2 of the new
-        // state and the step test belong to the next iteration (flush_decide does them when anybody else asks first)
-        { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, 1, c->stream); }
+        // the step is accepted whatever chi2 turns out to be: the landmark back-substitution, the chi2 of the new state and
+        // the step test all belong to the next iteration's k_linearize / k_assemble (flush_decide does them the
+        // classic way when anybody else asks first)
         c->decide_pending = true;
         c->cur_host ^= 1;
         HIPCHK(hipGetLastError());
         c->device_ahead = true;
         return VIO_OK;
     }
-    { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, 0, c->stream); }
+    { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, c->stream); }
     if (sharded(c)) {
         vio_launch_step_sum(T, 0, c->stream);
         VIOCHK(run_exchange(c, 1));
@@ -769,7 +770,7 @@ vio_status vio_solve_linear(vio_ctx *c, double lambda) {
     DeviceTables T = make_tables(c, pl);
     vio_launch_set_lambda(c->d_lm.p, lambda, c->stream);
     vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream);
-    vio_launch_backsub(T, 0, 0, c->stream);
+    vio_launch_backsub(T, 0, c->stream);
     HIPCHK(hipGetLastError());
     c->stepwise_updated = false;
     return VIO_OK;
@@ -795,7 +796,7 @@ vio_status vio_chi2(vio_ctx *c, double *chi2) {
     DeviceTables T = make_tables(c, pl);
     // the chi2 kernels read the pair table of the current state; after a stepwise update it is the trial table
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
-    vio_launch_backsub(T, 1, 0, c->stream);
+    vio_launch_backsub(T, 1, c->stream);
     if (sharded(c)) { vio_launch_step_sum(T, 2, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 2, 0, c->stream); }
     else vio_launch_lm_decide(T, 2, 1, c->stream);
     VIOCHK(read_lm(c));

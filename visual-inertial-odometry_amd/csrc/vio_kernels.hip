@@ -395,7 +395,33 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     double pf_lam = 1.0, pf_x = 0.0, pf_y = 0.0, pf_u = 0.0, pf_v = 0.0;
     if (tid < G * K) {
         const int k0 = tid / G, g0 = tid - k0 * G;
-        pf_lam = invd[g0]; pf_x = pts_i[2 * g0]; pf_y = pts_i[2 * g0 + 1]; pf_u = pts_j[2 * tid]; pf_v = pts_j[2 * tid + 1];
+        if (!(T.gn_flags & 2)) pf_lam = invd[g0];
+        pf_x = pts_i[2 * g0]; pf_y = pts_i[2 * g0 + 1]; pf_u = pts_j[2 * tid]; pf_v = pts_j[2 * tid + 1];
+    }
+    // GN mode (gn_flags bit 1): the landmarks still owe the back-substitution of the PREVIOUS step (problem.cc:445):
+    // delta_lambda = (b_l - w . dx_pose) / h from the rows this item's workgroup stored at the end of the previous
+    // linearisation.  The new inverse depth goes to the current copy of invd and, through the landmark record, to
+    // phase 1; the landmark part of the gain-ratio denominator goes to the record for the combine phase.
+    const bool owe = (T.gn_flags & 2) != 0;
+    if (owe && tid < G) {
+        const int g = tid;
+        const size_t li = (size_t)it.lm_base + g;
+        const double *lw = T.lw + it.lw_base;
+        double t = 0.0;
+        for (int p = 0; p < nb; ++p) {
+            const int cb = it.cam_block[p];
+            const int base = cb == 0 ? 0 : 6 + 15 * (cb - 1);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t += lw[(size_t)(6 * p + i) * G + g] * T.dx[base + i];
+        }
+        const double h = lw[(size_t)(6 * nb) * G + g], bl = lw[(size_t)(6 * nb + 1) * G + g];
+        const double dl = (1.0 / h) * (bl - t);
+        const double lam = T.invd[(size_t)(cur ^ 1) * T.Ns + li] + dl;
+        T.dxl[li] = dl;
+        T.invd[(size_t)cur * T.Ns + li] = lam;
+        double *L = sL + (size_t)g * LREC;
+        L[12 * nb + 3] = lam;
+        L[12 * nb + 4] = dl * (T.lm->lambda * dl + bl);
     }
     const double *ptab = T.pairtab + cur * PAIRTAB_STRIDE;
     for (int e = tid; e < K * PAIR_STRIDE; e += LIN_THREADS) {
@@ -416,7 +442,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         const int k = o / G, g = o - k * G;
         const double *PA = sPair + k * PAIR_STRIDE;
         const bool first = o == tid;
-        const double lam = first ? pf_lam : invd[g];
+        const double lam = owe ? sL[(size_t)g * LREC + 12 * nb + 3] : (first ? pf_lam : invd[g]);
         const double il = 1.0 / lam;
         const double x = first ? pf_x : pts_i[2 * g], y = first ? pf_y : pts_i[2 * g + 1];
         const double u = first ? pf_u : pts_j[2 * o], v = first ? pf_v : pts_j[2 * o + 1];
@@ -708,6 +734,12 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             out[e] = v;
         }
         if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
+        if (owe && tid == 64) {             // the previous step's gain-ratio partial of this item, landmarks in order
+            double sc = 0.0;
+            for (int g = 0; g < G; ++g) sc += sL[(size_t)g * LREC + 12 * nb + 4];
+            T.step_part[2 * b + STEP_SCALE] = sc;
+            T.step_part[2 * b + STEP_CHI] = 0.0;
+        }
         // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
         double *lw = T.lw + it.lw_base;
         for (int e = tid; e < (6 * nb + 2) * G; e += LIN_THREADS) {
@@ -1441,9 +1473,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 // Blocks >= n_items evaluate the IMU chi2.
 // ---------------------------------------------------------------------------------------------------------
 #define BS_THREADS 128      // one thread per landmark of the item (G <= 128)
-// lite (GN mode): the landmark update and the gain-ratio partial only; the chi2 of the new state comes out of the next
-// linearisation anyway (k_assemble's step test reads it there) and the IMU blocks are not launched.
-__global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode, int lite) {
+__global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const LmState *lm = T.lm;
     const int cur = d_cur(T);
@@ -1482,7 +1512,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
     const ItemDesc &it = sIt;
     const int G = it.G, K = it.K, nb = it.nb;
     const double *ptab = T.pairtab + which * PAIRTAB_STRIDE;
-    for (int e = lane; e < K * 12 && !lite; e += BS_THREADS) {
+    for (int e = lane; e < K * 12; e += BS_THREADS) {
         const int k = e / 12, o = e % 12;
         sPairCD[e] = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + PAIR_C + o];     // C (9) then d (3) are adjacent
     }
@@ -1508,7 +1538,6 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
             T.invd[(size_t)(cur ^ 1) * T.Ns + li] = lam;
             scale = dl * (lm->lambda * dl + bl);
         }
-        if (!lite) {
         const double il = 1.0 / lam;
         const double x = T.pts_i[2 * li], y = T.pts_i[2 * li + 1];
         const double pci[3] = {x * il, y * il, il};
@@ -1526,7 +1555,6 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
             double rho0, rho1, rho2;
             d_loss(T.loss_type, T.loss_delta, e2, rho0, rho1, rho2);
             chi += (T.loss_type == 0) ? e2 : rho0;
-        }
         }
     }
     // fixed order: DPP sum inside each wave, then wave 0 + wave 1
@@ -1788,9 +1816,8 @@ void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernel
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
 }
-void vio_launch_backsub(const DeviceTables &T, int mode, int lite, hipStream_t s) {
-    if (lite && T.n_items == 0) return;
-    hipLaunchKernelGGL(k_backsub, dim3(T.n_items + (lite ? 0 : T.n_imu_items)), dim3(BS_THREADS), 0, s, T, mode, lite);
+void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s) {
+    hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(BS_THREADS), 0, s, T, mode);
 }
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s) { hipLaunchKernelGGL(k_step_sum, dim3(1), dim3(256), 0, s, T, mode); }
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s) {
