@@ -385,3 +385,51 @@ def test_long_tracks_and_free_extrinsic(vio, oracle_lib, hip_lib, k_obs, ext_fix
     assert np.abs(dh - do).max() <= 1e-8 * max(np.abs(do).max(), 1e-12)
     rh, ro = ch.solve(10), co.solve(10)
     assert rh.final_chi2 <= 1.0001 * ro.final_chi2 + 1e-9
+
+
+@pytest.mark.gpu
+def test_gn_iterations_interleaved_with_everything_else(vio, oracle_lib, hip_lib):
+    """In GN mode a step leaves its landmark update, its chi2 and its test to the next iteration; any other call in
+    between must find them done (flush) and must not disturb the iterations that follow."""
+    w = vio.synth.make_window(700, seed=31, ragged=True)
+    lam = 5e5
+    plain, mixed = hip_lib.context(), hip_lib.context()
+    plain.load(w)
+    mixed.load(w)
+    for _ in range(6):
+        plain.gn_iteration(lam)
+    pp, sp, _ = plain.get_window()
+    lp = plain.get_landmarks()
+    chi_p = plain.chi2()
+    # the same six iterations with reads, a chi2 evaluation and a stepwise linearisation thrown in
+    mixed.gn_iteration(lam)
+    p1, _, _ = mixed.get_window()                        # read-back flushes the owed work
+    mixed.gn_iteration(lam)
+    mixed.gn_iteration(lam)
+    c3 = mixed.chi2()
+    l3 = mixed.get_landmarks()
+    mixed.gn_iteration(lam)
+    mixed.linearize()                                    # a stepwise call: same state, nothing moves
+    H, b = mixed.get_schur_system()
+    assert np.isfinite(H).all() and np.isfinite(b).all()
+    mixed.gn_iteration(lam)
+    mixed.gn_iteration(lam)
+    pm, sm, _ = mixed.get_window()
+    np.testing.assert_array_equal(pm, pp)
+    np.testing.assert_array_equal(sm, sp)
+    np.testing.assert_array_equal(mixed.get_landmarks(), lp)
+    assert mixed.chi2() == chi_p
+    # against the oracle's plain loop
+    o = oracle_lib.context()
+    o.load(w)
+    for _ in range(3):
+        o.gn_iteration(lam)
+    po, _, _ = o.get_window()
+    assert abs(c3 - o.chi2()) <= 1e-9 * c3
+    np.testing.assert_allclose(l3, o.get_landmarks(), rtol=1e-8, atol=1e-10)
+    assert p1.shape == po.shape
+    # an LM solve and a marginalisation straight after GN iterations start from the flushed state
+    rep = mixed.solve(5)
+    assert np.isfinite(rep.final_chi2) and rep.final_chi2 <= chi_p * (1 + 1e-9)
+    prior = mixed.marginalize(vio.MARG_OLD)
+    assert np.isfinite(prior["H"]).all()
