@@ -864,7 +864,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
             if (tid < s2) { sC[tid] += sC[tid + s2]; sM[tid] = fmax(sM[tid], sM[tid + s2]); }
             __syncthreads();
         }
-        if (tid == 0) { R.vis[VIS_CHI] = sC[0]; R.vis[VIS_MAXH] = sM[0]; }
+        if (tid == 0) { R.vis[VIS_CHI] = sC[0]; R.vis[VIS_MAXH] = sM[0]; R.vis[VIS_STEP] = 0.0; if (!R.step_part) R.vis[VIS_STEP + 1] = 0.0; }
         if (R.step_part) {      // landmark part of the previous step's gain-ratio denominator: summed here so that it is in the
             double sc = 0.0;    // exchange buffer when the shards all-reduce it (fixed order: strided partials, then the tree)
             for (int e = tid; e < R.n_step; e += RED_THREADS) sc += R.step_part[2 * e + STEP_SCALE];
