@@ -43,6 +43,14 @@ __shared__ unsigned long long g_stamps[8];
 // which copy of the double-buffered state is current: the host's hint when it tracks it (GN mode), else LmState
 __device__ __forceinline__ int d_cur(const DeviceTables &T) { return T.cur_hint >= 0 ? T.cur_hint : T.lm->cur; }
 
+// Device-driven LM loop (vio_solve): the host enqueues whole iterations ahead; a kernel whose turn has not come
+// (the loop has stopped, or the last trial was rejected and there is nothing to re-linearise) returns at once.
+__device__ __forceinline__ bool d_gated_off(const LmState *lm, int gate) {
+    if (gate == 0) return false;
+    if (lm->stop) return true;
+    return (gate & 1) && !lm->need_linearize;
+}
+
 __device__ __forceinline__ int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
 // inverse: -1 when the full index is a speed-bias dimension
 __device__ __forceinline__ int full_to_cam(int i) {
@@ -359,6 +367,7 @@ __host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    if (d_gated_off(T.lm, T.lm_gate)) return;
     if (b >= T.n_items) {
         STAMP(T, 0);
         d_imu_item(T, b - T.n_items, dyn_smem);
@@ -765,6 +774,8 @@ struct ReduceTables {
     double *vis;
     const double *step_part;     // GN mode: per-item partials of the previous step (k_backsub), or null
     int32_t n_step;              // items
+    int32_t gate;                // see d_gated_off
+    const LmState *lm;
 };
 
 #define RED_THREADS 1024
@@ -775,6 +786,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
     // is fixed by the list, not by timing.  Three dependent round trips (offsets, list, slab) whatever the list length.
     __shared__ double sV[56 * 18 + 8];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (d_gated_off(R.lm, R.gate)) return;
     const int lo = R.list_off[b], hi = R.list_off[b + 1];
     if (b < VIO_NPAIR) {
         constexpr int W = 36, NS = RED_THREADS / W;           // 28 slots
@@ -970,6 +982,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
     __shared__ int sPerm[176];
     __shared__ int sCnt[5 * 176];
     const int b = blockIdx.x, t = threadIdx.x;
+    if (d_gated_off(T.lm, T.lm_gate)) return;
     const int cur = d_cur(T);
     const int valid = d_imu_mask(T);
     if (t < VIO_PD) { double vv, vr; d_hs_entry(T, valid, t, t, vv, vr); sDg[t] = fabs(vv + vr); }
@@ -1205,6 +1218,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     const int wave = tid >> 6, lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     LmState *lm = T.lm;
+    if (d_gated_off(lm, T.lm_gate)) return;
     const int cur = d_cur(T), trial = cur ^ 1;
     const double lambda = lm->lambda;
     const int n = PS_N, NP = PS_NP;
@@ -1476,6 +1490,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const LmState *lm = T.lm;
+    if (d_gated_off(lm, T.lm_gate)) return;
     const int cur = d_cur(T);
     const int which = (mode == 1) ? cur : (cur ^ 1);
     if (b >= T.n_items) {
@@ -1669,6 +1684,7 @@ __device__ void d_lm_decide(const DeviceTables &T, int mode, int sum_local, doub
 __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int sum_local) {
     __shared__ double s0[8];
     __shared__ double sImu[16];
+    if (d_gated_off(T.lm, T.lm_gate)) return;
     d_lm_decide<256>(T, mode, sum_local, s0, sImu, threadIdx.x);
 }
 
