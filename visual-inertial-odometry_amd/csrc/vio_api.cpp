@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -193,14 +194,25 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     pl.marg = marg;
     pl.use_ext = marg ? 1 : (c->cfg.ext_fixed ? 0 : 1);
     const int64_t N = (int64_t)c->h_invd.size(), M = (int64_t)c->h_olm.size();
-    std::vector<std::vector<int32_t>> obs_of(N);
-    for (int64_t e = 0; e < M; ++e) obs_of[c->h_olm[e]].push_back((int32_t)e);
-    // pattern of each landmark
-    std::map<std::vector<int8_t>, int> pattern_id;
+    // observations of each landmark, in the caller's order (CSR; this runs once per frame on the host, so no
+    // per-landmark allocations and no tree lookups: 20 000 landmarks take well under a millisecond)
+    struct ObsRange { const int32_t *p; size_t n; size_t size() const { return n; } bool empty() const { return n == 0; }
+                      int32_t operator[](size_t i) const { return p[i]; } const int32_t *begin() const { return p; } const int32_t *end() const { return p + n; } };
+    std::vector<int64_t> obs_off(N + 1, 0);
+    for (int64_t e = 0; e < M; ++e) ++obs_off[c->h_olm[e] + 1];
+    for (int64_t l = 0; l < N; ++l) obs_off[l + 1] += obs_off[l];
+    std::vector<int32_t> obs_idx(std::max<int64_t>(M, 1));
+    {
+        std::vector<int64_t> fill(obs_off.begin(), obs_off.end() - 1);
+        for (int64_t e = 0; e < M; ++e) obs_idx[fill[c->h_olm[e]]++] = (int32_t)e;
+    }
+    auto obs_of = [&](int64_t l) { return ObsRange{obs_idx.data() + obs_off[l], (size_t)(obs_off[l + 1] - obs_off[l])}; };
+    // pattern of each landmark: (host, targets in observation order) packed 4 bits a frame
+    std::unordered_map<uint64_t, int> pattern_id;
     pl.patterns.clear();
     std::vector<int32_t> lm_pattern(N, -1);
     for (int64_t l = 0; l < N; ++l) {
-        const auto &ob = obs_of[l];
+        const ObsRange ob = obs_of(l);
         if (ob.empty()) {
             if (marg) continue;
             return fail(c, VIO_ERR_UNSUPPORTED, "landmark without observations (its 1x1 Hessian block would be singular)");
@@ -208,8 +220,10 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         const int h = c->h_ohost[ob[0]];
         if (marg && h != 0) continue;          // MargOldFrame keeps landmarks hosted in frame 0 only (estimator.cpp:762-764)
         if ((int)ob.size() > VIO_MAXK) return fail(c, VIO_ERR_UNSUPPORTED, "more than 10 observations of one landmark");
-        std::vector<int8_t> key;
-        key.push_back((int8_t)h);
+        int8_t key[1 + VIO_MAXK];
+        int nkey = 0;
+        key[nkey++] = (int8_t)h;
+        uint64_t packed = (uint64_t)ob.size() | ((uint64_t)h << 4);
         bool seen[NF] = {false};
         seen[h] = true;
         for (int32_t e : ob) {
@@ -218,13 +232,14 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
             const int t = c->h_otarget[e];
             if (seen[t]) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
             seen[t] = true;
-            key.push_back((int8_t)t);
+            packed |= (uint64_t)t << (4 * (nkey + 1));
+            key[nkey++] = (int8_t)t;
         }
-        auto itp = pattern_id.find(key);
+        auto itp = pattern_id.find(packed);
         int id;
         if (itp == pattern_id.end()) {
             id = (int)pl.patterns.size();
-            pattern_id[key] = id;
+            pattern_id[packed] = id;
             Pattern pt;
             std::memset(&pt, 0, sizeof(pt));
             pt.use_ext = pl.use_ext; pt.host = h; pt.K = (int)ob.size();
@@ -249,10 +264,13 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         lm_pattern[l] = id;
     }
     // sort landmarks by pattern (stable in the original index)
-    pl.sorted_to_orig.clear();
-    for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) pl.sorted_to_orig.push_back((int32_t)l);
-    std::stable_sort(pl.sorted_to_orig.begin(), pl.sorted_to_orig.end(),
-                     [&](int32_t a, int32_t b) { return lm_pattern[a] < lm_pattern[b]; });
+    {   // counting sort: pattern-major, original index inside a pattern
+        std::vector<int64_t> start(pl.patterns.size() + 1, 0);
+        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) ++start[lm_pattern[l] + 1];
+        for (size_t q = 0; q < pl.patterns.size(); ++q) start[q + 1] += start[q];
+        pl.sorted_to_orig.assign((size_t)start[pl.patterns.size()], 0);
+        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) pl.sorted_to_orig[start[lm_pattern[l]]++] = (int32_t)l;
+    }
     pl.Ns = (int64_t)pl.sorted_to_orig.size();
     // items
     pl.items.clear();
@@ -281,7 +299,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         pts_j.resize(2 * (obs_base + (int64_t)it.G * it.K));
         for (int g = 0; g < it.G; ++g) {
             const int32_t l = pl.sorted_to_orig[s + g];
-            const auto &ob = obs_of[l];
+            const ObsRange ob = obs_of(l);
             pts_i[2 * (s + g)] = c->h_pts_i[2 * ob[0]]; pts_i[2 * (s + g) + 1] = c->h_pts_i[2 * ob[0] + 1];
             for (int k = 0; k < it.K; ++k) {
                 const int64_t o = obs_base + (int64_t)k * it.G + g;
