@@ -35,8 +35,9 @@ def _worker(rank, world, port, out_dir, n, ragged):
     rep = sb.solve(10)
     poses, sbias, ext = sb.ctx.get_window()
     invd = sb.gather_landmarks()
+    marg = sb.marginalize(vio.capi.MARG_OLD)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), chi0=chi0, lam0=lam0, Hs=Hs, bs=bs, poses=poses, sb=sbias,
-             invd=invd, final_chi2=rep.final_chi2, iterations=rep.iterations, trials=rep.trials)
+             invd=invd, marg_H=marg["H"], marg_b=marg["b"], marg_err=marg["err"], marg_jt=marg["jt_inv"], final_chi2=rep.final_chi2, iterations=rep.iterations, trials=rep.trials)
     dist.destroy_process_group()
 
 
@@ -55,7 +56,16 @@ def test_sharded_solve_equals_unsharded(vio, oracle_lib, tmp_path, n, ragged):
     rep = ctx.solve(10)
     poses, sbias, _ = ctx.get_window()
     invd = ctx.get_landmarks()
+    marg = ctx.marginalize(vio.capi.MARG_OLD)
+    mscale = np.abs(marg["H"]).max()
     for r in (r0, r1):
+        # marginalisation of the old frame: partial Schur systems summed over the shards, identical tail on every rank
+        # (tolerance of tests/test_oracle_golden.py::check_prior: the Schur complement cancels O(1e16) terms, so a
+        # different summation order moves the prior by O(1e-6) of its largest entry)
+        assert np.abs(r["marg_H"] - marg["H"]).max() <= 2e-5 * mscale
+        evs, evr = np.linalg.eigvalsh(r["marg_H"]), np.linalg.eigvalsh(marg["H"])
+        assert np.abs(evs - evr).max() <= 2e-5 * evr.max()
+        assert np.abs(r["marg_b"] - marg["b"]).max() <= 1e-6 * max(1.0, np.abs(marg["b"]).max())
         # every rank holds the identical reduced system after the all-reduce
         assert abs(float(r["chi0"]) - chi0) <= 1e-12 * abs(chi0) and float(r["lam0"]) == lam0
         d = np.sqrt(np.abs(np.diag(Hs)) + 1e-300)
@@ -66,3 +76,5 @@ def test_sharded_solve_equals_unsharded(vio, oracle_lib, tmp_path, n, ragged):
         assert np.abs(r["invd"] - invd).max() <= 1e-7
     np.testing.assert_array_equal(r0["Hs"], r1["Hs"])      # bitwise identical on both ranks
     np.testing.assert_array_equal(r0["poses"], r1["poses"])
+    for k in ("marg_H", "marg_b", "marg_err", "marg_jt"):
+        np.testing.assert_array_equal(r0[k], r1[k])

@@ -359,6 +359,10 @@ def test_native_rccl_exchange_on_one_rank(vio, hip_lib):
     np.testing.assert_array_equal(ss, sr)
     np.testing.assert_array_equal(sb.ctx.get_landmarks(), ref.get_landmarks())
     assert sb.ctx.chi2() == ref.chi2()
+    # MargOldFrame over the shards: same all-reduce, identical tail on every rank
+    ms, mr = sb.marginalize(vio.MARG_OLD), ref.marginalize(vio.MARG_OLD)
+    for k in ("H", "b", "err", "jt_inv"):
+        np.testing.assert_array_equal(ms[k], mr[k])
     sb.ctx.comm_destroy()
 
 

@@ -67,6 +67,12 @@ class ShardedBackend:
     def gn_iteration(self, lam):
         self.ctx.gn_iteration(lam)
 
+    def marginalize(self, kind):
+        """Problem::Marginalize over the shards (SURVEY.md section 8e): every rank forms the partial Schur system of
+        its own frame-0-hosted landmarks, the same all-reduce as a linearisation sums them, and every rank runs the
+        identical eigen-decomposition tail on the identical 171x171 system — the new prior needs no broadcast."""
+        return self.ctx.marginalize(kind)
+
     def gather_landmarks(self):
         """All ranks' inverse depths, in the original landmark order."""
         local = self.ctx.get_landmarks()
