@@ -102,6 +102,166 @@ class SyntheticStream:
         self.init_noise = rng.normal(size=(len(self.lm_host),))
 
 
+IMU_COLUMNS = ("timestamp", "q_w", "q_x", "q_y", "q_z", "p_x", "p_y", "p_z", "gyro_x", "gyro_y", "gyro_z", "acc_x", "acc_y", "acc_z")
+KEYFRAME_COLUMNS = ("timestamp", "id", "x", "y", "z", "lambda", "x_normalized", "y_normalized", "u", "v")
+
+
+def write_simulator_files(stream, out_dir, fx=synth.FOCAL, cx=255.0, cy=255.0):
+    """Write a stream in the file formats of the reference's simulator: `imu_pose.txt`
+    (timestamp, ground-truth q and p, gyro, acc: simulator/src/utilities.cpp:150-171; the runner reads timestamp, gyro
+    and acc by name and ignores the rest, run_vio_simulation.cpp:43-49) and one `keyframe/all_points_<n>.txt` per frame
+    (timestamp, id, world point, lambda, normalised point, pixel: utilities.cpp:37-63, read at
+    run_vio_simulation.cpp:163-170).  Three extra columns v_x, v_y, v_z carry the ground-truth velocity."""
+    import os
+    os.makedirs(os.path.join(out_dir, "keyframe"), exist_ok=True)
+    st = stream
+    with open(os.path.join(out_dir, "imu_pose.txt"), "w") as f:
+        f.write(",".join(IMU_COLUMNS + ("v_x", "v_y", "v_z")) + "\n")
+        rows = []
+        for k, iv in enumerate(st.imu):
+            t = st.times[k]
+            if k == 0:
+                rows.append((t, iv["gyr0"], iv["acc0"]))
+            for dt, a, g in zip(iv["dt"], iv["acc"], iv["gyr"]):
+                t = t + dt
+                rows.append((t, g, a))
+            rows[-1] = (st.times[k + 1], rows[-1][1], rows[-1][2])      # the frame stamp itself, not an accumulated sum
+        for t, g, a in rows:
+            m = synth.motion_model(t)
+            q = synth.rot_to_quat(m.Rwb)                                 # (x, y, z, w)
+            vals = [t, q[3], q[0], q[1], q[2], *m.twb, *g, *a, *m.vel]
+            f.write(",".join(repr(float(v)) for v in vals) + "\n")
+    for k in range(st.n_frames):
+        with open(os.path.join(out_dir, "keyframe", "all_points_%d.txt" % k), "w") as f:
+            f.write(",".join(KEYFRAME_COLUMNS) + "\n")
+            for l, h in enumerate(st.lm_host):
+                if h == k:
+                    xy = np.asarray(st.lm_px[l], dtype=np.float64)
+                elif k in st.lm_obs[l]:
+                    xy = np.asarray(st.lm_obs[l][k], dtype=np.float64)
+                else:
+                    continue
+                pw = st.R[h] @ (synth.R_IC @ (np.array([st.lm_px[l][0], st.lm_px[l][1], 1.0]) * st.lm_depth[l]) + synth.T_IC) + st.P[h]
+                vals = [st.times[k], l, *pw, 1.0, xy[0], xy[1], fx * xy[0] + cx, fx * xy[1] + cy]
+                f.write(",".join(str(v) if isinstance(v, int) else repr(float(v)) for v in vals) + "\n")
+
+
+def _read_csv(path, wanted, optional=()):
+    """Columns by name, extra columns ignored (io::ignore_extra_column of the reference's CSV reader)."""
+    with open(path) as f:
+        header = [h.strip() for h in f.readline().strip().split(",")]
+        missing = [w for w in wanted if w not in header]
+        if missing:
+            raise ValueError("%s: missing column(s) %s" % (path, ", ".join(missing)))
+        cols = [header.index(w) for w in wanted]
+        opt = [header.index(w) if w in header else -1 for w in optional]
+        data, extra = [], []
+        for line in f:
+            line = line.strip()
+            if not line:
+                continue
+            parts = line.split(",")
+            data.append([float(parts[c]) for c in cols])
+            extra.append([float(parts[c]) if c >= 0 else np.nan for c in opt])
+    return np.array(data, dtype=np.float64).reshape(-1, len(wanted)), np.array(extra, dtype=np.float64).reshape(-1, len(optional))
+
+
+class SimulatorFileStream:
+    """A stream read from the reference simulator's files (see write_simulator_files): the same attributes as
+    SyntheticStream, so StreamDriver runs on either.  IMU samples are cut into per-frame intervals the way
+    System::ProcessBackEnd does (System.cpp:363-401): every sample up to the image stamp, then one sample linearly
+    interpolated to the stamp itself, which also opens the next interval (Estimator::processIMU, acc_0 / gyr_0)."""
+
+    def __init__(self, directory, imu_file="imu_pose.txt", keyframe_dir="keyframe", max_frames=None, seed=0):
+        import os
+        import re
+        imu, extra = _read_csv(os.path.join(directory, imu_file),
+                               ("timestamp", "gyro_x", "gyro_y", "gyro_z", "acc_x", "acc_y", "acc_z"),
+                               ("q_w", "q_x", "q_y", "q_z", "p_x", "p_y", "p_z", "v_x", "v_y", "v_z"))
+        files = []
+        for name in os.listdir(os.path.join(directory, keyframe_dir)):
+            m = re.fullmatch(r"all_points_(.*)\.txt", name)
+            if m:
+                files.append((int(m.group(1)), os.path.join(directory, keyframe_dir, name)))
+        files.sort()                                        # by sequence id, run_vio_simulation.cpp:141-147
+        if max_frames:
+            files = files[:max_frames]
+        frames = []
+        for _, path in files:
+            kf, world = _read_csv(path, ("timestamp", "id", "x_normalized", "y_normalized"), ("x", "y", "z"))
+            if len(kf):
+                frames.append((kf, world))
+        self.n_frames = len(frames)
+        self.times = [float(kf[0, 0]) for kf, _ in frames]
+        self.t0, self.frame_dt = self.times[0], (self.times[-1] - self.times[0]) / max(1, self.n_frames - 1)
+        self.ext = np.concatenate([synth.T_IC, synth.rot_to_quat(synth.R_IC)])
+        t_imu = imu[:, 0]
+
+        def at(t, cols):                                    # linear interpolation of imu/extra columns at stamp t
+            j = int(np.clip(np.searchsorted(t_imu, t), 1, len(t_imu) - 1))
+            w = (t - t_imu[j - 1]) / (t_imu[j] - t_imu[j - 1])
+            w = min(max(w, 0.0), 1.0)
+            return (1.0 - w) * cols[j - 1] + w * cols[j]
+
+        # ground truth at the frame stamps (initial guesses and the ATE reference); velocity by central differences
+        # of the position when the file has no v columns
+        have_gt = not np.isnan(extra[:, 0:7]).any()
+        self.P, self.Q, self.R, self.V = (np.zeros((self.n_frames, 3)), np.zeros((self.n_frames, 4)),
+                                          np.zeros((self.n_frames, 3, 3)), np.zeros((self.n_frames, 3)))
+        for k, t in enumerate(self.times):
+            if not have_gt:
+                self.Q[k] = (0, 0, 0, 1)
+                self.R[k] = np.eye(3)
+                continue
+            g = at(t, extra)
+            q = np.array([g[1], g[2], g[3], g[0]])
+            self.Q[k] = q / np.linalg.norm(q)
+            self.R[k] = synth.quat_to_rot(self.Q[k])
+            self.P[k] = g[4:7]
+            if not np.isnan(extra[:, 7:10]).any():
+                self.V[k] = g[7:10]
+            else:
+                h = 2.0 * np.median(np.diff(t_imu))
+                self.V[k] = (at(t + h, extra)[4:7] - at(t - h, extra)[4:7]) / (2.0 * h)
+        self.has_ground_truth = bool(have_gt)
+        # IMU intervals
+        self.imu, self.preint = [], []
+        meas = imu[:, [4, 5, 6, 1, 2, 3]]                  # acc, gyro
+        for k in range(self.n_frames - 1):
+            ta, tb = self.times[k], self.times[k + 1]
+            first = at(ta, meas)
+            dts, accs, gyrs, cur = [], [], [], ta
+            for j in np.nonzero((t_imu > ta) & (t_imu <= tb))[0]:
+                if t_imu[j] - cur > 0:
+                    dts.append(float(t_imu[j] - cur)); accs.append(meas[j, 0:3].copy()); gyrs.append(meas[j, 3:6].copy())
+                    cur = float(t_imu[j])
+            if tb - cur > 1e-12:
+                last = at(tb, meas)
+                dts.append(float(tb - cur)); accs.append(last[0:3].copy()); gyrs.append(last[3:6].copy())
+            self.imu.append(dict(acc0=first[0:3].copy(), gyr0=first[3:6].copy(), dt=dts, acc=accs, gyr=gyrs))
+            self.preint.append(synth.preintegrate(first[0:3], first[3:6], np.zeros(3), np.zeros(3), dts, accs, gyrs))
+        # tracks: a feature id is hosted by the first frame that sees it
+        index = {}
+        self.lm_host, self.lm_px, self.lm_depth, self.lm_obs, self.lm_id = [], [], [], [], []
+        for k, (kf, world) in enumerate(frames):
+            for row, pw in zip(kf, world):
+                fid = int(row[1])
+                if fid not in index:
+                    index[fid] = len(self.lm_host)
+                    self.lm_host.append(k)
+                    self.lm_px.append(row[2:4].copy())
+                    depth = np.nan
+                    if have_gt and not np.isnan(pw).any():
+                        pc = synth.R_IC.T @ (self.R[k].T @ (pw - self.P[k]) - synth.T_IC)
+                        depth = float(pc[2])
+                    self.lm_depth.append(depth)
+                    self.lm_obs.append({})
+                    self.lm_id.append(fid)
+                else:
+                    self.lm_obs[index[fid]][k] = row[2:4].copy()
+        self.init_noise = np.random.RandomState(seed).normal(size=(len(self.lm_host),))
+
+
 class StreamDriver:
     def __init__(self, lib, stream, ctx_kwargs=None, pos_noise=0.02, rot_noise=0.005, depth_noise=0.05, seed=1,
                  triangulate=False, nonkey_every=0):
@@ -332,6 +492,57 @@ def ate_rmse(traj, gt):
     """Translation APE without alignment (the windows are anchored to the initial frame), RMSE in metres."""
     d = traj[:, 1:4] - gt[:, 1:4]
     return float(np.sqrt((d * d).sum(axis=1).mean()))
+
+
+def read_tum(path):
+    """TUM trajectory file: `stamp px py pz qx qy qz qw` per line (System.cpp:438), '#' comments allowed."""
+    rows = []
+    with open(path) as f:
+        for line in f:
+            line = line.strip()
+            if line and not line.startswith("#"):
+                rows.append([float(v) for v in line.replace(",", " ").split()[:8]])
+    return np.array(rows, dtype=np.float64).reshape(-1, 8)
+
+
+def associate(est, gt, max_diff=0.01):
+    """Pair every estimated stamp with the closest ground-truth stamp not further than max_diff (one to one, in time
+    order) — the association of `evo_ape tum` (README.md:169 of the reference's assignment 17)."""
+    ti, tj = est[:, 0], gt[:, 0]
+    j = np.clip(np.searchsorted(tj, ti), 1, len(tj) - 1)
+    j = np.where(np.abs(tj[j - 1] - ti) <= np.abs(tj[j] - ti), j - 1, j)
+    ok = np.abs(tj[j] - ti) <= max_diff
+    # one to one: keep the first estimate claiming a ground-truth sample
+    _, first = np.unique(np.where(ok, j, -1), return_index=True)
+    keep = np.zeros(len(ti), dtype=bool)
+    keep[first] = True
+    keep &= ok
+    return np.nonzero(keep)[0], j[keep]
+
+
+def umeyama_se3(x, y):
+    """Rotation R and translation t minimising sum |R x_k + t - y_k|^2 (Umeyama 1991, no scale): `evo_ape -a`."""
+    mx, my = x.mean(axis=0), y.mean(axis=0)
+    S = (y - my).T @ (x - mx) / len(x)
+    U, _, Vt = np.linalg.svd(S)
+    D = np.eye(3)
+    if np.linalg.det(U) * np.linalg.det(Vt) < 0:
+        D[2, 2] = -1.0
+    R = U @ D @ Vt
+    return R, my - R @ mx
+
+
+def ape_stats(est, gt, align=True, max_diff=0.01):
+    """Translation APE statistics as `evo_ape tum gt est -va` prints them (rmse, mean, median, std, min, max, sse)."""
+    ie, ig = associate(est, gt, max_diff)
+    x, y = est[ie, 1:4], gt[ig, 1:4]
+    if align:
+        R, t = umeyama_se3(x, y)
+        x = x @ R.T + t
+    e = np.linalg.norm(x - y, axis=1)
+    return {"rmse": float(np.sqrt((e * e).mean())), "mean": float(e.mean()), "median": float(np.median(e)),
+            "std": float(e.std()), "min": float(e.min()), "max": float(e.max()), "sse": float((e * e).sum()),
+            "pairs": int(len(e))}
 
 
 def write_tum(path, traj):
