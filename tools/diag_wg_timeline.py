@@ -1,29 +1,39 @@
+"""When and where the workgroups of one k_linearize launch ran (diagnostic build with in-kernel stamps):
+s_memrealtime (100 MHz, device-wide) at the first and last stamp of every workgroup, XCC_ID and HW_ID."""
 import ctypes as C, os, sys
 import numpy as np
-ROOT="/root/repo"
-sys.path.insert(0, os.path.join(ROOT,"tests"))
+ROOT = "/root/repo"
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_package
 vio = load_package()
-lib = vio.VioLib(os.path.join(ROOT,"visual-inertial-odometry_amd","csrc","diag","libvio_hip_stamps.so"),"vio_")
-n=20000
-g=int(os.environ.get("VIO_G_MAX","48"))
+lib = vio.VioLib(os.path.join(ROOT, "visual-inertial-odometry_amd", "csrc", "diag", "libvio_hip_stamps.so"), "vio_")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 w = vio.synth.make_window(n, seed=42)
 ctx = lib.context(); ctx.load(w)
 for _ in range(3): ctx.linearize()
 ctx.synchronize()
-nb=(n+g-1)//g+10
-buf=np.zeros((nb,16),dtype=np.uint64)
-f=lib.dll.vio_debug_stamps; f.restype=C.c_int
-assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(nb))==0
-st=buf.astype(np.int64)
-v=st[:,5]>0
-s0=st[v][:,0]; e=st[v][:,5]
-# s_memtime is per XCD (unsynchronised): cluster the workgroups by clock domain, then look inside each
-order=np.argsort(s0); s0=s0[order]; e=e[order]
-cl=np.concatenate([[0],np.cumsum(np.diff(s0)>10_000_000)])
-print("G",g,"blocks",int(v.sum()),"clock domains",int(cl.max()+1))
-for k in range(int(cl.max())+1):
-    m=cl==k
-    a0=s0[m].min()
-    so=np.sort(s0[m]-a0); eo=np.sort(e[m]-a0)
-    print(" domain %d: %3d workgroups; starts %s ... ends %s; span %d" % (k, m.sum(), so[[0,len(so)//4,len(so)//2,3*len(so)//4,-1]].tolist(), eo[[0,len(eo)//2,-1]].tolist(), eo[-1]))
+nb = (n + 95) // 96 + 10 if len(sys.argv) > 2 else 270
+buf = np.zeros((nb, 16), dtype=np.uint64)
+f = lib.dll.vio_debug_stamps; f.restype = C.c_int
+assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(nb)) == 0
+st = buf.astype(np.int64)
+v = (st[:, 9] > st[:, 8]) & (st[:, 8] > 0) & (st[:, 9] - st[:, 8] < 10_000_000)
+idx = np.nonzero(v)[0]
+t0, t1 = st[v][:, 8], st[v][:, 9]
+xcc = st[v][:, 10] & 0xF
+hw = st[v][:, 11]
+cu, sh, se = (hw >> 8) & 0xF, (hw >> 12) & 0x1, (hw >> 13) & 0x7
+cyc = st[v][:, 5] - st[v][:, 0]
+base = t0.min()
+print("workgroups stamped: %d (blocks %d..%d); kernel-internal span %.2f us; workgroup time median %.2f us (%d cycles)"
+      % (v.sum(), idx.min(), idx.max(), (t1.max() - base) / 100.0, np.median(t1 - t0) / 100.0, np.median(cyc)))
+print("start offsets (us): min %.2f  p25 %.2f  median %.2f  p75 %.2f  max %.2f" % tuple(np.percentile(t0 - base, [0, 25, 50, 75, 100]) / 100.0))
+print("end offsets   (us): min %.2f  p25 %.2f  median %.2f  p75 %.2f  max %.2f" % tuple(np.percentile(t1 - base, [0, 25, 50, 75, 100]) / 100.0))
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        slots = set(zip(se[m].tolist(), sh[m].tolist(), cu[m].tolist()))
+        print(" XCC %d: %3d workgroups on %3d distinct (se,sh,cu); starts %.2f..%.2f us, ends %.2f..%.2f us"
+              % (x, m.sum(), len(slots), (t0[m] - base).min() / 100.0, (t0[m] - base).max() / 100.0, (t1[m] - base).min() / 100.0, (t1[m] - base).max() / 100.0))
+late = np.argsort(t0)[-12:]
+print("latest starters: " + ", ".join("b%d@%.2f(xcc%d)" % (idx[i], (t0[i] - base) / 100.0, xcc[i]) for i in late))

@@ -50,7 +50,7 @@ int lin_lds_doubles_host(int G, int K, int nb, int use_ext);
 namespace {
 
 constexpr int NF = VIO_NUM_FRAMES, PD = VIO_POSE_DIM, PRD = VIO_PRIOR_DIM;
-constexpr int LDS_BUDGET_DOUBLES = 150 * 1024 / 8;     // per linearize workgroup (160 KiB per CU on gfx950)
+constexpr int LDS_BUDGET_DOUBLES = (160 * 1024 - 512) / 8;   // per linearize workgroup: 160 KiB per CU on gfx950, 112 bytes of it static
 constexpr int POSE_SOLVE_TILED = 66 * 272 + 192;   // PS_PACKED of vio_kernels.hip: 66 tiles of 16x17 + the rhs row
 constexpr int POSE_SOLVE_LDS = (POSE_SOLVE_TILED + 176 + 272 + 272 + 192 + 176 + 112 + 176 + 184) * 8 + 176 * 4 + 64;
 constexpr int IMU_ITEM_LDS_DOUBLES = 450 + 225 + 450 + 32;
@@ -126,6 +126,8 @@ struct vio_ctx {
     bool want_natural_hs = false;              // set by vio_get_schur_system: re-run k_assemble with the natural-order copy
     bool natural_hs_valid = false;
     int g_max = 0;                             // landmarks per item; 0 = automatic (VIO_G_MAX overrides; <= 128: k_backsub has one thread per landmark)
+    int g_min = 8;                             // lower end of the automatic choice (VIO_G_MIN overrides)
+    int n_cus = 256;                           // CUs of the device (one k_linearize workgroup each)
     Plan solve_plan, marg_plan;
     Plan *active = nullptr;
     // device buffers independent of the topology
@@ -253,12 +255,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
                 pt.target[k] = key[1 + k];
                 for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + key[1 + k]) pt.tslot[k] = (int8_t)q;
             }
-            // Items per window: one k_linearize workgroup each, one workgroup per CU (LDS).  48 landmarks per item is
-            // the fastest workgroup; when that would need a second round on the 256 CUs, bigger items that still fit one
-            // round win (20 000 landmarks: 250 items of 80 instead of 417 of 48 - same kernel time, shorter k_reduce lists).
-            const int n_lm_total = (int)N;
-            const int g_auto = std::min(96, std::max(48, (n_lm_total + 247) / 248));
-            build_pattern_tables(pt, c->g_max > 0 ? c->g_max : g_auto);
+            build_pattern_tables(pt, c->g_max > 0 ? c->g_max : 128);      // pt.G = the most landmarks the LDS holds
             pl.patterns.push_back(pt);
         } else id = itp->second;
         lm_pattern[l] = id;
@@ -272,6 +269,37 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) pl.sorted_to_orig[start[lm_pattern[l]]++] = (int32_t)l;
     }
     pl.Ns = (int64_t)pl.sorted_to_orig.size();
+    // Landmarks per item.  One k_linearize workgroup per item, one workgroup per CU (LDS), so the kernel takes
+    // rounds x (time of a workgroup), rounds = ceil((items + IMU workgroups) / CUs), and a workgroup of g landmarks takes
+    // ~ (70 + g) x 170 cycles (measured 48..80, tools/diag_wg_timeline.py).  A workgroup too many doubles the kernel:
+    // 20 000 landmarks in 7 patterns are 252 + 10 workgroups at 80 landmarks per item and 245 + 10 at 82 — one round on
+    // the 256 CUs of an MI355X instead of two (20 -> 12 us).  Items of a pattern are then evened out.
+    {
+        std::vector<int64_t> n_of(pl.patterns.size(), 0);
+        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) ++n_of[lm_pattern[l]];
+        const int cus = std::max(1, c->n_cus);
+        int best_g = 0;
+        double best_cost = 0.0;
+        for (int g = c->g_min; g <= 128; ++g) {
+            int64_t blocks = VIO_WINDOW_SIZE;
+            int g_eff = 1;
+            for (size_t q = 0; q < pl.patterns.size(); ++q) {
+                const int gp = std::min(g, pl.patterns[q].G);
+                const int64_t ni = (n_of[q] + gp - 1) / gp;
+                blocks += ni;
+                if (ni) g_eff = std::max<int>(g_eff, (int)((n_of[q] + ni - 1) / ni));
+            }
+            const double cost = (double)((blocks + cus - 1) / cus) * (70.0 + g_eff);
+            if (best_g == 0 || cost < best_cost) { best_g = g; best_cost = cost; }
+        }
+        for (size_t q = 0; q < pl.patterns.size(); ++q) {
+            Pattern &pt = pl.patterns[q];
+            const int gp = std::min(best_g, pt.G);
+            const int64_t ni = std::max<int64_t>(1, (n_of[q] + gp - 1) / gp);
+            pt.G = (int)std::max<int64_t>(1, (n_of[q] + ni - 1) / ni);
+            pt.lds_doubles = lin_lds_doubles_host(pt.G, pt.K, pt.nb, pt.use_ext);
+        }
+    }
     // items
     pl.items.clear();
     std::vector<double> pts_i(2 * std::max<int64_t>(pl.Ns, 1)), pts_j;
@@ -674,6 +702,9 @@ vio_status vio_create(const vio_config *cfg, vio_ctx **out) {
     c->h_pre.assign(VIO_WINDOW_SIZE * PRE_STRIDE, 0.0);
     c->h_Hprior.assign(PD * PD, 0.0); c->h_bprior.assign(PD, 0.0); c->h_errprior.assign(PRD, 0.0); c->h_Jtinv.assign(PRD * PRD, 0.0);
     if (const char *e = std::getenv("VIO_G_MAX")) { int v = std::atoi(e); if (v >= 1 && v <= 128) c->g_max = v; }
+    if (const char *e = std::getenv("VIO_G_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 128) c->g_min = v; }
+    if (c->g_max > 0) c->g_min = c->g_max;     // a forced size is exactly that size (LDS permitting)
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->cfg.device) == hipSuccess && v > 0) c->n_cus = v; }
     if (vio_set_kernel_attributes() != 0) { c->err = "hipFuncSetAttribute failed"; }
     vio_status s = alloc_fixed(c);
     if (s != VIO_OK) { vio_destroy(c); return s; }

@@ -32,9 +32,15 @@
 #ifdef VIO_STAMPS
 // Stamps go to LDS and are flushed once at the end: a global store in front of a barrier would add its own round
 // trip to the phase it is meant to time.
-__shared__ unsigned long long g_stamps[8];
-#define STAMP(T, slot) do { if (threadIdx.x == 0) g_stamps[slot] = __builtin_amdgcn_s_memtime(); } while (0)
-#define STAMP_FLUSH(T) do { if (threadIdx.x == 0 && (T).dbg) for (int q__ = 0; q__ < 8; ++q__) (T).dbg[(size_t)blockIdx.x * 16 + q__] = g_stamps[q__]; } while (0)
+// Slots 8/9: s_memrealtime (the 100 MHz reference clock, one clock domain for the whole device) at the first and at the
+// last stamp; slot 10: XCC_ID, slot 11: HW_ID — where and when a workgroup ran relative to the others.
+__shared__ unsigned long long g_stamps[12];
+__device__ __forceinline__ unsigned d_hwreg_xcc() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x; }
+__device__ __forceinline__ unsigned d_hwreg_hwid() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x)); return x; }
+#define STAMP(T, slot) do { if (threadIdx.x == 0) { g_stamps[slot] = __builtin_amdgcn_s_memtime(); \
+        if ((slot) == 0) { g_stamps[8] = __builtin_amdgcn_s_memrealtime(); g_stamps[10] = d_hwreg_xcc(); g_stamps[11] = d_hwreg_hwid(); } \
+        if ((slot) == 5) g_stamps[9] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#define STAMP_FLUSH(T) do { if (threadIdx.x == 0 && (T).dbg) for (int q__ = 0; q__ < 12; ++q__) (T).dbg[(size_t)blockIdx.x * 16 + q__] = g_stamps[q__]; } while (0)
 #else
 #define STAMP(T, slot) do { } while (0)
 #define STAMP_FLUSH(T) do { } while (0)
@@ -1856,7 +1862,7 @@ int lin_lds_doubles_host(int G, int K, int nb, int use_ext) {
     return lin_lds_doubles(G, K, nb, use_ext);
 }
 int vio_set_kernel_attributes() {
-    hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+    hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     hipError_t e2 = hipFuncSetAttribute((const void *)k_pose_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
 }
