@@ -437,3 +437,47 @@ def test_gn_iterations_interleaved_with_everything_else(vio, oracle_lib, hip_lib
     assert np.isfinite(rep.final_chi2) and rep.final_chi2 <= chi_p * (1 + 1e-9)
     prior = mixed.marginalize(vio.MARG_OLD)
     assert np.isfinite(prior["H"]).all()
+
+
+def test_gn_iterations_with_a_prior(vio, oracle_lib, hip_lib):
+    """With a marginalisation prior a GN step leaves err_prior to the next k_reduce (the pose solve writes b_prior' only)
+    or to the flush: b_prior, err_prior and chi2 must equal the classic path bit for bit whenever anybody looks, and
+    the oracle's within rounding."""
+    w0 = vio.synth.make_window(300, seed=41, t0=0.9)
+    c0 = oracle_lib.context()
+    c0.load(w0)
+    c0.solve(10)
+    w = vio.synth.make_window(700, seed=42, ragged=True)
+    w.prior = c0.marginalize(vio.MARG_OLD)
+    lam = 5e5
+    plain, mixed, o = hip_lib.context(), hip_lib.context(), oracle_lib.context()
+    for c in (plain, mixed, o):
+        c.load(w)
+    for _ in range(4):
+        plain.gn_iteration(lam)
+        o.gn_iteration(lam)
+    bp, ep = plain.get_prior()
+    chi_p = plain.chi2()
+    mixed.gn_iteration(lam)
+    b1, e1 = mixed.get_prior()                  # flush: err_prior of the pending step comes from k_errprior
+    mixed.gn_iteration(lam)
+    mixed.gn_iteration(lam)
+    c3 = mixed.chi2()
+    mixed.gn_iteration(lam)
+    bm, em = mixed.get_prior()
+    np.testing.assert_array_equal(bm, bp)
+    np.testing.assert_array_equal(em, ep)
+    assert mixed.chi2() == chi_p and np.isfinite(c3)
+    assert np.abs(e1).max() > 0 and not np.array_equal(e1, em)
+    bo, eo = o.get_prior()
+    assert tu.rel_max(bp, bo) <= 1e-9 and tu.rel_max(ep, eo) <= 1e-7
+    assert abs(chi_p - o.chi2()) <= 1e-9 * chi_p
+    # the LM path forms err_prior inside the pose solve: same numbers as the deferred path on the same step
+    a, b = hip_lib.context(), hip_lib.context()
+    a.load(w)
+    b.load(w)
+    a.gn_iteration(lam)
+    b.linearize()
+    b.solve_linear(lam)
+    b.update_states()
+    np.testing.assert_array_equal(a.get_prior()[1], b.get_prior()[1])

@@ -31,7 +31,11 @@ struct ReduceTables {
     int32_t n_step;
     int32_t gate;
     const LmState *lm;
+    const double *jtinv;
+    const double *bprior;
+    double *errprior;
 };
+void vio_launch_errprior(const DeviceTables &T, hipStream_t s);
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s);
 void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s);
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
@@ -434,6 +438,7 @@ vio_status flush_decide(vio_ctx *c) {
     c->decide_pending = false;
     DeviceTables T = make_tables_raw(c, *c->active);
     vio_launch_backsub(T, 0, c->stream);
+    if (T.has_prior) vio_launch_errprior(T, c->stream);      // the GN step left err_prior of its trial slot undone
     if (c->hook || c->comm) {
         vio_launch_step_sum(T, 0, c->stream);
         VIOCHK(run_exchange(c, 1));
@@ -610,7 +615,11 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     if (test_prev) T.gn_flags = 2;
     if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
     { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
-    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items, gate, T.lm};
+    // with a prior, the previous GN step left err_prior to this k_reduce (k_pose_solve wrote b_prior' only)
+    const bool err_prev = test_prev && T.has_prior;
+    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items, gate, T.lm,
+                   err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + c->cur_host * 176 : nullptr,
+                   err_prev ? T.errprior + c->cur_host * 160 : nullptr};
     { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
     VIOCHK(run_exchange(c, 0));
     if (test_prev) { T.gn_flags = 1; c->decide_pending = false; }
@@ -637,7 +646,7 @@ vio_status enqueue_init_lm(vio_ctx *c, const DeviceTables &T, int max_iter) {
 vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int gate = 0) {
     DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
     T.lm_gate = gate;
-    if (gn) T.cur_hint = c->cur_host;
+    if (gn) { T.cur_hint = c->cur_host; T.gn_flags = 4; }      // bit 2: err_prior is formed by the next k_reduce (or by flush_decide)
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     if (gn) {
         // the step is accepted whatever chi2 turns out to be: the landmark back-substitution, the chi2 of the new state and

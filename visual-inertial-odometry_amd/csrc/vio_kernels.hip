@@ -782,9 +782,29 @@ struct ReduceTables {
     int32_t n_step;              // items
     int32_t gate;                // see d_gated_off
     const LmState *lm;
+    const double *jtinv;         // GN mode with a prior: err_prior of the previous step is formed here (blocks >= 91), or null
+    const double *bprior;        // b_prior after that step
+    double *errprior;
 };
 
 #define RED_THREADS 1024
+#define RED_ERR_BLOCKS ((VIO_PRD + RED_THREADS / 64 - 1) / (RED_THREADS / 64))
+
+// err_prior[i] = -(Jt_prior_inv b_prior.head(156))[i]  (problem.cc:474), one wave per row; the same sum whoever calls it
+__device__ __forceinline__ double d_errprior_dot(double j0, double j1, double j2, double y0, double y1, double y2) {
+    double s = 0;
+    s += -j0 * y0;
+    s += -j1 * y1;
+    s += -j2 * y2;
+    return d_wave_sum_to_lane63(s);
+}
+__device__ __forceinline__ void d_errprior_row(const double *jt, const double *b, double *err, int i, int lane) {
+    const bool in2 = lane + 128 < VIO_PRD;
+    const double j0 = jt[i * VIO_PRD + lane], j1 = jt[i * VIO_PRD + lane + 64], j2 = in2 ? jt[i * VIO_PRD + lane + 128] : 0.0;
+    const double y0 = b[lane], y1 = b[lane + 64], y2 = in2 ? b[lane + 128] : 0.0;
+    const double s = d_errprior_dot(j0, j1, j2, y0, y1, y2);
+    if (lane == 63) err[i] = s;
+}
 
 __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
     // A list is cut into interleaved slots (entry e belongs to slot e mod nslots); a group of 36 (18) threads owns a
@@ -793,6 +813,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
     __shared__ double sV[56 * 18 + 8];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (d_gated_off(R.lm, R.gate)) return;
+    if (b >= VIO_NPAIR + VIO_NCB + 1) {          // GN mode: err_prior of the step k_pose_solve took (it left b_prior' only)
+        const int row = (b - (VIO_NPAIR + VIO_NCB + 1)) * (RED_THREADS / 64) + (tid >> 6);
+        if (row < VIO_PRD) d_errprior_row(R.jtinv, R.bprior, R.errprior, row, tid & 63);
+        return;
+    }
     const int lo = R.list_off[b], hi = R.list_off[b + 1];
     if (b < VIO_NPAIR) {
         constexpr int W = 36, NS = RED_THREADS / W;           // 28 slots
@@ -1091,6 +1116,8 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
 // (UpdateStates :453-480, vertex_pose.cc:7-19), their pair table, and the first-order prior update (:473-474).
 // ---------------------------------------------------------------------------------------------------------
 #define PS_THREADS 1024
+#define PS_PRIOR_ROWS 12   // rows of H_prior per wave (15 waves x 12 >= 171)
+#define PS_JT_ROWS 12      // rows of Jt_prior_inv per wave (14 waves x 12 >= 156)
 #define PS_TY (PS_THREADS / 32)
 
 
@@ -1438,7 +1465,25 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
         if (cc <= j) P[tix(I, I) + j * PS_TROW + cc] = 0.0;
     }
     __syncthreads();
+    // While wave 0 back-substitutes, the other 15 waves fetch their rows of H_prior for the prior update of the tail
+    // (problem.cc:466-475): 171 x 171 doubles through one CU are ~17 k cycles when every row waits for its own loads,
+    // and nothing when they are in registers before dx exists.
+    double hp[PS_PRIOR_ROWS][3], bp[PS_PRIOR_ROWS];
+#pragma unroll
+    for (int r = 0; r < PS_PRIOR_ROWS; ++r) { hp[r][0] = 0.0; hp[r][1] = 0.0; hp[r][2] = 0.0; bp[r] = 0.0; }
     if (uwave == 0) ps_backsub((lds_double *)P, lane);
+    else if (T.has_prior) {
+#pragma unroll
+        for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
+            const int i = (uwave - 1) + 15 * r;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int j = lane + 64 * q;
+                if (i < n && j < n) hp[r][q] = T.Hprior[i * n + j];
+            }
+            if (i < n) bp[r] = T.bprior[cur * 176 + i];
+        }
+    }
     __syncthreads();
     PS_OUT(2);
     for (int r = tid; r < n; r += PS_THREADS) {
@@ -1448,40 +1493,67 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     }
     __syncthreads();
 
-    // trial states = current (+) dx   (UpdateStates, problem.cc:456-463): in place in the LDS copy of the states
-    // (the pair table below reads them from there, not back from HBM) and out to the trial slot
-    double *stt = T.state + trial * STATE_STRIDE;
-    if (tid < 12) {
-        double *p = (tid == 0) ? sState + STATE_EXT : sState + STATE_POSE + 7 * (tid - 1);
-        double *o = (tid == 0) ? stt + STATE_EXT : stt + STATE_POSE + 7 * (tid - 1);
-        const double *d = (tid == 0) ? sDx : sDx + 6 + 15 * (tid - 1);
-        double tmp[7];
-        d_pose_plus(p, d, tmp);
-        for (int k = 0; k < 7; ++k) { p[k] = tmp[k]; o[k] = tmp[k]; }
-    } else if (tid >= 32 && tid < 32 + 99) {
-        const int e = tid - 32, f = e / 9, k = e % 9;
-        const double v = sState[STATE_SB + e] + sDx[12 + 15 * f + k];
-        sState[STATE_SB + e] = v;
-        stt[STATE_SB + e] = v;
-    }
-    __syncthreads();
-    d_build_pairtab(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, PS_THREADS);
-
-    // prior: b' = b - H_prior*dx ; err' = -Jt_prior_inv * b'.head(156)   (problem.cc:466-475)
-    if (T.has_prior) {
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int i = wave; i < n; i += PS_THREADS / 64) {
+    // prior: b' = b - H_prior*dx ; err' = -Jt_prior_inv * b'.head(156)   (problem.cc:466-475).  The rows of H_prior are
+    // in registers already.
+    if (T.has_prior && uwave != 0) {
+        const double x0 = sDx[lane], x1 = sDx[lane + 64], x2 = (lane + 128 < n) ? sDx[lane + 128] : 0.0;
+#pragma unroll
+        for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
+            const int i = (uwave - 1) + 15 * r;
             double s = 0;
-            for (int j = lane; j < n; j += 64) s += T.Hprior[i * n + j] * sDx[j];
+            s += hp[r][0] * x0;
+            s += hp[r][1] * x1;
+            s += hp[r][2] * x2;
             s = d_wave_sum_to_lane63(s);
-            if (lane == 63) { const double v = T.bprior[cur * 176 + i] - s; sB[i] = v; T.bprior[trial * 176 + i] = v; }
+            if (lane == 63 && i < n) { const double v = bp[r] - s; sB[i] = v; T.bprior[trial * 176 + i] = v; }
+        }
+    }
+    // In the GN loop (gn_flags bit 2) err_prior is left to the next k_reduce: nobody needs it before the step test there.
+    const bool err_here = T.has_prior && !(T.gn_flags & 4);
+    // From here the waves split by role (wave-uniform branches; both sides pass the same two barriers):
+    //   waves 0,1: trial states = current (+) dx (UpdateStates, problem.cc:456-463) in place in the LDS copy of the states
+    //              and out to the trial slot, then the pair table of the trial states, read from that LDS copy;
+    //   waves 2..15: the rows of Jt_prior_inv, requested before the barriers and used after them, when b' is complete.
+    if (uwave < 2) {
+        double *stt = T.state + trial * STATE_STRIDE;
+        if (tid < 12) {
+            double *p = (tid == 0) ? sState + STATE_EXT : sState + STATE_POSE + 7 * (tid - 1);
+            double *o = (tid == 0) ? stt + STATE_EXT : stt + STATE_POSE + 7 * (tid - 1);
+            const double *d = (tid == 0) ? sDx : sDx + 6 + 15 * (tid - 1);
+            double tmp[7];
+            d_pose_plus(p, d, tmp);
+            for (int k = 0; k < 7; ++k) { p[k] = tmp[k]; o[k] = tmp[k]; }
+        } else if (tid >= 16 && tid < 16 + 99) {
+            const int e = tid - 16, f = e / 9, k = e % 9;
+            const double v = sState[STATE_SB + e] + sDx[12 + 15 * f + k];
+            sState[STATE_SB + e] = v;
+            stt[STATE_SB + e] = v;
         }
         __syncthreads();
-        for (int i = wave; i < VIO_PRD; i += PS_THREADS / 64) {
-            double s = 0;
-            for (int j = lane; j < VIO_PRD; j += 64) s += -T.Jtinv[i * VIO_PRD + j] * sB[j];
-            s = d_wave_sum_to_lane63(s);
-            if (lane == 63) T.errprior[trial * 160 + i] = s;
+        d_build_pairtab(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, 128);      // one more barrier inside
+    } else {
+        double jp[PS_JT_ROWS][3];
+        if (err_here) {
+#pragma unroll
+            for (int r = 0; r < PS_JT_ROWS; ++r) {
+                const int i = (uwave - 2) + 14 * r;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int j = lane + 64 * q;
+                    jp[r][q] = (i < VIO_PRD && j < VIO_PRD) ? T.Jtinv[i * VIO_PRD + j] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        __syncthreads();
+        if (err_here) {
+            const double y0 = sB[lane], y1 = sB[lane + 64], y2 = (lane + 128 < VIO_PRD) ? sB[lane + 128] : 0.0;
+#pragma unroll
+            for (int r = 0; r < PS_JT_ROWS; ++r) {
+                const int i = (uwave - 2) + 14 * r;
+                const double s = d_errprior_dot(jp[r][0], jp[r][1], jp[r][2], y0, y1, y2);
+                if (lane == 63 && i < VIO_PRD) T.errprior[trial * 160 + i] = s;
+            }
         }
     }
     PS_OUT(3);
@@ -1832,8 +1904,15 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
     hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1), dim3(RED_THREADS), 0, s, R);
+    hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1 + (R.errprior ? RED_ERR_BLOCKS : 0)), dim3(RED_THREADS), 0, s, R);
 }
+// err_prior of a GN step whose test is flushed the classic way (flush_decide): the trial slot, before k_lm_decide reads it
+__global__ __launch_bounds__(RED_THREADS) void k_errprior(DeviceTables T) {
+    const int trial = 1 - d_cur(T);
+    const int row = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
+    if (row < VIO_PRD) d_errprior_row(T.Jtinv, T.bprior + trial * 176, T.errprior + trial * 160, row, threadIdx.x & 63);
+}
+void vio_launch_errprior(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_errprior, dim3(RED_ERR_BLOCKS), dim3(RED_THREADS), 0, s, T); }
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(PS_NP + 1), dim3(ASM_THREADS), 0, s, T); }
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
