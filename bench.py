@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--landmarks", type=int, default=20000, help="landmarks per GPU")
     ap.add_argument("--obs-per-landmark", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prior", action="store_true", help="first-window case: no marginalisation prior")
     ap.add_argument("--cpu-baseline-steps", type=int, default=0, help="0 = sized for about 10-20 s")
     args = ap.parse_args()
 
@@ -100,6 +101,23 @@ def main():
 
     n_per_gpu, k_obs = args.landmarks, args.obs_per_landmark
     full = vio.synth.make_window(n_per_gpu * world, seed=42, obs_per_landmark=k_obs)
+    if not args.no_prior:
+        # the steady-state window carries a marginalisation prior ("produced by running one MargOldFrame
+        # on a preceding window"; its 235 KB are part of B_win): solve the window one frame earlier, marginalise its
+        # oldest frame (rank 0; the others receive the same bytes)
+        prior = None
+        if rank == 0:
+            wp = vio.synth.make_window(300, seed=41, t0=0.9, obs_per_landmark=k_obs)
+            cp = hip.context(device=local_rank)
+            cp.load(wp)
+            cp.solve(10)
+            prior = cp.marginalize(vio.MARG_OLD)
+            del cp
+        if dist is not None:
+            box = [prior]
+            dist.broadcast_object_list(box, src=0)
+            prior = box[0]
+        full.prior = prior
 
     # N > 1: the library all-reduces with RCCL itself on its own stream (VIO_EXCHANGE=hook selects the
     # torch.distributed hook instead, which has to share torch's current stream)
@@ -238,8 +256,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic 11-frame VIO window (SURVEY.md 8d): %d landmarks x %d observations per GPU, "
-                                   "10 IMU factors, Cauchy loss, extrinsic fixed, fixed-lambda GN iteration"
-                                   % (n_per_gpu, k_obs),
+                                   "10 IMU factors, %s, Cauchy loss, extrinsic fixed, fixed-lambda GN iteration"
+                                   % (n_per_gpu, k_obs, "no prior" if args.no_prior else "marginalisation prior of the preceding window"),
                        "landmarks_per_gpu": n_per_gpu, "observations_per_gpu": m, "landmarks_total": n_per_gpu * world,
                        "lambda": lam, "parallelism": "landmark-sharded x%d, all-reduce of the 72x72 reduced system" % world
                        if world > 1 else "single GPU", "exchange": sb.exchange},
