@@ -20,7 +20,7 @@ ctx.load(w)
 for _ in range(3):
     ctx.linearize()
 ctx.synchronize()
-gmax = int(os.environ.get("VIO_G_MAX", "48"))
+gmax = int(os.environ.get("VIO_G_MAX", "82"))
 nb = (n + gmax - 1) // gmax + 10
 buf = np.zeros((nb, 16), dtype=np.uint64)
 f = lib.dll.vio_debug_stamps
