@@ -437,8 +437,10 @@ vio_status flush_decide(vio_ctx *c) {
     if (!c->decide_pending || !c->active) return VIO_OK;
     c->decide_pending = false;
     DeviceTables T = make_tables_raw(c, *c->active);
-    vio_launch_backsub(T, 0, c->stream);
-    if (T.has_prior) vio_launch_errprior(T, c->stream);      // the GN step left err_prior of its trial slot undone
+    T.gn_flags = 8;                                          // the GN step left the prior update of its trial slot undone:
+    vio_launch_backsub(T, 0, c->stream);                     // b_prior' by k_backsub,
+    T.gn_flags = 0;
+    if (T.has_prior) vio_launch_errprior(T, c->stream);      // err_prior' by k_errprior
     if (c->hook || c->comm) {
         vio_launch_step_sum(T, 0, c->stream);
         VIOCHK(run_exchange(c, 1));
@@ -646,7 +648,7 @@ vio_status enqueue_init_lm(vio_ctx *c, const DeviceTables &T, int max_iter) {
 vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int gate = 0) {
     DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
     T.lm_gate = gate;
-    if (gn) { T.cur_hint = c->cur_host; T.gn_flags = 4; }      // bit 2: err_prior is formed by the next k_reduce (or by flush_decide)
+    if (gn) { T.cur_hint = c->cur_host; T.gn_flags = 4; }      // bit 2: the prior update is left to the next k_linearize / k_reduce (or to flush_decide)
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     if (gn) {
         // the step is accepted whatever chi2 turns out to be: the landmark back-substitution, the chi2 of the new state and

@@ -370,12 +370,36 @@ __host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext
     return VIO_MAXK * PAIR_STRIDE + 16 + 2 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
 }
 
+// b_prior'[i] = b_prior[i] - (H_prior dx)[i]  (problem.cc:473), one wave per row; the same sum whoever calls it
+__device__ __forceinline__ double d_bprior_dot(double h0, double h1, double h2, double x0, double x1, double x2, double b) {
+    double s = 0;
+    s += h0 * x0;
+    s += h1 * x1;
+    s += h2 * x2;
+    s = d_wave_sum_to_lane63(s);
+    return b - s;
+}
+// rows first, first + step, ... of the update above, from HBM (the GN loop's deferred form: k_linearize, k_backsub)
+__device__ __forceinline__ void d_bprior_rows(const DeviceTables &T, int from, int to, int first, int step, int lane) {
+    const bool in2 = lane + 128 < VIO_PD;
+    const double x0 = T.dx[lane], x1 = T.dx[lane + 64], x2 = in2 ? T.dx[lane + 128] : 0.0;
+    for (int i = first; i < VIO_PD; i += step) {
+        const double *h = T.Hprior + (size_t)i * VIO_PD;
+        const double v = d_bprior_dot(h[lane], h[lane + 64], in2 ? h[lane + 128] : 0.0, x0, x1, x2, T.bprior[from * 176 + i]);
+        if (lane == 63) T.bprior[to * 176 + i] = v;
+    }
+}
+
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (d_gated_off(T.lm, T.lm_gate)) return;
+    // GN mode (gn_flags bit 1) with a prior: the previous step also owes b_prior' = b_prior - H_prior dx (problem.cc:473).
+    // Row r belongs to workgroup r mod grid, to its last wave: idle in phase 1 of a landmark item, first thing in an IMU item.
+    const bool owe_prior = (T.gn_flags & 2) && T.has_prior;
     if (b >= T.n_items) {
         STAMP(T, 0);
+        if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, gridDim.x, tid & 63); }
         d_imu_item(T, b - T.n_items, dyn_smem);
         STAMP(T, 5);
         STAMP_FLUSH(T);
@@ -452,6 +476,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
 
     // ---------------- phase 1 ----------------
     STAMP(T, 1);
+    if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, gridDim.x, tid & 63);
     double chi_acc = 0.0;
     for (int o = tid; o < G * K; o += LIN_THREADS) {
         const int k = o / G, g = o - k * G;
@@ -1116,7 +1141,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
 // (UpdateStates :453-480, vertex_pose.cc:7-19), their pair table, and the first-order prior update (:473-474).
 // ---------------------------------------------------------------------------------------------------------
 #define PS_THREADS 1024
-#define PS_PRIOR_ROWS 12   // rows of H_prior per wave (15 waves x 12 >= 171)
+#define PS_PRIOR_ROWS 13   // rows of H_prior per wave (14 waves x 13 >= 171)
 #define PS_JT_ROWS 12      // rows of Jt_prior_inv per wave (14 waves x 12 >= 156)
 #define PS_TY (PS_THREADS / 32)
 
@@ -1381,7 +1406,16 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) tt[cofs + 4 * PS_TROW * q] = acc[q];
         } else if (uwave == PS_THREADS / 64 - 2) {
-            if (lane < PS_NB) sDinv[k0 + lane] = d_fast_rcp(P[tix(K, K) + lane * (PS_TROW + 1)]);
+            // reciprocals of the pivots; then M_K takes the factored tile's place: nobody reads that tile again but the
+            // back-substitution, which multiplies by M_K = L_KK^-T instead of running a 16-step chain through L_KK
+            double dd = 0.0, mk[4];
+            if (lane < PS_NB) dd = d_fast_rcp(P[tix(K, K) + lane * (PS_TROW + 1)]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mk[q] = sM[((lane >> 4) + 4 * q) * PS_TROW + (lane & 15)];
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane < PS_NB) sDinv[k0 + lane] = dd;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) P[tix(K, K) + ((lane >> 4) + 4 * q) * PS_TROW + (lane & 15)] = mk[q];
         } else if (uwave == PS_THREADS / 64 - 1) {
             double y = 0.0;
             if (lane < PS_NB) {
@@ -1457,32 +1491,68 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     if (tid == 0 && T.dbg) { T.dbg[8] = t_panel; T.dbg[9] = t_trail; }
 #endif
 
-    // ---- z = D^+ y, then x = L^-T z (solve of Cholesky/LDLT.h:558-600): one wave, no barriers (ps_backsub).
-    //      First the diagonal tiles are cleaned: F left them transposed with junk on and left of the diagonal;
-    //      zeros there let the chain read whole rows unmasked. ----
-    for (int e = tid; e < PS_NT * PS_NB * PS_NB; e += PS_THREADS) {
-        const int I = e >> 8, j = (e >> 4) & 15, cc = e & 15;
-        if (cc <= j) P[tix(I, I) + j * PS_TROW + cc] = 0.0;
-    }
-    __syncthreads();
-    // While wave 0 back-substitutes, the other 15 waves fetch their rows of H_prior for the prior update of the tail
-    // (problem.cc:466-475): 171 x 171 doubles through one CU are ~17 k cycles when every row waits for its own loads,
-    // and nothing when they are in registers before dx exists.
-    double hp[PS_PRIOR_ROWS][3], bp[PS_PRIOR_ROWS];
+    // ---- z = D^+ y, then x = L^-T z (solve of Cholesky/LDLT.h:558-600), block by block from the bottom:
+    //      x_K = M_K (z_K - D_K^-1 sum_{J>K} U_JK^T x_J),  M_K = L_KK^-T parked in the diagonal tile by the S phase.
+    //      Wave K owns block column K; only its lanes 0..15 work (lane = column): LDS bandwidth is what a round costs
+    //      — a 64-lane broadcast read returns 1 KB however few distinct addresses it has (tools/microbench/barrier_cost.hip:
+    //      a barrier is ~25 cycles, 16 waves x 8 such reads ~700) — so nothing is read by lanes that do not need it.
+    //      Round J (x_J is out, one barrier per round): every wave K < J adds U_JK^T x_J to its running sum; wave J-1 then
+    //      has its whole sum and finishes x_{J-1} with one 16-term product per lane, the v_j taken from lane j of the row by
+    //      DPP (no LDS round trip).
+    {
+        const int i16 = lane & 15, K = uwave;
+        const bool work = lane < PS_NB;
+        double acc = 0.0, mw[PS_NB], ucol[PS_NB], own_dinv = 0.0, own_z = 0.0;
 #pragma unroll
-    for (int r = 0; r < PS_PRIOR_ROWS; ++r) { hp[r][0] = 0.0; hp[r][1] = 0.0; hp[r][2] = 0.0; bp[r] = 0.0; }
-    if (uwave == 0) ps_backsub((lds_double *)P, lane);
-    else if (T.has_prior) {
+        for (int j = 0; j < PS_NB; ++j) { mw[j] = 0.0; ucol[j] = 0.0; }
+        // PS_DOT16: out = init + sum_j arr[j] v_j with v_j taken from lane j of the 16-lane row (DPP row_newbcast): each lane
+        // holds ONE element of the vector, so a vector costs one LDS read instruction, not eight broadcast reads (a 64-lane
+        // read returns 1 KB whatever its addresses: ~20 cycles each on the critical path).  Two chains; s_nop: DPP reads a
+        // VGPR the VALU has just written.
+#define PS_DOT16(out, init, vin, arr) do { double x__ = (init), x2__ = 0.0; const double v__ = (vin); \
+            asm volatile("s_nop 1\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %13 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %14 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %15 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %16 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %17 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %18 row_newbcast:15 row_mask:0xf bank_mask:0xf" \
+                         : "+v"(x__), "+v"(x2__) \
+                         : "v"(v__), "v"(arr[0]), "v"(arr[1]), "v"(arr[2]), "v"(arr[3]), "v"(arr[4]), "v"(arr[5]), "v"(arr[6]), "v"(arr[7]), \
+                           "v"(arr[8]), "v"(arr[9]), "v"(arr[10]), "v"(arr[11]), "v"(arr[12]), "v"(arr[13]), "v"(arr[14]), "v"(arr[15])); \
+            (out) = x__ + x2__; } while (0)
+        // column i16 of U_{I,K2}
+#define PS_LOAD_COL(I_, K_) do { const double *src__ = P + tix((I_), (K_)) + i16; _Pragma("unroll") for (int r = 0; r < PS_NB; ++r) ucol[r] = src__[r * PS_TROW]; } while (0)
+        if (K < PS_NT && work) {
+            const double *src = P + tix(K, K) + i16 * PS_TROW;                       // row i16 of M_K
 #pragma unroll
-        for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
-            const int i = (uwave - 1) + 15 * r;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int j = lane + 64 * q;
-                if (i < n && j < n) hp[r][q] = T.Hprior[i * n + j];
-            }
-            if (i < n) bp[r] = T.bprior[cur * 176 + i];
+            for (int j = 0; j < PS_NB; ++j) mw[j] = src[j];
+            own_dinv = sDinv[K * PS_NB + i16];
+            own_z = sY[K * PS_NB + i16] * own_dinv;                                  // sY holds y = L^-1 b (unscaled)
+            if (K == PS_NT - 1) { double x; PS_DOT16(x, 0.0, own_z, mw); sX[K * PS_NB + i16] = x; }
+            else PS_LOAD_COL(PS_NT - 1, K);
         }
+        __syncthreads();                                                             // x_10 is out
+        int J = PS_NT - 1;
+        for (; J >= K + 1; --J) {
+            if (work) {
+                PS_DOT16(acc, acc, sX[J * PS_NB + i16], ucol);
+                if (J > K + 1) PS_LOAD_COL(J - 1, K);       // does not depend on x: in flight across the barrier
+                else { double x; PS_DOT16(x, 0.0, fma(-own_dinv, acc, own_z), mw); sX[K * PS_NB + i16] = x; }
+            }
+            __syncthreads();
+        }
+        for (; J >= 1; --J) __syncthreads();
     }
     __syncthreads();
     PS_OUT(2);
@@ -1493,27 +1563,15 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     }
     __syncthreads();
 
-    // prior: b' = b - H_prior*dx ; err' = -Jt_prior_inv * b'.head(156)   (problem.cc:466-475).  The rows of H_prior are
-    // in registers already.
-    if (T.has_prior && uwave != 0) {
-        const double x0 = sDx[lane], x1 = sDx[lane + 64], x2 = (lane + 128 < n) ? sDx[lane + 128] : 0.0;
-#pragma unroll
-        for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
-            const int i = (uwave - 1) + 15 * r;
-            double s = 0;
-            s += hp[r][0] * x0;
-            s += hp[r][1] * x1;
-            s += hp[r][2] * x2;
-            s = d_wave_sum_to_lane63(s);
-            if (lane == 63 && i < n) { const double v = bp[r] - s; sB[i] = v; T.bprior[trial * 176 + i] = v; }
-        }
-    }
-    // In the GN loop (gn_flags bit 2) err_prior is left to the next k_reduce: nobody needs it before the step test there.
-    const bool err_here = T.has_prior && !(T.gn_flags & 4);
-    // From here the waves split by role (wave-uniform branches; both sides pass the same two barriers):
+    // prior: b' = b - H_prior*dx ; err' = -Jt_prior_inv * b'.head(156)   (problem.cc:466-475).  In the GN loop
+    // (gn_flags bit 2) both are left to the next iteration, where they cost nothing: the rows of b' to the head of
+    // k_linearize, err' to k_reduce (flush_decide does them when anybody else asks first).  An LM trial needs them
+    // before its k_lm_decide: here, by waves 2..15, every load of a pass requested before the first is used.
+    const bool prior_here = T.has_prior && !(T.gn_flags & 4);
+    // The waves split by role (wave-uniform branches; both sides pass the same two barriers):
     //   waves 0,1: trial states = current (+) dx (UpdateStates, problem.cc:456-463) in place in the LDS copy of the states
     //              and out to the trial slot, then the pair table of the trial states, read from that LDS copy;
-    //   waves 2..15: the rows of Jt_prior_inv, requested before the barriers and used after them, when b' is complete.
+    //   waves 2..15: b' before the first barrier, the rows of Jt_prior_inv requested between the two, err' after.
     if (uwave < 2) {
         double *stt = T.state + trial * STATE_STRIDE;
         if (tid < 12) {
@@ -1532,8 +1590,29 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
         __syncthreads();
         d_build_pairtab(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, 128);      // one more barrier inside
     } else {
+        if (prior_here) {
+            double hp[PS_PRIOR_ROWS][3], bp[PS_PRIOR_ROWS];
+#pragma unroll
+            for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
+                const int i = (uwave - 2) + 14 * r;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int j = lane + 64 * q;
+                    hp[r][q] = (i < n && j < n) ? T.Hprior[i * n + j] : 0.0;
+                }
+                bp[r] = (i < n) ? T.bprior[cur * 176 + i] : 0.0;
+            }
+            const double x0 = sDx[lane], x1 = sDx[lane + 64], x2 = (lane + 128 < n) ? sDx[lane + 128] : 0.0;
+#pragma unroll
+            for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
+                const int i = (uwave - 2) + 14 * r;
+                const double v = d_bprior_dot(hp[r][0], hp[r][1], hp[r][2], x0, x1, x2, bp[r]);
+                if (lane == 63 && i < n) { sB[i] = v; T.bprior[trial * 176 + i] = v; }
+            }
+        }
+        __syncthreads();
         double jp[PS_JT_ROWS][3];
-        if (err_here) {
+        if (prior_here) {
 #pragma unroll
             for (int r = 0; r < PS_JT_ROWS; ++r) {
                 const int i = (uwave - 2) + 14 * r;
@@ -1545,8 +1624,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
             }
         }
         __syncthreads();
-        __syncthreads();
-        if (err_here) {
+        if (prior_here) {
             const double y0 = sB[lane], y1 = sB[lane + 64], y2 = (lane + 128 < VIO_PRD) ? sB[lane + 128] : 0.0;
 #pragma unroll
             for (int r = 0; r < PS_JT_ROWS; ++r) {
@@ -1571,6 +1649,8 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
     if (d_gated_off(lm, T.lm_gate)) return;
     const int cur = d_cur(T);
     const int which = (mode == 1) ? cur : (cur ^ 1);
+    // flush of a GN step (gn_flags bit 3): its b_prior' rows, which the next k_linearize would have formed
+    if ((T.gn_flags & 8) && T.has_prior && (lane >> 6) == 1) d_bprior_rows(T, cur, cur ^ 1, b, gridDim.x, lane & 63);
     if (b >= T.n_items) {
         const int k = b - T.n_items;
         if (lane == 0) {

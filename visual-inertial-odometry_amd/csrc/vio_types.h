@@ -157,7 +157,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     int32_t n_step_blocks;
     int32_t gn_flags;            // GN mode, for the PREVIOUS step: bit 0: k_assemble runs its test (its chi2 is the one this linearisation
                                  // computed); bit 1: k_linearize applies its landmark back-substitution first; bit 2 (k_pose_solve):
-                                 // this step's err_prior is left to the next k_reduce
+                                 // this step's prior update is left to the next k_linearize (b_prior') and k_reduce (err_prior');
+                                 // bit 3 (k_backsub): flush of such a step, form b_prior' here
     int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur
     int32_t lm_gate;             // device-driven LM loop: 0 run; 2: skip if lm->stop; 3: skip unless lm->need_linearize && !lm->stop
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
