@@ -648,7 +648,8 @@ vio_status enqueue_init_lm(vio_ctx *c, const DeviceTables &T, int max_iter) {
 vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int gate = 0) {
     DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
     T.lm_gate = gate;
-    if (gn) { T.cur_hint = c->cur_host; T.gn_flags = 4; }      // bit 2: the prior update is left to the next k_linearize / k_reduce (or to flush_decide)
+    T.gn_flags = 4;         // bit 2: k_pose_solve leaves the prior update to the kernels that follow (all paths now)
+    if (gn) T.cur_hint = c->cur_host;      // GN: the update rides with the next k_linearize / k_reduce (or with flush_decide)
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     if (gn) {
         // the step is accepted whatever chi2 turns out to be: the landmark back-substitution, the chi2 of the new state and
@@ -660,7 +661,12 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int ga
         c->device_ahead = true;
         return VIO_OK;
     }
+    // the prior update of an LM trial (problem.cc:466-475) is spread over the kernels that follow, like a flushed GN step's:
+    // b_prior' by k_backsub's workgroups, err_prior' by k_errprior (one CU alone needs ~10 us for the two matrices)
+    T.gn_flags = 8;
     { ProfScope ps(c, VIO_K_BACKSUB); vio_launch_backsub(T, 0, c->stream); }
+    T.gn_flags = 0;
+    if (T.has_prior) vio_launch_errprior(T, c->stream);
     if (sharded(c)) {
         vio_launch_step_sum(T, 0, c->stream);
         VIOCHK(run_exchange(c, 1));

@@ -1986,8 +1986,10 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1 + (R.errprior ? RED_ERR_BLOCKS : 0)), dim3(RED_THREADS), 0, s, R);
 }
-// err_prior of a GN step whose test is flushed the classic way (flush_decide): the trial slot, before k_lm_decide reads it
+// err_prior of a trial step (an LM trial, or a GN step whose test is flushed the classic way): the trial slot, before
+// k_lm_decide reads it
 __global__ __launch_bounds__(RED_THREADS) void k_errprior(DeviceTables T) {
+    if (d_gated_off(T.lm, T.lm_gate)) return;
     const int trial = 1 - d_cur(T);
     const int row = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
     if (row < VIO_PRD) d_errprior_row(T.Jtinv, T.bprior + trial * 176, T.errprior + trial * 160, row, threadIdx.x & 63);
