@@ -6,7 +6,7 @@ import glob
 import sys
 from collections import defaultdict
 
-f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv") + glob.glob(sys.argv[1] + "/*_kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 600

@@ -21,14 +21,14 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stats_dir = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-src = glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))[0]
+src = (glob.glob(os.path.join(stats_dir, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(stats_dir, "*_kernel_stats.csv")))[0]
 shutil.copy(src, os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
 print(open(src).read()[:1500])
 
 
 def per_kernel(pmc_dir, counter):
     tot, cnt = defaultdict(float), defaultdict(int)
-    for f in glob.glob(os.path.join(pmc_dir, "*", "*_counter_collection.csv")):
+    for f in glob.glob(os.path.join(pmc_dir, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(pmc_dir, "*_counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter:
                 name = row["Kernel_Name"].split("(")[0]
