@@ -36,6 +36,8 @@ print("visual workgroups: %d   (s_memtime ticks = 100 MHz?  constant clock; shar
 for k, nm in enumerate(names):
     print("  %-28s mean %8.1f  max %8.1f" % (nm, d[:, k].mean(), d[:, k].max()))
 print("  inside phase 2, wave 0: product done after %.0f, vector sums done after %.0f (of the phase)" % ((st[vis][:, 6] - st[vis][:, 3]).mean(), (st[vis][:, 7] - st[vis][:, 3]).mean()))
+print("  wave 0 (direct product): chunk loop done after %.0f, remainder %.0f, stored %.0f | wave 4 (Schur tile): starts %.0f, chunk loop done %.0f (of the phase)" % tuple(
+    (st[vis][:, b_] - st[vis][:, 3]).mean() for b_ in (14, 15, 6, 12, 13)))
 print("  total                        mean %8.1f  max %8.1f" % ((st[vis][:, 5] - st[vis][:, 0]).mean(), (st[vis][:, 5] - st[vis][:, 0]).max()))
 if imu.any():
     t = st[imu][:, 5] - st[imu][:, 0]

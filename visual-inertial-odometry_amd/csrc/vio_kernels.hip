@@ -34,13 +34,13 @@
 // trip to the phase it is meant to time.
 // Slots 8/9: s_memrealtime (the 100 MHz reference clock, one clock domain for the whole device) at the first and at the
 // last stamp; slot 10: XCC_ID, slot 11: HW_ID — where and when a workgroup ran relative to the others.
-__shared__ unsigned long long g_stamps[12];
+__shared__ unsigned long long g_stamps[16];
 __device__ __forceinline__ unsigned d_hwreg_xcc() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x; }
 __device__ __forceinline__ unsigned d_hwreg_hwid() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(x)); return x; }
 #define STAMP(T, slot) do { if (threadIdx.x == 0) { g_stamps[slot] = __builtin_amdgcn_s_memtime(); \
         if ((slot) == 0) { g_stamps[8] = __builtin_amdgcn_s_memrealtime(); g_stamps[10] = d_hwreg_xcc(); g_stamps[11] = d_hwreg_hwid(); } \
         if ((slot) == 5) g_stamps[9] = __builtin_amdgcn_s_memrealtime(); } } while (0)
-#define STAMP_FLUSH(T) do { if (threadIdx.x == 0 && (T).dbg) for (int q__ = 0; q__ < 12; ++q__) (T).dbg[(size_t)blockIdx.x * 16 + q__] = g_stamps[q__]; } while (0)
+#define STAMP_FLUSH(T) do { if (threadIdx.x == 0 && (T).dbg) for (int q__ = 0; q__ < 16; ++q__) (T).dbg[(size_t)blockIdx.x * 16 + q__] = g_stamps[q__]; } while (0)
 #else
 #define STAMP(T, slot) do { } while (0)
 #define STAMP_FLUSH(T) do { } while (0)
@@ -637,25 +637,37 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
                 const double *pa = ca < Dk ? plane + oa : sZero;
                 const double *pb = cb < Dk ? plane + ob : sZero;
                 const int sa = ca < Dk ? 2 * RROW : 0, sb = cb < Dk ? 2 * RROW : 0;      // 2 landmarks per MFMA step
-                const bool same = t != 1;                            // diagonal tiles: B is A
+                // (on a diagonal tile B is A: both streams are read all the same — a branch-free loop of loads and MFMAs
+                // is worth more than the four reads it would save)
                 const int steps_full = G >> 1;                       // steps whose two landmarks both exist
                 const int chunks_full = steps_full >> 2;
                 double va[4], vb[4], xa[4], xb[4];
-                if (chunks_full > 0) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = same ? va[u] : pb[u * sb]; }
-                }
-                for (int ch = 0; ch < chunks_full; ++ch) {
+                for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; }      // (G >= 1: in range even if unused)
+                // lgkmcnt(0) here, by hand: left to itself the compiler puts a partial wait on the loop header, i.e. in front
+                // of every chunk's MFMAs and on the loads just issued for the next one (an LDS latency per chunk)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                // two chunks per trip, the operand registers taking turns (no copies); a load that would run past the last
+                // full chunk re-reads the chunk before it instead of branching
+                int ch = 0;
+                for (; ch + 2 <= chunks_full; ch += 2) {
                     pa += 4 * sa; pb += 4 * sb;
-                    if (ch + 1 < chunks_full) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; if (!same) xb[u] = pb[u * sb]; }
-                    }
+                    for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; xb[u] = pb[u * sb]; }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], same ? va[u] : vb[u], acc, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+                    const int nx = ch + 2 < chunks_full ? 4 : 0;
+                    pa += nx * sa; pb += nx * sb;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { va[u] = xa[u]; vb[u] = xb[u]; }
+                    for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xb[u], acc, 0, 0, 0);
                 }
+                if (ch < chunks_full) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+                }
+                STAMP(T, 14);
                 // the remaining steps (fewer than 4 full ones, plus the half step of an odd G), landmark by landmark masked
                 for (int st = 4 * chunks_full; 2 * st < G; ++st) {
                     const int g = 2 * st + (rg >> 1);
@@ -680,21 +692,35 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
                 const int sa = a < D ? 4 * LREC : 0, sb = bq < D ? 4 * LREC : 0, sh = 4 * LREC;
                 const int chunks_full = (G >> 2) >> 2;               // chunks whose 16 landmarks all exist
                 double va[4], vb[4], vh[4], xa[4], xb[4], xh[4];
+#ifdef VIO_STAMPS
+                if (tid == 256) g_stamps[12] = __builtin_amdgcn_s_memtime();
+#endif
                 if (chunks_full > 0) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; vh[u] = ph[u * sh]; }
                 }
-                for (int ch = 0; ch < chunks_full; ++ch) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                int ch = 0;
+                for (; ch + 2 <= chunks_full; ch += 2) {             // as above: two chunks per trip, registers taking turns
                     pa += 4 * sa; pb += 4 * sb; ph += 4 * sh;
-                    if (ch + 1 < chunks_full) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; xb[u] = pb[u * sb]; xh[u] = ph[u * sh]; }
-                    }
+                    for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; xb[u] = pb[u * sb]; xh[u] = ph[u * sh]; }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], -(vb[u] * vh[u]), acc, 0, 0, 0);
+                    const int nx = ch + 2 < chunks_full ? 4 : 0;
+                    pa += nx * sa; pb += nx * sb; ph += nx * sh;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { va[u] = xa[u]; vb[u] = xb[u]; vh[u] = xh[u]; }
+                    for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; vh[u] = ph[u * sh]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], -(xb[u] * xh[u]), acc, 0, 0, 0);
                 }
+                if (ch < chunks_full) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], -(vb[u] * vh[u]), acc, 0, 0, 0);
+                }
+#ifdef VIO_STAMPS
+                if (tid == 256) g_stamps[13] = __builtin_amdgcn_s_memtime();
+#endif
                 for (int st = 16 * chunks_full; st < G; st += 4) {   // the remaining landmarks, masked
                     const int g = st + rg, gc = min(g, G - 1);
                     const double m = g < G ? 1.0 : 0.0;
@@ -703,6 +729,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa * m, -(wb * Lg[12 * nb]), acc, 0, 0, 0);
                 }
             }
+            STAMP(T, 15);
             double *tl = sTile + (size_t)wk * 256 + rg * 16 + cl;   // C/D image: row rg + 4v, column cl
 #pragma unroll
             for (int v = 0; v < 4; ++v) tl[64 * v] = acc[v];
