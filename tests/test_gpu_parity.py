@@ -481,3 +481,15 @@ def test_gn_iterations_with_a_prior(vio, oracle_lib, hip_lib):
     b.solve_linear(lam)
     b.update_states()
     np.testing.assert_array_equal(a.get_prior()[1], b.get_prior()[1])
+
+
+@pytest.mark.parametrize("n,ragged", [(25000, False), (60000, True), (3000, True)])
+def test_item_sizing_regimes(vio, oracle_lib, hip_lib, n, ragged):
+    """The landmarks-per-item choice follows the number of k_linearize rounds the window needs on the device's CUs: one
+    round with items as small as 8 landmarks (3 000), exactly one (the headline), two and more (25 000 = the per-GPU share
+    of BASELINE.json's 200k configuration; 60 000 ragged = every pattern, several rounds).  Same arithmetic everywhere."""
+    w = vio.synth.make_window(n, seed=77, ragged=ragged)
+    ch, co = hip_lib.context(), oracle_lib.context()
+    ch.load(w)
+    co.load(w)
+    compare_stepwise(tu.run_stepwise(ch), tu.run_stepwise(co))
