@@ -419,6 +419,8 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     T.Hs = c->d_Hs.p; T.Pg = c->d_Pg.p; T.perm = c->d_perm.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
     T.gn_flags = 0; T.cur_hint = -1; T.lm_gate = 0;
+    T.imu_mask = 0;
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) T.imu_mask |= (c->imu_valid[k] ? 1 : 0) << k;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
 #ifdef VIO_STAMPS

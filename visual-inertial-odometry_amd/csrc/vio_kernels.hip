@@ -999,13 +999,8 @@ __device__ __forceinline__ int tix(int I, int J) { return (I * (I + 1) / 2 + J) 
 __device__ __forceinline__ int telem(int r, int c) { return tix(r >> 4, c >> 4) + (r & 15) * PS_TROW + (c & 15); }
 
 // entry (i,j), i >= j, of H_pp_schur_ without lambda: the lower triangle as Eigen's LDLT reads it
-// valid: bit k set = IMU edge k exists (d_imu_mask: read once per kernel so that an entry costs one round trip, not two)
-__device__ __forceinline__ int d_imu_mask(const DeviceTables &T) {
-    int m = 0;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) m |= (T.imu_valid[k] != 0) << k;
-    return m;
-}
+// valid: bit k set = IMU edge k exists (a kernel argument: an entry costs one round trip, not two)
+__device__ __forceinline__ int d_imu_mask(const DeviceTables &T) { return T.imu_mask; }
 __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int i, int j, double &vv, double &vr) {
     vv = 0.0; vr = 0.0;                 // reduced visual part, IMU + prior part
     const int ci = full_to_cam(i), cj = full_to_cam(j);
@@ -1068,7 +1063,17 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
     if (d_gated_off(T.lm, T.lm_gate)) return;
     const int cur = d_cur(T);
     const int valid = d_imu_mask(T);
-    if (t < VIO_PD) { double vv, vr; d_hs_entry(T, valid, t, t, vv, vr); sDg[t] = fabs(vv + vr); }
+    // Workgroup b < 171 owns NATURAL row b: its entries are requested together with the diagonal (one round trip for both)
+    // and scattered once the ranks are known: natural row b is row rank(b) of the permuted matrix.
+    double row_e = 0.0;
+    if (t < VIO_PD) {
+        double vv, vr;
+        d_hs_entry(T, valid, t, t, vv, vr);
+        double wv = 0.0, wr = 0.0;
+        if (b < VIO_PD) d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
+        sDg[t] = fabs(vv + vr);
+        row_e = wv + wr;
+    }
     __syncthreads();
     if (t < 5 * VIO_PD) {           // rank_i = #{j : d_j > d_i or (d_j == d_i and j < i)}, 5 threads per entry
         const int i = t % VIO_PD, part = t / VIO_PD;
@@ -1082,26 +1087,22 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
         sCnt[part * 176 + i] = rank;
     }
     __syncthreads();
-    if (t < VIO_PD) sPerm[sCnt[t] + sCnt[176 + t] + sCnt[352 + t] + sCnt[528 + t] + sCnt[704 + t]] = t;
-    __syncthreads();
-    if (t >= 192) return;
+    int my_rank = 0;
+    if (t < VIO_PD) { my_rank = sCnt[t] + sCnt[176 + t] + sCnt[352 + t] + sCnt[528 + t] + sCnt[704 + t]; sPerm[my_rank] = t; }
     if (b < VIO_PD) {
-        const int i = b;
         if (t < VIO_PD) {
-            if (T.natural_hs) {                 // natural-order H_pp_schur_: only the getters and Marginalize read it
-                double vv, vr;
-                d_hs_entry(T, valid, max(i, t), min(i, t), vv, vr);
-                T.Hs[i * VIO_PD + t] = vv + vr;
-            }
-            if (t <= i) {                       // permuted row i of the tiled triangle
-                const int pi = sPerm[i], pj = sPerm[t];
-                double wv, wr;
-                d_hs_entry(T, valid, max(pi, pj), min(pi, pj), wv, wr);
-                T.Pg[telem(i, t)] = wv + wr;
-                if (t < i && (t >> 4) == (i >> 4)) T.Pg[telem(t, i)] = wv + wr;      // upper half of a diagonal tile
+            if (T.natural_hs) T.Hs[b * VIO_PD + t] = row_e;      // natural-order H_pp_schur_: only the getters and Marginalize read it
+            const int i = sCnt[b] + sCnt[176 + b] + sCnt[352 + b] + sCnt[528 + b] + sCnt[704 + b], j = my_rank;
+            if (j <= i) {                       // entry (i, j) of the permuted, tiled triangle
+                T.Pg[telem(i, j)] = row_e;
+                if (j < i && (j >> 4) == (i >> 4)) T.Pg[telem(j, i)] = row_e;      // upper half of a diagonal tile
             }
         }
-    } else if (b < PS_NP) {
+        return;
+    }
+    __syncthreads();
+    if (t >= 192) return;
+    if (b < PS_NP) {
         if (t <= b) {
             T.Pg[telem(b, t)] = (t == b) ? 1.0 : 0.0;
             if (t < b && (t >> 4) == (b >> 4)) T.Pg[telem(t, b)] = 0.0;
@@ -1155,17 +1156,15 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
 // Pivoting: Eigen's LDLT picks, at step k, the largest |diagonal| among the NOT YET UPDATED trailing diagonal
 // (it is a left-looking algorithm, Cholesky/LDLT.h:317-320), so the whole pivot order is a sort of |diag(A)| and is
 // known before the factorisation starts: k_assemble rank-sorts the diagonal and writes the permuted lower triangle
-// as 16x16 tiles; this kernel copies them into LDS (140 KB of the CU's 160 KB) and runs an unpivoted blocked
-// right-looking LDL^T, 11 block columns of 16:
-//   panel            up to three waves, one lane per sub-diagonal row (16 columns in registers) plus a copy of the
-//                    diagonal tile's row (lane & 15) in every lane, so pivot-row entries are v_readlane broadcasts;
-//                    reciprocal by v_rcp_f64 + Newton; columns stay unscaled (U(r,k) = L(r,k) d_k)
-//   trailing update  all 16 waves, one 16x16 tile at a time: C -= U_ik (D^-1 U_jk^T) as four chained
-//                    v_mfma_f64_16x16x4_f64 with both operands read straight from the panel's tiles
+// as 16x16 tiles (row stride 17); this kernel copies them into LDS (143 KB of the CU's 160 KB) and runs an unpivoted
+// blocked right-looking LDL^T, 11 block columns of 16, as a task graph with look-ahead (see the loop below):
+//   F(K)      factor the diagonal tile: one wave, lane = row, the identity's rows riding along give M_K = L_KK^-T
+//   S(I,K)    U_IK = A_IK M_K, one MFMA product per tile below the diagonal (U = L D: columns stay unscaled)
+//   U(I,J,K)  A_IJ -= U_IK D_K^-1 U_JK^T, four chained v_mfma_f64_16x16x4_f64 per tile, operands straight from the tiles
 // The right-hand side rides along as row 176, so the forward substitution is free; the back-substitution with L^T
-// runs block by block from the bottom: a 16-step chain inside the diagonal tile, then every column left of it
-// accumulates that block's contribution (outer-product form, one barrier per block).  Then: trial pose states
-// (UpdateStates :453-480, vertex_pose.cc:7-19), their pair table, and the first-order prior update (:473-474).
+// runs block by block from the bottom on all waves: x_K = M_K (z_K - D_K^-1 sum_{J>K} U_JK^T x_J), one barrier per block.
+// Then: trial pose states (UpdateStates :453-480, vertex_pose.cc:7-19) and their pair table.  The first-order prior
+// update (:473-474) is formed here only on the stepwise path; the solve paths leave it to the kernels that follow.
 // ---------------------------------------------------------------------------------------------------------
 #define PS_THREADS 1024
 #define PS_PRIOR_ROWS 13   // rows of H_prior per wave (14 waves x 13 >= 171)
@@ -1196,7 +1195,7 @@ __device__ __forceinline__ double d_fast_rcp(double d) {                // 1/d t
 //   * the pivot column is not broadcast with v_readlane (two per value plus a hazard nop) but published to LDS —
 //     lane c stores U(c,j) as soon as it is final — and read back as uniform loads, two values per instruction;
 //   * it is published INTO the tile, transposed (U(c,j) at [17 j + c]): that is the factored tile's final place,
-//     no copy-back; the back-substitution reads the diagonal tiles in that transposed form;
+//     no copy-back (the pivots on its diagonal are what the S phase takes the reciprocals from, before M_K replaces it);
 //   * the sched_barriers pin the order publish -> (4 updates, 2 refills) groups, which gives every load a full
 //     reciprocal chain of slack; the reciprocals themselves are recomputed from the stored pivots by another
 //     wave (sDinv), off this chain.
@@ -1243,49 +1242,6 @@ __device__ __noinline__ void ps_factor_diag(lds_double *tile, lds_double *sI, ld
     }
 }
 
-// Back-substitution of k_pose_solve, one wave.  Lane l owns columns l, l+64, l+128 (slots) and keeps
-// acc = sum over the rows below the column's block of U(r,c) x_r for each.  Per block I, from the bottom:
-//   chain   the 16 lanes of the block's slot: x_j = z_j - dinv_j (acc_j + sum_{jj>j} U(16I+jj, c_j) x_jj), 16 steps,
-//           x_jj broadcast by v_readlane; the diagonal tile is stored transposed and zero on/left of the diagonal,
-//           so a lane's 16 multipliers are one unmasked row
-//   spread  every column left of the block adds the block's 16 terms, the x_jj still in scalar registers
-// No LDS round trip for x, no barrier; the z = y / d of Eigen is y * (1/d) with the factorisation's reciprocal.
-__device__ __noinline__ void ps_backsub(lds_double *P, int lane) {
-    lds_double *sY = P + PS_YOFF, *sDinv = P + PS_PACKED, *sX = sDinv + 176 + 2 * PS_TS;
-    double acc[3] = {0.0, 0.0, 0.0}, xs[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int I = PS_NT - 1; I >= 0; --I) {
-        const int slot = (I * PS_NB) >> 6, lb = (I * PS_NB) & 63;
-        const int j = (lane - lb) & 15;                 // lanes outside the block compute on junk, never read back
-        const int cc = I * PS_NB + j;
-        lds_double *dt = P + tix(I, I) + j * PS_TROW;
-        const double dinv = sDinv[cc];
-        const double z = sY[cc] * dinv;                 // sY holds y = L^-1 b (unscaled)
-        double blk[PS_NB];
-#pragma unroll
-        for (int jj = 0; jj < PS_NB; ++jj) blk[jj] = dt[jj];
-        double a = acc[slot];
-        double xr[PS_NB];
-#pragma unroll
-        for (int jj = PS_NB - 1; jj >= 0; --jj) {
-            xr[jj] = d_readlane(fma(-dinv, a, z), lb + jj);
-            a = fma(blk[jj], xr[jj], a);
-        }
-        const double xmine = fma(-dinv, a, z);          // blk[jj] = 0 for jj <= j: a stopped changing after step j+1
-        xs[slot] = (lane >= lb && lane < lb + PS_NB) ? xmine : xs[slot];
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-            if (sl * 64 < I * PS_NB) {                  // the slot still has columns left of the block
-                const int c = min(lane + 64 * sl, I * PS_NB - 1);      // clamped lanes redo a neighbour's sum: unused
-                lds_double *ut = P + tix(I, c >> 4) + (c & 15);
-#pragma unroll
-                for (int jj = 0; jj < PS_NB; ++jj) acc[sl] = fma(ut[jj * PS_TROW], xr[jj], acc[sl]);
-            }
-        }
-    }
-#pragma unroll
-    for (int sl = 0; sl < 3; ++sl) sX[lane + 64 * sl] = xs[sl];
-}
 
 __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     double *P = dyn_smem;                          // 66 tiles of 16x17, then the rhs row (192)

@@ -160,6 +160,7 @@ struct DeviceTables {            // everything a kernel needs, passed by value
                                  // this step's prior update is left to the next k_linearize (b_prior') and k_reduce (err_prior');
                                  // bit 3 (k_backsub): flush of such a step, form b_prior' here
     int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur
+    int32_t imu_mask;            // bit k: IMU edge k exists (the host's copy of imu_valid: saves the kernels a dependent load)
     int32_t lm_gate;             // device-driven LM loop: 0 run; 2: skip if lm->stop; 3: skip unless lm->need_linearize && !lm->stop
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
     LmState *lm;
