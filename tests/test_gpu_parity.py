@@ -493,3 +493,37 @@ def test_item_sizing_regimes(vio, oracle_lib, hip_lib, n, ragged):
     ch.load(w)
     co.load(w)
     compare_stepwise(tu.run_stepwise(ch), tu.run_stepwise(co))
+
+
+def test_bench_workload_with_prior_against_oracle(vio, oracle_lib, hip_lib, big_window):
+    """The workload bench.py times: the 20 000-landmark window with the marginalisation prior of a preceding window.
+    One stepwise LM step and five GN iterations against the oracle; Solve(10) against the oracle's end state."""
+    w0 = vio.synth.make_window(300, seed=41, t0=0.9)
+    c0 = oracle_lib.context()
+    c0.load(w0)
+    c0.solve(10)
+    w = big_window.copy()
+    w.prior = c0.marginalize(vio.MARG_OLD)
+    ch, co = hip_lib.context(), oracle_lib.context()
+    ch.load(w)
+    co.load(w)
+    compare_stepwise(tu.run_stepwise(ch), tu.run_stepwise(co))
+    ch.load(w)
+    co.load(w)
+    ch.linearize()
+    _, lam = ch.init_lm()
+    for _ in range(5):
+        ch.gn_iteration(lam)
+        co.gn_iteration(lam)
+    ph, sh, _ = ch.get_window()
+    po, so_, _ = co.get_window()
+    assert np.abs(ph - po).max() <= 1e-8 and np.abs(sh - so_).max() <= 1e-7
+    assert np.abs(ch.get_landmarks() - co.get_landmarks()).max() <= 1e-8
+    assert abs(ch.chi2() - co.chi2()) <= 1e-9 * co.chi2()
+    bh, eh = ch.get_prior()
+    bo, eo = co.get_prior()
+    assert tu.rel_max(bh, bo) <= 1e-9 and tu.rel_max(eh, eo) <= 1e-7
+    ch.load(w)
+    co.load(w)
+    rh, ro = ch.solve(10), co.solve(10)
+    assert rh.iterations == ro.iterations and abs(rh.final_chi2 - ro.final_chi2) <= 1e-6 * ro.final_chi2

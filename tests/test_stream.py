@@ -166,3 +166,20 @@ def test_simulator_file_formats_round_trip(vio, oracle_lib, tmp_path):
     fs2 = vio.stream.SimulatorFileStream(str(tmp_path))
     assert abs(sum(fs2.imu[1]["dt"]) - (t_mid - fs2.times[1])) <= 1e-12 and len(fs2.imu[1]["dt"]) == 21
     assert abs(fs2.preint[1]["sum_dt"] + fs2.preint[2]["sum_dt"] - 0.2) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_runs_a_stream_read_from_simulator_files(vio, oracle_lib, hip_lib, tmp_path):
+    """The file-format path end to end on the GPU: write the simulator's files, read them back, run the HIP backend over
+    the stream with triangulated depths and a non-keyframe every fourth frame; same trajectory as the oracle's."""
+    st = vio.stream.SyntheticStream(n_frames=22, landmarks_per_frame=20, seed=9)
+    vio.stream.write_simulator_files(st, str(tmp_path))
+    fs = vio.stream.SimulatorFileStream(str(tmp_path))
+    dh = vio.stream.StreamDriver(hip_lib, fs, triangulate=True, nonkey_every=4)
+    do = vio.stream.StreamDriver(oracle_lib, fs, triangulate=True, nonkey_every=4)
+    th, to = dh.run(), do.run()
+    gt = do.ground_truth()
+    sh, so = vio.stream.ape_stats(th, gt), vio.stream.ape_stats(to, gt)
+    assert so["rmse"] < 0.05 and abs(sh["rmse"] - so["rmse"]) <= 0.01 * so["rmse"] + 1e-6
+    assert np.abs(th[:, 1:4] - to[:, 1:4]).max() < 1e-3
+    assert dh.flags == do.flags
