@@ -1179,12 +1179,12 @@ __device__ __forceinline__ double d_readlane(double x, int lane) {      // lane 
 }
 __device__ __forceinline__ double d_fast_rcp(double d) {                // 1/d to within an ulp; 0 for d == 0
     if (d == 0.0) return 0.0;
+    // v_rcp_f64 is good to 4.6e-8; one cubic step x (1 + e + e^2), e = 1 - d x, brings it to 1.1e-16 (the same as two Newton
+    // steps, measured over 1M values) with three dependent FMAs instead of four: this sits on the chain of every pivot
     double x = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
-    e = fma(-d, x, 1.0);
-    x = fma(x, e, x);
-    return x;
+    const double e = fma(-d, x, 1.0);
+    const double t = fma(e, e, e);
+    return fma(x, t, x);
 }
 
 // F(K) of k_pose_solve: factor the 16x16 diagonal tile `tile` (row stride 17) in place, one wave.
