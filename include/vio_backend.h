@@ -51,7 +51,8 @@ typedef enum {
     VIO_OK = 0,
     VIO_ERR_BAD_ARG = -1,
     VIO_ERR_HIP = -2,          /* a HIP runtime call failed; see vio_last_error() */
-    VIO_ERR_NOT_FINITE = -3,   /* chi2 or the linear solve produced a non-finite value */
+    VIO_ERR_NOT_FINITE = -3,   /* chi2 or the linear solve produced a non-finite value; from vio_solve: such trials were
+                                * rejected as in problem.cc:559, the states are the last accepted ones */
     VIO_ERR_EMPTY = -4,        /* Problem::Solve returns false on an empty graph, problem.cc:172-175 */
     VIO_ERR_UNSUPPORTED = -5,  /* graph shape outside what the window layout can express */
     VIO_ERR_NO_DEVICE = -6

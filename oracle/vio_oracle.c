@@ -888,6 +888,7 @@ struct vioo_ctx {
     double Hv_dir[CD * CD];              /* un-Schur'd visual part (local shard only), for vioo_get_pose_hessian */
     vio_exchange_fn hook;
     void *hook_user;
+    int nonfinite;               /* a trial chi2 was not finite during the last vio_solve (reported as VIO_ERR_NOT_FINITE) */
 };
 
 static int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
@@ -1072,12 +1073,17 @@ static void linearize_visual(struct vioo_ctx *c, int marg_mode) {
     /* Schur terms, landmarks in index order */
     double *S = (double *)calloc(CD * CD, sizeof(double));
     double sb[CD];
+    int degenerate = 0;
     memset(sb, 0, sizeof(sb));
     for (int64_t l = 0; l < c->N; ++l) {
         const double *w = &c->Hpl[(size_t)l * CD];
         if (marg_mode && c->hll[l] == 0.0) continue;       /* landmark not in the marginalisation graph */
         maxh = fmax(maxh, fabs(c->hll[l]));
         double hinv = 1.0 / c->hll[l];                      /* Hmm_inv (problem.cc:419-425) */
+        /* a landmark without information (every edge weighted to zero by the loss): the reference's dense tempH = Hpm *
+         * Hmm_inv (problem.cc:427) multiplies zeros by that infinity, and the NaNs fill H_pp_schur; the sparse loop below
+         * would skip them, so say it explicitly */
+        if (c->hll[l] == 0.0) degenerate = 1;
         int nzc[CD], nn = 0;
         for (int a = 0; a < CD; ++a) if (w[a] != 0.0) nzc[nn++] = a;
         for (int x = 0; x < nn; ++x) {
@@ -1092,6 +1098,11 @@ static void linearize_visual(struct vioo_ctx *c, int marg_mode) {
         c->vis[VIS_BDIR + a] = bv[a];
         c->vis[VIS_DIAG + a] = Hv[a * CD + a];
     }
+    if (degenerate)
+        for (int a = 0; a < CD; ++a) {
+            for (int b2 = 0; b2 < CD; ++b2) c->vis[VIS_H + a * CD + b2] = NAN;
+            c->vis[VIS_BRED + a] = NAN;
+        }
     c->vis[VIS_CHI] = chi;
     c->vis[VIS_MAXH] = maxh;
     free(S);
@@ -1331,6 +1342,7 @@ vio_status vio_eval_step(struct vioo_ctx *c, int32_t *accepted, double *chi2, do
     scale += 1e-6;
     double rho = (c->chi - tempChi) / scale;
     int ok;
+    if (!isfinite(tempChi)) c->nonfinite = 1;
     if (rho > 0 && isfinite(tempChi)) {
         double alpha = 1. - pow((2 * rho - 1), 3);
         alpha = fmin(alpha, 2. / 3.);
@@ -1362,8 +1374,10 @@ vio_status vio_solve(struct vioo_ctx *c, int32_t iterations, vio_solve_report *r
     c->t_hessian_ms = 0;
     vio_solve_report r;
     memset(&r, 0, sizeof(r));
+    c->nonfinite = 0;
     vio_linearize(c);
     vio_init_lm(c, &r.initial_chi2, NULL);
+    if (!isfinite(r.initial_chi2)) c->nonfinite = 1;
     int stop = 0, iter = 0;
     double last_chi = 1e20;
     while (!stop && iter < iterations) {
@@ -1386,7 +1400,9 @@ vio_status vio_solve(struct vioo_ctx *c, int32_t iterations, vio_solve_report *r
     r.final_chi2 = c->chi; r.final_lambda = c->lambda;
     r.solve_ms = now_ms() - t0; r.hessian_ms = c->t_hessian_ms;
     if (rep) *rep = r;
-    return VIO_OK;
+    /* the reference's Solve returns true here: non-finite trials were rejected (problem.cc:559) and the states are the
+     * last accepted ones; the ABI says so in its status (include/vio_backend.h) */
+    return c->nonfinite ? VIO_ERR_NOT_FINITE : VIO_OK;
 }
 
 vio_status vio_gn_iteration(struct vioo_ctx *c, double lambda) {

@@ -527,3 +527,29 @@ def test_bench_workload_with_prior_against_oracle(vio, oracle_lib, hip_lib, big_
     co.load(w)
     rh, ro = ch.solve(10), co.solve(10)
     assert rh.iterations == ro.iterations and abs(rh.final_chi2 - ro.final_chi2) <= 1e-6 * ro.final_chi2
+
+
+def test_landmark_without_information_gives_an_error_not_a_crash(vio, oracle_lib, hip_lib):
+    """A landmark whose every edge the loss weights to zero (single-observation tracks, Tukey, outliers) has h_ll = 0: the
+    reference's Hmm_inv is infinite and its dense products fill H_pp_schur with NaN (problem.cc:419-429).  Same here and
+    in the oracle: non-finite step, VIO_ERR_NOT_FINITE from vio_solve — and the NaN diagonal must still rank to a valid
+    pivot permutation (it used to index out of bounds)."""
+    kw = dict(pos_noise=0.001, rot_noise=0.0002, depth_noise=0.003, pixel_noise=0.25 / 460, outlier_fraction=0.05)
+    w = vio.synth.make_window(200, seed=1019, ragged=False, obs_per_landmark=1, **kw)
+    ch, co = hip_lib.context(ext_fixed=0, loss_type=3), oracle_lib.context(ext_fixed=0, loss_type=3)
+    ch.load(w)
+    co.load(w)
+    a, b = tu.run_stepwise(ch), tu.run_stepwise(co)
+    assert (b["hll"] == 0).any() and np.array_equal(a["hll"] == 0, b["hll"] == 0)
+    assert not np.isfinite(a["dx_pose"]).all() and not np.isfinite(b["dx_pose"]).all()
+    ch.load(w)
+    ch.linearize()
+    for _ in range(3):
+        ch.gn_iteration(5e5)
+    assert not np.isfinite(ch.chi2())
+    ch.load(w)
+    with pytest.raises(vio.VioError) as e:
+        ch.solve(10)
+    assert "NOT_FINITE" in str(e.value)
+    ch.load(vio.synth.make_window(300, seed=8, **kw))       # the context is still usable (tracks of 4: every landmark has information)
+    assert np.isfinite(ch.solve(10).final_chi2)

@@ -66,3 +66,31 @@ def test_empty_graph_is_rejected(vio, oracle_lib):
     with pytest.raises(vio.VioError) as e:
         ctx.solve(10)
     assert e.value.status == -4
+
+
+def test_landmark_without_information(vio, oracle_lib, ref_lib):
+    """Single-observation tracks under Tukey: some landmarks keep no weighted edge, h_ll = 0, and the reference's dense
+    Hpm * Hmm_inv multiplies zeros by infinity (problem.cc:419-429): its step is NaN.  The oracle's sparse loop must say
+    the same, and its Solve must end the reference's way — NaN trials rejected (problem.cc:559), last accepted states kept —
+    with the ABI's VIO_ERR_NOT_FINITE as status."""
+    kw = dict(pos_noise=0.001, rot_noise=0.0002, depth_noise=0.003, pixel_noise=0.25 / 460, outlier_fraction=0.05)
+    w = vio.synth.make_window(200, seed=1019, ragged=False, obs_per_landmark=1, **kw)
+    co, cr = oracle_lib.context(ext_fixed=0, loss_type=3), ref_lib.context(ext_fixed=0, loss_type=3)
+    co.load(w)
+    cr.load(w)
+    a, b = tu.run_stepwise(co), tu.run_stepwise(cr)
+    assert (a["hll"] == 0).any()
+    assert not np.isfinite(a["dx_pose"]).all() and not np.isfinite(b["dx_pose"]).all()
+    co.load(w)
+    p0, _, _ = co.get_window()
+    with pytest.raises(vio.VioError) as e:
+        co.solve(10)
+    assert "NOT_FINITE" in str(e.value)
+    p1, _, _ = co.get_window()
+    np.testing.assert_array_equal(p0, p1)           # no trial was ever accepted: the states did not move
+    cr.load(w)
+    try:
+        cr.solve(10)
+    except vio.VioError:
+        pass
+    np.testing.assert_array_equal(cr.get_window()[0], p0)

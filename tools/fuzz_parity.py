@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (diagnostic; the fixed cases live in tests/): HIP against the oracle on windows of random size,
+track structure, loss, extrinsic mode and prior; one stepwise LM step, a few GN iterations and Solve(10) each.
+  python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import ORACLE_DIR, load_package  # noqa: E402
+import vio_testutil as tu  # noqa: E402
+
+vio = load_package()
+hip = vio.load_hip()
+orc = vio.VioLib(os.path.join(ORACLE_DIR, "liboracle.so"), "vioo_")
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+w0 = vio.synth.make_window(300, seed=41, t0=0.9)
+c0 = orc.context(); c0.load(w0); c0.solve(10)
+prior = c0.marginalize(vio.MARG_OLD)
+worst = {"dx": 0.0, "state": 0.0, "gn": 0.0}
+for case in range(cases):
+    n = int(rng.choice([1, 7, 33, 200, 777, 2500, 6000, 11000]))
+    ragged = bool(rng.randint(2))
+    k_obs = int(rng.randint(1, 11))
+    ext_fixed = int(rng.randint(2))
+    loss = int(rng.choice([0, 2, 2, 2, 3]))
+    with_prior = bool(rng.randint(2))
+    kw = dict(pos_noise=0.001, rot_noise=0.0002, depth_noise=0.003, pixel_noise=0.25 / 460, outlier_fraction=0.05) if loss == 3 else {}
+    w = vio.synth.make_window(n, seed=1000 + case, ragged=ragged, obs_per_landmark=k_obs, **kw)
+    if with_prior:
+        w.prior = prior
+    ch, co = hip.context(ext_fixed=ext_fixed, loss_type=loss), orc.context(ext_fixed=ext_fixed, loss_type=loss)
+    ch.load(w); co.load(w)
+    a, b = tu.run_stepwise(ch), tu.run_stepwise(co)
+    if not np.isfinite(b["dx_pose"]).all():       # a landmark without information: NaN in the reference, the oracle and here
+        okd = not np.isfinite(a["dx_pose"]).all()
+        try:
+            ch.load(w); ch.solve(10); okd = False
+        except vio.VioError:
+            pass
+        print("%s case %2d: n=%5d ragged=%d K=%2d ext_fixed=%d loss=%d prior=%d | degenerate (non-finite in both, error status from vio_solve)"
+              % ("ok  " if okd else "FAIL", case, n, ragged, k_obs, ext_fixed, loss, with_prior))
+        continue
+    dx = max(np.abs(a["dx_pose"] - b["dx_pose"]).max(), np.abs(a["dx_lm"] - b["dx_lm"]).max() if n else 0.0)
+    ok = dx <= 1e-8 and int(a["accepted"]) == int(b["accepted"]) and a["lambda0"] == b["lambda0"]
+    ch.load(w); co.load(w)
+    ch.linearize(); _, lam = ch.init_lm()
+    for _ in range(3):
+        ch.gn_iteration(lam); co.gn_iteration(lam)
+    gn = np.abs(ch.get_window()[0] - co.get_window()[0]).max()
+    ok = ok and gn <= 1e-7
+    ch.load(w); co.load(w)
+    def try_solve(c):
+        try:
+            return c.solve(10), None
+        except vio.VioError as exc:
+            return None, str(exc)
+    (rh, eh), (ro, eo) = try_solve(ch), try_solve(co)
+    if eh or eo:                                   # a landmark lost its last weighted edge on the way: both must say so
+        okd = bool(eh) and bool(eo) and ("NOT_FINITE" in eh) and ("NOT_FINITE" in eo)
+        okd = okd and np.abs(ch.get_window()[0] - co.get_window()[0]).max() <= 1e-5      # the last accepted states
+        print("%s case %2d: n=%5d ragged=%d K=%2d ext_fixed=%d loss=%d prior=%d | solve not finite: hip %r oracle %r"
+              % ("ok  " if okd else "FAIL", case, n, ragged, k_obs, ext_fixed, loss, with_prior, eh, eo))
+        continue
+    st = np.abs(ch.get_window()[0] - co.get_window()[0]).max()
+    ok = ok and rh.iterations == ro.iterations and st <= 1e-5
+    worst["dx"], worst["state"], worst["gn"] = max(worst["dx"], dx), max(worst["state"], st), max(worst["gn"], gn)
+    print("%s case %2d: n=%5d ragged=%d K=%2d ext_fixed=%d loss=%d prior=%d | dx %.1e gn %.1e solve %.1e iters %d/%d"
+          % ("ok  " if ok else "FAIL", case, n, ragged, k_obs, ext_fixed, loss, with_prior, dx, gn, st, rh.iterations, ro.iterations))
+print("worst:", worst)

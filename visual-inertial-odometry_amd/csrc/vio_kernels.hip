@@ -1001,6 +1001,9 @@ __device__ __forceinline__ int telem(int r, int c) { return tix(r >> 4, c >> 4) 
 // entry (i,j), i >= j, of H_pp_schur_ without lambda: the lower triangle as Eigen's LDLT reads it
 // valid: bit k set = IMU edge k exists (a kernel argument: an entry costs one round trip, not two)
 __device__ __forceinline__ int d_imu_mask(const DeviceTables &T) { return T.imu_mask; }
+// key of the pivot rank sort: |d|, with NaN mapped to +inf — the ranks must be a permutation whatever the matrix holds
+// (a landmark without information makes 1/h_ll infinite in the reference too; its NaNs must not become wild indices here)
+__device__ __forceinline__ double d_rank_key(double d) { const double a = fabs(d); return a == a ? a : __builtin_huge_val(); }
 __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int i, int j, double &vv, double &vr) {
     vv = 0.0; vr = 0.0;                 // reduced visual part, IMU + prior part
     const int ci = full_to_cam(i), cj = full_to_cam(j);
@@ -1071,7 +1074,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
         d_hs_entry(T, valid, t, t, vv, vr);
         double wv = 0.0, wr = 0.0;
         if (b < VIO_PD) d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
-        sDg[t] = fabs(vv + vr);
+        sDg[t] = d_rank_key(vv + vr);
         row_e = wv + wr;
     }
     __syncthreads();
@@ -1310,10 +1313,10 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
         for (int i = tid; i < n; i += PS_THREADS) { double vv, vr; d_hs_entry(T, valid, i, i, vv, vr); sDg[i] = vv + vr + lambda; }
         __syncthreads();
         for (int i = tid; i < n; i += PS_THREADS) {
-            const double di = fabs(sDg[i]);
+            const double di = d_rank_key(sDg[i]);
             int rank = 0;
             for (int j = 0; j < n; ++j) {
-                const double dj = fabs(sDg[j]);
+                const double dj = d_rank_key(sDg[j]);
                 rank += (dj > di || (dj == di && j < i)) ? 1 : 0;
             }
             sPerm[rank] = i;
