@@ -20,7 +20,7 @@ rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 w0 = vio.synth.make_window(300, seed=41, t0=0.9)
 c0 = orc.context(); c0.load(w0); c0.solve(10)
 prior = c0.marginalize(vio.MARG_OLD)
-worst = {"dx": 0.0, "state": 0.0, "gn": 0.0}
+worst = {"dx": 0.0, "state": 0.0, "gn": 0.0, "marg": 0.0}
 for case in range(cases):
     n = int(rng.choice([1, 7, 33, 200, 777, 2500, 6000, 11000]))
     ragged = bool(rng.randint(2))
@@ -32,6 +32,18 @@ for case in range(cases):
     w = vio.synth.make_window(n, seed=1000 + case, ragged=ragged, obs_per_landmark=k_obs, **kw)
     if with_prior:
         w.prior = prior
+    drop_obs, drop_imu = rng.rand() < 0.3, rng.rand() < 0.3
+    if drop_obs and w.n_observations > 4:          # some landmarks lose observations
+        keep = rng.rand(w.n_observations) > 0.2
+        _, first = np.unique(w.lm, return_index=True)
+        keep[first] = True                         # (a landmark without any edge is rejected at the boundary: VIO_ERR_UNSUPPORTED)
+        w.lm, w.host, w.target = w.lm[keep].copy(), w.host[keep].copy(), w.target[keep].copy()
+        w.pts_i, w.pts_j = w.pts_i[keep].copy(), w.pts_j[keep].copy()
+        w.n_observations = int(keep.sum())
+    if drop_imu:                                   # estimator.cpp:959-960 skips an IMU edge with sum_dt > 10
+        w.preint = list(w.preint)
+        for k in rng.choice(10, size=int(rng.randint(1, 4)), replace=False):
+            w.preint[int(k)] = None
     ch, co = hip.context(ext_fixed=ext_fixed, loss_type=loss), orc.context(ext_fixed=ext_fixed, loss_type=loss)
     ch.load(w); co.load(w)
     a, b = tu.run_stepwise(ch), tu.run_stepwise(co)
@@ -67,7 +79,25 @@ for case in range(cases):
         continue
     st = np.abs(ch.get_window()[0] - co.get_window()[0]).max()
     ok = ok and rh.iterations == ro.iterations and st <= 1e-5
-    worst["dx"], worst["state"], worst["gn"] = max(worst["dx"], dx), max(worst["state"], st), max(worst["gn"], gn)
-    print("%s case %2d: n=%5d ragged=%d K=%2d ext_fixed=%d loss=%d prior=%d | dx %.1e gn %.1e solve %.1e iters %d/%d"
-          % ("ok  " if ok else "FAIL", case, n, ragged, k_obs, ext_fixed, loss, with_prior, dx, gn, st, rh.iterations, ro.iterations))
+    # MargOldFrame on the same solved state (the oracle's): the invariants of tests/test_oracle_golden.py::check_prior
+    # (entry-wise the result is ill-posed: eigenvalue cut at 1e-8, see there)
+    ws = w.copy()
+    ws.poses, ws.speed_bias, ws.ext = co.get_window()
+    ws.inv_depth = co.get_landmarks()
+    ch.load(ws); co.load(ws)
+    mh, mo = ch.marginalize(vio.MARG_OLD), co.marginalize(vio.MARG_OLD)
+    mg = np.abs(mh["H"] - mo["H"]).max() / max(np.abs(mo["H"]).max(), 1e-300)
+    # (check_prior's finer invariants are tuned to the golden windows: on arbitrary ones the reference itself misses them,
+    # e.g. |H P H - H| = 204 against a bound of 236 on seed 1023, the oracle 757; here: entries and spectrum only)
+    ev_h, ev_o = np.linalg.eigvalsh(0.5 * (mh["H"] + mh["H"].T)), np.linalg.eigvalsh(0.5 * (mo["H"] + mo["H"].T))
+    # judged only where the problem is posed: with few edges hosted in frame 0 and no prior the marginalised block is the
+    # IMU factor with its gauge freedom, eigenvalues sit on the 1e-8 cut and oracle and reference themselves differ by O(1)
+    posed = with_prior or int((ws.host == 0).sum()) >= 300
+    okm = np.isfinite(mh["H"]).all() and (not posed or (mg <= 2e-4 and np.abs(ev_h - ev_o).max() <= 2e-4 * ev_o.max()))
+    ok = ok and okm
+    if not posed:
+        mg = 0.0
+    worst["dx"], worst["state"], worst["gn"], worst["marg"] = max(worst["dx"], dx), max(worst["state"], st), max(worst["gn"], gn), max(worst["marg"], mg)
+    print("%s case %2d: n=%5d ragged=%d K=%2d ext_fixed=%d loss=%d prior=%d drop=%d%d | dx %.1e gn %.1e solve %.1e marg %.1e iters %d/%d"
+          % ("ok  " if ok else "FAIL", case, n, ragged, k_obs, ext_fixed, loss, with_prior, drop_obs, drop_imu, dx, gn, st, mg, rh.iterations, ro.iterations))
 print("worst:", worst)
