@@ -97,6 +97,25 @@ for case in range(cases):
     ok = ok and okm
     if not posed:
         mg = 0.0
+    if with_prior:                                 # MargNewFrame: the prior alone, frame 9 out (estimator.cpp:830-901)
+        nh, no_ = ch.marginalize(vio.MARG_SECOND_NEW), co.marginalize(vio.MARG_SECOND_NEW)
+        ok = ok and np.abs(nh["H"] - no_["H"]).max() <= 2e-4 * max(np.abs(no_["H"]).max(), 1e-300)
+    if case % 3 == 0:                              # the sharded kernel sequence on one rank (RCCL sums are identities): bit for bit
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sb = vio.sharded.ShardedBackend(hip, w, 0, 1, dist=None, torch_device="cuda", force_hook=True, exchange="native",
+                                        ctx_kwargs=dict(ext_fixed=ext_fixed, loss_type=loss))
+        plain = hip.context(ext_fixed=ext_fixed, loss_type=loss); plain.load(w)
+        rs, rp = try_solve(sb.ctx), try_solve(plain)
+        same = (rs[1] is None) == (rp[1] is None) and np.array_equal(sb.ctx.get_window()[0], plain.get_window()[0]) \
+            and np.array_equal(sb.ctx.get_landmarks(), plain.get_landmarks())
+        sb.ctx.load(w); plain.load(w)
+        for _ in range(3):
+            sb.gn_iteration(lam); plain.gn_iteration(lam)
+        same = same and np.array_equal(sb.ctx.get_window()[0], plain.get_window()[0]) and sb.ctx.chi2() == plain.chi2()
+        sb.ctx.comm_destroy()
+        if not same:
+            ok = False
+            print("     sharded-on-one-rank differs from unsharded")
     worst["dx"], worst["state"], worst["gn"], worst["marg"] = max(worst["dx"], dx), max(worst["state"], st), max(worst["gn"], gn), max(worst["marg"], mg)
     print("%s case %2d: n=%5d ragged=%d K=%2d ext_fixed=%d loss=%d prior=%d drop=%d%d | dx %.1e gn %.1e solve %.1e marg %.1e iters %d/%d"
           % ("ok  " if ok else "FAIL", case, n, ragged, k_obs, ext_fixed, loss, with_prior, drop_obs, drop_imu, dx, gn, st, mg, rh.iterations, ro.iterations))
