@@ -215,6 +215,34 @@ def main():
                         "sample": "%d GN iterations of the same %d-landmark / %d-observation window, oracle/vio_oracle.c "
                                   "(plain C, -O2, 1 thread)" % (steps, n, m)}
 
+    # the same port on all host cores (OpenMP over landmarks, oracle/liboracle_omp.so; SURVEY.md 8d asks for both figures)
+    cpu_baseline_all_cores = None
+    if cpu_baseline is not None:
+        try:
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "omp"])
+            omp = vio.VioLib(os.path.join(ROOT, "oracle", "liboracle_omp.so"), "vioo_")
+            cm = omp.context()
+            cm.load(full)
+            cm.gn_iteration(lam)
+            t = time.perf_counter()
+            cm.gn_iteration(lam)
+            one = time.perf_counter() - t
+            steps = max(3, min(300, int(6.0 / max(one, 1e-3))))
+            t = time.perf_counter()
+            for _ in range(steps):
+                cm.gn_iteration(lam)
+            dt = time.perf_counter() - t
+            navail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            ncores = min(16, navail)           # oracle_threads(): one window's work saturates at about 16 threads
+            cpu_baseline_all_cores = {"value": steps / dt, "unit": "GN iter/s", "cores": ncores, "kind": "port",
+                                      "ms_per_iter": dt * 1e3 / steps,
+                                      "sample": "%d GN iterations of the same window, oracle/vio_oracle.c built with -fopenmp "
+                                                "(landmark-parallel linearisation, Schur terms, back-substitution and chi2; "
+                                                "the 171x171 LDLT stays serial), %d threads of the %d available" % (steps, ncores, navail)}
+        except Exception as exc:      # a reported extra, never a reason to lose the line
+            cpu_baseline_all_cores = {"error": str(exc)}
+
     # the reference's own backend (compiled from its sources where they lie, oracle/_ref, by the recipe in oracle/Makefile;
     # present when the repo was built where /root/reference exists): its dense (171+N)^2 solver needs 18 s and 13 GB per
     # iteration at N = 20 000, so it is timed on a 2 000-landmark window of the same generator and reported beside the port
@@ -264,6 +292,7 @@ def main():
             "final_chi2": chi2,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "cpu_baseline_all_cores": cpu_baseline_all_cores,
             "cpu_reference": cpu_reference,
         }
         import ctypes

@@ -235,3 +235,26 @@ def check_prior(m, ref):
     # Jt_inv^T Jt_inv is the pseudo-inverse of H_prior restricted to the kept eigenspace: H P H == H
     P = m["jt_inv"].T @ m["jt_inv"]
     assert np.abs(m["H"] @ P @ m["H"] - m["H"]).max() <= 1e-5 * Hs
+
+
+def test_openmp_build_of_the_oracle_agrees_with_the_serial_one(vio, oracle_lib):
+    """oracle/liboracle_omp.so is bench.py's all-cores CPU figure (never the parity checker): same terms, summed
+    landmark-major per thread; it must agree with the pinned serial build to rounding on every path it touches."""
+    import subprocess
+    from conftest import ORACLE_DIR
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "omp"])
+    omp = vio.VioLib(os.path.join(ORACLE_DIR, "liboracle_omp.so"), "vioo_")
+    for n, ragged, ext_fixed in ((300, True, 0), (2000, False, 1)):
+        w = vio.synth.make_window(n, seed=12, ragged=ragged)
+        a, b = oracle_lib.context(ext_fixed=ext_fixed), omp.context(ext_fixed=ext_fixed)
+        a.load(w)
+        b.load(w)
+        sa, sb_ = tu.run_stepwise(a), tu.run_stepwise(b)
+        assert tu.scaled_sym_err(sb_["Hs"], sa["Hs"]) <= 1e-11
+        assert np.abs(sa["dx_pose"] - sb_["dx_pose"]).max() <= 1e-10 and np.abs(sa["dx_lm"] - sb_["dx_lm"]).max() <= 1e-10
+        a.load(w)
+        b.load(w)
+        ra, rb = a.solve(10), b.solve(10)
+        assert ra.iterations == rb.iterations and abs(ra.final_chi2 - rb.final_chi2) <= 1e-8 * ra.final_chi2
+        ma, mb = a.marginalize(vio.MARG_OLD), b.marginalize(vio.MARG_OLD)
+        assert np.abs(ma["H"] - mb["H"]).max() <= 2e-5 * np.abs(ma["H"]).max()
