@@ -1,0 +1,116 @@
+"""The literal drop-in: visual-inertial-odometry_amd/host/problem_shim/problem_hip.cc replaces the
+reference's VM/src/backend/problem.cc behind the reference's UNMODIFIED problem.h.  oracle/_ref/libvio_refshim.so is the
+reference harness (oracle/ref_harness.cpp: graphs built with the reference's own Vertex / Edge classes in the order of
+Estimator::problemSolve, MargOldFrame and MargNewFrame) linked against that file instead, with the CPU oracle as the C-ABI
+backend.  So: flat window -> reference objects -> Problem::Solve / Problem::Marginalize (shim) -> C ABI, and the results
+must be the ones the same backend gives on the flat window directly.  Built only where /root/reference exists."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ORACLE_DIR
+
+pytestmark = pytest.mark.ref
+
+
+@pytest.fixture(scope="module")
+def shim_lib(vio, ref_lib):
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s", "refshim"])
+    return vio.VioLib(os.path.join(ORACLE_DIR, "_ref", "libvio_refshim.so"), "vior_")
+
+
+@pytest.mark.parametrize("n,seed,ragged,ext_fixed,loss", [(60, 5, False, 1, 2), (250, 6, True, 0, 2), (120, 7, True, 1, 1), (40, 8, False, 1, 0)])
+def test_solve_through_reference_objects(vio, oracle_lib, shim_lib, n, seed, ragged, ext_fixed, loss):
+    w = vio.synth.make_window(n, seed=seed, ragged=ragged)
+    cs, co = shim_lib.context(ext_fixed=ext_fixed, loss_type=loss), oracle_lib.context(ext_fixed=ext_fixed, loss_type=loss)
+    cs.load(w)
+    co.load(w)
+    cs.solve(10)
+    co.solve(10)
+    for a, b in zip(cs.get_window(), co.get_window()):
+        assert np.abs(a - b).max() <= 1e-11
+    assert np.abs(cs.get_landmarks() - co.get_landmarks()).max() <= 1e-11
+
+
+def test_window_chain_through_reference_objects(vio, oracle_lib, shim_lib, ref_lib):
+    """Solve, MargOldFrame, next window with the prior (Solve updates b_prior / err_prior), MargNewFrame: the sequence of
+    Estimator::backendOptimization, every Problem call going through the shim; and the reference's own problem.cc beside it."""
+    w = vio.synth.make_window(150, seed=31)
+    cs, co, cr = shim_lib.context(), oracle_lib.context(), ref_lib.context()
+    for c in (cs, co, cr):
+        c.load(w)
+        c.solve(10)
+    ws = w.copy()
+    ws.poses, ws.speed_bias, ws.ext = co.get_window()
+    ws.inv_depth = co.get_landmarks()
+    for c in (cs, co, cr):
+        c.load(ws)
+    ms, mo, mr = cs.marginalize(vio.MARG_OLD), co.marginalize(vio.MARG_OLD), cr.marginalize(vio.MARG_OLD)
+    for k in ("H", "b", "err", "jt_inv"):
+        np.testing.assert_allclose(ms[k], mo[k], rtol=0, atol=1e-9 * max(1.0, np.abs(mo[k]).max()))
+    assert np.abs(ms["H"] - mr["H"]).max() <= 2e-5 * np.abs(mr["H"]).max()      # against the reference's own Marginalize
+    w2 = vio.synth.make_window(150, seed=32, t0=1.1)
+    w2.prior = mo
+    cs.load(w2)
+    co.load(w2)
+    cs.solve(10)
+    co.solve(10)
+    assert np.abs(cs.get_window()[0] - co.get_window()[0]).max() <= 1e-10
+    bs, es = cs.get_prior()
+    bo, eo = co.get_prior()
+    assert np.abs(bs[:156] - bo[:156]).max() <= 1e-9 * max(1.0, np.abs(bo).max()) and np.abs(es - eo).max() <= 1e-9 * max(1.0, np.abs(eo).max())
+    w3 = w2.copy()
+    w3.poses, w3.speed_bias, w3.ext = co.get_window()
+    w3.inv_depth = co.get_landmarks()
+    w3.prior = dict(mo)
+    w3.prior["b"], w3.prior["err"] = bo[:156].copy(), eo.copy()
+    cs.load(w3)
+    co.load(w3)
+    ns, no = cs.marginalize(vio.MARG_SECOND_NEW), co.marginalize(vio.MARG_SECOND_NEW)
+    for k in ("H", "b", "err", "jt_inv"):
+        np.testing.assert_allclose(ns[k], no[k], rtol=0, atol=1e-9 * max(1.0, np.abs(no[k]).max()))
+
+
+def test_shim_rejects_what_the_window_cannot_express(vio, shim_lib):
+    w = vio.synth.make_window(0, seed=5)
+    w.preint = [None] * 10
+    c = shim_lib.context()
+    c.load(w)
+    with pytest.raises(vio.VioError):
+        c.solve(10)                       # no edges at all: Problem::Solve returns false (problem.cc:172-175)
+
+
+@pytest.mark.gpu
+def test_drop_in_on_the_gpu(vio, oracle_lib):
+    """oracle/_ref/libvio_refshim_hip.so: the same harness and shim with libvio_hip.so as the backend — reference
+    Vertex / Edge objects -> Problem::Solve / Marginalize (problem_hip.cc) -> HIP kernels.  The library is compiled where the
+    reference's headers are and travels to the GPU box with the other built .so files."""
+    so = os.path.join(ORACLE_DIR, "_ref", "libvio_refshim_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libvio_refshim_hip.so was not built (needs /root/reference at build time)")
+    shim = vio.VioLib(so, "vior_")
+    w = vio.synth.make_window(400, seed=41, ragged=True)
+    cs, co = shim.context(), oracle_lib.context()
+    cs.load(w)
+    co.load(w)
+    cs.solve(10)
+    co.solve(10)
+    for a, b in zip(cs.get_window(), co.get_window()):
+        assert np.abs(a - b).max() <= 1e-6
+    assert np.abs(cs.get_landmarks() - co.get_landmarks()).max() <= 1e-6
+    ws = w.copy()
+    ws.poses, ws.speed_bias, ws.ext = co.get_window()
+    ws.inv_depth = co.get_landmarks()
+    cs.load(ws)
+    co.load(ws)
+    ms, mo = cs.marginalize(vio.MARG_OLD), co.marginalize(vio.MARG_OLD)
+    assert np.abs(ms["H"] - mo["H"]).max() <= 2e-5 * np.abs(mo["H"]).max()
+    w2 = vio.synth.make_window(400, seed=42, t0=1.1)
+    w2.prior = mo
+    cs.load(w2)
+    co.load(w2)
+    cs.solve(10)
+    co.solve(10)
+    assert np.abs(cs.get_window()[0] - co.get_window()[0]).max() <= 1e-6
