@@ -150,6 +150,19 @@ DEV void d_block_sum_max(double &sum, double &mx, double *scratch, int tid) {
     sum = ts; mx = tm;
 }
 
+// Two sums and a maximum in one pass, same fixed order.  scratch: 3 * NT / 64 doubles.  All threads must call.
+template <int NT>
+DEV void d_block_sum2_max(double &a, double &b, double &mx, double *scratch, int tid) {
+    const double sa = d_wave_sum_to_lane63(a), sb = d_wave_sum_to_lane63(b), m = d_wave_max_to_lane63(mx);
+    if ((tid & 63) == 63) { scratch[tid >> 6] = sa; scratch[NT / 64 + (tid >> 6)] = sb; scratch[2 * (NT / 64) + (tid >> 6)] = m; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0, tm = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { ta += scratch[w]; tb += scratch[NT / 64 + w]; tm = fmax(tm, scratch[2 * (NT / 64) + w]); }
+    __syncthreads();
+    a = ta; b = tb; mx = tm;
+}
+
 // Two sums over a workgroup of NT threads in one pass (DPP inside the wave, wave partials added in wave order).
 // scratch: 2 * NT / 64 doubles.  All threads must call; every thread gets both totals.
 template <int NT>

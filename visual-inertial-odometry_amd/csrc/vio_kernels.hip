@@ -367,7 +367,7 @@ __host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext
     int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256 + 2 * 6 * nb * LIN_VS;
     int shared = aux > part ? aux : part;
     shared = (shared + 1) & ~1;
-    return VIO_MAXK * PAIR_STRIDE + 16 + 2 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
+    return VIO_MAXK * PAIR_STRIDE + 16 + 3 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
 }
 
 // b_prior'[i] = b_prior[i] - (H_prior dx)[i]  (problem.cc:473), one wave per row; the same sum whoever calls it
@@ -420,8 +420,8 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     double *sPair = dyn_smem;                         // VIO_MAXK * PAIR_STRIDE
     double *sCam = sPair + VIO_MAXK * PAIR_STRIDE;    // ric, tic
     double *sZero = sCam + 12;                        // a zero for the padding lanes of phase 2 (sCam holds 12 values)
-    double *sRed = sCam + 16;                         // 2 * waves
-    double *sRows = sRed + 2 * (LIN_THREADS / 64);    // K * PLANE
+    double *sRed = sCam + 16;                         // 3 * waves
+    double *sRows = sRed + 3 * (LIN_THREADS / 64);    // K * PLANE
     double *sL = sRows + K * PLANE;                   // G * LREC
     double *sAux = sL + G * LREC;                     // G*K*RAUX, dead after phase 1.5 ...
     double *sTile = sAux;                             // ... then the 16x16 tiles of phase 2 and the vector partials
@@ -758,8 +758,10 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         const int n_out = it.n_rows * 6;
         const int n_pair = (nb * (nb + 1) / 2) * 36;
         // block reductions first: a global store followed by a barrier costs the store's whole round trip
-        double chi = chi_acc, mh = maxh;
-        d_block_sum_max<LIN_THREADS>(chi, mh, sRed, tid);
+        // (with them, in GN mode, the previous step's gain-ratio partial of this item: thread g holds landmark g's term, so
+        // the sum is the one k_backsub forms — DPP inside waves 0 and 1, then wave 0 + wave 1 — bit for bit)
+        double chi = chi_acc, mh = maxh, sc = (owe && tid < G) ? sL[(size_t)tid * LREC + 12 * nb + 4] : 0.0;
+        d_block_sum2_max<LIN_THREADS>(chi, sc, mh, sRed, tid);
         // entry (x, y) of the k-th direct product; x, y: host 0..5, target 6..11, extrinsic 12..17
         auto cdir = [&](int k, int x, int y) -> double {
             const int hi = max(x, y), lo = min(x, y);
@@ -801,12 +803,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             out[e] = v;
         }
         if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
-        if (owe && tid == 64) {             // the previous step's gain-ratio partial of this item, landmarks in order
-            double sc = 0.0;
-            for (int g = 0; g < G; ++g) sc += sL[(size_t)g * LREC + 12 * nb + 4];
-            T.step_part[2 * b + STEP_SCALE] = sc;
-            T.step_part[2 * b + STEP_CHI] = 0.0;
-        }
+        if (owe && tid == 64) { T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0; }
         // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
         double *lw = T.lw + it.lw_base;
         for (int e = tid; e < (6 * nb + 2) * G; e += LIN_THREADS) {
