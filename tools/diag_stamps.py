@@ -19,6 +19,10 @@ ctx = lib.context()
 ctx.load(w)
 for _ in range(3):
     ctx.linearize()
+if os.environ.get("VIO_DIAG_GN") == "1":        # the GN loop's k_linearize (carries the previous step's landmark update)
+    _, lam_gn = ctx.init_lm()
+    for _ in range(4):
+        ctx.gn_iteration(lam_gn)
 ctx.synchronize()
 gmax = int(os.environ.get("VIO_G_MAX", "82"))
 nb = (n + gmax - 1) // gmax + 10

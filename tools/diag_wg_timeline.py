@@ -11,6 +11,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 w = vio.synth.make_window(n, seed=42)
 ctx = lib.context(); ctx.load(w)
 for _ in range(3): ctx.linearize()
+if os.environ.get("VIO_DIAG_GN") == "1":        # the GN loop's k_linearize (carries the previous step's landmark update)
+    _, lam = ctx.init_lm()
+    for _ in range(4): ctx.gn_iteration(lam)
 ctx.synchronize()
 nb = (n + 95) // 96 + 10 if len(sys.argv) > 2 else 270
 buf = np.zeros((nb, 16), dtype=np.uint64)

@@ -191,6 +191,7 @@ void build_pattern_tables(Pattern &pt, int g_max) {
     pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
     int G = std::max(1, std::min(g_max, 1024 / K));          // one thread per observation in k_linearize's phase 1
     while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext) > LDS_BUDGET_DOUBLES) --G;
+    while (G > 1 && (6 * nb + 2) * G > 7 * 1024) --G;        // k_linearize stages the item's Schur rows with 7 loads per thread
     pt.G = G;
     pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
 }

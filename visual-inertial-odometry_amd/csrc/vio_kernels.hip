@@ -355,7 +355,7 @@ typedef double ps_v4d __attribute__((ext_vector_type(4)));      // accumulator o
 __host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles)
 __host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 27 : 15; }      // per-observation partials (odd stride)
 __host__ __device__ inline int lin_plane(int G, int use_ext) { return G * lin_rrow(use_ext) + 6; }
-__host__ __device__ inline int lin_lrec(int nb) { return 12 * nb + 5; }                 // landmark record stride (odd)
+__host__ __device__ inline int lin_lrec(int nb) { return 12 * nb + 7; }                 // landmark record stride (odd): w, b, 1/h.., lambda, GN terms
 #define LIN_VS 8            // landmark splits of the vector sums of phase 2
 // tiles of phase 2: K direct products (1 tile of 16x16, 3 with the extrinsic) + the lower tiles of the 6nb x 6nb Schur term
 __host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
@@ -437,37 +437,59 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         if (!(T.gn_flags & 2)) pf_lam = invd[g0];
         pf_x = pts_i[2 * g0]; pf_y = pts_i[2 * g0 + 1]; pf_u = pts_j[2 * tid]; pf_v = pts_j[2 * tid + 1];
     }
+    // the pair table entries of this item, requested now, stored after the landmark update below has used their place
+    const double *ptab = T.pairtab + cur * PAIRTAB_STRIDE;
+    double pv = 0.0, cv = 0.0;
+    if (tid < K * PAIR_STRIDE) {
+        const int k = tid / PAIR_STRIDE, o = tid % PAIR_STRIDE;
+        pv = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + o];
+    }
+    if (tid < 12) cv = ptab[121 * PAIR_STRIDE + tid];
     // GN mode (gn_flags bit 1): the landmarks still owe the back-substitution of the PREVIOUS step (problem.cc:445):
     // delta_lambda = (b_l - w . dx_pose) / h from the rows this item's workgroup stored at the end of the previous
     // linearisation.  The new inverse depth goes to the current copy of invd and, through the landmark record, to
     // phase 1; the landmark part of the gain-ratio denominator goes to the record for the combine phase.
+    // The item's rows ((6 nb + 2) x G doubles) and the pose update come in as one coalesced copy by the whole workgroup —
+    // one round trip instead of one per pattern block — into LDS that phase 1 only needs later (sAux, sPair).
     const bool owe = (T.gn_flags & 2) != 0;
-    if (owe && tid < G) {
-        const int g = tid;
-        const size_t li = (size_t)it.lm_base + g;
+    if (owe) {
         const double *lw = T.lw + it.lw_base;
-        double t = 0.0;
-        for (int p = 0; p < nb; ++p) {
-            const int cb = it.cam_block[p];
-            const int base = cb == 0 ? 0 : 6 + 15 * (cb - 1);
+        const int nlw = (6 * nb + 2) * G;                  // <= 7 * LIN_THREADS: nb <= 12, G <= 86
+        double *sStage = sAux, *sDxS = sPair;
+        double stv[7];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) t += lw[(size_t)(6 * p + i) * G + g] * T.dx[base + i];
+        for (int q = 0; q < 7; ++q) { const int e = tid + q * LIN_THREADS; stv[q] = e < nlw ? lw[e] : 0.0; }
+        const double dxv = tid < VIO_PD ? T.dx[tid] : 0.0;
+        // (what the update itself reads from HBM is requested here too, not behind the barrier)
+        const double inv_prev = tid < G ? T.invd[(size_t)(cur ^ 1) * T.Ns + it.lm_base + tid] : 0.0;
+        const double lambda_lm = T.lm->lambda;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { const int e = tid + q * LIN_THREADS; if (e < nlw) sStage[e] = stv[q]; }
+        if (tid < 176) sDxS[tid] = dxv;
+        __syncthreads();
+        if (tid < G) {
+            const int g = tid;
+            double t = 0.0;
+            for (int p = 0; p < nb; ++p) {
+                const int cb = it.cam_block[p];
+                const int base = cb == 0 ? 0 : 6 + 15 * (cb - 1);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) t += sStage[(6 * p + i) * G + g] * sDxS[base + i];
+            }
+            const double h = sStage[(6 * nb) * G + g], bl = sStage[(6 * nb + 1) * G + g];
+            const double dl = (1.0 / h) * (bl - t);
+            const double lam = inv_prev + dl;
+            // dxl and the new inverse depth go out to HBM at the end of the kernel: a global store in front of a barrier
+            // costs the store's whole round trip
+            double *L = sL + (size_t)g * LREC;
+            L[12 * nb + 3] = lam;
+            L[12 * nb + 4] = dl * (lambda_lm * dl + bl);
+            L[12 * nb + 5] = dl;
         }
-        const double h = lw[(size_t)(6 * nb) * G + g], bl = lw[(size_t)(6 * nb + 1) * G + g];
-        const double dl = (1.0 / h) * (bl - t);
-        const double lam = T.invd[(size_t)(cur ^ 1) * T.Ns + li] + dl;
-        T.dxl[li] = dl;
-        T.invd[(size_t)cur * T.Ns + li] = lam;
-        double *L = sL + (size_t)g * LREC;
-        L[12 * nb + 3] = lam;
-        L[12 * nb + 4] = dl * (T.lm->lambda * dl + bl);
+        __syncthreads();
     }
-    const double *ptab = T.pairtab + cur * PAIRTAB_STRIDE;
-    for (int e = tid; e < K * PAIR_STRIDE; e += LIN_THREADS) {
-        const int k = e / PAIR_STRIDE, o = e % PAIR_STRIDE;
-        sPair[e] = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + o];
-    }
-    if (tid < 12) sCam[tid] = ptab[121 * PAIR_STRIDE + tid];
+    if (tid < K * PAIR_STRIDE) sPair[tid] = pv;
+    if (tid < 12) sCam[tid] = cv;
     if (tid >= 12 && tid < 16) sCam[tid] = 0.0;
     __syncthreads();
 
@@ -804,6 +826,12 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         }
         if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
         if (owe && tid == 64) { T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0; }
+        if (owe && tid < G) {               // the landmark update of the head, out to HBM now
+            const size_t li = (size_t)it.lm_base + tid;
+            const double *L = sL + (size_t)tid * LREC;
+            T.dxl[li] = L[12 * nb + 5];
+            T.invd[(size_t)cur * T.Ns + li] = L[12 * nb + 3];
+        }
         // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
         double *lw = T.lw + it.lw_base;
         for (int e = tid; e < (6 * nb + 2) * G; e += LIN_THREADS) {
