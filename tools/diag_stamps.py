@@ -42,6 +42,7 @@ for k, nm in enumerate(names):
 print("  inside phase 2, wave 0: product done after %.0f, vector sums done after %.0f (of the phase)" % ((st[vis][:, 6] - st[vis][:, 3]).mean(), (st[vis][:, 7] - st[vis][:, 3]).mean()))
 print("  wave 0 (direct product): chunk loop done after %.0f, remainder %.0f, stored %.0f | wave 4 (Schur tile): starts %.0f, chunk loop done %.0f (of the phase)" % tuple(
     (st[vis][:, b_] - st[vis][:, 3]).mean() for b_ in (14, 15, 6, 12, 13)))
+print("  combine: block sums done after %.0f, slab elements after %.0f, rows stored after %.0f (of the phase)" % tuple((st[vis][:, b_] - st[vis][:, 4]).mean() for b_ in (12, 13, 5)))
 print("  total                        mean %8.1f  max %8.1f" % ((st[vis][:, 5] - st[vis][:, 0]).mean(), (st[vis][:, 5] - st[vis][:, 0]).max()))
 if imu.any():
     t = st[imu][:, 5] - st[imu][:, 0]

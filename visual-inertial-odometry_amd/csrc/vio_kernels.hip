@@ -624,6 +624,16 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             else L[6 * nb + (q - pkBE)] = sum;
         }
     }
+    // The item's chi2, max |h_ll| and (GN) the previous step's gain-ratio partial: the wave partials go to LDS now, while the
+    // per-thread terms are still in registers (kept until the combine phase they come back from scratch, a memory round
+    // trip in front of it), and are added after this barrier by the thread that stores them.  The partial of the GN step:
+    // thread g holds landmark g's term, so the sum is the one k_backsub forms — DPP inside waves 0 and 1, then wave 0 +
+    // wave 1 — bit for bit.
+    {
+        double sc = (owe && tid < G) ? sL[(size_t)tid * LREC + 12 * nb + 4] : 0.0;
+        const double ws = d_wave_sum_to_lane63(chi_acc), wsc = d_wave_sum_to_lane63(sc), wm = d_wave_max_to_lane63(maxh);
+        if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
+    }
     __syncthreads();
 
     // ---------------- phase 2: the item's contribution as 16x16 products on the matrix cores ----------------
@@ -779,11 +789,15 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
         double *out = T.slab + it.out_base;
         const int n_out = it.n_rows * 6;
         const int n_pair = (nb * (nb + 1) / 2) * 36;
-        // block reductions first: a global store followed by a barrier costs the store's whole round trip
-        // (with them, in GN mode, the previous step's gain-ratio partial of this item: thread g holds landmark g's term, so
-        // the sum is the one k_backsub forms — DPP inside waves 0 and 1, then wave 0 + wave 1 — bit for bit)
-        double chi = chi_acc, mh = maxh, sc = (owe && tid < G) ? sL[(size_t)tid * LREC + 12 * nb + 4] : 0.0;
-        d_block_sum2_max<LIN_THREADS>(chi, sc, mh, sRed, tid);
+        // the block totals from the wave partials of phase 1.5 (fixed order: wave 0 first)
+        double chi = 0.0, sc = 0.0, mh = 0.0;
+        if (tid == 0 || tid == 64) {
+#pragma unroll
+            for (int w = 0; w < LIN_THREADS / 64; ++w) {
+                chi += sRed[w]; sc += sRed[LIN_THREADS / 64 + w]; mh = fmax(mh, sRed[2 * (LIN_THREADS / 64) + w]);
+            }
+        }
+        STAMP(T, 12);
         // entry (x, y) of the k-th direct product; x, y: host 0..5, target 6..11, extrinsic 12..17
         auto cdir = [&](int k, int x, int y) -> double {
             const int hi = max(x, y), lo = min(x, y);
@@ -824,6 +838,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
             }
             out[e] = v;
         }
+        STAMP(T, 13);
         if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
         if (owe && tid == 64) { T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0; }
         if (owe && tid < G) {               // the landmark update of the head, out to HBM now
