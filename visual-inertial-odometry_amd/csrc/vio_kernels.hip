@@ -1582,11 +1582,9 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     }
     __syncthreads();
     PS_OUT(2);
-    for (int r = tid; r < n; r += PS_THREADS) {
-        const double v = sX[r];
-        sDx[sPerm[r]] = v;
-        T.dx[sPerm[r]] = v;
-    }
+    // (dx and the trial states go out to HBM at the very end, from their LDS copies: a global store in front of a barrier
+    // costs the store's whole round trip, and there are three barriers to come)
+    for (int r = tid; r < n; r += PS_THREADS) sDx[sPerm[r]] = sX[r];
     __syncthreads();
 
     // prior: b' = b - H_prior*dx ; err' = -Jt_prior_inv * b'.head(156)   (problem.cc:466-475).  In the GN loop
@@ -1599,19 +1597,15 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     //              and out to the trial slot, then the pair table of the trial states, read from that LDS copy;
     //   waves 2..15: b' before the first barrier, the rows of Jt_prior_inv requested between the two, err' after.
     if (uwave < 2) {
-        double *stt = T.state + trial * STATE_STRIDE;
         if (tid < 12) {
             double *p = (tid == 0) ? sState + STATE_EXT : sState + STATE_POSE + 7 * (tid - 1);
-            double *o = (tid == 0) ? stt + STATE_EXT : stt + STATE_POSE + 7 * (tid - 1);
             const double *d = (tid == 0) ? sDx : sDx + 6 + 15 * (tid - 1);
             double tmp[7];
             d_pose_plus(p, d, tmp);
-            for (int k = 0; k < 7; ++k) { p[k] = tmp[k]; o[k] = tmp[k]; }
+            for (int k = 0; k < 7; ++k) p[k] = tmp[k];
         } else if (tid >= 16 && tid < 16 + 99) {
             const int e = tid - 16, f = e / 9, k = e % 9;
-            const double v = sState[STATE_SB + e] + sDx[12 + 15 * f + k];
-            sState[STATE_SB + e] = v;
-            stt[STATE_SB + e] = v;
+            sState[STATE_SB + e] = sState[STATE_SB + e] + sDx[12 + 15 * f + k];
         }
         __syncthreads();
         d_build_pairtab(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, 128);      // one more barrier inside
@@ -1660,6 +1654,10 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
             }
         }
     }
+    // dx and the trial states, from LDS (both final since the barriers above; the waves that did not write them read them
+    // after those barriers)
+    if (tid >= 192 && tid < 192 + n) T.dx[tid - 192] = sDx[tid - 192];
+    if (tid >= 384 && tid < 384 + STATE_STRIDE) T.state[trial * STATE_STRIDE + (tid - 384)] = sState[tid - 384];
     PS_OUT(3);
 }
 
