@@ -4,8 +4,9 @@
 //   77 doubles poses[11][7]; 7 doubles ext; int32 n_ops; per op: int32 code [+ payload]
 //   codes: 1 triangulate (needs the GPU)  2 setDepth (int64 n, n doubles)  3 removeFailures  4 removeBackShiftDepth
 //          (9+3+9+3 doubles)  5 removeBack  6 removeFront (int32 frame_count)  7 clearDepth (int64 n, n doubles)
+//          8 addFeatureCheckParallax (int32 frame_count, int32 n, n x int32 id, n x (x,y))
 // Output: int32 getFeatureCount; int64 n_dep, getDepthVector(); int64 n_tracks; per track: id, start, n_obs, depth,
-//   int32 solve_flag, points.
+//   int32 solve_flag, points; int32 n_images; per op 8: int32 keyframe decision, int32 last_track_num.
 #include <cstdio>
 #include <vector>
 
@@ -35,6 +36,7 @@ int main(int argc, char **argv) {
     int32_t nops;
     if (!rd(f, &nops, 1)) return 4;
     vio_ctx *ctx = nullptr;
+    std::vector<int32_t> decisions;
     for (int32_t k = 0; k < nops; ++k) {
         int32_t code;
         if (!rd(f, &code, 1)) return 4;
@@ -64,6 +66,14 @@ int main(int argc, char **argv) {
             int32_t fc;
             if (!rd(f, &fc, 1)) return 4;
             fm.removeFront(fc);
+        } else if (code == 8) {
+            int32_t fc, n;
+            if (!rd(f, &fc, 1) || !rd(f, &n, 1)) return 4;
+            std::vector<int32_t> ids(n);
+            std::vector<double> pts(2 * (size_t)n);
+            if (n && (!rd(f, ids.data(), n) || !rd(f, pts.data(), 2 * (size_t)n))) return 4;
+            decisions.push_back(fm.addFeatureCheckParallax(fc, n, ids.data(), pts.data()) ? 1 : 0);
+            decisions.push_back(fm.last_track_num);
         } else return 8;
     }
     std::fclose(f);
@@ -85,6 +95,9 @@ int main(int argc, char **argv) {
         std::fwrite(&sfl, 4, 1, o);
         for (auto &p : t.feature_per_frame) std::fwrite(p.data(), 8, 2, o);
     }
+    int32_t nimg = (int32_t)decisions.size() / 2;
+    std::fwrite(&nimg, 4, 1, o);
+    std::fwrite(decisions.data(), 4, decisions.size(), o);
     std::fclose(o);
     return 0;
 }

@@ -1,9 +1,10 @@
 """FeatureManager::triangulate: tracks -> depths.
 
-The reference's FeatureManager does not compile in this container (parameters.h needs OpenCV), so the oracle's
-restatement (oracle/vio_oracle.c: vio_triangulate, citing feature_manager.cpp:203-257) is pinned against an independent
-transcription of the same published algorithm with numpy.linalg.svd (LAPACK) on the very matrix svd_A the reference
-builds; the HIP kernel (Jacobi on A^T A, one thread per track) is then checked against the oracle through the C ABI."""
+The pin against the reference's own FeatureManager (compiled from VM/src/feature_manager.cpp) is
+tests/test_feature_manager_golden.py.  Here, second opinions and sizes the golden file does not hold: the oracle's
+restatement (oracle/vio_oracle.c: vio_triangulate, citing feature_manager.cpp:203-257) against an independent
+transcription of the same algorithm with numpy.linalg.svd (LAPACK) on the very matrix svd_A the reference builds, and
+the HIP kernel (Jacobi on A^T A, one thread per track) against the oracle through the C ABI up to 50 000 tracks."""
 import numpy as np
 import pytest
 

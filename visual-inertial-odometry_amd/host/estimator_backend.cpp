@@ -1,9 +1,87 @@
 // estimator_backend.cpp — see estimator_backend.h.
 #include "estimator_backend.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace vio {
+
+// ---- the small rotation helpers vector2double / double2vector are made of; row-major 3x3 ----
+namespace {
+
+const double kPi = 3.14159265358979323846;
+
+// Utility::R2ypr (VM/include/utility/utility.h:68-84), degrees
+void R2ypr(const double R[9], double ypr[3]) {
+    const double n[3] = {R[0], R[3], R[6]}, o[3] = {R[1], R[4], R[7]}, a[3] = {R[2], R[5], R[8]};
+    const double y = std::atan2(n[1], n[0]);
+    const double p = std::atan2(-n[2], n[0] * std::cos(y) + n[1] * std::sin(y));
+    const double r = std::atan2(a[0] * std::sin(y) - a[1] * std::cos(y), -o[0] * std::sin(y) + o[1] * std::cos(y));
+    ypr[0] = y / kPi * 180.0; ypr[1] = p / kPi * 180.0; ypr[2] = r / kPi * 180.0;
+}
+
+void matmul3(const double A[9], const double B[9], double C[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+void matvec3(const double A[9], const double v[3], double out[3]) {
+    for (int i = 0; i < 3; ++i) out[i] = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+}
+
+// Utility::ypr2R (utility.h:86-110): Rz * Ry * Rx, degrees
+void ypr2R(const double ypr[3], double R[9]) {
+    const double y = ypr[0] / 180.0 * kPi, p = ypr[1] / 180.0 * kPi, r = ypr[2] / 180.0 * kPi;
+    const double Rz[9] = {std::cos(y), -std::sin(y), 0, std::sin(y), std::cos(y), 0, 0, 0, 1};
+    const double Ry[9] = {std::cos(p), 0, std::sin(p), 0, 1, 0, -std::sin(p), 0, std::cos(p)};
+    const double Rx[9] = {1, 0, 0, 0, std::cos(r), -std::sin(r), 0, std::sin(r), std::cos(r)};
+    double T[9];
+    matmul3(Rz, Ry, T);
+    matmul3(T, Rx, R);
+}
+
+// Eigen::Quaterniond(w, x, y, z)[.normalized()].toRotationMatrix(); q as para_Pose stores it (x, y, z, w)
+void quat2R(const double q[4], bool normalize, double R[9]) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    if (normalize) {
+        const double n = std::sqrt(x * x + y * y + z * z + w * w);
+        x /= n; y /= n; z /= n; w /= n;
+    }
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+// Eigen::Quaterniond q{R}: the branch on the trace, then on the largest diagonal element
+void R2quat(const double R[9], double q[4]) {
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+        return;
+    }
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+    q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+    q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+}
+
+bool usable(FeaturePerId &f) {          // feature_manager.cpp:146-148 and every other loop over the tracks
+    f.used_num = (int)f.feature_per_frame.size();
+    return f.used_num >= 2 && f.start_frame < WINDOW_SIZE - 2;
+}
+
+}  // namespace
 
 EstimatorBackend::EstimatorBackend(const vio_config &cfg) {
     std::memset(para_Pose, 0, sizeof(para_Pose));
@@ -11,13 +89,72 @@ EstimatorBackend::EstimatorBackend(const vio_config &cfg) {
     std::memset(para_Ex_Pose, 0, sizeof(para_Ex_Pose));
     for (auto &p : pre_integrations) p = nullptr;
     std::memset(&last_report, 0, sizeof(last_report));
+    std::memset(Ps, 0, sizeof(Ps)); std::memset(Vs, 0, sizeof(Vs)); std::memset(Bas, 0, sizeof(Bas)); std::memset(Bgs, 0, sizeof(Bgs));
+    std::memset(tic, 0, sizeof(tic)); std::memset(last_P0, 0, sizeof(last_P0));
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (auto &R : Rs) std::memcpy(R, I3, sizeof(I3));
+    std::memcpy(ric[0], I3, sizeof(I3)); std::memcpy(last_R0, I3, sizeof(I3));
     vio_status st = vio_create(&cfg, &ctx_);
     if (st != VIO_OK) { ctx_ = nullptr; err_ = "vio_create failed with status " + std::to_string((int)st); }
 }
 
 EstimatorBackend::~EstimatorBackend() { if (ctx_) vio_destroy(ctx_); }
 
-const char *EstimatorBackend::last_error() const { return ctx_ ? vio_last_error(ctx_) : err_.c_str(); }
+const char *EstimatorBackend::last_error() const { return (ctx_ && err_.empty()) ? vio_last_error(ctx_) : err_.c_str(); }
+
+void EstimatorBackend::vector2double() {                                      // estimator.cpp:505-547
+    for (int i = 0; i <= WINDOW_SIZE; ++i) {
+        for (int k = 0; k < 3; ++k) {
+            para_Pose[i][k] = Ps[i][k];
+            para_SpeedBias[i][k] = Vs[i][k]; para_SpeedBias[i][3 + k] = Bas[i][k]; para_SpeedBias[i][6 + k] = Bgs[i][k];
+        }
+        R2quat(Rs[i], &para_Pose[i][3]);
+    }
+    for (int k = 0; k < 3; ++k) para_Ex_Pose[0][k] = tic[0][k];
+    R2quat(ric[0], &para_Ex_Pose[0][3]);
+    para_Feature.clear();                                                     // f_manager.getDepthVector(), feature_manager.cpp:184-200
+    for (auto &f : feature) if (usable(f)) para_Feature.push_back(1.0 / f.estimated_depth);
+}
+
+void EstimatorBackend::double2vector() {                                      // estimator.cpp:549-617
+    double origin_R0[3], origin_R00[3], origin_P0[3], R00[9], rot_diff[9];
+    R2ypr(Rs[0], origin_R0);
+    std::memcpy(origin_P0, Ps[0], sizeof(origin_P0));
+    if (failure_occur) {                                                      // :554-559
+        R2ypr(last_R0, origin_R0);
+        std::memcpy(origin_P0, last_P0, sizeof(origin_P0));
+        failure_occur = false;
+    }
+    quat2R(&para_Pose[0][3], false, R00);
+    R2ypr(R00, origin_R00);
+    const double ypr[3] = {origin_R0[0] - origin_R00[0], 0.0, 0.0};
+    ypr2R(ypr, rot_diff);
+    if (std::fabs(std::fabs(origin_R0[1]) - 90) < 1.0 || std::fabs(std::fabs(origin_R00[1]) - 90) < 1.0) {   // euler singular point, :567-575
+        const double R00t[9] = {R00[0], R00[3], R00[6], R00[1], R00[4], R00[7], R00[2], R00[5], R00[8]};
+        double Rs0[9];
+        std::memcpy(Rs0, Rs[0], sizeof(Rs0));
+        matmul3(Rs0, R00t, rot_diff);
+    }
+    for (int i = 0; i <= WINDOW_SIZE; ++i) {                                  // :577-597
+        double Rq[9];
+        quat2R(&para_Pose[i][3], true, Rq);
+        matmul3(rot_diff, Rq, Rs[i]);
+        const double d[3] = {para_Pose[i][0] - para_Pose[0][0], para_Pose[i][1] - para_Pose[0][1], para_Pose[i][2] - para_Pose[0][2]};
+        double rd[3];
+        matvec3(rot_diff, d, rd);
+        for (int k = 0; k < 3; ++k) Ps[i][k] = rd[k] + origin_P0[k];
+        matvec3(rot_diff, &para_SpeedBias[i][0], Vs[i]);
+        for (int k = 0; k < 3; ++k) { Bas[i][k] = para_SpeedBias[i][3 + k]; Bgs[i][k] = para_SpeedBias[i][6 + k]; }
+    }
+    for (int k = 0; k < 3; ++k) tic[0][k] = para_Ex_Pose[0][k];              // :599-609
+    quat2R(&para_Ex_Pose[0][3], false, ric[0]);
+    size_t k = 0;                                                             // f_manager.setDepth(dep), :611-614 -> feature_manager.cpp:141-160
+    for (auto &f : feature) {
+        if (!usable(f) || k >= para_Feature.size()) continue;
+        f.estimated_depth = 1.0 / para_Feature[k++];
+        f.solve_flag = f.estimated_depth < 0 ? 2 : 1;
+    }
+}
 
 // What the three graph-building blocks of estimator.cpp do (:909-1034, :699-810, :834-885), once.
 bool EstimatorBackend::uploadWindow() {
@@ -41,11 +178,9 @@ bool EstimatorBackend::uploadWindow() {
             pj.push_back(it_per_frame[0]); pj.push_back(it_per_frame[1]);
         }
     }
-    para_Feature.resize(feature_index + 1);
-    {
-        int k = 0;                                                            // vector2double, estimator.cpp:541-543
-        for (const auto &f : feature)
-            if (f.used_num >= 2 && f.start_frame < WINDOW_SIZE - 2) para_Feature[k++] = f.inv_depth;
+    if ((int)para_Feature.size() != feature_index + 1) {                      // para_Feature is vector2double's (:541-543), one per selected track
+        err_ = "para_Feature does not match the feature list: call vector2double() first";
+        return false;
     }
     if (vio_set_landmarks(ctx_, (int64_t)para_Feature.size(), para_Feature.data()) != VIO_OK) return false;
     if (vio_set_observations(ctx_, (int64_t)lm.size(), lm.data(), host.data(), target.data(), pi.data(), pj.data()) != VIO_OK)
@@ -72,9 +207,6 @@ bool EstimatorBackend::problemSolve() {
     }
     if (vio_get_window(ctx_, &para_Pose[0][0], &para_SpeedBias[0][0], nullptr) != VIO_OK) return false;   // :1051-1065
     if (vio_get_landmarks(ctx_, (int64_t)para_Feature.size(), para_Feature.data()) != VIO_OK) return false;   // :1067-1072
-    int k = 0;                                                                // double2vector -> f_manager.setDepth
-    for (auto &f : feature)
-        if (f.used_num >= 2 && f.start_frame < WINDOW_SIZE - 2) f.inv_depth = para_Feature[k++];
     return true;
 }
 
@@ -96,9 +228,16 @@ bool EstimatorBackend::MargNewFrame() {
 }
 
 void EstimatorBackend::backendOptimization(MarginalizationFlag marginalization_flag) {
-    problemSolve();                                     // vector2double / double2vector stay with the caller
-    if (marginalization_flag == MARGIN_OLD) MargOldFrame();
-    else if (!Hprior_.empty()) MargNewFrame();          // estimator.cpp:1107-1114
+    vector2double();                                    // estimator.cpp:1079-1083
+    if (!problemSolve()) return;
+    double2vector();
+    if (marginalization_flag == MARGIN_OLD) {           // :1088-1092
+        vector2double();
+        MargOldFrame();
+    } else if (!Hprior_.empty()) {                      // :1107-1114
+        vector2double();
+        MargNewFrame();
+    }
 }
 
 }  // namespace vio

@@ -1,5 +1,8 @@
 // estimator_backend.h — C++ host mirror of the three Estimator methods that talk to the backend
-// (SURVEY.md section 8f-1).  Same names, same data members, same call order as
+//  and of the two that convert its state for them (8a1).  Same names, same data members, same
+// call order as
+//   Estimator::vector2double         VM/src/estimator.cpp:505-547
+//   Estimator::double2vector         VM/src/estimator.cpp:549-617   (the relocalisation tail :620-643 is out of scope)
 //   Estimator::problemSolve          VM/src/estimator.cpp:902-1073
 //   Estimator::MargOldFrame          VM/src/estimator.cpp:693-829
 //   Estimator::MargNewFrame          VM/src/estimator.cpp:830-901
@@ -24,7 +27,6 @@ constexpr int WINDOW_SIZE = VIO_WINDOW_SIZE;   // parameters.h:35
 struct FeaturePerId {
     int start_frame = 0;
     std::vector<std::array<double, 2>> feature_per_frame;   // normalised (x, y), z == 1
-    double inv_depth = 0.0;                                  // what getDepthVector()/setDepth() exchange (feature_manager.cpp:184-200)
     int used_num = 0;
     int feature_id = 0;
     double estimated_depth = -1.0;                           // FeaturePerId::estimated_depth (feature_manager.h:62,74): <= 0 = not triangulated yet
@@ -42,6 +44,11 @@ public:
     EstimatorBackend &operator=(const EstimatorBackend &) = delete;
 
     // ---- the members Estimator keeps (estimator.h:66-69,113-119) ----
+    double Ps[WINDOW_SIZE + 1][3], Vs[WINDOW_SIZE + 1][3], Bas[WINDOW_SIZE + 1][3], Bgs[WINDOW_SIZE + 1][3];
+    double Rs[WINDOW_SIZE + 1][9];                    // row-major 3x3
+    double tic[1][3], ric[1][9];
+    bool failure_occur = false;                       // estimator.h:129-131: re-anchor to last_R0 / last_P0 once
+    double last_R0[9], last_P0[3];
     double para_Pose[WINDOW_SIZE + 1][7];
     double para_SpeedBias[WINDOW_SIZE + 1][9];
     double para_Ex_Pose[1][7];
@@ -52,10 +59,12 @@ public:
     vio_solve_report last_report;
 
     // ---- the methods ----
+    void vector2double();                             // Ps/Rs/Vs/Bas/Bgs/tic/ric + the depth vector -> para_*
+    void double2vector();                             // para_* -> Ps/Rs/..., yaw and position re-anchored to the pre-solve frame 0; setDepth
     bool problemSolve();
     bool MargOldFrame();
     bool MargNewFrame();
-    void backendOptimization(MarginalizationFlag marginalization_flag);
+    void backendOptimization(MarginalizationFlag marginalization_flag);   // vector2double .. double2vector (estimator.cpp:1075-1141)
     const char *last_error() const;
 
 private:

@@ -2,10 +2,12 @@
 #include "feature_manager.h"
 
 #include <algorithm>
+#include <cmath>
+#include <numeric>
 
 namespace vio {
 
-void FeatureManager::addObservation(int feature_id, int frame_count, double x, double y) {
+bool FeatureManager::addObservation(int feature_id, int frame_count, double x, double y) {
     // :67-89: look the id up; unknown -> new FeaturePerId starting at frame_count, known -> append
     auto it = std::find_if(feature.begin(), feature.end(), [&](const FeaturePerId &f) { return f.feature_id == feature_id; });
     if (it == feature.end()) {
@@ -14,9 +16,36 @@ void FeatureManager::addObservation(int feature_id, int frame_count, double x, d
         f.start_frame = frame_count;
         f.feature_per_frame.push_back({x, y});
         feature.push_back(f);
-    } else {
-        it->feature_per_frame.push_back({x, y});
+        return false;
     }
+    it->feature_per_frame.push_back({x, y});
+    return true;
+}
+
+bool FeatureManager::addFeatureCheckParallax(int frame_count, int n, const int *ids, const double *pts_xy) {   // :55-115
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ids[a] < ids[b]; });
+    double parallax_sum = 0;
+    int parallax_num = 0;
+    last_track_num = 0;
+    for (int k : order)
+        if (addObservation(ids[k], frame_count, pts_xy[2 * k], pts_xy[2 * k + 1])) ++last_track_num;
+    if (frame_count < 2 || last_track_num < 20) return true;
+    for (const auto &f : feature)
+        if (f.start_frame <= frame_count - 2 && f.start_frame + (int)f.feature_per_frame.size() - 1 >= frame_count - 1) {
+            parallax_sum += compensatedParallax2(f, frame_count);
+            ++parallax_num;
+        }
+    if (parallax_num == 0) return true;
+    return parallax_sum / parallax_num >= MIN_PARALLAX;
+}
+
+double FeatureManager::compensatedParallax2(const FeaturePerId &f, int frame_count) {   // :352-388 (z == 1: no rotation compensation)
+    const auto &pi = f.feature_per_frame[frame_count - 2 - f.start_frame];
+    const auto &pj = f.feature_per_frame[frame_count - 1 - f.start_frame];
+    const double du = pi[0] - pj[0], dv = pi[1] - pj[1];
+    return std::max(0.0, std::sqrt(du * du + dv * dv));
 }
 
 int FeatureManager::getFeatureCount() {             // :37-52

@@ -46,7 +46,7 @@ def ypr2r(ypr):
 def anchor_gauge(poses_before, poses_after, sb_after):
     """double2vector's re-anchoring of yaw and position to the pre-solve frame 0 (estimator.cpp:551-600)."""
     R0_before = synth.quat_to_rot(poses_before[0, 3:7])
-    R0_after = synth.quat_to_rot(poses_after[0, 3:7] / np.linalg.norm(poses_after[0, 3:7]))
+    R0_after = synth.quat_to_rot(poses_after[0, 3:7])       # not normalised here (:557-561), normalised below (:579)
     o0, o00 = r2ypr(R0_before), r2ypr(R0_after)
     rot_diff = ypr2r([o0[0] - o00[0], 0, 0])
     if abs(abs(o0[1]) - 90) < 1.0 or abs(abs(o00[1]) - 90) < 1.0:
