@@ -131,6 +131,26 @@ vio_status vio_set_landmarks(struct vio_ctx *ctx, int64_t n, const double *inv_d
 vio_status vio_set_observations(struct vio_ctx *ctx, int64_t m, const int32_t *lm,
                                 const int32_t *host, const int32_t *target,
                                 const double *pts_i_xy, const double *pts_j_xy);
+/* ---- 3-D landmarks: VertexPointXYZ (VM/include/backend/vertex_point_xyz.h:16) observed through EdgeReprojectionXYZ
+ *      (VM/src/backend/edge_reprojection.cc:130-180; VM/include/backend/edge_reprojection.h:56-83) instead of inverse
+ *      depths in a host frame.  The landmark blocks of Hmm are 3x3; Problem inverts them with the generic
+ *      Hmm.block(..).inverse() of problem.cc:421-425 (no lambda on landmarks).  A context holds ONE kind of landmark:
+ *      vio_set_landmarks_xyz switches it to this kind (and drops the observation list), vio_set_landmarks switches back.
+ *      Everything else of the window (poses, speed-biases, IMU edges, prior, the 171-dim pose ordering with the
+ *      extrinsic vertex first) is unchanged; the extrinsic is a constant of these edges (SetTranslationImuFromCamera,
+ *      edge_reprojection.cc:142-145), not one of their vertices, so it gets no visual information.
+ *      In this mode the landmark arrays of vio_get_delta / vio_get_landmark_system hold 3 (bl, delta) resp. 9 (H_ll,
+ *      row-major 3x3) doubles per landmark.  vio_marginalize(VIO_MARG_OLD) is VIO_ERR_UNSUPPORTED: Problem::Marginalize
+ *      keeps only the edges connected to the marginalised pose (problem.cc:621), which leaves every 3x3 landmark block
+ *      with the rank 2 of a single observation — the reference has no caller for it either. */
+/* VertexPointXYZ x N: world coordinates xyz[n][3] */
+vio_status vio_set_landmarks_xyz(struct vio_ctx *ctx, int64_t n, const double *xyz);
+/* EdgeReprojectionXYZ x M: edge e connects landmark lm[e] and the pose of frame[e]; pts_xy is the normalised
+ * observation (obs_, z == 1).  At most one observation of a landmark per frame. */
+vio_status vio_set_observations_xyz(struct vio_ctx *ctx, int64_t m, const int32_t *lm, const int32_t *frame,
+                                    const double *pts_xy);
+vio_status vio_get_landmarks_xyz(struct vio_ctx *ctx, int64_t n, double *xyz);
+
 /* EdgeImu between frames k and k+1, k in [0,10) (estimator.cpp:956-970).  pre == NULL removes the
  * edge (the reference skips it when sum_dt > 10). */
 vio_status vio_set_imu(struct vio_ctx *ctx, int32_t k, const vio_preint *pre);

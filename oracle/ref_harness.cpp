@@ -40,6 +40,7 @@
 #include "backend/problem.h"
 #include "backend/edge_reprojection.h"
 #include "backend/vertex_inverse_depth.h"
+#include "backend/vertex_point_xyz.h"
 #include "backend/vertex_pose.h"
 #include "backend/vertex_speedbias.h"
 #include "backend/loss_function.h"
@@ -82,6 +83,10 @@
 #undef vio_profile_end
 #undef vio_kernel_name
 #undef vio_preintegrate
+#undef vio_triangulate
+#undef vio_set_landmarks_xyz
+#undef vio_set_observations_xyz
+#undef vio_get_landmarks_xyz
 
 using namespace myslam::backend;
 typedef Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor> RowMat;
@@ -130,7 +135,7 @@ struct Graph {
     std::shared_ptr<VertexPose> ext;
     std::vector<std::shared_ptr<VertexPose>> cams;
     std::vector<std::shared_ptr<VertexSpeedBias>> vbs;
-    std::vector<std::shared_ptr<VertexInverseDepth>> pts;      /* indexed by landmark id, may be null */
+    std::vector<std::shared_ptr<Vertex>> pts;      /* VertexInverseDepth or VertexPointXYZ, indexed by landmark id, may be null */
     std::vector<std::shared_ptr<Edge>> edges;
     std::unique_ptr<LossFunction> loss;
 };
@@ -141,8 +146,9 @@ struct vior_ctx {
     vio_config cfg;
     std::string err;
     double pose[NF * 7], sb[NF * 9], ext[7];
-    std::vector<double> invd;
-    std::vector<int32_t> lm, host, target;
+    std::vector<double> invd;       /* [N] inverse depths, or [N][3] world points when lm_dim == 3 */
+    int lm_dim;
+    std::vector<int32_t> lm, host, target;      /* lm_dim == 3: target = the observing frame, pts_j = the observation */
     std::vector<double> pts_i, pts_j;
     bool imu_valid[VIO_WINDOW_SIZE];
     vio_preint pre[VIO_WINDOW_SIZE];
@@ -205,7 +211,32 @@ static std::unique_ptr<Graph> build_graph(vior_ctx *c, int marg) {
         }
         const double s = c->cfg.reproj_sqrt_info;
         Eigen::Matrix2d sqrt_info = s * Eigen::Matrix2d::Identity();
-        g->pts.assign(c->invd.size(), nullptr);
+        g->pts.assign(c->invd.size() / c->lm_dim, nullptr);
+        if (c->lm_dim == 3) {
+            /* VertexPointXYZ + EdgeReprojectionXYZ (edge_reprojection.h:56-83): vertices (landmark, pose), the camera
+             * extrinsic handed to the edge as a constant */
+            Eigen::Quaterniond qic(c->ext[6], c->ext[3], c->ext[4], c->ext[5]);
+            Vec3 tic(c->ext[0], c->ext[1], c->ext[2]);
+            for (size_t e = 0; e < c->lm.size(); ++e) {
+                const int l = c->lm[e];
+                if (!g->pts[l]) {
+                    std::shared_ptr<VertexPointXYZ> v(new VertexPointXYZ());
+                    VecX xyz(3);
+                    xyz << c->invd[3 * l], c->invd[3 * l + 1], c->invd[3 * l + 2];
+                    v->SetParameters(xyz);
+                    problem.AddVertex(v);
+                    g->pts[l] = v;
+                }
+                std::shared_ptr<EdgeReprojectionXYZ> edge(new EdgeReprojectionXYZ(Vec3(c->pts_j[2 * e], c->pts_j[2 * e + 1], 1.0)));
+                std::vector<std::shared_ptr<Vertex>> ev{g->pts[l], g->cams[c->target[e]]};
+                edge->SetVertex(ev);
+                edge->SetTranslationImuFromCamera(qic, tic);
+                edge->SetInformation(sqrt_info.transpose() * sqrt_info);
+                if (g->loss) edge->SetLossFunction(g->loss.get());
+                problem.AddEdge(edge);
+                g->edges.push_back(edge);
+            }
+        } else
         /* landmarks are created on first use so that the vertex-id order equals estimator.cpp:988-1016
          * when the caller lists observations grouped by landmark, as the reference does */
         for (size_t e = 0; e < c->lm.size(); ++e) {
@@ -255,7 +286,8 @@ static void pull_states(vior_ctx *c) {
         for (int k = 0; k < 7; ++k) c->pose[7 * i + k] = g.cams[i]->Parameters()[k];
         for (int k = 0; k < 9; ++k) c->sb[9 * i + k] = g.vbs[i]->Parameters()[k];
     }
-    for (size_t l = 0; l < c->invd.size(); ++l) if (g.pts[l]) c->invd[l] = g.pts[l]->Parameters()[0];
+    for (size_t l = 0; l < g.pts.size(); ++l)
+        if (g.pts[l]) for (int k = 0; k < c->lm_dim; ++k) c->invd[c->lm_dim * l + k] = g.pts[l]->Parameters()[k];
 }
 
 struct CoutSilencer {
@@ -276,6 +308,7 @@ vio_status vior_create(const vio_config *cfg, vior_ctx **out) {
     std::memset(c->pose, 0, sizeof(c->pose)); std::memset(c->sb, 0, sizeof(c->sb)); std::memset(c->ext, 0, sizeof(c->ext));
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) c->imu_valid[k] = false;
     c->prior_dim = 0;
+    c->lm_dim = 1;
     c->silent = true;
     *out = c;
     return VIO_OK;
@@ -290,7 +323,28 @@ vio_status vior_set_window(vior_ctx *c, const double *poses, const double *sb, c
 }
 vio_status vior_set_landmarks(vior_ctx *c, int64_t n, const double *invd) {
     c->invd.assign(invd, invd + n);
+    if (c->lm_dim != 1) { c->lm.clear(); c->host.clear(); c->target.clear(); c->pts_i.clear(); c->pts_j.clear(); }
+    c->lm_dim = 1;
     c->g.reset();
+    return VIO_OK;
+}
+vio_status vior_set_landmarks_xyz(vior_ctx *c, int64_t n, const double *xyz) {
+    c->invd.assign(xyz, xyz + 3 * n);
+    if (c->lm_dim != 3) { c->lm.clear(); c->host.clear(); c->target.clear(); c->pts_i.clear(); c->pts_j.clear(); }
+    c->lm_dim = 3;
+    c->g.reset();
+    return VIO_OK;
+}
+vio_status vior_set_observations_xyz(vior_ctx *c, int64_t m, const int32_t *lm, const int32_t *frame, const double *pts) {
+    if (c->lm_dim != 3) return VIO_ERR_BAD_ARG;
+    c->lm.assign(lm, lm + m); c->target.assign(frame, frame + m); c->host.assign(m, 0);
+    c->pts_j.assign(pts, pts + 2 * m); c->pts_i.assign(2 * m, 0.0);
+    c->g.reset();
+    return VIO_OK;
+}
+vio_status vior_get_landmarks_xyz(vior_ctx *c, int64_t n, double *xyz) {
+    if (c->lm_dim != 3 || (size_t)(3 * n) != c->invd.size()) return VIO_ERR_BAD_ARG;
+    std::memcpy(xyz, c->invd.data(), sizeof(double) * 3 * n);
     return VIO_OK;
 }
 vio_status vior_set_observations(vior_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target,
@@ -433,6 +487,7 @@ vio_status vior_gn_iteration(vior_ctx *c, double lambda) {
 vio_status vior_synchronize(vior_ctx *) { return VIO_OK; }
 
 vio_status vior_marginalize(vior_ctx *c, int32_t kind, double *H, double *b, double *err, double *jt) {
+    if (kind == VIO_MARG_OLD && c->lm_dim == 3) return VIO_ERR_UNSUPPORTED;     /* include/vio_backend.h: no such caller */
     std::unique_ptr<Graph> g = build_graph(c, kind == VIO_MARG_OLD ? 1 : 2);
     std::vector<std::shared_ptr<Vertex>> marg;
     int f = kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1;
@@ -460,7 +515,7 @@ vio_status vior_get_window(vior_ctx *c, double *poses, double *sb, double *ext) 
     return VIO_OK;
 }
 vio_status vior_get_landmarks(vior_ctx *c, int64_t n, double *invd) {
-    if ((size_t)n != c->invd.size()) return VIO_ERR_BAD_ARG;
+    if (c->lm_dim != 1 || (size_t)n != c->invd.size()) return VIO_ERR_BAD_ARG;
     std::memcpy(invd, c->invd.data(), sizeof(double) * n);
     return VIO_OK;
 }
@@ -489,7 +544,8 @@ vio_status vior_get_delta(vior_ctx *c, double *dxp, int64_t n, double *dxl) {
     if (!c->g) return VIO_ERR_BAD_ARG;
     Problem &p = *c->g->problem;
     if (dxp) for (int i = 0; i < PD; ++i) dxp[i] = p.delta_x_[i];
-    if (dxl) for (int64_t l = 0; l < n; ++l) dxl[l] = c->g->pts[l] ? p.delta_x_[c->g->pts[l]->OrderingId()] : 0.0;
+    const int d = c->lm_dim;
+    if (dxl) for (int64_t l = 0; l < n; ++l) for (int k = 0; k < d; ++k) dxl[d * l + k] = c->g->pts[l] ? p.delta_x_[c->g->pts[l]->OrderingId() + k] : 0.0;
     return VIO_OK;
 }
 vio_status vior_get_schur_system(vior_ctx *c, double *H, double *b) {
@@ -501,10 +557,13 @@ vio_status vior_get_schur_system(vior_ctx *c, double *H, double *b) {
 vio_status vior_get_landmark_system(vior_ctx *c, int64_t n, double *hll, double *bl) {
     if (!c->g) return VIO_ERR_BAD_ARG;
     Problem &p = *c->g->problem;
+    const int d = c->lm_dim;
     for (int64_t l = 0; l < n; ++l) {
         int id = c->g->pts[l] ? (int)c->g->pts[l]->OrderingId() : -1;
-        if (hll) hll[l] = id >= 0 ? p.Hessian_(id, id) : 0.0;
-        if (bl) bl[l] = id >= 0 ? p.b_[id] : 0.0;
+        for (int a = 0; a < d; ++a) {
+            if (hll) for (int b2 = 0; b2 < d; ++b2) hll[d * d * l + d * a + b2] = id >= 0 ? p.Hessian_(id + a, id + b2) : 0.0;
+            if (bl) bl[d * l + a] = id >= 0 ? p.b_[id + a] : 0.0;
+        }
     }
     return VIO_OK;
 }
@@ -545,6 +604,39 @@ void vior_reproj_edge(const double *pose_i, const double *pose_j, const double *
         J_i[6 * r + k] = edge.jacobians_[1](r, k); J_j[6 * r + k] = edge.jacobians_[2](r, k); J_e[6 * r + k] = edge.jacobians_[3](r, k);
     }
     global_vertex_id = 0;
+}
+
+/* EdgeReprojectionXYZ::ComputeResidual/ComputeJacobians on one edge */
+void vior_reproj_xyz_edge(const double *pose, const double *ext, const double *pw, const double *obs, double *residual,
+                          double *J_f, double *J_p) {
+    std::shared_ptr<VertexPointXYZ> vl(new VertexPointXYZ());
+    std::shared_ptr<VertexPose> vi(new VertexPose());
+    VecX x(3); x << pw[0], pw[1], pw[2]; vl->SetParameters(x);
+    Eigen::VectorXd a(7);
+    for (int k = 0; k < 7; ++k) a[k] = pose[k];
+    vi->SetParameters(a);
+    EdgeReprojectionXYZ edge(Vec3(obs[0], obs[1], 1.0));
+    edge.SetVertex(std::vector<std::shared_ptr<Vertex>>{vl, vi});
+    Eigen::Quaterniond qic(ext[6], ext[3], ext[4], ext[5]);
+    Vec3 tic(ext[0], ext[1], ext[2]);
+    edge.SetTranslationImuFromCamera(qic, tic);
+    edge.ComputeResidual();
+    edge.ComputeJacobians();
+    residual[0] = edge.residual_[0]; residual[1] = edge.residual_[1];
+    for (int r = 0; r < 2; ++r) {
+        for (int k = 0; k < 3; ++k) J_f[3 * r + k] = edge.jacobians_[0](r, k);
+        for (int k = 0; k < 6; ++k) J_p[6 * r + k] = edge.jacobians_[1](r, k);
+    }
+    global_vertex_id = 0;
+}
+
+/* Hmm.block(idx, idx, size, size).inverse() as problem.cc:424 evaluates it: a block of a dynamic matrix */
+void vior_inverse3(const double *A, double *Ainv) {
+    MatXX Hmm(MatXX::Zero(5, 5));
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Hmm(1 + i, 1 + j) = A[3 * i + j];
+    MatXX inv(MatXX::Zero(5, 5));
+    inv.block(1, 1, 3, 3) = Hmm.block(1, 1, 3, 3).inverse();
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Ainv[3 * i + j] = inv(1 + i, 1 + j);
 }
 
 /* LossFunction::Compute */

@@ -298,6 +298,92 @@ void vioo_reproj_edge(const double *pose_i, const double *pose_j, const double *
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* EdgeReprojectionXYZ: edge_reprojection.cc:130-180                                            */
+/* ------------------------------------------------------------------------------------------ */
+void vioo_reproj_xyz_edge(const double *pose, const double *ext, const double *pw, const double *obs_xy,
+                          double *residual, double *J_f, double *J_p) {
+    quat Qi = q_from_pose(pose), qic = q_from_pose(ext);
+    const double *Pi = pose, *tic = ext;
+    double d[3], pts_imu[3], e[3], pc[3];
+    for (int k = 0; k < 3; ++k) d[k] = pw[k] - Pi[k];
+    q_rot(q_inv(Qi), d, pts_imu);                       /* Qi.inverse() * (pts_w - Pi) */
+    for (int k = 0; k < 3; ++k) e[k] = pts_imu[k] - tic[k];
+    q_rot(q_inv(qic), e, pc);                           /* qic.inverse() * (pts_imu_i - tic) */
+    const double dep = pc[2];
+    if (residual) {
+        residual[0] = pc[0] / dep - obs_xy[0];
+        residual[1] = pc[1] / dep - obs_xy[1];
+    }
+    if (!J_f && !J_p) return;
+    double Ri[9], ric[9], RiT[9], ricT[9];
+    q_to_R(Qi, Ri); q_to_R(qic, ric);
+    m3_T(Ri, RiT); m3_T(ric, ricT);
+    const double reduce[6] = {1. / dep, 0, -pc[0] / (dep * dep),
+                              0, 1. / dep, -pc[1] / (dep * dep)};
+    if (J_p) {
+        /* jaco_i = [ric^T * -Ri^T | ric^T * hat(pts_imu_i)], jacobian_pose_i = reduce * jaco_i */
+        double nRiT[9], left[9], H[9], right[9];
+        for (int k = 0; k < 9; ++k) nRiT[k] = -RiT[k];
+        m3_mul(ricT, nRiT, left);
+        skew(pts_imu, H);
+        m3_mul(ricT, H, right);
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c) {
+                J_p[6 * r + c] = reduce[3 * r] * left[c] + reduce[3 * r + 1] * left[3 + c] + reduce[3 * r + 2] * left[6 + c];
+                J_p[6 * r + 3 + c] = reduce[3 * r] * right[c] + reduce[3 * r + 1] * right[3 + c] + reduce[3 * r + 2] * right[6 + c];
+            }
+    }
+    if (J_f) {
+        /* jacobian_feature = (reduce * ric^T) * Ri^T */
+        double rr[6];
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c)
+                rr[3 * r + c] = reduce[3 * r] * ricT[c] + reduce[3 * r + 1] * ricT[3 + c] + reduce[3 * r + 2] * ricT[6 + c];
+        for (int r = 0; r < 2; ++r)
+            for (int c = 0; c < 3; ++c)
+                J_f[3 * r + c] = rr[3 * r] * RiT[c] + rr[3 * r + 1] * RiT[3 + c] + rr[3 * r + 2] * RiT[6 + c];
+    }
+}
+
+/* Hmm.block(idx, idx, 3, 3).inverse() (problem.cc:424).  The block is a dynamic-size expression, so Eigen takes
+ * compute_inverse<.., Dynamic>: PartialPivLU (LU/PartialPivLU.h, unblocked_lu for sizes <= 16: first largest |entry| of the
+ * column as pivot, the column divided by it, rank-1 update of the rest) and inverse() = solve(Identity):
+ * P * I, then the unit-lower and the upper triangular solves of TriangularSolverMatrix.h (column by column,
+ * the diagonal applied as a multiplication by its reciprocal). */
+void vioo_inverse3(const double *A, double *Ainv) {
+    double lu[9];
+    int piv[3];
+    for (int k = 0; k < 9; ++k) lu[k] = A[k];
+    for (int k = 0; k < 3; ++k) {
+        int best = k;
+        double big = fabs(lu[3 * k + k]);
+        for (int i = k + 1; i < 3; ++i) if (fabs(lu[3 * i + k]) > big) { big = fabs(lu[3 * i + k]); best = i; }
+        piv[k] = best;
+        if (big != 0.0) {
+            if (best != k) for (int j = 0; j < 3; ++j) { double t = lu[3 * k + j]; lu[3 * k + j] = lu[3 * best + j]; lu[3 * best + j] = t; }
+            for (int i = k + 1; i < 3; ++i) lu[3 * i + k] /= lu[3 * k + k];
+        }
+        for (int i = k + 1; i < 3; ++i)
+            for (int j = k + 1; j < 3; ++j) lu[3 * i + j] -= lu[3 * i + k] * lu[3 * k + j];
+    }
+    double X[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 3; ++k)
+        if (piv[k] != k) for (int j = 0; j < 3; ++j) { double t = X[3 * k + j]; X[3 * k + j] = X[3 * piv[k] + j]; X[3 * piv[k] + j] = t; }
+    for (int j = 0; j < 3; ++j) {
+        for (int i = 0; i < 3; ++i) {                   /* unit lower: forward */
+            const double b = X[3 * i + j];
+            for (int r = i + 1; r < 3; ++r) X[3 * r + j] -= b * lu[3 * r + i];
+        }
+        for (int i = 2; i >= 0; --i) {                  /* upper: backward, a = 1 / tri(i, i) */
+            const double a = 1.0 / lu[3 * i + i];
+            const double b = (X[3 * i + j] *= a);
+            for (int r = 0; r < i; ++r) X[3 * r + j] -= b * lu[3 * r + i];
+        }
+    }
+    for (int k = 0; k < 9; ++k) Ainv[k] = X[k];
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* IMU factor: integration_base.h:160-186 (evaluate), edge_imu.cc:38-156 (Jacobians)           */
 /* ------------------------------------------------------------------------------------------ */
 #define O_P 0
@@ -868,6 +954,8 @@ struct vioo_ctx {
     double pose[NF * 7], sb[NF * 9], ext[7];
     double pose_bak[NF * 7], sb_bak[NF * 9], ext_bak[7];
     int64_t N, M;
+    int lm_dim;                 /* 1: VertexInverseDepth (invd[N]); 3: VertexPointXYZ (invd[N][3] holds the world points,
+                                 * target[] the observing frame, pts_j the observation; hll 3x3, bl 3, Hpl 72x3 per landmark) */
     double *invd, *invd_bak;
     int32_t *lm, *host, *target;
     double *pts_i, *pts_j;
@@ -923,6 +1011,7 @@ vio_status vio_create(const vio_config *cfg, struct vioo_ctx **out) {
     c->cfg = *cfg;
     if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
     c->ni = 2; c->lambda = -1;
+    c->lm_dim = 1;
     c->vis = c->vis_own; c->step = c->step_own;
     for (int i = 0; i < NF; ++i) c->pose[7 * i + 6] = 1.0;
     c->ext[6] = 1.0;
@@ -946,18 +1035,46 @@ vio_status vio_set_window(struct vioo_ctx *c, const double *poses, const double 
     return VIO_OK;
 }
 
-vio_status vio_set_landmarks(struct vioo_ctx *c, int64_t n, const double *invd) {
-    if (!c || n < 0 || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+static vio_status set_landmarks_dim(struct vioo_ctx *c, int64_t n, const double *val, int dim) {
+    if (!c || n < 0 || (n > 0 && !val)) return VIO_ERR_BAD_ARG;
     free(c->invd); free(c->invd_bak); free(c->hll); free(c->bl); free(c->Hpl); free(c->dx_lm);
+    if (dim != c->lm_dim || n != c->N) c->M = 0;        /* the observation list refers to the other kind / other indices */
     c->N = n;
+    c->lm_dim = dim;
     size_t nn = (size_t)(n > 0 ? n : 1);
-    c->invd = (double *)malloc(sizeof(double) * nn);
-    c->invd_bak = (double *)malloc(sizeof(double) * nn);
-    c->hll = (double *)calloc(nn, sizeof(double));
-    c->bl = (double *)calloc(nn, sizeof(double));
-    c->Hpl = (double *)calloc(nn * CD, sizeof(double));
-    c->dx_lm = (double *)calloc(nn, sizeof(double));
-    if (n > 0) memcpy(c->invd, invd, sizeof(double) * n);
+    c->invd = (double *)malloc(sizeof(double) * nn * dim);
+    c->invd_bak = (double *)malloc(sizeof(double) * nn * dim);
+    c->hll = (double *)calloc(nn * dim * dim, sizeof(double));
+    c->bl = (double *)calloc(nn * dim, sizeof(double));
+    c->Hpl = (double *)calloc(nn * CD * dim, sizeof(double));
+    c->dx_lm = (double *)calloc(nn * dim, sizeof(double));
+    if (n > 0) memcpy(c->invd, val, sizeof(double) * n * dim);
+    c->linearized = 0;
+    return VIO_OK;
+}
+
+vio_status vio_set_landmarks(struct vioo_ctx *c, int64_t n, const double *invd) { return set_landmarks_dim(c, n, invd, 1); }
+vio_status vio_set_landmarks_xyz(struct vioo_ctx *c, int64_t n, const double *xyz) { return set_landmarks_dim(c, n, xyz, 3); }
+
+/* EdgeReprojectionXYZ x M: (landmark, observing frame, observation) */
+vio_status vio_set_observations_xyz(struct vioo_ctx *c, int64_t m, const int32_t *lm, const int32_t *frame, const double *pts) {
+    if (!c || m < 0 || (m > 0 && (!lm || !frame || !pts))) return VIO_ERR_BAD_ARG;
+    if (c->lm_dim != 3) { snprintf(c->err, sizeof(c->err), "vio_set_observations_xyz needs vio_set_landmarks_xyz first"); return VIO_ERR_BAD_ARG; }
+    for (int64_t e = 0; e < m; ++e)
+        if (lm[e] < 0 || lm[e] >= c->N || frame[e] < 0 || frame[e] >= NF) {
+            snprintf(c->err, sizeof(c->err), "observation %lld out of range", (long long)e);
+            return VIO_ERR_BAD_ARG;
+        }
+    free(c->lm); free(c->host); free(c->target); free(c->pts_i); free(c->pts_j);
+    c->M = m;
+    size_t mm = (size_t)(m > 0 ? m : 1);
+    c->lm = (int32_t *)malloc(sizeof(int32_t) * mm); c->host = (int32_t *)calloc(mm, sizeof(int32_t));
+    c->target = (int32_t *)malloc(sizeof(int32_t) * mm);
+    c->pts_i = (double *)calloc(2 * mm, sizeof(double)); c->pts_j = (double *)malloc(sizeof(double) * 2 * mm);
+    if (m > 0) {
+        memcpy(c->lm, lm, sizeof(int32_t) * m); memcpy(c->target, frame, sizeof(int32_t) * m);
+        memcpy(c->pts_j, pts, sizeof(double) * 2 * m);
+    }
     c->linearized = 0;
     return VIO_OK;
 }
@@ -965,6 +1082,7 @@ vio_status vio_set_landmarks(struct vioo_ctx *c, int64_t n, const double *invd) 
 vio_status vio_set_observations(struct vioo_ctx *c, int64_t m, const int32_t *lm, const int32_t *host,
                                 const int32_t *target, const double *pi, const double *pj) {
     if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
+    if (c->lm_dim == 3) { snprintf(c->err, sizeof(c->err), "the context holds XYZ landmarks: use vio_set_observations_xyz"); return VIO_ERR_BAD_ARG; }
     for (int64_t e = 0; e < m; ++e) {
         if (lm[e] < 0 || lm[e] >= c->N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF ||
             host[e] == target[e]) {
@@ -1089,7 +1207,79 @@ static void accum_schur(struct vioo_ctx *c, int64_t l, int marg_mode, double *S,
     }
 }
 
+/* XYZ landmarks: one EdgeReprojectionXYZ's share of MakeHessian.  Vertex order of the edge: (landmark, pose). */
+static void accum_edge_xyz(struct vioo_ctx *c, int64_t e, double *Hv, double *bv, double *chi) {
+    const double s = c->cfg.reproj_sqrt_info, info = s * s;
+    const int l = c->lm[e], f = c->target[e];
+    double r[2], Jf[6], Jp[12], W[4], drho;
+    vioo_reproj_xyz_edge(&c->pose[7 * f], c->ext, &c->invd[3 * (size_t)l], &c->pts_j[2 * e], r, Jf, Jp);
+    vioo_robust_info2(c->cfg.loss_type, c->cfg.loss_delta, s, r, &drho, W);
+    *chi += robust_chi2_2(c->cfg.loss_type, c->cfg.loss_delta, s, r);
+    const int ip = 6 + 6 * f;
+    double *hl = &c->hll[9 * (size_t)l], *w = &c->Hpl[(size_t)l * CD * 3];
+    for (int a = 0; a < 3; ++a) {
+        const double t0 = Jf[a] * W[0] + Jf[3 + a] * W[2], t1 = Jf[a] * W[1] + Jf[3 + a] * W[3];     /* (Jf^T W) row a */
+        for (int b2 = 0; b2 < 3; ++b2) hl[3 * a + b2] += t0 * Jf[b2] + t1 * Jf[3 + b2];
+        for (int k = 0; k < 6; ++k) w[(ip + k) * 3 + a] += t0 * Jp[k] + t1 * Jp[6 + k];              /* Hpm(pose k, landmark a) */
+    }
+    add_cam_block(Hv, ip, ip, Jp, W, Jp, 1);
+    const double ir0 = info * r[0], ir1 = info * r[1];
+    for (int a = 0; a < 3; ++a) c->bl[3 * (size_t)l + a] -= drho * (Jf[a] * ir0 + Jf[3 + a] * ir1);
+    for (int k = 0; k < 6; ++k) bv[ip + k] -= drho * (Jp[k] * ir0 + Jp[6 + k] * ir1);
+}
+
+/* tempH = Hpm * Hmm_inv for one landmark's three columns, then S += tempH * Hmp, sb += tempH * bmm (problem.cc:419-429).
+ * `Y` (72 x 3) is returned for the back-substitution's sake only through c->hll: the caller keeps Hmm_inv there. */
+static void accum_schur_xyz(struct vioo_ctx *c, int64_t l, double *S, double *sb, double *maxh, int *degenerate) {
+    const double *w = &c->Hpl[(size_t)l * CD * 3], *hl = &c->hll[9 * (size_t)l], *bl = &c->bl[3 * (size_t)l];
+    for (int a = 0; a < 3; ++a) *maxh = fmax(*maxh, fabs(hl[4 * a]));
+    double hinv[9];
+    vioo_inverse3(hl, hinv);
+    for (int k = 0; k < 9; ++k) if (!isfinite(hinv[k])) *degenerate = 1;
+    int nzc[CD], nn = 0;
+    for (int a = 0; a < CD; ++a) if (w[3 * a] != 0.0 || w[3 * a + 1] != 0.0 || w[3 * a + 2] != 0.0) nzc[nn++] = a;
+    for (int x = 0; x < nn; ++x) {
+        const double *wa = &w[3 * nzc[x]];
+        double ta[3];
+        for (int j = 0; j < 3; ++j) ta[j] = wa[0] * hinv[j] + wa[1] * hinv[3 + j] + wa[2] * hinv[6 + j];
+        for (int y = 0; y < nn; ++y) {
+            const double *wb = &w[3 * nzc[y]];
+            S[nzc[x] * CD + nzc[y]] += ta[0] * wb[0] + ta[1] * wb[1] + ta[2] * wb[2];
+        }
+        sb[nzc[x]] += ta[0] * bl[0] + ta[1] * bl[1] + ta[2] * bl[2];
+    }
+}
+
+static void linearize_visual_xyz(struct vioo_ctx *c) {
+    double *Hv = c->Hv_dir;
+    double bv[CD], sb[CD];
+    memset(Hv, 0, sizeof(double) * CD * CD); memset(bv, 0, sizeof(bv)); memset(sb, 0, sizeof(sb));
+    const size_t nn = (size_t)(c->N > 0 ? c->N : 1);
+    memset(c->hll, 0, sizeof(double) * nn * 9); memset(c->bl, 0, sizeof(double) * nn * 3);
+    memset(c->Hpl, 0, sizeof(double) * nn * CD * 3);
+    double chi = 0, maxh = 0;
+    double *S = (double *)calloc(CD * CD, sizeof(double));
+    int degenerate = 0;
+    for (int64_t e = 0; e < c->M; ++e) accum_edge_xyz(c, e, Hv, bv, &chi);
+    for (int64_t l = 0; l < c->N; ++l) accum_schur_xyz(c, l, S, sb, &maxh, &degenerate);
+    for (int a = 0; a < CD; ++a) {
+        for (int b2 = 0; b2 < CD; ++b2) c->vis[VIS_H + a * CD + b2] = Hv[a * CD + b2] - S[a * CD + b2];
+        c->vis[VIS_BRED + a] = bv[a] - sb[a];
+        c->vis[VIS_BDIR + a] = bv[a];
+        c->vis[VIS_DIAG + a] = Hv[a * CD + a];
+    }
+    if (degenerate)
+        for (int a = 0; a < CD; ++a) {
+            for (int b2 = 0; b2 < CD; ++b2) c->vis[VIS_H + a * CD + b2] = NAN;
+            c->vis[VIS_BRED + a] = NAN;
+        }
+    c->vis[VIS_CHI] = chi;
+    c->vis[VIS_MAXH] = maxh;
+    free(S);
+}
+
 static void linearize_visual(struct vioo_ctx *c, int marg_mode) {
+    if (c->lm_dim == 3) { linearize_visual_xyz(c); return; }
     const int fixed = marg_mode ? 0 : c->cfg.ext_fixed;
     double *Hv = c->Hv_dir;
     double bv[CD];
@@ -1261,7 +1451,7 @@ vio_status vio_linearize(struct vioo_ctx *c) {
     memcpy(c->diagfull, diag, sizeof(diag));
     free(R);
     memset(c->dx_pose, 0, sizeof(c->dx_pose));
-    for (int64_t l = 0; l < c->N; ++l) c->dx_lm[l] = 0;
+    for (int64_t l = 0; l < c->N * c->lm_dim; ++l) c->dx_lm[l] = 0;
     c->linearized = 1;
     return VIO_OK;
 }
@@ -1270,6 +1460,14 @@ vio_status vio_linearize(struct vioo_ctx *c) {
 static double chi2_visual(struct vioo_ctx *c) {
     const double s = c->cfg.reproj_sqrt_info;
     double chi = 0;
+    if (c->lm_dim == 3) {
+        for (int64_t e = 0; e < c->M; ++e) {
+            double r[2];
+            vioo_reproj_xyz_edge(&c->pose[7 * c->target[e]], c->ext, &c->invd[3 * (size_t)c->lm[e]], &c->pts_j[2 * e], r, NULL, NULL);
+            chi += robust_chi2_2(c->cfg.loss_type, c->cfg.loss_delta, s, r);
+        }
+        return chi;
+    }
 #ifdef _OPENMP
     #pragma omp parallel for reduction(+ : chi) schedule(static) num_threads(oracle_threads())
 #endif
@@ -1343,6 +1541,22 @@ vio_status vio_solve_linear(struct vioo_ctx *c, double lambda) {
     for (int i = 0; i < PD; ++i) H[i * PD + i] += lambda;
     vioo_ldlt_solve(PD, H, c->bs, c->dx_pose, NULL);
     free(H);
+    if (c->lm_dim == 3) {       /* delta_x_ll = Hmm_inv * (bmm - Hmp * delta_x_pp), problem.cc:445 */
+        for (int64_t l = 0; l < c->N; ++l) {
+            const double *w = &c->Hpl[(size_t)l * CD * 3];
+            double t[3] = {0, 0, 0}, hinv[9], v[3];
+            for (int a = 0; a < CD; ++a) {
+                if (w[3 * a] == 0.0 && w[3 * a + 1] == 0.0 && w[3 * a + 2] == 0.0) continue;
+                const double d = c->dx_pose[cam_to_full(a)];
+                for (int j = 0; j < 3; ++j) t[j] += w[3 * a + j] * d;
+            }
+            vioo_inverse3(&c->hll[9 * (size_t)l], hinv);
+            for (int j = 0; j < 3; ++j) v[j] = c->bl[3 * (size_t)l + j] - t[j];
+            for (int i = 0; i < 3; ++i) c->dx_lm[3 * (size_t)l + i] = hinv[3 * i] * v[0] + hinv[3 * i + 1] * v[1] + hinv[3 * i + 2] * v[2];
+        }
+        c->lambda = lambda;
+        return VIO_OK;
+    }
 #ifdef _OPENMP
     #pragma omp parallel for schedule(static) num_threads(oracle_threads())
 #endif
@@ -1361,13 +1575,13 @@ vio_status vio_update_states(struct vioo_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
     memcpy(c->pose_bak, c->pose, sizeof(c->pose)); memcpy(c->sb_bak, c->sb, sizeof(c->sb));
     memcpy(c->ext_bak, c->ext, sizeof(c->ext));
-    if (c->N > 0) memcpy(c->invd_bak, c->invd, sizeof(double) * c->N);
+    if (c->N > 0) memcpy(c->invd_bak, c->invd, sizeof(double) * c->N * c->lm_dim);
     vioo_pose_plus(c->ext, &c->dx_pose[0]);
     for (int i = 0; i < NF; ++i) {
         vioo_pose_plus(&c->pose[7 * i], &c->dx_pose[6 + 15 * i]);
         for (int k = 0; k < 9; ++k) c->sb[9 * i + k] += c->dx_pose[12 + 15 * i + k];
     }
-    for (int64_t l = 0; l < c->N; ++l) c->invd[l] += c->dx_lm[l];
+    for (int64_t l = 0; l < c->N * c->lm_dim; ++l) c->invd[l] += c->dx_lm[l];       /* Vertex::Plus (vertex.cc:28-30) */
     if (c->has_prior) {
         memcpy(c->bprior_bak, c->bprior, sizeof(c->bprior)); memcpy(c->errprior_bak, c->errprior, sizeof(c->errprior));
         double tmp[PD];
@@ -1387,7 +1601,7 @@ vio_status vio_rollback_states(struct vioo_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
     memcpy(c->pose, c->pose_bak, sizeof(c->pose)); memcpy(c->sb, c->sb_bak, sizeof(c->sb));
     memcpy(c->ext, c->ext_bak, sizeof(c->ext));
-    if (c->N > 0) memcpy(c->invd, c->invd_bak, sizeof(double) * c->N);
+    if (c->N > 0) memcpy(c->invd, c->invd_bak, sizeof(double) * c->N * c->lm_dim);
     if (c->has_prior) { memcpy(c->bprior, c->bprior_bak, sizeof(c->bprior)); memcpy(c->errprior, c->errprior_bak, sizeof(c->errprior)); }
     return VIO_OK;
 }
@@ -1396,7 +1610,7 @@ vio_status vio_rollback_states(struct vioo_ctx *c) {
 vio_status vio_eval_step(struct vioo_ctx *c, int32_t *accepted, double *chi2, double *lambda) {
     if (!c) return VIO_ERR_BAD_ARG;
     double scale_lm = 0, scale = 0;
-    for (int64_t l = 0; l < c->N; ++l) scale_lm += c->dx_lm[l] * (c->lambda * c->dx_lm[l] + c->bl[l]);
+    for (int64_t l = 0; l < c->N * c->lm_dim; ++l) scale_lm += c->dx_lm[l] * (c->lambda * c->dx_lm[l] + c->bl[l]);
     double tempChi;
     vio_status st = chi2_exchange(c, scale_lm, &tempChi, &scale_lm);
     if (st != VIO_OK) return st;
@@ -1539,6 +1753,10 @@ void vioo_schur_pinv(int n, int m2, const double *H, const double *b, double *Hp
 vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, double *bout, double *errout, double *jtout) {
     if (!c || !Hout || !bout || !errout || !jtout) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
+    if (kind == VIO_MARG_OLD && c->lm_dim == 3) {
+        snprintf(c->err, sizeof(c->err), "MargOldFrame is not defined for XYZ landmarks (include/vio_backend.h)");
+        return VIO_ERR_UNSUPPORTED;
+    }
     const int n = PD;
     double *H = (double *)calloc(n * n, sizeof(double));
     double b[PD];
@@ -1604,8 +1822,13 @@ vio_status vio_get_window(struct vioo_ctx *c, double *poses, double *sb, double 
     return VIO_OK;
 }
 vio_status vio_get_landmarks(struct vioo_ctx *c, int64_t n, double *invd) {
-    if (!c || n != c->N || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+    if (!c || n != c->N || c->lm_dim != 1 || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
     if (n > 0) memcpy(invd, c->invd, sizeof(double) * n);
+    return VIO_OK;
+}
+vio_status vio_get_landmarks_xyz(struct vioo_ctx *c, int64_t n, double *xyz) {
+    if (!c || n != c->N || c->lm_dim != 3 || (n > 0 && !xyz)) return VIO_ERR_BAD_ARG;
+    if (n > 0) memcpy(xyz, c->invd, sizeof(double) * 3 * n);
     return VIO_OK;
 }
 vio_status vio_get_prior(struct vioo_ctx *c, double *b, double *err) {
@@ -1617,7 +1840,7 @@ vio_status vio_get_prior(struct vioo_ctx *c, double *b, double *err) {
 vio_status vio_get_delta(struct vioo_ctx *c, double *dxp, int64_t n, double *dxl) {
     if (!c || (dxl && n != c->N)) return VIO_ERR_BAD_ARG;
     if (dxp) memcpy(dxp, c->dx_pose, sizeof(c->dx_pose));
-    if (dxl && n > 0) memcpy(dxl, c->dx_lm, sizeof(double) * n);
+    if (dxl && n > 0) memcpy(dxl, c->dx_lm, sizeof(double) * n * c->lm_dim);
     return VIO_OK;
 }
 vio_status vio_get_schur_system(struct vioo_ctx *c, double *H, double *b) {
@@ -1628,8 +1851,8 @@ vio_status vio_get_schur_system(struct vioo_ctx *c, double *H, double *b) {
 }
 vio_status vio_get_landmark_system(struct vioo_ctx *c, int64_t n, double *hll, double *bl) {
     if (!c || n != c->N) return VIO_ERR_BAD_ARG;
-    if (hll && n > 0) memcpy(hll, c->hll, sizeof(double) * n);
-    if (bl && n > 0) memcpy(bl, c->bl, sizeof(double) * n);
+    if (hll && n > 0) memcpy(hll, c->hll, sizeof(double) * n * c->lm_dim * c->lm_dim);
+    if (bl && n > 0) memcpy(bl, c->bl, sizeof(double) * n * c->lm_dim);
     return VIO_OK;
 }
 vio_status vio_get_pose_gradient(struct vioo_ctx *c, double *b, double *diag) {

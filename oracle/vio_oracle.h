@@ -45,6 +45,9 @@
 #define vio_kernel_name vioo_kernel_name
 #define vio_preintegrate vioo_preintegrate_abi
 #define vio_triangulate vioo_triangulate
+#define vio_set_landmarks_xyz vioo_set_landmarks_xyz
+#define vio_set_observations_xyz vioo_set_observations_xyz
+#define vio_get_landmarks_xyz vioo_get_landmarks_xyz
 #include "../include/vio_backend.h"
 
 #ifdef __cplusplus
@@ -58,6 +61,15 @@ extern "C" {
 void vioo_reproj_edge(const double *pose_i, const double *pose_j, const double *ext, double inv_depth,
                       const double *pts_i_xy, const double *pts_j_xy, double *residual,
                       double *J_lambda, double *J_pose_i, double *J_pose_j, double *J_ext);
+
+/* EdgeReprojectionXYZ::ComputeResidual + ComputeJacobians (edge_reprojection.cc:130-180): landmark pw (world xyz)
+ * seen from the body pose `pose` through the camera extrinsic `ext`.  J_feature row-major 2x3, J_pose 2x6; may be NULL. */
+void vioo_reproj_xyz_edge(const double *pose, const double *ext, const double *pw, const double *obs_xy,
+                          double *residual, double *J_feature, double *J_pose);
+
+/* MatXX::inverse() of a 3x3 block as problem.cc:424 runs it: Eigen's dynamic-size path, PartialPivLU (unblocked,
+ * LU/PartialPivLU.h) then the two triangular solves of the identity.  Row-major in/out. */
+void vioo_inverse3(const double *A, double *Ainv);
 
 /* IntegrationBase::evaluate + EdgeImu::ComputeJacobians (integration_base.h:160-186,
  * edge_imu.cc:38-156). Jacobians row-major 15x6, 15x9, 15x6, 15x9; may be NULL. */

@@ -71,7 +71,7 @@ def run_stepwise(ctx, lam=None):
     out["dx_pose"], out["dx_lm"] = ctx.get_delta()
     ctx.update_states()
     out["poses1"], out["sb1"], out["ext1"] = ctx.get_window()
-    out["invd1"] = ctx.get_landmarks()
+    out["invd1"] = ctx.get_landmarks() if ctx.lm_dim == 1 else ctx.get_landmarks_xyz()
     out["bprior1"], out["errprior1"] = ctx.get_prior()
     out["chi1"] = np.float64(ctx.chi2())
     ok, chi, lam1 = ctx.eval_step()
@@ -83,7 +83,7 @@ def run_solve(ctx, iterations=10):
     rep = ctx.solve(iterations)
     out = {}
     out["posesF"], out["sbF"], out["extF"] = ctx.get_window()
-    out["invdF"] = ctx.get_landmarks()
+    out["invdF"] = ctx.get_landmarks() if ctx.lm_dim == 1 else ctx.get_landmarks_xyz()
     out["bpriorF"], out["errpriorF"] = ctx.get_prior()
     out["final_chi2"], out["final_lambda"] = np.float64(rep.final_chi2), np.float64(rep.final_lambda)
     out["iterations"] = np.int32(rep.iterations)

@@ -84,7 +84,8 @@ class VioLib:
                "solve_linear", "update_states", "rollback_states", "chi2", "eval_step", "gn_iteration",
                "synchronize", "marginalize", "get_window", "get_landmarks", "get_prior", "get_delta",
                "get_schur_system", "get_landmark_system", "get_pose_gradient", "exchange_buffers",
-               "set_exchange_hook", "bind_exchange_buffers"]
+               "set_exchange_hook", "bind_exchange_buffers", "set_landmarks_xyz", "set_observations_xyz",
+               "get_landmarks_xyz"]
     # outside the backend proper: the compiled-reference harness (vior_) has no FeatureManager
     OPTIONAL = ["triangulate"]
 
@@ -169,6 +170,7 @@ class VioContext:
         self.h = C.c_void_p()
         self.n = 0
         self.m = 0
+        self.lm_dim = 1     # 1: inverse depths, 3: XYZ landmarks (set_landmarks / set_landmarks_xyz switch it)
         st = lib.fn["create"](C.byref(cfg), C.byref(self.h))
         if st != 0:
             raise VioError(st, lib.prefix + "create")
@@ -196,8 +198,23 @@ class VioContext:
 
     def set_landmarks(self, inv_depth):
         d = _f64(inv_depth).reshape(-1)
-        self.n = d.size
+        self.n, self.lm_dim = d.size, 1
         self._ck(self.lib.fn["set_landmarks"](self.h, C.c_int64(d.size), _dp(d)), "set_landmarks")
+
+    def set_landmarks_xyz(self, xyz):
+        """VertexPointXYZ x N: world points [N][3]; the context now holds XYZ landmarks."""
+        d = _f64(xyz).reshape(-1, 3)
+        self.n, self.lm_dim = d.shape[0], 3
+        self._ck(self.lib.fn["set_landmarks_xyz"](self.h, C.c_int64(self.n), _dp(d)), "set_landmarks_xyz")
+
+    def set_observations_xyz(self, lm, frame, pts):
+        """EdgeReprojectionXYZ x M: (landmark, observing frame, normalised observation)."""
+        lm = np.ascontiguousarray(lm, dtype=np.int32)
+        frame = np.ascontiguousarray(frame, dtype=np.int32)
+        self.m = lm.size
+        p = _f64(pts, (self.m, 2))
+        self._ck(self.lib.fn["set_observations_xyz"](self.h, C.c_int64(self.m), _ip(lm), _ip(frame), _dp(p)),
+                 "set_observations_xyz")
 
     def set_observations(self, lm, host, target, pts_i, pts_j):
         lm = np.ascontiguousarray(lm, dtype=np.int32)
@@ -228,8 +245,13 @@ class VioContext:
         """Upload a synth.Window (or any object/dict with the same fields)."""
         g = (lambda k: w[k]) if isinstance(w, dict) else (lambda k: getattr(w, k))
         self.set_window(g("poses"), g("speed_bias"), g("ext"))
-        self.set_landmarks(g("inv_depth"))
-        self.set_observations(g("lm"), g("host"), g("target"), g("pts_i"), g("pts_j"))
+        xyz = w.get("xyz") if isinstance(w, dict) else getattr(w, "xyz", None)
+        if xyz is not None:                                   # synth.make_window_xyz
+            self.set_landmarks_xyz(xyz)
+            self.set_observations_xyz(g("lm"), g("frame"), g("pts"))
+        else:
+            self.set_landmarks(g("inv_depth"))
+            self.set_observations(g("lm"), g("host"), g("target"), g("pts_i"), g("pts_j"))
         for k, pre in enumerate(g("preint")):
             self.set_imu(k, pre)
         self.set_prior(g("prior"))
@@ -292,15 +314,21 @@ class VioContext:
         self._ck(self.lib.fn["get_landmarks"](self.h, C.c_int64(self.n), _dp(d)), "get_landmarks")
         return d[:self.n]
 
+    def get_landmarks_xyz(self):
+        d = np.zeros((max(self.n, 1), 3))
+        self._ck(self.lib.fn["get_landmarks_xyz"](self.h, C.c_int64(self.n), _dp(d)), "get_landmarks_xyz")
+        return d[:self.n]
+
     def get_prior(self):
         b, err = np.zeros(POSE_DIM), np.zeros(PRIOR_DIM)
         self._ck(self.lib.fn["get_prior"](self.h, _dp(b), _dp(err)), "get_prior")
         return b, err
 
     def get_delta(self):
-        dp, dl = np.zeros(POSE_DIM), np.zeros(max(self.n, 1))
+        d = self.lm_dim
+        dp, dl = np.zeros(POSE_DIM), np.zeros(max(self.n, 1) * d)
         self._ck(self.lib.fn["get_delta"](self.h, _dp(dp), C.c_int64(self.n), _dp(dl)), "get_delta")
-        return dp, dl[:self.n]
+        return dp, (dl[:self.n] if d == 1 else dl[:self.n * d].reshape(self.n, d))
 
     def get_schur_system(self):
         H, b = np.zeros((POSE_DIM, POSE_DIM)), np.zeros(POSE_DIM)
@@ -308,10 +336,13 @@ class VioContext:
         return H, b
 
     def get_landmark_system(self):
-        h, b = np.zeros(max(self.n, 1)), np.zeros(max(self.n, 1))
+        d = self.lm_dim
+        h, b = np.zeros(max(self.n, 1) * d * d), np.zeros(max(self.n, 1) * d)
         self._ck(self.lib.fn["get_landmark_system"](self.h, C.c_int64(self.n), _dp(h), _dp(b)),
                  "get_landmark_system")
-        return h[:self.n], b[:self.n]
+        if d == 1:
+            return h[:self.n], b[:self.n]
+        return h[:self.n * d * d].reshape(self.n, d, d), b[:self.n * d].reshape(self.n, d)
 
     def get_pose_gradient(self):
         b, d = np.zeros(POSE_DIM), np.zeros(POSE_DIM)

@@ -232,6 +232,42 @@ def make_window(n_landmarks, seed=42, obs_per_landmark=4, t0=1.0, imu_rate=200, 
                   inv_depth_gt=1.0 / depth, seed=seed, n_landmarks=N, n_observations=int(lm.size))
 
 
+def make_window_xyz(n_landmarks, seed=42, xyz_noise=0.05, **kw):
+    """The same window with its landmarks as world points (VertexPointXYZ) and one EdgeReprojectionXYZ per observation
+    (VM/src/backend/edge_reprojection.cc:130-180): a landmark hosted in frame h and tracked into h+1..h+K of
+    make_window() is observed K+1 times here — the host observation is an observation like the others.  Observations
+    are listed landmark-major, frames ascending.  Fields: xyz [N][3], lm / frame / pts [M]."""
+    w = make_window(n_landmarks, seed=seed, **kw)
+    rng = np.random.RandomState(seed + 7919)
+    N = w.n_landmarks
+    host_of = np.zeros(N, dtype=np.int64)
+    px = np.zeros((N, 2))
+    host_of[w.lm] = w.host
+    px[w.lm] = w.pts_i
+    Rg = np.stack([quat_to_rot(q) for q in w.poses_gt[:, 3:7]])
+    Pg = w.poses_gt[:, 0:3]
+    pc = np.concatenate([px, np.ones((N, 1))], axis=1) / w.inv_depth_gt[:, None]
+    pb = pc @ R_IC.T + T_IC
+    xyz_gt = np.einsum("nij,nj->ni", Rg[host_of], pb) + Pg[host_of]
+    k_of = np.bincount(w.lm, minlength=N)
+    first = np.concatenate([[0], np.cumsum(k_of)[:-1]]) if N else np.zeros(0, dtype=np.int64)
+    M = int(w.lm.size + N)
+    lm = np.repeat(np.arange(N, dtype=np.int32), k_of + 1)
+    pos = np.concatenate([[0], np.cumsum(k_of + 1)[:-1]]) if N else np.zeros(0, dtype=np.int64)
+    frame = np.zeros(M, dtype=np.int32)
+    pts = np.zeros((M, 2))
+    frame[pos] = host_of
+    pts[pos] = px + rng.normal(0.0, kw.get("pixel_noise", 1.0 / FOCAL), size=(N, 2))
+    rest = np.ones(M, dtype=bool)
+    rest[pos] = False
+    frame[rest] = w.target
+    pts[rest] = w.pts_j
+    xyz = xyz_gt + rng.normal(0.0, xyz_noise, size=(N, 3))
+    return Window(poses=w.poses, speed_bias=w.speed_bias, ext=w.ext, xyz=xyz, lm=lm, frame=frame, pts=pts, preint=w.preint,
+                  prior=None, poses_gt=w.poses_gt, speed_bias_gt=w.speed_bias_gt, xyz_gt=xyz_gt, seed=seed, n_landmarks=N,
+                  n_observations=M)
+
+
 def shard_window(w, rank, world):
     """Block-partition the landmarks (with all their observations) over `world` ranks
     (SURVEY.md section 8e): poses, speed-biases, extrinsic, pre-integrations and prior are replicated."""
