@@ -81,7 +81,7 @@ typedef struct vio_config {
     double gravity[3];         /* global G read by IntegrationBase::evaluate (integration_base.h:178-180) */
     void *stream;              /* optional hipStream_t to enqueue on (NULL: the library creates its own) */
     int32_t shard_rank;        /* landmark shard index of this context (multi-GPU), 0 when unsharded */
-    int32_t shard_count;       /* number of shards; IMU + prior terms are added by rank 0 only */
+    int32_t shard_count;       /* number of shards; IMU + prior terms are replicated: every rank adds them after the exchange */
 } vio_config;
 
 /* State of one IntegrationBase as EdgeImu consumes it (VM/include/factor/integration_base.h:160-208,

@@ -1720,7 +1720,7 @@ static void move_to_bottom(double *H, double *b, int n, int idx, int dim) {
 void vioo_schur_pinv(int n, int m2, const double *H, const double *b, double *Hp, double *bp) {
     const int n2 = n - m2;
     const double eps = 1e-8;
-    double *Amm = (double *)malloc(sizeof(double) * m2 * m2), *ev = (double *)malloc(sizeof(double) * m2);
+    double *Amm = (double *)calloc((size_t)m2 * m2, sizeof(double)), *ev = (double *)malloc(sizeof(double) * m2);
     double *V = (double *)malloc(sizeof(double) * m2 * m2), *Ainv = (double *)malloc(sizeof(double) * m2 * m2);
     double *tempB = (double *)malloc(sizeof(double) * (n2 > 0 ? n2 : 1) * m2);
     for (int i = 0; i < m2; ++i) for (int j = 0; j < m2; ++j) Amm[i * m2 + j] = 0.5 * (H[(n2 + i) * n + n2 + j] + H[(n2 + j) * n + n2 + i]);

@@ -36,8 +36,8 @@ def cfg_of(z):
 
 
 def test_golden_files_present():
-    assert len(WINDOW_FILES) >= 8
-    for f in ("reproj_edges", "loss_and_robust", "pose_plus", "ldlt", "symmetric_eigen", "inverse15"):
+    assert len(WINDOW_FILES) >= 14 and sum("window_xyz_" in f for f in WINDOW_FILES) >= 6
+    for f in ("reproj_edges", "loss_and_robust", "pose_plus", "ldlt", "symmetric_eigen", "inverse15", "reproj_xyz_edges", "inverse3"):
         assert os.path.exists(os.path.join(GOLDEN_DIR, f + ".npz"))
 
 
@@ -52,6 +52,32 @@ def test_reprojection_edge(oracle_lib):
         for got, key in ((r, "residual"), (Jl, "J_lambda"), (Ji, "J_pose_i"), (Jj, "J_pose_j"), (Je, "J_ext")):
             want = z[key][e]
             assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (e, key)
+
+
+def test_reprojection_xyz_edge(oracle_lib):
+    """EdgeReprojectionXYZ::ComputeResidual / ComputeJacobians (edge_reprojection.cc:130-180)."""
+    z = load("reproj_xyz_edges")
+    f = oracle_lib.dll.vioo_reproj_xyz_edge
+    f.restype = None
+    ext = np.ascontiguousarray(z["ext"])
+    for e in range(z["residual"].shape[0]):
+        r, Jf, Jp = np.zeros(2), np.zeros(6), np.zeros(12)
+        f(dp(np.ascontiguousarray(z["pose"][e])), dp(ext), dp(np.ascontiguousarray(z["pw"][e])), dp(np.ascontiguousarray(z["obs"][e])),
+          dp(r), dp(Jf), dp(Jp))
+        for got, key in ((r, "residual"), (Jf, "J_feature"), (Jp, "J_pose")):
+            want = z[key][e]
+            assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max()), (e, key)
+
+
+def test_inverse3_matches_eigens_dynamic_inverse(oracle_lib):
+    """Hmm.block(idx, idx, 3, 3).inverse() (problem.cc:424): PartialPivLU, every pivot choice in the file."""
+    z = load("inverse3")
+    f = oracle_lib.dll.vioo_inverse3
+    f.restype = None
+    for k in range(z["A"].shape[0]):
+        out = np.zeros((3, 3))
+        f(dp(np.ascontiguousarray(z["A"][k])), dp(out))
+        np.testing.assert_allclose(out, z["Ainv"][k], rtol=1e-13, atol=1e-13 * np.abs(z["Ainv"][k]).max())
 
 
 def test_loss_functions_and_robust_info(oracle_lib):

@@ -1,0 +1,237 @@
+"""XYZ landmarks (VertexPointXYZ + EdgeReprojectionXYZ, VM/src/backend/edge_reprojection.cc:130-180; 3x3 blocks of Hmm
+inverted by problem.cc:421-425): the oracle against structural known answers and — where the compiled reference exists —
+against it on fresh seeds; the HIP kernels (k_linearize_xyz, k_backsub_xyz) against the oracle.  The golden files
+window_xyz_*.npz are covered by test_oracle_golden.py (oracle) and test_gpu_parity.py (HIP)."""
+import numpy as np
+import pytest
+
+import vio_testutil as tu
+
+CAM = [6 + 15 * f + k for f in range(11) for k in range(6)]          # the camera-pose columns of the 171-dim ordering
+
+
+def nullspace_window(vio):
+    """The reference's Hessian null-space demonstration (A/14-sliding-window/src/hessian_nullspace_test.cpp:46-144):
+    poses on an arc (theta_n = n 2 pi / 40, radius 8), 20 landmarks in x, y in [-4, 4], z in [8, 10], every landmark
+    seen from every pose, identity intrinsics and weights.  There: 10 poses; here the window's 11."""
+    synth = vio.synth
+    rng = np.random.RandomState(4)
+    poses = np.zeros((11, 7))
+    for n in range(11):
+        th = n * 2 * np.pi / 40
+        R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+        poses[n, 0:3] = [8 * np.cos(th) - 8, 8 * np.sin(th), np.sin(2 * th)]
+        poses[n, 3:7] = synth.rot_to_quat(R)
+    xyz = np.stack([rng.uniform(-4, 4, 20), rng.uniform(-4, 4, 20), rng.uniform(8, 10, 20)], axis=1)
+    ext = np.array([0, 0, 0, 0, 0, 0, 1.0])                         # camera == body
+    lm = np.repeat(np.arange(20, dtype=np.int32), 11)
+    frame = np.tile(np.arange(11, dtype=np.int32), 20)
+    pts = np.zeros((220, 2))
+    for e in range(220):
+        pc = synth.quat_to_rot(poses[frame[e], 3:7]).T @ (xyz[lm[e]] - poses[frame[e], 0:3])
+        pts[e] = pc[0:2] / pc[2]
+    return synth.Window(poses=poses, speed_bias=np.zeros((11, 9)), ext=ext, xyz=xyz, lm=lm, frame=frame, pts=pts,
+                        preint=[None] * 10, prior=None, n_landmarks=20, n_observations=220)
+
+
+def check_nullspace(vio, lib):
+    ctx = lib.context(loss_type=vio.LOSS_TRIVIAL, reproj_sqrt_info=1.0)
+    ctx.load(nullspace_window(vio))
+    ctx.linearize()
+    H, _ = ctx.get_schur_system()
+    Hc = H[np.ix_(CAM, CAM)]
+    ev = np.linalg.eigvalsh(0.5 * (Hc + Hc.T))
+    # monocular bundle adjustment: 7 unobservable directions (6 of the gauge + scale); the landmark Schur complement
+    # keeps the nullity of the full Hessian the reference prints
+    assert np.abs(ev[:7]).max() <= 1e-9 * ev[-1], ev[:8]
+    assert ev[7] >= 1e-5 * ev[-1], ev[:9]
+    other = [i for i in range(171) if i not in CAM]
+    assert np.abs(H[other]).max() == 0.0                             # no IMU, no prior: nothing else gets information
+
+
+def test_hessian_nullspace_of_the_oracle(vio, oracle_lib):
+    check_nullspace(vio, oracle_lib)
+
+
+def test_xyz_solve_brings_the_residuals_down_to_the_pixel_noise(vio, oracle_lib):
+    w = vio.synth.make_window_xyz(150, seed=5)
+    ctx = oracle_lib.context()
+    ctx.load(w)
+    rep = ctx.solve(10)
+    assert rep.final_chi2 < 1e-3 * rep.initial_chi2
+    # whitened residuals of N(0, 1/460) pixel noise at information (460/1.5)^2: e2 ~ 2 / 1.5^2 per edge, Cauchy rho(e2) below that
+    assert rep.final_chi2 < 0.5 * w.n_observations
+
+
+def test_kind_switch_and_unsupported_calls(vio, oracle_lib):
+    w3, w1 = vio.synth.make_window_xyz(20, seed=1), vio.synth.make_window(20, seed=1)
+    ctx = oracle_lib.context()
+    ctx.load(w3)
+    a = ctx.solve(10).final_chi2
+    with pytest.raises(vio.VioError):
+        ctx.marginalize(vio.MARG_OLD)                                # no such graph for XYZ landmarks (include/vio_backend.h)
+    with pytest.raises(vio.VioError):
+        ctx.set_observations(w1.lm, w1.host, w1.target, w1.pts_i, w1.pts_j)    # wrong kind of observation list
+    ctx.load(w1)
+    b = ctx.solve(10).final_chi2
+    ctx.load(w3)
+    assert ctx.solve(10).final_chi2 == a and a != b
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("n,seed,ragged,ext_fixed,kw", [(1, 1, False, 1, {}), (12, 2, True, 1, {}), (80, 3, True, 0, {}),
+                                                        (40, 4, False, 1, dict(obs_per_landmark=10))])
+def test_oracle_vs_reference_on_fresh_xyz_windows(vio, oracle_lib, ref_lib, n, seed, ragged, ext_fixed, kw):
+    w = vio.synth.make_window_xyz(n, seed=seed, ragged=ragged, **kw)
+    co, cr = oracle_lib.context(ext_fixed=ext_fixed), ref_lib.context(ext_fixed=ext_fixed)
+    co.load(w)
+    cr.load(w)
+    a, b = tu.run_stepwise(co), tu.run_stepwise(cr)
+    assert tu.scaled_sym_err(a["Hs"][np.ix_(CAM, CAM)], b["Hs"][np.ix_(CAM, CAM)]) <= 1e-9
+    assert np.abs(a["dx_pose"] - b["dx_pose"]).max() <= 1e-9 and np.abs(a["dx_lm"] - b["dx_lm"]).max() <= 1e-9
+    assert tu.rel_max(a["hll"], b["hll"]) <= 1e-11 and int(a["accepted"]) == int(b["accepted"])
+    co.load(w)
+    cr.load(w)
+    sa, _ = tu.run_solve(co)
+    sb, _ = tu.run_solve(cr)
+    assert int(sa["iterations"]) == int(sb["iterations"])
+    assert np.abs(sa["posesF"] - sb["posesF"]).max() <= 1e-6 and np.abs(sa["invdF"] - sb["invdF"]).max() <= 1e-6
+
+
+# ------------------------------------------------------- GPU ----------------------------------------------------------------
+def compare_stepwise(a, b, dx_tol=1e-8):
+    assert tu.scaled_sym_err(a["Hs"][np.ix_(CAM, CAM)], b["Hs"][np.ix_(CAM, CAM)]) <= 1e-9
+    assert np.abs(a["bs"] - b["bs"]).max() <= 1e-10 * max(np.abs(b["bs"]).max(), 1e-300)
+    assert np.abs(a["bpp"] - b["bpp"]).max() <= 1e-10 * max(np.abs(b["bpp"]).max(), 1e-300)
+    assert tu.rel_max(a["diag"], b["diag"]) <= 1e-11
+    assert tu.rel_max(a["hll"], b["hll"]) <= 1e-10 and tu.rel_max(a["bl"], b["bl"]) <= 1e-9
+    assert abs(a["chi0"] - b["chi0"]) <= 1e-10 * abs(b["chi0"])
+    assert a["lambda0"] == b["lambda0"]
+    assert np.abs(a["dx_pose"] - b["dx_pose"]).max() <= dx_tol
+    assert np.abs(a["dx_lm"] - b["dx_lm"]).max() <= dx_tol
+    for k in ("poses1", "sb1", "ext1", "invd1"):
+        assert np.abs(a[k] - b[k]).max() <= dx_tol, k
+    assert abs(a["chi1"] - b["chi1"]) <= 1e-8 * abs(b["chi1"])
+    assert int(a["accepted"]) == int(b["accepted"])
+    assert abs(a["lambda1"] - b["lambda1"]) <= 1e-9 * abs(b["lambda1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,ragged,ext_fixed,loss,kw", [
+    (1, 1, False, 1, 2, {}),                                   # one landmark, five observations
+    (9, 2, True, 1, 2, {}),                                    # ragged: 2 .. 11 observations per landmark
+    (57, 3, False, 1, 2, {}),                                  # item boundaries
+    (300, 5, True, 0, 2, {}),                                  # every pattern, extrinsic vertex free (it gets no information)
+    (1000, 6, True, 1, 2, {}),
+    (300, 7, False, 1, 0, {}),                                 # no loss object
+    (300, 8, False, 1, 3, dict(pos_noise=0.001, rot_noise=0.0002, pixel_noise=0.25 / 460, outlier_fraction=0.05, xyz_noise=0.003)),
+    (120, 9, False, 1, 2, dict(obs_per_landmark=10)),          # every landmark seen from all 11 frames (K = 11, 66 pattern columns)
+    (5000, 10, False, 1, 2, {}),
+])
+def test_hip_stepwise_against_oracle(vio, oracle_lib, hip_lib, n, seed, ragged, ext_fixed, loss, kw):
+    w = vio.synth.make_window_xyz(n, seed=seed, ragged=ragged, **kw)
+    ch, co = hip_lib.context(ext_fixed=ext_fixed, loss_type=loss), oracle_lib.context(ext_fixed=ext_fixed, loss_type=loss)
+    ch.load(w)
+    co.load(w)
+    compare_stepwise(tu.run_stepwise(ch), tu.run_stepwise(co))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed,ragged", [(50, 11, False), (300, 12, True), (2000, 14, False)])
+def test_hip_full_solve_against_oracle(vio, oracle_lib, hip_lib, n, seed, ragged):
+    w = vio.synth.make_window_xyz(n, seed=seed, ragged=ragged)
+    ch, co = hip_lib.context(), oracle_lib.context()
+    ch.load(w)
+    co.load(w)
+    sh, rh = tu.run_solve(ch)
+    so, ro = tu.run_solve(co)
+    assert rh.iterations == ro.iterations and rh.trials == ro.trials and rh.accepted == ro.accepted
+    np.testing.assert_allclose(sh["chi2_trace"], so["chi2_trace"], rtol=1e-6)
+    assert abs(rh.final_chi2 - ro.final_chi2) <= 1e-6 * ro.final_chi2
+    for k in ("posesF", "sbF", "extF", "invdF"):
+        assert np.abs(sh[k] - so[k]).max() <= 1e-6, k
+
+
+@pytest.mark.gpu
+def test_hip_gn_iterations_against_oracle(vio, oracle_lib, hip_lib):
+    w = vio.synth.make_window_xyz(400, seed=21)
+    ch, co = hip_lib.context(), oracle_lib.context()
+    ch.load(w)
+    co.load(w)
+    for _ in range(5):
+        ch.gn_iteration(1e3)
+        co.gn_iteration(1e3)
+    ch.synchronize()
+    ph, sh, _ = ch.get_window()
+    po, so, _ = co.get_window()
+    assert np.abs(ph - po).max() <= 1e-7 and np.abs(sh - so).max() <= 1e-7
+    assert np.abs(ch.get_landmarks_xyz() - co.get_landmarks_xyz()).max() <= 1e-7
+    assert abs(ch.chi2() - co.chi2()) <= 1e-7 * co.chi2()
+
+
+@pytest.mark.gpu
+def test_hip_hessian_nullspace(vio, hip_lib):
+    check_nullspace(vio, hip_lib)
+
+
+@pytest.mark.gpu
+def test_hip_kind_switch_prior_and_marg_new(vio, oracle_lib, hip_lib):
+    """One context across both kinds of landmark; a window with a prior; MargNewFrame (edge-free, any kind)."""
+    w1 = vio.synth.make_window(120, seed=31)
+    ch, co = hip_lib.context(), oracle_lib.context()
+    ch.load(w1)
+    co.load(w1)
+    sh, _ = tu.run_solve(ch)
+    so, _ = tu.run_solve(co)
+    ws = w1.copy()
+    ws.poses, ws.speed_bias, ws.ext, ws.inv_depth = so["posesF"], so["sbF"], so["extF"], so["invdF"]
+    co.load(ws)
+    prior = co.marginalize(vio.MARG_OLD)
+    w3 = vio.synth.make_window_xyz(200, seed=32, t0=1.1)
+    w3.prior = prior
+    ch.load(w3)                                                  # the same context, now with XYZ landmarks
+    co.load(w3)
+    compare_stepwise(tu.run_stepwise(ch), tu.run_stepwise(co))
+    ch.load(w3)
+    co.load(w3)
+    sh, rh = tu.run_solve(ch)
+    so, ro = tu.run_solve(co)
+    assert rh.iterations == ro.iterations
+    assert np.abs(sh["posesF"] - so["posesF"]).max() <= 1e-6 and np.abs(sh["invdF"] - so["invdF"]).max() <= 1e-6
+    assert tu.rel_max(sh["bpriorF"], so["bpriorF"]) <= 1e-7
+    with pytest.raises(vio.VioError):
+        ch.marginalize(vio.MARG_OLD)
+    from test_oracle_golden import check_prior
+    check_prior(ch.marginalize(vio.MARG_SECOND_NEW), co.marginalize(vio.MARG_SECOND_NEW))
+    ch.load(w1)                                                  # and back to inverse depths
+    co.load(w1)
+    assert abs(ch.solve(10).final_chi2 - co.solve(10).final_chi2) <= 1e-6 * co.solve(10).final_chi2 + 1e-9
+
+
+@pytest.mark.gpu
+def test_hip_headline_size_properties(vio, oracle_lib, hip_lib):
+    """20 000 XYZ landmarks / 100 000 observations: the update against the oracle, chi2 decreasing over GN iterations,
+    run-to-run bitwise reproducibility."""
+    w = vio.synth.make_window_xyz(20000, seed=42)
+    ch, co = hip_lib.context(), oracle_lib.context()
+    ch.load(w)
+    co.load(w)
+    ch.linearize(); co.linearize()
+    (chi_h, lam_h), (chi_o, lam_o) = ch.init_lm(), co.init_lm()
+    assert lam_h == lam_o and abs(chi_h - chi_o) <= 1e-10 * chi_o
+    ch.solve_linear(lam_o); co.solve_linear(lam_o)
+    (dph, dlh), (dpo, dlo) = ch.get_delta(), co.get_delta()
+    assert np.abs(dph - dpo).max() <= 1e-8 and np.abs(dlh - dlo).max() <= 1e-8
+    runs = []
+    for _ in range(2):
+        c = hip_lib.context()
+        c.load(w)
+        chis = []
+        for _ in range(4):
+            c.gn_iteration(1e2)
+            chis.append(c.chi2())
+        assert all(b <= a for a, b in zip(chis, chis[1:])), chis
+        runs.append((c.get_window()[0], c.get_landmarks_xyz(), chis))
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    assert runs[0][2] == runs[1][2]

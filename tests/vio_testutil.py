@@ -7,7 +7,9 @@ PRIOR_FIELDS = ("H", "b", "err", "jt_inv")
 
 def window_to_arrays(w, prefix="in_"):
     d = {}
-    for k in ("poses", "speed_bias", "ext", "inv_depth", "lm", "host", "target", "pts_i", "pts_j"):
+    xyz = getattr(w, "xyz", None) is not None       # synth.make_window_xyz: VertexPointXYZ landmarks
+    for k in (("poses", "speed_bias", "ext", "xyz", "lm", "frame", "pts") if xyz else
+              ("poses", "speed_bias", "ext", "inv_depth", "lm", "host", "target", "pts_i", "pts_j")):
         d[prefix + k] = np.asarray(getattr(w, k))
     for f in PREINT_FIELDS:
         d[prefix + "pre_" + f] = np.stack([np.asarray(p[f], dtype=np.float64).reshape(-1) for p in w.preint])
@@ -30,6 +32,11 @@ def arrays_to_window(vio, z, prefix="in_"):
     if prefix + "prior_H" in z:
         prior = {f: z[prefix + "prior_" + f].copy() for f in PRIOR_FIELDS}
     lm = z[prefix + "lm"]
+    if prefix + "xyz" in z:
+        return vio.synth.Window(poses=z[prefix + "poses"].copy(), speed_bias=z[prefix + "speed_bias"].copy(),
+                                ext=z[prefix + "ext"].copy(), xyz=z[prefix + "xyz"].copy(), lm=lm.copy(),
+                                frame=z[prefix + "frame"].copy(), pts=z[prefix + "pts"].copy(), preint=pre, prior=prior,
+                                n_landmarks=int(z[prefix + "xyz"].shape[0]), n_observations=int(lm.size))
     return vio.synth.Window(poses=z[prefix + "poses"].copy(), speed_bias=z[prefix + "speed_bias"].copy(),
                             ext=z[prefix + "ext"].copy(), inv_depth=z[prefix + "inv_depth"].copy(),
                             lm=lm.copy(), host=z[prefix + "host"].copy(), target=z[prefix + "target"].copy(),

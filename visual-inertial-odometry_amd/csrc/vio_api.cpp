@@ -50,6 +50,7 @@ void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
 int vio_set_kernel_attributes();
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext);
+int xyz_lds_doubles_host(int G, int K);
 
 namespace {
 
@@ -85,7 +86,7 @@ struct Pattern {
 // Everything that depends on the graph topology (which landmark is seen from where).
 struct Plan {
     bool valid = false;
-    int marg = 0, use_ext = 0;
+    int marg = 0, use_ext = 0, lm_dim = 1;
     int64_t Ns = 0, Ms = 0;
     std::vector<int32_t> sorted_to_orig;       // landmark permutation
     std::vector<ItemDesc> items;
@@ -113,6 +114,7 @@ struct vio_ctx {
     bool own_stream = false;
     // host mirrors of the inputs (original landmark order)
     double h_state[STATE_STRIDE];
+    int lm_dim = 1;                            // 1: inverse depths; 3: XYZ points (h_invd [N][3], h_otarget = observing frame, h_pts_j = observation)
     std::vector<double> h_invd, h_pts_i, h_pts_j;
     std::vector<int32_t> h_olm, h_ohost, h_otarget;   // observation -> landmark / host frame / target frame
     bool imu_valid[VIO_WINDOW_SIZE];
@@ -144,6 +146,7 @@ struct vio_ctx {
     vio_exchange_fn hook = nullptr;
     void *comm = nullptr;                              // ncclComm_t of the native exchange (vio_comm_init)
     int cur_host = -1;                                 // LmState.cur as the host tracks it through GN iterations (-1: unknown)
+    vio_status flush_status = VIO_OK;                  // what the flush_decide inside the last make_tables returned
     bool decide_pending = false;                       // GN mode: the last step's test has not run yet (k_assemble of the next iteration does it)
     void *hook_user = nullptr;
     double hessian_ms = 0;
@@ -196,9 +199,127 @@ void build_pattern_tables(Pattern &pt, int g_max) {
     pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
 }
 
-vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
+vio_status upload_plan(vio_ctx *c, Plan &pl, const std::vector<double> &pts_i, const std::vector<double> &pts_j);
+
+// The plan of a window of XYZ landmarks (vio_kernels_xyz.h): a pattern is the set of frames a landmark is seen from,
+// one pattern block per frame, no host frame and no extrinsic block.
+vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
     pl.valid = false;
-    pl.marg = marg;
+    pl.marg = 0; pl.use_ext = 0; pl.lm_dim = 3;
+    const int64_t N = (int64_t)c->h_invd.size() / 3, M = (int64_t)c->h_olm.size();
+    // observation of landmark l in frame f: obs_at[l * NF + f] (or -1)
+    std::vector<int32_t> obs_at((size_t)std::max<int64_t>(N, 1) * NF, -1);
+    for (int64_t e = 0; e < M; ++e) {
+        int32_t &slot = obs_at[(size_t)c->h_olm[e] * NF + c->h_otarget[e]];
+        if (slot >= 0) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
+        slot = (int32_t)e;
+    }
+    std::vector<int32_t> mask(N, 0), pat_of_mask(1 << NF, -1), lm_pattern(N, -1);
+    pl.patterns.clear();
+    for (int64_t l = 0; l < N; ++l) {
+        int m = 0;
+        for (int f = 0; f < NF; ++f) if (obs_at[(size_t)l * NF + f] >= 0) m |= 1 << f;
+        if (m == 0) return fail(c, VIO_ERR_UNSUPPORTED, "landmark without observations (its 3x3 Hessian block would be singular)");
+        mask[l] = m;
+        if (pat_of_mask[m] < 0) {
+            pat_of_mask[m] = (int)pl.patterns.size();
+            Pattern pt;
+            std::memset(&pt, 0, sizeof(pt));
+            pt.host = -1; pt.host_slot = -1;
+            int p = 0;
+            for (int f = 0; f < NF; ++f) if ((m >> f) & 1) {
+                pt.cam_block[p] = (int8_t)(1 + f);
+                if (p < VIO_MAXK) { pt.target[p] = (int8_t)f; pt.tslot[p] = (int8_t)p; }
+                pt.btype_i[p] = 2; pt.bk_i[p] = p;
+                ++p;
+            }
+            pt.K = pt.nb = p;
+            pt.n_rows = item_nbp(pt.nb) * 6 + 3 * pt.nb;
+            int G = std::max(1, std::min(c->g_max > 0 ? c->g_max : 128, 1024 / pt.K));
+            while (G > 1 && xyz_lds_doubles_host(G, pt.K) > LDS_BUDGET_DOUBLES) --G;
+            pt.G = G;
+            pt.lds_doubles = xyz_lds_doubles_host(G, pt.K);
+            pl.patterns.push_back(pt);
+        }
+        lm_pattern[l] = pat_of_mask[m];
+    }
+    {   // counting sort: pattern-major, original index inside a pattern
+        std::vector<int64_t> start(pl.patterns.size() + 1, 0);
+        for (int64_t l = 0; l < N; ++l) ++start[lm_pattern[l] + 1];
+        for (size_t q = 0; q < pl.patterns.size(); ++q) start[q + 1] += start[q];
+        pl.sorted_to_orig.assign((size_t)N, 0);
+        for (int64_t l = 0; l < N; ++l) pl.sorted_to_orig[start[lm_pattern[l]]++] = (int32_t)l;
+    }
+    pl.Ns = N;
+    {   // landmarks per item: whole rounds of the device's CUs, as build_plan does, within what the LDS holds per pattern
+        std::vector<int64_t> n_of(pl.patterns.size(), 0);
+        for (int64_t l = 0; l < N; ++l) ++n_of[lm_pattern[l]];
+        const int cus = std::max(1, c->n_cus);
+        int best_g = 0;
+        double best_cost = 0.0;
+        for (int g = c->g_min; g <= 128; ++g) {
+            int64_t blocks = VIO_WINDOW_SIZE;
+            int g_eff = 1;
+            for (size_t q = 0; q < pl.patterns.size(); ++q) {
+                const int gp = std::min(g, pl.patterns[q].G);
+                const int64_t ni = (n_of[q] + gp - 1) / gp;
+                blocks += ni;
+                if (ni) g_eff = std::max<int>(g_eff, (int)((n_of[q] + ni - 1) / ni));
+            }
+            const double cost = (double)((blocks + cus - 1) / cus) * (70.0 + g_eff);
+            if (best_g == 0 || cost < best_cost) { best_g = g; best_cost = cost; }
+        }
+        for (size_t q = 0; q < pl.patterns.size(); ++q) {
+            Pattern &pt = pl.patterns[q];
+            const int gp = std::min(best_g, pt.G);
+            const int64_t ni = std::max<int64_t>(1, (n_of[q] + gp - 1) / gp);
+            pt.G = (int)std::max<int64_t>(1, (n_of[q] + ni - 1) / ni);
+            pt.lds_doubles = xyz_lds_doubles_host(pt.G, pt.K);
+        }
+    }
+    pl.items.clear();
+    std::vector<double> pts_i(2, 0.0), pts_j;
+    pl.slab_doubles = 0; pl.lw_doubles = 0; pl.max_lds_doubles = IMU_ITEM_LDS_DOUBLES;
+    int64_t s = 0, obs_base = 0;
+    while (s < pl.Ns) {
+        const int id = lm_pattern[pl.sorted_to_orig[s]];
+        const Pattern &pt = pl.patterns[id];
+        int64_t e = s;
+        while (e < pl.Ns && e - s < pt.G && lm_pattern[pl.sorted_to_orig[e]] == id) ++e;
+        ItemDesc it;
+        std::memset(&it, 0, sizeof(it));
+        it.lm_base = (int32_t)s; it.G = (int32_t)(e - s); it.K = pt.K; it.nb = pt.nb; it.host = -1;
+        it.host_slot = -1; it.use_ext = 0; it.obs_base = (int32_t)obs_base;
+        it.out_base = (int32_t)pl.slab_doubles; it.lw_base = (int32_t)pl.lw_doubles;
+        std::memcpy(it.target, pt.target, sizeof(it.target)); std::memcpy(it.tslot, pt.tslot, sizeof(it.tslot));
+        std::memcpy(it.cam_block, pt.cam_block, sizeof(it.cam_block));
+        for (int p = 0; p < pt.nb; ++p) { it.btype[p] = 2; it.bk[p] = (int8_t)p; }
+        it.n_rows = pt.n_rows; it.lds_doubles = pt.lds_doubles;
+        pl.items.push_back(it);
+        pl.max_lds_doubles = std::max(pl.max_lds_doubles, pt.lds_doubles);
+        pl.slab_doubles += (size_t)item_out_count(pt.nb);
+        pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
+        pl.lw_doubles += (size_t)(18 * pt.nb + 9) * it.G;
+        pts_j.resize(2 * (obs_base + (int64_t)it.G * it.K));
+        for (int g = 0; g < it.G; ++g) {
+            const int32_t l = pl.sorted_to_orig[s + g];
+            for (int k = 0; k < it.K; ++k) {
+                const int32_t oe = obs_at[(size_t)l * NF + (pt.cam_block[k] - 1)];
+                const int64_t o = obs_base + (int64_t)k * it.G + g;
+                pts_j[2 * o] = c->h_pts_j[2 * oe]; pts_j[2 * o + 1] = c->h_pts_j[2 * oe + 1];
+            }
+        }
+        obs_base += (int64_t)it.G * it.K;
+        s = e;
+    }
+    pl.Ms = obs_base;
+    return upload_plan(c, pl, pts_i, pts_j);
+}
+
+vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
+    if (c->lm_dim == 3) return build_plan_xyz(c, pl);
+    pl.valid = false;
+    pl.marg = marg; pl.lm_dim = 1;
     pl.use_ext = marg ? 1 : (c->cfg.ext_fixed ? 0 : 1);
     const int64_t N = (int64_t)c->h_invd.size(), M = (int64_t)c->h_olm.size();
     // observations of each landmark, in the caller's order (CSR; this runs once per frame on the host, so no
@@ -343,7 +464,11 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         s = e;
     }
     pl.Ms = obs_base;
-    // inverted lists for k_reduce
+    return upload_plan(c, pl, pts_i, pts_j);
+}
+
+// inverted lists for k_reduce, device buffers, upload: common to both kinds of landmark
+vio_status upload_plan(vio_ctx *c, Plan &pl, const std::vector<double> &pts_i, const std::vector<double> &pts_j) {
     const int n_lists = VIO_NPAIR + VIO_NCB + 1;
     std::vector<std::vector<int32_t>> lists(n_lists);
     for (const ItemDesc &it : pl.items) {
@@ -370,15 +495,16 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     const size_t ni = pl.items.size();
     HIPCHK(pl.d_items.resize(ni));
     HIPCHK(pl.d_list_off.resize(pl.list_off.size())); HIPCHK(pl.d_list.resize(pl.list.size()));
+    const size_t ld = (size_t)pl.lm_dim;
     HIPCHK(pl.d_pts_i.resize(2 * (size_t)pl.Ns)); HIPCHK(pl.d_pts_j.resize(2 * (size_t)pl.Ms));
-    HIPCHK(pl.d_invd.resize(2 * (size_t)std::max<int64_t>(pl.Ns, 1))); HIPCHK(pl.d_slab.resize(pl.slab_doubles));
-    HIPCHK(pl.d_lw.resize(pl.lw_doubles)); HIPCHK(pl.d_dxl.resize((size_t)pl.Ns));
+    HIPCHK(pl.d_invd.resize(2 * ld * (size_t)std::max<int64_t>(pl.Ns, 1))); HIPCHK(pl.d_slab.resize(pl.slab_doubles));
+    HIPCHK(pl.d_lw.resize(pl.lw_doubles)); HIPCHK(pl.d_dxl.resize(ld * (size_t)pl.Ns));
     HIPCHK(pl.d_step_part.resize(4 * (ni + VIO_WINDOW_SIZE)));
     hipStream_t st = c->stream;
     if (ni) HIPCHK(hipMemcpyAsync(pl.d_items.p, pl.items.data(), ni * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(pl.d_list_off.p, pl.list_off.data(), pl.list_off.size() * 4, hipMemcpyHostToDevice, st));
     if (!pl.list.empty()) HIPCHK(hipMemcpyAsync(pl.d_list.p, pl.list.data(), pl.list.size() * 4, hipMemcpyHostToDevice, st));
-    if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i.data(), 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
+    if (pl.Ns && pl.lm_dim == 1) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i.data(), 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
     if (pl.Ms) HIPCHK(hipMemcpyAsync(pl.d_pts_j.p, pts_j.data(), 2 * (size_t)pl.Ms * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));
     pl.valid = true;
@@ -406,7 +532,7 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     DeviceTables T;
     std::memset(&T, 0, sizeof(T));
     T.items = pl.d_items.p; T.n_items = (int32_t)pl.items.size(); T.n_imu_items = VIO_WINDOW_SIZE;
-    T.Ns = (int32_t)pl.Ns; T.ext_fixed = c->cfg.ext_fixed; T.loss_type = c->cfg.loss_type; T.marg_mode = pl.marg;
+    T.Ns = (int32_t)pl.Ns; T.lm_dim = pl.lm_dim; T.ext_fixed = c->cfg.ext_fixed; T.loss_type = c->cfg.loss_type; T.marg_mode = pl.marg;
     T.loss_delta = c->cfg.loss_delta; T.sqrt_info = c->cfg.reproj_sqrt_info;
     for (int k = 0; k < 3; ++k) T.gravity[k] = c->cfg.gravity[k];
     T.state = c->d_state.p; T.invd = pl.d_invd.p; T.pts_i = pl.d_pts_i.p; T.pts_j = pl.d_pts_j.p;
@@ -457,10 +583,11 @@ vio_status flush_decide(vio_ctx *c) {
 // tables for every path but the GN loop: bring the device's LmState up to date first; the host's idea of `cur` is void
 // until the next read_lm
 DeviceTables make_tables(vio_ctx *c, Plan &pl) {
-    (void)flush_decide(c);
+    c->flush_status = flush_decide(c);      // checked by the caller right after (MAKE_TABLES)
     c->cur_host = -1;
     return make_tables_raw(c, pl);
 }
+#define MAKE_TABLES(T, c, pl) DeviceTables T = make_tables((c), (pl)); VIOCHK((c)->flush_status)
 
 vio_status read_lm(vio_ctx *c) {
     VIOCHK(flush_decide(c));
@@ -477,16 +604,18 @@ vio_status pull_from_device(vio_ctx *c) {
     const int cur = c->h_lm.cur;
     HIPCHK(hipMemcpyAsync(c->h_state, c->d_state.p + cur * STATE_STRIDE, STATE_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
     Plan &pl = c->solve_plan;
-    std::vector<double> tmp((size_t)std::max<int64_t>(pl.Ns, 1));
+    const size_t ld = (size_t)pl.lm_dim;
+    std::vector<double> tmp(ld * (size_t)std::max<int64_t>(pl.Ns, 1));
     if (pl.valid && pl.Ns)
-        HIPCHK(hipMemcpyAsync(tmp.data(), pl.d_invd.p + (size_t)cur * pl.Ns, (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(tmp.data(), pl.d_invd.p + (size_t)cur * ld * pl.Ns, ld * (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
     if (c->has_prior) {
         HIPCHK(hipMemcpyAsync(c->h_bprior.data(), c->d_bprior.p + cur * 176, PD * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_errprior.data(), c->d_errprior.p + cur * 160, PRD * 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     if (pl.valid)
-        for (int64_t s = 0; s < pl.Ns; ++s) c->h_invd[pl.sorted_to_orig[s]] = tmp[s];
+        for (int64_t s = 0; s < pl.Ns; ++s)
+            for (size_t k = 0; k < ld; ++k) c->h_invd[ld * pl.sorted_to_orig[s] + k] = tmp[k * pl.Ns + s];      // device: coordinate-major
     c->device_ahead = false;
     return VIO_OK;
 }
@@ -495,9 +624,11 @@ vio_status pull_from_device(vio_ctx *c) {
 vio_status push_to_device(vio_ctx *c, Plan &pl) {
     hipStream_t st = c->stream;
     HIPCHK(hipMemcpyAsync(c->d_state.p, c->h_state, STATE_STRIDE * 8, hipMemcpyHostToDevice, st));
-    std::vector<double> tmp((size_t)std::max<int64_t>(pl.Ns, 1));
-    for (int64_t s = 0; s < pl.Ns; ++s) tmp[s] = c->h_invd[pl.sorted_to_orig[s]];
-    if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_invd.p, tmp.data(), (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
+    const size_t ld = (size_t)pl.lm_dim;
+    std::vector<double> tmp(ld * (size_t)std::max<int64_t>(pl.Ns, 1));
+    for (int64_t s = 0; s < pl.Ns; ++s)
+        for (size_t k = 0; k < ld; ++k) tmp[k * pl.Ns + s] = c->h_invd[ld * pl.sorted_to_orig[s] + k];
+    if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_invd.p, tmp.data(), ld * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_pre.p, c->h_pre.data(), VIO_WINDOW_SIZE * PRE_STRIDE * 8, hipMemcpyHostToDevice, st));
     int32_t iv[16] = {0};
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) iv[k] = c->imu_valid[k] ? 1 : 0;
@@ -614,11 +745,12 @@ vio_status run_exchange(vio_ctx *c, int which) {
 // gate != 0: one slot of vio_solve's device-driven loop (the kernels skip themselves when it is not their turn)
 vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0) {
     DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
+    if (!gn) VIOCHK(c->flush_status);
     T.lm_gate = gate;
     const bool test_prev = gn && c->decide_pending;
     if (gn) T.cur_hint = c->cur_host;
     if (test_prev) T.gn_flags = 2;
-    if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
+    if (!c->pairtab_valid && pl.lm_dim == 1) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
     { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
     // with a prior, the previous GN step left err_prior to this k_reduce (k_pose_solve wrote b_prior' only)
     const bool err_prev = test_prev && T.has_prior;
@@ -650,6 +782,7 @@ vio_status enqueue_init_lm(vio_ctx *c, const DeviceTables &T, int max_iter) {
 
 vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int gate = 0) {
     DeviceTables T = gn ? make_tables_raw(c, pl) : make_tables(c, pl);
+    if (!gn) VIOCHK(c->flush_status);
     T.lm_gate = gate;
     T.gn_flags = 4;         // bit 2: k_pose_solve leaves the prior update to the kernels that follow (all paths now)
     if (gn) T.cur_hint = c->cur_host;      // GN: the update rides with the next k_linearize / k_reduce (or with flush_decide)
@@ -751,6 +884,7 @@ const char *vio_last_error(const vio_ctx *c) { return c ? c->err.c_str() : "null
 
 vio_status vio_set_window(vio_ctx *c, const double *poses, const double *sb, const double *ext) {
     if (!c || !poses || !sb || !ext) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     VIOCHK(pull_from_device(c));
     std::memcpy(c->h_state + STATE_EXT, ext, 7 * 8);
     std::memcpy(c->h_state + STATE_POSE, poses, 77 * 8);
@@ -759,12 +893,14 @@ vio_status vio_set_window(vio_ctx *c, const double *poses, const double *sb, con
     return VIO_OK;
 }
 
-vio_status vio_set_landmarks(vio_ctx *c, int64_t n, const double *invd) {
-    if (!c || n < 0 || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+static vio_status set_landmarks_dim(vio_ctx *c, int64_t n, const double *val, int dim) {
+    if (!c || n < 0 || (n > 0 && !val)) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     VIOCHK(pull_from_device(c));
-    const bool resized = (int64_t)c->h_invd.size() != n;
-    c->h_invd.assign(invd, invd + n);
-    if (resized) {      // the observation list refers to landmark indices: it must be set again
+    const bool resized = (int64_t)c->h_invd.size() != n * dim || c->lm_dim != dim;
+    c->h_invd.assign(val, val + n * dim);
+    c->lm_dim = dim;
+    if (resized) {      // the observation list refers to landmark indices (of this kind): it must be set again
         c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear();
         c->topo_dirty = true;
     }
@@ -772,9 +908,28 @@ vio_status vio_set_landmarks(vio_ctx *c, int64_t n, const double *invd) {
     return VIO_OK;
 }
 
+vio_status vio_set_landmarks(vio_ctx *c, int64_t n, const double *invd) { return set_landmarks_dim(c, n, invd, 1); }
+vio_status vio_set_landmarks_xyz(vio_ctx *c, int64_t n, const double *xyz) { return set_landmarks_dim(c, n, xyz, 3); }
+
+vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, const int32_t *frame, const double *pts) {
+    if (!c || m < 0 || (m > 0 && (!lm || !frame || !pts))) return VIO_ERR_BAD_ARG;
+    if (c->lm_dim != 3) return fail(c, VIO_ERR_BAD_ARG, "vio_set_observations_xyz needs vio_set_landmarks_xyz first");
+    const int64_t N = (int64_t)c->h_invd.size() / 3;
+    for (int64_t e = 0; e < m; ++e)
+        if (lm[e] < 0 || lm[e] >= N || frame[e] < 0 || frame[e] >= NF)
+            return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
+    VIOCHK(pull_from_device(c));
+    c->h_olm.assign(lm, lm + m); c->h_otarget.assign(frame, frame + m); c->h_ohost.assign((size_t)m, 0);
+    c->h_pts_j.assign(pts, pts + 2 * m); c->h_pts_i.assign(2 * (size_t)m, 0.0);
+    c->topo_dirty = true;
+    c->dirty_inputs = true;
+    return VIO_OK;
+}
+
 vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target,
                                 const double *pi, const double *pj) {
     if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
+    if (c->lm_dim == 3) return fail(c, VIO_ERR_BAD_ARG, "the context holds XYZ landmarks: use vio_set_observations_xyz");
     const int64_t N = (int64_t)c->h_invd.size();
     for (int64_t e = 0; e < m; ++e)
         if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
@@ -789,6 +944,7 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
 
 vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
     if (!c || k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     VIOCHK(pull_from_device(c));
     c->imu_valid[k] = pre != nullptr;
     double *o = c->h_pre.data() + (size_t)k * PRE_STRIDE;
@@ -806,6 +962,7 @@ vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
 vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double *b, const double *err, const double *jt) {
     if (!c || (dim != 0 && dim != PRD)) return VIO_ERR_BAD_ARG;
     if (dim && (!H || !b || !err || !jt)) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     VIOCHK(pull_from_device(c));
     std::fill(c->h_Hprior.begin(), c->h_Hprior.end(), 0.0); std::fill(c->h_bprior.begin(), c->h_bprior.end(), 0.0);
     std::fill(c->h_errprior.begin(), c->h_errprior.end(), 0.0); std::fill(c->h_Jtinv.begin(), c->h_Jtinv.end(), 0.0);
@@ -830,7 +987,8 @@ vio_status vio_linearize(vio_ctx *c) {
 
 vio_status vio_init_lm(vio_ctx *c, double *chi2, double *lambda) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
-    DeviceTables T = make_tables(c, *c->active);
+    hipSetDevice(c->cfg.device);
+    MAKE_TABLES(T, c, *c->active);
     VIOCHK(enqueue_init_lm(c, T, 1 << 30));
     VIOCHK(read_lm(c));
     if (chi2) *chi2 = c->h_lm.chi;
@@ -840,8 +998,9 @@ vio_status vio_init_lm(vio_ctx *c, double *chi2, double *lambda) {
 
 vio_status vio_solve_linear(vio_ctx *c, double lambda) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     Plan &pl = *c->active;
-    DeviceTables T = make_tables(c, pl);
+    MAKE_TABLES(T, c, pl);
     vio_launch_set_lambda(c->d_lm.p, lambda, c->stream);
     vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream);
     vio_launch_backsub(T, 0, c->stream);
@@ -852,12 +1011,14 @@ vio_status vio_solve_linear(vio_ctx *c, double lambda) {
 
 vio_status vio_update_states(vio_ctx *c) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     if (!c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = true; c->device_ahead = true; }
     return VIO_OK;
 }
 
 vio_status vio_rollback_states(vio_ctx *c) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     if (c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = false; c->device_ahead = true; }
     return VIO_OK;
 }
@@ -867,9 +1028,9 @@ vio_status vio_chi2(vio_ctx *c, double *chi2) {
     hipSetDevice(c->cfg.device);
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = *c->active;
-    DeviceTables T = make_tables(c, pl);
+    MAKE_TABLES(T, c, pl);
     // the chi2 kernels read the pair table of the current state; after a stepwise update it is the trial table
-    if (!c->pairtab_valid) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
+    if (!c->pairtab_valid && pl.lm_dim == 1) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
     vio_launch_backsub(T, 1, c->stream);
     if (sharded(c)) { vio_launch_step_sum(T, 2, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 2, 0, c->stream); }
     else vio_launch_lm_decide(T, 2, 1, c->stream);
@@ -880,8 +1041,9 @@ vio_status vio_chi2(vio_ctx *c, double *chi2) {
 
 vio_status vio_eval_step(vio_ctx *c, int32_t *accepted, double *chi2, double *lambda) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     Plan &pl = *c->active;
-    DeviceTables T = make_tables(c, pl);
+    MAKE_TABLES(T, c, pl);
     // the decide kernel expects the trial copy to be "the other one"
     if (c->stepwise_updated) vio_launch_flip(c->d_lm.p, c->stream);
     if (sharded(c)) { vio_launch_step_sum(T, 0, c->stream); VIOCHK(run_exchange(c, 1)); vio_launch_lm_decide(T, 0, 0, c->stream); }
@@ -909,17 +1071,21 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
     const auto t0 = std::chrono::steady_clock::now();
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = c->solve_plan;
-    hipEvent_t ev0, ev1;
-    HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
-    HIPCHK(hipEventRecord(ev0, c->stream));
-    VIOCHK(enqueue_linearize(c, pl));
-    HIPCHK(hipEventRecord(ev1, c->stream));
-    DeviceTables T = make_tables(c, pl);
-    VIOCHK(enqueue_init_lm(c, T, iterations));
-    VIOCHK(read_lm(c));
     float first_lin_ms = 0;
-    hipEventElapsedTime(&first_lin_ms, ev0, ev1);
-    hipEventDestroy(ev0); hipEventDestroy(ev1);
+    {
+        struct EventPair {      // destroyed on every way out
+            hipEvent_t a = nullptr, b = nullptr;
+            ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+        } ev;
+        HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
+        HIPCHK(hipEventRecord(ev.a, c->stream));
+        VIOCHK(enqueue_linearize(c, pl));
+        HIPCHK(hipEventRecord(ev.b, c->stream));
+        MAKE_TABLES(T, c, pl);
+        VIOCHK(enqueue_init_lm(c, T, iterations));
+        VIOCHK(read_lm(c));
+        hipEventElapsedTime(&first_lin_ms, ev.a, ev.b);
+    }
     vio_solve_report r;
     std::memset(&r, 0, sizeof(r));
     r.initial_chi2 = c->h_lm.chi;
@@ -930,7 +1096,8 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
         // batch; the kernels of a slot gate themselves (a rejected trial skips its re-linearisation, everything after
         // the stop skips itself).  When every trial is accepted - the usual case - that is one read-back per solve.
         while (status == VIO_OK && !c->h_lm.stop && c->h_lm.iter < iterations) {
-            const int batch = iterations - c->h_lm.iter;
+            // (at most 10 slots ahead: a loop that stops early leaves the rest as empty launches, ~20 us each)
+            const int batch = std::min(iterations - c->h_lm.iter, 10);
             for (int sl = 0; sl < batch && status == VIO_OK; ++sl) {
                 status = enqueue_trial(c, pl, 0, false, 2);
                 if (status == VIO_OK) status = enqueue_linearize(c, pl, false, 3);
@@ -968,18 +1135,23 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
 
 vio_status vio_gn_iteration(vio_ctx *c, double lambda) {
     if (!c) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = c->solve_plan;
-    const bool gn = true;       // chi2 and the gain-ratio partial of a step reach its test through vis: one exchange per iteration
+    // chi2 and the gain-ratio partial of a step reach its test through vis: one exchange per iteration.  XYZ landmarks take
+    // the classic sequence (k_pose_solve -> k_backsub_xyz -> k_lm_decide): k_linearize_xyz has no deferred head yet.
+    const bool gn = c->lm_dim == 1;
     if (gn && c->cur_host < 0) VIOCHK(read_lm(c));      // once: from here on the host tracks LmState.cur itself
     if (lambda != c->gn_lambda) { vio_launch_set_lambda(c->d_lm.p, lambda, c->stream); c->gn_lambda = lambda; }
     VIOCHK(enqueue_linearize(c, pl, gn));
     VIOCHK(enqueue_trial(c, pl, 1, gn));
+    if (!gn) c->cur_host = -1;
     return VIO_OK;
 }
 
 vio_status vio_synchronize(vio_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     HIPCHK(hipStreamSynchronize(c->stream));
     return VIO_OK;
 }
@@ -988,6 +1160,7 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
     if (!c || !H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
+    if (kind == VIO_MARG_OLD && c->lm_dim == 3) return fail(c, VIO_ERR_UNSUPPORTED, "MargOldFrame is not defined for XYZ landmarks (include/vio_backend.h)");
     std::vector<double> Hm((size_t)PD * PD), bm(PD);
     if (kind == VIO_MARG_OLD) {
         VIOCHK(activate(c, c->marg_plan, 1));
@@ -1008,6 +1181,7 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
 
 vio_status vio_get_window(vio_ctx *c, double *poses, double *sb, double *ext) {
     if (!c) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     VIOCHK(pull_from_device(c));
     if (ext) std::memcpy(ext, c->h_state + STATE_EXT, 7 * 8);
     if (poses) std::memcpy(poses, c->h_state + STATE_POSE, 77 * 8);
@@ -1016,14 +1190,22 @@ vio_status vio_get_window(vio_ctx *c, double *poses, double *sb, double *ext) {
 }
 
 vio_status vio_get_landmarks(vio_ctx *c, int64_t n, double *invd) {
-    if (!c || n != (int64_t)c->h_invd.size() || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+    if (!c || c->lm_dim != 1 || n != (int64_t)c->h_invd.size() || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
     VIOCHK(pull_from_device(c));
     if (n) std::memcpy(invd, c->h_invd.data(), (size_t)n * 8);
     return VIO_OK;
 }
 
+vio_status vio_get_landmarks_xyz(vio_ctx *c, int64_t n, double *xyz) {
+    if (!c || c->lm_dim != 3 || 3 * n != (int64_t)c->h_invd.size() || (n > 0 && !xyz)) return VIO_ERR_BAD_ARG;
+    VIOCHK(pull_from_device(c));
+    if (n) std::memcpy(xyz, c->h_invd.data(), (size_t)n * 24);
+    return VIO_OK;
+}
+
 vio_status vio_get_prior(vio_ctx *c, double *b, double *err) {
     if (!c) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     VIOCHK(pull_from_device(c));
     if (b) std::memcpy(b, c->h_bprior.data(), PD * 8);
     if (err) std::memcpy(err, c->h_errprior.data(), PRD * 8);
@@ -1032,24 +1214,29 @@ vio_status vio_get_prior(vio_ctx *c, double *b, double *err) {
 
 vio_status vio_get_delta(vio_ctx *c, double *dxp, int64_t n, double *dxl) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
-    if (dxl && n != (int64_t)c->h_invd.size()) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
+    const size_t ld = (size_t)c->lm_dim;
+    if (dxl && n * (int64_t)ld != (int64_t)c->h_invd.size()) return VIO_ERR_BAD_ARG;
+    VIOCHK(flush_decide(c));        // a GN step's landmark update is owed until somebody asks (or the next linearisation)
     Plan &pl = *c->active;
     if (dxp) HIPCHK(hipMemcpyAsync(dxp, c->d_dx.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
-    std::vector<double> tmp((size_t)std::max<int64_t>(pl.Ns, 1));
-    if (dxl && pl.Ns) HIPCHK(hipMemcpyAsync(tmp.data(), pl.d_dxl.p, (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> tmp(ld * (size_t)std::max<int64_t>(pl.Ns, 1));
+    if (dxl && pl.Ns) HIPCHK(hipMemcpyAsync(tmp.data(), pl.d_dxl.p, ld * (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (dxl) {
-        for (int64_t l = 0; l < n; ++l) dxl[l] = 0.0;
-        for (int64_t s = 0; s < pl.Ns; ++s) dxl[pl.sorted_to_orig[s]] = tmp[s];
+        for (int64_t l = 0; l < n * (int64_t)ld; ++l) dxl[l] = 0.0;
+        for (int64_t s = 0; s < pl.Ns; ++s)
+            for (size_t k = 0; k < ld; ++k) dxl[ld * pl.sorted_to_orig[s] + k] = tmp[k * pl.Ns + s];
     }
     return VIO_OK;
 }
 
 vio_status vio_get_schur_system(vio_ctx *c, double *H, double *b) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     if (H && !c->natural_hs_valid) {            // the solve path keeps only the permuted packed copy: assemble once more
         c->want_natural_hs = true;
-        DeviceTables T = make_tables(c, *c->active);
+        MAKE_TABLES(T, c, *c->active);
         vio_launch_assemble(T, c->stream);
         c->want_natural_hs = false;
         c->natural_hs_valid = true;
@@ -1061,11 +1248,25 @@ vio_status vio_get_schur_system(vio_ctx *c, double *H, double *b) {
 }
 
 vio_status vio_get_landmark_system(vio_ctx *c, int64_t n, double *hll, double *bl) {
-    if (!c || !c->linearized || n != (int64_t)c->h_invd.size()) return VIO_ERR_BAD_ARG;
+    if (!c || !c->linearized || n * c->lm_dim != (int64_t)c->h_invd.size()) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
+    VIOCHK(flush_decide(c));
     Plan &pl = *c->active;
     std::vector<double> lw(std::max<size_t>(pl.lw_doubles, 1));
     if (pl.lw_doubles) HIPCHK(hipMemcpyAsync(lw.data(), pl.d_lw.p, pl.lw_doubles * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (pl.lm_dim == 3) {       // H_ll as 3x3 row-major from its 6 distinct entries, b_l (3)
+        for (int64_t l = 0; l < n; ++l) { if (hll) for (int k = 0; k < 9; ++k) hll[9 * l + k] = 0; if (bl) for (int k = 0; k < 3; ++k) bl[3 * l + k] = 0; }
+        static const int sym[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+        for (const ItemDesc &it : pl.items)
+            for (int g = 0; g < it.G; ++g) {
+                const int32_t l = pl.sorted_to_orig[it.lm_base + g];
+                const size_t f0 = (size_t)it.lw_base + (size_t)(18 * it.nb) * it.G + g;
+                if (hll) for (int k = 0; k < 9; ++k) hll[9 * l + k] = lw[f0 + (size_t)sym[k] * it.G];
+                if (bl) for (int k = 0; k < 3; ++k) bl[3 * l + k] = lw[f0 + (size_t)(6 + k) * it.G];
+            }
+        return VIO_OK;
+    }
     for (int64_t l = 0; l < n; ++l) { if (hll) hll[l] = 0; if (bl) bl[l] = 0; }
     for (const ItemDesc &it : pl.items)
         for (int g = 0; g < it.G; ++g) {
@@ -1078,6 +1279,7 @@ vio_status vio_get_landmark_system(vio_ctx *c, int64_t n, double *hll, double *b
 
 vio_status vio_get_pose_gradient(vio_ctx *c, double *b, double *diag) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
+    hipSetDevice(c->cfg.device);
     if (b) HIPCHK(hipMemcpyAsync(b, c->d_bfull.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
     if (diag) HIPCHK(hipMemcpyAsync(diag, c->d_diagfull.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -1667,6 +1667,30 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
 // Blocks >= n_items evaluate the IMU chi2.
 // ---------------------------------------------------------------------------------------------------------
 #define BS_THREADS 128      // one thread per landmark of the item (G <= 128)
+// workgroup b >= n_items of a back-substitution grid: r^T Info r of IMU edge b - n_items at state copy `which`
+__device__ void d_backsub_imu_block(const DeviceTables &T, int mode, int which, int b, int lane) {
+    const int k = b - T.n_items;
+    if (lane != 0) return;
+    double chi = 0.0;
+    if (T.imu_valid[k]) {
+        const double *st = T.state + which * STATE_STRIDE;
+        const double *pre = T.pre + k * PRE_STRIDE;
+        const double *pi = st + STATE_POSE + 7 * k, *pj = pi + 7, *si = st + STATE_SB + 9 * k, *sj = si + 9;
+        ImuCommon c;
+        d_imu_common(pre, pi, si, pj, c);
+        double r[15];
+        d_imu_residual(pre, T.gravity, pi, si, pj, sj, c, r);
+        for (int i = 0; i < 15; ++i) {
+            double t = 0;
+            for (int j = 0; j < 15; ++j) t += pre[PRE_INFO + 15 * i + j] * r[j];
+            chi += r[i] * t;
+        }
+    }
+    double *part = (mode == 1) ? T.chi_part : T.step_part;
+    part[2 * b + STEP_CHI] = chi;
+    part[2 * b + STEP_SCALE] = 0.0;
+}
+
 __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const LmState *lm = T.lm;
@@ -1675,30 +1699,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
     const int which = (mode == 1) ? cur : (cur ^ 1);
     // flush of a GN step (gn_flags bit 3): its b_prior' rows, which the next k_linearize would have formed
     if ((T.gn_flags & 8) && T.has_prior && (lane >> 6) == 1) d_bprior_rows(T, cur, cur ^ 1, b, gridDim.x, lane & 63);
-    if (b >= T.n_items) {
-        const int k = b - T.n_items;
-        if (lane == 0) {
-            double chi = 0.0;
-            if (T.imu_valid[k]) {
-                const double *st = T.state + which * STATE_STRIDE;
-                const double *pre = T.pre + k * PRE_STRIDE;
-                const double *pi = st + STATE_POSE + 7 * k, *pj = pi + 7, *si = st + STATE_SB + 9 * k, *sj = si + 9;
-                ImuCommon c;
-                d_imu_common(pre, pi, si, pj, c);
-                double r[15];
-                d_imu_residual(pre, T.gravity, pi, si, pj, sj, c, r);
-                for (int i = 0; i < 15; ++i) {
-                    double t = 0;
-                    for (int j = 0; j < 15; ++j) t += pre[PRE_INFO + 15 * i + j] * r[j];
-                    chi += r[i] * t;
-                }
-            }
-            double *part = (mode == 1) ? T.chi_part : T.step_part;
-            part[2 * b + STEP_CHI] = chi;
-            part[2 * b + STEP_SCALE] = 0.0;
-        }
-        return;
-    }
+    if (b >= T.n_items) { d_backsub_imu_block(T, mode, which, b, lane); return; }
     __shared__ double sPairCD[VIO_MAXK * 12];
     __shared__ double sDxp[176];
     __shared__ ItemDesc sIt;
@@ -1996,6 +1997,8 @@ __global__ __launch_bounds__(256) void k_triangulate(TriTables Q) {
     Q.depth[i] = dep;
 }
 
+#include "vio_kernels_xyz.h"
+
 void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
     hipLaunchKernelGGL(k_triangulate, dim3((unsigned)((Q.n + 255) / 256)), dim3(256), 0, s, Q);
 }
@@ -2005,7 +2008,8 @@ void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(128), 0, s, T); }
 void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
+    if (T.lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
+    else hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1 + (R.errprior ? RED_ERR_BLOCKS : 0)), dim3(RED_THREADS), 0, s, R);
@@ -2024,7 +2028,8 @@ void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t 
     hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
 }
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s) {
-    hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(BS_THREADS), 0, s, T, mode);
+    if (T.lm_dim == 3) hipLaunchKernelGGL(k_backsub_xyz, dim3(T.n_items + T.n_imu_items), dim3(BS_THREADS), 0, s, T, mode);
+    else hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(BS_THREADS), 0, s, T, mode);
 }
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s) { hipLaunchKernelGGL(k_step_sum, dim3(1), dim3(256), 0, s, T, mode); }
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s) {
@@ -2046,8 +2051,10 @@ void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext) {
     return lin_lds_doubles(G, K, nb, use_ext);
 }
+int xyz_lds_doubles_host(int G, int K) { return xyz_lds_doubles(G, K); }
 int vio_set_kernel_attributes() {
     hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     hipError_t e2 = hipFuncSetAttribute((const void *)k_pose_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : -1;
+    hipError_t e3 = hipFuncSetAttribute((const void *)k_linearize_xyz, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -1;
 }

@@ -1,0 +1,479 @@
+// vio_kernels_xyz.h — the XYZ-landmark variants of the per-item kernels (included by vio_kernels.hip).
+//
+// Landmarks are world points (VertexPointXYZ, VM/include/backend/vertex_point_xyz.h:16) observed through
+// EdgeReprojectionXYZ (VM/src/backend/edge_reprojection.cc:130-180): vertices (landmark, pose), the camera extrinsic a
+// constant of the edge.  Every landmark owns a 3x3 block of Hmm, inverted without damping (problem.cc:419-425), three
+// columns of Hpm per observing pose, and its Schur term is  Hpm Hmm^-1 Hmp = W H^-1 W^T  with W (6K x 3).
+//
+//   k_linearize_xyz   one workgroup of 1024 threads per item = up to G landmarks seen from the same K frames
+//     phase 0    thread k < K: the frame's camera map  p_c = A_k p_w + d_k,  A_k = ric^T R_k^T,  d_k = -ric^T (R_k^T P_k + tic)
+//     phase 1    thread per observation: residual, J_feature (2x3), J_pose (2x6), robust weight; the whitened pose rows
+//                L J_pose go to sRows (the operand of the direct products), W_k = (L J_pose)^T (L J_feature) and the pose
+//                part of b straight to the landmark record, the observation's terms of H_ll and b_l to sAux
+//     phase 1.5  thread per landmark: H_ll, b_l, H_ll^-1 (partial-pivot LU, as Eigen's dynamic-size inverse());
+//                then thread per (landmark, k): Y_k = W_k H_ll^-1
+//     phase 2    fp64 MFMA tiles: the direct blocks C_k = sum_g (L J_pose)^T (L J_pose), two observation indices per 16x16
+//                tile, and the lower tiles of the Schur term - sum_g W_g Y_g^T over the 6K pattern columns: the matrix
+//                core's k index runs over (landmark, coordinate), 4 landmarks per step, 3 passes (one per coordinate)
+//     combine    thread per slab element, same slab layout as k_linearize (k_reduce and k_assemble are shared)
+//   k_backsub_xyz     delta_l = H_ll^-1 (b_l - W^T dx_pose) (problem.cc:445), trial points, chi2 of the trial state
+//
+// HBM layout differences to the inverse-depth plan: invd[2][3][Ns] holds the points coordinate-major, dxl[3][Ns],
+// lw per item = (18 nb + 9) fields x G: W (18 nb), the 6 distinct entries of H_ll, b_l (3).
+#ifndef VIO_KERNELS_XYZ_H
+#define VIO_KERNELS_XYZ_H
+
+__host__ __device__ inline int xyz_lrec(int nb) { return 42 * nb + 19; }       // W 18nb | Y 18nb | b_pose 6nb | H 6 | Hinv 9 | b_l 3 (+1: odd stride)
+__host__ __device__ inline int xyz_ntd(int K) { return (K + 1) >> 1; }         // direct tiles: two observation indices each
+__host__ __device__ inline int xyz_plane(int G) { return G * 24 + 8; }
+__host__ __device__ inline int xyz_tiles(int K) { const int ts = (6 * K + 15) >> 4; return xyz_ntd(K) + ts * (ts + 1) / 2; }
+#define XYZ_FRAME_TAB (VIO_NF * 12 + 16)        // A_k (9), d_k (3) per frame, then ric (9), tic (3)
+__host__ __device__ inline int xyz_lds_doubles(int G, int K) {
+    int aux = G * K * 9, part = xyz_tiles(K) * 256 + 2 * 6 * K * LIN_VS;
+    int shared = aux > part ? aux : part;
+    shared = (shared + 1) & ~1;
+    return XYZ_FRAME_TAB + 3 * (LIN_THREADS / 64) + xyz_ntd(K) * xyz_plane(G) + G * xyz_lrec(K) + shared;
+}
+
+// Hmm.block(idx, idx, 3, 3).inverse() the way Eigen evaluates it for a block of a dynamic matrix: PartialPivLU
+// (first largest |entry| of the column, the column divided by the pivot, rank-1 update), then P * I through the unit-lower
+// and the upper triangular solves, the diagonal applied as a multiplication by its reciprocal.  Row-major.
+__device__ __forceinline__ void d_inverse3(const double *A, double *X) {
+    double lu[9];
+    int piv[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) lu[k] = A[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int best = k;
+        double big = fabs(lu[3 * k + k]);
+#pragma unroll
+        for (int i = k + 1; i < 3; ++i) if (fabs(lu[3 * i + k]) > big) { big = fabs(lu[3 * i + k]); best = i; }
+        piv[k] = best;
+        if (big != 0.0) {
+            if (best != k) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    // (selects, not run-time indices: lu stays in registers)
+                    const double rk = lu[3 * k + j];
+                    const double rb = (best == 1) ? lu[3 + j] : lu[6 + j];
+                    lu[3 * k + j] = rb;
+                    if (best == 1) lu[3 + j] = rk; else lu[6 + j] = rk;
+                }
+            }
+#pragma unroll
+            for (int i = k + 1; i < 3; ++i) lu[3 * i + k] /= lu[3 * k + k];
+        }
+#pragma unroll
+        for (int i = k + 1; i < 3; ++i)
+#pragma unroll
+            for (int j = k + 1; j < 3; ++j) lu[3 * i + j] -= lu[3 * i + k] * lu[3 * k + j];
+    }
+    double Xr[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (piv[k] != k) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double rk = Xr[3 * k + j];
+                const double rb = (piv[k] == 1) ? Xr[3 + j] : Xr[6 + j];
+                Xr[3 * k + j] = rb;
+                if (piv[k] == 1) Xr[3 + j] = rk; else Xr[6 + j] = rk;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double b = Xr[3 * i + j];
+#pragma unroll
+            for (int r = i + 1; r < 3; ++r) Xr[3 * r + j] -= b * lu[3 * r + i];
+        }
+#pragma unroll
+        for (int i = 2; i >= 0; --i) {
+            const double a = 1.0 / lu[3 * i + i];
+            const double b = (Xr[3 * i + j] *= a);
+#pragma unroll
+            for (int r = 0; r < i; ++r) Xr[3 * r + j] -= b * lu[3 * r + i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) X[k] = Xr[k];
+}
+
+// camera map of frame f at the state `st`: out[0..8] = A = ric^T R_f^T, out[9..11] = d = -ric^T (R_f^T P_f + tic)
+__device__ __forceinline__ void d_xyz_frame(const double *st, int f, const double *ric, double *out) {
+    double Rf[9], M[9], u[3], w[3];
+    d_quat_to_R(st + STATE_POSE + 7 * f + 3, Rf);
+    d_m3_mul(Rf, ric, M);                                   // A = (R_f ric)^T
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = M[3 * j + i];
+    d_m3_tvec(Rf, st + STATE_POSE + 7 * f, u);              // R_f^T P_f
+#pragma unroll
+    for (int k = 0; k < 3; ++k) u[k] += st[STATE_EXT + k];
+    d_m3_tvec(ric, u, w);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[9 + k] = -w[k];
+}
+
+__global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (d_gated_off(T.lm, T.lm_gate)) return;
+    if (b >= T.n_items) {
+        d_imu_item(T, b - T.n_items, dyn_smem);
+        return;
+    }
+    __shared__ ItemDesc sIt;
+    const int cur = d_cur(T);
+    if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
+    __syncthreads();
+    const ItemDesc &it = sIt;
+    const int G = it.G, K = it.K, nb = it.nb;              // nb == K: one pattern block per observing frame
+    const int LREC = xyz_lrec(nb), PLANE = xyz_plane(G), NTD = xyz_ntd(K);
+    const int offW = 0, offY = 18 * nb, offBP = 36 * nb, offH = 42 * nb, offHI = 42 * nb + 6, offBL = 42 * nb + 15;
+
+    double *sFr = dyn_smem;                                // [11][12] camera maps of the item's frames (indexed by k), then ric, tic
+    double *sCam = sFr + VIO_NF * 12;
+    double *sRed = sFr + XYZ_FRAME_TAB;                    // 3 * waves
+    double *sRows = sRed + 3 * (LIN_THREADS / 64);         // NTD planes of G x 24
+    double *sL = sRows + NTD * PLANE;                      // G * LREC
+    double *sAux = sL + G * LREC;                          // G*K*9, dead after phase 1.5 ...
+    double *sTile = sAux;                                  // ... then the tiles and the vector partials
+
+    const double *st = T.state + cur * STATE_STRIDE;
+    const double *xyz = T.invd + (size_t)cur * 3 * T.Ns + it.lm_base;
+    const double *pts = T.pts_j + 2 * (size_t)it.obs_base;
+    // phase 0: camera maps
+    if (tid < K) {
+        double ric[9], o[12];
+        d_quat_to_R(st + STATE_EXT + 3, ric);
+        d_xyz_frame(st, it.cam_block[tid] - 1, ric, o);          // K may be 11: the frame comes from cam_block, not target[10]
+#pragma unroll
+        for (int k = 0; k < 12; ++k) sFr[12 * tid + k] = o[k];
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sCam[k] = ric[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sCam[9 + k] = st[STATE_EXT + k];
+        }
+    }
+    // an odd K leaves the second half of the last plane unused: the direct products read it, so it holds zeros
+    if (K & 1) for (int e = tid; e < G * 12; e += LIN_THREADS) sRows[(NTD - 1) * PLANE + (e / 12) * 24 + 12 + e % 12] = 0.0;
+    __syncthreads();
+
+    const double s_info = T.sqrt_info, info = s_info * s_info;
+    const double *ric = sCam, *tic = sCam + 9;
+
+    // ---------------- phase 1: thread per observation ----------------
+    double chi_acc = 0.0;
+    for (int o = tid; o < G * K; o += LIN_THREADS) {
+        const int k = o / G, g = o - k * G;
+        const double *A = sFr + 12 * k;
+        const double pw[3] = {xyz[g], xyz[(size_t)T.Ns + g], xyz[2 * (size_t)T.Ns + g]};
+        const double u = pts[2 * o], v = pts[2 * o + 1];
+        double pc[3], pim[3];
+        d_m3_vec(A, pw, pc);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) pc[m] += A[9 + m];
+        d_m3_vec(ric, pc, pim);                             // pts_imu_i = ric p_c + tic
+#pragma unroll
+        for (int m = 0; m < 3; ++m) pim[m] += tic[m];
+        const double iz = 1.0 / pc[2];
+        const double r0 = pc[0] * iz - u, r1 = pc[1] * iz - v;
+        const double ra = -pc[0] * (iz * iz), rb = -pc[1] * (iz * iz);        // reduce = [iz 0 ra; 0 iz rb]
+        double Jf0[3], Jf1[3], RR0[3], RR1[3], Jp0[6], Jp1[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            Jf0[c] = iz * A[c] + ra * A[6 + c];             // jacobian_feature = reduce * ric^T * Ri^T
+            Jf1[c] = iz * A[3 + c] + rb * A[6 + c];
+            RR0[c] = iz * ric[3 * c] + ra * ric[3 * c + 2]; // reduce * ric^T
+            RR1[c] = iz * ric[3 * c + 1] + rb * ric[3 * c + 2];
+            Jp0[c] = -Jf0[c]; Jp1[c] = -Jf1[c];             // reduce * ric^T * -Ri^T
+        }
+        // reduce * ric^T * hat(pts_imu_i): row * hat(v) = row x v
+        Jp0[3] = RR0[1] * pim[2] - RR0[2] * pim[1]; Jp0[4] = RR0[2] * pim[0] - RR0[0] * pim[2]; Jp0[5] = RR0[0] * pim[1] - RR0[1] * pim[0];
+        Jp1[3] = RR1[1] * pim[2] - RR1[2] * pim[1]; Jp1[4] = RR1[2] * pim[0] - RR1[0] * pim[2]; Jp1[5] = RR1[0] * pim[1] - RR1[1] * pim[0];
+
+        // robust weight: Edge::RobustInfo (edge.cc:48-74) with information = s^2 I — as k_linearize
+        const double e2 = r0 * (info * r0) + r1 * (info * r1);
+        double rho0, rho1, rho2;
+        d_loss(T.loss_type, T.loss_delta, e2, rho0, rho1, rho2);
+        chi_acc += (T.loss_type == 0) ? e2 : rho0;
+        double lam2 = rho1;
+        if (T.loss_type != 0 && rho1 + 2 * rho2 * e2 > 0.) lam2 = rho1 + 2 * rho2 * e2;
+        const double al = sqrt(rho1), be = sqrt(fmax(lam2, 0.0));
+        const double rn2 = r0 * r0 + r1 * r1;
+        const double irn2 = rn2 > 0 ? 1.0 / rn2 : 0.0;
+        const double gm = (be - al) * irn2;
+        const double L00 = s_info * (al + gm * r0 * r0), L01 = s_info * (gm * r0 * r1), L11 = s_info * (al + gm * r1 * r1);
+        const double c0 = rho1 * (info * r0), c1 = rho1 * (info * r1);         // drho * Information * residual
+
+        double lf0[3], lf1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lf0[c] = L00 * Jf0[c] + L01 * Jf1[c]; lf1[c] = L01 * Jf0[c] + L11 * Jf1[c]; }
+        double *rec = sRows + (k >> 1) * PLANE + g * 24 + (k & 1) * 12;
+        double *Lg = sL + (size_t)g * LREC;
+        double *pk = sAux + (size_t)o * 9;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double lp0 = L00 * Jp0[i] + L01 * Jp1[i], lp1 = L01 * Jp0[i] + L11 * Jp1[i];
+            rec[i] = lp0; rec[6 + i] = lp1;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Lg[offW + (6 * k + i) * 3 + c] = lp0 * lf0[c] + lp1 * lf1[c];     // Hpm block of (pose k, landmark)
+            Lg[offBP + 6 * k + i] = Jp0[i] * c0 + Jp1[i] * c1;
+        }
+        pk[0] = lf0[0] * lf0[0] + lf1[0] * lf1[0]; pk[1] = lf0[0] * lf0[1] + lf1[0] * lf1[1]; pk[2] = lf0[0] * lf0[2] + lf1[0] * lf1[2];
+        pk[3] = lf0[1] * lf0[1] + lf1[1] * lf1[1]; pk[4] = lf0[1] * lf0[2] + lf1[1] * lf1[2]; pk[5] = lf0[2] * lf0[2] + lf1[2] * lf1[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pk[6 + c] = Jf0[c] * c0 + Jf1[c] * c1;
+    }
+    __syncthreads();
+
+    // ---------------- phase 1.5 a: thread per landmark: H_ll, b_l, H_ll^-1 ----------------
+    double maxh = 0.0;
+    if (tid < G) {
+        const int g = tid;
+        double h[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
+        for (int k = 0; k < K; ++k) {
+            const double *pk = sAux + (size_t)(k * G + g) * 9;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) h[q] += pk[q];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bl[c] += pk[6 + c];
+        }
+        const double Hm[9] = {h[0], h[1], h[2], h[1], h[3], h[4], h[2], h[4], h[5]};
+        double Hi[9];
+        d_inverse3(Hm, Hi);
+        double *Lg = sL + (size_t)g * LREC;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Lg[offH + q] = h[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Lg[offHI + q] = Hi[q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Lg[offBL + c] = -bl[c];
+        maxh = fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5])));
+    }
+    {
+        const double ws = d_wave_sum_to_lane63(chi_acc), wm = d_wave_max_to_lane63(maxh);
+        if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
+    }
+    __syncthreads();
+    // ---------------- phase 1.5 b: thread per (landmark, k): Y_k = W_k H_ll^-1  (tempH = Hpm * Hmm_inv, problem.cc:427) ----------------
+    for (int o = tid; o < G * K; o += LIN_THREADS) {
+        const int k = o / G, g = o - k * G;
+        double *Lg = sL + (size_t)g * LREC;
+        double Hi[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Hi[q] = Lg[offHI + q];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double *w = Lg + offW + (6 * k + i) * 3;
+            const double w0 = w[0], w1 = w[1], w2 = w[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Lg[offY + (6 * k + i) * 3 + c] = w0 * Hi[c] + w1 * Hi[3 + c] + w2 * Hi[6 + c];
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: tiles on the matrix cores ----------------
+    const int D = 6 * nb;
+    const int TS = (D + 15) >> 4, nts = TS * (TS + 1) / 2;
+    double *sVec = sTile + (size_t)(NTD + nts) * 256;
+    {
+        const int wave = tid >> 6, lane = tid & 63, cl = lane & 15, rg = lane >> 4;
+        const int nwork = NTD + nts;
+        for (int wk = wave; wk < nwork; wk += LIN_THREADS / 64) {
+            ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
+            if (wk < NTD) {
+                // C = V^T V, V = the 2G whitened pose rows of observation indices 2 wk and 2 wk + 1 side by side (12 columns);
+                // one MFMA step takes two landmarks (lane row group rg: landmark rg >> 1, row rg & 1)
+                const bool live = cl < 12;
+                const int off = (cl < 6 ? 0 : 12) + (rg & 1) * 6 + (cl < 6 ? cl : cl - 6);
+                const double *plane = sRows + wk * PLANE + (live ? off : 0);
+                for (int st2 = 0; 2 * st2 < G; ++st2) {
+                    const int g = 2 * st2 + (rg >> 1);
+                    const double vv = (live && g < G) ? plane[g * 24] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vv, vv, acc, 0, 0, 0);
+                }
+            } else {
+                const int ts = wk - NTD;
+                int ta = 0;
+                while ((ta + 1) * (ta + 2) / 2 <= ts) ++ta;
+                const int tb = ts - ta * (ta + 1) / 2;
+                const int a = 16 * ta + cl, bq = 16 * tb + cl;
+                const bool la = a < D, lb = bq < D;
+                const double *pa = sL + offW + (la ? a : 0) * 3, *pb = sL + offY + (lb ? bq : 0) * 3;
+                for (int c = 0; c < 3; ++c)
+                    for (int st4 = 0; 4 * st4 < G; ++st4) {
+                        const int g = 4 * st4 + rg;
+                        const bool ok = g < G;
+                        const double wa = (ok && la) ? pa[(size_t)g * LREC + c] : 0.0;
+                        const double yb = (ok && lb) ? pb[(size_t)g * LREC + c] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, -yb, acc, 0, 0, 0);
+                    }
+            }
+            double *tl = sTile + (size_t)wk * 256 + rg * 16 + cl;   // C/D image: row rg + 4v, column cl
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tl[64 * v] = acc[v];
+        }
+        // b vectors: which 0: direct b = - sum_g (drho J_pose^T Info r)_g;  1: Schur correction = sum_g Y_g b_l,g   (fixed order)
+        for (int e = tid; e < 2 * D * LIN_VS; e += LIN_THREADS) {
+            const int part = e % LIN_VS, a = (e / LIN_VS) % D, which = e / (LIN_VS * D);
+            double sum = 0.0;
+            for (int g = part; g < G; g += LIN_VS) {
+                const double *Lg = sL + (size_t)g * LREC;
+                if (which == 0) sum += -Lg[offBP + a];
+                else sum += Lg[offY + 3 * a] * Lg[offBL] + Lg[offY + 3 * a + 1] * Lg[offBL + 1] + Lg[offY + 3 * a + 2] * Lg[offBL + 2];
+            }
+            sVec[e] = sum;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- combine: thread per slab element ----------------
+    {
+        double *out = T.slab + it.out_base;
+        const int n_out = it.n_rows * 6;
+        const int n_pair = (nb * (nb + 1) / 2) * 36;
+        double chi = 0.0, mh = 0.0;
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 0; w < LIN_THREADS / 64; ++w) { chi += sRed[w]; mh = fmax(mh, sRed[2 * (LIN_THREADS / 64) + w]); }
+        }
+        // entry (i, j) of the direct block of pattern block p
+        auto cdir = [&](int p, int i, int j) -> double { return sTile[(size_t)(p >> 1) * 256 + ((p & 1) * 6 + i) * 16 + (p & 1) * 6 + j]; };
+        for (int e = tid; e < n_out; e += LIN_THREADS) {
+            double v = 0.0;
+            if (e < n_pair) {
+                const int pi = e / 36, rem = e - 36 * pi, i = rem / 6, j = rem - 6 * i;
+                int p = 0, left = pi;
+                while (left >= nb - p) { left -= nb - p; ++p; }
+                const int q = p + left;
+                const int a = 6 * p + i, bq = 6 * q + j;
+                const int hi = (a >> 4) >= (bq >> 4) ? a : bq, lo = (a >> 4) >= (bq >> 4) ? bq : a;
+                const int ta = hi >> 4, tb = lo >> 4;
+                v = sTile[(size_t)(NTD + ta * (ta + 1) / 2 + tb) * 256 + (hi & 15) * 16 + (lo & 15)];
+                if (p == q) v += cdir(p, i, j);
+            } else {
+                const int ve = e - n_pair, which = ve / D, a = ve - which * D;
+                if (which < 2) {
+                    const double *pv = sVec + (size_t)(which * D + a) * LIN_VS;
+#pragma unroll
+                    for (int q = 0; q < LIN_VS; ++q) v += pv[q];
+                } else {
+                    const int p = a / 6, i = a - 6 * p;
+                    v = cdir(p, i, i);
+                }
+            }
+            out[e] = v;
+        }
+        if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
+        // W, H_ll, b_l of the item's landmarks for the back-substitution
+        double *lw = T.lw + it.lw_base;
+        const int nf = 18 * nb + 9;
+        for (int e = tid; e < nf * G; e += LIN_THREADS) {
+            const int r = e / G, g = e - r * G;
+            const double *Lg = sL + (size_t)g * LREC;
+            lw[e] = (r < 18 * nb) ? Lg[offW + r] : (r < 18 * nb + 6 ? Lg[offH + (r - 18 * nb)] : Lg[offBL + (r - 18 * nb - 6)]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_backsub_xyz: one workgroup per item, one thread per landmark.  mode as k_backsub.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS_THREADS) void k_backsub_xyz(DeviceTables T, int mode) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const LmState *lm = T.lm;
+    if (d_gated_off(lm, T.lm_gate)) return;
+    const int cur = d_cur(T);
+    const int which = (mode == 1) ? cur : (cur ^ 1);
+    if ((T.gn_flags & 8) && T.has_prior && (lane >> 6) == 1) d_bprior_rows(T, cur, cur ^ 1, b, gridDim.x, lane & 63);
+    if (b >= T.n_items) { d_backsub_imu_block(T, mode, which, b, lane); return; }
+    __shared__ double sFr[VIO_NF * 12];
+    __shared__ double sDxp[176];
+    __shared__ ItemDesc sIt;
+    if (mode == 0) { sDxp[lane] = T.dx[lane]; if (lane + BS_THREADS < 176) sDxp[lane + BS_THREADS] = T.dx[lane + BS_THREADS]; }
+    if (lane < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[lane] = ((const int32_t *)(T.items + b))[lane];
+    __syncthreads();
+    const ItemDesc &it = sIt;
+    const int G = it.G, K = it.K, nb = it.nb;
+    const double *st = T.state + which * STATE_STRIDE;
+    if (lane < K) {
+        double ric[9], o[12];
+        d_quat_to_R(st + STATE_EXT + 3, ric);
+        d_xyz_frame(st, it.cam_block[lane] - 1, ric, o);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) sFr[12 * lane + k] = o[k];
+    }
+    __syncthreads();
+    double chi = 0.0, scale = 0.0;
+    if (lane < G) {
+        const int g = lane;
+        const size_t li = (size_t)it.lm_base + g;
+        const size_t Ns = (size_t)T.Ns;
+        double pw[3] = {T.invd[(size_t)cur * 3 * Ns + li], T.invd[(size_t)cur * 3 * Ns + Ns + li], T.invd[(size_t)cur * 3 * Ns + 2 * Ns + li]};
+        if (mode == 0) {
+            const double *lw = T.lw + it.lw_base;
+            double t[3] = {0.0, 0.0, 0.0};
+            for (int p = 0; p < nb; ++p) {
+                const int base = 6 + 15 * (it.cam_block[p] - 1);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double d = sDxp[base + i];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) t[c] += lw[(size_t)((6 * p + i) * 3 + c) * G + g] * d;
+                }
+            }
+            double h[6], bl[3], Hi[9], dl[3];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) h[q] = lw[(size_t)(18 * nb + q) * G + g];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bl[c] = lw[(size_t)(18 * nb + 6 + c) * G + g];
+            const double Hm[9] = {h[0], h[1], h[2], h[1], h[3], h[4], h[2], h[4], h[5]};
+            d_inverse3(Hm, Hi);
+            const double v0 = bl[0] - t[0], v1 = bl[1] - t[1], v2 = bl[2] - t[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                dl[i] = Hi[3 * i] * v0 + Hi[3 * i + 1] * v1 + Hi[3 * i + 2] * v2;
+                T.dxl[(size_t)i * Ns + li] = dl[i];
+                pw[i] += dl[i];
+                T.invd[(size_t)(cur ^ 1) * 3 * Ns + (size_t)i * Ns + li] = pw[i];
+                scale += dl[i] * (lm->lambda * dl[i] + bl[i]);
+            }
+        }
+        const double s_info = T.sqrt_info, info = s_info * s_info;
+        for (int k = 0; k < K; ++k) {
+            const double *A = sFr + 12 * k;
+            const size_t o = (size_t)it.obs_base + (size_t)k * G + g;
+            double pc[3];
+            d_m3_vec(A, pw, pc);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) pc[m] += A[9 + m];
+            const double iz = 1.0 / pc[2];
+            const double r0 = pc[0] * iz - T.pts_j[2 * o], r1 = pc[1] * iz - T.pts_j[2 * o + 1];
+            const double e2 = r0 * (info * r0) + r1 * (info * r1);
+            double rho0, rho1, rho2;
+            d_loss(T.loss_type, T.loss_delta, e2, rho0, rho1, rho2);
+            chi += (T.loss_type == 0) ? e2 : rho0;
+        }
+    }
+    __shared__ double sSum[2 * (BS_THREADS / 64)];
+    chi = d_wave_sum_to_lane63(chi);
+    scale = d_wave_sum_to_lane63(scale);
+    if ((lane & 63) == 63) { sSum[2 * (lane >> 6)] = chi; sSum[2 * (lane >> 6) + 1] = scale; }
+    __syncthreads();
+    if (lane == 0) {
+        double c = 0.0, sc = 0.0;
+#pragma unroll
+        for (int w = 0; w < BS_THREADS / 64; ++w) { c += sSum[2 * w]; sc += sSum[2 * w + 1]; }
+        double *part = (mode == 1) ? T.chi_part : T.step_part;
+        part[2 * b + STEP_CHI] = c; part[2 * b + STEP_SCALE] = sc;
+    }
+}
+
+#endif

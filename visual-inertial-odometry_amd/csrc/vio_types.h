@@ -3,6 +3,7 @@
 // Data layout in HBM (all fp64 unless noted):
 //   state[2][STATE_STRIDE]   ext(7) | pose(11x7) | speed-bias(11x9); two copies: "current" and "trial"
 //   invd[2][Ns]              inverse depths in PATTERN-SORTED landmark order, current / trial
+//                            (XYZ landmarks: invd[2][3][Ns], the world points coordinate-major; see vio_kernels_xyz.h)
 //   pts_i[Ns][2]             host observation of each landmark
 //   pts_j[M][2]              target observations, item-major, inside an item k-major: obs_base + k*G + g
 //   items[n_items]           ItemDesc: <= G_MAX landmarks sharing (host, targets) — the unit of work of a workgroup
@@ -115,8 +116,9 @@ struct LmState {
 struct DeviceTables {            // everything a kernel needs, passed by value
     const ItemDesc *items;
     int32_t n_items;
-    int32_t n_imu_items;         // IMU edges appended to the linearize grid (0 on shards with rank > 0)
+    int32_t n_imu_items;         // IMU edges appended to the linearize grid (replicated on every shard: their terms are added after the exchange)
     int32_t Ns;                  // landmarks in sorted order
+    int32_t lm_dim;              // 1: inverse depths (k_linearize, k_backsub); 3: XYZ points (k_linearize_xyz, k_backsub_xyz)
     int32_t ext_fixed;
     int32_t loss_type;
     int32_t marg_mode;           // 1: Problem::Marginalize assembly (ext free, no fixed masking)
@@ -143,7 +145,7 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     const double *Jtinv;         // [156x156]
     int32_t has_prior;
     int32_t natural_hs;          // 1: k_assemble also writes H_pp_schur_ in natural order (getters, marginalisation)
-    int32_t add_imu_prior;       // 1 on shard rank 0
+    int32_t add_imu_prior;       // 1 on every rank: IMU and prior terms are replicated and added after the exchange
     double *Hs;                  // [171x171]
     double *Pg;                  // permuted, padded, packed lower triangle + rhs row, written by k_assemble
     int32_t *perm;               // [176] pivot order found by k_assemble
