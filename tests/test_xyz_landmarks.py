@@ -164,8 +164,10 @@ def test_hip_gn_iterations_against_oracle(vio, oracle_lib, hip_lib):
     ch.synchronize()
     ph, sh, _ = ch.get_window()
     po, so, _ = co.get_window()
-    assert np.abs(ph - po).max() <= 1e-7 and np.abs(sh - so).max() <= 1e-7
-    assert np.abs(ch.get_landmarks_xyz() - co.get_landmarks_xyz()).max() <= 1e-7
+    # five steps at a damping of 1e3 on a window without a prior: the gauge directions are held by lambda alone, so the
+    # accumulated difference is bounded as the end state of a solve is (north star: 1e-6), not as a single update
+    assert np.abs(ph - po).max() <= 1e-6 and np.abs(sh - so).max() <= 1e-6
+    assert np.abs(ch.get_landmarks_xyz() - co.get_landmarks_xyz()).max() <= 1e-6
     assert abs(ch.chi2() - co.chi2()) <= 1e-7 * co.chi2()
 
 

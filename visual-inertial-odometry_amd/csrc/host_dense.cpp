@@ -44,11 +44,14 @@ void inverse15(const double *cov, double *info) {
     }
 }
 
-// Householder tridiagonalisation followed by the implicit-shift QL iteration.
+// Householder tridiagonalisation followed by the implicit-shift QL iteration.  The work matrix is kept column-major
+// (at(i, j) = V[j n + i]): every inner loop of the two phases walks down a column.
+// (compiled twice, AVX2 and baseline, dispatched at load time: same operations in the same order, wider vectors)
+__attribute__((target_clones("avx2", "default")))
 bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout) {
     std::vector<double> Vv((size_t)n * n), ev(n);
     double *V = Vv.data(), *e = ev.data();
-    auto at = [&](int i, int j) -> double & { return V[(size_t)i * n + j]; };
+    auto at = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
     for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) { at(i, j) = Ain[(size_t)i * n + j]; at(j, i) = at(i, j); }
     for (int j = 0; j < n; ++j) d[j] = at(n - 1, j);
@@ -165,7 +168,8 @@ bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout) {
             for (int j = 0; j < n; ++j) std::swap(at(j, i), at(j, k));
         }
     }
-    std::memcpy(Vout, V, sizeof(double) * (size_t)n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Vout[(size_t)i * n + j] = at(i, j);
     return ok;
 }
 
@@ -183,6 +187,7 @@ static void move_to_bottom(std::vector<double> &H, std::vector<double> &b, int n
     b.swap(tb);
 }
 
+__attribute__((target_clones("avx2", "default")))
 void marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *bout, double *errout, double *jtout) {
     const int n = 171, m2 = 15, n2 = n - m2;
     std::vector<double> H(Hin, Hin + (size_t)n * n), b(bin, bin + n);
@@ -228,15 +233,18 @@ void marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double 
         for (int j = 0; j < n2; ++j) s += -jtout[(size_t)i * n2 + j] * bp[j];
         errout[i] = s;
     }
-    for (int i = 0; i < n2; ++i)
-        for (int j = 0; j < n2; ++j) {
-            double s = 0;
-            for (int k = 0; k < n2; ++k) {
-                const double sk = ev2[k] > eps ? ev2[k] : 0.0;
-                s += V2[(size_t)i * n2 + k] * sk * V2[(size_t)j * n2 + k];
+    {   // H_prior = J^T J with J = sqrt(S) V^T (problem.cc:775-777): sum_k V_ik s_k V_jk, k ascending; (V_ik s_k) formed once
+        std::vector<double> VS((size_t)n2 * n2);
+        for (int i = 0; i < n2; ++i)
+            for (int k = 0; k < n2; ++k) VS[(size_t)i * n2 + k] = V2[(size_t)i * n2 + k] * (ev2[k] > eps ? ev2[k] : 0.0);
+        for (int i = 0; i < n2; ++i)
+            for (int j = 0; j < n2; ++j) {
+                const double *a = &VS[(size_t)i * n2], *c = &V2[(size_t)j * n2];
+                double s = 0;
+                for (int k = 0; k < n2; ++k) s += a[k] * c[k];
+                Hout[(size_t)i * n2 + j] = std::fabs(s) > 1e-9 ? s : 0.0;     // problem.cc:778
             }
-            Hout[(size_t)i * n2 + j] = std::fabs(s) > 1e-9 ? s : 0.0;     // problem.cc:778
-        }
+    }
     std::memcpy(bout, bp.data(), sizeof(double) * n2);
 }
 
