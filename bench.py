@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — GN iterations/s of the MI355X sliding-window VIO backend on BASELINE.json's headline config.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks L]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--landmarks L] [--landmark-type invdepth|xyz]
 
 One "step" = one Gauss-Newton iteration of the hot path: linearise all reprojection
 + IMU factors, reduce the landmark Schur complement, add the prior, damped pivoted LDLT of the 171x171 pose
@@ -22,6 +22,8 @@ The JSON line also carries
                 peak = 8 TB/s HBM
   cpu_baseline  the oracle's (oracle/vio_oracle.c, plain C, 1 thread) GN iteration on the same window,
                 timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
+  per_frame     what surrounds the inner iteration once per frame: vio_set_*, plan + upload + first linearisation,
+                Solve(10), MargOldFrame — host wall clock, for the HIP library and for the CPU port
 """
 import argparse
 import importlib.util
@@ -46,7 +48,12 @@ def load_package():
 
 
 # algorithmic bytes of one launch of each kernel, N landmarks / M observations on this GPU
-def kernel_algorithmic_bytes(name, n, m):
+def kernel_algorithmic_bytes(name, n, m, xyz=False):
+    if xyz:     # per observation (x, y) fp64 + 2 int32 of indices; per landmark 3 fp64 read, 3 fp64 written (+ 3 of delta)
+        b_state, b_imu = 1464, 10 * (10 + 225 + 225 + 6 + 1) * 8
+        b_sys = (171 * 171 + 171) * 8
+        return {"k_linearize": 24 * m + 48 * n + b_state + b_imu, "k_reduce": 78 * 36 * 8 * 2, "k_assemble": 2 * b_sys,
+                "k_pose_solve": 2 * b_sys + b_state + 171 * 8, "k_backsub": 24 * m + 72 * n + b_state, "k_lm_decide": 4096}[name]
     b_state = 1464
     b_imu = 10 * (10 + 225 + 225 + 6 + 1) * 8
     b_sys = (171 * 171 + 171) * 8
@@ -72,6 +79,10 @@ def main():
     ap.add_argument("--obs-per-landmark", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prior", action="store_true", help="first-window case: no marginalisation prior")
+    ap.add_argument("--landmark-type", choices=("invdepth", "xyz"), default="invdepth",
+                    help="invdepth: VertexInverseDepth + EdgeReprojection (what Estimator builds, the headline); "
+                         "xyz: VertexPointXYZ + EdgeReprojectionXYZ (3x3 landmark blocks)")
+    ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame cost block (set / plan+upload / Solve(10) / marginalise)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=0, help="0 = sized for about 10-20 s")
     args = ap.parse_args()
 
@@ -100,7 +111,9 @@ def main():
     hip = vio.load_hip()        # raises if csrc/libvio_hip.so is missing: no fallback path
 
     n_per_gpu, k_obs = args.landmarks, args.obs_per_landmark
-    full = vio.synth.make_window(n_per_gpu * world, seed=42, obs_per_landmark=k_obs)
+    xyz = args.landmark_type == "xyz"
+    make = vio.synth.make_window_xyz if xyz else vio.synth.make_window
+    full = make(n_per_gpu * world, seed=42, obs_per_landmark=k_obs)
     if not args.no_prior:
         # the steady-state window carries a marginalisation prior ("produced by running one MargOldFrame
         # on a preceding window"; its 235 KB are part of B_win): solve the window one frame earlier, marginalise its
@@ -178,27 +191,73 @@ def main():
     value = world * args.steps / elapsed
 
     dom_launch_s = (dom_ms / max(dom_cnt, 1)) * 1e-3
-    alg_bytes = kernel_algorithmic_bytes(dominant, n, m)
+    alg_bytes = kernel_algorithmic_bytes(dominant, n, m, xyz)
     achieved = alg_bytes / dom_launch_s / 1e9 if dom_launch_s > 0 else 0.0
-    traffic = None
-    tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+    # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 around the process): the figure of the
+    # committed counter pass over this same command (profiles/traffic.json <- tools/summarize_profile.py), labelled as such
+    traffic, traffic_source = None, None
+    tr_path = os.path.join(ROOT, "profiles", "traffic_xyz.json" if xyz else "traffic.json")
     if os.path.exists(tr_path):
         try:
             traffic = json.load(open(tr_path)).get(dominant, {}).get("hbm_bytes_per_launch")
+            traffic_source = "committed rocprofv3 --pmc pass (profiles/%s), not this run" % os.path.basename(tr_path)
         except Exception:
             traffic = None
+    it_bytes = (24 * m + 72 * n + 280000) if xyz else vio.synth.algorithmic_bytes(n, m)
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic,
+                "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_us": round(dom_launch_s * 1e6, 3),
-                "iteration_algorithmic_bytes": vio.synth.algorithmic_bytes(n, m),
-                "iteration_achieved_GBps": round(vio.synth.algorithmic_bytes(n, m) / (ms_per_step * 1e-3) / 1e9, 3),
-                "kernel_us": {k: round(v * 1e3, 3) for k, v in per_kernel.items()}}
+                "launch_us_method": "HIP event pairs on the library's stream around every 8th launch of the timed steps "
+                                    "(includes the event's own drain, ~8 % above rocprofv3's kernel duration)",
+                "iteration_algorithmic_bytes": it_bytes,
+                "iteration_achieved_GBps": round(it_bytes / (ms_per_step * 1e-3) / 1e9, 3),
+                "kernel_us_event_bracketed": {k: round(v * 1e3, 3) for k, v in per_kernel.items()}}
+
+    # ---- what one frame costs around the inner iteration (Estimator::backendOptimization, estimator.cpp:1075-1141):
+    #      vio_set_* of a fresh window, plan + upload + first linearisation, Solve(10), MargOldFrame — host wall clock
+    per_frame = None
+    if rank == 0 and world == 1 and not args.no_per_frame:
+        def frame_costs(lib, reps):
+            c = lib.context(**({"device": local_rank} if lib is hip else {}))
+            acc = {"set_ms": 0.0, "plan_upload_linearize_ms": 0.0, "solve10_ms": 0.0, "marginalize_ms": 0.0}
+            iters = 0
+            for r in range(reps + 1):
+                t0 = time.perf_counter()
+                c.load(full)
+                t1 = time.perf_counter()
+                c.linearize()
+                if lib is hip:
+                    c.synchronize()
+                t2 = time.perf_counter()
+                rep = c.solve(10)
+                t3 = time.perf_counter()
+                t4 = t3
+                if not xyz:
+                    c.marginalize(vio.MARG_OLD)
+                    t4 = time.perf_counter()
+                if r == 0:
+                    continue                # first pass: allocations, first touches
+                acc["set_ms"] += (t1 - t0) * 1e3; acc["plan_upload_linearize_ms"] += (t2 - t1) * 1e3
+                acc["solve10_ms"] += (t3 - t2) * 1e3; acc["marginalize_ms"] += (t4 - t3) * 1e3
+                iters = rep.iterations
+            out = {k: round(v / reps, 4) for k, v in acc.items()}
+            out["frame_ms"] = round(sum(out.values()), 4)
+            out["solve10_iterations"] = iters
+            if xyz:
+                out["marginalize_ms"] = None      # MargOldFrame is not defined for XYZ landmarks (include/vio_backend.h)
+            return out
+        per_frame = {"gpu": frame_costs(hip, 5),
+                     "note": "host wall clock per call on the bench window; set = vio_set_window/landmarks/observations/imu/prior "
+                             "(host copies), plan_upload_linearize = pattern grouping + H2D + first linearisation, marginalize = "
+                             "MargOldFrame: GPU assembly + Schur, 171x171 D2H, eigen-decomposition tail on one host thread"}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
         orc = vio.VioLib(os.path.join(ROOT, "oracle", "liboracle.so"), "vioo_")
+        if per_frame is not None:
+            per_frame["cpu_port_1_thread"] = frame_costs(orc, 1)
         co = orc.context()
         co.load(full)
         co.gn_iteration(lam)        # warm-up / first touch
@@ -217,7 +276,7 @@ def main():
 
     # the same port on all host cores (OpenMP over landmarks, oracle/liboracle_omp.so; SURVEY.md 8d asks for both figures)
     cpu_baseline_all_cores = None
-    if cpu_baseline is not None:
+    if cpu_baseline is not None and not xyz:       # (the OpenMP build parallelises the inverse-depth path only)
         try:
             import subprocess
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "omp"])
@@ -251,7 +310,7 @@ def main():
     if cpu_baseline is not None and os.path.exists(ref_so):
         try:
             rl = vio.VioLib(ref_so, "vior_")
-            wr = vio.synth.make_window(2000, seed=42, obs_per_landmark=k_obs)
+            wr = make(2000, seed=42, obs_per_landmark=k_obs)
             cr = rl.context()
             cr.load(wr)
             cr.linearize()
@@ -284,14 +343,17 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic 11-frame VIO window (SURVEY.md 8d): %d landmarks x %d observations per GPU, "
-                                   "10 IMU factors, %s, Cauchy loss, extrinsic fixed, fixed-lambda GN iteration"
-                                   % (n_per_gpu, k_obs, "no prior" if args.no_prior else "marginalisation prior of the preceding window"),
+                                   "10 IMU factors, %s, Cauchy loss, extrinsic fixed, fixed-lambda GN iteration, %s"
+                                   % (n_per_gpu, k_obs + (1 if xyz else 0), "no prior" if args.no_prior else "marginalisation prior of the preceding window",
+                                      "XYZ landmarks (VertexPointXYZ, 3x3 blocks)" if xyz else "inverse-depth landmarks"),
+                       "landmark_type": args.landmark_type,
                        "landmarks_per_gpu": n_per_gpu, "observations_per_gpu": m, "landmarks_total": n_per_gpu * world,
                        "lambda": lam, "parallelism": "landmark-sharded x%d, all-reduce of the 72x72 reduced system" % world
                        if world > 1 else "single GPU", "exchange": sb.exchange},
             "final_chi2": chi2,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "per_frame": per_frame,
             "cpu_baseline_all_cores": cpu_baseline_all_cores,
             "cpu_reference": cpu_reference,
         }

@@ -754,7 +754,10 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
     // with a prior, the previous GN step left err_prior to this k_reduce (k_pose_solve wrote b_prior' only)
     const bool err_prev = test_prev && T.has_prior;
-    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items, gate, T.lm,
+    // sharded + gated slot: the all-reduce below runs whether the slot is live or not (every rank enqueues the same
+    // collectives), in place on vis; k_reduce therefore always runs and puts this rank's own sums back first (a skipped
+    // re-linearisation leaves the slabs as they were), so the buffer never accumulates the sum of sums
+    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items, sharded(c) ? 0 : gate, T.lm,
                    err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + c->cur_host * 176 : nullptr,
                    err_prev ? T.errprior + c->cur_host * 160 : nullptr};
     { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
@@ -1090,11 +1093,13 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
     std::memset(&r, 0, sizeof(r));
     r.initial_chi2 = c->h_lm.chi;
     vio_status status = VIO_OK;
-    if (!sharded(c)) {
+    {
         // Device-driven loop: LmState lives on the device and k_lm_decide does all of Problem::Solve's bookkeeping, so the
         // host enqueues as many (trial, re-linearisation) slots as outer iterations are left and looks at LmState once per
         // batch; the kernels of a slot gate themselves (a rejected trial skips its re-linearisation, everything after
         // the stop skips itself).  When every trial is accepted - the usual case - that is one read-back per solve.
+        // Sharded solves run the same loop: the two exchanges of a slot are enqueued unconditionally (every rank holds the
+        // identical LmState, so every rank enqueues the same collectives), a dead slot all-reduces buffers nobody reads.
         while (status == VIO_OK && !c->h_lm.stop && c->h_lm.iter < iterations) {
             // (at most 10 slots ahead: a loop that stops early leaves the rest as empty launches, ~20 us each)
             const int batch = std::min(iterations - c->h_lm.iter, 10);
@@ -1103,18 +1108,6 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
                 if (status == VIO_OK) status = enqueue_linearize(c, pl, false, 3);
             }
             if (status == VIO_OK) status = read_lm(c);
-        }
-    } else {
-        // sharded: the exchanges are collectives issued by the host, so the loop stays on the host, one read-back per trial
-        while (!c->h_lm.stop && c->h_lm.iter < iterations) {
-            status = enqueue_trial(c, pl, 0);
-            if (status != VIO_OK) break;
-            status = read_lm(c);
-            if (status != VIO_OK) break;
-            if (c->h_lm.accepted && !c->h_lm.stop) {
-                status = enqueue_linearize(c, pl);
-                if (status != VIO_OK) break;
-            }
         }
     }
     if (status != VIO_OK) return status;

@@ -20,8 +20,10 @@ class ShardedBackend:
                  exchange=None):
         """exchange: "native" — the library all-reduces with RCCL itself, in stream order, no Python in the loop
         (HIP library on GPUs; the 128-byte communicator id travels through torch.distributed once);
-        "hook" — torch.distributed.all_reduce from the library's exchange hook (any backend: gloo in the CPU tests).
-        Default: native when the library exports it and the device is a GPU, unless VIO_EXCHANGE=hook."""
+        "hook" — torch.distributed.all_reduce from the library's exchange hook (any backend: gloo in the CPU tests);
+        "hook_host" — the same hook staging the buffers through pinned host memory: gloo between processes whose tensors
+        live on a GPU (RCCL refuses two ranks on one device; this is how the two-rank protocol runs on a one-GPU box).
+        Default: native when the library exports it and the device is a GPU, unless VIO_EXCHANGE says otherwise."""
         import torch
         self.torch = torch
         self.dist = dist
@@ -30,6 +32,12 @@ class ShardedBackend:
         self.shard = synth.shard_window(window, rank, world) if world > 1 else window
         kw = dict(ctx_kwargs or {})
         kw.update(shard_rank=rank, shard_count=world)
+        if exchange is None:
+            import os
+            exchange = os.environ.get("VIO_EXCHANGE", "native" if (lib.has("comm_init") and str(torch_device).startswith("cuda")) else "hook")
+        if exchange in ("hook", "hook_host") and str(torch_device).startswith("cuda") and "stream" not in kw:
+            # the hook's collective / copies are ordered by torch's current stream: the library must enqueue on it too
+            kw["stream"] = torch.cuda.current_stream().cuda_stream
         self.ctx = lib.context(**kw)
         self.ctx.load(self.shard)
         (_, self.n_red), (_, self.n_sc) = self.ctx.exchange_buffers()
@@ -38,9 +46,6 @@ class ShardedBackend:
         self.sca = torch.zeros(8, dtype=torch.float64, device=torch_device)
         self.ctx.bind_exchange_buffers(self.red.data_ptr(), self.sca.data_ptr())
         self._views = (self.red[:self.n_red], self.sca[:self.n_sc], self.sca[2:3])
-        if exchange is None:
-            import os
-            exchange = os.environ.get("VIO_EXCHANGE", "native" if (lib.has("comm_init") and str(torch_device).startswith("cuda")) else "hook")
         self.exchange = exchange if (world > 1 or force_hook) else "none"
         if self.exchange == "native":
             idt = torch.zeros(128, dtype=torch.uint8, device=torch_device)
@@ -51,6 +56,9 @@ class ShardedBackend:
             self.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
         elif self.exchange == "hook":     # force_hook: exercise the exchange path on a single rank (tests)
             self.ctx.set_exchange_hook(self._exchange)
+        elif self.exchange == "hook_host":
+            self._host = [torch.zeros(v.shape, dtype=v.dtype).pin_memory() for v in self._views]
+            self.ctx.set_exchange_hook(self._exchange_host)
 
     def _exchange(self, which):
         try:
@@ -58,6 +66,18 @@ class ShardedBackend:
             self.dist.all_reduce(self._views[which], op=op)
             return 0
         except Exception as exc:      # the C side turns a non-zero return into VIO_ERR_HIP
+            print("exchange hook failed:", exc)
+            return 1
+
+    def _exchange_host(self, which):
+        try:
+            v, h = self._views[which], self._host[which]
+            h.copy_(v)                  # D2H on torch's current stream (the library's): waits for the kernels before it
+            if self.world > 1:
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX if which == 2 else self.dist.ReduceOp.SUM)
+            v.copy_(h)
+            return 0
+        except Exception as exc:
             print("exchange hook failed:", exc)
             return 1
 

@@ -276,6 +276,13 @@ def shard_window(w, rank, world):
     hi = (N * (rank + 1)) // world
     keep = (w.lm >= lo) & (w.lm < hi)
     s = w.copy()
+    if getattr(w, "xyz", None) is not None:         # XYZ landmarks (make_window_xyz)
+        s.xyz, s.xyz_gt = w.xyz[lo:hi].copy(), w.xyz_gt[lo:hi].copy()
+        s.lm = (w.lm[keep] - lo).astype(np.int32)
+        s.frame, s.pts = w.frame[keep].copy(), w.pts[keep].copy()
+        s.n_landmarks, s.n_observations = hi - lo, int(s.lm.size)
+        s.landmark_range = (lo, hi)
+        return s
     s.inv_depth = w.inv_depth[lo:hi].copy()
     s.inv_depth_gt = w.inv_depth_gt[lo:hi].copy()
     s.lm = (w.lm[keep] - lo).astype(np.int32)
