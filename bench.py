@@ -134,9 +134,7 @@ def main():
 
     # N > 1: the library all-reduces with RCCL itself on its own stream (VIO_EXCHANGE=hook selects the
     # torch.distributed hook instead, which has to share torch's current stream)
-    kw = dict(device=local_rank)
-    if os.environ.get("VIO_EXCHANGE", "native") == "hook":
-        kw["stream"] = torch.cuda.current_stream().cuda_stream
+    kw = dict(device=local_rank)       # (with VIO_EXCHANGE=hook, ShardedBackend puts the library and the collective on one torch stream)
     force = os.environ.get("VIO_BENCH_FORCE_EXCHANGE") == "1"      # diagnostic: run the sharded kernel sequence on one rank
     if force and dist is None and os.environ.get("VIO_EXCHANGE", "native") == "hook":
         import torch.distributed as dist

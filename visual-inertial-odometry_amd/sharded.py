@@ -35,9 +35,12 @@ class ShardedBackend:
         if exchange is None:
             import os
             exchange = os.environ.get("VIO_EXCHANGE", "native" if (lib.has("comm_init") and str(torch_device).startswith("cuda")) else "hook")
-        if exchange in ("hook", "hook_host") and str(torch_device).startswith("cuda") and "stream" not in kw:
-            # the hook's collective / copies are ordered by torch's current stream: the library must enqueue on it too
-            kw["stream"] = torch.cuda.current_stream().cuda_stream
+        self.stream = None
+        if exchange in ("hook", "hook_host") and str(torch_device).startswith("cuda") and not kw.get("stream"):
+            # the hook's collective / copies must be ordered with the library's kernels: one explicit torch stream for
+            # both (torch's default stream is the null stream, whose handle 0 the library reads as "create your own")
+            self.stream = torch.cuda.Stream()
+            kw["stream"] = self.stream.cuda_stream
         self.ctx = lib.context(**kw)
         self.ctx.load(self.shard)
         (_, self.n_red), (_, self.n_sc) = self.ctx.exchange_buffers()
@@ -60,10 +63,15 @@ class ShardedBackend:
             self._host = [torch.zeros(v.shape, dtype=v.dtype).pin_memory() for v in self._views]
             self.ctx.set_exchange_hook(self._exchange_host)
 
+    def _on_stream(self):
+        import contextlib
+        return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def _exchange(self, which):
         try:
             op = self.dist.ReduceOp.MAX if which == 2 else self.dist.ReduceOp.SUM
-            self.dist.all_reduce(self._views[which], op=op)
+            with self._on_stream():
+                self.dist.all_reduce(self._views[which], op=op)
             return 0
         except Exception as exc:      # the C side turns a non-zero return into VIO_ERR_HIP
             print("exchange hook failed:", exc)
@@ -72,10 +80,11 @@ class ShardedBackend:
     def _exchange_host(self, which):
         try:
             v, h = self._views[which], self._host[which]
-            h.copy_(v)                  # D2H on torch's current stream (the library's): waits for the kernels before it
-            if self.world > 1:
-                self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX if which == 2 else self.dist.ReduceOp.SUM)
-            v.copy_(h)
+            with self._on_stream():
+                h.copy_(v)              # D2H on the stream the library enqueues on: waits for the kernels before it
+                if self.world > 1:
+                    self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX if which == 2 else self.dist.ReduceOp.SUM)
+                v.copy_(h)
             return 0
         except Exception as exc:
             print("exchange hook failed:", exc)
