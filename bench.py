@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--landmark-type", choices=("invdepth", "xyz"), default="invdepth",
                     help="invdepth: VertexInverseDepth + EdgeReprojection (what Estimator builds, the headline); "
                          "xyz: VertexPointXYZ + EdgeReprojectionXYZ (3x3 landmark blocks)")
+    ap.add_argument("--batch", type=int, default=64, help="windows of the batched block (vio_batch_gn_iteration); 0 skips it")
     ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame cost block (set / plan+upload / Solve(10) / marginalise)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=0, help="0 = sized for about 10-20 s")
     args = ap.parse_args()
@@ -249,6 +250,35 @@ def main():
                              "(host copies), plan_upload_linearize = pattern grouping + H2D + first linearisation, marginalize = "
                              "MargOldFrame: GPU assembly + Schur, 171x171 D2H, eigen-decomposition tail on one host thread"}
 
+    # ---- B independent windows per launch (vio_batch_gn_iteration): the regime in which the device is full.  Same window
+    #      size as the headline, different seeds; reported beside the single-window line, never instead of it
+    batched = None
+    if rank == 0 and world == 1 and args.batch > 0 and not xyz:
+        B = args.batch
+        lead = hip.context(device=local_rank)
+        members = [lead] + [hip.context(device=local_rank, stream=lead.get_stream()) for _ in range(B - 1)]
+        for i, cb in enumerate(members):
+            wb = vio.synth.make_window(n_per_gpu, seed=100 + i, obs_per_landmark=k_obs)
+            wb.prior = full.prior
+            cb.load(wb)
+        for _ in range(5):
+            hip.batch_gn_iteration(members, lam)
+        lead.synchronize()
+        bsteps = max(20, args.steps // 4)
+        tb = time.perf_counter()
+        for _ in range(bsteps):
+            hip.batch_gn_iteration(members, lam)
+        lead.synchronize()
+        tb = time.perf_counter() - tb
+        bytes_it = vio.synth.algorithmic_bytes(n, m)
+        batched = {"windows": B, "steps": bsteps, "ms_per_batch_iteration": tb * 1e3 / bsteps,
+                   "window_iterations_per_s": B * bsteps / tb, "us_per_window_iteration": tb * 1e6 / (bsteps * B),
+                   "algorithmic_GBps": round(B * bytes_it * bsteps / tb / 1e9, 2), "hbm_frac": B * bytes_it * bsteps / tb / 8e12,
+                   "final_chi2_window0": lead.chi2(),
+                   "note": "B independent 20k-landmark windows (seeds 100..), one launch per kernel for all of them (grid.y = window); "
+                           "bit-identical to B separate vio_gn_iteration runs (tests/test_gpu_batch.py)"}
+        del members, lead
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
@@ -352,6 +382,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "per_frame": per_frame,
+            "batched": batched,
             "cpu_baseline_all_cores": cpu_baseline_all_cores,
             "cpu_reference": cpu_reference,
         }

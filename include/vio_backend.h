@@ -179,6 +179,15 @@ vio_status vio_eval_step(struct vio_ctx *ctx, int32_t *accepted, double *chi2, d
  * This is BASELINE.json's "GN iteration" (SURVEY.md section 8d). */
 vio_status vio_gn_iteration(struct vio_ctx *ctx, double lambda);
 vio_status vio_synchronize(struct vio_ctx *ctx);
+/* The stream the context enqueues on (its own, or vio_config.stream). */
+vio_status vio_get_stream(struct vio_ctx *ctx, void **stream);
+/* vio_gn_iteration for `count` independent windows at once: one launch per kernel for the whole batch (the grid's second
+ * dimension is the window), i.e. `count` pose solves side by side instead of one workgroup on one of the 256 compute units.
+ * Every window is an ordinary context (its own graph, states, prior, LmState) and is read back with the ordinary
+ * getters; the contexts must share one device and one stream (create the others with vio_config.stream = the first one's
+ * vio_get_stream) and hold inverse-depth landmarks.  Results are bit-identical to calling vio_gn_iteration on each.
+ * Not a reference entry point: the reference solves one window at a time (System::ProcessBackEnd, one estimator). */
+vio_status vio_batch_gn_iteration(struct vio_ctx *const *ctxs, int32_t count, double lambda);
 
 /* ---- IMU pre-integration (host side, as in the reference: Estimator::processIMU -> IntegrationBase::push_back ->
  *      propagate -> midPointIntegration, integration_base.h:30-36,54-158).  Starts from (acc0, gyr0) — the sample the

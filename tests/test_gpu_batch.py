@@ -1,0 +1,78 @@
+"""vio_batch_gn_iteration: B independent windows advanced by one launch per kernel (grid.y = window).  Every window is an
+ordinary context; the batched sequence runs the same kernel bodies on the same data, so the result must equal B separate
+vio_gn_iteration runs bit for bit — also when a getter looks at one window in the middle of the sequence."""
+import numpy as np
+import pytest
+
+import vio_testutil as tu
+
+pytestmark = pytest.mark.gpu
+
+
+def windows(vio, oracle_lib):
+    ws = [vio.synth.make_window(700, seed=1, ragged=True), vio.synth.make_window(2500, seed=2), vio.synth.make_window(300, seed=3, t0=1.1),
+          vio.synth.make_window(64, seed=4), vio.synth.make_window(1, seed=5)]
+    # the third window carries a marginalisation prior (of the oracle: test infrastructure makes the input, not the result)
+    co = oracle_lib.context()
+    wp = vio.synth.make_window(120, seed=9)
+    co.load(wp)
+    co.solve(10)
+    p, s, e = co.get_window()
+    wp.poses, wp.speed_bias, wp.ext, wp.inv_depth = p, s, e, co.get_landmarks()
+    co.load(wp)
+    ws[2].prior = co.marginalize(vio.MARG_OLD)
+    return ws
+
+
+def state_of(ctx):
+    p, s, e = ctx.get_window()
+    return p, s, e, ctx.get_landmarks(), ctx.chi2()
+
+
+def test_batched_gn_equals_separate_runs(vio, hip_lib, oracle_lib):
+    ws = windows(vio, oracle_lib)
+    lam = 5e5
+    lead = hip_lib.context()
+    batch = [lead] + [hip_lib.context(stream=lead.get_stream()) for _ in ws[1:]]
+    solo = [hip_lib.context() for _ in ws]
+    for c, w in zip(batch, ws):
+        c.load(w)
+    for c, w in zip(solo, ws):
+        c.load(w)
+    for it in range(5):
+        hip_lib.batch_gn_iteration(batch, lam)
+        for c in solo:
+            c.gn_iteration(lam)
+        if it == 1:             # a getter in the middle: settles that window's pending step test the classic way
+            a, b = state_of(batch[1]), state_of(solo[1])
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+    for c, r in zip(batch, solo):
+        for x, y in zip(state_of(c), state_of(r)):
+            np.testing.assert_array_equal(x, y)
+    # a window re-loaded in the middle of a batch's life, a smaller batch, a bigger one
+    batch[3].load(ws[3])
+    solo[3].load(ws[3])
+    for _ in range(2):
+        hip_lib.batch_gn_iteration(batch[:4], lam)
+        for c in solo[:4]:
+            c.gn_iteration(lam)
+    hip_lib.batch_gn_iteration(batch, lam)
+    for c in solo:
+        c.gn_iteration(lam)
+    for c, r in zip(batch, solo):
+        for x, y in zip(state_of(c), state_of(r)):
+            np.testing.assert_array_equal(x, y)
+
+
+def test_batch_argument_checks(vio, hip_lib):
+    a, b = hip_lib.context(), hip_lib.context()            # two streams
+    w = vio.synth.make_window(50, seed=1)
+    a.load(w)
+    b.load(w)
+    with pytest.raises(vio.VioError):
+        hip_lib.batch_gn_iteration([a, b], 1e3)
+    c = hip_lib.context(stream=a.get_stream())
+    c.load(vio.synth.make_window_xyz(50, seed=1))
+    with pytest.raises(vio.VioError):
+        hip_lib.batch_gn_iteration([a, c], 1e3)            # XYZ windows take the classic sequence: not batched

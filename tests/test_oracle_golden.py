@@ -257,7 +257,9 @@ def check_prior(m, ref):
         mu = 1e-4 * np.linalg.eigvalsh(Hs_).max()
         return float(b @ np.linalg.solve(Hs_ + mu * np.eye(H.shape[0]), b))
     qa, qb = damped_energy(m["H"], m["b"]), damped_energy(ref["H"], ref["b"])
-    assert abs(qa - qb) <= 1e-3 * max(qb, 1e-9)
+    # H itself moves by 1e-5 lambda_max = 0.1 mu between any two evaluation orders of the same arithmetic (two builds of
+    # the HIP library: 5e-5 .. 1.6e-3 on the golden windows, profiles/r02d_marg_invariant_scatter.txt; the oracle: 1.6e-4)
+    assert abs(qa - qb) <= 5e-3 * max(qb, 1e-9)
     # Jt_inv^T Jt_inv is the pseudo-inverse of H_prior restricted to the kept eigenspace: H P H == H
     P = m["jt_inv"].T @ m["jt_inv"]
     assert np.abs(m["H"] @ P @ m["H"] - m["H"]).max() <= 1e-5 * Hs

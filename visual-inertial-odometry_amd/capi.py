@@ -91,7 +91,7 @@ class VioLib:
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
-                "comm_unique_id", "comm_init", "comm_destroy"]
+                "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration"]
     KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
@@ -139,6 +139,14 @@ class VioLib:
         if st != 0:
             raise VioError(st, self.prefix + "comm_unique_id", "(is librccl.so loadable?)")
         return bytes(buf.raw)
+
+    def batch_gn_iteration(self, ctxs, lam):
+        """One fixed-lambda GN iteration of every window of `ctxs` in one launch per kernel (vio_batch_gn_iteration)."""
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        st = self.fn["batch_gn_iteration"](arr, C.c_int32(len(ctxs)), C.c_double(lam))
+        if st != 0:
+            msg = self.fn["last_error"](ctxs[0].h)
+            raise VioError(st, self.prefix + "batch_gn_iteration", (msg or b"").decode(errors="replace"))
 
     def has(self, name):
         return hasattr(self.dll, self.prefix + name)
@@ -294,6 +302,11 @@ class VioContext:
 
     def synchronize(self):
         self._ck(self.lib.fn["synchronize"](self.h), "synchronize")
+
+    def get_stream(self):
+        st = C.c_void_p()
+        self._ck(self.lib.fn["get_stream"](self.h, C.byref(st)), "get_stream")
+        return st.value
 
     def marginalize(self, kind):
         H = np.zeros((PRIOR_DIM, PRIOR_DIM))

@@ -48,6 +48,8 @@ void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStr
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
+void vio_launch_batch_gn(const DeviceTables *tabs, int B, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
+                         size_t ps_lds, hipStream_t s);
 int vio_set_kernel_attributes();
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext);
 int xyz_lds_doubles_host(int G, int K);
@@ -146,6 +148,12 @@ struct vio_ctx {
     vio_exchange_fn hook = nullptr;
     void *comm = nullptr;                              // ncclComm_t of the native exchange (vio_comm_init)
     int cur_host = -1;                                 // LmState.cur as the host tracks it through GN iterations (-1: unknown)
+    uint64_t tables_gen = 1;                           // bumped whenever what make_tables_raw produces may have changed
+    // a batch this context leads (vio_batch_gn_iteration): the members' tables as a device array + what it was built from
+    std::vector<vio_ctx *> batch_members;
+    std::vector<uint64_t> batch_gens;
+    DevBuf<DeviceTables> d_batch_tabs;
+    int batch_iters = 0;                               // iterations since the array was built (its parity flips every window's cur)
     vio_status flush_status = VIO_OK;                  // what the flush_decide inside the last make_tables returned
     bool decide_pending = false;                       // GN mode: the last step's test has not run yet (k_assemble of the next iteration does it)
     void *hook_user = nullptr;
@@ -550,6 +558,7 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) T.imu_mask |= (c->imu_valid[k] ? 1 : 0) << k;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
+    T.list_off = pl.d_list_off.p; T.list = pl.d_list.p;
 #ifdef VIO_STAMPS
     (void)c->d_dbg.resize(16 * (size_t)(T.n_items + T.n_imu_items + 16));
     T.dbg = c->d_dbg.p;
@@ -656,6 +665,7 @@ vio_status activate(vio_ctx *c, Plan &pl, int marg) {
             VIOCHK(build_plan(c, pl, marg));
         }
         VIOCHK(push_to_device(c, pl));
+        ++c->tables_gen;
         c->active = &pl;
         c->dirty_inputs = false;
         c->linearized = false;
@@ -878,6 +888,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
+    c->d_batch_tabs.release();
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1142,6 +1153,79 @@ vio_status vio_gn_iteration(vio_ctx *c, double lambda) {
     return VIO_OK;
 }
 
+vio_status vio_get_stream(vio_ctx *c, void **stream) {
+    if (!c || !stream) return VIO_ERR_BAD_ARG;
+    *stream = (void *)c->stream;
+    return VIO_OK;
+}
+
+// B independent windows, one launch per kernel for all of them (grid.y = window): the regime in which the chip is full —
+// one window's k_pose_solve is a single workgroup on one of 256 CUs.  Every context keeps its own plan, buffers and
+// LmState; the leader (ctxs[0]) holds the device array of the members' tables.
+vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double lambda) {
+    if (!ctxs || count < 1 || !ctxs[0]) return VIO_ERR_BAD_ARG;
+    vio_ctx *c = ctxs[0];       // leader: errors are reported on it
+    hipSetDevice(c->cfg.device);
+    for (int i = 0; i < count; ++i) {
+        vio_ctx *m = ctxs[i];
+        if (!m) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_gn_iteration: null context");
+        if (m->cfg.device != c->cfg.device || m->stream != c->stream)
+            return fail(c, VIO_ERR_BAD_ARG, "vio_batch_gn_iteration: the contexts must share one device and one stream (vio_config.stream; vio_get_stream)");
+        if (sharded(m)) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_gn_iteration: sharded contexts cannot be batched");
+        if (m->lm_dim != 1) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_gn_iteration: inverse-depth windows only");
+    }
+    bool rebuild = (int)c->batch_members.size() != count;
+    for (int i = 0; i < count; ++i) {
+        vio_ctx *m = ctxs[i];
+        const uint64_t g0 = m->tables_gen;
+        vio_status st = activate(m, m->solve_plan, 0);
+        if (st != VIO_OK) return st == VIO_OK ? st : fail(c, st, "window " + std::to_string(i) + ": " + m->err);
+        if (!rebuild && (c->batch_members[i] != m || c->batch_gens[i] != m->tables_gen || g0 != m->tables_gen)) rebuild = true;
+        // a step waiting for its test belongs to the batch's own sequence only if the array is current; otherwise settle it
+        if (m->cur_host < 0 || (rebuild && m->decide_pending)) VIOCHK(read_lm(m));
+        if (!m->pairtab_valid) { DeviceTables T = make_tables_raw(m, m->solve_plan); T.cur_hint = m->cur_host; vio_launch_prepare(T, m->stream); m->pairtab_valid = true; }
+        if (lambda != m->gn_lambda) { vio_launch_set_lambda(m->d_lm.p, lambda, m->stream); m->gn_lambda = lambda; }
+    }
+    if (!rebuild)
+        for (int i = 0; i < count; ++i) if (ctxs[i]->decide_pending != ctxs[0]->decide_pending) rebuild = true;
+    if (rebuild) {
+        for (int i = 0; i < count; ++i) if (ctxs[i]->decide_pending || ctxs[i]->cur_host < 0) VIOCHK(read_lm(ctxs[i]));
+        std::vector<DeviceTables> tabs((size_t)count);
+        c->batch_members.assign(ctxs, ctxs + count);
+        c->batch_gens.resize((size_t)count);
+        for (int i = 0; i < count; ++i) {
+            tabs[i] = make_tables_raw(ctxs[i], ctxs[i]->solve_plan);
+            tabs[i].cur_hint = ctxs[i]->cur_host;         // this window's `cur` now; the kernels flip it by the iteration parity
+            c->batch_gens[i] = ctxs[i]->tables_gen;
+        }
+        HIPCHK(c->d_batch_tabs.resize((size_t)count));
+        HIPCHK(hipMemcpyAsync(c->d_batch_tabs.p, tabs.data(), (size_t)count * sizeof(DeviceTables), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));           // `tabs` goes out of scope
+        c->batch_iters = 0;
+    }
+    int max_blocks = 1, any_prior = 0;
+    size_t lds = 0;
+    for (int i = 0; i < count; ++i) {
+        const Plan &pl = ctxs[i]->solve_plan;
+        max_blocks = std::max<int>(max_blocks, (int)pl.items.size() + VIO_WINDOW_SIZE);
+        lds = std::max(lds, (size_t)pl.max_lds_doubles * 8);
+        any_prior |= ctxs[i]->has_prior;
+    }
+    const int test_prev = ctxs[0]->decide_pending ? 1 : 0;
+    vio_launch_batch_gn(c->d_batch_tabs.p, count, max_blocks, lds, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, c->stream);
+    HIPCHK(hipGetLastError());
+    ++c->batch_iters;
+    for (int i = 0; i < count; ++i) {
+        vio_ctx *m = ctxs[i];
+        m->decide_pending = true;
+        m->cur_host ^= 1;
+        m->device_ahead = true;
+        m->linearized = true;
+        m->natural_hs_valid = false;
+    }
+    return VIO_OK;
+}
+
 vio_status vio_synchronize(vio_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
@@ -1292,6 +1376,7 @@ vio_status vio_set_exchange_hook(vio_ctx *c, vio_exchange_fn fn, void *user) {
     if (!c) return VIO_ERR_BAD_ARG;
     c->hook = fn;
     c->hook_user = user;
+    ++c->tables_gen;
     return VIO_OK;
 }
 
@@ -1377,6 +1462,7 @@ vio_status vio_bind_exchange_buffers(vio_ctx *c, void *reduced, void *scalars) {
     if (!c) return VIO_ERR_BAD_ARG;
     c->ext_vis = (double *)reduced;
     c->ext_step = (double *)scalars;
+    ++c->tables_gen;
     c->linearized = false;
     return VIO_OK;
 }

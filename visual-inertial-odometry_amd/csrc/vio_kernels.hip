@@ -390,7 +390,7 @@ __device__ __forceinline__ void d_bprior_rows(const DeviceTables &T, int from, i
     }
 }
 
-__global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
+__device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (d_gated_off(T.lm, T.lm_gate)) return;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     const bool owe_prior = (T.gn_flags & 2) && T.has_prior;
     if (b >= T.n_items) {
         STAMP(T, 0);
-        if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, gridDim.x, tid & 63); }
+        if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
         d_imu_item(T, b - T.n_items, dyn_smem);
         STAMP(T, 5);
         STAMP_FLUSH(T);
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
 
     // ---------------- phase 1 ----------------
     STAMP(T, 1);
-    if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, gridDim.x, tid & 63);
+    if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, T.n_step_blocks, tid & 63);
     double chi_acc = 0.0;
     for (int o = tid; o < G * K; o += LIN_THREADS) {
         const int k = o / G, g = o - k * G;
@@ -858,6 +858,27 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) {
     STAMP(T, 5);
     STAMP_FLUSH(T);
 }
+__global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) { d_linearize_body(T); }
+
+// Batched launches (vio_batch_gn_iteration): B independent windows in one launch, blockIdx.y = window.  The windows'
+// tables sit in a device array built once per batch; what changes from iteration to iteration travels as kernel
+// arguments: the GN flags, and the parity of the iteration count, which every window's own starting `cur` is flipped by.
+struct BatchArgs {
+    const DeviceTables *tabs;
+    int32_t gn_flags;
+    int32_t parity;
+};
+__device__ __forceinline__ DeviceTables d_batch_tables(const BatchArgs &a) {
+    DeviceTables T = a.tabs[blockIdx.y];
+    T.gn_flags = a.gn_flags;
+    T.cur_hint ^= a.parity;
+    return T;
+}
+__global__ __launch_bounds__(LIN_THREADS) void k_linearize_b(BatchArgs a) {
+    const DeviceTables T = d_batch_tables(a);
+    if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;       // the grid is the widest window's
+    d_linearize_body(T);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // k_reduce: fixed-order sum of the item slabs through inverted lists built at upload time.
@@ -898,7 +919,7 @@ __device__ __forceinline__ void d_errprior_row(const double *jt, const double *b
     if (lane == 63) err[i] = s;
 }
 
-__global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
+__device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
     // A list is cut into interleaved slots (entry e belongs to slot e mod nslots); a group of 36 (18) threads owns a
     // slot and sums its entries with 8 gathers in flight, then the slots are added in slot order: the summation order
     // is fixed by the list, not by timing.  Three dependent round trips (offsets, list, slab) whatever the list length.
@@ -1014,6 +1035,17 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) {
         }
     }
 }
+__global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) { d_reduce_body(R); }
+// batched: the tables of k_reduce are made of the window's DeviceTables; bit 0 of gn_flags here = "a step is waiting for its test"
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_b(BatchArgs a) {
+    const DeviceTables T = d_batch_tables(a);
+    const bool test_prev = (a.gn_flags & 1) != 0, err_prev = test_prev && T.has_prior;
+    if ((int)blockIdx.x >= VIO_NPAIR + VIO_NCB + 1 && !err_prev) return;
+    const int cur = T.cur_hint;
+    ReduceTables R{T.list_off, T.list, T.slab, T.vis, test_prev ? T.step_part : nullptr, T.n_items, 0, T.lm,
+                   err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + cur * 176 : nullptr, err_prev ? T.errprior + cur * 160 : nullptr};
+    d_reduce_body(R);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // k_assemble: row i of H_pp_schur_ (without lambda) = reduced visual (72 -> 171) + IMU blocks + prior
@@ -1098,7 +1130,7 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid
 // (every workgroup recomputes the 171 ranks, 5 threads per entry: cheaper than one more launch).  Workgroups 171..175: identity padding.
 // Workgroup 176: right-hand side row, b_pp_schur_, pose part of b_, diag(Hessian_).
 #define ASM_THREADS 896        // 5 x 171 threads rank-sort, then 171 write the row
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
+__device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
     __shared__ double sDg[176];
     __shared__ int sPerm[176];
     __shared__ int sCnt[5 * 176];
@@ -1192,6 +1224,8 @@ __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) {
         if (t < PS_NP) T.Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
     }
 }
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) { d_assemble_body(T); }
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble_b(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_assemble_body(T); }
 
 // ---------------------------------------------------------------------------------------------------------
 // k_pose_solve: single workgroup, 1024 threads.  (H_pp_schur_ + lambda I) dx = b_pp_schur_ (problem.cc:434-439).
@@ -1286,7 +1320,7 @@ __device__ __noinline__ void ps_factor_diag(lds_double *tile, lds_double *sI, ld
 }
 
 
-__global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
+__device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
     double *P = dyn_smem;                          // 66 tiles of 16x17, then the rhs row (192)
     double *sY = P + PS_YOFF;
     double *sDinv = P + PS_PACKED;                 // 176
@@ -1660,6 +1694,8 @@ __global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) {
     if (tid >= 384 && tid < 384 + STATE_STRIDE) T.state[trial * STATE_STRIDE + (tid - 384)] = sState[tid - 384];
     PS_OUT(3);
 }
+__global__ __launch_bounds__(PS_THREADS) void k_pose_solve(DeviceTables T) { d_pose_solve_body(T); }
+__global__ __launch_bounds__(PS_THREADS) void k_pose_solve_b(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_pose_solve_body(T); }
 
 // ---------------------------------------------------------------------------------------------------------
 // k_backsub: one wave per item.  delta_lambda = Hmm^-1 (bmm - Hmp dx_p) (problem.cc:445), trial inverse depth,
@@ -1698,7 +1734,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
     const int cur = d_cur(T);
     const int which = (mode == 1) ? cur : (cur ^ 1);
     // flush of a GN step (gn_flags bit 3): its b_prior' rows, which the next k_linearize would have formed
-    if ((T.gn_flags & 8) && T.has_prior && (lane >> 6) == 1) d_bprior_rows(T, cur, cur ^ 1, b, gridDim.x, lane & 63);
+    if ((T.gn_flags & 8) && T.has_prior && (lane >> 6) == 1) d_bprior_rows(T, cur, cur ^ 1, b, T.n_step_blocks, lane & 63);
     if (b >= T.n_items) { d_backsub_imu_block(T, mode, which, b, lane); return; }
     __shared__ double sPairCD[VIO_MAXK * 12];
     __shared__ double sDxp[176];
@@ -2011,6 +2047,17 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
     if (T.lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
     else hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
+// batched GN iteration (inverse-depth windows): grid.y = window
+void vio_launch_batch_gn(const DeviceTables *tabs, int B, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
+                         size_t ps_lds, hipStream_t s) {
+    BatchArgs a{tabs, test_prev ? 2 : 0, parity};
+    hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+    a.gn_flags = test_prev ? 1 : 0;
+    hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(ASM_THREADS), 0, s, a);
+    a.gn_flags = 4;
+    hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
+}
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1 + (R.errprior ? RED_ERR_BLOCKS : 0)), dim3(RED_THREADS), 0, s, R);
 }
@@ -2055,6 +2102,8 @@ int xyz_lds_doubles_host(int G, int K) { return xyz_lds_doubles(G, K); }
 int vio_set_kernel_attributes() {
     hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     hipError_t e2 = hipFuncSetAttribute((const void *)k_pose_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    if (hipFuncSetAttribute((const void *)k_linearize_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_pose_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     hipError_t e3 = hipFuncSetAttribute((const void *)k_linearize_xyz, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -1;
 }

@@ -164,6 +164,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur
     int32_t imu_mask;            // bit k: IMU edge k exists (the host's copy of imu_valid: saves the kernels a dependent load)
     int32_t lm_gate;             // device-driven LM loop: 0 run; 2: skip if lm->stop; 3: skip unless lm->need_linearize && !lm->stop
+    const int32_t *list_off;     // k_reduce's inverted lists (a batched launch builds its ReduceTables from here)
+    const int32_t *list;
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
     LmState *lm;
     unsigned long long *dbg;     // diagnostic builds only (-DVIO_STAMPS): [block][16] s_memtime stamps
