@@ -222,27 +222,60 @@ void marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double 
         for (int k = 0; k < m2; ++k) s += tempB[(size_t)i * m2 + k] * b[n2 + k];
         bp[i] = b[i] - s;
     }
-    std::vector<double> ev2(n2), V2((size_t)n2 * n2);
-    symmetric_eigen(n2, Hp.data(), ev2.data(), V2.data());
+    // Eigen-decomposition of the reduced system (problem.cc:766).  Rows and columns that are exactly zero — frames the
+    // marginalised frame's landmarks and the old prior do not reach: 90 of the 156 in the steady state of a window with
+    // tracks of 4 frames — are eigenvectors e_i of eigenvalue 0 already and fall under the 1e-8 cut whatever basis a solver
+    // picks for them, so only the block they leave is decomposed (cost ~ n^3).
+    std::vector<int> live;
     for (int i = 0; i < n2; ++i) {
-        const double sinv = ev2[i] > eps ? std::sqrt(1.0 / ev2[i]) : 0.0;
+        bool any = false;
+        for (int j = 0; j < n2 && !any; ++j) any = Hp[(size_t)i * n2 + j] != 0.0 || Hp[(size_t)j * n2 + i] != 0.0;
+        if (any) live.push_back(i);
+    }
+    const int nl = (int)live.size(), nz = n2 - nl;
+    std::vector<double> ev2(n2, 0.0), V2((size_t)n2 * n2, 0.0);
+    {
+        std::vector<double> Hc((size_t)std::max(nl, 1) * std::max(nl, 1)), evc(std::max(nl, 1)), Vc((size_t)std::max(nl, 1) * std::max(nl, 1));
+        for (int a = 0; a < nl; ++a)
+            for (int c = 0; c < nl; ++c) Hc[(size_t)a * nl + c] = Hp[(size_t)live[a] * n2 + live[c]];
+        if (nl > 0) symmetric_eigen(nl, Hc.data(), evc.data(), Vc.data());
+        // columns 0 .. nz-1: the unit vectors of the dead indices (eigenvalue 0); then the live block's, ascending.  (A negative
+        // eigenvalue of the live block would sort before the zeros in the reference; both are below the cut.)
+        int col = 0;
+        std::vector<char> is_live(n2, 0);
+        for (int a = 0; a < nl; ++a) is_live[live[a]] = 1;
+        for (int i = 0; i < n2; ++i) if (!is_live[i]) V2[(size_t)i * n2 + col++] = 1.0;
+        for (int k = 0; k < nl; ++k) {
+            ev2[nz + k] = evc[k];
+            for (int a = 0; a < nl; ++a) V2[(size_t)live[a] * n2 + nz + k] = Vc[(size_t)a * nl + k];
+        }
+    }
+    std::vector<int> kept;      // eigenvalues above the cut: the only ones the three products below see
+    for (int k = 0; k < n2; ++k) if (ev2[k] > eps) kept.push_back(k);
+    std::fill(jtout, jtout + (size_t)n2 * n2, 0.0);
+    for (int i : kept) {
+        const double sinv = std::sqrt(1.0 / ev2[i]);
         for (int j = 0; j < n2; ++j) jtout[(size_t)i * n2 + j] = sinv * V2[(size_t)j * n2 + i];
     }
-    for (int i = 0; i < n2; ++i) {
+    std::fill(errout, errout + n2, 0.0);
+    for (int i : kept) {                                    // err_prior = -Jt_prior_inv b (problem.cc:774); the other rows of Jt are zero
         double s = 0;
         for (int j = 0; j < n2; ++j) s += -jtout[(size_t)i * n2 + j] * bp[j];
         errout[i] = s;
     }
-    {   // H_prior = J^T J with J = sqrt(S) V^T (problem.cc:775-777): sum_k V_ik s_k V_jk, k ascending; (V_ik s_k) formed once
-        std::vector<double> VS((size_t)n2 * n2);
-        for (int i = 0; i < n2; ++i)
-            for (int k = 0; k < n2; ++k) VS[(size_t)i * n2 + k] = V2[(size_t)i * n2 + k] * (ev2[k] > eps ? ev2[k] : 0.0);
-        for (int i = 0; i < n2; ++i)
-            for (int j = 0; j < n2; ++j) {
-                const double *a = &VS[(size_t)i * n2], *c = &V2[(size_t)j * n2];
+    {   // H_prior = J^T J with J = sqrt(S) V^T (problem.cc:775-777): sum over the kept k of V_ik s_k V_jk, k ascending; the
+        // kept eigenvectors live on the live indices only, every other entry of the product is an exact zero
+        const int nk = (int)kept.size();
+        std::vector<double> VS((size_t)std::max(nl, 1) * std::max(nk, 1)), VK((size_t)std::max(nl, 1) * std::max(nk, 1));
+        for (int a = 0; a < nl; ++a)
+            for (int q = 0; q < nk; ++q) { VK[(size_t)a * nk + q] = V2[(size_t)live[a] * n2 + kept[q]]; VS[(size_t)a * nk + q] = VK[(size_t)a * nk + q] * ev2[kept[q]]; }
+        std::fill(Hout, Hout + (size_t)n2 * n2, 0.0);
+        for (int a = 0; a < nl; ++a)
+            for (int c = 0; c < nl; ++c) {
+                const double *x = &VS[(size_t)a * nk], *y = &VK[(size_t)c * nk];
                 double s = 0;
-                for (int k = 0; k < n2; ++k) s += a[k] * c[k];
-                Hout[(size_t)i * n2 + j] = std::fabs(s) > 1e-9 ? s : 0.0;     // problem.cc:778
+                for (int q = 0; q < nk; ++q) s += x[q] * y[q];
+                Hout[(size_t)live[a] * n2 + live[c]] = std::fabs(s) > 1e-9 ? s : 0.0;     // problem.cc:778
             }
     }
     std::memcpy(bout, bp.data(), sizeof(double) * n2);
