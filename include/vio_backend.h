@@ -117,6 +117,10 @@ vio_status vio_create(const vio_config *cfg, struct vio_ctx **out);
 void vio_destroy(struct vio_ctx *ctx);
 const char *vio_last_error(const struct vio_ctx *ctx);   /* valid until the next call on ctx */
 void vio_default_config(vio_config *cfg);                /* the reference's constants */
+/* Change what a Problem decides per graph — ext_fixed (SetFixed), the loss and its delta, the edge information, gravity —
+ * on a living context, so that one context (its stream and device buffers) serves every Problem a process builds
+ * (problem_hip.cc keeps one).  device, stream and the shard fields must be the ones the context was created with. */
+vio_status vio_set_config(struct vio_ctx *ctx, const vio_config *cfg);
 
 /* ---- graph construction: replaces AddVertex/AddEdge in estimator.cpp:909-1034 ----------- */
 /* para_Pose[11][7], para_SpeedBias[11][9], para_Ex_Pose[0][7]  (estimator.h:113-119) */

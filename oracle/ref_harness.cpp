@@ -53,6 +53,7 @@
 #undef vio_destroy
 #undef vio_last_error
 #undef vio_default_config
+#undef vio_set_config
 #undef vio_set_window
 #undef vio_set_landmarks
 #undef vio_set_observations
@@ -314,6 +315,7 @@ vio_status vior_create(const vio_config *cfg, vior_ctx **out) {
     return VIO_OK;
 }
 void vior_destroy(vior_ctx *c) { delete c; }
+vio_status vior_set_config(vior_ctx *c, const vio_config *cfg) { if (!c || !cfg) return VIO_ERR_BAD_ARG; c->cfg = *cfg; c->g.reset(); return VIO_OK; }
 const char *vior_last_error(const vior_ctx *c) { return c ? c->err.c_str() : "null"; }
 
 vio_status vior_set_window(vior_ctx *c, const double *poses, const double *sb, const double *ext) {

@@ -1019,6 +1019,14 @@ vio_status vio_create(const vio_config *cfg, struct vioo_ctx **out) {
     return VIO_OK;
 }
 
+vio_status vio_set_config(struct vioo_ctx *c, const vio_config *cfg) {
+    if (!c || !cfg) return VIO_ERR_BAD_ARG;
+    c->cfg = *cfg;
+    if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
+    c->linearized = 0;
+    return VIO_OK;
+}
+
 void vio_destroy(struct vioo_ctx *c) {
     if (!c) return;
     free(c->invd); free(c->invd_bak); free(c->lm); free(c->host); free(c->target);

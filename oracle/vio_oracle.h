@@ -14,6 +14,7 @@
 #define vio_destroy vioo_destroy
 #define vio_last_error vioo_last_error
 #define vio_default_config vioo_default_config
+#define vio_set_config vioo_set_config
 #define vio_set_window vioo_set_window
 #define vio_set_landmarks vioo_set_landmarks
 #define vio_set_observations vioo_set_observations

@@ -34,6 +34,34 @@ def test_solve_through_reference_objects(vio, oracle_lib, shim_lib, n, seed, rag
     assert np.abs(cs.get_landmarks() - co.get_landmarks()).max() <= 1e-11
 
 
+@pytest.mark.parametrize("n,seed,ragged,ext_fixed", [(80, 15, False, 1), (150, 16, True, 0)])
+def test_xyz_solve_through_reference_objects(vio, oracle_lib, shim_lib, n, seed, ragged, ext_fixed):
+    """VertexPointXYZ + EdgeReprojectionXYZ graphs through the shim: the edges' own (qic, tic) become the window's extrinsic."""
+    w = vio.synth.make_window_xyz(n, seed=seed, ragged=ragged)
+    cs, co = shim_lib.context(ext_fixed=ext_fixed), oracle_lib.context(ext_fixed=ext_fixed)
+    cs.load(w)
+    co.load(w)
+    cs.solve(10)
+    co.solve(10)
+    for a, b in zip(cs.get_window(), co.get_window()):
+        assert np.abs(a - b).max() <= 1e-11
+    assert np.abs(cs.get_landmarks_xyz() - co.get_landmarks_xyz()).max() <= 1e-11
+
+
+def test_one_backend_context_serves_every_problem(vio, oracle_lib, shim_lib):
+    """The shim keeps one backend context for the process and re-configures it per graph: graphs of different size, loss,
+    extrinsic flag and landmark kind in a row give what fresh contexts give."""
+    seq = [(vio.synth.make_window(60, seed=1), dict(ext_fixed=1, loss_type=2)), (vio.synth.make_window_xyz(40, seed=2), dict(ext_fixed=1, loss_type=2)),
+           (vio.synth.make_window(90, seed=3, ragged=True), dict(ext_fixed=0, loss_type=1)), (vio.synth.make_window(60, seed=1), dict(ext_fixed=1, loss_type=0))]
+    for w, kw in seq:
+        cs, co = shim_lib.context(**kw), oracle_lib.context(**kw)
+        cs.load(w)
+        co.load(w)
+        cs.solve(10)
+        co.solve(10)
+        assert np.abs(cs.get_window()[0] - co.get_window()[0]).max() <= 1e-11
+
+
 def test_window_chain_through_reference_objects(vio, oracle_lib, shim_lib, ref_lib):
     """Solve, MargOldFrame, next window with the prior (Solve updates b_prior / err_prior), MargNewFrame: the sequence of
     Estimator::backendOptimization, every Problem call going through the shim; and the reference's own problem.cc beside it."""
@@ -114,3 +142,11 @@ def test_drop_in_on_the_gpu(vio, oracle_lib):
     cs.solve(10)
     co.solve(10)
     assert np.abs(cs.get_window()[0] - co.get_window()[0]).max() <= 1e-6
+    # the same (one, persistent) backend context, now for a graph of XYZ landmarks
+    w3 = vio.synth.make_window_xyz(300, seed=43, ragged=True)
+    cs.load(w3)
+    co.load(w3)
+    cs.solve(10)
+    co.solve(10)
+    assert np.abs(cs.get_window()[0] - co.get_window()[0]).max() <= 1e-6
+    assert np.abs(cs.get_landmarks_xyz() - co.get_landmarks_xyz()).max() <= 1e-6

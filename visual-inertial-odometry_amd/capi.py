@@ -85,7 +85,7 @@ class VioLib:
                "synchronize", "marginalize", "get_window", "get_landmarks", "get_prior", "get_delta",
                "get_schur_system", "get_landmark_system", "get_pose_gradient", "exchange_buffers",
                "set_exchange_hook", "bind_exchange_buffers", "set_landmarks_xyz", "set_observations_xyz",
-               "get_landmarks_xyz"]
+               "get_landmarks_xyz", "set_config"]
     # outside the backend proper: the compiled-reference harness (vior_) has no FeatureManager
     OPTIONAL = ["triangulate"]
 
@@ -182,6 +182,15 @@ class VioContext:
         st = lib.fn["create"](C.byref(cfg), C.byref(self.h))
         if st != 0:
             raise VioError(st, lib.prefix + "create")
+
+    def set_config(self, **overrides):
+        """vio_set_config: ext_fixed / loss_type / loss_delta / reproj_sqrt_info / gravity on the living context."""
+        for k, v in overrides.items():
+            if k == "gravity":
+                self.cfg.gravity[:] = list(v)
+            else:
+                setattr(self.cfg, k, v)
+        self._ck(self.lib.fn["set_config"](self.h, C.byref(self.cfg)), "set_config")
 
     def close(self):
         if self.h:

@@ -878,6 +878,23 @@ vio_status vio_create(const vio_config *cfg, vio_ctx **out) {
     return VIO_OK;
 }
 
+vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
+    if (!c || !cfg) return VIO_ERR_BAD_ARG;
+    if (cfg->device != c->cfg.device || (cfg->stream && (hipStream_t)cfg->stream != c->stream) || cfg->shard_rank != c->cfg.shard_rank ||
+        std::max(cfg->shard_count, 1) != c->cfg.shard_count)
+        return fail(c, VIO_ERR_BAD_ARG, "vio_set_config: device, stream and shard fields belong to the context's creation");
+    hipSetDevice(c->cfg.device);
+    VIOCHK(pull_from_device(c));
+    void *keep_stream = c->cfg.stream;
+    const bool replan = cfg->ext_fixed != c->cfg.ext_fixed;     // the patterns carry an extrinsic block or not
+    c->cfg = *cfg;
+    c->cfg.stream = keep_stream;
+    if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
+    if (replan) c->topo_dirty = true;
+    c->dirty_inputs = true;
+    return VIO_OK;
+}
+
 void vio_destroy(vio_ctx *c) {
     if (!c) return;
     hipSetDevice(c->cfg.device);

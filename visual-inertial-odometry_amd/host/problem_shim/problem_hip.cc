@@ -4,7 +4,8 @@
 // myslam::backend::Problem that Estimator uses — AddVertex, AddEdge, ExtendHessiansPriorSize, Solve, Marginalize (the
 // vector form), the destructor's id reset — on top of the C ABI of include/vio_backend.h.  AddVertex / AddEdge only
 // record the graph (the containers the header declares); Solve and Marginalize flatten it into the window layout
-//   [ext | (pose, speed-bias) x 11 | inverse depths],  one row per EdgeReprojection,  one record per EdgeImu,
+//   [ext | (pose, speed-bias) x 11 | inverse depths or XYZ points],  one row per EdgeReprojection / EdgeReprojectionXYZ,
+//   one record per EdgeImu,
 // hand it to the backend, and write the results back into the Vertex objects and the prior members, so that an
 // unmodified estimator.cpp (problemSolve :902-1073, MargOldFrame :693-829, MargNewFrame :830-901) links against it.
 // A maintainer swaps this file for problem.cc in VM/CMakeLists.txt and links libvio_hip.so.
@@ -15,6 +16,11 @@
 // reference's own headers (no layout change); the third through vio_shim_edge_imu(), defined below for the reference's
 // EdgeImu when VIO_SHIM_WITH_EDGE_IMU is set (its header needs Ceres: the reference tree has it, this repo's image
 // does not) and by the test harness otherwise.
+//
+// One backend context serves every Problem of the process (a function-local static, re-configured per graph with
+// vio_set_config): the reference builds a fresh Problem per call — one for Solve, another for Marginalize, each with its own
+// graph (MargOldFrame keeps the landmarks hosted in frame 0 only) — so two uploads per frame are the reference's own
+// construction; what is not repeated is the stream and the ~30 device allocations behind the handle.
 //
 // Only the SLAM problem type over the window layout is supported; anything else fails loudly (Solve returns false
 // after printing the backend's message).  RemoveVertex/RemoveEdge/GetOutlierEdges/TestComputePrior, which Estimator
@@ -41,10 +47,12 @@
 #include "backend/vertex_pose.h"
 #include "backend/vertex_speedbias.h"
 #include "backend/vertex_inverse_depth.h"
+#include "backend/vertex_point_xyz.h"
 #include "backend/edge_reprojection.h"
 #include "backend/loss_function.h"
 #ifdef VIO_SHIM_WITH_EDGE_IMU
 #include "backend/edge_imu.h"
+#include "parameters.h"          // the global G that IntegrationBase::evaluate reads (parameters.h:46, integration_base.h:178-180)
 #endif
 #undef private
 #undef protected
@@ -63,6 +71,10 @@ vio_status ABI(create)(const vio_config *, struct vio_ctx **);
 void ABI(destroy)(struct vio_ctx *);
 const char *ABI(last_error)(const struct vio_ctx *);
 void ABI(default_config)(vio_config *);
+vio_status ABI(set_config)(struct vio_ctx *, const vio_config *);
+vio_status ABI(set_landmarks_xyz)(struct vio_ctx *, int64_t, const double *);
+vio_status ABI(set_observations_xyz)(struct vio_ctx *, int64_t, const int32_t *, const int32_t *, const double *);
+vio_status ABI(get_landmarks_xyz)(struct vio_ctx *, int64_t, double *);
 vio_status ABI(set_window)(struct vio_ctx *, const double *, const double *, const double *);
 vio_status ABI(set_landmarks)(struct vio_ctx *, int64_t, const double *);
 vio_status ABI(set_observations)(struct vio_ctx *, int64_t, const int32_t *, const int32_t *, const int32_t *, const double *, const double *);
@@ -114,8 +126,10 @@ bool is_pose_type(const std::shared_ptr<Vertex> &v) {
 struct FlatWindow {
     std::shared_ptr<Vertex> ext;
     std::vector<std::shared_ptr<Vertex>> pose, sb, lm;          // frames in id order, landmarks in id order
-    std::vector<int32_t> o_lm, o_host, o_target;
+    std::vector<int32_t> o_lm, o_host, o_target;                // XYZ: o_target = the observing frame, o_pj = the observation
     std::vector<double> o_pi, o_pj;
+    bool xyz = false;                                           // VertexPointXYZ landmarks observed through EdgeReprojectionXYZ
+    double xyz_ext[7];                                          // their camera extrinsic: a constant of those edges (qic, tic)
     vio_config cfg;
     bool ok = false;
     std::string why;
@@ -141,6 +155,9 @@ int loss_of(LossFunction *lf, double *delta) {
 FlatWindow flatten(Problem &p) {
     FlatWindow w;
     ABI(default_config)(&w.cfg);
+#ifdef VIO_SHIM_WITH_EDGE_IMU
+    for (int k = 0; k < 3; ++k) w.cfg.gravity[k] = G[k];
+#endif
     vio_shim_config(&w.cfg);
     std::vector<std::shared_ptr<Edge>> edges;
     for (auto &kv : p.edges_) edges.push_back(kv.second);
@@ -154,20 +171,34 @@ FlatWindow flatten(Problem &p) {
             if (!w.ext) w.ext = v;
             if (v->Id() != w.ext->Id()) w.pose.push_back(v);
         } else if (t == "VertexSpeedBias") w.sb.push_back(v);
-        else if (t == "VertexInverseDepth") w.lm.push_back(v);
+        else if (t == "VertexInverseDepth") { if (w.xyz) { w.why = "a window holds one kind of landmark"; return w; } w.lm.push_back(v); }
+        else if (t == "VertexPointXYZ") { if (!w.xyz && !w.lm.empty()) { w.why = "a window holds one kind of landmark"; return w; } w.xyz = true; w.lm.push_back(v); }
         else { w.why = "vertex type outside the window layout: " + t; return w; }
     }
     if (!w.ext || (int)w.pose.size() != NF || (int)w.sb.size() != NF) { w.why = "expected 1 extrinsic + 11 (pose, speed-bias) pairs"; return w; }
     w.cfg.ext_fixed = w.ext->IsFixed() ? 1 : 0;
     bool have_loss = false;
+    bool have_ext = false;
     for (auto &e : edges) {
-        if (e->TypeInfo() != "EdgeReprojection") continue;
+        if (e->TypeInfo() == "EdgeReprojectionXYZ") {
+            auto *re = static_cast<EdgeReprojectionXYZ *>(e.get());
+            const int l = index_of(w.lm, e->verticies_[0]), f = index_of(w.pose, e->verticies_[1]);
+            if (!w.xyz || l < 0 || f < 0) { w.why = "XYZ reprojection edge with vertices outside the window"; return w; }
+            const double ex[7] = {re->tic[0], re->tic[1], re->tic[2], re->qic.x(), re->qic.y(), re->qic.z(), re->qic.w()};
+            if (have_ext && std::memcmp(ex, w.xyz_ext, sizeof(ex)) != 0) { w.why = "XYZ edges differ in their camera extrinsic"; return w; }
+            std::memcpy(w.xyz_ext, ex, sizeof(ex));
+            have_ext = true;
+            w.o_lm.push_back(l); w.o_target.push_back(f);
+            w.o_pj.push_back(re->obs_[0] / re->obs_[2]); w.o_pj.push_back(re->obs_[1] / re->obs_[2]);
+        } else if (e->TypeInfo() != "EdgeReprojection") continue;
+        else {
         const int l = index_of(w.lm, e->verticies_[0]), h = index_of(w.pose, e->verticies_[1]), t = index_of(w.pose, e->verticies_[2]);
         if (l < 0 || h < 0 || t < 0 || e->verticies_[3]->Id() != w.ext->Id()) { w.why = "reprojection edge with vertices outside the window"; return w; }
         auto *re = static_cast<EdgeReprojection *>(e.get());
         w.o_lm.push_back(l); w.o_host.push_back(h); w.o_target.push_back(t);
         w.o_pi.push_back(re->pts_i_[0] / re->pts_i_[2]); w.o_pi.push_back(re->pts_i_[1] / re->pts_i_[2]);
         w.o_pj.push_back(re->pts_j_[0] / re->pts_j_[2]); w.o_pj.push_back(re->pts_j_[1] / re->pts_j_[2]);
+        }
         const MatXX info = e->Information();
         double delta;
         const int loss = loss_of(e->lossfunction_, &delta);
@@ -186,20 +217,32 @@ struct Ctx {
     ~Ctx() { if (h) ABI(destroy)(h); }
 };
 
-// window + landmarks + observations + IMU edges + prior into a fresh backend context
+// the one backend context of the process, created at the first graph and re-configured for every later one
+Ctx &shared_ctx() {
+    static Ctx c;
+    return c;
+}
+
+// window + landmarks + observations + IMU edges + prior into the backend context
 bool upload(Problem &p, const FlatWindow &w, Ctx &c) {
-    if (ABI(create)(&w.cfg, &c.h) != VIO_OK) { std::cerr << "vio_create failed" << std::endl; return false; }
+    if (!c.h) {
+        if (ABI(create)(&w.cfg, &c.h) != VIO_OK) { c.h = nullptr; std::cerr << "vio_create failed" << std::endl; return false; }
+    } else if (ABI(set_config)(c.h, &w.cfg) != VIO_OK) { std::cerr << "vio_set_config: " << ABI(last_error)(c.h) << std::endl; return false; }
     double poses[NF * 7], sbs[NF * 9], ext[7];
     for (int i = 0; i < NF; ++i) {
         for (int k = 0; k < 7; ++k) poses[7 * i + k] = w.pose[i]->parameters_[k];
         for (int k = 0; k < 9; ++k) sbs[9 * i + k] = w.sb[i]->parameters_[k];
     }
-    for (int k = 0; k < 7; ++k) ext[k] = w.ext->parameters_[k];
-    std::vector<double> invd(w.lm.size());
-    for (size_t l = 0; l < w.lm.size(); ++l) invd[l] = w.lm[l]->parameters_[0];
-    bool ok = ABI(set_window)(c.h, poses, sbs, ext) == VIO_OK
-           && ABI(set_landmarks)(c.h, (int64_t)invd.size(), invd.data()) == VIO_OK
-           && ABI(set_observations)(c.h, (int64_t)w.o_lm.size(), w.o_lm.data(), w.o_host.data(), w.o_target.data(), w.o_pi.data(), w.o_pj.data()) == VIO_OK;
+    for (int k = 0; k < 7; ++k) ext[k] = w.xyz && !w.o_lm.empty() ? w.xyz_ext[k] : w.ext->parameters_[k];
+    const int dim = w.xyz ? 3 : 1;
+    std::vector<double> lmv(w.lm.size() * dim);
+    for (size_t l = 0; l < w.lm.size(); ++l) for (int k = 0; k < dim; ++k) lmv[dim * l + k] = w.lm[l]->parameters_[k];
+    bool ok = ABI(set_window)(c.h, poses, sbs, ext) == VIO_OK;
+    if (w.xyz) ok = ok && ABI(set_landmarks_xyz)(c.h, (int64_t)w.lm.size(), lmv.data()) == VIO_OK
+                       && ABI(set_observations_xyz)(c.h, (int64_t)w.o_lm.size(), w.o_lm.data(), w.o_target.data(), w.o_pj.data()) == VIO_OK;
+    else ok = ok && ABI(set_landmarks)(c.h, (int64_t)lmv.size(), lmv.data()) == VIO_OK
+                 && ABI(set_observations)(c.h, (int64_t)w.o_lm.size(), w.o_lm.data(), w.o_host.data(), w.o_target.data(), w.o_pi.data(), w.o_pj.data()) == VIO_OK;
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) ok = ok && ABI(set_imu)(c.h, k, nullptr) == VIO_OK;      // the context outlives the graph: start from no IMU edges
     for (auto &kv : p.edges_) {
         Edge *e = kv.second.get();
         if (e->TypeInfo() != "EdgeImu") continue;
@@ -223,7 +266,7 @@ bool upload(Problem &p, const FlatWindow &w, Ctx &c) {
             for (int j = 0; j < PRD; ++j) { H[(size_t)i * PRD + j] = p.H_prior_(i, j); J[(size_t)i * PRD + j] = p.Jt_prior_inv_(i, j); }
         }
         ok = ok && ABI(set_prior)(c.h, PRD, H.data(), b.data(), err.data(), J.data()) == VIO_OK;
-    }
+    } else ok = ok && ABI(set_prior)(c.h, 0, nullptr, nullptr, nullptr, nullptr) == VIO_OK;
     if (!ok) std::cerr << "backend rejected the graph: " << ABI(last_error)(c.h) << std::endl;
     return ok;
 }
@@ -266,20 +309,22 @@ bool Problem::Solve(int iterations) {
     if (problemType_ != ProblemType::SLAM_PROBLEM) { std::cerr << "problem_hip.cc: only SLAM_PROBLEM is supported" << std::endl; return false; }
     FlatWindow w = flatten(*this);
     if (!w.ok) { std::cerr << "problem_hip.cc: " << w.why << std::endl; return false; }
-    Ctx c;
+    Ctx &c = shared_ctx();
     if (!upload(*this, w, c)) return false;
     vio_solve_report rep;
     const vio_status st = ABI(solve)(c.h, iterations, &rep);
     if (st != VIO_OK && st != VIO_ERR_NOT_FINITE) { std::cerr << "vio_solve: " << ABI(last_error)(c.h) << std::endl; return false; }
     double poses[NF * 7], sbs[NF * 9], ext[7];
-    std::vector<double> invd(w.lm.size());
-    if (ABI(get_window)(c.h, poses, sbs, ext) != VIO_OK || ABI(get_landmarks)(c.h, (int64_t)invd.size(), invd.data()) != VIO_OK) return false;
+    const int dim = w.xyz ? 3 : 1;
+    std::vector<double> lmv(w.lm.size() * dim);
+    if (ABI(get_window)(c.h, poses, sbs, ext) != VIO_OK) return false;
+    if ((w.xyz ? ABI(get_landmarks_xyz)(c.h, (int64_t)w.lm.size(), lmv.data()) : ABI(get_landmarks)(c.h, (int64_t)lmv.size(), lmv.data())) != VIO_OK) return false;
     for (int i = 0; i < NF; ++i) {
         for (int k = 0; k < 7; ++k) w.pose[i]->parameters_[k] = poses[7 * i + k];
         for (int k = 0; k < 9; ++k) w.sb[i]->parameters_[k] = sbs[9 * i + k];
     }
-    for (int k = 0; k < 7; ++k) w.ext->parameters_[k] = ext[k];
-    for (size_t l = 0; l < w.lm.size(); ++l) w.lm[l]->parameters_[0] = invd[l];
+    if (!w.xyz) for (int k = 0; k < 7; ++k) w.ext->parameters_[k] = ext[k];      // (XYZ edges do not name the extrinsic vertex: it gets no update)
+    for (size_t l = 0; l < w.lm.size(); ++l) for (int k = 0; k < dim; ++k) w.lm[l]->parameters_[k] = lmv[dim * l + k];
     if (err_prior_.rows() > 0) {                    // b_prior_ / err_prior_ after the first-order updates (estimator.cpp:1040-1049)
         double b[VIO_POSE_DIM], err[VIO_PRIOR_DIM];
         if (ABI(get_prior)(c.h, b, err) != VIO_OK) return false;
@@ -298,7 +343,7 @@ bool Problem::Marginalize(const std::vector<std::shared_ptr<Vertex>> margVertexs
     if (!w.ok) { std::cerr << "problem_hip.cc: " << w.why << std::endl; return false; }
     const int k = margVertexs.empty() ? -1 : index_of(w.pose, margVertexs[0]);
     if (k != 0 && k != VIO_WINDOW_SIZE - 1) { std::cerr << "problem_hip.cc: Marginalize of frame " << k << " is not a window operation" << std::endl; return false; }
-    Ctx c;
+    Ctx &c = shared_ctx();
     if (!upload(*this, w, c)) return false;
     std::vector<double> H((size_t)PRD * PRD), J((size_t)PRD * PRD), b(PRD), err(PRD);
     if (ABI(marginalize)(c.h, k == 0 ? VIO_MARG_OLD : VIO_MARG_SECOND_NEW, H.data(), b.data(), err.data(), J.data()) != VIO_OK) {
