@@ -233,6 +233,55 @@ def check_window_against_golden(vio, lib, path, dx_tol=1e-9, state_tol=1e-6, lam
         check_prior(m, {k: z["marg%d_%s" % (kind, k)] for k in tu.PRIOR_FIELDS})
 
 
+def solve_trace_stepwise(lib, w, kw, iterations=10):
+    """Problem::Solve's loop (problem.cc:188-245) through the single-step entry points; per outer iteration
+    (state vector, chi2, lambda, trials).  Same loop as tools/parity_trace.py, which made tests/golden/solve_trace.npz."""
+    c = lib.context(**kw)
+    c.load(w)
+    c.linearize()
+    chi, lam = c.init_lm()
+    out, last = [], 1e20
+    for it in range(iterations):
+        ok, false_cnt, trials = False, 0, 0
+        while not ok and false_cnt < 10:
+            c.solve_linear(lam)
+            c.update_states()
+            ok, chi, lam = c.eval_step()
+            trials += 1
+            if ok:
+                c.linearize()
+            else:
+                false_cnt += 1
+                c.rollback_states()
+        p, s, e = c.get_window()
+        lm = c.get_landmarks() if c.lm_dim == 1 else c.get_landmarks_xyz().ravel()
+        out.append((np.concatenate([p.ravel(), s.ravel(), e.ravel(), lm]), chi, lam, trials))
+        if last - chi < 1e-5:
+            break
+        last = chi
+    return out
+
+
+def test_solve_trace_against_the_reference_iteration_by_iteration(vio, oracle_lib):
+    """The oracle stays within 1e-13 of the reference while lambda is large; the difference appears where lambda has walked
+    down to O(10..100) (cond(H + lambda I) ~ 1e15) and stays below 1e-6 (measured 1.9e-7, profiles/parity_trace.json)."""
+    zr = np.load(os.path.join(GOLDEN_DIR, "solve_trace.npz"))
+    n_checked = 0
+    for path in WINDOW_FILES:
+        z = dict(np.load(path))
+        name = os.path.basename(path)[:-4]
+        if name + "_state" not in zr:
+            continue
+        tr = solve_trace_stepwise(oracle_lib, tu.arrays_to_window(vio, z), cfg_of(z))
+        rs, rl = zr[name + "_state"], zr[name + "_lam"]
+        assert len(tr) == len(rs) and [t[3] for t in tr] == list(zr[name + "_trials"]), name
+        d = [float(np.abs(t[0] - r).max()) for t, r in zip(tr, rs)]
+        assert max(d[:4]) <= 1e-11 and max(d) <= 1e-6, (name, d)
+        assert max(abs(t[2] - l) / l for t, l in zip(tr, rl)) <= 1e-6, name
+        n_checked += 1
+    assert n_checked >= 7
+
+
 def check_prior(m, ref):
     """Marginalisation outputs are compared through invariants: the Schur complement subtracts O(1e16) terms
     whose difference is O(1e5), the eps = 1e-8 eigenvalue cut and the 1e-9 zeroing are discontinuous, and
