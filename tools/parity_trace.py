@@ -58,6 +58,8 @@ def cfg_of(z):
         kw["ext_fixed"] = int(z["cfg_ext_fixed"])
     if "cfg_loss_type" in z:
         kw["loss_type"] = int(z["cfg_loss_type"])
+    if "cfg_loss_delta" in z:
+        kw["loss_delta"] = float(z["cfg_loss_delta"])
     return kw
 
 
