@@ -3,7 +3,7 @@
 
   python tools/run_stream.py --sim-dir <dir>      # reference simulator output: imu_pose.txt + keyframe/all_points_<n>.txt
   python tools/run_stream.py --frames 60          # synthetic stream on the simulator's trajectory
-  options: --lib hip|oracle  --triangulate  --nonkey-every N  --out pose_output.txt  --export-sim-dir <dir>
+  options: --lib hip|oracle|ref  --triangulate  --nonkey-every N  --out pose_output.txt  --export-sim-dir <dir>
 
 Prints the APE the reference evaluates with (`evo_ape tum ground-truth.txt pose_output.txt -va`) when ground truth is
 available.  The front end (feature tracking, initialisation) is out of scope: tracks come from the files' feature ids,
@@ -23,7 +23,8 @@ def main():
     ap.add_argument("--sim-dir")
     ap.add_argument("--frames", type=int, default=40)
     ap.add_argument("--landmarks-per-frame", type=int, default=30)
-    ap.add_argument("--lib", choices=("hip", "oracle"), default="hip")
+    ap.add_argument("--lib", choices=("hip", "oracle", "ref"), default="hip",
+                    help="hip: the product; oracle: the CPU restatement; ref: the reference's own backend compiled into oracle/_ref (test infrastructure)")
     ap.add_argument("--triangulate", action="store_true")
     ap.add_argument("--nonkey-every", type=int, default=0)
     ap.add_argument("--pos-noise", type=float, default=0.02)
@@ -40,7 +41,12 @@ def main():
         st = vio.stream.SyntheticStream(n_frames=a.frames, landmarks_per_frame=a.landmarks_per_frame)
     if a.export_sim_dir:
         vio.stream.write_simulator_files(st, a.export_sim_dir)
-    lib = vio.load_hip() if a.lib == "hip" else vio.VioLib(os.path.join(ORACLE_DIR, "liboracle.so"), "vioo_")
+    if a.lib == "hip":
+        lib = vio.load_hip()
+    elif a.lib == "ref":
+        lib = vio.VioLib(os.path.join(ORACLE_DIR, "_ref", "libvio_ref.so"), "vior_")
+    else:
+        lib = vio.VioLib(os.path.join(ORACLE_DIR, "liboracle.so"), "vioo_")
     drv = vio.stream.StreamDriver(lib, st, pos_noise=a.pos_noise, rot_noise=a.rot_noise, triangulate=a.triangulate,
                                   nonkey_every=a.nonkey_every)
     t = time.perf_counter()

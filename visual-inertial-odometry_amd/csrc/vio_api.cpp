@@ -141,7 +141,7 @@ struct vio_ctx {
     // device buffers independent of the topology
     DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
         d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi;
-    DevBuf<int32_t> d_imu_valid, d_perm;
+    DevBuf<int32_t> d_imu_valid, d_perm, d_rank;
     DevBuf<double> d_Pg;
     DevBuf<LmState> d_lm;
     LmState h_lm;
@@ -528,7 +528,7 @@ vio_status alloc_fixed(vio_ctx *c) {
     HIPCHK(c->d_Hs.resize(PD * PD)); HIPCHK(c->d_bs.resize(176)); HIPCHK(c->d_bfull.resize(176));
     HIPCHK(c->d_diagfull.resize(176)); HIPCHK(c->d_dx.resize(176)); HIPCHK(c->d_step_tot.resize(8));
     HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
-    HIPCHK(c->d_perm.resize(176)); HIPCHK(c->d_Pg.resize(POSE_SOLVE_TILED));
+    HIPCHK(c->d_perm.resize(176)); HIPCHK(c->d_rank.resize(176)); HIPCHK(c->d_Pg.resize(POSE_SOLVE_TILED));
     HIPCHK(hipMemset(c->d_Pg.p, 0, POSE_SOLVE_TILED * sizeof(double)));   // tile padding (17th column) is never written again
     HIPCHK(hipMemsetAsync(c->d_vis.p, 0, VIS_COUNT * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_step_tot.p, 0, 8 * 8, c->stream));
@@ -551,7 +551,7 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     // Problem always carries a 171x171 prior block (zero before the first marginalisation); err_prior_ exists
     // only once a prior has been set (problem.cc:466,505,554)
     T.has_prior = c->has_prior; T.add_imu_prior = 1; T.natural_hs = (pl.marg || c->want_natural_hs) ? 1 : 0;
-    T.Hs = c->d_Hs.p; T.Pg = c->d_Pg.p; T.perm = c->d_perm.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
+    T.Hs = c->d_Hs.p; T.Pg = c->d_Pg.p; T.perm = c->d_perm.p; T.rank = c->d_rank.p; T.bs = c->d_bs.p; T.bfull = c->d_bfull.p; T.diagfull = c->d_diagfull.p; T.dx = c->d_dx.p;
     T.dxl = pl.d_dxl.p; T.step_part = pl.d_step_part.p; T.n_step_blocks = T.n_items + T.n_imu_items;
     T.gn_flags = 0; T.cur_hint = -1; T.lm_gate = 0;
     T.imu_mask = 0;
@@ -905,7 +905,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
-    c->d_batch_tabs.release();
+    c->d_batch_tabs.release(); c->d_rank.release();
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;

@@ -1130,27 +1130,10 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid
 // (every workgroup recomputes the 171 ranks, 5 threads per entry: cheaper than one more launch).  Workgroups 171..175: identity padding.
 // Workgroup 176: right-hand side row, b_pp_schur_, pose part of b_, diag(Hessian_).
 #define ASM_THREADS 896        // 5 x 171 threads rank-sort, then 171 write the row
-__device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
-    __shared__ double sDg[176];
-    __shared__ int sPerm[176];
-    __shared__ int sCnt[5 * 176];
-    const int b = blockIdx.x, t = threadIdx.x;
-    if (d_gated_off(T.lm, T.lm_gate)) return;
-    const int cur = d_cur(T);
-    const int valid = d_imu_mask(T);
-    // Workgroup b < 171 owns NATURAL row b: its entries are requested together with the diagonal (one round trip for both)
-    // and scattered once the ranks are known: natural row b is row rank(b) of the permuted matrix.
-    double row_e = 0.0;
-    if (t < VIO_PD) {
-        double vv, vr;
-        d_hs_entry(T, valid, t, t, vv, vr);
-        double wv = 0.0, wr = 0.0;
-        if (b < VIO_PD) d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
-        sDg[t] = d_rank_key(vv + vr);
-        row_e = wv + wr;
-    }
-    __syncthreads();
-    if (t < 5 * VIO_PD) {           // rank_i = #{j : d_j > d_i or (d_j == d_i and j < i)}, 5 threads per entry
+// the pivot ranks of the 171 diagonal entries: rank_i = #{j : d_j > d_i or (d_j == d_i and j < i)}, 5 threads per entry.
+// On return (after its barriers) sCnt holds the five partial counts of every entry; needs >= 5 * 171 threads.
+__device__ __forceinline__ void d_rank_sort(const double *sDg, int *sCnt, int t) {
+    if (t < 5 * VIO_PD) {
         const int i = t % VIO_PD, part = t / VIO_PD;
         const int j0 = part * 35, j1 = min(VIO_PD, j0 + 35);
         const double di = sDg[i];
@@ -1162,12 +1145,52 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
         sCnt[part * 176 + i] = rank;
     }
     __syncthreads();
-    int my_rank = 0;
-    if (t < VIO_PD) { my_rank = sCnt[t] + sCnt[176 + t] + sCnt[352 + t] + sCnt[528 + t] + sCnt[704 + t]; sPerm[my_rank] = t; }
+}
+__device__ __forceinline__ int d_rank_of(const int *sCnt, int i) { return sCnt[i] + sCnt[176 + i] + sCnt[352 + i] + sCnt[528 + i] + sCnt[704 + i]; }
+
+// RANKS_GIVEN (batched launches): the ranks come from k_rank_b (T.rank, T.perm), the workgroup has 192 threads and skips the
+// sort every workgroup of the single-window kernel repeats (one launch more is nothing once it is shared by the batch)
+template <bool RANKS_GIVEN>
+__device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
+    __shared__ double sDg[176];
+    __shared__ int sPerm[176];
+    __shared__ int sCnt[RANKS_GIVEN ? 8 : 5 * 176];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (d_gated_off(T.lm, T.lm_gate)) return;
+    const int cur = d_cur(T);
+    const int valid = d_imu_mask(T);
+    // Workgroup b < 171 owns NATURAL row b: its entries are requested together with the diagonal (one round trip for both)
+    // and scattered once the ranks are known: natural row b is row rank(b) of the permuted matrix.
+    double row_e = 0.0;
+    int my_rank = 0, row_rank = 0;
+    if (RANKS_GIVEN) {
+        if (t < VIO_PD) {
+            double wv = 0.0, wr = 0.0;
+            if (b < VIO_PD) d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
+            row_e = wv + wr;
+            my_rank = T.rank[t];
+            sPerm[t] = T.perm[t];
+        }
+        if (b < VIO_PD) row_rank = T.rank[b];
+        __syncthreads();
+    } else {
+        if (t < VIO_PD) {
+            double vv, vr;
+            d_hs_entry(T, valid, t, t, vv, vr);
+            double wv = 0.0, wr = 0.0;
+            if (b < VIO_PD) d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
+            sDg[t] = d_rank_key(vv + vr);
+            row_e = wv + wr;
+        }
+        __syncthreads();
+        d_rank_sort(sDg, sCnt, t);
+        if (t < VIO_PD) { my_rank = d_rank_of(sCnt, t); sPerm[my_rank] = t; }
+        if (b < VIO_PD) row_rank = d_rank_of(sCnt, b);
+    }
     if (b < VIO_PD) {
         if (t < VIO_PD) {
             if (T.natural_hs) T.Hs[b * VIO_PD + t] = row_e;      // natural-order H_pp_schur_: only the getters and Marginalize read it
-            const int i = sCnt[b] + sCnt[176 + b] + sCnt[352 + b] + sCnt[528 + b] + sCnt[704 + b], j = my_rank;
+            const int i = row_rank, j = my_rank;
             if (j <= i) {                       // entry (i, j) of the permuted, tiled triangle
                 T.Pg[telem(i, j)] = row_e;
                 if (j < i && (j >> 4) == (i >> 4)) T.Pg[telem(j, i)] = row_e;      // upper half of a diagonal tile
@@ -1194,7 +1217,7 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
         }
         if (t < VIO_PD) {
             sDg[t] = d_rhs_entries(T, valid, t, cur);
-            T.perm[t] = sPerm[t];
+            if (!RANKS_GIVEN) T.perm[t] = sPerm[t];
         }
         if (T.gn_flags & 1) {
             __shared__ double sSum[8];
@@ -1224,8 +1247,19 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
         if (t < PS_NP) T.Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
     }
 }
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) { d_assemble_body(T); }
-__global__ __launch_bounds__(ASM_THREADS) void k_assemble_b(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_assemble_body(T); }
+__global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) { d_assemble_body<false>(T); }
+// batched: the ranks once per window (k_rank_b), then 177 light workgroups of 192 threads per window
+__global__ __launch_bounds__(ASM_THREADS) void k_rank_b(BatchArgs a) {
+    __shared__ double sDg[176];
+    __shared__ int sCnt[5 * 176];
+    const DeviceTables T = d_batch_tables(a);
+    const int t = threadIdx.x;
+    if (t < VIO_PD) { double vv, vr; d_hs_entry(T, d_imu_mask(T), t, t, vv, vr); sDg[t] = d_rank_key(vv + vr); }
+    __syncthreads();
+    d_rank_sort(sDg, sCnt, t);
+    if (t < VIO_PD) { const int r = d_rank_of(sCnt, t); T.rank[t] = r; T.perm[r] = t; }
+}
+__global__ __launch_bounds__(192) void k_assemble_b(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_assemble_body<true>(T); }
 
 // ---------------------------------------------------------------------------------------------------------
 // k_pose_solve: single workgroup, 1024 threads.  (H_pp_schur_ + lambda I) dx = b_pp_schur_ (problem.cc:434-439).
@@ -2054,7 +2088,8 @@ void vio_launch_batch_gn(const DeviceTables *tabs, int B, int max_blocks, size_t
     hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
     a.gn_flags = test_prev ? 1 : 0;
     hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(ASM_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(192), 0, s, a);
     a.gn_flags = 4;
     hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
 }

@@ -149,6 +149,7 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     double *Hs;                  // [171x171]
     double *Pg;                  // permuted, padded, packed lower triangle + rhs row, written by k_assemble
     int32_t *perm;               // [176] pivot order found by k_assemble
+    int32_t *rank;               // [176] its inverse (batched launches: k_rank_b writes both, k_assemble_b reads them)
     double *bs;                  // [171]
     double *bfull;               // [171] pose part of b_ (direct + imu + prior), for the gain ratio
     double *diagfull;            // [171] diag(Hessian_) pose part, for lambda_0
