@@ -307,7 +307,7 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
         pl.max_lds_doubles = std::max(pl.max_lds_doubles, pt.lds_doubles);
         pl.slab_doubles += (size_t)item_out_count(pt.nb);
         pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
-        pl.lw_doubles += (size_t)(18 * pt.nb + 9) * it.G;
+        pl.lw_doubles += (size_t)9 * it.G;            // H_ll (6), b_l (3): W is formed again where it is needed
         pts_j.resize(2 * (obs_base + (int64_t)it.G * it.K));
         for (int g = 0; g < it.G; ++g) {
             const int32_t l = pl.sorted_to_orig[s + g];
@@ -1159,9 +1159,8 @@ vio_status vio_gn_iteration(vio_ctx *c, double lambda) {
     hipSetDevice(c->cfg.device);
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = c->solve_plan;
-    // chi2 and the gain-ratio partial of a step reach its test through vis: one exchange per iteration.  XYZ landmarks take
-    // the classic sequence (k_pose_solve -> k_backsub_xyz -> k_lm_decide): k_linearize_xyz has no deferred head yet.
-    const bool gn = c->lm_dim == 1;
+    // chi2 and the gain-ratio partial of a step reach its test through vis: one exchange per iteration
+    const bool gn = true;
     if (gn && c->cur_host < 0) VIOCHK(read_lm(c));      // once: from here on the host tracks LmState.cur itself
     if (lambda != c->gn_lambda) { vio_launch_set_lambda(c->d_lm.p, lambda, c->stream); c->gn_lambda = lambda; }
     VIOCHK(enqueue_linearize(c, pl, gn));
@@ -1355,7 +1354,7 @@ vio_status vio_get_landmark_system(vio_ctx *c, int64_t n, double *hll, double *b
         for (const ItemDesc &it : pl.items)
             for (int g = 0; g < it.G; ++g) {
                 const int32_t l = pl.sorted_to_orig[it.lm_base + g];
-                const size_t f0 = (size_t)it.lw_base + (size_t)(18 * it.nb) * it.G + g;
+                const size_t f0 = (size_t)it.lw_base + g;
                 if (hll) for (int k = 0; k < 9; ++k) hll[9 * l + k] = lw[f0 + (size_t)sym[k] * it.G];
                 if (bl) for (int k = 0; k < 3; ++k) bl[3 * l + k] = lw[f0 + (size_t)(6 + k) * it.G];
             }

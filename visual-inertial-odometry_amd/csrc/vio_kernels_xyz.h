@@ -19,18 +19,22 @@
 //   k_backsub_xyz     delta_l = H_ll^-1 (b_l - W^T dx_pose) (problem.cc:445), trial points, chi2 of the trial state
 //
 // HBM layout differences to the inverse-depth plan: invd[2][3][Ns] holds the points coordinate-major, dxl[3][Ns],
-// lw per item = (18 nb + 9) fields x G: W (18 nb), the 6 distinct entries of H_ll, b_l (3).
+// lw per item = 9 fields x G: the 6 distinct entries of H_ll, b_l (3).  W is not kept: the back-substitution (k_backsub_xyz,
+// or the GN head of the next k_linearize_xyz) forms it again from the state it was linearised at.
 #ifndef VIO_KERNELS_XYZ_H
 #define VIO_KERNELS_XYZ_H
 
-__host__ __device__ inline int xyz_lrec(int nb) { return 42 * nb + 19; }       // W 18nb | Y 18nb | b_pose 6nb | H 6 | Hinv 9 | b_l 3 (+1: odd stride)
+// landmark record: W 18nb | Y 18nb | b_pose 6nb | H 6 | Hinv 9 | b_l 3 | GN head: new point 3, delta 3, gain-ratio term 1 (+2: odd stride)
+__host__ __device__ inline int xyz_lrec(int nb) { return 42 * nb + 27; }
 __host__ __device__ inline int xyz_ntd(int K) { return (K + 1) >> 1; }         // direct tiles: two observation indices each
 __host__ __device__ inline int xyz_plane(int G) { return G * 24 + 8; }
 __host__ __device__ inline int xyz_tiles(int K) { const int ts = (6 * K + 15) >> 4; return xyz_ntd(K) + ts * (ts + 1) / 2; }
 #define XYZ_FRAME_TAB (VIO_NF * 12 + 16)        // A_k (9), d_k (3) per frame, then ric (9), tic (3)
 __host__ __device__ inline int xyz_lds_doubles(int G, int K) {
     int aux = G * K * 9, part = xyz_tiles(K) * 256 + 2 * 6 * K * LIN_VS;
+    int head = 3 * G * K + 12 * K + 12 + 176 + 12 * G;      // GN head: W^T dx per observation, the old camera maps, dx, (H_ll, b_l, point) per landmark
     int shared = aux > part ? aux : part;
+    if (head > shared) shared = head;
     shared = (shared + 1) & ~1;
     return XYZ_FRAME_TAB + 3 * (LIN_THREADS / 64) + xyz_ntd(K) * xyz_plane(G) + G * xyz_lrec(K) + shared;
 }
@@ -119,11 +123,91 @@ __device__ __forceinline__ void d_xyz_frame(const double *st, int f, const doubl
     for (int k = 0; k < 3; ++k) out[9 + k] = -w[k];
 }
 
+// One EdgeReprojectionXYZ at the point pw seen through the camera map (A, d) of its frame: residual, jacobians
+// (edge_reprojection.cc:147-180), robust weight (Edge::RobustInfo, edge.cc:48-74, information = s^2 I) as the whitening
+// L (L^T L = the robustified information) and c = drho * Information * residual.  Shared by the linearisation and by the
+// back-substitution, which forms W again from the state it was linearised at instead of reading it back from HBM.
+struct XyzObs {
+    double Jf0[3], Jf1[3], Jp0[6], Jp1[6];
+    double L00, L01, L11, c0, c1, chi;
+};
+__device__ __forceinline__ void d_xyz_obs(const double *A, const double *ric, const double *tic, const double *pw, double u, double v,
+                                          int loss_type, double loss_delta, double s_info, XyzObs &o) {
+    const double info = s_info * s_info;
+    double pc[3], pim[3];
+    d_m3_vec(A, pw, pc);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) pc[m] += A[9 + m];
+    d_m3_vec(ric, pc, pim);                             // pts_imu_i = ric p_c + tic
+#pragma unroll
+    for (int m = 0; m < 3; ++m) pim[m] += tic[m];
+    const double iz = 1.0 / pc[2];
+    const double r0 = pc[0] * iz - u, r1 = pc[1] * iz - v;
+    const double ra = -pc[0] * (iz * iz), rb = -pc[1] * (iz * iz);        // reduce = [iz 0 ra; 0 iz rb]
+    double RR0[3], RR1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o.Jf0[c] = iz * A[c] + ra * A[6 + c];             // jacobian_feature = reduce * ric^T * Ri^T
+        o.Jf1[c] = iz * A[3 + c] + rb * A[6 + c];
+        RR0[c] = iz * ric[3 * c] + ra * ric[3 * c + 2];   // reduce * ric^T
+        RR1[c] = iz * ric[3 * c + 1] + rb * ric[3 * c + 2];
+        o.Jp0[c] = -o.Jf0[c]; o.Jp1[c] = -o.Jf1[c];       // reduce * ric^T * -Ri^T
+    }
+    // reduce * ric^T * hat(pts_imu_i): row * hat(v) = row x v
+    o.Jp0[3] = RR0[1] * pim[2] - RR0[2] * pim[1]; o.Jp0[4] = RR0[2] * pim[0] - RR0[0] * pim[2]; o.Jp0[5] = RR0[0] * pim[1] - RR0[1] * pim[0];
+    o.Jp1[3] = RR1[1] * pim[2] - RR1[2] * pim[1]; o.Jp1[4] = RR1[2] * pim[0] - RR1[0] * pim[2]; o.Jp1[5] = RR1[0] * pim[1] - RR1[1] * pim[0];
+
+    const double e2 = r0 * (info * r0) + r1 * (info * r1);
+    double rho0, rho1, rho2;
+    d_loss(loss_type, loss_delta, e2, rho0, rho1, rho2);
+    o.chi = (loss_type == 0) ? e2 : rho0;
+    double lam2 = rho1;
+    if (loss_type != 0 && rho1 + 2 * rho2 * e2 > 0.) lam2 = rho1 + 2 * rho2 * e2;
+    const double al = sqrt(rho1), be = sqrt(fmax(lam2, 0.0));
+    const double rn2 = r0 * r0 + r1 * r1;
+    const double irn2 = rn2 > 0 ? 1.0 / rn2 : 0.0;
+    const double gm = (be - al) * irn2;
+    o.L00 = s_info * (al + gm * r0 * r0); o.L01 = s_info * (gm * r0 * r1); o.L11 = s_info * (al + gm * r1 * r1);
+    o.c0 = rho1 * (info * r0); o.c1 = rho1 * (info * r1);               // drho * Information * residual
+}
+
+// the observation's term of W^T dx_pose: t[c] = sum_i (L J_pose)_i^T (L J_feature)_c dx[i]  (the Hpm block times the pose step)
+__device__ __forceinline__ void d_xyz_obs_wtdx(const XyzObs &o, const double *d, double *t) {
+    double lf0[3], lf1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lf0[c] = o.L00 * o.Jf0[c] + o.L01 * o.Jf1[c]; lf1[c] = o.L01 * o.Jf0[c] + o.L11 * o.Jf1[c]; t[c] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double lp0 = o.L00 * o.Jp0[i] + o.L01 * o.Jp1[i], lp1 = o.L01 * o.Jp0[i] + o.L11 * o.Jp1[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[c] += (lp0 * lf0[c] + lp1 * lf1[c]) * d[i];
+    }
+}
+
+// delta_l = H_ll^-1 (b_l - W^T dx_pose) (problem.cc:445) and the landmark's term of the gain-ratio denominator
+__device__ __forceinline__ double d_xyz_landmark_step(const double *h, const double *bl, const double *t, double lambda, double *dl) {
+    const double Hm[9] = {h[0], h[1], h[2], h[1], h[3], h[4], h[2], h[4], h[5]};
+    double Hi[9];
+    d_inverse3(Hm, Hi);
+    const double v0 = bl[0] - t[0], v1 = bl[1] - t[1], v2 = bl[2] - t[2];
+    double scale = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        dl[i] = Hi[3 * i] * v0 + Hi[3 * i + 1] * v1 + Hi[3 * i + 2] * v2;
+        scale += dl[i] * (lambda * dl[i] + bl[i]);
+    }
+    return scale;
+}
+
+
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (d_gated_off(T.lm, T.lm_gate)) return;
+    // GN mode (gn_flags bit 1), as in k_linearize: the previous step's b_prior' rows and landmark back-substitution come first
+    const bool owe = (T.gn_flags & 2) != 0, owe_prior = owe && T.has_prior;
     if (b >= T.n_items) {
+        if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
         d_imu_item(T, b - T.n_items, dyn_smem);
         return;
     }
@@ -135,6 +219,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
     const int G = it.G, K = it.K, nb = it.nb;              // nb == K: one pattern block per observing frame
     const int LREC = xyz_lrec(nb), PLANE = xyz_plane(G), NTD = xyz_ntd(K);
     const int offW = 0, offY = 18 * nb, offBP = 36 * nb, offH = 42 * nb, offHI = 42 * nb + 6, offBL = 42 * nb + 15;
+    const int offPW = 42 * nb + 18, offDL = 42 * nb + 21, offSC = 42 * nb + 24;
 
     double *sFr = dyn_smem;                                // [11][12] camera maps of the item's frames (indexed by k), then ric, tic
     double *sCam = sFr + VIO_NF * 12;
@@ -147,76 +232,102 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
     const double *st = T.state + cur * STATE_STRIDE;
     const double *xyz = T.invd + (size_t)cur * 3 * T.Ns + it.lm_base;
     const double *pts = T.pts_j + 2 * (size_t)it.obs_base;
-    // phase 0: camera maps
-    if (tid < K) {
+    const double s_info = T.sqrt_info;
+    if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, T.n_step_blocks, tid & 63);
+    // phase 0: camera maps (their loads leave together with the head's: one global round trip for both)
+    if (tid >= 896 && tid < 896 + K) {                       // wave 14: no head loads of its own in front of these
+        const int k = tid - 896;
         double ric[9], o[12];
         d_quat_to_R(st + STATE_EXT + 3, ric);
-        d_xyz_frame(st, it.cam_block[tid] - 1, ric, o);          // K may be 11: the frame comes from cam_block, not target[10]
+        d_xyz_frame(st, it.cam_block[k] - 1, ric, o);            // K may be 11: the frame comes from cam_block, not target[10]
 #pragma unroll
-        for (int k = 0; k < 12; ++k) sFr[12 * tid + k] = o[k];
-        if (tid == 0) {
+        for (int q = 0; q < 12; ++q) sFr[12 * k + q] = o[q];
+        if (k == 0) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) sCam[k] = ric[k];
+            for (int q = 0; q < 9; ++q) sCam[q] = ric[q];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) sCam[9 + k] = st[STATE_EXT + k];
+            for (int q = 0; q < 3; ++q) sCam[9 + q] = st[STATE_EXT + q];
         }
     }
     // an odd K leaves the second half of the last plane unused: the direct products read it, so it holds zeros
     if (K & 1) for (int e = tid; e < G * 12; e += LIN_THREADS) sRows[(NTD - 1) * PLANE + (e / 12) * 24 + 12 + e % 12] = 0.0;
+    // ---------------- GN head: delta_l of the PREVIOUS step (problem.cc:445) ----------------
+    // W is not kept in HBM: every observation forms its block again at the state it was linearised at (the other copy of the
+    // state and of the points) and multiplies it by the pose step; H_ll and b_l (9 values per landmark) come from lw.
+    if (owe) {
+        double *sT = sAux;                                 // 3 per observation
+        double *sFrO = sAux + 3 * G * K, *sCamO = sFrO + 12 * K, *sDx = sCamO + 12;      // fits: xyz_lds_doubles
+        const double *sto = T.state + (cur ^ 1) * STATE_STRIDE;
+        const double *xyzo = T.invd + (size_t)(cur ^ 1) * 3 * T.Ns + it.lm_base;
+        const double *lw = T.lw + it.lw_base;
+        double *sHb = sDx + 176;                           // 12 per landmark: H_ll (6), b_l (3), the old point
+        for (int e = tid; e < 12 * G; e += LIN_THREADS) {
+            const int q = e / G, g = e - q * G;
+            sHb[12 * g + q] = q < 9 ? lw[e] : xyzo[(size_t)(q - 9) * T.Ns + g];
+        }
+        const double lambda_lm = T.lm->lambda;
+        if (tid < 176) sDx[tid] = T.dx[tid];
+        if (tid >= 192 && tid < 192 + K) {
+            const int k = tid - 192;
+            double ric[9], o[12];
+            d_quat_to_R(sto + STATE_EXT + 3, ric);
+            d_xyz_frame(sto, it.cam_block[k] - 1, ric, o);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) sFrO[12 * k + q] = o[q];
+            if (k == 0) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) sCamO[q] = ric[q];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) sCamO[9 + q] = sto[STATE_EXT + q];
+            }
+        }
+        __syncthreads();
+        for (int o = tid; o < G * K; o += LIN_THREADS) {
+            const int k = o / G, g = o - k * G;
+            const double pw[3] = {sHb[12 * g + 9], sHb[12 * g + 10], sHb[12 * g + 11]};
+            XyzObs ob;
+            d_xyz_obs(sFrO + 12 * k, sCamO, sCamO + 9, pw, pts[2 * o], pts[2 * o + 1], T.loss_type, T.loss_delta, s_info, ob);
+            double t[3];
+            d_xyz_obs_wtdx(ob, sDx + 6 + 15 * (it.cam_block[k] - 1), t);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sT[3 * o + c] = t[c];
+        }
+        __syncthreads();
+        if (tid < G) {
+            double t[3] = {0.0, 0.0, 0.0}, dl[3];
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) t[c] += sT[3 * (k * G + tid) + c];
+            double hb[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) hb[q] = sHb[12 * tid + q];
+            const double sc = d_xyz_landmark_step(hb, hb + 6, t, lambda_lm, dl);
+            double *Lg = sL + (size_t)tid * LREC;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { Lg[offPW + c] = hb[9 + c] + dl[c]; Lg[offDL + c] = dl[c]; }
+            Lg[offSC] = sc;
+        }
+    }
     __syncthreads();
-
-    const double s_info = T.sqrt_info, info = s_info * s_info;
     const double *ric = sCam, *tic = sCam + 9;
 
     // ---------------- phase 1: thread per observation ----------------
     double chi_acc = 0.0;
     for (int o = tid; o < G * K; o += LIN_THREADS) {
         const int k = o / G, g = o - k * G;
-        const double *A = sFr + 12 * k;
-        const double pw[3] = {xyz[g], xyz[(size_t)T.Ns + g], xyz[2 * (size_t)T.Ns + g]};
-        const double u = pts[2 * o], v = pts[2 * o + 1];
-        double pc[3], pim[3];
-        d_m3_vec(A, pw, pc);
+        double *Lg = sL + (size_t)g * LREC;
+        double pw[3];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) pc[m] += A[9 + m];
-        d_m3_vec(ric, pc, pim);                             // pts_imu_i = ric p_c + tic
-#pragma unroll
-        for (int m = 0; m < 3; ++m) pim[m] += tic[m];
-        const double iz = 1.0 / pc[2];
-        const double r0 = pc[0] * iz - u, r1 = pc[1] * iz - v;
-        const double ra = -pc[0] * (iz * iz), rb = -pc[1] * (iz * iz);        // reduce = [iz 0 ra; 0 iz rb]
-        double Jf0[3], Jf1[3], RR0[3], RR1[3], Jp0[6], Jp1[6];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            Jf0[c] = iz * A[c] + ra * A[6 + c];             // jacobian_feature = reduce * ric^T * Ri^T
-            Jf1[c] = iz * A[3 + c] + rb * A[6 + c];
-            RR0[c] = iz * ric[3 * c] + ra * ric[3 * c + 2]; // reduce * ric^T
-            RR1[c] = iz * ric[3 * c + 1] + rb * ric[3 * c + 2];
-            Jp0[c] = -Jf0[c]; Jp1[c] = -Jf1[c];             // reduce * ric^T * -Ri^T
-        }
-        // reduce * ric^T * hat(pts_imu_i): row * hat(v) = row x v
-        Jp0[3] = RR0[1] * pim[2] - RR0[2] * pim[1]; Jp0[4] = RR0[2] * pim[0] - RR0[0] * pim[2]; Jp0[5] = RR0[0] * pim[1] - RR0[1] * pim[0];
-        Jp1[3] = RR1[1] * pim[2] - RR1[2] * pim[1]; Jp1[4] = RR1[2] * pim[0] - RR1[0] * pim[2]; Jp1[5] = RR1[0] * pim[1] - RR1[1] * pim[0];
-
-        // robust weight: Edge::RobustInfo (edge.cc:48-74) with information = s^2 I — as k_linearize
-        const double e2 = r0 * (info * r0) + r1 * (info * r1);
-        double rho0, rho1, rho2;
-        d_loss(T.loss_type, T.loss_delta, e2, rho0, rho1, rho2);
-        chi_acc += (T.loss_type == 0) ? e2 : rho0;
-        double lam2 = rho1;
-        if (T.loss_type != 0 && rho1 + 2 * rho2 * e2 > 0.) lam2 = rho1 + 2 * rho2 * e2;
-        const double al = sqrt(rho1), be = sqrt(fmax(lam2, 0.0));
-        const double rn2 = r0 * r0 + r1 * r1;
-        const double irn2 = rn2 > 0 ? 1.0 / rn2 : 0.0;
-        const double gm = (be - al) * irn2;
-        const double L00 = s_info * (al + gm * r0 * r0), L01 = s_info * (gm * r0 * r1), L11 = s_info * (al + gm * r1 * r1);
-        const double c0 = rho1 * (info * r0), c1 = rho1 * (info * r1);         // drho * Information * residual
-
+        for (int c = 0; c < 3; ++c) pw[c] = owe ? Lg[offPW + c] : xyz[(size_t)c * T.Ns + g];
+        XyzObs ob;
+        d_xyz_obs(sFr + 12 * k, ric, tic, pw, pts[2 * o], pts[2 * o + 1], T.loss_type, T.loss_delta, s_info, ob);
+        chi_acc += ob.chi;
+        const double *Jf0 = ob.Jf0, *Jf1 = ob.Jf1, *Jp0 = ob.Jp0, *Jp1 = ob.Jp1;
+        const double L00 = ob.L00, L01 = ob.L01, L11 = ob.L11, c0 = ob.c0, c1 = ob.c1;
         double lf0[3], lf1[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { lf0[c] = L00 * Jf0[c] + L01 * Jf1[c]; lf1[c] = L01 * Jf0[c] + L11 * Jf1[c]; }
         double *rec = sRows + (k >> 1) * PLANE + g * 24 + (k & 1) * 12;
-        double *Lg = sL + (size_t)g * LREC;
         double *pk = sAux + (size_t)o * 9;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -258,8 +369,10 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
         maxh = fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5])));
     }
     {
-        const double ws = d_wave_sum_to_lane63(chi_acc), wm = d_wave_max_to_lane63(maxh);
-        if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
+        // (GN) the previous step's gain-ratio partial: thread g holds landmark g's term, summed as k_backsub_xyz sums it
+        const double sc = (owe && tid < G) ? sL[(size_t)tid * LREC + offSC] : 0.0;
+        const double ws = d_wave_sum_to_lane63(chi_acc), wsc = d_wave_sum_to_lane63(sc), wm = d_wave_max_to_lane63(maxh);
+        if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
     }
     __syncthreads();
     // ---------------- phase 1.5 b: thread per (landmark, k): Y_k = W_k H_ll^-1  (tempH = Hpm * Hmm_inv, problem.cc:427) ----------------
@@ -372,13 +485,27 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
             out[e] = v;
         }
         if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
-        // W, H_ll, b_l of the item's landmarks for the back-substitution
+        if (owe && tid == 64) {
+            double sc = 0.0;
+#pragma unroll
+            for (int w = 0; w < BS_THREADS / 64; ++w) sc += sRed[LIN_THREADS / 64 + w];
+            T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0;
+        }
+        if (owe && tid < G) {               // the landmark update of the head, out to HBM now
+            const size_t li = (size_t)it.lm_base + tid;
+            const double *Lg = sL + (size_t)tid * LREC;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T.dxl[(size_t)c * T.Ns + li] = Lg[offDL + c];
+                T.invd[((size_t)cur * 3 + c) * T.Ns + li] = Lg[offPW + c];
+            }
+        }
+        // H_ll (6 distinct entries) and b_l of the item's landmarks for the back-substitution
         double *lw = T.lw + it.lw_base;
-        const int nf = 18 * nb + 9;
-        for (int e = tid; e < nf * G; e += LIN_THREADS) {
+        for (int e = tid; e < 9 * G; e += LIN_THREADS) {
             const int r = e / G, g = e - r * G;
             const double *Lg = sL + (size_t)g * LREC;
-            lw[e] = (r < 18 * nb) ? Lg[offW + r] : (r < 18 * nb + 6 ? Lg[offH + (r - 18 * nb)] : Lg[offBL + (r - 18 * nb - 6)]);
+            lw[e] = r < 6 ? Lg[offH + r] : Lg[offBL + (r - 6)];
         }
     }
 }
@@ -394,14 +521,15 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub_xyz(DeviceTables T, int 
     const int which = (mode == 1) ? cur : (cur ^ 1);
     if ((T.gn_flags & 8) && T.has_prior && (lane >> 6) == 1) d_bprior_rows(T, cur, cur ^ 1, b, gridDim.x, lane & 63);
     if (b >= T.n_items) { d_backsub_imu_block(T, mode, which, b, lane); return; }
-    __shared__ double sFr[VIO_NF * 12];
+    __shared__ double sFr[VIO_NF * 12];       // camera maps at the state whose chi2 is wanted
+    __shared__ double sFrO[VIO_NF * 12 + 12]; // mode 0: the maps (and ric, tic) at the state the step was linearised at
     __shared__ double sDxp[176];
     __shared__ ItemDesc sIt;
     if (mode == 0) { sDxp[lane] = T.dx[lane]; if (lane + BS_THREADS < 176) sDxp[lane + BS_THREADS] = T.dx[lane + BS_THREADS]; }
     if (lane < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[lane] = ((const int32_t *)(T.items + b))[lane];
     __syncthreads();
     const ItemDesc &it = sIt;
-    const int G = it.G, K = it.K, nb = it.nb;
+    const int G = it.G, K = it.K;
     const double *st = T.state + which * STATE_STRIDE;
     if (lane < K) {
         double ric[9], o[12];
@@ -409,44 +537,53 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub_xyz(DeviceTables T, int 
         d_xyz_frame(st, it.cam_block[lane] - 1, ric, o);
 #pragma unroll
         for (int k = 0; k < 12; ++k) sFr[12 * lane + k] = o[k];
+    } else if (mode == 0 && lane >= 64 && lane < 64 + K) {
+        const int k = lane - 64;
+        const double *sto = T.state + cur * STATE_STRIDE;
+        double ric[9], o[12];
+        d_quat_to_R(sto + STATE_EXT + 3, ric);
+        d_xyz_frame(sto, it.cam_block[k] - 1, ric, o);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) sFrO[12 * k + q] = o[q];
+        if (k == 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) sFrO[VIO_NF * 12 + q] = ric[q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) sFrO[VIO_NF * 12 + 9 + q] = sto[STATE_EXT + q];
+        }
     }
     __syncthreads();
     double chi = 0.0, scale = 0.0;
+    const double s_info = T.sqrt_info, info = s_info * s_info;
     if (lane < G) {
         const int g = lane;
         const size_t li = (size_t)it.lm_base + g;
         const size_t Ns = (size_t)T.Ns;
         double pw[3] = {T.invd[(size_t)cur * 3 * Ns + li], T.invd[(size_t)cur * 3 * Ns + Ns + li], T.invd[(size_t)cur * 3 * Ns + 2 * Ns + li]};
         if (mode == 0) {
+            // W^T dx_pose with W formed again from the linearisation state (k_linearize_xyz keeps H_ll and b_l only);
+            // summed per observation, then over the observations: the association of the GN head of k_linearize_xyz
             const double *lw = T.lw + it.lw_base;
-            double t[3] = {0.0, 0.0, 0.0};
-            for (int p = 0; p < nb; ++p) {
-                const int base = 6 + 15 * (it.cam_block[p] - 1);
+            double hb[9], t[3] = {0.0, 0.0, 0.0}, dl[3];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const double d = sDxp[base + i];
+            for (int q = 0; q < 9; ++q) hb[q] = lw[(size_t)q * G + g];
+            for (int k = 0; k < K; ++k) {
+                const size_t o = (size_t)it.obs_base + (size_t)k * G + g;
+                XyzObs ob;
+                d_xyz_obs(sFrO + 12 * k, sFrO + VIO_NF * 12, sFrO + VIO_NF * 12 + 9, pw, T.pts_j[2 * o], T.pts_j[2 * o + 1], T.loss_type, T.loss_delta, s_info, ob);
+                double tk[3];
+                d_xyz_obs_wtdx(ob, sDxp + 6 + 15 * (it.cam_block[k] - 1), tk);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) t[c] += lw[(size_t)((6 * p + i) * 3 + c) * G + g] * d;
-                }
+                for (int c = 0; c < 3; ++c) t[c] += tk[c];
             }
-            double h[6], bl[3], Hi[9], dl[3];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) h[q] = lw[(size_t)(18 * nb + q) * G + g];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) bl[c] = lw[(size_t)(18 * nb + 6 + c) * G + g];
-            const double Hm[9] = {h[0], h[1], h[2], h[1], h[3], h[4], h[2], h[4], h[5]};
-            d_inverse3(Hm, Hi);
-            const double v0 = bl[0] - t[0], v1 = bl[1] - t[1], v2 = bl[2] - t[2];
+            scale = d_xyz_landmark_step(hb, hb + 6, t, lm->lambda, dl);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                dl[i] = Hi[3 * i] * v0 + Hi[3 * i + 1] * v1 + Hi[3 * i + 2] * v2;
                 T.dxl[(size_t)i * Ns + li] = dl[i];
                 pw[i] += dl[i];
                 T.invd[(size_t)(cur ^ 1) * 3 * Ns + (size_t)i * Ns + li] = pw[i];
-                scale += dl[i] * (lm->lambda * dl[i] + bl[i]);
             }
         }
-        const double s_info = T.sqrt_info, info = s_info * s_info;
         for (int k = 0; k < K; ++k) {
             const double *A = sFr + 12 * k;
             const size_t o = (size_t)it.obs_base + (size_t)k * G + g;
