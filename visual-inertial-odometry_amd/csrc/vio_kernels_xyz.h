@@ -7,14 +7,18 @@
 //
 //   k_linearize_xyz   one workgroup of 1024 threads per item = up to G landmarks seen from the same K frames
 //     phase 0    thread k < K: the frame's camera map  p_c = A_k p_w + d_k,  A_k = ric^T R_k^T,  d_k = -ric^T (R_k^T P_k + tic)
-//     phase 1    thread per observation: residual, J_feature (2x3), J_pose (2x6), robust weight; the whitened pose rows
-//                L J_pose go to sRows (the operand of the direct products), W_k = (L J_pose)^T (L J_feature) and the pose
-//                part of b straight to the landmark record, the observation's terms of H_ll and b_l to sAux
-//     phase 1.5  thread per landmark: H_ll, b_l, H_ll^-1 (partial-pivot LU, as Eigen's dynamic-size inverse());
-//                then thread per (landmark, k): Y_k = W_k H_ll^-1
+//     phase 1    thread per observation (a wave holds observations of ONE frame index k): residual, J_feature (2x3),
+//                J_pose (2x6), robust weight; the whitened pose rows L J_pose go to sRows (the operand of the direct
+//                products), W_k = (L J_pose)^T (L J_feature) to the landmark record, the observation's terms of H_ll and
+//                b_l to sAux; the pose part of b is summed inside the wave (one partial per wave)
+//     phase 1.5  thread per landmark: H_ll, b_l, H_ll^-1 (partial-pivot LU, as Eigen's dynamic-size inverse()), H_ll^-1 b_l
 //     phase 2    fp64 MFMA tiles: the direct blocks C_k = sum_g (L J_pose)^T (L J_pose), two observation indices per 16x16
-//                tile, and the lower tiles of the Schur term - sum_g W_g Y_g^T over the 6K pattern columns: the matrix
-//                core's k index runs over (landmark, coordinate), 4 landmarks per step, 3 passes (one per coordinate)
+//                tile, and the lower tiles of the Schur term - sum_g W_g Y_g^T, Y = W H_ll^-1 (tempH, problem.cc:427) over the
+//                6K pattern columns: the matrix core's k index runs over 4 landmarks, 3 steps per group (one per
+//                coordinate); Y is formed in registers from W and H_ll^-1 on the way into the B operand, never stored:
+//                the record of a landmark is 18K + 29 doubles and a 5-frame item holds 82 landmarks, so that the 20k
+//                landmarks of the bench window are ONE round of workgroups on the 256 CUs (with W, Y and the b terms
+//                in LDS it held 56: 357 items, two rounds)
 //     combine    thread per slab element, same slab layout as k_linearize (k_reduce and k_assemble are shared)
 //   k_backsub_xyz     delta_l = H_ll^-1 (b_l - W^T dx_pose) (problem.cc:445), trial points, chi2 of the trial state
 //
@@ -24,19 +28,20 @@
 #ifndef VIO_KERNELS_XYZ_H
 #define VIO_KERNELS_XYZ_H
 
-// landmark record: W 18nb | Y 18nb | b_pose 6nb | H 6 | Hinv 9 | b_l 3 | GN head: new point 3, delta 3, gain-ratio term 1 (+2: odd stride)
-__host__ __device__ inline int xyz_lrec(int nb) { return 42 * nb + 27; }
+// landmark record: W 18nb | H 6 | Hinv 9 | b_l 3 | Hinv b_l 3 | GN head: new point 3, delta 3, gain-ratio term 1 (+1: odd stride)
+__host__ __device__ inline int xyz_lrec(int nb) { return 18 * nb + 29; }
 __host__ __device__ inline int xyz_ntd(int K) { return (K + 1) >> 1; }         // direct tiles: two observation indices each
 __host__ __device__ inline int xyz_plane(int G) { return G * 24 + 8; }
 __host__ __device__ inline int xyz_tiles(int K) { const int ts = (6 * K + 15) >> 4; return xyz_ntd(K) + ts * (ts + 1) / 2; }
 #define XYZ_FRAME_TAB (VIO_NF * 12 + 16)        // A_k (9), d_k (3) per frame, then ric (9), tic (3)
+#define XYZ_BP_TAB (VIO_NF * 2 * 6)             // pose part of b: per frame index, per 64-landmark chunk (G <= 128)
 __host__ __device__ inline int xyz_lds_doubles(int G, int K) {
-    int aux = G * K * 9, part = xyz_tiles(K) * 256 + 2 * 6 * K * LIN_VS;
+    int aux = G * K * 9, part = xyz_tiles(K) * 256 + 6 * K * LIN_VS;
     int head = 3 * G * K + 12 * K + 12 + 176 + 12 * G;      // GN head: W^T dx per observation, the old camera maps, dx, (H_ll, b_l, point) per landmark
     int shared = aux > part ? aux : part;
     if (head > shared) shared = head;
     shared = (shared + 1) & ~1;
-    return XYZ_FRAME_TAB + 3 * (LIN_THREADS / 64) + xyz_ntd(K) * xyz_plane(G) + G * xyz_lrec(K) + shared;
+    return XYZ_FRAME_TAB + XYZ_BP_TAB + 3 * (LIN_THREADS / 64) + xyz_ntd(K) * xyz_plane(G) + G * xyz_lrec(K) + shared;
 }
 
 // Hmm.block(idx, idx, 3, 3).inverse() the way Eigen evaluates it for a block of a dynamic matrix: PartialPivLU
@@ -218,12 +223,12 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
     const ItemDesc &it = sIt;
     const int G = it.G, K = it.K, nb = it.nb;              // nb == K: one pattern block per observing frame
     const int LREC = xyz_lrec(nb), PLANE = xyz_plane(G), NTD = xyz_ntd(K);
-    const int offW = 0, offY = 18 * nb, offBP = 36 * nb, offH = 42 * nb, offHI = 42 * nb + 6, offBL = 42 * nb + 15;
-    const int offPW = 42 * nb + 18, offDL = 42 * nb + 21, offSC = 42 * nb + 24;
+    const int offW = 0, offH = 18 * nb, offHI = offH + 6, offBL = offH + 15, offV = offH + 18, offPW = offH + 21, offDL = offH + 24, offSC = offH + 27;
 
     double *sFr = dyn_smem;                                // [11][12] camera maps of the item's frames (indexed by k), then ric, tic
     double *sCam = sFr + VIO_NF * 12;
-    double *sRed = sFr + XYZ_FRAME_TAB;                    // 3 * waves
+    double *sBp = sFr + XYZ_FRAME_TAB;                     // [K][2][6] wave partials of the pose part of b
+    double *sRed = sBp + XYZ_BP_TAB;                       // 3 * waves
     double *sRows = sRed + 3 * (LIN_THREADS / 64);         // NTD planes of G x 24
     double *sL = sRows + NTD * PLANE;                      // G * LREC
     double *sAux = sL + G * LREC;                          // G*K*9, dead after phase 1.5 ...
@@ -249,6 +254,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
             for (int q = 0; q < 3; ++q) sCam[9 + q] = st[STATE_EXT + q];
         }
     }
+    if (tid >= 256 && tid < 256 + XYZ_BP_TAB) sBp[tid - 256] = 0.0;
     // an odd K leaves the second half of the last plane unused: the direct products read it, so it holds zeros
     if (K & 1) for (int e = tid; e < G * 12; e += LIN_THREADS) sRows[(NTD - 1) * PLANE + (e / 12) * 24 + 12 + e % 12] = 0.0;
     // ---------------- GN head: delta_l of the PREVIOUS step (problem.cc:445) ----------------
@@ -312,39 +318,52 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
     const double *ric = sCam, *tic = sCam + 9;
 
     // ---------------- phase 1: thread per observation ----------------
+    // thread -> (k, g) with the landmarks of a frame index padded to whole waves: every wave works on one k, so that the
+    // pose part of b, - sum_g drho J_pose^T Info r, is a sum inside the wave (it had 6 doubles per observation in LDS)
     double chi_acc = 0.0;
-    for (int o = tid; o < G * K; o += LIN_THREADS) {
-        const int k = o / G, g = o - k * G;
-        double *Lg = sL + (size_t)g * LREC;
-        double pw[3];
+    const int Gp = ((G + 63) >> 6) << 6;
+    for (int o2 = tid; o2 < K * Gp; o2 += LIN_THREADS) {
+        const int k = o2 / Gp, g = o2 - k * Gp;
+        const bool act = g < G;
+        double bpv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        if (act) {
+            const int o = k * G + g;
+            double *Lg = sL + (size_t)g * LREC;
+            double pw[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) pw[c] = owe ? Lg[offPW + c] : xyz[(size_t)c * T.Ns + g];
-        XyzObs ob;
-        d_xyz_obs(sFr + 12 * k, ric, tic, pw, pts[2 * o], pts[2 * o + 1], T.loss_type, T.loss_delta, s_info, ob);
-        chi_acc += ob.chi;
-        const double *Jf0 = ob.Jf0, *Jf1 = ob.Jf1, *Jp0 = ob.Jp0, *Jp1 = ob.Jp1;
-        const double L00 = ob.L00, L01 = ob.L01, L11 = ob.L11, c0 = ob.c0, c1 = ob.c1;
-        double lf0[3], lf1[3];
+            for (int c = 0; c < 3; ++c) pw[c] = owe ? Lg[offPW + c] : xyz[(size_t)c * T.Ns + g];
+            XyzObs ob;
+            d_xyz_obs(sFr + 12 * k, ric, tic, pw, pts[2 * o], pts[2 * o + 1], T.loss_type, T.loss_delta, s_info, ob);
+            chi_acc += ob.chi;
+            const double *Jf0 = ob.Jf0, *Jf1 = ob.Jf1, *Jp0 = ob.Jp0, *Jp1 = ob.Jp1;
+            const double L00 = ob.L00, L01 = ob.L01, L11 = ob.L11, c0 = ob.c0, c1 = ob.c1;
+            double lf0[3], lf1[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { lf0[c] = L00 * Jf0[c] + L01 * Jf1[c]; lf1[c] = L01 * Jf0[c] + L11 * Jf1[c]; }
-        double *rec = sRows + (k >> 1) * PLANE + g * 24 + (k & 1) * 12;
-        double *pk = sAux + (size_t)o * 9;
+            for (int c = 0; c < 3; ++c) { lf0[c] = L00 * Jf0[c] + L01 * Jf1[c]; lf1[c] = L01 * Jf0[c] + L11 * Jf1[c]; }
+            double *rec = sRows + (k >> 1) * PLANE + g * 24 + (k & 1) * 12;
+            double *pk = sAux + (size_t)o * 9;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double lp0 = L00 * Jp0[i] + L01 * Jp1[i], lp1 = L01 * Jp0[i] + L11 * Jp1[i];
+                rec[i] = lp0; rec[6 + i] = lp1;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Lg[offW + (6 * k + i) * 3 + c] = lp0 * lf0[c] + lp1 * lf1[c];     // Hpm block of (pose k, landmark)
+                bpv[i] = Jp0[i] * c0 + Jp1[i] * c1;
+            }
+            pk[0] = lf0[0] * lf0[0] + lf1[0] * lf1[0]; pk[1] = lf0[0] * lf0[1] + lf1[0] * lf1[1]; pk[2] = lf0[0] * lf0[2] + lf1[0] * lf1[2];
+            pk[3] = lf0[1] * lf0[1] + lf1[1] * lf1[1]; pk[4] = lf0[1] * lf0[2] + lf1[1] * lf1[2]; pk[5] = lf0[2] * lf0[2] + lf1[2] * lf1[2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pk[6 + c] = Jf0[c] * c0 + Jf1[c] * c1;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            const double lp0 = L00 * Jp0[i] + L01 * Jp1[i], lp1 = L01 * Jp0[i] + L11 * Jp1[i];
-            rec[i] = lp0; rec[6 + i] = lp1;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Lg[offW + (6 * k + i) * 3 + c] = lp0 * lf0[c] + lp1 * lf1[c];     // Hpm block of (pose k, landmark)
-            Lg[offBP + 6 * k + i] = Jp0[i] * c0 + Jp1[i] * c1;
+            const double wsum = d_wave_sum_to_lane63(bpv[i]);
+            if ((tid & 63) == 63) sBp[(2 * k + (g >> 6)) * 6 + i] = wsum;
         }
-        pk[0] = lf0[0] * lf0[0] + lf1[0] * lf1[0]; pk[1] = lf0[0] * lf0[1] + lf1[0] * lf1[1]; pk[2] = lf0[0] * lf0[2] + lf1[0] * lf1[2];
-        pk[3] = lf0[1] * lf0[1] + lf1[1] * lf1[1]; pk[4] = lf0[1] * lf0[2] + lf1[1] * lf1[2]; pk[5] = lf0[2] * lf0[2] + lf1[2] * lf1[2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) pk[6 + c] = Jf0[c] * c0 + Jf1[c] * c1;
     }
     __syncthreads();
 
-    // ---------------- phase 1.5 a: thread per landmark: H_ll, b_l, H_ll^-1 ----------------
+    // ---------------- phase 1.5: thread per landmark: H_ll, b_l, H_ll^-1, H_ll^-1 b_l ----------------
     double maxh = 0.0;
     if (tid < G) {
         const int g = tid;
@@ -366,6 +385,8 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
         for (int q = 0; q < 9; ++q) Lg[offHI + q] = Hi[q];
 #pragma unroll
         for (int c = 0; c < 3; ++c) Lg[offBL + c] = -bl[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Lg[offV + c] = Hi[3 * c] * -bl[0] + Hi[3 * c + 1] * -bl[1] + Hi[3 * c + 2] * -bl[2];      // H_ll^-1 b_l
         maxh = fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5])));
     }
     {
@@ -375,23 +396,6 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
         if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
     }
     __syncthreads();
-    // ---------------- phase 1.5 b: thread per (landmark, k): Y_k = W_k H_ll^-1  (tempH = Hpm * Hmm_inv, problem.cc:427) ----------------
-    for (int o = tid; o < G * K; o += LIN_THREADS) {
-        const int k = o / G, g = o - k * G;
-        double *Lg = sL + (size_t)g * LREC;
-        double Hi[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) Hi[q] = Lg[offHI + q];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double *w = Lg + offW + (6 * k + i) * 3;
-            const double w0 = w[0], w1 = w[1], w2 = w[2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) Lg[offY + (6 * k + i) * 3 + c] = w0 * Hi[c] + w1 * Hi[3 + c] + w2 * Hi[6 + c];
-        }
-    }
-    __syncthreads();
-
     // ---------------- phase 2: tiles on the matrix cores ----------------
     const int D = 6 * nb;
     const int TS = (D + 15) >> 4, nts = TS * (TS + 1) / 2;
@@ -419,28 +423,39 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
                 const int tb = ts - ta * (ta + 1) / 2;
                 const int a = 16 * ta + cl, bq = 16 * tb + cl;
                 const bool la = a < D, lb = bq < D;
-                const double *pa = sL + offW + (la ? a : 0) * 3, *pb = sL + offY + (lb ? bq : 0) * 3;
-                for (int c = 0; c < 3; ++c)
-                    for (int st4 = 0; 4 * st4 < G; ++st4) {
-                        const int g = 4 * st4 + rg;
-                        const bool ok = g < G;
-                        const double wa = (ok && la) ? pa[(size_t)g * LREC + c] : 0.0;
-                        const double yb = (ok && lb) ? pb[(size_t)g * LREC + c] : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa, -yb, acc, 0, 0, 0);
+                // one group of 4 landmarks (k index rg) per step, three matrix instructions (coordinate c) per group:
+                // A = W[a][c], B = -Y[bq][c] with Y = W H_ll^-1 formed here from the three W of the row and H_ll^-1
+                const double *pa = sL + offW + (la ? a : 0) * 3, *pb = sL + offW + (lb ? bq : 0) * 3;
+                const bool diag = ta == tb;
+                for (int st4 = 0; 4 * st4 < G; ++st4) {
+                    const int g = 4 * st4 + rg;
+                    const bool ok = g < G;
+                    const double *Lg = sL + (size_t)(ok ? g : 0) * LREC;
+                    double wb[3], wa[3], hi[9];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) wb[c] = (ok && lb) ? pb[(size_t)g * LREC + c] : 0.0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) wa[c] = diag ? wb[c] : ((ok && la) ? pa[(size_t)g * LREC + c] : 0.0);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) hi[q] = Lg[offHI + q];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double yb = wb[0] * hi[c] + wb[1] * hi[3 + c] + wb[2] * hi[6 + c];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[c], -yb, acc, 0, 0, 0);
                     }
+                }
             }
             double *tl = sTile + (size_t)wk * 256 + rg * 16 + cl;   // C/D image: row rg + 4v, column cl
 #pragma unroll
             for (int v = 0; v < 4; ++v) tl[64 * v] = acc[v];
         }
-        // b vectors: which 0: direct b = - sum_g (drho J_pose^T Info r)_g;  1: Schur correction = sum_g Y_g b_l,g   (fixed order)
-        for (int e = tid; e < 2 * D * LIN_VS; e += LIN_THREADS) {
-            const int part = e % LIN_VS, a = (e / LIN_VS) % D, which = e / (LIN_VS * D);
+        // Schur correction of b = sum_g Y_g b_l,g = sum_g W_g (H_ll^-1 b_l)_g   (fixed order)
+        for (int e = tid; e < D * LIN_VS; e += LIN_THREADS) {
+            const int part = e % LIN_VS, a = e / LIN_VS;
             double sum = 0.0;
             for (int g = part; g < G; g += LIN_VS) {
                 const double *Lg = sL + (size_t)g * LREC;
-                if (which == 0) sum += -Lg[offBP + a];
-                else sum += Lg[offY + 3 * a] * Lg[offBL] + Lg[offY + 3 * a + 1] * Lg[offBL + 1] + Lg[offY + 3 * a + 2] * Lg[offBL + 2];
+                sum += Lg[offW + 3 * a] * Lg[offV] + Lg[offW + 3 * a + 1] * Lg[offV + 1] + Lg[offW + 3 * a + 2] * Lg[offV + 2];
             }
             sVec[e] = sum;
         }
@@ -473,8 +488,11 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
                 if (p == q) v += cdir(p, i, j);
             } else {
                 const int ve = e - n_pair, which = ve / D, a = ve - which * D;
-                if (which < 2) {
-                    const double *pv = sVec + (size_t)(which * D + a) * LIN_VS;
+                if (which == 0) {           // direct b: the wave partials of phase 1 (a = 6 k + i; second chunk zero for G <= 64)
+                    const int p = a / 6, i = a - 6 * p;
+                    v = -(sBp[(2 * p) * 6 + i] + sBp[(2 * p + 1) * 6 + i]);
+                } else if (which == 1) {
+                    const double *pv = sVec + (size_t)a * LIN_VS;
 #pragma unroll
                     for (int q = 0; q < LIN_VS; ++q) v += pv[q];
                 } else {
