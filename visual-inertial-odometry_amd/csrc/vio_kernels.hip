@@ -1489,7 +1489,30 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
         const int k0 = K * PS_NB, k1 = k0 + PS_NB;
         const int nk = PS_NT - 1 - K;                           // block rows below the panel
         // ---- S: one tile per wave; the rhs row's 16 entries by wave 15 ----
-        if (uwave < nk) {
+        if (uwave == 0 && nk > 0) {
+            // Wave 0 is the critical path (F(K) -> U_{K+1,K} -> A_{K+1,K+1} -> F(K+1)): it forms its S product TRANSPOSED,
+            // (A M)^T = M^T A^T — the same loads with the operand roles swapped, the same products in the same order — so that
+            // the accumulator IS the A/B operand image of U_{K+1,K} and the update of the next diagonal tile follows from
+            // registers, inside this phase instead of after the barrier.  The pivots are still on the factored tile's
+            // diagonal (M_K is parked around them: its own diagonal is 1).
+            double *tt = P + tix(K + 1, K);
+            double *td = P + tix(K + 1, K + 1) + cofs;
+            const double *pd = P + tix(K, K) + (lane >> 4) * (PS_TROW + 1);
+            double av[4], bv[4], pv[4];
+            ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = tt[lofs + 4 * q]; bv[q] = sM[cofs + 4 * PS_TROW * q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pv[q] = pd[4 * q * (PS_TROW + 1)]; acc2[q] = td[4 * PS_TROW * q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[q], av[q], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tt[lofs + 4 * q] = acc[q];          // U_{K+1,K}[l & 15][(l >> 4) + 4 q]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q], acc[q] * -d_fast_rcp(pv[q]), acc2, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) td[4 * PS_TROW * q] = acc2[q];
+        } else if (uwave < nk) {
             double *tt = P + tix(K + 1 + uwave, K);
             double av[4], bv[4];
             ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -1509,7 +1532,8 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
             __builtin_amdgcn_sched_barrier(0);
             if (lane < PS_NB) sDinv[k0 + lane] = dd;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) P[tix(K, K) + ((lane >> 4) + 4 * q) * PS_TROW + (lane & 15)] = mk[q];
+            for (int q = 0; q < 4; ++q)         // (not the diagonal: M_K's is 1, and the pivots stay readable)
+                if ((lane >> 4) + 4 * q != (lane & 15)) P[tix(K, K) + ((lane >> 4) + 4 * q) * PS_TROW + (lane & 15)] = mk[q];
         } else if (uwave == PS_THREADS / 64 - 1) {
             double y = 0.0;
             if (lane < PS_NB) {
@@ -1534,8 +1558,7 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
 #ifdef VIO_STAMPS
                 const unsigned long long f0 = __builtin_amdgcn_s_memtime();
 #endif
-                update_tile(K + 1, K + 1, K, nd);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // (its update of tile (K+1,K+1) happened in the S phase, from registers)
 #ifdef VIO_STAMPS
                 const unsigned long long f1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1630,7 +1653,7 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
         if (K < PS_NT && work) {
             const double *src = P + tix(K, K) + i16 * PS_TROW;                       // row i16 of M_K
 #pragma unroll
-            for (int j = 0; j < PS_NB; ++j) mw[j] = src[j];
+            for (int j = 0; j < PS_NB; ++j) mw[j] = (j == i16) ? 1.0 : src[j];     // (the tile's diagonal still holds the pivots)
             own_dinv = sDinv[K * PS_NB + i16];
             own_z = sY[K * PS_NB + i16] * own_dinv;                                  // sY holds y = L^-1 b (unscaled)
             if (K == PS_NT - 1) { double x; PS_DOT16(x, 0.0, own_z, mw); sX[K * PS_NB + i16] = x; }
@@ -1676,7 +1699,9 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
             sState[STATE_SB + e] = sState[STATE_SB + e] + sDx[12 + 15 * f + k];
         }
         __syncthreads();
-        d_build_pairtab(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, 128);      // one more barrier inside
+        // (XYZ windows have no host frames: k_linearize_xyz composes its camera maps from the states)
+        if (T.lm_dim == 3) __syncthreads();
+        else d_build_pairtab(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, 128);  // one more barrier inside
     } else {
         if (prior_here) {
             double hp[PS_PRIOR_ROWS][3], bp[PS_PRIOR_ROWS];
