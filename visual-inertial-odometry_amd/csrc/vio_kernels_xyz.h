@@ -176,17 +176,44 @@ __device__ __forceinline__ void d_xyz_obs(const double *A, const double *ric, co
     o.c0 = rho1 * (info * r0); o.c1 = rho1 * (info * r1);               // drho * Information * residual
 }
 
-// the observation's term of W^T dx_pose: t[c] = sum_i (L J_pose)_i^T (L J_feature)_c dx[i]  (the Hpm block times the pose step)
-__device__ __forceinline__ void d_xyz_obs_wtdx(const XyzObs &o, const double *d, double *t) {
-    double lf0[3], lf1[3];
+// the observation's term of W^T dx_pose, W = (L J_pose)^T (L J_feature) the Hpm block of (pose, landmark), without forming
+// the jacobians:  W^T dx = J_feature^T (L L (J_pose dx)),  J_pose dx = reduce (-A dp + ric^T (p_imu x dtheta)) — the
+// directional derivative of the projection along the pose step (J_pose = [-reduce A | reduce ric^T hat(p_imu)],
+// edge_reprojection.cc:170-176) — and J_feature = reduce A.  A third of the arithmetic of d_xyz_obs.
+__device__ __forceinline__ void d_xyz_obs_tdx(const double *A, const double *ric, const double *tic, const double *pw, double u, double v,
+                                              int loss_type, double loss_delta, double s_info, const double *d, double *t) {
+    const double info = s_info * s_info;
+    double pc[3], pim[3];
+    d_m3_vec(A, pw, pc);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { lf0[c] = o.L00 * o.Jf0[c] + o.L01 * o.Jf1[c]; lf1[c] = o.L01 * o.Jf0[c] + o.L11 * o.Jf1[c]; t[c] = 0.0; }
+    for (int m = 0; m < 3; ++m) pc[m] += A[9 + m];
+    d_m3_vec(ric, pc, pim);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double lp0 = o.L00 * o.Jp0[i] + o.L01 * o.Jp1[i], lp1 = o.L01 * o.Jp0[i] + o.L11 * o.Jp1[i];
+    for (int m = 0; m < 3; ++m) pim[m] += tic[m];
+    const double iz = 1.0 / pc[2];
+    const double r0 = pc[0] * iz - u, r1 = pc[1] * iz - v;
+    const double ra = -pc[0] * (iz * iz), rb = -pc[1] * (iz * iz);
+    const double cr[3] = {pim[1] * d[5] - pim[2] * d[4], pim[2] * d[3] - pim[0] * d[5], pim[0] * d[4] - pim[1] * d[3]};     // p_imu x dtheta
+    double dp[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) t[c] += (lp0 * lf0[c] + lp1 * lf1[c]) * d[i];
-    }
+    for (int m = 0; m < 3; ++m)
+        dp[m] = (ric[m] * cr[0] + ric[3 + m] * cr[1] + ric[6 + m] * cr[2]) - (A[3 * m] * d[0] + A[3 * m + 1] * d[1] + A[3 * m + 2] * d[2]);
+    const double s0 = iz * dp[0] + ra * dp[2], s1 = iz * dp[1] + rb * dp[2];
+    const double e2 = r0 * (info * r0) + r1 * (info * r1);
+    double rho0, rho1, rho2;
+    d_loss(loss_type, loss_delta, e2, rho0, rho1, rho2);
+    double lam2 = rho1;
+    if (loss_type != 0 && rho1 + 2 * rho2 * e2 > 0.) lam2 = rho1 + 2 * rho2 * e2;
+    const double al = sqrt(rho1), be = sqrt(fmax(lam2, 0.0));
+    const double rn2 = r0 * r0 + r1 * r1;
+    const double irn2 = rn2 > 0 ? 1.0 / rn2 : 0.0;
+    const double gm = (be - al) * irn2;
+    const double L00 = s_info * (al + gm * r0 * r0), L01 = s_info * (gm * r0 * r1), L11 = s_info * (al + gm * r1 * r1);
+    const double y0 = L00 * s0 + L01 * s1, y1 = L01 * s0 + L11 * s1;
+    const double z0 = L00 * y0 + L01 * y1, z1 = L01 * y0 + L11 * y1;
+    const double w0 = iz * z0, w1 = iz * z1, w2 = ra * z0 + rb * z1;                  // reduce^T z
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] = A[c] * w0 + A[3 + c] * w1 + A[6 + c] * w2;
 }
 
 // delta_l = H_ll^-1 (b_l - W^T dx_pose) (problem.cc:445) and the landmark's term of the gain-ratio denominator
@@ -291,10 +318,9 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
         for (int o = tid; o < G * K; o += LIN_THREADS) {
             const int k = o / G, g = o - k * G;
             const double pw[3] = {sHb[12 * g + 9], sHb[12 * g + 10], sHb[12 * g + 11]};
-            XyzObs ob;
-            d_xyz_obs(sFrO + 12 * k, sCamO, sCamO + 9, pw, pts[2 * o], pts[2 * o + 1], T.loss_type, T.loss_delta, s_info, ob);
             double t[3];
-            d_xyz_obs_wtdx(ob, sDx + 6 + 15 * (it.cam_block[k] - 1), t);
+            d_xyz_obs_tdx(sFrO + 12 * k, sCamO, sCamO + 9, pw, pts[2 * o], pts[2 * o + 1], T.loss_type, T.loss_delta, s_info,
+                          sDx + 6 + 15 * (it.cam_block[k] - 1), t);
 #pragma unroll
             for (int c = 0; c < 3; ++c) sT[3 * o + c] = t[c];
         }
@@ -587,10 +613,9 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub_xyz(DeviceTables T, int 
             for (int q = 0; q < 9; ++q) hb[q] = lw[(size_t)q * G + g];
             for (int k = 0; k < K; ++k) {
                 const size_t o = (size_t)it.obs_base + (size_t)k * G + g;
-                XyzObs ob;
-                d_xyz_obs(sFrO + 12 * k, sFrO + VIO_NF * 12, sFrO + VIO_NF * 12 + 9, pw, T.pts_j[2 * o], T.pts_j[2 * o + 1], T.loss_type, T.loss_delta, s_info, ob);
                 double tk[3];
-                d_xyz_obs_wtdx(ob, sDxp + 6 + 15 * (it.cam_block[k] - 1), tk);
+                d_xyz_obs_tdx(sFrO + 12 * k, sFrO + VIO_NF * 12, sFrO + VIO_NF * 12 + 9, pw, T.pts_j[2 * o], T.pts_j[2 * o + 1], T.loss_type, T.loss_delta, s_info,
+                              sDxp + 6 + 15 * (it.cam_block[k] - 1), tk);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) t[c] += tk[c];
             }
