@@ -253,12 +253,12 @@ def main():
     # ---- B independent windows per launch (vio_batch_gn_iteration): the regime in which the device is full.  Same window
     #      size as the headline, different seeds; reported beside the single-window line, never instead of it
     batched = None
-    if rank == 0 and world == 1 and args.batch > 0 and not xyz:
+    if rank == 0 and world == 1 and args.batch > 0:
         B = args.batch
         lead = hip.context(device=local_rank)
         members = [lead] + [hip.context(device=local_rank, stream=lead.get_stream()) for _ in range(B - 1)]
         for i, cb in enumerate(members):
-            wb = vio.synth.make_window(n_per_gpu, seed=100 + i, obs_per_landmark=k_obs)
+            wb = (vio.synth.make_window_xyz if xyz else vio.synth.make_window)(n_per_gpu, seed=100 + i, obs_per_landmark=k_obs)
             wb.prior = full.prior
             cb.load(wb)
         for _ in range(5):

@@ -189,7 +189,8 @@ vio_status vio_get_stream(struct vio_ctx *ctx, void **stream);
  * dimension is the window), i.e. `count` pose solves side by side instead of one workgroup on one of the 256 compute units.
  * Every window is an ordinary context (its own graph, states, prior, LmState) and is read back with the ordinary
  * getters; the contexts must share one device and one stream (create the others with vio_config.stream = the first one's
- * vio_get_stream) and hold inverse-depth landmarks.  Results are bit-identical to calling vio_gn_iteration on each.
+ * vio_get_stream) and hold one kind of landmark (all inverse depths or all XYZ points).  Results are bit-identical to calling
+ * vio_gn_iteration on each.
  * Not a reference entry point: the reference solves one window at a time (System::ProcessBackEnd, one estimator). */
 vio_status vio_batch_gn_iteration(struct vio_ctx *const *ctxs, int32_t count, double lambda);
 

@@ -65,6 +65,30 @@ def test_batched_gn_equals_separate_runs(vio, hip_lib, oracle_lib):
             np.testing.assert_array_equal(x, y)
 
 
+def test_batched_gn_xyz_windows(vio, hip_lib):
+    """XYZ-landmark windows in one batch (k_linearize_xyz_b): equal to separate runs bit for bit, ragged sizes included."""
+    ws = [vio.synth.make_window_xyz(600, seed=11, ragged=True), vio.synth.make_window_xyz(2000, seed=12), vio.synth.make_window_xyz(40, seed=13),
+          vio.synth.make_window_xyz(1, seed=14, obs_per_landmark=4)]
+    lam = 2e5
+    lead = hip_lib.context()
+    batch = [lead] + [hip_lib.context(stream=lead.get_stream()) for _ in ws[1:]]
+    solo = [hip_lib.context() for _ in ws]
+    for c, r, w in zip(batch, solo, ws):
+        c.load(w)
+        r.load(w)
+    for it in range(4):
+        hip_lib.batch_gn_iteration(batch, lam)
+        for r in solo:
+            r.gn_iteration(lam)
+        if it == 1:
+            np.testing.assert_array_equal(batch[0].get_landmarks_xyz(), solo[0].get_landmarks_xyz())
+    for c, r in zip(batch, solo):
+        for x, y in zip(c.get_window(), r.get_window()):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(c.get_landmarks_xyz(), r.get_landmarks_xyz())
+        assert c.chi2() == r.chi2()
+
+
 def test_batch_argument_checks(vio, hip_lib):
     a, b = hip_lib.context(), hip_lib.context()            # two streams
     w = vio.synth.make_window(50, seed=1)
@@ -75,4 +99,4 @@ def test_batch_argument_checks(vio, hip_lib):
     c = hip_lib.context(stream=a.get_stream())
     c.load(vio.synth.make_window_xyz(50, seed=1))
     with pytest.raises(vio.VioError):
-        hip_lib.batch_gn_iteration([a, c], 1e3)            # XYZ windows take the classic sequence: not batched
+        hip_lib.batch_gn_iteration([a, c], 1e3)            # one kind of landmark per batch

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep for XYZ-landmark windows (diagnostic; the fixed cases live in tests/test_xyz_landmarks.py): HIP
 against the oracle on windows of random size, pattern structure, loss, extrinsic flag and prior; one stepwise LM step, three
-GN iterations, Solve(10), and a batched pass is not part of it (XYZ windows take the classic sequence).
+GN iterations and Solve(10) (the batched pass of XYZ windows is in tests/test_gpu_batch.py).
   python tools/fuzz_parity_xyz.py [cases] [seed]"""
 import os
 import sys

@@ -48,7 +48,7 @@ void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStr
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
-void vio_launch_batch_gn(const DeviceTables *tabs, int B, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
+void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
                          size_t ps_lds, hipStream_t s);
 int vio_set_kernel_attributes();
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext);
@@ -1188,7 +1188,7 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         if (m->cfg.device != c->cfg.device || m->stream != c->stream)
             return fail(c, VIO_ERR_BAD_ARG, "vio_batch_gn_iteration: the contexts must share one device and one stream (vio_config.stream; vio_get_stream)");
         if (sharded(m)) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_gn_iteration: sharded contexts cannot be batched");
-        if (m->lm_dim != 1) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_gn_iteration: inverse-depth windows only");
+        if (m->lm_dim != c->lm_dim) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_gn_iteration: the windows of a batch hold one kind of landmark");
     }
     bool rebuild = (int)c->batch_members.size() != count;
     for (int i = 0; i < count; ++i) {
@@ -1199,7 +1199,7 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         if (!rebuild && (c->batch_members[i] != m || c->batch_gens[i] != m->tables_gen || g0 != m->tables_gen)) rebuild = true;
         // a step waiting for its test belongs to the batch's own sequence only if the array is current; otherwise settle it
         if (m->cur_host < 0 || (rebuild && m->decide_pending)) VIOCHK(read_lm(m));
-        if (!m->pairtab_valid) { DeviceTables T = make_tables_raw(m, m->solve_plan); T.cur_hint = m->cur_host; vio_launch_prepare(T, m->stream); m->pairtab_valid = true; }
+        if (!m->pairtab_valid && m->lm_dim == 1) { DeviceTables T = make_tables_raw(m, m->solve_plan); T.cur_hint = m->cur_host; vio_launch_prepare(T, m->stream); m->pairtab_valid = true; }
         if (lambda != m->gn_lambda) { vio_launch_set_lambda(m->d_lm.p, lambda, m->stream); m->gn_lambda = lambda; }
     }
     if (!rebuild)
@@ -1228,7 +1228,7 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         any_prior |= ctxs[i]->has_prior;
     }
     const int test_prev = ctxs[0]->decide_pending ? 1 : 0;
-    vio_launch_batch_gn(c->d_batch_tabs.p, count, max_blocks, lds, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, c->stream);
+    vio_launch_batch_gn(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, c->stream);
     HIPCHK(hipGetLastError());
     ++c->batch_iters;
     for (int i = 0; i < count; ++i) {

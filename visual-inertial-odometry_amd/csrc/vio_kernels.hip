@@ -2106,11 +2106,12 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
     if (T.lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
     else hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
-// batched GN iteration (inverse-depth windows): grid.y = window
-void vio_launch_batch_gn(const DeviceTables *tabs, int B, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
+// batched GN iteration (windows of one landmark kind): grid.y = window
+void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
                          size_t ps_lds, hipStream_t s) {
     BatchArgs a{tabs, test_prev ? 2 : 0, parity};
-    hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+    if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+    else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
     a.gn_flags = test_prev ? 1 : 0;
     hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
@@ -2165,5 +2166,6 @@ int vio_set_kernel_attributes() {
     if (hipFuncSetAttribute((const void *)k_linearize_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_pose_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     hipError_t e3 = hipFuncSetAttribute((const void *)k_linearize_xyz, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -1;
 }

@@ -232,7 +232,7 @@ __device__ __forceinline__ double d_xyz_landmark_step(const double *h, const dou
 }
 
 
-__global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
+__device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (d_gated_off(T.lm, T.lm_gate)) return;
@@ -552,6 +552,13 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) {
             lw[e] = r < 6 ? Lg[offH + r] : Lg[offBL + (r - 6)];
         }
     }
+}
+
+__global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) { d_linearize_xyz_body(T); }
+__global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz_b(BatchArgs a) {
+    const DeviceTables T = d_batch_tables(a);
+    if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;       // the grid is the widest window's
+    d_linearize_xyz_body(T);
 }
 
 // ---------------------------------------------------------------------------------------------------------
