@@ -472,6 +472,12 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         s = e;
     }
     pl.Ms = obs_base;
+    if (std::getenv("VIO_HOST_TIMING")) {
+        const auto tb = std::chrono::steady_clock::now();
+        const vio_status st = upload_plan(c, pl, pts_i, pts_j);
+        std::fprintf(stderr, "[vio host timing] build_plan: upload_plan %.0f us of it\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count());
+        return st;
+    }
     return upload_plan(c, pl, pts_i, pts_j);
 }
 
@@ -659,12 +665,21 @@ vio_status activate(vio_ctx *c, Plan &pl, int marg) {
     const bool need_build = !pl.valid || c->topo_dirty;
     const bool switching = c->active != &pl;
     if (need_build || switching || c->dirty_inputs) {
+        static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;      // diagnostic: where a frame's host time goes
+        const auto t0 = std::chrono::steady_clock::now();
         VIOCHK(pull_from_device(c));
+        const auto t1 = std::chrono::steady_clock::now();
         if (need_build) {
             if (c->topo_dirty) { c->solve_plan.valid = false; c->marg_plan.valid = false; c->topo_dirty = false; }
             VIOCHK(build_plan(c, pl, marg));
         }
+        const auto t2 = std::chrono::steady_clock::now();
         VIOCHK(push_to_device(c, pl));
+        if (timing) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            std::fprintf(stderr, "[vio host timing] activate(marg=%d): pull %.0f us, build_plan+upload %.0f us, push %.0f us\n", marg, us(t0, t1), us(t1, t2), us(t2, t3));
+        }
         ++c->tables_gen;
         c->active = &pl;
         c->dirty_inputs = false;
