@@ -277,7 +277,7 @@ def main():
                    "final_chi2_window0": lead.chi2(),
                    "note": "B independent 20k-landmark windows (seeds 100..), one launch per kernel for all of them (grid.y = window); "
                            "bit-identical to B separate vio_gn_iteration runs (tests/test_gpu_batch.py)"}
-        del members, lead
+        del cb, members, lead          # (members first: they run on the leader's stream)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -913,7 +913,10 @@ vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
 void vio_destroy(vio_ctx *c) {
     if (!c) return;
     hipSetDevice(c->cfg.device);
-    hipStreamSynchronize(c->stream);
+    // A stream the caller supplied (vio_config.stream, e.g. the leader's of a batch) may be gone already when this context
+    // goes: it is not touched here.  hipFree waits for the device itself, so nothing in flight loses its buffers.
+    if (c->own_stream) hipStreamSynchronize(c->stream);
+    else hipDeviceSynchronize();
     vio_comm_destroy(c);
     c->solve_plan.release(); c->marg_plan.release();
     c->d_state.release(); c->d_pairtab.release(); c->d_vis.release(); c->d_pre.release(); c->d_imu_out.release();
