@@ -172,6 +172,46 @@ def test_hip_gn_iterations_against_oracle(vio, oracle_lib, hip_lib):
 
 
 @pytest.mark.gpu
+def test_hip_gn_loop_defers_and_flushes_consistently(vio, oracle_lib, hip_lib):
+    """The GN loop of an XYZ window leaves a step's landmark back-substitution, chi2 and test to the head of the next
+    k_linearize_xyz, which forms W^T dx again from the state the step was linearised at; anybody else who asks first gets them
+    from k_backsub_xyz + k_lm_decide (flush).  Both form the same per-observation terms in the same order: the same bits,
+    whatever is interleaved; and the stepwise entry points (linearize / solve_linear / update) are the same arithmetic."""
+    w = vio.synth.make_window_xyz(900, seed=23, ragged=True)
+    lam = 2e5
+    plain, mixed, steps = hip_lib.context(), hip_lib.context(), hip_lib.context()
+    for c in (plain, mixed, steps):
+        c.load(w)
+    for _ in range(6):
+        plain.gn_iteration(lam)
+        steps.linearize()
+        steps.solve_linear(lam)
+        steps.update_states()
+    mixed.gn_iteration(lam)
+    mixed.get_window()                                   # read-back: flush
+    mixed.gn_iteration(lam)
+    mixed.gn_iteration(lam)
+    c3 = mixed.chi2()
+    mixed.get_landmarks_xyz()
+    mixed.gn_iteration(lam)
+    mixed.linearize()
+    mixed.gn_iteration(lam)
+    mixed.gn_iteration(lam)
+    for c in (mixed, steps):
+        for a, b in zip(c.get_window(), plain.get_window()):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(c.get_landmarks_xyz(), plain.get_landmarks_xyz())
+        assert c.chi2() == plain.chi2()
+    o = oracle_lib.context()
+    o.load(w)
+    for _ in range(3):
+        o.gn_iteration(lam)
+    assert abs(c3 - o.chi2()) <= 1e-9 * c3
+    rep = mixed.solve(5)                                  # an LM solve straight after GN iterations starts from the flushed state
+    assert np.isfinite(rep.final_chi2) and rep.final_chi2 <= plain.chi2() * (1 + 1e-9)
+
+
+@pytest.mark.gpu
 def test_hip_hessian_nullspace(vio, hip_lib):
     check_nullspace(vio, hip_lib)
 
