@@ -78,6 +78,61 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; n = 0; }
 };
 
+// Pinned staging for the uploads of a frame (plan tables, observations, states, prior): the copies out of it are truly
+// asynchronous, so activate() does not wait for the device at all (two hipStreamSynchronize per activation before: ~0.2 ms
+// of a 2.6 ms frame).  begin() waits for the copies of the previous use (long done in practice), then hands out pieces;
+// a piece that does not fit opens a new chunk, and the next begin() makes one chunk of the total.
+struct HostArena {
+    struct Chunk { char *p; size_t cap, off; };
+    std::vector<Chunk> chunks;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    hipError_t begin() {
+        if (pending) { hipError_t e = hipEventSynchronize(ev); if (e != hipSuccess) return e; pending = false; }
+        if (chunks.size() > 1) {
+            size_t tot = 0;
+            for (Chunk &c : chunks) { tot += c.cap; hipHostFree(c.p); }
+            chunks.clear();
+            Chunk c{nullptr, tot + tot / 4, 0};
+            hipError_t e = hipHostMalloc((void **)&c.p, c.cap, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            chunks.push_back(c);
+        }
+        for (Chunk &c : chunks) c.off = 0;
+        return hipSuccess;
+    }
+    void *alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (chunks.empty() || chunks.back().off + bytes > chunks.back().cap) {
+            Chunk c{nullptr, std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20), 0};
+            if (hipHostMalloc((void **)&c.p, c.cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+            chunks.push_back(c);
+        }
+        Chunk &c = chunks.back();
+        void *r = c.p + c.off;
+        c.off += bytes;
+        return r;
+    }
+    template <typename T> T *put(const T *src, size_t count) {
+        T *d = (T *)alloc(std::max<size_t>(count, 1) * sizeof(T));
+        if (d && count) std::memcpy(d, src, count * sizeof(T));
+        return d;
+    }
+    hipError_t end(hipStream_t st) {
+        if (!ev) { hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
+        hipError_t e = hipEventRecord(ev, st);
+        pending = e == hipSuccess;
+        return e;
+    }
+    void release() {
+        if (pending && ev) hipEventSynchronize(ev);
+        for (Chunk &c : chunks) hipHostFree(c.p);
+        chunks.clear();
+        if (ev) hipEventDestroy(ev);
+        ev = nullptr; pending = false;
+    }
+};
+
 struct Pattern {
     int use_ext, host, K, nb, host_slot, G;
     int btype_i[VIO_MAXNB], bk_i[VIO_MAXNB];
@@ -123,6 +178,10 @@ struct vio_ctx {
     std::vector<double> h_pre;                 // [10][PRE_STRIDE]
     int has_prior = 0;
     std::vector<double> h_Hprior, h_bprior, h_errprior, h_Jtinv;
+    HostArena arena;                           // pinned staging of the uploads
+    double *pull_stage = nullptr;              // pinned staging of the landmark read-back (pull_from_device)
+    size_t pull_cap = 0;
+    bool prior_dirty = true, imu_dirty = true; // h_Hprior / h_Jtinv resp. h_pre newer than their device copies
     // dirty tracking
     bool dirty_inputs = true;                  // host mirrors newer than the device
     bool device_ahead = false;                 // device states newer than the host mirrors
@@ -207,7 +266,7 @@ void build_pattern_tables(Pattern &pt, int g_max) {
     pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
 }
 
-vio_status upload_plan(vio_ctx *c, Plan &pl, const std::vector<double> &pts_i, const std::vector<double> &pts_j);
+vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j);
 
 // The plan of a window of XYZ landmarks (vio_kernels_xyz.h): a pattern is the set of frames a landmark is seen from,
 // one pattern block per frame, no host frame and no extrinsic block.
@@ -286,7 +345,10 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
         }
     }
     pl.items.clear();
-    std::vector<double> pts_i(2, 0.0), pts_j;
+    // observations in item order, written straight into the pinned staging (every observation of the window has a place)
+    const double *pts_i = nullptr;
+    double *pts_j = (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>((int64_t)c->h_olm.size(), 1) * 8);
+    if (!pts_j) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
     pl.slab_doubles = 0; pl.lw_doubles = 0; pl.max_lds_doubles = IMU_ITEM_LDS_DOUBLES;
     int64_t s = 0, obs_base = 0;
     while (s < pl.Ns) {
@@ -308,7 +370,6 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
         pl.slab_doubles += (size_t)item_out_count(pt.nb);
         pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
         pl.lw_doubles += (size_t)9 * it.G;            // H_ll (6), b_l (3): W is formed again where it is needed
-        pts_j.resize(2 * (obs_base + (int64_t)it.G * it.K));
         for (int g = 0; g < it.G; ++g) {
             const int32_t l = pl.sorted_to_orig[s + g];
             for (int k = 0; k < it.K; ++k) {
@@ -330,6 +391,10 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     pl.marg = marg; pl.lm_dim = 1;
     pl.use_ext = marg ? 1 : (c->cfg.ext_fixed ? 0 : 1);
     const int64_t N = (int64_t)c->h_invd.size(), M = (int64_t)c->h_olm.size();
+    static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const auto tp0 = tnow();
     // observations of each landmark, in the caller's order (CSR; this runs once per frame on the host, so no
     // per-landmark allocations and no tree lookups: 20 000 landmarks take well under a millisecond)
     struct ObsRange { const int32_t *p; size_t n; size_t size() const { return n; } bool empty() const { return n == 0; }
@@ -343,6 +408,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         for (int64_t e = 0; e < M; ++e) obs_idx[fill[c->h_olm[e]]++] = (int32_t)e;
     }
     auto obs_of = [&](int64_t l) { return ObsRange{obs_idx.data() + obs_off[l], (size_t)(obs_off[l + 1] - obs_off[l])}; };
+    const auto tp1 = tnow();
     // pattern of each landmark: (host, targets in observation order) packed 4 bits a frame
     std::unordered_map<uint64_t, int> pattern_id;
     pl.patterns.clear();
@@ -394,6 +460,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         } else id = itp->second;
         lm_pattern[l] = id;
     }
+    const auto tp2 = tnow();
     // sort landmarks by pattern (stable in the original index)
     {   // counting sort: pattern-major, original index inside a pattern
         std::vector<int64_t> start(pl.patterns.size() + 1, 0);
@@ -435,8 +502,12 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         }
     }
     // items
+    const auto tp3 = tnow();
     pl.items.clear();
-    std::vector<double> pts_i(2 * std::max<int64_t>(pl.Ns, 1)), pts_j;
+    // host observations / observations in item order, written straight into the pinned staging
+    double *pts_i = (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>(pl.Ns, 1) * 8);
+    double *pts_j = (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>(M, 1) * 8);
+    if (!pts_i || !pts_j) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
     pl.slab_doubles = 0; pl.lw_doubles = 0; pl.max_lds_doubles = IMU_ITEM_LDS_DOUBLES;
     int64_t s = 0, obs_base = 0;
     while (s < pl.Ns) {
@@ -458,7 +529,6 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         pl.slab_doubles += (size_t)item_out_count(pt.nb);
         pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
         pl.lw_doubles += (size_t)item_lw_fields(pt.nb) * it.G;
-        pts_j.resize(2 * (obs_base + (int64_t)it.G * it.K));
         for (int g = 0; g < it.G; ++g) {
             const int32_t l = pl.sorted_to_orig[s + g];
             const ObsRange ob = obs_of(l);
@@ -472,8 +542,9 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         s = e;
     }
     pl.Ms = obs_base;
-    if (std::getenv("VIO_HOST_TIMING")) {
+    if (timing) {
         const auto tb = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[vio host timing] build_plan: obs lists %.0f us, patterns %.0f us, sort + sizing %.0f us, items + gather %.0f us\n", tus(tp0, tp1), tus(tp1, tp2), tus(tp2, tp3), tus(tp3, tb));
         const vio_status st = upload_plan(c, pl, pts_i, pts_j);
         std::fprintf(stderr, "[vio host timing] build_plan: upload_plan %.0f us of it\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count());
         return st;
@@ -482,7 +553,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
 }
 
 // inverted lists for k_reduce, device buffers, upload: common to both kinds of landmark
-vio_status upload_plan(vio_ctx *c, Plan &pl, const std::vector<double> &pts_i, const std::vector<double> &pts_j) {
+vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j) {
     const int n_lists = VIO_NPAIR + VIO_NCB + 1;
     std::vector<std::vector<int32_t>> lists(n_lists);
     for (const ItemDesc &it : pl.items) {
@@ -515,12 +586,15 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const std::vector<double> &pts_i, c
     HIPCHK(pl.d_lw.resize(pl.lw_doubles)); HIPCHK(pl.d_dxl.resize(ld * (size_t)pl.Ns));
     HIPCHK(pl.d_step_part.resize(4 * (ni + VIO_WINDOW_SIZE)));
     hipStream_t st = c->stream;
-    if (ni) HIPCHK(hipMemcpyAsync(pl.d_items.p, pl.items.data(), ni * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(pl.d_list_off.p, pl.list_off.data(), pl.list_off.size() * 4, hipMemcpyHostToDevice, st));
-    if (!pl.list.empty()) HIPCHK(hipMemcpyAsync(pl.d_list.p, pl.list.data(), pl.list.size() * 4, hipMemcpyHostToDevice, st));
-    if (pl.Ns && pl.lm_dim == 1) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i.data(), 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
-    if (pl.Ms) HIPCHK(hipMemcpyAsync(pl.d_pts_j.p, pts_j.data(), 2 * (size_t)pl.Ms * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));
+    // everything leaves from the pinned staging: no wait here (activate() marks the staging busy until these copies are done)
+    const ItemDesc *s_items = c->arena.put(pl.items.data(), ni);
+    const int32_t *s_off = c->arena.put(pl.list_off.data(), pl.list_off.size()), *s_list = c->arena.put(pl.list.data(), pl.list.size());
+    if (!s_items || !s_off || !s_list) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+    if (ni) HIPCHK(hipMemcpyAsync(pl.d_items.p, s_items, ni * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(pl.d_list_off.p, s_off, pl.list_off.size() * 4, hipMemcpyHostToDevice, st));
+    if (!pl.list.empty()) HIPCHK(hipMemcpyAsync(pl.d_list.p, s_list, pl.list.size() * 4, hipMemcpyHostToDevice, st));
+    if (pl.Ns && pl.lm_dim == 1) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i, 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
+    if (pl.Ms) HIPCHK(hipMemcpyAsync(pl.d_pts_j.p, pts_j, 2 * (size_t)pl.Ms * 8, hipMemcpyHostToDevice, st));
     pl.valid = true;
     return VIO_OK;
 }
@@ -620,9 +694,17 @@ vio_status pull_from_device(vio_ctx *c) {
     HIPCHK(hipMemcpyAsync(c->h_state, c->d_state.p + cur * STATE_STRIDE, STATE_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
     Plan &pl = c->solve_plan;
     const size_t ld = (size_t)pl.lm_dim;
-    std::vector<double> tmp(ld * (size_t)std::max<int64_t>(pl.Ns, 1));
+    // the landmarks come back through a pinned buffer of the context's (a pageable destination is staged by the runtime)
+    const size_t need = ld * (size_t)std::max<int64_t>(pl.Ns, 1);
+    if (need > c->pull_cap) {
+        if (c->pull_stage) hipHostFree(c->pull_stage);
+        c->pull_stage = nullptr; c->pull_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&c->pull_stage, (need + need / 4) * 8, hipHostMallocDefault));
+        c->pull_cap = need + need / 4;
+    }
+    double *tmp = c->pull_stage;
     if (pl.valid && pl.Ns)
-        HIPCHK(hipMemcpyAsync(tmp.data(), pl.d_invd.p + (size_t)cur * ld * pl.Ns, ld * (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(tmp, pl.d_invd.p + (size_t)cur * ld * pl.Ns, ld * (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
     if (c->has_prior) {
         HIPCHK(hipMemcpyAsync(c->h_bprior.data(), c->d_bprior.p + cur * 176, PD * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_errprior.data(), c->d_errprior.p + cur * 160, PRD * 8, hipMemcpyDeviceToHost, c->stream));
@@ -638,24 +720,40 @@ vio_status pull_from_device(vio_ctx *c) {
 // upload the host mirrors into copy 0 and reset the LM state
 vio_status push_to_device(vio_ctx *c, Plan &pl) {
     hipStream_t st = c->stream;
-    HIPCHK(hipMemcpyAsync(c->d_state.p, c->h_state, STATE_STRIDE * 8, hipMemcpyHostToDevice, st));
+    HostArena &A = c->arena;
     const size_t ld = (size_t)pl.lm_dim;
-    std::vector<double> tmp(ld * (size_t)std::max<int64_t>(pl.Ns, 1));
-    for (int64_t s = 0; s < pl.Ns; ++s)
-        for (size_t k = 0; k < ld; ++k) tmp[k * pl.Ns + s] = c->h_invd[ld * pl.sorted_to_orig[s] + k];
-    if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_invd.p, tmp.data(), ld * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_pre.p, c->h_pre.data(), VIO_WINDOW_SIZE * PRE_STRIDE * 8, hipMemcpyHostToDevice, st));
+    double *s_state = A.put(c->h_state, (size_t)STATE_STRIDE);
+    double *s_invd = (double *)A.alloc(ld * (size_t)std::max<int64_t>(pl.Ns, 1) * 8);
+    double *s_b = A.put(c->h_bprior.data(), (size_t)PD), *s_e = A.put(c->h_errprior.data(), (size_t)PRD);
     int32_t iv[16] = {0};
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) iv[k] = c->imu_valid[k] ? 1 : 0;
-    HIPCHK(hipMemcpyAsync(c->d_imu_valid.p, iv, sizeof(iv), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_Hprior.p, c->h_Hprior.data(), PD * PD * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_bprior.p, c->h_bprior.data(), PD * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_errprior.p, c->h_errprior.data(), PRD * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_Jtinv.p, c->h_Jtinv.data(), PRD * PRD * 8, hipMemcpyHostToDevice, st));
+    int32_t *s_iv = A.put(iv, (size_t)16);
     std::memset(&c->h_lm, 0, sizeof(LmState));
     c->h_lm.ni = 2; c->h_lm.lambda = -1; c->h_lm.finite = 1; c->h_lm.last_chi = 1e20;
-    HIPCHK(hipMemcpyAsync(c->d_lm.p, &c->h_lm, sizeof(LmState), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));      // the staging vectors above go out of scope
+    LmState *s_lm = A.put(&c->h_lm, (size_t)1);
+    if (!s_state || !s_invd || !s_b || !s_e || !s_iv || !s_lm) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+    HIPCHK(hipMemcpyAsync(c->d_state.p, s_state, STATE_STRIDE * 8, hipMemcpyHostToDevice, st));
+    for (int64_t s = 0; s < pl.Ns; ++s)
+        for (size_t k = 0; k < ld; ++k) s_invd[k * pl.Ns + s] = c->h_invd[ld * pl.sorted_to_orig[s] + k];
+    if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_invd.p, s_invd, ld * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
+    // the pre-integrations and the two matrices of the prior never change on the device: uploaded when the caller set them
+    if (c->imu_dirty) {
+        double *s_pre = A.put(c->h_pre.data(), (size_t)VIO_WINDOW_SIZE * PRE_STRIDE);
+        if (!s_pre) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+        HIPCHK(hipMemcpyAsync(c->d_pre.p, s_pre, VIO_WINDOW_SIZE * PRE_STRIDE * 8, hipMemcpyHostToDevice, st));
+        c->imu_dirty = false;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_imu_valid.p, s_iv, sizeof(iv), hipMemcpyHostToDevice, st));
+    if (c->prior_dirty) {
+        double *s_H = A.put(c->h_Hprior.data(), (size_t)PD * PD), *s_J = A.put(c->h_Jtinv.data(), (size_t)PRD * PRD);
+        if (!s_H || !s_J) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+        HIPCHK(hipMemcpyAsync(c->d_Hprior.p, s_H, PD * PD * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->d_Jtinv.p, s_J, PRD * PRD * 8, hipMemcpyHostToDevice, st));
+        c->prior_dirty = false;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_bprior.p, s_b, PD * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_errprior.p, s_e, PRD * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_lm.p, s_lm, sizeof(LmState), hipMemcpyHostToDevice, st));
     c->decide_pending = false; c->cur_host = 0;      // a fresh LmState: nothing of the old one is owed
     return VIO_OK;
 }
@@ -668,6 +766,7 @@ vio_status activate(vio_ctx *c, Plan &pl, int marg) {
         static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;      // diagnostic: where a frame's host time goes
         const auto t0 = std::chrono::steady_clock::now();
         VIOCHK(pull_from_device(c));
+        HIPCHK(c->arena.begin());                   // (waits for the copies of the previous activation: long done)
         const auto t1 = std::chrono::steady_clock::now();
         if (need_build) {
             if (c->topo_dirty) { c->solve_plan.valid = false; c->marg_plan.valid = false; c->topo_dirty = false; }
@@ -675,6 +774,7 @@ vio_status activate(vio_ctx *c, Plan &pl, int marg) {
         }
         const auto t2 = std::chrono::steady_clock::now();
         VIOCHK(push_to_device(c, pl));
+        HIPCHK(c->arena.end(c->stream));
         if (timing) {
             const auto t3 = std::chrono::steady_clock::now();
             auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
@@ -924,6 +1024,8 @@ void vio_destroy(vio_ctx *c) {
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
     c->d_batch_tabs.release(); c->d_rank.release();
+    c->arena.release();
+    if (c->pull_stage) hipHostFree(c->pull_stage);
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1004,6 +1106,7 @@ vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
         std::memcpy(o + PRE_JAC, pre->jacobian, 225 * 8);
         vio_host::inverse15(pre->covariance, o + PRE_INFO);     // SetInformation(covariance.inverse()), edge_imu.cc:35
     }
+    c->imu_dirty = true;
     c->dirty_inputs = true;
     return VIO_OK;
 }
@@ -1016,6 +1119,7 @@ vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double 
     std::fill(c->h_Hprior.begin(), c->h_Hprior.end(), 0.0); std::fill(c->h_bprior.begin(), c->h_bprior.end(), 0.0);
     std::fill(c->h_errprior.begin(), c->h_errprior.end(), 0.0); std::fill(c->h_Jtinv.begin(), c->h_Jtinv.end(), 0.0);
     c->has_prior = dim ? 1 : 0;
+    c->prior_dirty = true;
     if (dim) {      // ExtendHessiansPriorSize(15): 15 zero rows/cols appended (problem.cc:82-91)
         for (int i = 0; i < PRD; ++i) { std::memcpy(&c->h_Hprior[(size_t)i * PD], &H[(size_t)i * PRD], PRD * 8); c->h_bprior[i] = b[i]; }
         std::memcpy(c->h_errprior.data(), err, PRD * 8);
