@@ -40,6 +40,7 @@ void vio_launch_prepare(const DeviceTables &T, hipStream_t s);
 void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s);
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
+void vio_launch_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map, hipStream_t s);
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s);
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s);
@@ -179,12 +180,13 @@ struct vio_ctx {
     int has_prior = 0;
     std::vector<double> h_Hprior, h_bprior, h_errprior, h_Jtinv;
     HostArena arena;                           // pinned staging of the uploads
+    double *marg_stage = nullptr;              // pinned: H_marg (171 x 171) and b_marg for the host tail of vio_marginalize
     double *pull_stage = nullptr;              // pinned staging of the landmark read-back (pull_from_device)
     size_t pull_cap = 0;
     bool prior_dirty = true, imu_dirty = true; // h_Hprior / h_Jtinv resp. h_pre newer than their device copies
     // dirty tracking
     bool dirty_inputs = true;                  // host mirrors newer than the device
-    bool device_ahead = false;                 // device states newer than the host mirrors
+    unsigned ahead = 0;                        // what the device holds newer than the host mirrors: 1 states, 2 landmarks, 4 b_prior / err_prior
     bool topo_dirty = true;
     bool linearized = false;
     bool pairtab_valid = false;
@@ -200,7 +202,7 @@ struct vio_ctx {
     // device buffers independent of the topology
     DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
         d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi;
-    DevBuf<int32_t> d_imu_valid, d_perm, d_rank;
+    DevBuf<int32_t> d_imu_valid, d_perm, d_rank, d_gather_map;
     DevBuf<double> d_Pg;
     DevBuf<LmState> d_lm;
     LmState h_lm;
@@ -687,33 +689,36 @@ vio_status read_lm(vio_ctx *c) {
 }
 
 // bring the host mirrors up to date with the device (states, inverse depths, prior vectors)
-vio_status pull_from_device(vio_ctx *c) {
-    if (!c->device_ahead) return VIO_OK;
+vio_status pull_from_device(vio_ctx *c, unsigned mask = 7u) {
+    const unsigned need = c->ahead & mask;
+    if (!need) return VIO_OK;
     VIOCHK(read_lm(c));
     const int cur = c->h_lm.cur;
-    HIPCHK(hipMemcpyAsync(c->h_state, c->d_state.p + cur * STATE_STRIDE, STATE_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
+    if (need & 1u) HIPCHK(hipMemcpyAsync(c->h_state, c->d_state.p + cur * STATE_STRIDE, STATE_STRIDE * 8, hipMemcpyDeviceToHost, c->stream));
     Plan &pl = c->solve_plan;
     const size_t ld = (size_t)pl.lm_dim;
-    // the landmarks come back through a pinned buffer of the context's (a pageable destination is staged by the runtime)
-    const size_t need = ld * (size_t)std::max<int64_t>(pl.Ns, 1);
-    if (need > c->pull_cap) {
-        if (c->pull_stage) hipHostFree(c->pull_stage);
-        c->pull_stage = nullptr; c->pull_cap = 0;
-        HIPCHK(hipHostMalloc((void **)&c->pull_stage, (need + need / 4) * 8, hipHostMallocDefault));
-        c->pull_cap = need + need / 4;
+    double *tmp = nullptr;
+    if ((need & 2u) && pl.valid && pl.Ns) {
+        // the landmarks come back through a pinned buffer of the context's (a pageable destination is staged by the runtime)
+        const size_t cnt = ld * (size_t)pl.Ns;
+        if (cnt > c->pull_cap) {
+            if (c->pull_stage) hipHostFree(c->pull_stage);
+            c->pull_stage = nullptr; c->pull_cap = 0;
+            HIPCHK(hipHostMalloc((void **)&c->pull_stage, (cnt + cnt / 4) * 8, hipHostMallocDefault));
+            c->pull_cap = cnt + cnt / 4;
+        }
+        tmp = c->pull_stage;
+        HIPCHK(hipMemcpyAsync(tmp, pl.d_invd.p + (size_t)cur * ld * pl.Ns, cnt * 8, hipMemcpyDeviceToHost, c->stream));
     }
-    double *tmp = c->pull_stage;
-    if (pl.valid && pl.Ns)
-        HIPCHK(hipMemcpyAsync(tmp, pl.d_invd.p + (size_t)cur * ld * pl.Ns, ld * (size_t)pl.Ns * 8, hipMemcpyDeviceToHost, c->stream));
-    if (c->has_prior) {
+    if ((need & 4u) && c->has_prior) {
         HIPCHK(hipMemcpyAsync(c->h_bprior.data(), c->d_bprior.p + cur * 176, PD * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipMemcpyAsync(c->h_errprior.data(), c->d_errprior.p + cur * 160, PRD * 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (pl.valid)
+    if (tmp)
         for (int64_t s = 0; s < pl.Ns; ++s)
             for (size_t k = 0; k < ld; ++k) c->h_invd[ld * pl.sorted_to_orig[s] + k] = tmp[k * pl.Ns + s];      // device: coordinate-major
-    c->device_ahead = false;
+    c->ahead &= ~need;
     return VIO_OK;
 }
 
@@ -922,7 +927,7 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int ga
         c->decide_pending = true;
         c->cur_host ^= 1;
         HIPCHK(hipGetLastError());
-        c->device_ahead = true;
+        c->ahead = 7u;
         return VIO_OK;
     }
     // the prior update of an LM trial (problem.cc:466-475) is spread over the kernels that follow, like a flushed GN step's:
@@ -941,7 +946,7 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int ga
         vio_launch_lm_decide(T, mode, 1, c->stream);
     }
     HIPCHK(hipGetLastError());
-    c->device_ahead = true;
+    c->ahead = 7u;
     return VIO_OK;
 }
 
@@ -1023,9 +1028,10 @@ void vio_destroy(vio_ctx *c) {
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
-    c->d_batch_tabs.release(); c->d_rank.release();
+    c->d_batch_tabs.release(); c->d_rank.release(); c->d_gather_map.release();
     c->arena.release();
     if (c->pull_stage) hipHostFree(c->pull_stage);
+    if (c->marg_stage) hipHostFree(c->marg_stage);
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1036,7 +1042,7 @@ const char *vio_last_error(const vio_ctx *c) { return c ? c->err.c_str() : "null
 vio_status vio_set_window(vio_ctx *c, const double *poses, const double *sb, const double *ext) {
     if (!c || !poses || !sb || !ext) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    VIOCHK(pull_from_device(c));
+    c->ahead &= ~1u;                 // the states are replaced whole: nothing of the device's to keep
     std::memcpy(c->h_state + STATE_EXT, ext, 7 * 8);
     std::memcpy(c->h_state + STATE_POSE, poses, 77 * 8);
     std::memcpy(c->h_state + STATE_SB, sb, 99 * 8);
@@ -1047,7 +1053,7 @@ vio_status vio_set_window(vio_ctx *c, const double *poses, const double *sb, con
 static vio_status set_landmarks_dim(vio_ctx *c, int64_t n, const double *val, int dim) {
     if (!c || n < 0 || (n > 0 && !val)) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    VIOCHK(pull_from_device(c));
+    c->ahead &= ~2u;                 // the landmarks are replaced whole
     const bool resized = (int64_t)c->h_invd.size() != n * dim || c->lm_dim != dim;
     c->h_invd.assign(val, val + n * dim);
     c->lm_dim = dim;
@@ -1069,7 +1075,7 @@ vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, co
     for (int64_t e = 0; e < m; ++e)
         if (lm[e] < 0 || lm[e] >= N || frame[e] < 0 || frame[e] >= NF)
             return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
-    VIOCHK(pull_from_device(c));
+    // (what the device holds newer than the host mirrors stays there until activate() needs it: the old plan is alive till then)
     c->h_olm.assign(lm, lm + m); c->h_otarget.assign(frame, frame + m); c->h_ohost.assign((size_t)m, 0);
     c->h_pts_j.assign(pts, pts + 2 * m); c->h_pts_i.assign(2 * (size_t)m, 0.0);
     c->topo_dirty = true;
@@ -1085,7 +1091,6 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
     for (int64_t e = 0; e < m; ++e)
         if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
             return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
-    VIOCHK(pull_from_device(c));
     c->h_olm.assign(lm, lm + m); c->h_ohost.assign(host, host + m); c->h_otarget.assign(target, target + m);
     c->h_pts_i.assign(pi, pi + 2 * m); c->h_pts_j.assign(pj, pj + 2 * m);
     c->topo_dirty = true;
@@ -1096,7 +1101,6 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
 vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
     if (!c || k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    VIOCHK(pull_from_device(c));
     c->imu_valid[k] = pre != nullptr;
     double *o = c->h_pre.data() + (size_t)k * PRE_STRIDE;
     if (pre) {
@@ -1115,7 +1119,7 @@ vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double 
     if (!c || (dim != 0 && dim != PRD)) return VIO_ERR_BAD_ARG;
     if (dim && (!H || !b || !err || !jt)) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    VIOCHK(pull_from_device(c));
+    c->ahead &= ~4u;                 // b_prior and err_prior are replaced whole
     std::fill(c->h_Hprior.begin(), c->h_Hprior.end(), 0.0); std::fill(c->h_bprior.begin(), c->h_bprior.end(), 0.0);
     std::fill(c->h_errprior.begin(), c->h_errprior.end(), 0.0); std::fill(c->h_Jtinv.begin(), c->h_Jtinv.end(), 0.0);
     c->has_prior = dim ? 1 : 0;
@@ -1165,14 +1169,14 @@ vio_status vio_solve_linear(vio_ctx *c, double lambda) {
 vio_status vio_update_states(vio_ctx *c) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    if (!c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = true; c->device_ahead = true; }
+    if (!c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = true; c->ahead = 7u; }
     return VIO_OK;
 }
 
 vio_status vio_rollback_states(vio_ctx *c) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    if (c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = false; c->device_ahead = true; }
+    if (c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = false; c->ahead = 7u; }
     return VIO_OK;
 }
 
@@ -1208,7 +1212,7 @@ vio_status vio_eval_step(vio_ctx *c, int32_t *accepted, double *chi2, double *la
     } else if (c->stepwise_updated) {
         vio_launch_flip(c->d_lm.p, c->stream);  // stay on the updated states until the caller rolls back (problem.cc:228-231)
     }
-    c->device_ahead = true;
+    c->ahead = 7u;
     if (accepted) *accepted = ok ? 1 : 0;
     if (chi2) *chi2 = c->h_lm.chi;
     if (lambda) *lambda = c->h_lm.lambda;
@@ -1357,7 +1361,7 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         vio_ctx *m = ctxs[i];
         m->decide_pending = true;
         m->cur_host ^= 1;
-        m->device_ahead = true;
+        m->ahead = 7u;
         m->linearized = true;
         m->natural_hs_valid = false;
     }
@@ -1376,28 +1380,65 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
     if (kind == VIO_MARG_OLD && c->lm_dim == 3) return fail(c, VIO_ERR_UNSUPPORTED, "MargOldFrame is not defined for XYZ landmarks (include/vio_backend.h)");
-    std::vector<double> Hm((size_t)PD * PD), bm(PD);
+    static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!c->marg_stage) HIPCHK(hipHostMalloc((void **)&c->marg_stage, ((size_t)PD * PD + PD) * 8, hipHostMallocDefault));      // pinned: the 234 KB come back by DMA
+    double *Hm = c->marg_stage, *bm = c->marg_stage + (size_t)PD * PD;
     if (kind == VIO_MARG_OLD) {
-        VIOCHK(activate(c, c->marg_plan, 1));
+        // Straight after a solve (the frame loop) everything the marginalisation graph needs is on the device already, at the
+        // current slot of the double buffers: only the plan's tables are new, and its landmarks (those hosted in frame 0) are a
+        // gather out of the solve plan's.  No read-back of the window, no second upload of it.
+        const bool resident = c->active == &c->solve_plan && c->solve_plan.valid && !c->dirty_inputs && !c->topo_dirty && c->lm_dim == 1 &&
+                              !c->stepwise_updated;
+        if (resident) {
+            Plan &mp = c->marg_plan, &sp = c->solve_plan;
+            VIOCHK(flush_decide(c));
+            HIPCHK(c->arena.begin());
+            if (!mp.valid) VIOCHK(build_plan(c, mp, 1));
+            std::vector<int32_t> pos(c->h_invd.size(), -1);
+            for (int64_t q = 0; q < sp.Ns; ++q) pos[sp.sorted_to_orig[q]] = (int32_t)q;
+            int32_t *map = (int32_t *)c->arena.alloc((size_t)std::max<int64_t>(mp.Ns, 1) * 4);
+            if (!map) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+            for (int64_t q = 0; q < mp.Ns; ++q) map[q] = pos[mp.sorted_to_orig[q]];
+            HIPCHK(c->d_gather_map.resize((size_t)std::max<int64_t>(mp.Ns, 1)));
+            if (mp.Ns) {
+                HIPCHK(hipMemcpyAsync(c->d_gather_map.p, map, (size_t)mp.Ns * 4, hipMemcpyHostToDevice, c->stream));
+                vio_launch_gather_landmarks(c->d_lm.p, sp.d_invd.p, (int)sp.Ns, mp.d_invd.p, (int)mp.Ns, c->d_gather_map.p, c->stream);
+            }
+            HIPCHK(c->arena.end(c->stream));
+            ++c->tables_gen;
+            c->active = &mp;
+            c->linearized = false;
+            c->pairtab_valid = false;
+            c->gn_lambda = -1.0;
+        } else {
+            VIOCHK(activate(c, c->marg_plan, 1));
+        }
         VIOCHK(enqueue_linearize(c, c->marg_plan));
-        HIPCHK(hipMemcpyAsync(Hm.data(), c->d_Hs.p, (size_t)PD * PD * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(bm.data(), c->d_bs.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(Hm, c->d_Hs.p, (size_t)PD * PD * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(bm, c->d_bs.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         c->linearized = false;
     } else {
         // MargNewFrame builds a graph without edges (estimator.cpp:830-901): H_marg is the prior alone
-        VIOCHK(pull_from_device(c));
-        Hm = c->h_Hprior;
-        bm = c->h_bprior;
+        VIOCHK(pull_from_device(c, 4u));
+        std::memcpy(Hm, c->h_Hprior.data(), (size_t)PD * PD * 8);
+        std::memcpy(bm, c->h_bprior.data(), (size_t)PD * 8);
     }
-    vio_host::marginalize_tail(Hm.data(), bm.data(), kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, H, b, err, jt);
+    const auto t1 = std::chrono::steady_clock::now();
+    vio_host::marginalize_tail(Hm, bm, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, H, b, err, jt);
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[vio host timing] vio_marginalize(kind=%d): activate + kernels + read-back %.0f us, host tail %.0f us\n", kind,
+                     std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count());
+    }
     return VIO_OK;
 }
 
 vio_status vio_get_window(vio_ctx *c, double *poses, double *sb, double *ext) {
     if (!c) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    VIOCHK(pull_from_device(c));
+    VIOCHK(pull_from_device(c, 1u));
     if (ext) std::memcpy(ext, c->h_state + STATE_EXT, 7 * 8);
     if (poses) std::memcpy(poses, c->h_state + STATE_POSE, 77 * 8);
     if (sb) std::memcpy(sb, c->h_state + STATE_SB, 99 * 8);
@@ -1406,14 +1447,14 @@ vio_status vio_get_window(vio_ctx *c, double *poses, double *sb, double *ext) {
 
 vio_status vio_get_landmarks(vio_ctx *c, int64_t n, double *invd) {
     if (!c || c->lm_dim != 1 || n != (int64_t)c->h_invd.size() || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
-    VIOCHK(pull_from_device(c));
+    VIOCHK(pull_from_device(c, 2u));
     if (n) std::memcpy(invd, c->h_invd.data(), (size_t)n * 8);
     return VIO_OK;
 }
 
 vio_status vio_get_landmarks_xyz(vio_ctx *c, int64_t n, double *xyz) {
     if (!c || c->lm_dim != 3 || 3 * n != (int64_t)c->h_invd.size() || (n > 0 && !xyz)) return VIO_ERR_BAD_ARG;
-    VIOCHK(pull_from_device(c));
+    VIOCHK(pull_from_device(c, 2u));
     if (n) std::memcpy(xyz, c->h_invd.data(), (size_t)n * 24);
     return VIO_OK;
 }
@@ -1421,7 +1462,7 @@ vio_status vio_get_landmarks_xyz(vio_ctx *c, int64_t n, double *xyz) {
 vio_status vio_get_prior(vio_ctx *c, double *b, double *err) {
     if (!c) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    VIOCHK(pull_from_device(c));
+    VIOCHK(pull_from_device(c, 4u));
     if (b) std::memcpy(b, c->h_bprior.data(), PD * 8);
     if (err) std::memcpy(err, c->h_errprior.data(), PRD * 8);
     return VIO_OK;

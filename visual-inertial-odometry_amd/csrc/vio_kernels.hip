@@ -2131,6 +2131,17 @@ __global__ __launch_bounds__(RED_THREADS) void k_errprior(DeviceTables T) {
     if (row < VIO_PRD) d_errprior_row(T.Jtinv, T.bprior + trial * 176, T.errprior + trial * 160, row, threadIdx.x & 63);
 }
 void vio_launch_errprior(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_errprior, dim3(RED_ERR_BLOCKS), dim3(RED_THREADS), 0, s, T); }
+// the landmarks of one plan out of another's, at the current slot of both double buffers (MargOldFrame straight after a solve:
+// dst = the landmarks hosted in frame 0, map = their places in the solve plan's order)
+__global__ __launch_bounds__(256) void k_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= ns_dst) return;
+    const int cur = lm->cur;
+    dst[(size_t)cur * ns_dst + s] = src[(size_t)cur * ns_src + map[s]];
+}
+void vio_launch_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_landmarks, dim3((ns_dst + 255) / 256), dim3(256), 0, s, lm, src, ns_src, dst, ns_dst, map);
+}
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(PS_NP + 1), dim3(ASM_THREADS), 0, s, T); }
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
     hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
