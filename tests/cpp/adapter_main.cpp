@@ -16,8 +16,11 @@
 //        Hprior 156*156, bprior 156; (iterations, final_chi2) as doubles
 // mode 2  double2vector() then vector2double() alone (no device): in: Rs[0] 9, Ps[0] 3, para_Pose 77, para_SpeedBias 99;
 //         out: Rs 99, Ps 33, Vs 33, para_Pose 77
+#include <chrono>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../../visual-inertial-odometry_amd/host/feature_manager.h"
@@ -89,6 +92,34 @@ int main(int argc, char **argv) {
             t.used_num = (int)t.feature_per_frame.size();
             if (t.used_num >= 2 && t.start_frame < vio::WINDOW_SIZE - 2) est.para_Feature.push_back(1.0 / t.estimated_depth);
         }
+        if (const char *reps_s = std::getenv("VIO_TIME_REPS")) {
+            // timing of the frame's backend part as an integrator's C++ sees it (tools/bench_cpp_frame.py): the same inputs again
+            // and again, problemSolve() (upload, Solve(10), read-back) and MargOldFrame(), wall clock per call
+            const int reps = std::max(1, std::atoi(reps_s));
+            double keep_pose[77], keep_sb[99], keep_ex[7];
+            std::memcpy(keep_pose, &est.para_Pose[0][0], sizeof(keep_pose)); std::memcpy(keep_sb, &est.para_SpeedBias[0][0], sizeof(keep_sb));
+            std::memcpy(keep_ex, &est.para_Ex_Pose[0][0], sizeof(keep_ex));
+            const std::vector<double> keep_f = est.para_Feature, kH = est.Hprior_, kb = est.bprior_, ke = est.errprior_, kJ = est.Jprior_inv_;
+            double t_solve = 0, t_marg = 0;
+            for (int r = 0; r <= reps; ++r) {
+                std::memcpy(&est.para_Pose[0][0], keep_pose, sizeof(keep_pose)); std::memcpy(&est.para_SpeedBias[0][0], keep_sb, sizeof(keep_sb));
+                std::memcpy(&est.para_Ex_Pose[0][0], keep_ex, sizeof(keep_ex));
+                est.para_Feature = keep_f; est.Hprior_ = kH; est.bprior_ = kb; est.errprior_ = ke; est.Jprior_inv_ = kJ;
+                // a frame never repeats the one before (the library keeps the plans of a graph it already holds): one observation moves by 1e-13
+                if (!est.feature.empty() && est.feature[0].feature_per_frame.size() > 1) est.feature[0].feature_per_frame[1][0] += (r & 1) ? 1e-13 : -1e-13;
+                const auto t0 = std::chrono::steady_clock::now();
+                if (!est.problemSolve()) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
+                const auto t1 = std::chrono::steady_clock::now();
+                if (!est.MargOldFrame()) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
+                const auto t2 = std::chrono::steady_clock::now();
+                if (r == 0) continue;           // first pass: allocations
+                t_solve += std::chrono::duration<double, std::milli>(t1 - t0).count();
+                t_marg += std::chrono::duration<double, std::milli>(t2 - t1).count();
+            }
+            std::printf("cpp_frame problemSolve_ms %.4f MargOldFrame_ms %.4f frame_ms %.4f reps %d landmarks %zu iterations %d\n", t_solve / reps, t_marg / reps,
+                        (t_solve + t_marg) / reps, reps, est.para_Feature.size(), est.last_report.iterations);
+            return 0;
+        }
         if (!est.problemSolve() || !est.MargOldFrame()) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
         FILE *o = std::fopen(argv[2], "wb");
         std::fwrite(&est.para_Pose[0][0], 8, 77, o);
@@ -105,6 +136,40 @@ int main(int argc, char **argv) {
         return 0;
     }
 
+    if (const char *reps_s = std::getenv("VIO_TIME_REPS")) {
+        // the frame's backend part exactly as Estimator::backendOptimization runs it (vector2double, problemSolve, double2vector,
+        // vector2double, MargOldFrame), timed as a whole, the same inputs restored before every pass; an optional prior follows
+        // the pre-integrations in the input file
+        const int reps = std::max(1, std::atoi(reps_s));
+        int32_t has_prior = 0;
+        std::vector<double> kH, kb, ke, kJ;
+        if (rd(f, &has_prior, 1) && has_prior) {
+            kH.resize(156 * 156); kb.resize(156); ke.resize(156); kJ.resize(156 * 156);
+            if (!rd(f, kH.data(), kH.size()) || !rd(f, kb.data(), 156) || !rd(f, ke.data(), 156) || !rd(f, kJ.data(), kJ.size())) return 4;
+        }
+        std::fclose(f);
+        double kP[33], kR[99], kV[33], kBa[33], kBg[33];
+        std::memcpy(kP, &est.Ps[0][0], sizeof(kP)); std::memcpy(kR, &est.Rs[0][0], sizeof(kR)); std::memcpy(kV, &est.Vs[0][0], sizeof(kV));
+        std::memcpy(kBa, &est.Bas[0][0], sizeof(kBa)); std::memcpy(kBg, &est.Bgs[0][0], sizeof(kBg));
+        std::vector<double> kdepth;
+        for (auto &t : est.feature) kdepth.push_back(t.estimated_depth);
+        double total = 0;
+        for (int r = 0; r <= reps; ++r) {
+            std::memcpy(&est.Ps[0][0], kP, sizeof(kP)); std::memcpy(&est.Rs[0][0], kR, sizeof(kR)); std::memcpy(&est.Vs[0][0], kV, sizeof(kV));
+            std::memcpy(&est.Bas[0][0], kBa, sizeof(kBa)); std::memcpy(&est.Bgs[0][0], kBg, sizeof(kBg));
+            size_t q = 0;
+            for (auto &t : est.feature) { t.estimated_depth = kdepth[q++]; t.solve_flag = 0; }
+            est.Hprior_ = kH; est.bprior_ = kb; est.errprior_ = ke; est.Jprior_inv_ = kJ;
+            if (!est.feature.empty() && est.feature[0].feature_per_frame.size() > 1) est.feature[0].feature_per_frame[1][0] += (r & 1) ? 1e-13 : -1e-13;     // (a new frame)
+            const auto t0 = std::chrono::steady_clock::now();
+            est.backendOptimization(vio::MARGIN_OLD);
+            const auto t1 = std::chrono::steady_clock::now();
+            if (est.Hprior_.size() != 156 * 156) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
+            if (r) total += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        }
+        std::printf("cpp_frame backendOptimization_ms %.4f reps %d tracks %zu iterations %d\n", total / reps, reps, est.feature.size(), est.last_report.iterations);
+        return 0;
+    }
     std::fclose(f);
     vio::FeatureManager f_manager(est.feature);
     est.vector2double();                                    // the mirror's triangulate takes Ps / Rs as para_Pose rows

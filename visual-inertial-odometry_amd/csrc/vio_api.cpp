@@ -1053,8 +1053,11 @@ vio_status vio_set_window(vio_ctx *c, const double *poses, const double *sb, con
 static vio_status set_landmarks_dim(vio_ctx *c, int64_t n, const double *val, int dim) {
     if (!c || n < 0 || (n > 0 && !val)) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    c->ahead &= ~2u;                 // the landmarks are replaced whole
     const bool resized = (int64_t)c->h_invd.size() != n * dim || c->lm_dim != dim;
+    // The same values as the mirror holds, the mirror current: nothing to do.  (The reference's frame sets the window twice,
+    // for Solve and for Marginalize, with the landmarks the solve gave it: estimator.cpp:1083-1092.)
+    if (!resized && !(c->ahead & 2u) && (n == 0 || std::memcmp(c->h_invd.data(), val, (size_t)n * dim * 8) == 0)) return VIO_OK;
+    c->ahead &= ~2u;                 // the landmarks are replaced whole
     c->h_invd.assign(val, val + n * dim);
     c->lm_dim = dim;
     if (resized) {      // the observation list refers to landmark indices (of this kind): it must be set again
@@ -1076,6 +1079,9 @@ vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, co
         if (lm[e] < 0 || lm[e] >= N || frame[e] < 0 || frame[e] >= NF)
             return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
     // (what the device holds newer than the host mirrors stays there until activate() needs it: the old plan is alive till then)
+    if ((int64_t)c->h_olm.size() == m && (m == 0 || (std::memcmp(c->h_olm.data(), lm, (size_t)m * 4) == 0 && std::memcmp(c->h_otarget.data(), frame, (size_t)m * 4) == 0 &&
+                                                     std::memcmp(c->h_pts_j.data(), pts, (size_t)m * 16) == 0)))
+        return VIO_OK;               // the graph the context already holds: its plans stay
     c->h_olm.assign(lm, lm + m); c->h_otarget.assign(frame, frame + m); c->h_ohost.assign((size_t)m, 0);
     c->h_pts_j.assign(pts, pts + 2 * m); c->h_pts_i.assign(2 * (size_t)m, 0.0);
     c->topo_dirty = true;
@@ -1091,6 +1097,10 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
     for (int64_t e = 0; e < m; ++e)
         if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
             return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
+    if ((int64_t)c->h_olm.size() == m && (m == 0 || (std::memcmp(c->h_olm.data(), lm, (size_t)m * 4) == 0 && std::memcmp(c->h_ohost.data(), host, (size_t)m * 4) == 0 &&
+                                                     std::memcmp(c->h_otarget.data(), target, (size_t)m * 4) == 0 && std::memcmp(c->h_pts_i.data(), pi, (size_t)m * 16) == 0 &&
+                                                     std::memcmp(c->h_pts_j.data(), pj, (size_t)m * 16) == 0)))
+        return VIO_OK;               // the graph the context already holds: its plans stay
     c->h_olm.assign(lm, lm + m); c->h_ohost.assign(host, host + m); c->h_otarget.assign(target, target + m);
     c->h_pts_i.assign(pi, pi + 2 * m); c->h_pts_j.assign(pj, pj + 2 * m);
     c->topo_dirty = true;
@@ -1101,8 +1111,9 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
 vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
     if (!c || k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
-    c->imu_valid[k] = pre != nullptr;
-    double *o = c->h_pre.data() + (size_t)k * PRE_STRIDE;
+    double blk[PRE_STRIDE];
+    double *o = blk;
+    std::memcpy(blk, c->h_pre.data() + (size_t)k * PRE_STRIDE, sizeof(blk));
     if (pre) {
         o[PRE_SUMDT] = pre->sum_dt;
         for (int i = 0; i < 3; ++i) { o[PRE_DP + i] = pre->delta_p[i]; o[PRE_DV + i] = pre->delta_v[i]; o[PRE_BA + i] = pre->linearized_ba[i]; o[PRE_BG + i] = pre->linearized_bg[i]; }
@@ -1110,6 +1121,9 @@ vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
         std::memcpy(o + PRE_JAC, pre->jacobian, 225 * 8);
         vio_host::inverse15(pre->covariance, o + PRE_INFO);     // SetInformation(covariance.inverse()), edge_imu.cc:35
     }
+    if (c->imu_valid[k] == (pre != nullptr) && std::memcmp(blk, c->h_pre.data() + (size_t)k * PRE_STRIDE, sizeof(blk)) == 0) return VIO_OK;     // unchanged
+    c->imu_valid[k] = pre != nullptr;
+    std::memcpy(c->h_pre.data() + (size_t)k * PRE_STRIDE, blk, sizeof(blk));
     c->imu_dirty = true;
     c->dirty_inputs = true;
     return VIO_OK;
@@ -1119,15 +1133,30 @@ vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double 
     if (!c || (dim != 0 && dim != PRD)) return VIO_ERR_BAD_ARG;
     if (dim && (!H || !b || !err || !jt)) return VIO_ERR_BAD_ARG;
     hipSetDevice(c->cfg.device);
+    // The two matrices are 430 KB of upload: left alone when they are the ones the context holds (the reference hands the same
+    // H_prior / Jt_prior_inv to Solve and then to Marginalize, with b_prior / err_prior as the solve updated them)
+    bool same_mats = c->has_prior == (dim ? 1 : 0);
+    if (same_mats && dim) {
+        same_mats = std::memcmp(c->h_Jtinv.data(), jt, (size_t)PRD * PRD * 8) == 0;
+        for (int i = 0; same_mats && i < PRD; ++i) same_mats = std::memcmp(&c->h_Hprior[(size_t)i * PD], &H[(size_t)i * PRD], PRD * 8) == 0;
+    }
+    const bool same_vecs = same_mats && !(c->ahead & 4u) &&
+                           (dim == 0 || (std::memcmp(c->h_bprior.data(), b, PRD * 8) == 0 && std::memcmp(c->h_errprior.data(), err, PRD * 8) == 0));
+    if (same_vecs) return VIO_OK;
     c->ahead &= ~4u;                 // b_prior and err_prior are replaced whole
-    std::fill(c->h_Hprior.begin(), c->h_Hprior.end(), 0.0); std::fill(c->h_bprior.begin(), c->h_bprior.end(), 0.0);
-    std::fill(c->h_errprior.begin(), c->h_errprior.end(), 0.0); std::fill(c->h_Jtinv.begin(), c->h_Jtinv.end(), 0.0);
-    c->has_prior = dim ? 1 : 0;
-    c->prior_dirty = true;
+    std::fill(c->h_bprior.begin(), c->h_bprior.end(), 0.0); std::fill(c->h_errprior.begin(), c->h_errprior.end(), 0.0);
+    if (!same_mats) {
+        std::fill(c->h_Hprior.begin(), c->h_Hprior.end(), 0.0); std::fill(c->h_Jtinv.begin(), c->h_Jtinv.end(), 0.0);
+        c->has_prior = dim ? 1 : 0;
+        c->prior_dirty = true;
+    }
     if (dim) {      // ExtendHessiansPriorSize(15): 15 zero rows/cols appended (problem.cc:82-91)
-        for (int i = 0; i < PRD; ++i) { std::memcpy(&c->h_Hprior[(size_t)i * PD], &H[(size_t)i * PRD], PRD * 8); c->h_bprior[i] = b[i]; }
+        for (int i = 0; i < PRD; ++i) c->h_bprior[i] = b[i];
         std::memcpy(c->h_errprior.data(), err, PRD * 8);
-        std::memcpy(c->h_Jtinv.data(), jt, (size_t)PRD * PRD * 8);
+        if (!same_mats) {
+            for (int i = 0; i < PRD; ++i) std::memcpy(&c->h_Hprior[(size_t)i * PD], &H[(size_t)i * PRD], PRD * 8);
+            std::memcpy(c->h_Jtinv.data(), jt, (size_t)PRD * PRD * 8);
+        }
     }
     c->dirty_inputs = true;
     return VIO_OK;

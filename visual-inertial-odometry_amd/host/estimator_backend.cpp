@@ -1,6 +1,10 @@
 // estimator_backend.cpp — see estimator_backend.h.
 #include "estimator_backend.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <cmath>
 #include <cstring>
 
@@ -157,11 +161,25 @@ void EstimatorBackend::double2vector() {                                      //
 }
 
 // What the three graph-building blocks of estimator.cpp do (:909-1034, :699-810, :834-885), once.
-bool EstimatorBackend::uploadWindow() {
+bool EstimatorBackend::uploadWindow(bool graph_unchanged) {
     if (!ctx_) return false;
     if (vio_set_window(ctx_, &para_Pose[0][0], &para_SpeedBias[0][0], &para_Ex_Pose[0][0]) != VIO_OK) return false;
+    if (graph_unchanged) {
+        // MargOldFrame / MargNewFrame straight after problemSolve (estimator.cpp:1083-1114): the same tracks, the landmarks the
+        // solve returned, the same pre-integrations — the context holds them; what changed is the states (double2vector's gauge)
+        // and the prior's vectors
+        // (the depths went through setDepth / getDepthVector, 1 / (1 / x): sent again, the library keeps what is bitwise the same)
+        if (vio_set_landmarks(ctx_, (int64_t)para_Feature.size(), para_Feature.data()) != VIO_OK) return false;
+        if (!Hprior_.empty()) {
+            if (vio_set_prior(ctx_, VIO_PRIOR_DIM, Hprior_.data(), bprior_.data(), errprior_.data(), Jprior_inv_.data()) != VIO_OK) return false;
+        } else if (vio_set_prior(ctx_, 0, nullptr, nullptr, nullptr, nullptr) != VIO_OK) return false;
+        return true;
+    }
+    size_t n_obs = 0;
+    for (const auto &it_per_id : feature) n_obs += it_per_id.feature_per_frame.size();
     std::vector<int32_t> lm, host, target;
     std::vector<double> pi, pj;
+    lm.reserve(n_obs); host.reserve(n_obs); target.reserve(n_obs); pi.reserve(2 * n_obs); pj.reserve(2 * n_obs);
     int feature_index = -1;
     for (auto &it_per_id : feature) {                                         // estimator.cpp:975-1016
         it_per_id.used_num = (int)it_per_id.feature_per_frame.size();
@@ -197,8 +215,16 @@ bool EstimatorBackend::uploadWindow() {
 }
 
 bool EstimatorBackend::problemSolve() {
+    static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (!uploadWindow()) return false;
+    const auto t1 = std::chrono::steady_clock::now();
     if (vio_solve(ctx_, 10, &last_report) != VIO_OK) return false;           // problem.Solve(10), estimator.cpp:1037
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[vio host timing] problemSolve: uploadWindow %.0f us, vio_solve %.0f us\n", std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                     std::chrono::duration<double, std::micro>(t2 - t1).count());
+    }
     if (!Hprior_.empty()) {                                                   // estimator.cpp:1040-1049
         std::vector<double> b(VIO_POSE_DIM), e(VIO_PRIOR_DIM);
         if (vio_get_prior(ctx_, b.data(), e.data()) != VIO_OK) return false;
@@ -218,26 +244,35 @@ static bool marginalize(vio_ctx *ctx, int kind, std::vector<double> &H, std::vec
 }
 
 bool EstimatorBackend::MargOldFrame() {
-    if (!uploadWindow()) return false;
+    const bool same = graph_uploaded_;
+    graph_uploaded_ = false;
+    if (!uploadWindow(same)) return false;
     return marginalize(ctx_, VIO_MARG_OLD, Hprior_, bprior_, errprior_, Jprior_inv_);      // estimator.cpp:821-828
 }
 
 bool EstimatorBackend::MargNewFrame() {
-    if (!uploadWindow()) return false;
+    const bool same = graph_uploaded_;
+    graph_uploaded_ = false;
+    if (!uploadWindow(same)) return false;
     return marginalize(ctx_, VIO_MARG_SECOND_NEW, Hprior_, bprior_, errprior_, Jprior_inv_);   // estimator.cpp:893-900
 }
 
 void EstimatorBackend::backendOptimization(MarginalizationFlag marginalization_flag) {
     vector2double();                                    // estimator.cpp:1079-1083
+    graph_uploaded_ = false;
     if (!problemSolve()) return;
     double2vector();
+    // (vector2double re-reads the depths double2vector has just written: para_Feature is what the context already holds)
     if (marginalization_flag == MARGIN_OLD) {           // :1088-1092
         vector2double();
+        graph_uploaded_ = true;
         MargOldFrame();
     } else if (!Hprior_.empty()) {                      // :1107-1114
         vector2double();
+        graph_uploaded_ = true;
         MargNewFrame();
     }
+    graph_uploaded_ = false;
 }
 
 }  // namespace vio

@@ -68,7 +68,10 @@ public:
     const char *last_error() const;
 
 private:
-    bool uploadWindow();
+    // graph_unchanged: landmarks, observations and IMU factors are the ones of the upload before (backendOptimization's second
+    // upload, for the marginalisation of the frame it has just solved): only the states and the prior are sent
+    bool uploadWindow(bool graph_unchanged = false);
+    bool graph_uploaded_ = false;                     // set by problemSolve inside backendOptimization, used by the Marg*Frame that follows
 public:
     vio_ctx *context() { return ctx_; }               // for FeatureManager::triangulate
 private:
