@@ -18,7 +18,7 @@ N > 1: one process per GPU (torch.distributed, backend nccl == RCCL, for the ren
 
 The JSON line also carries
   roofline      achieved = algorithmic bytes per launch / measured launch duration of the dominant kernel
-                (HIP event pairs on the library's stream around every 8th launch during the timed steps),
+                (HIP event pairs on the library's stream around about ten launches spread over the timed steps),
                 peak = 8 TB/s HBM
   cpu_baseline  the oracle's (oracle/vio_oracle.c, plain C, 1 thread) GN iteration on the same window,
                 timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
@@ -168,9 +168,11 @@ def main():
         per_kernel[name] = ms / max(cnt, 1)
     dominant = max(per_kernel, key=per_kernel.get)
 
-    # timed region: exactly K steps; an event pair around every 8th launch of the dominant kernel (a hipEventRecord
-    # drains the stream, ~7 us each: bracketing every launch would add ~15 % to the step it is meant to observe)
-    ctx.profile_begin_sampled(hip.KERNELS.index(dominant), 8)
+    # timed region: exactly K steps; an event pair around every `stride`-th launch of the dominant kernel — about ten pairs
+    # over the region, never fewer than every 8th launch (a hipEventRecord drains the stream, ~7 us each: bracketing every
+    # launch would add ~15 % to the step it is meant to observe, every 8th still 2.5 %)
+    stride = max(8, args.steps // 10)
+    ctx.profile_begin_sampled(hip.KERNELS.index(dominant), stride)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -206,7 +208,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                 "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_us": round(dom_launch_s * 1e6, 3),
-                "launch_us_method": "HIP event pairs on the library's stream around every 8th launch of the timed steps "
+                "launch_us_method": "HIP event pairs on the library's stream around every %d-th launch of the timed steps " % stride +
                                     "(includes the event's own drain, ~8 % above rocprofv3's kernel duration)",
                 "iteration_algorithmic_bytes": it_bytes,
                 "iteration_achieved_GBps": round(it_bytes / (ms_per_step * 1e-3) / 1e9, 3),
