@@ -286,6 +286,48 @@ def test_headline_window_solve_converges_and_matches_oracle_step(vio, oracle_lib
     assert errF < err0
 
 
+def test_200k_landmarks_in_eight_shards(vio, oracle_lib, hip_lib):
+    """BASELINE.json configs[3]: 200 000 landmarks / 800 000 observations, 25 000 per GPU on eight GPUs.  One GPU is what a
+    test box has, so: (a) the whole window on it, one LM step against the CPU restatement (the oracle's sparse Schur
+    finishes a step of this size in a few seconds; the reference's dense solver would need 320 GB); (b) the eight 25 000-landmark
+    shards of the exchange protocol one after the other on the same device — their reduced systems, the payload of the
+    all-reduce, add up to the whole window's (minus the seven extra copies of the replicated IMU + prior part), and so do their
+    chi2 sums."""
+    w = vio.synth.make_window(200000, seed=44)
+    ch, co = hip_lib.context(), oracle_lib.context()
+    ch.load(w)
+    co.load(w)
+    a, b = tu.run_stepwise(ch), tu.run_stepwise(co)
+    compare_stepwise(a, b)
+    Hf, bf, chif = a["Hs"], a["bs"], float(a["chi0"])
+    empty = w.copy()
+    empty.inv_depth, empty.lm = empty.inv_depth[:0], empty.lm[:0]
+    empty.host, empty.target, empty.pts_i, empty.pts_j = empty.host[:0], empty.target[:0], empty.pts_i[:0], empty.pts_j[:0]
+    c0 = hip_lib.context()
+    c0.load(empty)
+    c0.linearize()
+    H0, b0 = c0.get_schur_system()
+    chi00, _ = c0.init_lm()
+    Hsum, bsum, chisum, n_seen = -7.0 * H0, -7.0 * b0, -7.0 * chi00, 0
+    for r in range(8):
+        s = vio.synth.shard_window(w, r, 8)
+        assert s.n_landmarks == 25000
+        n_seen += s.n_landmarks
+        c = hip_lib.context()
+        c.load(s)
+        c.linearize()
+        Hs, bs = c.get_schur_system()
+        chi, _ = c.init_lm()
+        Hsum += Hs
+        bsum += bs
+        chisum += chi
+        del c
+    assert n_seen == 200000
+    assert tu.scaled_sym_err(Hsum, Hf) <= 1e-10
+    assert np.abs(bsum - bf).max() <= 1e-10 * np.abs(bf).max()
+    assert abs(chisum - chif) <= 1e-10 * chif
+
+
 def test_gn_iteration_is_the_same_arithmetic_as_the_steps(vio, hip_lib):
     """vio_gn_iteration (what bench.py times) = linearize + solve_linear + update at a fixed lambda."""
     w = vio.synth.make_window(500, seed=17)
