@@ -1163,6 +1163,22 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
     // and scattered once the ranks are known: natural row b is row rank(b) of the permuted matrix.
     double row_e = 0.0;
     int my_rank = 0, row_rank = 0;
+    // The last workgroup (right-hand sides + the GN step test) is the kernel's long pole: four dependent round trips if its
+    // loads are issued where they are used.  Everything it reads that does not depend on the ranks is requested here, before
+    // the diagonal: the previous step's dx / b_ / err_prior, the scalars of the test, the terms of the right-hand sides.
+    const bool last_wg = b == PS_NP;
+    const bool test_prev = last_wg && (T.gn_flags & 1);
+    double p_dx = 0.0, p_bf = 0.0, p_er = 0.0, p_lambda = 0.0, p_chi = 0.0, p_step = 0.0, p_lmchi = 0.0, p_imu[10], rhs_v = 0.0;
+    if (test_prev) {
+        p_lambda = T.lm->lambda;
+        if (t < VIO_PD) { p_dx = T.dx[t]; p_bf = T.bfull[t]; }          // b_ of the previous linearisation: read before d_rhs_entries replaces it
+        if (T.has_prior && t < VIO_PRD) p_er = T.errprior[cur * 160 + t];
+        if (t == 0) {
+            p_chi = T.vis[VIS_CHI]; p_step = T.vis[VIS_STEP + 1]; p_lmchi = T.lm->chi;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) p_imu[k] = ((valid >> k) & 1) ? T.imu_out[k * IMU_OUT + IMU_CHI] : 0.0;
+        }
+    }
     if (RANKS_GIVEN) {
         if (t < VIO_PD) {
             double wv = 0.0, wr = 0.0;
@@ -1170,6 +1186,7 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
             row_e = wv + wr;
             my_rank = T.rank[t];
             sPerm[t] = T.perm[t];
+            if (last_wg) rhs_v = d_rhs_entries(T, valid, t, cur);
         }
         if (b < VIO_PD) row_rank = T.rank[b];
         __syncthreads();
@@ -1181,6 +1198,7 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
             if (b < VIO_PD) d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
             sDg[t] = d_rank_key(vv + vr);
             row_e = wv + wr;
+            if (last_wg) rhs_v = d_rhs_entries(T, valid, t, cur);
         }
         __syncthreads();
         d_rank_sort(sDg, sCnt, t);
@@ -1211,12 +1229,12 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
         // with the rest of vis when sharded), so nobody evaluates it twice.  b_ of the previous linearisation is read
         // before d_rhs_entries replaces it.
         double sp = 0.0, e2 = 0.0;
-        if (T.gn_flags & 1) {
-            if (t < VIO_PD) { const double d = T.dx[t]; sp = d * (T.lm->lambda * d + T.bfull[t]); }
-            if (T.has_prior && t < VIO_PRD) { const double v = T.errprior[cur * 160 + t]; e2 = v * v; }
+        if (test_prev) {
+            if (t < VIO_PD) sp = p_dx * (p_lambda * p_dx + p_bf);
+            if (T.has_prior && t < VIO_PRD) e2 = p_er * p_er;
         }
         if (t < VIO_PD) {
-            sDg[t] = d_rhs_entries(T, valid, t, cur);
+            sDg[t] = rhs_v;
             if (!RANKS_GIVEN) T.perm[t] = sPerm[t];
         }
         if (T.gn_flags & 1) {
@@ -1225,13 +1243,14 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
             if (t == 0) {
                 LmState *lm = T.lm;
                 double chi_imu = 0.0;
-                for (int k = 0; k < 10; ++k) if ((valid >> k) & 1) chi_imu += T.imu_out[k * IMU_OUT + IMU_CHI];
-                double total = T.vis[VIS_CHI] + chi_imu;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) if ((valid >> k) & 1) chi_imu += p_imu[k];
+                double total = p_chi + chi_imu;
                 if (T.has_prior) total += sqrt(e2);             // err_prior_.norm(), not squared (problem.cc:554-556)
                 const double tempChi = 0.5 * total;
-                const double scale = 0.5 * (T.vis[VIS_STEP + 1] + sp) + 1e-6;
+                const double scale = 0.5 * (p_step + sp) + 1e-6;
                 lm->chi_try = tempChi;
-                lm->rho = (lm->chi - tempChi) / scale;
+                lm->rho = (p_lmchi - tempChi) / scale;
                 lm->scale = scale;
                 lm->trials += 1;
                 lm->chi = tempChi;
