@@ -97,7 +97,7 @@ int main(int argc, char **argv) {
     }
     int32_t nimg = (int32_t)decisions.size() / 2;
     std::fwrite(&nimg, 4, 1, o);
-    std::fwrite(decisions.data(), 4, decisions.size(), o);
+    if (!decisions.empty()) std::fwrite(decisions.data(), 4, decisions.size(), o);
     std::fclose(o);
     return 0;
 }
