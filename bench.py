@@ -262,10 +262,12 @@ def main():
         B = args.batch
         lead = hip.context(device=local_rank)
         members = [lead] + [hip.context(device=local_rank, stream=lead.get_stream()) for _ in range(B - 1)]
+        wbs = []
         for i, cb in enumerate(members):
             wb = (vio.synth.make_window_xyz if xyz else vio.synth.make_window)(n_per_gpu, seed=100 + i, obs_per_landmark=k_obs)
             wb.prior = full.prior
             cb.load(wb)
+            wbs.append(wb)
         for _ in range(5):
             hip.batch_gn_iteration(members, lam)
         lead.synchronize()
@@ -282,6 +284,21 @@ def main():
                    "final_chi2_window0": lead.chi2(),
                    "note": "B independent 20k-landmark windows (seeds 100..), one launch per kernel for all of them (grid.y = window); "
                            "bit-identical to B separate vio_gn_iteration runs (tests/test_gpu_batch.py)"}
+        # Problem::Solve(10) of the same B windows in one batched call (vio_batch_solve), from their initial states; the uploads
+        # in front of it are not timed (per_frame has those)
+        ts, its = [], 0
+        for _ in range(3):
+            for cb, wb in zip(members, wbs):
+                cb.load(wb)
+                cb.linearize()
+            lead.synchronize()
+            tb0 = time.perf_counter()
+            reps_b = hip.batch_solve(members, 10)
+            ts.append(time.perf_counter() - tb0)
+            its = sum(r.iterations for r in reps_b) / len(reps_b)
+        batched["solve10_ms_per_batch"] = min(ts) * 1e3
+        batched["solve10_ms_per_window"] = min(ts) * 1e3 / B
+        batched["solve10_mean_iterations"] = its
         del cb, members, lead          # (members first: they run on the leader's stream)
 
     cpu_baseline = None

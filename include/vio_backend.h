@@ -193,6 +193,12 @@ vio_status vio_get_stream(struct vio_ctx *ctx, void **stream);
  * vio_gn_iteration on each.
  * Not a reference entry point: the reference solves one window at a time (System::ProcessBackEnd, one estimator). */
 vio_status vio_batch_gn_iteration(struct vio_ctx *const *ctxs, int32_t count, double lambda);
+/* vio_solve (Problem::Solve, problem.cc:169-250) for `count` independent windows at once, the same way: every kernel of the
+ * device-driven LM loop is launched once for the whole batch, every window follows its own LmState (its lambda, its accept /
+ * reject decisions, its stop), and the host reads the states once per batch of slots.  Same requirements on the contexts as
+ * vio_batch_gn_iteration; results are bit-identical to vio_solve on each.  reports: `count` entries, or NULL.
+ * VIO_ERR_NOT_FINITE if any window ended non-finite (its report says which). */
+vio_status vio_batch_solve(struct vio_ctx *const *ctxs, int32_t count, int32_t iterations, vio_solve_report *reports);
 
 /* ---- IMU pre-integration (host side, as in the reference: Estimator::processIMU -> IntegrationBase::push_back ->
  *      propagate -> midPointIntegration, integration_base.h:30-36,54-158).  Starts from (acc0, gyr0) — the sample the

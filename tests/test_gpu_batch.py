@@ -89,6 +89,46 @@ def test_batched_gn_xyz_windows(vio, hip_lib):
         assert c.chi2() == r.chi2()
 
 
+@pytest.mark.parametrize("kind", ["invdepth", "xyz"])
+def test_batched_lm_solve_equals_separate_solves(vio, hip_lib, oracle_lib, kind):
+    """vio_batch_solve: Problem::Solve of several windows with one launch per kernel for all of them.  Every window has its own
+    LmState — windows that converge early stop while the others go on, rejected trials re-solve with their own lambda — and the
+    result equals vio_solve on each, bit for bit (same kernel bodies, same data); reports included."""
+    if kind == "xyz":
+        ws = [vio.synth.make_window_xyz(500, seed=31, ragged=True), vio.synth.make_window_xyz(1500, seed=32), vio.synth.make_window_xyz(60, seed=33),
+              vio.synth.make_window_xyz(8, seed=34, obs_per_landmark=4)]
+        get = lambda c: c.get_landmarks_xyz()     # noqa: E731
+    else:
+        ws = windows(vio, oracle_lib)
+        ws.append(vio.synth.make_window(900, seed=8, ragged=True, outlier_fraction=0.1))       # rejected trials on the way
+        get = lambda c: c.get_landmarks()         # noqa: E731
+    lead = hip_lib.context()
+    batch = [lead] + [hip_lib.context(stream=lead.get_stream()) for _ in ws[1:]]
+    solo = [hip_lib.context() for _ in ws]
+    for c, r, w in zip(batch, solo, ws):
+        c.load(w)
+        r.load(w)
+    reps = hip_lib.batch_solve(batch, 40)
+    for c, r, rb in zip(batch, solo, reps):
+        rs = r.solve(40)
+        assert (rb.iterations, rb.trials, rb.accepted, rb.stop_reason) == (rs.iterations, rs.trials, rs.accepted, rs.stop_reason)
+        assert rb.final_chi2 == rs.final_chi2 and rb.final_lambda == rs.final_lambda and rb.initial_chi2 == rs.initial_chi2
+        np.testing.assert_array_equal(np.array(rb.chi2_trace[:]), np.array(rs.chi2_trace[:]))
+        for x, y in zip(c.get_window(), r.get_window()):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(get(c), get(r))
+    assert len({rb.iterations for rb in reps}) > 1 or len({rb.trials for rb in reps}) > 1       # the windows did not run in lockstep
+    # the contexts go on as usual: a second batched solve, a single one, a marginalisation
+    reps2 = hip_lib.batch_solve(batch[:3], 4)
+    for c, r, rb in zip(batch[:3], solo[:3], reps2):
+        rs = r.solve(4)
+        assert rb.iterations == rs.iterations and rb.final_chi2 == rs.final_chi2
+        np.testing.assert_array_equal(get(c), get(r))
+    if kind != "xyz":
+        ma, mb = batch[1].marginalize(vio.MARG_OLD), solo[1].marginalize(vio.MARG_OLD)
+        np.testing.assert_array_equal(ma["H"], mb["H"])
+
+
 def test_batch_argument_checks(vio, hip_lib):
     a, b = hip_lib.context(), hip_lib.context()            # two streams
     w = vio.synth.make_window(50, seed=1)

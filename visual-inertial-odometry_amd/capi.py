@@ -91,7 +91,7 @@ class VioLib:
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
-                "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration"]
+                "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration", "batch_solve"]
     KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
@@ -147,6 +147,16 @@ class VioLib:
         if st != 0:
             msg = self.fn["last_error"](ctxs[0].h)
             raise VioError(st, self.prefix + "batch_gn_iteration", (msg or b"").decode(errors="replace"))
+
+    def batch_solve(self, ctxs, iterations=10):
+        """Problem::Solve of every window of `ctxs` with one launch per kernel for the batch (vio_batch_solve); the reports."""
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        reps = (VioSolveReport * len(ctxs))()
+        st = self.fn["batch_solve"](arr, C.c_int32(len(ctxs)), C.c_int32(iterations), reps)
+        if st != 0:
+            msg = self.fn["last_error"](ctxs[0].h)
+            raise VioError(st, self.prefix + "batch_solve", (msg or b"").decode(errors="replace"))
+        return list(reps)
 
     def has(self, name):
         return hasattr(self.dll, self.prefix + name)

@@ -49,6 +49,8 @@ void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStr
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
+void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int any_prior, size_t ps_lds, int what,
+                         int max_iter, hipStream_t s);
 void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
                          size_t ps_lds, hipStream_t s);
 int vio_set_kernel_attributes();
@@ -1395,6 +1397,90 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         m->natural_hs_valid = false;
     }
     return VIO_OK;
+}
+
+// Problem::Solve for `count` independent windows at once: vio_solve's device-driven loop with every kernel launched once for the
+// whole batch (grid.y = window).  Every window follows its own LmState — its own lambda, its own accept / reject decisions,
+// its own stop — and the kernels of a window that has stopped skip themselves; the host reads the LmStates once per batch of
+// slots.  The same kernel bodies on the same data as vio_solve: bit-identical results.
+vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iterations, vio_solve_report *reports) {
+    if (!ctxs || count < 1 || !ctxs[0] || iterations < 0) return VIO_ERR_BAD_ARG;
+    vio_ctx *c = ctxs[0];       // leader: errors are reported on it
+    hipSetDevice(c->cfg.device);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < count; ++i) {
+        vio_ctx *m = ctxs[i];
+        if (!m) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_solve: null context");
+        if (m->cfg.device != c->cfg.device || m->stream != c->stream)
+            return fail(c, VIO_ERR_BAD_ARG, "vio_batch_solve: the contexts must share one device and one stream (vio_config.stream; vio_get_stream)");
+        if (sharded(m)) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_solve: sharded contexts cannot be batched");
+        if (m->lm_dim != c->lm_dim) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_solve: the windows of a batch hold one kind of landmark");
+        bool any_imu = false;
+        for (int k = 0; k < VIO_WINDOW_SIZE; ++k) any_imu |= m->imu_valid[k];
+        if (m->h_olm.empty() && !any_imu) return fail(c, VIO_ERR_EMPTY, "window " + std::to_string(i) + ": Cannot solve problem without edges or verticies");
+    }
+    std::vector<DeviceTables> tabs((size_t)count);
+    int max_blocks = 1, any_prior = 0;
+    size_t lds = 0;
+    for (int i = 0; i < count; ++i) {
+        vio_ctx *m = ctxs[i];
+        vio_status st = activate(m, m->solve_plan, 0);
+        if (st != VIO_OK) return m == c ? st : fail(c, st, "window " + std::to_string(i) + ": " + m->err);
+        st = flush_decide(m);
+        if (st != VIO_OK) return st;
+        m->cur_host = -1;
+        tabs[i] = make_tables_raw(m, m->solve_plan);         // cur_hint = -1: the kernels take `cur` from the window's LmState
+        if (!m->pairtab_valid && m->lm_dim == 1) { vio_launch_prepare(tabs[i], m->stream); m->pairtab_valid = true; }
+        const Plan &pl = m->solve_plan;
+        max_blocks = std::max<int>(max_blocks, (int)pl.items.size() + VIO_WINDOW_SIZE);
+        lds = std::max(lds, (size_t)pl.max_lds_doubles * 8);
+        any_prior |= m->has_prior;
+    }
+    c->batch_members.clear();                                // the GN batch's cached array is overwritten
+    HIPCHK(c->d_batch_tabs.resize((size_t)count));
+    HIPCHK(hipMemcpyAsync(c->d_batch_tabs.p, tabs.data(), (size_t)count * sizeof(DeviceTables), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    auto read_all = [&]() -> vio_status {
+        for (int i = 0; i < count; ++i) HIPCHK(hipMemcpyAsync(&ctxs[i]->h_lm, ctxs[i]->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return VIO_OK;
+    };
+    vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, 0, iterations, c->stream);
+    HIPCHK(hipGetLastError());
+    VIOCHK(read_all());
+    for (;;) {
+        int left = 0;           // slots the slowest window may still need
+        for (int i = 0; i < count; ++i)
+            if (!ctxs[i]->h_lm.stop && ctxs[i]->h_lm.iter < iterations) left = std::max(left, iterations - ctxs[i]->h_lm.iter);
+        if (left == 0) break;
+        const int batch = std::min(left, 10);
+        for (int sl = 0; sl < batch; ++sl)
+            vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, 1, iterations, c->stream);
+        HIPCHK(hipGetLastError());
+        VIOCHK(read_all());
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    bool finite = true;
+    for (int i = 0; i < count; ++i) {
+        vio_ctx *m = ctxs[i];
+        m->ahead = 7u;
+        m->decide_pending = false;
+        m->linearized = !(m->h_lm.accepted && m->h_lm.stop);
+        m->natural_hs_valid = false;
+        m->stepwise_updated = false;
+        finite = finite && m->h_lm.finite;
+        if (reports) {
+            vio_solve_report r;
+            std::memset(&r, 0, sizeof(r));
+            r.initial_chi2 = m->h_lm.init_chi;
+            r.iterations = m->h_lm.iter; r.trials = m->h_lm.trials; r.accepted = m->h_lm.naccepted; r.stop_reason = m->h_lm.stop_reason;
+            r.final_chi2 = m->h_lm.chi; r.final_lambda = m->h_lm.lambda;
+            for (int k = 0; k < 128; ++k) { r.chi2_trace[k] = m->h_lm.chi_trace[k]; r.lambda_trace[k] = m->h_lm.lambda_trace[k]; }
+            r.solve_ms = ms;        // the whole batch's wall clock
+            reports[i] = r;
+        }
+    }
+    return finite ? VIO_OK : VIO_ERR_NOT_FINITE;
 }
 
 vio_status vio_synchronize(vio_ctx *c) {

@@ -866,12 +866,14 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) { d_l
 struct BatchArgs {
     const DeviceTables *tabs;
     int32_t gn_flags;
-    int32_t parity;
+    int32_t parity;              // GN loop: 0 / 1, flips the window's cur_hint; -1 (batched LM solve): `cur` comes from the window's LmState
+    int32_t gate;                // d_gated_off's gate (batched LM solve: every window follows its own LmState)
 };
 __device__ __forceinline__ DeviceTables d_batch_tables(const BatchArgs &a) {
     DeviceTables T = a.tabs[blockIdx.y];
     T.gn_flags = a.gn_flags;
-    T.cur_hint ^= a.parity;
+    if (a.parity < 0) T.cur_hint = -1; else T.cur_hint ^= a.parity;
+    T.lm_gate = a.gate;
     return T;
 }
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize_b(BatchArgs a) {
@@ -1042,7 +1044,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_b(BatchArgs a) {
     const bool test_prev = (a.gn_flags & 1) != 0, err_prev = test_prev && T.has_prior;
     if ((int)blockIdx.x >= VIO_NPAIR + VIO_NCB + 1 && !err_prev) return;
     const int cur = T.cur_hint;
-    ReduceTables R{T.list_off, T.list, T.slab, T.vis, test_prev ? T.step_part : nullptr, T.n_items, 0, T.lm,
+    ReduceTables R{T.list_off, T.list, T.slab, T.vis, test_prev ? T.step_part : nullptr, T.n_items, a.gate, T.lm,
                    err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + cur * 176 : nullptr, err_prev ? T.errprior + cur * 160 : nullptr};
     d_reduce_body(R);
 }
@@ -1273,6 +1275,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_rank_b(BatchArgs a) {
     __shared__ int sCnt[5 * 176];
     const DeviceTables T = d_batch_tables(a);
     const int t = threadIdx.x;
+    if (d_gated_off(T.lm, T.lm_gate)) return;
     if (t < VIO_PD) { double vv, vr; d_hs_entry(T, d_imu_mask(T), t, t, vv, vr); sDg[t] = d_rank_key(vv + vr); }
     __syncthreads();
     d_rank_sort(sDg, sCnt, t);
@@ -1805,7 +1808,7 @@ __device__ void d_backsub_imu_block(const DeviceTables &T, int mode, int which, 
     part[2 * b + STEP_SCALE] = 0.0;
 }
 
-__global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode) {
+__device__ __forceinline__ void d_backsub_body(const DeviceTables &T, int mode) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const LmState *lm = T.lm;
     if (d_gated_off(lm, T.lm_gate)) return;
@@ -1883,6 +1886,12 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode
         double *part = (mode == 1) ? T.chi_part : T.step_part;
         part[2 * b + STEP_CHI] = c; part[2 * b + STEP_SCALE] = sc;
     }
+}
+__global__ __launch_bounds__(BS_THREADS) void k_backsub(DeviceTables T, int mode) { d_backsub_body(T, mode); }
+__global__ __launch_bounds__(BS_THREADS) void k_backsub_b(BatchArgs a, int mode) {
+    const DeviceTables T = d_batch_tables(a);
+    if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;       // the grid is the widest window's
+    d_backsub_body(T, mode);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1985,8 +1994,16 @@ __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int
     d_lm_decide<256>(T, mode, sum_local, s0, sImu, threadIdx.x);
 }
 
+__global__ __launch_bounds__(256) void k_lm_decide_b(BatchArgs a, int mode) {
+    __shared__ double s0[8];
+    __shared__ double sImu[16];
+    const DeviceTables T = d_batch_tables(a);
+    if (d_gated_off(T.lm, T.lm_gate)) return;
+    d_lm_decide<256>(T, mode, 1, s0, sImu, threadIdx.x);
+}
+
 // ComputeLambdaInitLM (problem.cc:497-522)
-__global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter, const double *maxh_src) {
+__device__ __forceinline__ void d_init_lm_body(const DeviceTables &T, int max_iter, const double *maxh_src) {
     __shared__ double s0[256];
     const int tid = threadIdx.x;
     LmState *lm = T.lm;
@@ -2012,6 +2029,11 @@ __global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter, c
     lm->iter = 0; lm->false_cnt = 0; lm->trials = 0; lm->naccepted = 0; lm->stop = 0; lm->stop_reason = 0;
     lm->finite = 1; lm->max_iter = max_iter; lm->accepted = 0; lm->need_linearize = 0;
     lm->chi_trace[0] = chi; lm->lambda_trace[0] = lm->lambda;
+}
+__global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter, const double *maxh_src) { d_init_lm_body(T, max_iter, maxh_src); }
+__global__ __launch_bounds__(256) void k_init_lm_b(BatchArgs a, int max_iter) {
+    const DeviceTables T = d_batch_tables(a);
+    d_init_lm_body(T, max_iter, T.vis + VIS_MAXH);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2128,7 +2150,7 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
 // batched GN iteration (windows of one landmark kind): grid.y = window
 void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
                          size_t ps_lds, hipStream_t s) {
-    BatchArgs a{tabs, test_prev ? 2 : 0, parity};
+    BatchArgs a{tabs, test_prev ? 2 : 0, parity, 0};
     if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
     else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
     a.gn_flags = test_prev ? 1 : 0;
@@ -2138,6 +2160,36 @@ void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_bl
     a.gn_flags = 4;
     hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
 }
+__global__ __launch_bounds__(RED_THREADS) void k_errprior_b(BatchArgs a);
+// Batched LM solve (vio_batch_solve): the kernels of vio_solve's device-driven loop with grid.y = window;
+// every window follows its own LmState (parity -1: `cur` from LmState; gate as in the single-window loop).
+//   what 0: first linearisation + ComputeLambdaInitLM      what 1: one slot = trial (gate 2) + re-linearisation (gate 3)
+void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int any_prior, size_t ps_lds, int what,
+                         int max_iter, hipStream_t s) {
+    auto linearize = [&](int gate) {
+        BatchArgs a{tabs, 0, -1, gate};
+        if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+        else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+        hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1, B), dim3(RED_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
+        hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(192), 0, s, a);
+    };
+    if (what == 0) {
+        linearize(0);
+        BatchArgs a{tabs, 0, -1, 0};
+        hipLaunchKernelGGL(k_init_lm_b, dim3(1, B), dim3(256), 0, s, a, max_iter);
+        return;
+    }
+    BatchArgs a{tabs, 4, -1, 2};
+    hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
+    a.gn_flags = 8;
+    if (lm_dim == 3) hipLaunchKernelGGL(k_backsub_xyz_b, dim3(max_blocks, B), dim3(BS_THREADS), 0, s, a, 0);
+    else hipLaunchKernelGGL(k_backsub_b, dim3(max_blocks, B), dim3(BS_THREADS), 0, s, a, 0);
+    a.gn_flags = 0;
+    if (any_prior) hipLaunchKernelGGL(k_errprior_b, dim3(RED_ERR_BLOCKS, B), dim3(RED_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_lm_decide_b, dim3(1, B), dim3(256), 0, s, a, 0);
+    linearize(3);
+}
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1 + (R.errprior ? RED_ERR_BLOCKS : 0)), dim3(RED_THREADS), 0, s, R);
 }
@@ -2145,6 +2197,13 @@ void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
 // k_lm_decide reads it
 __global__ __launch_bounds__(RED_THREADS) void k_errprior(DeviceTables T) {
     if (d_gated_off(T.lm, T.lm_gate)) return;
+    const int trial = 1 - d_cur(T);
+    const int row = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
+    if (row < VIO_PRD) d_errprior_row(T.Jtinv, T.bprior + trial * 176, T.errprior + trial * 160, row, threadIdx.x & 63);
+}
+__global__ __launch_bounds__(RED_THREADS) void k_errprior_b(BatchArgs a) {
+    const DeviceTables T = d_batch_tables(a);
+    if (!T.has_prior || d_gated_off(T.lm, T.lm_gate)) return;
     const int trial = 1 - d_cur(T);
     const int row = blockIdx.x * (RED_THREADS / 64) + (threadIdx.x >> 6);
     if (row < VIO_PRD) d_errprior_row(T.Jtinv, T.bprior + trial * 176, T.errprior + trial * 160, row, threadIdx.x & 63);

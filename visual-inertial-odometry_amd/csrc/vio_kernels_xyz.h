@@ -564,7 +564,7 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz_b(BatchArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // k_backsub_xyz: one workgroup per item, one thread per landmark.  mode as k_backsub.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BS_THREADS) void k_backsub_xyz(DeviceTables T, int mode) {
+__device__ __forceinline__ void d_backsub_xyz_body(const DeviceTables &T, int mode) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const LmState *lm = T.lm;
     if (d_gated_off(lm, T.lm_gate)) return;
@@ -661,6 +661,13 @@ __global__ __launch_bounds__(BS_THREADS) void k_backsub_xyz(DeviceTables T, int 
         double *part = (mode == 1) ? T.chi_part : T.step_part;
         part[2 * b + STEP_CHI] = c; part[2 * b + STEP_SCALE] = sc;
     }
+}
+
+__global__ __launch_bounds__(BS_THREADS) void k_backsub_xyz(DeviceTables T, int mode) { d_backsub_xyz_body(T, mode); }
+__global__ __launch_bounds__(BS_THREADS) void k_backsub_xyz_b(BatchArgs a, int mode) {
+    const DeviceTables T = d_batch_tables(a);
+    if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;
+    d_backsub_xyz_body(T, mode);
 }
 
 #endif
