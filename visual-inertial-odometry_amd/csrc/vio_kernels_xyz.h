@@ -570,7 +570,7 @@ __device__ __forceinline__ void d_backsub_xyz_body(const DeviceTables &T, int mo
     if (d_gated_off(lm, T.lm_gate)) return;
     const int cur = d_cur(T);
     const int which = (mode == 1) ? cur : (cur ^ 1);
-    if ((T.gn_flags & 8) && T.has_prior && (lane >> 6) == 1) d_bprior_rows(T, cur, cur ^ 1, b, gridDim.x, lane & 63);
+    if ((T.gn_flags & 8) && T.has_prior && (lane >> 6) == 1) d_bprior_rows(T, cur, cur ^ 1, b, T.n_step_blocks, lane & 63);
     if (b >= T.n_items) { d_backsub_imu_block(T, mode, which, b, lane); return; }
     __shared__ double sFr[VIO_NF * 12];       // camera maps at the state whose chi2 is wanted
     __shared__ double sFrO[VIO_NF * 12 + 12]; // mode 0: the maps (and ric, tic) at the state the step was linearised at
