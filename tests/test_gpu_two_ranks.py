@@ -26,7 +26,20 @@ def _free_port():
 
 
 def _make(vio, kind, n, ragged):
-    return vio.synth.make_window_xyz(n, seed=21, ragged=ragged) if kind == "xyz" else vio.synth.make_window(n, seed=21, ragged=ragged)
+    # (tools/fuzz_two_ranks.py varies the seed and adds a prior through the environment, which the spawned ranks inherit)
+    seed = int(os.environ.get("VIO_TWO_RANK_SEED", "21"))
+    w = vio.synth.make_window_xyz(n, seed=seed, ragged=ragged) if kind == "xyz" else vio.synth.make_window(n, seed=seed, ragged=ragged)
+    if os.environ.get("VIO_TWO_RANK_PRIOR") == "1":
+        p = np.random.RandomState(seed).normal(size=(156, 40))
+        H = p @ p.T * 1e3                           # any symmetric positive semi-definite prior will do for the protocol
+        ev, V = np.linalg.eigh(H)
+        keep = ev > 1e-8 * ev.max()
+        J = (V[:, keep] / np.sqrt(ev[keep])).T
+        jt = np.zeros((156, 156))
+        jt[:J.shape[0]] = J
+        b = H @ np.random.RandomState(seed + 1).normal(scale=1e-3, size=156)
+        w.prior = dict(H=H, b=b, err=-(jt @ b), jt_inv=jt)
+    return w
 
 
 def _worker(rank, world, port, out_dir, kind, n, ragged):
