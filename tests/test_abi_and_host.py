@@ -25,6 +25,16 @@ def test_header_declares_the_reference_call_sequence():
         assert need in fns
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/vio_backend.h compiles as C99 and as C++11, pedantic, with nothing but the standard headers."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "vio_backend.h"\nint main(void) { vio_config c; vio_solve_report r; (void)c; (void)r; return 0; }\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-c", str(src), "-o", str(tmp_path / "a.o")])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")])
+
+
 def test_hip_library_exports_every_declared_symbol(vio):
     """No compute call here (there is no GPU in the CPU tier): only that the product library exists, loads and
     resolves each prototype of include/vio_backend.h."""
