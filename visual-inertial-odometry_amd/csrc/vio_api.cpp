@@ -127,8 +127,8 @@ struct HostArena {
         pending = e == hipSuccess;
         return e;
     }
-    void release() {
-        if (pending && ev) hipEventSynchronize(ev);
+    void release(bool stream_alive) {
+        if (pending && ev && stream_alive) hipEventSynchronize(ev);       // (otherwise the caller has waited for the device)
         for (Chunk &c : chunks) hipHostFree(c.p);
         chunks.clear();
         if (ev) hipEventDestroy(ev);
@@ -244,6 +244,13 @@ namespace {
         vio_status s__ = (expr);                        \
         if (s__ != VIO_OK) return s__;                  \
     } while (0)
+
+// every entry point: the context's device, and whatever error an earlier call of anybody's left on this thread forgotten (the
+// launch checks below ask hipGetLastError(), which would report it as theirs)
+static inline void enter_device(const vio_ctx *c) {
+    (void)hipSetDevice(c->cfg.device);
+    (void)hipGetLastError();
+}
 
 vio_status fail(vio_ctx *c, vio_status s, const std::string &msg) {
     c->err = msg;
@@ -1005,7 +1012,7 @@ vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
     if (cfg->device != c->cfg.device || (cfg->stream && (hipStream_t)cfg->stream != c->stream) || cfg->shard_rank != c->cfg.shard_rank ||
         std::max(cfg->shard_count, 1) != c->cfg.shard_count)
         return fail(c, VIO_ERR_BAD_ARG, "vio_set_config: device, stream and shard fields belong to the context's creation");
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     VIOCHK(pull_from_device(c));
     void *keep_stream = c->cfg.stream;
     const bool replan = cfg->ext_fixed != c->cfg.ext_fixed;     // the patterns carry an extrinsic block or not
@@ -1019,7 +1026,7 @@ vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
 
 void vio_destroy(vio_ctx *c) {
     if (!c) return;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     // A stream the caller supplied (vio_config.stream, e.g. the leader's of a batch) may be gone already when this context
     // goes: it is not touched here.  hipFree waits for the device itself, so nothing in flight loses its buffers.
     if (c->own_stream) hipStreamSynchronize(c->stream);
@@ -1031,11 +1038,12 @@ void vio_destroy(vio_ctx *c) {
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
     c->d_batch_tabs.release(); c->d_rank.release(); c->d_gather_map.release();
-    c->arena.release();
+    c->arena.release(c->own_stream);
     if (c->pull_stage) hipHostFree(c->pull_stage);
     if (c->marg_stage) hipHostFree(c->marg_stage);
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
+    (void)hipGetLastError();         // (an event of a borrowed stream that is gone may have complained: not the next caller's business)
     delete c;
 }
 
@@ -1043,7 +1051,7 @@ const char *vio_last_error(const vio_ctx *c) { return c ? c->err.c_str() : "null
 
 vio_status vio_set_window(vio_ctx *c, const double *poses, const double *sb, const double *ext) {
     if (!c || !poses || !sb || !ext) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     c->ahead &= ~1u;                 // the states are replaced whole: nothing of the device's to keep
     std::memcpy(c->h_state + STATE_EXT, ext, 7 * 8);
     std::memcpy(c->h_state + STATE_POSE, poses, 77 * 8);
@@ -1054,7 +1062,7 @@ vio_status vio_set_window(vio_ctx *c, const double *poses, const double *sb, con
 
 static vio_status set_landmarks_dim(vio_ctx *c, int64_t n, const double *val, int dim) {
     if (!c || n < 0 || (n > 0 && !val)) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     const bool resized = (int64_t)c->h_invd.size() != n * dim || c->lm_dim != dim;
     // The same values as the mirror holds, the mirror current: nothing to do.  (The reference's frame sets the window twice,
     // for Solve and for Marginalize, with the landmarks the solve gave it: estimator.cpp:1083-1092.)
@@ -1112,7 +1120,7 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
 
 vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
     if (!c || k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     double blk[PRE_STRIDE];
     double *o = blk;
     std::memcpy(blk, c->h_pre.data() + (size_t)k * PRE_STRIDE, sizeof(blk));
@@ -1134,7 +1142,7 @@ vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
 vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double *b, const double *err, const double *jt) {
     if (!c || (dim != 0 && dim != PRD)) return VIO_ERR_BAD_ARG;
     if (dim && (!H || !b || !err || !jt)) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     // The two matrices are 430 KB of upload: left alone when they are the ones the context holds (the reference hands the same
     // H_prior / Jt_prior_inv to Solve and then to Marginalize, with b_prior / err_prior as the solve updated them)
     bool same_mats = c->has_prior == (dim ? 1 : 0);
@@ -1166,7 +1174,7 @@ vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double 
 
 vio_status vio_linearize(vio_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     VIOCHK(activate(c, c->solve_plan, 0));
     if (c->stepwise_updated) c->stepwise_updated = false;     // a new linearisation commits the step
     VIOCHK(enqueue_linearize(c, c->solve_plan));
@@ -1175,7 +1183,7 @@ vio_status vio_linearize(vio_ctx *c) {
 
 vio_status vio_init_lm(vio_ctx *c, double *chi2, double *lambda) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     MAKE_TABLES(T, c, *c->active);
     VIOCHK(enqueue_init_lm(c, T, 1 << 30));
     VIOCHK(read_lm(c));
@@ -1186,7 +1194,7 @@ vio_status vio_init_lm(vio_ctx *c, double *chi2, double *lambda) {
 
 vio_status vio_solve_linear(vio_ctx *c, double lambda) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     Plan &pl = *c->active;
     MAKE_TABLES(T, c, pl);
     vio_launch_set_lambda(c->d_lm.p, lambda, c->stream);
@@ -1199,21 +1207,21 @@ vio_status vio_solve_linear(vio_ctx *c, double lambda) {
 
 vio_status vio_update_states(vio_ctx *c) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     if (!c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = true; c->ahead = 7u; }
     return VIO_OK;
 }
 
 vio_status vio_rollback_states(vio_ctx *c) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     if (c->stepwise_updated) { vio_launch_flip(c->d_lm.p, c->stream); c->stepwise_updated = false; c->ahead = 7u; }
     return VIO_OK;
 }
 
 vio_status vio_chi2(vio_ctx *c, double *chi2) {
     if (!c || !chi2) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = *c->active;
     MAKE_TABLES(T, c, pl);
@@ -1229,7 +1237,7 @@ vio_status vio_chi2(vio_ctx *c, double *chi2) {
 
 vio_status vio_eval_step(vio_ctx *c, int32_t *accepted, double *chi2, double *lambda) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     Plan &pl = *c->active;
     MAKE_TABLES(T, c, pl);
     // the decide kernel expects the trial copy to be "the other one"
@@ -1252,7 +1260,7 @@ vio_status vio_eval_step(vio_ctx *c, int32_t *accepted, double *chi2, double *la
 
 vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
     if (!c) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     bool any_imu = false;
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) any_imu |= c->imu_valid[k];
     if (c->h_olm.empty() && !any_imu) return fail(c, VIO_ERR_EMPTY, "Cannot solve problem without edges or verticies");
@@ -1313,7 +1321,7 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
 
 vio_status vio_gn_iteration(vio_ctx *c, double lambda) {
     if (!c) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = c->solve_plan;
     // chi2 and the gain-ratio partial of a step reach its test through vis: one exchange per iteration
@@ -1338,7 +1346,7 @@ vio_status vio_get_stream(vio_ctx *c, void **stream) {
 vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double lambda) {
     if (!ctxs || count < 1 || !ctxs[0]) return VIO_ERR_BAD_ARG;
     vio_ctx *c = ctxs[0];       // leader: errors are reported on it
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     for (int i = 0; i < count; ++i) {
         vio_ctx *m = ctxs[i];
         if (!m) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_gn_iteration: null context");
@@ -1406,7 +1414,7 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
 vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iterations, vio_solve_report *reports) {
     if (!ctxs || count < 1 || !ctxs[0] || iterations < 0) return VIO_ERR_BAD_ARG;
     vio_ctx *c = ctxs[0];       // leader: errors are reported on it
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < count; ++i) {
         vio_ctx *m = ctxs[i];
@@ -1485,7 +1493,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
 
 vio_status vio_synchronize(vio_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     return VIO_OK;
 }
@@ -1493,7 +1501,7 @@ vio_status vio_synchronize(vio_ctx *c) {
 vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, double *err, double *jt) {
     if (!c || !H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     if (kind == VIO_MARG_OLD && c->lm_dim == 3) return fail(c, VIO_ERR_UNSUPPORTED, "MargOldFrame is not defined for XYZ landmarks (include/vio_backend.h)");
     static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1552,7 +1560,7 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
 
 vio_status vio_get_window(vio_ctx *c, double *poses, double *sb, double *ext) {
     if (!c) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     VIOCHK(pull_from_device(c, 1u));
     if (ext) std::memcpy(ext, c->h_state + STATE_EXT, 7 * 8);
     if (poses) std::memcpy(poses, c->h_state + STATE_POSE, 77 * 8);
@@ -1576,7 +1584,7 @@ vio_status vio_get_landmarks_xyz(vio_ctx *c, int64_t n, double *xyz) {
 
 vio_status vio_get_prior(vio_ctx *c, double *b, double *err) {
     if (!c) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     VIOCHK(pull_from_device(c, 4u));
     if (b) std::memcpy(b, c->h_bprior.data(), PD * 8);
     if (err) std::memcpy(err, c->h_errprior.data(), PRD * 8);
@@ -1585,7 +1593,7 @@ vio_status vio_get_prior(vio_ctx *c, double *b, double *err) {
 
 vio_status vio_get_delta(vio_ctx *c, double *dxp, int64_t n, double *dxl) {
     if (!c || !c->active) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     const size_t ld = (size_t)c->lm_dim;
     if (dxl && n * (int64_t)ld != (int64_t)c->h_invd.size()) return VIO_ERR_BAD_ARG;
     VIOCHK(flush_decide(c));        // a GN step's landmark update is owed until somebody asks (or the next linearisation)
@@ -1604,7 +1612,7 @@ vio_status vio_get_delta(vio_ctx *c, double *dxp, int64_t n, double *dxl) {
 
 vio_status vio_get_schur_system(vio_ctx *c, double *H, double *b) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     if (H && !c->natural_hs_valid) {            // the solve path keeps only the permuted packed copy: assemble once more
         c->want_natural_hs = true;
         MAKE_TABLES(T, c, *c->active);
@@ -1620,7 +1628,7 @@ vio_status vio_get_schur_system(vio_ctx *c, double *H, double *b) {
 
 vio_status vio_get_landmark_system(vio_ctx *c, int64_t n, double *hll, double *bl) {
     if (!c || !c->linearized || n * c->lm_dim != (int64_t)c->h_invd.size()) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     VIOCHK(flush_decide(c));
     Plan &pl = *c->active;
     std::vector<double> lw(std::max<size_t>(pl.lw_doubles, 1));
@@ -1650,7 +1658,7 @@ vio_status vio_get_landmark_system(vio_ctx *c, int64_t n, double *hll, double *b
 
 vio_status vio_get_pose_gradient(vio_ctx *c, double *b, double *diag) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     if (b) HIPCHK(hipMemcpyAsync(b, c->d_bfull.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
     if (diag) HIPCHK(hipMemcpyAsync(diag, c->d_diagfull.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1684,7 +1692,7 @@ vio_status vio_triangulate(vio_ctx *c, int64_t n, const int32_t *start_frame, co
         const int64_t k = obs_offset[i + 1] - obs_offset[i];
         if (k < 0 || start_frame[i] < 0 || start_frame[i] + k > VIO_NF) return fail(c, VIO_ERR_BAD_ARG, "vio_triangulate: a track leaves the window");
     }
-    hipSetDevice(c->cfg.device);
+    enter_device(c);
     DevBuf<int32_t> d_sf; DevBuf<int64_t> d_off; DevBuf<double> d_pts, d_pose, d_depth;
     vio_status st = VIO_OK;
     auto body = [&]() -> vio_status {
