@@ -120,7 +120,7 @@ for seq in range(n_seq):
         if not state["ok"] or state.get("stop"):
             break
         op = rng.choice(["solve", "gn", "get", "chi2", "set_window", "set_landmarks", "set_prior", "reload_same", "load_other", "marg_old", "marg_new",
-                         "stepwise", "set_imu"], p=[.15, .1, .1, .08, .08, .07, .07, .05, .06, .1, .05, .05, .04])
+                         "stepwise", "set_imu", "set_config"], p=[.15, .1, .1, .08, .08, .07, .07, .05, .06, .08, .05, .05, .03, .03])
         if op in ("solve", "marg_old", "marg_new", "chi2", "stepwise"):
             if (op == "marg_new" and model["prior"] is None) or (op == "marg_old" and xyz):
                 continue
@@ -186,6 +186,9 @@ for seq in range(n_seq):
             pre = model["w"].preint[k] if rng.rand() < 0.7 else None
             model["preint"][k] = pre
             run("set_imu(%d,%s)" % (k, "yes" if pre is not None else "none"), lambda c: c.set_imu(k, pre))
+        elif op == "set_config":          # vio_set_config on the living context: other loss, extrinsic fixed or free
+            kw = dict(ext_fixed=int(rng.randint(2)), loss_type=int(rng.choice([0, 1, 2])))
+            run("set_config(%d,%d)" % (kw["ext_fixed"], kw["loss_type"]), lambda c: c.set_config(**kw))
         elif op in ("reload_same", "load_other"):
             if op == "load_other":
                 model["w"] = windows[1] if model["w"] is windows[0] else windows[0]
