@@ -14,7 +14,8 @@ from conftest import load_package  # noqa: E402
 vio = load_package()
 lib = vio.VioLib(os.path.join(ROOT, "visual-inertial-odometry_amd", "csrc", "diag", os.environ.get("VIO_DIAG_LIB", "libvio_hip_stamps.so")), "vio_")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
-w = vio.synth.make_window(n, seed=42)
+xyz = len(sys.argv) > 2 and sys.argv[2] == "xyz"          # k_linearize_xyz's phases (the finer slots below are the inverse-depth kernel's)
+w = (vio.synth.make_window_xyz if xyz else vio.synth.make_window)(n, seed=42)
 ctx = lib.context()
 ctx.load(w)
 for _ in range(3):
@@ -39,6 +40,9 @@ d = np.diff(st[vis][:, :6], axis=1)
 print("visual workgroups: %d   (s_memtime ticks = 100 MHz?  constant clock; shares are what matters)" % vis.sum())
 for k, nm in enumerate(names):
     print("  %-28s mean %8.1f  max %8.1f" % (nm, d[:, k].mean(), d[:, k].max()))
+if xyz:
+    print("  total                        mean %8.1f  max %8.1f" % ((st[vis][:, 5] - st[vis][:, 0]).mean(), (st[vis][:, 5] - st[vis][:, 0]).max()))
+    sys.exit(0)
 print("  inside phase 2, wave 0: product done after %.0f, vector sums done after %.0f (of the phase)" % ((st[vis][:, 6] - st[vis][:, 3]).mean(), (st[vis][:, 7] - st[vis][:, 3]).mean()))
 print("  wave 0 (direct product): chunk loop done after %.0f, remainder %.0f, stored %.0f | wave 4 (Schur tile): starts %.0f, chunk loop done %.0f (of the phase)" % tuple(
     (st[vis][:, b_] - st[vis][:, 3]).mean() for b_ in (14, 15, 6, 12, 13)))

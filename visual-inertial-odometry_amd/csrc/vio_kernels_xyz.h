@@ -266,6 +266,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     const double *pts = T.pts_j + 2 * (size_t)it.obs_base;
     const double s_info = T.sqrt_info;
     if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, T.n_step_blocks, tid & 63);
+    STAMP(T, 0);
     // phase 0: camera maps (their loads leave together with the head's: one global round trip for both)
     if (tid >= 896 && tid < 896 + K) {                       // wave 14: no head loads of its own in front of these
         const int k = tid - 896;
@@ -281,6 +282,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
             for (int q = 0; q < 3; ++q) sCam[9 + q] = st[STATE_EXT + q];
         }
     }
+    if (tid >= 128 && tid < 132) sCam[12 + (tid - 128)] = 0.0;        // zeros for the padding lanes of phase 2 to stream
     if (tid >= 256 && tid < 256 + XYZ_BP_TAB) sBp[tid - 256] = 0.0;
     // an odd K leaves the second half of the last plane unused: the direct products read it, so it holds zeros
     if (K & 1) for (int e = tid; e < G * 12; e += LIN_THREADS) sRows[(NTD - 1) * PLANE + (e / 12) * 24 + 12 + e % 12] = 0.0;
@@ -343,6 +345,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     __syncthreads();
     const double *ric = sCam, *tic = sCam + 9;
 
+    STAMP(T, 1);
     // ---------------- phase 1: thread per observation ----------------
     // thread -> (k, g) with the landmarks of a frame index padded to whole waves: every wave works on one k, so that the
     // pose part of b, - sum_g drho J_pose^T Info r, is a sum inside the wave (it had 6 doubles per observation in LDS)
@@ -389,6 +392,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     }
     __syncthreads();
 
+    STAMP(T, 2);
     // ---------------- phase 1.5: thread per landmark: H_ll, b_l, H_ll^-1, H_ll^-1 b_l ----------------
     double maxh = 0.0;
     if (tid < G) {
@@ -422,6 +426,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
         if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
     }
     __syncthreads();
+    STAMP(T, 3);
     // ---------------- phase 2: tiles on the matrix cores ----------------
     const int D = 6 * nb;
     const int TS = (D + 15) >> 4, nts = TS * (TS + 1) / 2;
@@ -434,13 +439,16 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
             if (wk < NTD) {
                 // C = V^T V, V = the 2G whitened pose rows of observation indices 2 wk and 2 wk + 1 side by side (12 columns);
                 // one MFMA step takes two landmarks (lane row group rg: landmark rg >> 1, row rg & 1)
+                // A padding lane (column >= 12) streams a zero with stride 0 and a step past the last landmark re-reads the last one
+                // with its A operand multiplied by 0: the loop is loads and matrix instructions, no masks, no branches
                 const bool live = cl < 12;
                 const int off = (cl < 6 ? 0 : 12) + (rg & 1) * 6 + (cl < 6 ? cl : cl - 6);
-                const double *plane = sRows + wk * PLANE + (live ? off : 0);
+                const double *plane = live ? sRows + wk * PLANE + off : sCam + 12;
+                const int sp = live ? 24 : 0;
                 for (int st2 = 0; 2 * st2 < G; ++st2) {
                     const int g = 2 * st2 + (rg >> 1);
-                    const double vv = (live && g < G) ? plane[g * 24] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vv, vv, acc, 0, 0, 0);
+                    const double vv = plane[min(g, G - 1) * sp];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(g < G ? vv : 0.0, vv, acc, 0, 0, 0);
                 }
             } else {
                 const int ts = wk - NTD;
@@ -451,23 +459,27 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
                 const bool la = a < D, lb = bq < D;
                 // one group of 4 landmarks (k index rg) per step, three matrix instructions (coordinate c) per group:
                 // A = W[a][c], B = -Y[bq][c] with Y = W H_ll^-1 formed here from the three W of the row and H_ll^-1
-                const double *pa = sL + offW + (la ? a : 0) * 3, *pb = sL + offW + (lb ? bq : 0) * 3;
+                // (branch-free as above: a padding row streams zeros with stride 0, a group past the last landmark re-reads the
+                // last one with its A operand multiplied by 0)
+                const double *pa = la ? sL + offW + a * 3 : sCam + 12, *pb = lb ? sL + offW + bq * 3 : sCam + 12;
+                const int sa = la ? LREC : 0, sb = lb ? LREC : 0;
                 const bool diag = ta == tb;
                 for (int st4 = 0; 4 * st4 < G; ++st4) {
-                    const int g = 4 * st4 + rg;
-                    const bool ok = g < G;
-                    const double *Lg = sL + (size_t)(ok ? g : 0) * LREC;
+                    const int g = 4 * st4 + rg, gc = min(g, G - 1);
+                    const double m = g < G ? 1.0 : 0.0;
+                    const double *Lg = sL + (size_t)gc * LREC + offHI;
                     double wb[3], wa[3], hi[9];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) wb[c] = (ok && lb) ? pb[(size_t)g * LREC + c] : 0.0;
+                    for (int c = 0; c < 3; ++c) wb[c] = pb[gc * sb + c];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) wa[c] = diag ? wb[c] : ((ok && la) ? pa[(size_t)g * LREC + c] : 0.0);
+                    for (int c = 0; c < 3; ++c) wa[c] = pa[gc * sa + c];
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) hi[q] = Lg[offHI + q];
+                    for (int q = 0; q < 9; ++q) hi[q] = Lg[q];
+                    (void)diag;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const double yb = wb[0] * hi[c] + wb[1] * hi[3 + c] + wb[2] * hi[6 + c];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[c], -yb, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[c] * m, -yb, acc, 0, 0, 0);
                     }
                 }
             }
@@ -488,6 +500,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     }
     __syncthreads();
 
+    STAMP(T, 4);
     // ---------------- combine: thread per slab element ----------------
     {
         double *out = T.slab + it.out_base;
@@ -552,6 +565,8 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
             lw[e] = r < 6 ? Lg[offH + r] : Lg[offBL + (r - 6)];
         }
     }
+    STAMP(T, 5);
+    STAMP_FLUSH(T);
 }
 
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) { d_linearize_xyz_body(T); }
