@@ -34,6 +34,8 @@ struct ReduceTables {
     const double *jtinv;
     const double *bprior;
     double *errprior;
+    int32_t lm_loop;             // 1 (vio_solve's loop): step_part / jtinv count only while lm->pending; bprior / errprior are the bases of
+                                 // the two copies and the step's copy is lm->cur ^ 1
 };
 void vio_launch_errprior(const DeviceTables &T, hipStream_t s);
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s);
@@ -594,7 +596,7 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *
     const size_t ld = (size_t)pl.lm_dim;
     HIPCHK(pl.d_pts_i.resize(2 * (size_t)pl.Ns)); HIPCHK(pl.d_pts_j.resize(2 * (size_t)pl.Ms));
     HIPCHK(pl.d_invd.resize(2 * ld * (size_t)std::max<int64_t>(pl.Ns, 1))); HIPCHK(pl.d_slab.resize(pl.slab_doubles));
-    HIPCHK(pl.d_lw.resize(pl.lw_doubles)); HIPCHK(pl.d_dxl.resize(ld * (size_t)pl.Ns));
+    HIPCHK(pl.d_lw.resize(2 * pl.lw_doubles)); HIPCHK(pl.d_dxl.resize(ld * (size_t)pl.Ns));      // lw: two sets, see DeviceTables.lw_set
     HIPCHK(pl.d_step_part.resize(4 * (ni + VIO_WINDOW_SIZE)));
     hipStream_t st = c->stream;
     // everything leaves from the pinned staging: no wait here (activate() marks the staging busy until these copies are done)
@@ -616,11 +618,11 @@ vio_status alloc_fixed(vio_ctx *c) {
     HIPCHK(c->d_vis.resize(VIS_COUNT)); HIPCHK(c->d_pre.resize(VIO_WINDOW_SIZE * PRE_STRIDE));
     HIPCHK(c->d_imu_out.resize(VIO_WINDOW_SIZE * IMU_OUT)); HIPCHK(c->d_Hprior.resize(PD * PD));
     HIPCHK(c->d_bprior.resize(2 * 176)); HIPCHK(c->d_errprior.resize(2 * 160)); HIPCHK(c->d_Jtinv.resize(PRD * PRD));
-    HIPCHK(c->d_Hs.resize(PD * PD)); HIPCHK(c->d_bs.resize(176)); HIPCHK(c->d_bfull.resize(176));
+    HIPCHK(c->d_Hs.resize(PD * PD)); HIPCHK(c->d_bs.resize(176)); HIPCHK(c->d_bfull.resize(2 * 176));
     HIPCHK(c->d_diagfull.resize(176)); HIPCHK(c->d_dx.resize(176)); HIPCHK(c->d_step_tot.resize(8));
     HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
-    HIPCHK(c->d_perm.resize(176)); HIPCHK(c->d_rank.resize(176)); HIPCHK(c->d_Pg.resize(POSE_SOLVE_TILED));
-    HIPCHK(hipMemset(c->d_Pg.p, 0, POSE_SOLVE_TILED * sizeof(double)));   // tile padding (17th column) is never written again
+    HIPCHK(c->d_perm.resize(2 * 176)); HIPCHK(c->d_rank.resize(176)); HIPCHK(c->d_Pg.resize(2 * POSE_SOLVE_TILED));     // two sets (vio_solve's loop)
+    HIPCHK(hipMemset(c->d_Pg.p, 0, 2 * POSE_SOLVE_TILED * sizeof(double)));   // tile padding (17th column) is never written again
     HIPCHK(hipMemsetAsync(c->d_vis.p, 0, VIS_COUNT * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_step_tot.p, 0, 8 * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_dx.p, 0, 176 * 8, c->stream));
@@ -635,7 +637,7 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     T.loss_delta = c->cfg.loss_delta; T.sqrt_info = c->cfg.reproj_sqrt_info;
     for (int k = 0; k < 3; ++k) T.gravity[k] = c->cfg.gravity[k];
     T.state = c->d_state.p; T.invd = pl.d_invd.p; T.pts_i = pl.d_pts_i.p; T.pts_j = pl.d_pts_j.p;
-    T.pairtab = c->d_pairtab.p; T.slab = pl.d_slab.p; T.lw = pl.d_lw.p; T.vis = c->ext_vis ? c->ext_vis : c->d_vis.p; T.pre = c->d_pre.p;
+    T.pairtab = c->d_pairtab.p; T.slab = pl.d_slab.p; T.lw = pl.d_lw.p; T.lw_set = (int64_t)pl.lw_doubles; T.vis = c->ext_vis ? c->ext_vis : c->d_vis.p; T.pre = c->d_pre.p;
     T.imu_valid = c->d_imu_valid.p; T.imu_out = c->d_imu_out.p; T.imu_chi_try = c->d_imu_chi.p;
     T.pair_slot = nullptr; T.blk_slot = nullptr;
     T.Hprior = c->d_Hprior.p; T.bprior = c->d_bprior.p; T.errprior = c->d_errprior.p; T.Jtinv = c->d_Jtinv.p;
@@ -959,6 +961,34 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int ga
     return VIO_OK;
 }
 
+// One slot of vio_solve's loop.  Problem::Solve tests a step by evaluating chi2 at the trial state and, when the step is good,
+// linearises there (problem.cc:210-233); here the linearisation comes first — chi2 is a by-product of it — so an iteration is the
+// GN loop's four launches: k_linearize at the trial state (the step's landmark back-substitution and b_prior' rows in its head),
+// k_reduce (+ err_prior'), [exchange], k_assemble (chi2 and the gain ratio's denominator into LmState), k_pose_solve (the
+// verdict; on accept the next step from the system just assembled; on reject nothing: the next slot linearises at the kept
+// state again, which a rejected trial costs here instead of a second evaluation).  `first`: the step from the initial linearisation.
+vio_status enqueue_lm_slot(vio_ctx *c, Plan &pl, bool first) {
+    DeviceTables T = make_tables_raw(c, pl);
+    T.cur_hint = -2;
+    T.lm_gate = 2;
+    if (!first) {
+        T.gn_flags = 2;
+        { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
+        // (sharded: k_reduce always runs, see enqueue_linearize)
+        ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, T.step_part, T.n_items, sharded(c) ? 0 : 2, T.lm,
+                       T.has_prior ? T.Jtinv : nullptr, T.has_prior ? T.bprior : nullptr, T.has_prior ? T.errprior : nullptr, 1};
+        { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
+        VIOCHK(run_exchange(c, 0));
+        T.gn_flags = 1;
+        { ProfScope ps(c, VIO_K_ASSEMBLE); vio_launch_assemble(T, c->stream); }
+    }
+    T.gn_flags = 4;
+    { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
+    HIPCHK(hipGetLastError());
+    c->ahead = 7u;
+    return VIO_OK;
+}
+
 }  // namespace
 
 // =========================================================================================================
@@ -1268,33 +1298,29 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = c->solve_plan;
     float first_lin_ms = 0;
+    struct EventPair {      // destroyed on every way out
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+    } ev;
+    HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
+    HIPCHK(hipEventRecord(ev.a, c->stream));
+    VIOCHK(enqueue_linearize(c, pl));
+    HIPCHK(hipEventRecord(ev.b, c->stream));
     {
-        struct EventPair {      // destroyed on every way out
-            hipEvent_t a = nullptr, b = nullptr;
-            ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
-        } ev;
-        HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
-        HIPCHK(hipEventRecord(ev.a, c->stream));
-        VIOCHK(enqueue_linearize(c, pl));
-        HIPCHK(hipEventRecord(ev.b, c->stream));
         MAKE_TABLES(T, c, pl);
         VIOCHK(enqueue_init_lm(c, T, iterations));
-        VIOCHK(read_lm(c));
-        hipEventElapsedTime(&first_lin_ms, ev.a, ev.b);
     }
-    vio_solve_report r;
-    std::memset(&r, 0, sizeof(r));
-    r.initial_chi2 = c->h_lm.chi;
+    // Device-driven loop: LmState lives on the device and the kernels do all of Problem::Solve's bookkeeping, so the host
+    // enqueues as many slots as outer iterations are left and looks at LmState once per batch of slots; everything after the
+    // stop skips itself.  When every trial is accepted - the usual case - that is one read-back per solve.
+    // Sharded solves run the same loop: the exchange of a slot is enqueued unconditionally (every rank holds the identical
+    // LmState, so every rank enqueues the same collectives), a dead slot all-reduces buffers nobody reads.
+    static const bool classic = std::getenv("VIO_LM_CLASSIC") != nullptr;     // diagnostic: the trial / re-linearisation slots of round 1
     vio_status status = VIO_OK;
-    {
-        // Device-driven loop: LmState lives on the device and k_lm_decide does all of Problem::Solve's bookkeeping, so the
-        // host enqueues as many (trial, re-linearisation) slots as outer iterations are left and looks at LmState once per
-        // batch; the kernels of a slot gate themselves (a rejected trial skips its re-linearisation, everything after
-        // the stop skips itself).  When every trial is accepted - the usual case - that is one read-back per solve.
-        // Sharded solves run the same loop: the two exchanges of a slot are enqueued unconditionally (every rank holds the
-        // identical LmState, so every rank enqueues the same collectives), a dead slot all-reduces buffers nobody reads.
+    if (classic) {
+        VIOCHK(read_lm(c));
         while (status == VIO_OK && !c->h_lm.stop && c->h_lm.iter < iterations) {
-            // (at most 10 slots ahead: a loop that stops early leaves the rest as empty launches, ~20 us each)
+            // (at most 10 slots ahead: a loop that stops early leaves the rest as empty launches)
             const int batch = std::min(iterations - c->h_lm.iter, 10);
             for (int sl = 0; sl < batch && status == VIO_OK; ++sl) {
                 status = enqueue_trial(c, pl, 0, false, 2);
@@ -1302,13 +1328,30 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
             }
             if (status == VIO_OK) status = read_lm(c);
         }
+    } else {
+        int done = 0;
+        bool stop = iterations <= 0;
+        if (!stop) status = enqueue_lm_slot(c, pl, true);
+        while (status == VIO_OK && !stop) {
+            const int batch = std::min(iterations - done, 10);
+            for (int sl = 0; sl < batch && status == VIO_OK; ++sl) status = enqueue_lm_slot(c, pl, false);
+            if (status == VIO_OK) status = read_lm(c);
+            done = c->h_lm.iter;
+            stop = c->h_lm.stop || done >= iterations;
+        }
+        if (status == VIO_OK && iterations <= 0) status = read_lm(c);
     }
     if (status != VIO_OK) return status;
+    hipEventElapsedTime(&first_lin_ms, ev.a, ev.b);
+    vio_solve_report r;
+    std::memset(&r, 0, sizeof(r));
+    r.initial_chi2 = c->h_lm.init_chi;
     // t_hessian_cost_ of the reference's printout (problem.cc:246-248): the first linearisation is timed, the others are
     // the same kernels on the same graph
     const int n_lin = 1 + c->h_lm.naccepted - ((c->h_lm.accepted && c->h_lm.stop) ? 1 : 0);
     const double hess_ms = (double)first_lin_ms * n_lin;
-    if (c->h_lm.accepted && c->h_lm.stop) c->linearized = false;   // the reference re-linearises here; nobody reads it
+    if (!classic || (c->h_lm.accepted && c->h_lm.stop)) c->linearized = false;   // the reference re-linearises here; nobody reads it
+    c->natural_hs_valid = c->natural_hs_valid && c->linearized;
     r.iterations = c->h_lm.iter; r.trials = c->h_lm.trials; r.accepted = c->h_lm.naccepted;
     r.stop_reason = c->h_lm.stop_reason;
     r.final_chi2 = c->h_lm.chi; r.final_lambda = c->h_lm.lambda;
@@ -1448,22 +1491,40 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
     HIPCHK(c->d_batch_tabs.resize((size_t)count));
     HIPCHK(hipMemcpyAsync(c->d_batch_tabs.p, tabs.data(), (size_t)count * sizeof(DeviceTables), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    // the windows still running: a window that has stopped leaves the launches (its workgroups would each hold a CU for the
+    // round trip that tells them so), the array on the device is rewritten with the ones that go on
+    std::vector<int> live((size_t)count);
+    for (int i = 0; i < count; ++i) live[i] = i;
     auto read_all = [&]() -> vio_status {
-        for (int i = 0; i < count; ++i) HIPCHK(hipMemcpyAsync(&ctxs[i]->h_lm, ctxs[i]->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+        for (int i : live) HIPCHK(hipMemcpyAsync(&ctxs[i]->h_lm, ctxs[i]->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         return VIO_OK;
     };
+    static const bool classic = std::getenv("VIO_LM_CLASSIC") != nullptr;
     vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, 0, iterations, c->stream);
+    if (!classic && iterations > 0) vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, 3, iterations, c->stream);
     HIPCHK(hipGetLastError());
-    VIOCHK(read_all());
+    if (classic || iterations <= 0) VIOCHK(read_all());
+    else for (int i = 0; i < count; ++i) { ctxs[i]->h_lm.stop = 0; ctxs[i]->h_lm.iter = 0; }
     for (;;) {
         int left = 0;           // slots the slowest window may still need
         for (int i = 0; i < count; ++i)
             if (!ctxs[i]->h_lm.stop && ctxs[i]->h_lm.iter < iterations) left = std::max(left, iterations - ctxs[i]->h_lm.iter);
         if (left == 0) break;
+        {
+            std::vector<int> keep;
+            for (int i : live) if (!ctxs[i]->h_lm.stop && ctxs[i]->h_lm.iter < iterations) keep.push_back(i);
+            if (keep.size() != live.size()) {
+                std::vector<DeviceTables> sub;
+                for (int i : keep) sub.push_back(tabs[i]);
+                HIPCHK(hipMemcpyAsync(c->d_batch_tabs.p, sub.data(), sub.size() * sizeof(DeviceTables), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));           // `sub` goes out of scope
+                live.swap(keep);
+            }
+        }
         const int batch = std::min(left, 10);
         for (int sl = 0; sl < batch; ++sl)
-            vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, 1, iterations, c->stream);
+            vio_launch_batch_lm(c->d_batch_tabs.p, (int)live.size(), c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, classic ? 1 : 2, iterations, c->stream);
         HIPCHK(hipGetLastError());
         VIOCHK(read_all());
     }
@@ -1473,7 +1534,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         vio_ctx *m = ctxs[i];
         m->ahead = 7u;
         m->decide_pending = false;
-        m->linearized = !(m->h_lm.accepted && m->h_lm.stop);
+        m->linearized = classic && !(m->h_lm.accepted && m->h_lm.stop);
         m->natural_hs_valid = false;
         m->stepwise_updated = false;
         finite = finite && m->h_lm.finite;

@@ -47,7 +47,20 @@ __device__ __forceinline__ unsigned d_hwreg_hwid() { unsigned x; asm volatile("s
 #endif
 
 // which copy of the double-buffered state is current: the host's hint when it tracks it (GN mode), else LmState
-__device__ __forceinline__ int d_cur(const DeviceTables &T) { return T.cur_hint >= 0 ? T.cur_hint : T.lm->cur; }
+__device__ __forceinline__ int d_cur(const DeviceTables &T) {
+    if (T.cur_hint >= 0) return T.cur_hint;
+    return T.cur_hint == -2 ? (T.lm->cur ^ T.lm->pending) : T.lm->cur;
+}
+// vio_solve's loop keeps two sets of what a linearisation leaves for later launches (the landmark rows lw, the permuted system
+// Pg / perm, b_ of the pose block): the set a launch reads — the system the pending step came from — and the one it writes
+__device__ __forceinline__ int d_set_r(const DeviceTables &T) { return T.cur_hint == -2 ? T.lm->sys : 0; }
+__device__ __forceinline__ int d_set_w(const DeviceTables &T) { return T.cur_hint == -2 ? (T.lm->sys ^ T.lm->pending) : 0; }
+#define PS_SET_STRIDE (66 * 272 + 192)      // PS_PACKED (defined with k_pose_solve)
+// bit 0 / bit 1 of gn_flags ("the previous step waits for its test / its landmark back-substitution"): in vio_solve's loop
+// (cur_hint -2) the host sets them on every slot and the device knows whether there is such a step
+__device__ __forceinline__ bool d_step_owed(const DeviceTables &T, int bit) {
+    return (T.gn_flags & bit) && (T.cur_hint != -2 || T.lm->pending != 0);
+}
 
 // Device-driven LM loop (vio_solve): the host enqueues whole iterations ahead; a kernel whose turn has not come
 // (the loop has stopped, or the last trial was rejected and there is nothing to re-linearise) returns at once.
@@ -396,7 +409,8 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     if (d_gated_off(T.lm, T.lm_gate)) return;
     // GN mode (gn_flags bit 1) with a prior: the previous step also owes b_prior' = b_prior - H_prior dx (problem.cc:473).
     // Row r belongs to workgroup r mod grid, to its last wave: idle in phase 1 of a landmark item, first thing in an IMU item.
-    const bool owe_prior = (T.gn_flags & 2) && T.has_prior;
+    const bool owe = d_step_owed(T, 2);
+    const bool owe_prior = owe && T.has_prior;
     if (b >= T.n_items) {
         STAMP(T, 0);
         if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
@@ -407,6 +421,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     }
     __shared__ ItemDesc sIt;        // kept in LDS: its small arrays are indexed at run time
     const int cur = d_cur(T);      // requested together with the descriptor: both are cold after the kernel boundary
+    const int64_t lw_r = d_set_r(T) * T.lw_set, lw_w = d_set_w(T) * T.lw_set;
     if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
     __syncthreads();
     const ItemDesc &it = sIt;
@@ -434,7 +449,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     double pf_lam = 1.0, pf_x = 0.0, pf_y = 0.0, pf_u = 0.0, pf_v = 0.0;
     if (tid < G * K) {
         const int k0 = tid / G, g0 = tid - k0 * G;
-        if (!(T.gn_flags & 2)) pf_lam = invd[g0];
+        if (!owe) pf_lam = invd[g0];
         pf_x = pts_i[2 * g0]; pf_y = pts_i[2 * g0 + 1]; pf_u = pts_j[2 * tid]; pf_v = pts_j[2 * tid + 1];
     }
     // the pair table entries of this item, requested now, stored after the landmark update below has used their place
@@ -451,9 +466,8 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     // phase 1; the landmark part of the gain-ratio denominator goes to the record for the combine phase.
     // The item's rows ((6 nb + 2) x G doubles) and the pose update come in as one coalesced copy by the whole workgroup —
     // one round trip instead of one per pattern block — into LDS that phase 1 only needs later (sAux, sPair).
-    const bool owe = (T.gn_flags & 2) != 0;
     if (owe) {
-        const double *lw = T.lw + it.lw_base;
+        const double *lw = T.lw + lw_r + it.lw_base;
         const int nlw = (6 * nb + 2) * G;                  // <= 7 * LIN_THREADS: nb <= 12, G <= 86
         double *sStage = sAux, *sDxS = sPair;
         double stv[7];
@@ -848,7 +862,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
             T.invd[(size_t)cur * T.Ns + li] = L[12 * nb + 3];
         }
         // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
-        double *lw = T.lw + it.lw_base;
+        double *lw = T.lw + lw_w + it.lw_base;
         for (int e = tid; e < (6 * nb + 2) * G; e += LIN_THREADS) {
             const int r = e / G, g = e - r * G;
             const double *L = sL + (size_t)g * LREC;
@@ -872,7 +886,7 @@ struct BatchArgs {
 __device__ __forceinline__ DeviceTables d_batch_tables(const BatchArgs &a) {
     DeviceTables T = a.tabs[blockIdx.y];
     T.gn_flags = a.gn_flags;
-    if (a.parity < 0) T.cur_hint = -1; else T.cur_hint ^= a.parity;
+    if (a.parity < 0) T.cur_hint = a.parity; else T.cur_hint ^= a.parity;
     T.lm_gate = a.gate;
     return T;
 }
@@ -900,6 +914,8 @@ struct ReduceTables {
     const double *jtinv;         // GN mode with a prior: err_prior of the previous step is formed here (blocks >= 91), or null
     const double *bprior;        // b_prior after that step
     double *errprior;
+    int32_t lm_loop;             // 1 (vio_solve's loop): step_part / jtinv count only while lm->pending; bprior / errprior are the bases of
+                                 // the two copies and the step's copy is lm->cur ^ 1
 };
 
 #define RED_THREADS 1024
@@ -928,9 +944,11 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
     __shared__ double sV[56 * 18 + 8];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (d_gated_off(R.lm, R.gate)) return;
+    const bool step_owed = !R.lm_loop || R.lm->pending != 0;
     if (b >= VIO_NPAIR + VIO_NCB + 1) {          // GN mode: err_prior of the step k_pose_solve took (it left b_prior' only)
         const int row = (b - (VIO_NPAIR + VIO_NCB + 1)) * (RED_THREADS / 64) + (tid >> 6);
-        if (row < VIO_PRD) d_errprior_row(R.jtinv, R.bprior, R.errprior, row, tid & 63);
+        const int copy = R.lm_loop ? (R.lm->cur ^ 1) : 0;
+        if (row < VIO_PRD && step_owed) d_errprior_row(R.jtinv, R.bprior + copy * 176, R.errprior + copy * 160, row, tid & 63);
         return;
     }
     const int lo = R.list_off[b], hi = R.list_off[b + 1];
@@ -1023,7 +1041,7 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
             __syncthreads();
         }
         if (tid == 0) { R.vis[VIS_CHI] = sC[0]; R.vis[VIS_MAXH] = sM[0]; R.vis[VIS_STEP] = 0.0; if (!R.step_part) R.vis[VIS_STEP + 1] = 0.0; }
-        if (R.step_part) {      // landmark part of the previous step's gain-ratio denominator: summed here so that it is in the
+        if (R.step_part && step_owed) {      // landmark part of the previous step's gain-ratio denominator: summed here so that it is in the
             double sc = 0.0;    // exchange buffer when the shards all-reduce it (fixed order: strided partials, then the tree)
             for (int e = tid; e < R.n_step; e += RED_THREADS) sc += R.step_part[2 * e + STEP_SCALE];
             __syncthreads();
@@ -1043,9 +1061,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_b(BatchArgs a) {
     const DeviceTables T = d_batch_tables(a);
     const bool test_prev = (a.gn_flags & 1) != 0, err_prev = test_prev && T.has_prior;
     if ((int)blockIdx.x >= VIO_NPAIR + VIO_NCB + 1 && !err_prev) return;
-    const int cur = T.cur_hint;
+    const int loop = T.cur_hint == -2, cur = loop ? 0 : T.cur_hint;
     ReduceTables R{T.list_off, T.list, T.slab, T.vis, test_prev ? T.step_part : nullptr, T.n_items, a.gate, T.lm,
-                   err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + cur * 176 : nullptr, err_prev ? T.errprior + cur * 160 : nullptr};
+                   err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + cur * 176 : nullptr, err_prev ? T.errprior + cur * 160 : nullptr, loop};
     d_reduce_body(R);
 }
 
@@ -1068,6 +1086,7 @@ __device__ __forceinline__ int imu_vblock(int a) { return a < 6 ? 0 : (a < 15 ? 
 #define PS_TILES (PS_NT * (PS_NT + 1) / 2)
 #define PS_YOFF (PS_TILES * PS_TS)
 #define PS_PACKED (PS_YOFF + 192)
+static_assert(PS_SET_STRIDE == PS_PACKED, "stride between the two sets of Pg");
 __device__ __forceinline__ int tix(int I, int J) { return (I * (I + 1) / 2 + J) * PS_TS; }
 // element (r, c) with c's block <= r's block (for a diagonal tile both halves exist)
 __device__ __forceinline__ int telem(int r, int c) { return tix(r >> 4, c >> 4) + (r & 15) * PS_TROW + (c & 15); }
@@ -1102,7 +1121,7 @@ __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int
 
 // Row i of the right-hand sides: b_pp_schur_ (returned and stored in T.bs), the pose part of b_ (T.bfull, for the
 // gain ratio) and diag(Hessian_) before the Schur complement (T.diagfull, for ComputeLambdaInitLM, problem.cc:511-516)
-__device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid, int i, int cur) {
+__device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid, int i, int cur, int wset) {
     const int ci = full_to_cam(i);
     const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
     double bred = 0.0, bdir = 0.0, dv, dr;
@@ -1120,7 +1139,7 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid
     }
     if (T.has_prior && !mask_i) extra += T.bprior[cur * 176 + i];
     T.bs[i] = bred + extra;
-    T.bfull[i] = bdir + extra;
+    T.bfull[wset * 176 + i] = bdir + extra;
     d_hs_entry(T, valid, i, i, dv, dr);
     T.diagfull[i] = ((ci >= 0) ? T.vis[VIS_DIAG + ci] : 0.0) + dr;
     return bred + extra;
@@ -1169,11 +1188,14 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
     // loads are issued where they are used.  Everything it reads that does not depend on the ranks is requested here, before
     // the diagonal: the previous step's dx / b_ / err_prior, the scalars of the test, the terms of the right-hand sides.
     const bool last_wg = b == PS_NP;
-    const bool test_prev = last_wg && (T.gn_flags & 1);
+    const bool test_prev = last_wg && d_step_owed(T, 1);
+    const int rset = d_set_r(T), wset = d_set_w(T);
+    double *Pg = T.Pg + wset * PS_SET_STRIDE;
+    int32_t *perm_w = T.perm + wset * 176;
     double p_dx = 0.0, p_bf = 0.0, p_er = 0.0, p_lambda = 0.0, p_chi = 0.0, p_step = 0.0, p_lmchi = 0.0, p_imu[10], rhs_v = 0.0;
     if (test_prev) {
         p_lambda = T.lm->lambda;
-        if (t < VIO_PD) { p_dx = T.dx[t]; p_bf = T.bfull[t]; }          // b_ of the previous linearisation: read before d_rhs_entries replaces it
+        if (t < VIO_PD) { p_dx = T.dx[t]; p_bf = T.bfull[rset * 176 + t]; }          // b_ of the previous linearisation: read before d_rhs_entries replaces it
         if (T.has_prior && t < VIO_PRD) p_er = T.errprior[cur * 160 + t];
         if (t == 0) {
             p_chi = T.vis[VIS_CHI]; p_step = T.vis[VIS_STEP + 1]; p_lmchi = T.lm->chi;
@@ -1187,8 +1209,8 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
             if (b < VIO_PD) d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
             row_e = wv + wr;
             my_rank = T.rank[t];
-            sPerm[t] = T.perm[t];
-            if (last_wg) rhs_v = d_rhs_entries(T, valid, t, cur);
+            sPerm[t] = perm_w[t];
+            if (last_wg) rhs_v = d_rhs_entries(T, valid, t, cur, wset);
         }
         if (b < VIO_PD) row_rank = T.rank[b];
         __syncthreads();
@@ -1200,7 +1222,7 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
             if (b < VIO_PD) d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
             sDg[t] = d_rank_key(vv + vr);
             row_e = wv + wr;
-            if (last_wg) rhs_v = d_rhs_entries(T, valid, t, cur);
+            if (last_wg) rhs_v = d_rhs_entries(T, valid, t, cur, wset);
         }
         __syncthreads();
         d_rank_sort(sDg, sCnt, t);
@@ -1212,8 +1234,8 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
             if (T.natural_hs) T.Hs[b * VIO_PD + t] = row_e;      // natural-order H_pp_schur_: only the getters and Marginalize read it
             const int i = row_rank, j = my_rank;
             if (j <= i) {                       // entry (i, j) of the permuted, tiled triangle
-                T.Pg[telem(i, j)] = row_e;
-                if (j < i && (j >> 4) == (i >> 4)) T.Pg[telem(j, i)] = row_e;      // upper half of a diagonal tile
+                Pg[telem(i, j)] = row_e;
+                if (j < i && (j >> 4) == (i >> 4)) Pg[telem(j, i)] = row_e;      // upper half of a diagonal tile
             }
         }
         return;
@@ -1222,8 +1244,8 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
     if (t >= 192) return;
     if (b < PS_NP) {
         if (t <= b) {
-            T.Pg[telem(b, t)] = (t == b) ? 1.0 : 0.0;
-            if (t < b && (t >> 4) == (b >> 4)) T.Pg[telem(t, b)] = 0.0;
+            Pg[telem(b, t)] = (t == b) ? 1.0 : 0.0;
+            if (t < b && (t >> 4) == (b >> 4)) Pg[telem(t, b)] = 0.0;
         }
     } else {
         // GN mode: the step test of the PREVIOUS iteration (IsGoodStepInLM's bookkeeping, always accepted).  The chi2 of
@@ -1237,9 +1259,9 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
         }
         if (t < VIO_PD) {
             sDg[t] = rhs_v;
-            if (!RANKS_GIVEN) T.perm[t] = sPerm[t];
+            if (!RANKS_GIVEN) perm_w[t] = sPerm[t];
         }
-        if (T.gn_flags & 1) {
+        if (test_prev) {
             __shared__ double sSum[8];
             d_block_sum2<192>(sp, e2, sSum, t);
             if (t == 0) {
@@ -1252,20 +1274,24 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
                 const double tempChi = 0.5 * total;
                 const double scale = 0.5 * (p_step + sp) + 1e-6;
                 lm->chi_try = tempChi;
-                lm->rho = (p_lmchi - tempChi) / scale;
                 lm->scale = scale;
-                lm->trials += 1;
-                lm->chi = tempChi;
-                lm->cur = cur;
-                lm->accepted = 1;
-                lm->naccepted += 1;
-                lm->need_linearize = 1;
-                lm->false_cnt = 0;
-                if (!isfinite(tempChi)) lm->finite = 0;
+                // vio_solve's loop: IsGoodStepInLM's verdict on these two numbers is k_pose_solve's first act (other workgroups
+                // of this kernel are still reading lm->cur)
+                if (T.cur_hint != -2) {
+                    lm->rho = (p_lmchi - tempChi) / scale;
+                    lm->trials += 1;
+                    lm->chi = tempChi;
+                    lm->cur = cur;
+                    lm->accepted = 1;
+                    lm->naccepted += 1;
+                    lm->need_linearize = 1;
+                    lm->false_cnt = 0;
+                    if (!isfinite(tempChi)) lm->finite = 0;
+                }
             }
         }
         __syncthreads();                        // the 192 remaining threads, all of them
-        if (t < PS_NP) T.Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
+        if (t < PS_NP) Pg[PS_YOFF + t] = (t < VIO_PD) ? sDg[sPerm[t]] : 0.0;
     }
 }
 __global__ __launch_bounds__(ASM_THREADS) void k_assemble(DeviceTables T) { d_assemble_body<false>(T); }
@@ -1279,7 +1305,7 @@ __global__ __launch_bounds__(ASM_THREADS) void k_rank_b(BatchArgs a) {
     if (t < VIO_PD) { double vv, vr; d_hs_entry(T, d_imu_mask(T), t, t, vv, vr); sDg[t] = d_rank_key(vv + vr); }
     __syncthreads();
     d_rank_sort(sDg, sCnt, t);
-    if (t < VIO_PD) { const int r = d_rank_of(sCnt, t); T.rank[t] = r; T.perm[r] = t; }
+    if (t < VIO_PD) { const int r = d_rank_of(sCnt, t); T.rank[t] = r; T.perm[d_set_w(T) * 176 + r] = t; }
 }
 __global__ __launch_bounds__(192) void k_assemble_b(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_assemble_body<true>(T); }
 
@@ -1376,6 +1402,62 @@ __device__ __noinline__ void ps_factor_diag(lds_double *tile, lds_double *sI, ld
 }
 
 
+// The scalars of LmState a step test touches, as a value: k_pose_solve runs the test while its other waves may still be reading
+// LmState (the gate, the set to copy), so it works on this copy and stores it once they are all past that.
+struct LmRegs {
+    double lambda, chi, ni, last_chi, rho, scale;
+    int32_t cur, accepted, stop, iter, false_cnt, trials, naccepted, need_linearize, finite, max_iter, stop_reason;
+};
+__device__ __forceinline__ void d_lm_load(const LmState *lm, LmRegs &r) {
+    r.lambda = lm->lambda; r.chi = lm->chi; r.ni = lm->ni; r.last_chi = lm->last_chi; r.rho = lm->rho; r.scale = lm->scale;
+    r.cur = lm->cur; r.accepted = lm->accepted; r.stop = lm->stop; r.iter = lm->iter; r.false_cnt = lm->false_cnt; r.trials = lm->trials;
+    r.naccepted = lm->naccepted; r.need_linearize = lm->need_linearize; r.finite = lm->finite; r.max_iter = lm->max_iter; r.stop_reason = lm->stop_reason;
+}
+__device__ __forceinline__ void d_lm_store(LmState *lm, const LmRegs &r) {
+    lm->lambda = r.lambda; lm->chi = r.chi; lm->ni = r.ni; lm->last_chi = r.last_chi; lm->rho = r.rho; lm->scale = r.scale;
+    lm->cur = r.cur; lm->accepted = r.accepted; lm->stop = r.stop; lm->iter = r.iter; lm->false_cnt = r.false_cnt; lm->trials = r.trials;
+    lm->naccepted = r.naccepted; lm->need_linearize = r.need_linearize; lm->finite = r.finite; lm->stop_reason = r.stop_reason;
+}
+// IsGoodStepInLM's verdict on a trial state's chi2 (problem.cc:541-573) and Problem::Solve's bookkeeping around it (:169-250).
+// `cur` is the accepted copy the step started from.  mode 0: LM; 1: always accept, no damping update (a flushed GN step).
+// (the traces go straight to `trace`: nobody but the host reads them)
+__device__ void d_lm_verdict(LmRegs &lm, LmState *trace, int mode, double tempChi, double scale, int cur) {
+    const double rho = (lm.chi - tempChi) / scale;
+    lm.rho = rho; lm.scale = scale;
+    lm.trials += 1;
+    const bool finite = isfinite(tempChi);
+    if (mode == 1 || (rho > 0 && finite)) {
+        if (mode == 0) {
+            double alpha = 1. - pow((2 * rho - 1), 3);
+            alpha = fmin(alpha, 2. / 3.);
+            const double scaleFactor = fmax(1. / 3., alpha);
+            lm.lambda *= scaleFactor;
+            lm.ni = 2;
+        }
+        lm.chi = tempChi;
+        lm.cur = cur ^ 1;
+        lm.accepted = 1;
+        lm.naccepted += 1;
+        lm.need_linearize = 1;
+        lm.false_cnt = 0;
+    } else {
+        lm.lambda *= lm.ni;
+        lm.ni *= 2;
+        lm.accepted = 0;
+        lm.need_linearize = 0;
+        lm.false_cnt += 1;
+    }
+    if (!finite) lm.finite = 0;
+    if (mode == 0 && (lm.accepted || lm.false_cnt >= 10)) {     // the inner while of Problem::Solve ends
+        lm.iter += 1;
+        lm.false_cnt = 0;
+        if (lm.last_chi - lm.chi < 1e-5) { lm.stop = 1; lm.stop_reason = 1; }
+        lm.last_chi = lm.chi;
+        if (lm.iter >= lm.max_iter) lm.stop = 1;
+        if (!lm.stop && lm.iter < 128) { trace->chi_trace[lm.iter] = lm.chi; trace->lambda_trace[lm.iter] = lm.lambda; }
+    }
+}
+
 __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
     double *P = dyn_smem;                          // 66 tiles of 16x17, then the rhs row (192)
     double *sY = P + PS_YOFF;
@@ -1392,9 +1474,13 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
     const int wave = tid >> 6, lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(wave);
     LmState *lm = T.lm;
+    __shared__ LmRegs sLm;
     if (d_gated_off(lm, T.lm_gate)) return;
-    const int cur = d_cur(T), trial = cur ^ 1;
-    const double lambda = lm->lambda;
+    // vio_solve's loop (cur_hint -2): this kernel opens with the verdict on the step the previous one took — k_assemble has
+    // just put the chi2 of its trial state and the gain ratio's denominator into LmState — by thread 0, under the copy below.
+    const bool lm_loop = T.cur_hint == -2;
+    int cur = lm_loop ? 0 : d_cur(T);
+    double lambda = lm_loop ? 0.0 : lm->lambda;
     const int n = PS_N, NP = PS_NP;
 #ifdef VIO_STAMPS
     unsigned long long t_panel = 0, t_trail = 0, t_mark = 0, t_start = __builtin_amdgcn_s_memtime();
@@ -1412,28 +1498,65 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
     // Fast path: the permuted tiles k_assemble wrote (pivot order fixed with lambda = 0) are valid as long as
     // |diag + lambda| is still non-increasing along the diagonal — always the case for lambda >= 0 on a
     // non-negative diagonal.  Coalesced 16-byte loads; lambda goes on the 171 real pivots.
-    {
-        const double2 *src = reinterpret_cast<const double2 *>(T.Pg);
+    // In vio_solve's loop the copy starts from the set k_assemble has just written (the system at the trial state: the one to
+    // solve if the step is accepted); a rejected step solves the other set — the system it came from — again, copied in then.
+    int set = lm_loop ? (lm->sys ^ lm->pending) : 0;
+    bool rejected = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double2 *src = reinterpret_cast<const double2 *>(T.Pg + set * PS_SET_STRIDE);
         double2 *dst = reinterpret_cast<double2 *>(P);
         // 9 loads per thread, all in flight before the first store (named scalars: a local array ends up in scratch)
         static_assert((PS_PACKED / 2 + PS_THREADS - 1) / PS_THREADS == 9, "copy below is written for 9 rounds");
 #define PS_LD(q) const double2 v##q = src[min(tid + q * PS_THREADS, PS_PACKED / 2 - 1)];
 #define PS_ST(q) dst[min(tid + q * PS_THREADS, PS_PACKED / 2 - 1)] = v##q;          /* clamped lanes rewrite the last pair */
         PS_LD(0) PS_LD(1) PS_LD(2) PS_LD(3) PS_LD(4) PS_LD(5) PS_LD(6) PS_LD(7) PS_LD(8)
-        const int pm = (tid < n) ? T.perm[tid] : 0;
-        const double stv = (tid < STATE_STRIDE) ? T.state[cur * STATE_STRIDE + tid] : 0.0;    // for the update at the end
-        PS_ST(0) PS_ST(1) PS_ST(2) PS_ST(3) PS_ST(4) PS_ST(5) PS_ST(6) PS_ST(7) PS_ST(8)
+        const int pm = (tid < n) ? T.perm[set * 176 + tid] : 0;
+        if (pass == 0) {
+            // the states, for the update at the end (which copy is current is known after the verdict: both are requested)
+            double stv = (tid < STATE_STRIDE) ? T.state[cur * STATE_STRIDE + tid] : 0.0;
+            const double stv1 = (lm_loop && tid < STATE_STRIDE) ? T.state[STATE_STRIDE + tid] : 0.0;
+            if (lm_loop && tid == 0) {
+                int go = 1, rej = 0, sys = lm->sys;
+                d_lm_load(lm, sLm);
+                if (lm->pending) {
+                    d_lm_verdict(sLm, lm, 0, lm->chi_try, lm->scale, sLm.cur);
+                    if (sLm.accepted) sys ^= 1; else rej = 1;
+                    go = !sLm.stop;
+                }
+                sX[0] = go ? 1.0 : 0.0; sX[1] = (double)sLm.cur; sX[2] = sLm.lambda; sX[3] = (double)sys; sX[4] = (double)rej;
+            }
+            PS_ST(0) PS_ST(1) PS_ST(2) PS_ST(3) PS_ST(4) PS_ST(5) PS_ST(6) PS_ST(7) PS_ST(8)
+            if (tid < n) sPerm[tid] = pm;
+            if (tid < PS_TS) sI[tid] = (tid / PS_TROW == tid % PS_TROW) ? 1.0 : 0.0;
+            __syncthreads();
+            int set_now = 0;
+            if (lm_loop) {
+                // every wave is past the gate and has its copy's addresses: LmState may change now
+                if (tid == 0) { d_lm_store(lm, sLm); lm->sys = (int)sX[3]; lm->pending = sX[0] != 0.0 ? 1 : 0; }
+                if (sX[0] == 0.0) return;
+                cur = (int)sX[1]; lambda = sX[2]; set_now = (int)sX[3]; rejected = sX[4] != 0.0;
+                if (cur) stv = stv1;
+            }
+            if (tid < STATE_STRIDE) sState[tid] = stv;
+            if (set_now == set) break;
+            set = set_now;
+            __syncthreads();        // (sX is read by everybody before the second copy's barrier lets anyone go on)
+        } else {
+            PS_ST(0) PS_ST(1) PS_ST(2) PS_ST(3) PS_ST(4) PS_ST(5) PS_ST(6) PS_ST(7) PS_ST(8)
+            if (tid < n) sPerm[tid] = pm;
+            __syncthreads();
+        }
 #undef PS_LD
 #undef PS_ST
-        if (tid < n) sPerm[tid] = pm;
-        if (tid < STATE_STRIDE) sState[tid] = stv;
-        if (tid < PS_TS) sI[tid] = (tid / PS_TROW == tid % PS_TROW) ? 1.0 : 0.0;
     }
-    __syncthreads();
+    const int trial = cur ^ 1;
     int same = 1;
     for (int k = tid; k + 1 < n; k += PS_THREADS)
         same &= (fabs(P[telem(k, k)] + lambda) >= fabs(P[telem(k + 1, k + 1)] + lambda)) ? 1 : 0;
     same = __syncthreads_and(same);
+    // (the gather below reads the reduced system of the LAST linearisation: after a rejected step of vio_solve's loop that is the
+    // trial state's, not this one's.  No step then: the next slot linearises at the kept state again and solves from there.)
+    if (lm_loop && rejected && !same) { if (tid == 0) lm->pending = 0; return; }
     if (same) {
         for (int k = tid; k < n; k += PS_THREADS) P[telem(k, k)] += lambda;
     } else {
@@ -1951,40 +2074,10 @@ __device__ void d_lm_decide(const DeviceTables &T, int mode, int sum_local, doub
     if (mode == 2) return;
     double scale = 0.5 * ((sum_local ? s : T.step_tot[1]) + scale_p);
     scale += 1e-6;
-    const double rho = (lm->chi - tempChi) / scale;
-    lm->rho = rho; lm->scale = scale;
-    lm->trials += 1;
-    const bool finite = isfinite(tempChi);
-    if (mode == 1 || (rho > 0 && finite)) {
-        if (mode == 0) {
-            double alpha = 1. - pow((2 * rho - 1), 3);
-            alpha = fmin(alpha, 2. / 3.);
-            const double scaleFactor = fmax(1. / 3., alpha);
-            lm->lambda *= scaleFactor;
-            lm->ni = 2;
-        }
-        lm->chi = tempChi;
-        lm->cur = cur ^ 1;
-        lm->accepted = 1;
-        lm->naccepted += 1;
-        lm->need_linearize = 1;
-        lm->false_cnt = 0;
-    } else {
-        lm->lambda *= lm->ni;
-        lm->ni *= 2;
-        lm->accepted = 0;
-        lm->need_linearize = 0;
-        lm->false_cnt += 1;
-    }
-    if (!finite) lm->finite = 0;
-    if (mode == 0 && (lm->accepted || lm->false_cnt >= 10)) {     // the inner while of Problem::Solve ends
-        lm->iter += 1;
-        lm->false_cnt = 0;
-        if (lm->last_chi - lm->chi < 1e-5) { lm->stop = 1; lm->stop_reason = 1; }
-        lm->last_chi = lm->chi;
-        if (lm->iter >= lm->max_iter) lm->stop = 1;
-        if (!lm->stop && lm->iter < 128) { lm->chi_trace[lm->iter] = lm->chi; lm->lambda_trace[lm->iter] = lm->lambda; }
-    }
+    LmRegs regs;
+    d_lm_load(lm, regs);
+    d_lm_verdict(regs, lm, mode, tempChi, scale, cur);
+    d_lm_store(lm, regs);
 }
 
 __global__ __launch_bounds__(256) void k_lm_decide(DeviceTables T, int mode, int sum_local) {
@@ -2027,7 +2120,7 @@ __device__ __forceinline__ void d_init_lm_body(const DeviceTables &T, int max_it
     lm->lambda = 1e-5 * maxDiagonal;
     lm->last_chi = 1e20;
     lm->iter = 0; lm->false_cnt = 0; lm->trials = 0; lm->naccepted = 0; lm->stop = 0; lm->stop_reason = 0;
-    lm->finite = 1; lm->max_iter = max_iter; lm->accepted = 0; lm->need_linearize = 0;
+    lm->finite = 1; lm->max_iter = max_iter; lm->accepted = 0; lm->need_linearize = 0; lm->pending = 0; lm->sys = 0;
     lm->chi_trace[0] = chi; lm->lambda_trace[0] = lm->lambda;
 }
 __global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter, const double *maxh_src) { d_init_lm_body(T, max_iter, maxh_src); }
@@ -2178,6 +2271,22 @@ void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_bl
         linearize(0);
         BatchArgs a{tabs, 0, -1, 0};
         hipLaunchKernelGGL(k_init_lm_b, dim3(1, B), dim3(256), 0, s, a, max_iter);
+        return;
+    }
+    if (what >= 2) {
+        // vio_solve's loop, batched: what 3 = the first step (k_pose_solve alone); what 2 = one slot: linearise at the step's trial state
+        // (its landmark back-substitution first), sum, assemble (chi2 and gain-ratio terms of the step), then k_pose_solve: verdict, next step
+        BatchArgs a{tabs, 2, -2, 2};
+        if (what == 2) {
+            if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+            else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+            a.gn_flags = 1;
+            hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + (any_prior ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
+            hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
+            hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(192), 0, s, a);
+        }
+        a.gn_flags = 4;
+        hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
         return;
     }
     BatchArgs a{tabs, 4, -1, 2};

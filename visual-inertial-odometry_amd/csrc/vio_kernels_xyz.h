@@ -237,7 +237,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     const int b = blockIdx.x;
     if (d_gated_off(T.lm, T.lm_gate)) return;
     // GN mode (gn_flags bit 1), as in k_linearize: the previous step's b_prior' rows and landmark back-substitution come first
-    const bool owe = (T.gn_flags & 2) != 0, owe_prior = owe && T.has_prior;
+    const bool owe = d_step_owed(T, 2), owe_prior = owe && T.has_prior;
     if (b >= T.n_items) {
         if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
         d_imu_item(T, b - T.n_items, dyn_smem);
@@ -245,6 +245,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     }
     __shared__ ItemDesc sIt;
     const int cur = d_cur(T);
+    const int64_t lw_r = d_set_r(T) * T.lw_set, lw_w = d_set_w(T) * T.lw_set;
     if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
     __syncthreads();
     const ItemDesc &it = sIt;
@@ -294,7 +295,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
         double *sFrO = sAux + 3 * G * K, *sCamO = sFrO + 12 * K, *sDx = sCamO + 12;      // fits: xyz_lds_doubles
         const double *sto = T.state + (cur ^ 1) * STATE_STRIDE;
         const double *xyzo = T.invd + (size_t)(cur ^ 1) * 3 * T.Ns + it.lm_base;
-        const double *lw = T.lw + it.lw_base;
+        const double *lw = T.lw + lw_r + it.lw_base;
         double *sHb = sDx + 176;                           // 12 per landmark: H_ll (6), b_l (3), the old point
         for (int e = tid; e < 12 * G; e += LIN_THREADS) {
             const int q = e / G, g = e - q * G;
@@ -558,7 +559,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
             }
         }
         // H_ll (6 distinct entries) and b_l of the item's landmarks for the back-substitution
-        double *lw = T.lw + it.lw_base;
+        double *lw = T.lw + lw_w + it.lw_base;
         for (int e = tid; e < 9 * G; e += LIN_THREADS) {
             const int r = e / G, g = e - r * G;
             const double *Lg = sL + (size_t)g * LREC;

@@ -108,6 +108,8 @@ struct LmState {
     int32_t finite;
     int32_t max_iter;
     int32_t stop_reason;
+    int32_t pending;             // vio_solve's loop: a step has been taken (trial copy written) and waits for its test
+    int32_t sys;                 // vio_solve's loop: which set of (lw, Pg, perm, bfull) holds the system linearised at copy `cur`
     int32_t pad_;
     double chi_trace[128];
     double lambda_trace[128];
@@ -132,6 +134,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     double *pairtab;             // [2][PAIRTAB_STRIDE]
     double *slab;
     double *lw;
+    int64_t lw_set;              // doubles between the two sets of lw (vio_solve's loop linearises a trial state into the other set, so that a
+                                 // rejected step leaves the system it came from intact); Pg, perm and bfull have two sets too (fixed strides)
     double *vis;                 // [VIS_COUNT]
     const double *pre;           // [10][PRE_STRIDE] packed pre-integrations + information
     const int32_t *imu_valid;    // [10]
@@ -162,7 +166,9 @@ struct DeviceTables {            // everything a kernel needs, passed by value
                                  // computed); bit 1: k_linearize applies its landmark back-substitution first; bit 2 (k_pose_solve):
                                  // this step's prior update is left to the next k_linearize (b_prior') and k_reduce (err_prior');
                                  // bit 3 (k_backsub): flush of such a step, form b_prior' here
-    int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur
+    int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur;
+                                 // -2 (vio_solve's loop): the copy to linearise at is lm->cur ^ lm->pending, and bits 0 / 1 of gn_flags
+                                 // count only while lm->pending
     int32_t imu_mask;            // bit k: IMU edge k exists (the host's copy of imu_valid: saves the kernels a dependent load)
     int32_t lm_gate;             // device-driven LM loop: 0 run; 2: skip if lm->stop; 3: skip unless lm->need_linearize && !lm->stop
     const int32_t *list_off;     // k_reduce's inverted lists (a batched launch builds its ReduceTables from here)
