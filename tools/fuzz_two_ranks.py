@@ -38,6 +38,9 @@ def main():
             print("ok   case %d: %s n=%d ragged=%d seed=%d prior=%d" % (case, kind, n, ragged, seed, with_prior))
         except AssertionError as exc:
             bad += 1
+            import traceback
+            tb = traceback.extract_tb(exc.__traceback__)[-1]
+            print("     (%s:%d: %s)" % (os.path.basename(tb.filename), tb.lineno, (tb.line or "")[:160]))
             print("FAIL case %d: %s n=%d ragged=%d seed=%d prior=%d: %s" % (case, kind, n, ragged, seed, with_prior, str(exc).splitlines()[0][:200] if str(exc) else "assertion"))
     print("failures:", bad)
 
