@@ -202,6 +202,7 @@ struct vio_ctx {
     int g_min = 8;                             // lower end of the automatic choice (VIO_G_MIN overrides)
     int n_cus = 256;                           // CUs of the device (one k_linearize workgroup each)
     Plan solve_plan, marg_plan;
+    bool marg_map_valid = false;          // d_gather_map holds the marg plan's landmarks as positions in the solve plan (both plans as they are)
     Plan *active = nullptr;
     // device buffers independent of the topology
     DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
@@ -210,6 +211,8 @@ struct vio_ctx {
     DevBuf<double> d_Pg;
     DevBuf<LmState> d_lm;
     LmState h_lm;
+    LmState *h_lm_pin = nullptr;               // pinned landing place of LmState's read-back (the copy is then a DMA the host need not wait in)
+    hipEvent_t lm_event = nullptr;             // recorded behind that copy: read_lm_end waits for it, not for what was enqueued after it
     vio_exchange_fn hook = nullptr;
     void *comm = nullptr;                              // ncclComm_t of the native exchange (vio_comm_init)
     int cur_host = -1;                                 // LmState.cur as the host tracks it through GN iterations (-1: unknown)
@@ -399,6 +402,7 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
 }
 
 vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
+    c->marg_map_valid = false;
     if (c->lm_dim == 3) return build_plan_xyz(c, pl);
     pl.valid = false;
     pl.marg = marg; pl.lm_dim = 1;
@@ -691,12 +695,25 @@ DeviceTables make_tables(vio_ctx *c, Plan &pl) {
 }
 #define MAKE_TABLES(T, c, pl) DeviceTables T = make_tables((c), (pl)); VIOCHK((c)->flush_status)
 
-vio_status read_lm(vio_ctx *c) {
+// LmState's read-back in two halves: whatever the host enqueues between them (vio_solve: the uploads of the next call's plan)
+// runs behind the copy and is not waited for
+vio_status read_lm_begin(vio_ctx *c) {
     VIOCHK(flush_decide(c));
-    HIPCHK(hipMemcpyAsync(&c->h_lm, c->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->h_lm_pin) HIPCHK(hipHostMalloc((void **)&c->h_lm_pin, sizeof(LmState), hipHostMallocDefault));
+    if (!c->lm_event) HIPCHK(hipEventCreateWithFlags(&c->lm_event, hipEventDisableTiming));
+    HIPCHK(hipMemcpyAsync(c->h_lm_pin, c->d_lm.p, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->lm_event, c->stream));
+    return VIO_OK;
+}
+vio_status read_lm_end(vio_ctx *c) {
+    HIPCHK(hipEventSynchronize(c->lm_event));
+    c->h_lm = *c->h_lm_pin;
     c->cur_host = c->h_lm.cur;
     return VIO_OK;
+}
+vio_status read_lm(vio_ctx *c) {
+    VIOCHK(read_lm_begin(c));
+    return read_lm_end(c);
 }
 
 // bring the host mirrors up to date with the device (states, inverse depths, prior vectors)
@@ -989,6 +1006,27 @@ vio_status enqueue_lm_slot(vio_ctx *c, Plan &pl, bool first) {
     return VIO_OK;
 }
 
+// MargOldFrame straight after a solve (the frame loop): its plan (the landmarks hosted in frame 0) and their positions in the solve
+// plan depend on the graph only, not on the solve's result.  vio_solve calls this between enqueueing its slots and waiting for
+// them, so the host builds the next call's tables while the device is busy; vio_marginalize calls it again (a no-op then).
+vio_status prepare_marg_plan(vio_ctx *c) {
+    Plan &mp = c->marg_plan, &sp = c->solve_plan;
+    if (c->lm_dim != 1 || c->active != &sp || !sp.valid || c->topo_dirty) return VIO_OK;
+    if (mp.valid && c->marg_map_valid) return VIO_OK;
+    HIPCHK(c->arena.begin());
+    if (!mp.valid) VIOCHK(build_plan(c, mp, 1));
+    std::vector<int32_t> pos(c->h_invd.size(), -1);
+    for (int64_t q = 0; q < sp.Ns; ++q) pos[sp.sorted_to_orig[q]] = (int32_t)q;
+    int32_t *map = (int32_t *)c->arena.alloc((size_t)std::max<int64_t>(mp.Ns, 1) * 4);
+    if (!map) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+    for (int64_t q = 0; q < mp.Ns; ++q) map[q] = pos[mp.sorted_to_orig[q]];
+    HIPCHK(c->d_gather_map.resize((size_t)std::max<int64_t>(mp.Ns, 1)));
+    if (mp.Ns) HIPCHK(hipMemcpyAsync(c->d_gather_map.p, map, (size_t)mp.Ns * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c->arena.end(c->stream));
+    c->marg_map_valid = true;
+    return VIO_OK;
+}
+
 }  // namespace
 
 // =========================================================================================================
@@ -1071,6 +1109,8 @@ void vio_destroy(vio_ctx *c) {
     c->arena.release(c->own_stream);
     if (c->pull_stage) hipHostFree(c->pull_stage);
     if (c->marg_stage) hipHostFree(c->marg_stage);
+    if (c->h_lm_pin) hipHostFree(c->h_lm_pin);
+    if (c->lm_event) hipEventDestroy(c->lm_event);
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     (void)hipGetLastError();         // (an event of a borrowed stream that is gone may have complained: not the next caller's business)
@@ -1335,7 +1375,11 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
         while (status == VIO_OK && !stop) {
             const int batch = std::min(iterations - done, 10);
             for (int sl = 0; sl < batch && status == VIO_OK; ++sl) status = enqueue_lm_slot(c, pl, false);
-            if (status == VIO_OK) status = read_lm(c);
+            // host work under the device's; a failure here is vio_marginalize's to report (it tries again)
+            if (status == VIO_OK) status = read_lm_begin(c);
+            static const bool no_prepare = std::getenv("VIO_NO_MARG_PREPARE") != nullptr;      // diagnostic
+            if (status == VIO_OK && done == 0 && !sharded(c) && !no_prepare) (void)prepare_marg_plan(c);
+            if (status == VIO_OK) status = read_lm_end(c);
             done = c->h_lm.iter;
             stop = c->h_lm.stop || done >= iterations;
         }
@@ -1577,19 +1621,8 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
         if (resident) {
             Plan &mp = c->marg_plan, &sp = c->solve_plan;
             VIOCHK(flush_decide(c));
-            HIPCHK(c->arena.begin());
-            if (!mp.valid) VIOCHK(build_plan(c, mp, 1));
-            std::vector<int32_t> pos(c->h_invd.size(), -1);
-            for (int64_t q = 0; q < sp.Ns; ++q) pos[sp.sorted_to_orig[q]] = (int32_t)q;
-            int32_t *map = (int32_t *)c->arena.alloc((size_t)std::max<int64_t>(mp.Ns, 1) * 4);
-            if (!map) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
-            for (int64_t q = 0; q < mp.Ns; ++q) map[q] = pos[mp.sorted_to_orig[q]];
-            HIPCHK(c->d_gather_map.resize((size_t)std::max<int64_t>(mp.Ns, 1)));
-            if (mp.Ns) {
-                HIPCHK(hipMemcpyAsync(c->d_gather_map.p, map, (size_t)mp.Ns * 4, hipMemcpyHostToDevice, c->stream));
-                vio_launch_gather_landmarks(c->d_lm.p, sp.d_invd.p, (int)sp.Ns, mp.d_invd.p, (int)mp.Ns, c->d_gather_map.p, c->stream);
-            }
-            HIPCHK(c->arena.end(c->stream));
+            VIOCHK(prepare_marg_plan(c));             // (vio_solve has done this while the device was busy)
+            if (mp.Ns) vio_launch_gather_landmarks(c->d_lm.p, sp.d_invd.p, (int)sp.Ns, mp.d_invd.p, (int)mp.Ns, c->d_gather_map.p, c->stream);
             ++c->tables_gen;
             c->active = &mp;
             c->linearized = false;
