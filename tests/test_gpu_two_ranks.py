@@ -1,6 +1,6 @@
 """The N = 2 protocol of the HIP library with two REAL ranks: two processes, each with its own
 context and its own shard of the landmarks, both on the one GPU a test box has.  RCCL refuses two ranks on one device, so
-the exchange is the library's hook with the 43 KB staged through pinned host memory and all-reduced with gloo
+the exchange is the library's hook with the 24 KB staged through pinned host memory and all-reduced with gloo
 (`exchange="hook_host"`, visual-inertial-odometry_amd/sharded.py) — the kernels around it (k_reduce -> exchange ->
 k_assemble, k_step_sum -> exchange -> k_lm_decide, the deferred sums of the GN loop, the sharded MargOldFrame) are exactly
 the ones the RCCL path runs, and here the sums are not identities.

@@ -986,11 +986,7 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
             double tot = 0.0;
 #pragma unroll
             for (int q = 0; q < NS; ++q) tot += sV[q * W + tid];
-            int P = 0, rem = b;
-            while (rem >= VIO_NCB - P) { rem -= VIO_NCB - P; ++P; }
-            const int Q = P + rem, i = tid / 6, j = tid % 6;
-            R.vis[VIS_H + (6 * P + i) * VIO_CD + 6 * Q + j] = tot;
-            if (P != Q) R.vis[VIS_H + (6 * Q + j) * VIO_CD + 6 * P + i] = tot;
+            R.vis[VIS_H + b * 36 + tid] = tot;         // block b = VIS_PAIR(P, Q), entry (i, j) = tid: the mirror image is not stored
         }
     } else if (b < VIO_NPAIR + VIO_NCB) {
         constexpr int W = 18, NS = RED_THREADS / W;           // 56 slots
@@ -1100,7 +1096,11 @@ __device__ __forceinline__ double d_rank_key(double d) { const double a = fabs(d
 __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int i, int j, double &vv, double &vr) {
     vv = 0.0; vr = 0.0;                 // reduced visual part, IMU + prior part
     const int ci = full_to_cam(i), cj = full_to_cam(j);
-    if (ci >= 0 && cj >= 0) vv = T.vis[VIS_H + ci * VIO_CD + cj];
+    if (ci >= 0 && cj >= 0) {
+        int P = ci / 6, a = ci - 6 * P, Q = cj / 6, bq = cj - 6 * Q;
+        if (P > Q) { const int t0 = P; P = Q; Q = t0; const int t1 = a; a = bq; bq = t1; }
+        vv = T.vis[VIS_H + VIS_PAIR(P, Q) * 36 + a * 6 + bq];
+    }
     if (i >= 6 && j >= 6) {
         const int fi = (i - 6) / 15;
         for (int k = fi - 1; k <= fi; ++k) {

@@ -43,8 +43,10 @@
 #define CAMTAB_TIC 9
 #define PAIRTAB_STRIDE (121 * PAIR_STRIDE + 16)
 
-#define VIS_H 0                              // 72x72 row-major, both triangles
-#define VIS_BRED (VIO_CD * VIO_CD)           // reduced b (after landmark Schur), 72
+#define VIS_H 0                              // the 78 blocks (P <= Q) of the symmetric 72x72, 36 doubles each (row-major 6x6), in k_reduce's
+                                             // block order: pair (P, Q) at VIS_PAIR(P, Q) * 36 — half of what the shards exchange
+#define VIS_PAIR(P, Q) ((P) * VIO_NCB - (P) * ((P) - 1) / 2 + ((Q) - (P)))
+#define VIS_BRED (VIO_NPAIR * 36)            // reduced b (after landmark Schur), 72
 #define VIS_BDIR (VIS_BRED + VIO_CD)         // direct b (pose part of b_), 72
 #define VIS_DIAG (VIS_BDIR + VIO_CD)         // direct diagonal of Hpp (visual part), 72
 #define VIS_CHI (VIS_DIAG + VIO_CD)          // sum of RobustChi2 over reprojection edges

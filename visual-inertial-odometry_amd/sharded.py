@@ -2,7 +2,8 @@
 
 One process per GPU.  Every rank holds a block of the landmarks with all their observations; poses,
 speed-biases, extrinsic, pre-integrations and prior are replicated.  Per linearisation one all-reduce (sum) of the
-packed reduced visual system (72x72 H, reduced b, direct b, direct diagonal, chi2: 5401 fp64 = 43 KB) and per
+packed reduced visual system (the 78 upper blocks of the 72x72 H, reduced b, direct b, direct diagonal, chi2, the step's
+gain-ratio partial: 3027 fp64 = 24 KB; the library says how many, vio_exchange_buffers) and, on the stepwise path only, per
 trial step one all-reduce of two scalars (chi2 of the trial state, landmark part of the gain-ratio
 denominator); every rank then runs the identical damped LDLT and updates its own landmarks.  The collective is
 RCCL over xGMI on the GPU box: by default the library calls ncclAllReduce itself on its own stream (vio_comm_init; the
