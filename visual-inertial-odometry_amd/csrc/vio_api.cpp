@@ -1664,6 +1664,7 @@ vio_status vio_get_window(vio_ctx *c, double *poses, double *sb, double *ext) {
 
 vio_status vio_get_landmarks(vio_ctx *c, int64_t n, double *invd) {
     if (!c || c->lm_dim != 1 || n != (int64_t)c->h_invd.size() || (n > 0 && !invd)) return VIO_ERR_BAD_ARG;
+    enter_device(c);
     VIOCHK(pull_from_device(c, 2u));
     if (n) std::memcpy(invd, c->h_invd.data(), (size_t)n * 8);
     return VIO_OK;
@@ -1671,6 +1672,7 @@ vio_status vio_get_landmarks(vio_ctx *c, int64_t n, double *invd) {
 
 vio_status vio_get_landmarks_xyz(vio_ctx *c, int64_t n, double *xyz) {
     if (!c || c->lm_dim != 3 || 3 * n != (int64_t)c->h_invd.size() || (n > 0 && !xyz)) return VIO_ERR_BAD_ARG;
+    enter_device(c);
     VIOCHK(pull_from_device(c, 2u));
     if (n) std::memcpy(xyz, c->h_invd.data(), (size_t)n * 24);
     return VIO_OK;
@@ -1867,6 +1869,7 @@ vio_status vio_bind_exchange_buffers(vio_ctx *c, void *reduced, void *scalars) {
 // diagnostic build: copy out the s_memtime stamps of the last k_linearize launch ([block][16])
 vio_status vio_debug_stamps(vio_ctx *c, unsigned long long *out, int64_t n_blocks) {
     if (!c || !c->d_dbg.p) return VIO_ERR_BAD_ARG;
+    enter_device(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(out, c->d_dbg.p, (size_t)n_blocks * 16 * 8, hipMemcpyDeviceToHost));
     return VIO_OK;
@@ -1895,6 +1898,7 @@ vio_status vio_profile_begin(vio_ctx *c, int32_t which) {
 
 vio_status vio_profile_end(vio_ctx *c, double *total_ms, int64_t *launches) {
     if (!c) return VIO_ERR_BAD_ARG;
+    enter_device(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     double tot = 0;
     for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
