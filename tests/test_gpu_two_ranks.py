@@ -103,7 +103,7 @@ def test_two_hip_ranks_equal_the_unsharded_run(vio, hip_lib, tmp_path, kind, n, 
         assert abs(float(r["chi0"]) - chi0) <= 1e-12 * abs(chi0) and float(r["lam0"]) == lam0
         d = np.sqrt(np.abs(np.diag(Hs)) + 1e-300)
         assert (np.abs(r["Hs"] - Hs) / np.outer(d, d)).max() <= 1e-12
-        assert int(r["iterations"]) == rep.iterations and int(r["trials"]) == rep.trials
+        assert int(r["iterations"]) == rep.iterations and int(r["trials"]) == rep.trials, (int(r["iterations"]), rep.iterations, int(r["trials"]), rep.trials, float(r["final_chi2"]), rep.final_chi2)
         assert abs(float(r["final_chi2"]) - rep.final_chi2) <= 1e-7 * rep.final_chi2
         assert np.abs(r["poses"] - poses).max() <= 1e-7 and np.abs(r["sb"] - sbias).max() <= 1e-6
         assert np.abs(r["lms"] - lms).max() <= 1e-7

@@ -40,7 +40,7 @@ def main():
             bad += 1
             import traceback
             tb = traceback.extract_tb(exc.__traceback__)[-1]
-            print("     (%s:%d: %s)" % (os.path.basename(tb.filename), tb.lineno, (tb.line or "")[:160]))
+            print("     (%s:%d: %s)%s" % (os.path.basename(tb.filename), tb.lineno, (tb.line or "")[:160], ("  " + str(exc)[:200]) if str(exc) else ""))
             print("FAIL case %d: %s n=%d ragged=%d seed=%d prior=%d: %s" % (case, kind, n, ragged, seed, with_prior, str(exc).splitlines()[0][:200] if str(exc) else "assertion"))
     print("failures:", bad)
 
