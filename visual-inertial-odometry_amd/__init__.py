@@ -11,7 +11,7 @@ from .capi import (CAM_DIM, LOSS_CAUCHY, LOSS_HUBER, LOSS_TRIVIAL, LOSS_TUKEY, M
                    VioPreint, VioSolveReport)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(PKG_DIR, "csrc", "libvio_hip.so")
+HIP_LIB = os.environ.get("VIO_HIP_LIB") or os.path.join(PKG_DIR, "csrc", "libvio_hip.so")     # (VIO_HIP_LIB: another build, for A/B measurements)
 
 _hip = None
 

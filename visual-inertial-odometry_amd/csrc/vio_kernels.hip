@@ -83,45 +83,56 @@ __device__ __forceinline__ int full_to_cam(int i) {
 //   p_cj = C * p_ci + d   with C = ric^T Rt^T Rh ric,  d = ric^T (Rt^T (Rh tic + Ph - Pt) - tic)
 // (edge_reprojection.cc:35-40 evaluated once per pair instead of once per edge)
 // ---------------------------------------------------------------------------------------------------------
-__device__ void d_build_pairtab(const double *st, double *tab, double *sR, int tid, int nt) {
+// The table is built in two steps: the 12 rotation matrices (extrinsic, 11 poses) into sR, then — after a barrier — one task per
+// (pair, row): row r of A, B, C, El and d[r].  k_pose_solve spreads the 330 tasks over its 1024 threads after the last barrier of
+// its tail (one thread per pair on two waves before: 64.24 -> 63.87 us per GN iteration, tools/ab_gn_timing.py); k_prepare loops
+// over them with 128.  Every entry is the same sum whoever forms it.
+__device__ __forceinline__ void d_pair_rotations(const double *st, double *sR, int tid) {
     if (tid < 12) {
         const double *q = (tid == 0) ? st + STATE_EXT + 3 : st + STATE_POSE + 7 * (tid - 1) + 3;
         d_quat_to_R(q, sR + 9 * tid);
     }
-    __syncthreads();
+}
+__device__ __forceinline__ void d_pair_rows(const double *st, double *tab, const double *sR, int tid, int nt) {
     const double *ric = sR;
     const double *tic = st + STATE_EXT;
-    for (int pr = tid; pr < 121; pr += nt) {
+    for (int task = tid; task < 121 * 3; task += nt) {
+        const int pr = task / 3, r = task - 3 * pr;
         const int h = pr / 11, t = pr % 11;
         if (h == t) continue;
         const double *Rh = sR + 9 * (1 + h), *Rt = sR + 9 * (1 + t);
         const double *Ph = st + STATE_POSE + 7 * h, *Pt = st + STATE_POSE + 7 * t;
-        double M[9], A[9], B[9], C[9], u[3], w[3], d[3], RtRh[9], El[9];
-        d_m3_mul(Rt, ric, M);                   // A = ric^T Rt^T = (Rt ric)^T
+        const double c0 = ric[r], c1 = ric[3 + r], c2 = ric[6 + r];          // column r of ric
+        double Ar[3], Br[3], Cr[3], Elr[3], u[3], w[3], RtRh[9];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Ar[j] = Rt[3 * j] * c0 + Rt[3 * j + 1] * c1 + Rt[3 * j + 2] * c2;      // A = ric^T Rt^T = (Rt ric)^T
 #pragma unroll
-            for (int j = 0; j < 3; ++j) A[3 * i + j] = M[3 * j + i];
-        d_m3_mul(A, Rh, B);
-        d_m3_mul(B, ric, C);
+        for (int j = 0; j < 3; ++j) Br[j] = Ar[0] * Rh[j] + Ar[1] * Rh[3 + j] + Ar[2] * Rh[6 + j];         // B = A Rh
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Cr[j] = Br[0] * ric[j] + Br[1] * ric[3 + j] + Br[2] * ric[6 + j];      // C = B ric
         d_m3_vec(Rh, tic, u);
 #pragma unroll
         for (int k = 0; k < 3; ++k) u[k] = u[k] + Ph[k] - Pt[k];
         d_m3_tvec(Rt, u, w);
 #pragma unroll
         for (int k = 0; k < 3; ++k) w[k] -= tic[k];
-        d_m3_tvec(ric, w, d);
+        const double dr = c0 * w[0] + c1 * w[1] + c2 * w[2];                                               // d = ric^T (Rt^T (Rh tic + Ph - Pt) - tic)
         d_m3_tmul(Rt, Rh, RtRh);
         RtRh[0] -= 1; RtRh[4] -= 1; RtRh[8] -= 1;
-        d_m3_tmul(ric, RtRh, El);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Elr[j] = c0 * RtRh[j] + c1 * RtRh[3 + j] + c2 * RtRh[6 + j];           // El = ric^T (Rt^T Rh - I)
         double *o = tab + pr * PAIR_STRIDE;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { o[PAIR_A + k] = A[k]; o[PAIR_B + k] = B[k]; o[PAIR_C + k] = C[k]; o[PAIR_EL + k] = El[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) o[PAIR_D + k] = d[k];
+        for (int j = 0; j < 3; ++j) { o[PAIR_A + 3 * r + j] = Ar[j]; o[PAIR_B + 3 * r + j] = Br[j]; o[PAIR_C + 3 * r + j] = Cr[j]; o[PAIR_EL + 3 * r + j] = Elr[j]; }
+        o[PAIR_D + r] = dr;
     }
     if (tid < 9) tab[121 * PAIR_STRIDE + CAMTAB_RIC + tid] = ric[tid];
     if (tid < 3) tab[121 * PAIR_STRIDE + CAMTAB_TIC + tid] = tic[tid];
+}
+__device__ void d_build_pairtab(const double *st, double *tab, double *sR, int tid, int nt) {
+    d_pair_rotations(st, sR, tid);
+    __syncthreads();
+    d_pair_rows(st, tab, sR, tid, nt);
 }
 
 __global__ __launch_bounds__(128) void k_prepare(DeviceTables T) {
@@ -1845,8 +1856,10 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
         }
         __syncthreads();
         // (XYZ windows have no host frames: k_linearize_xyz composes its camera maps from the states)
-        if (T.lm_dim == 3) __syncthreads();
-        else d_build_pairtab(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, 128);  // one more barrier inside
+        // the pair table of the trial states: the rotation matrices here, its rows after this barrier, by all the waves
+        // (XYZ windows have no host frames: k_linearize_xyz composes its camera maps from the states)
+        if (T.lm_dim != 3) d_pair_rotations(sState, sR, tid);
+        __syncthreads();
     } else {
         if (prior_here) {
             double hp[PS_PRIOR_ROWS][3], bp[PS_PRIOR_ROWS];
@@ -1892,6 +1905,7 @@ __device__ __forceinline__ void d_pose_solve_body(const DeviceTables &T) {
             }
         }
     }
+    if (T.lm_dim != 3) d_pair_rows(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, PS_THREADS);
     // dx and the trial states, from LDS (both final since the barriers above; the waves that did not write them read them
     // after those barriers)
     if (tid >= 192 && tid < 192 + n) T.dx[tid - 192] = sDx[tid - 192];
