@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-O=gpurun_out/r02m
+O=gpurun_out/r02r
 mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-per-frame > $O/bench_under_rocprof.log 2>$O/err1.log
 rocprofv3 --kernel-trace --stats -d $O/stats_xyz -o s -- python3 bench.py --landmark-type xyz --steps 200 --warmup 20 --no-cpu-baseline --no-per-frame > $O/bench_xyz_under_rocprof.log 2>$O/err2.log
