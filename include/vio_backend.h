@@ -236,7 +236,9 @@ vio_status vio_get_landmarks(struct vio_ctx *ctx, int64_t n, double *inv_depth);
 vio_status vio_get_prior(struct vio_ctx *ctx, double *b, double *err);
 /* delta_x_: pose part (171) and landmark part (n) of the last SolveLinearSystem */
 vio_status vio_get_delta(struct vio_ctx *ctx, double *dx_pose, int64_t n, double *dx_landmarks);
-/* H_pp_schur_ WITHOUT the lambda of problem.cc:434-436, and b_pp_schur_ (171x171, 171) */
+/* H_pp_schur_ WITHOUT the lambda of problem.cc:434-436, and b_pp_schur_ (171x171, 171): of the last vio_linearize /
+ * vio_gn_iteration.  VIO_ERR_BAD_ARG when the context holds no linearisation of its current state — after vio_solve in
+ * particular, whose last linearisation may be a rejected trial's: call vio_linearize first. */
 vio_status vio_get_schur_system(struct vio_ctx *ctx, double *H, double *b);
 /* Hmm diagonal and bmm (n entries each), and the pose part of b_ / diag(Hessian_) (171 each) */
 vio_status vio_get_landmark_system(struct vio_ctx *ctx, int64_t n, double *hll, double *bl);
