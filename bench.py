@@ -10,11 +10,17 @@ include/vio_backend.h, enqueued back to back with no host round trip.  Inputs ar
 timed region starts.
 
 N = 1: the 11-frame / 20 000-landmark / 80 000-observation synthetic window (BASELINE.json configs[2]).
-N > 1: one process per GPU (torch.distributed, backend nccl == RCCL, for the rendezvous, the barriers and the
-       128-byte communicator id); every rank holds a 20 000-landmark shard of an (N x 20 000)-landmark window;
-       per iteration the library itself issues one RCCL all-reduce of the 72x72 reduced visual system and one
-       of the 2 step scalars on its stream.  Weak scaling: `value` counts
-       shard-iterations per second over all ranks.
+N > 1: BASELINE.json configs[3] — ONE 200 000-landmark / 800 000-observation window, its landmarks block-sharded over the N
+       GPUs (25 000 per GPU at N = 8): strong scaling.  One process per GPU (torch.distributed, backend nccl == RCCL, for
+       the rendezvous, the barriers and the 128-byte communicator id); per iteration the library itself issues ONE RCCL
+       all-gather of the shards' 24 KB partial reduced systems on its stream and adds them in rank order (SURVEY.md
+       section 8e).  `value` = GN iterations/s of THAT window (steps / elapsed — N ranks working on
+       one iteration count once); `single_gpu_same_window_ms` is the same window unsharded on rank 0's GPU, measured in the
+       same run, so the speed-up is in the line.
+       Launch: `python bench.py --gpus N` spawns its N rank processes itself (the parent never touches a GPU), or
+       `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (RANK / WORLD_SIZE from the environment).
+       VIO_BENCH_ONE_DEVICE=1 puts every rank on device 0 with the exchange staged through host memory over gloo (RCCL
+       refuses two ranks on one device): the N > 1 code path on a one-GPU box (tests/test_gpu_bench_launch.py).
 
 The JSON line also carries
   roofline      achieved = algorithmic bytes per launch / measured launch duration of the dominant kernel
@@ -70,12 +76,41 @@ def kernel_algorithmic_bytes(name, n, m, xyz=False):
     }[name]
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes as children of this one — fresh interpreters,
+    started before this process has made any GPU call (it never makes one) — hand them the torch.distributed environment, pass
+    rank 0's stdout through, and leave with the first non-zero exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    if rc != 0:                 # a rank that died leaves the others in a collective: end them
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--landmarks", type=int, default=20000, help="landmarks per GPU")
+    ap.add_argument("--landmarks", type=int, default=20000, help="landmarks of the N = 1 window")
+    ap.add_argument("--landmarks-total", type=int, default=200000, help="landmarks of the window N > 1 GPUs share (BASELINE.json configs[3])")
     ap.add_argument("--obs-per-landmark", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prior", action="store_true", help="first-window case: no marginalisation prior")
@@ -87,18 +122,20 @@ def main():
     ap.add_argument("--cpu-baseline-steps", type=int, default=0, help="0 = sized for about 10-20 s")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))          # before anything here has touched a GPU (torch is not even imported yet)
+
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("VIO_BENCH_ONE_DEVICE") == "1":      # diagnostic: all ranks on device 0 (if RCCL lets them)
+    one_device = os.environ.get("VIO_BENCH_ONE_DEVICE") == "1"      # all ranks on device 0: the N > 1 path on a one-GPU box
+    if one_device:
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
@@ -106,15 +143,21 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:      # RCCL refuses two ranks on one device: gloo for the rendezvous, the exchange through pinned host memory
+            os.environ.setdefault("VIO_EXCHANGE", "hook_host")
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     vio = load_package()
     hip = vio.load_hip()        # raises if csrc/libvio_hip.so is missing: no fallback path
 
-    n_per_gpu, k_obs = args.landmarks, args.obs_per_landmark
+    k_obs = args.obs_per_landmark
+    n_total = args.landmarks if world == 1 else args.landmarks_total
+    n_per_gpu = (n_total + world - 1) // world
     xyz = args.landmark_type == "xyz"
     make = vio.synth.make_window_xyz if xyz else vio.synth.make_window
-    full = make(n_per_gpu * world, seed=42, obs_per_landmark=k_obs)
+    full = make(n_total, seed=42, obs_per_landmark=k_obs)
     if not args.no_prior:
         # the steady-state window carries a marginalisation prior ("produced by running one MargOldFrame
         # on a preceding window"; its 235 KB are part of B_win): solve the window one frame earlier, marginalise its
@@ -150,6 +193,7 @@ def main():
     _, lam = ctx.init_lm()
 
     def barrier():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -183,13 +227,33 @@ def main():
     dom_ms, dom_cnt = ctx.profile_end()
     elapsed = t1 - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     chi2 = ctx.chi2()
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * args.steps / elapsed
+    value = args.steps / elapsed            # iterations of THE window per second: N ranks working on one iteration count once
+
+    # N > 1: the same window unsharded on rank 0's GPU, in the same run (the others wait at the barrier)
+    single_gpu = None
+    if world > 1:
+        if rank == 0:
+            c1 = hip.context(device=local_rank)
+            c1.load(full)
+            c1.linearize()
+            _, lam1 = c1.init_lm()
+            for _ in range(10):
+                c1.gn_iteration(lam1)
+            c1.synchronize()
+            n1 = max(20, min(args.steps, 100))
+            t = time.perf_counter()
+            for _ in range(n1):
+                c1.gn_iteration(lam1)
+            c1.synchronize()
+            single_gpu = (time.perf_counter() - t) * 1e3 / n1
+            del c1
+        barrier()
 
     dom_launch_s = (dom_ms / max(dom_cnt, 1)) * 1e-3
     alg_bytes = kernel_algorithmic_bytes(dominant, n, m, xyz)
@@ -221,17 +285,28 @@ def main():
         other = make(n_per_gpu, seed=43, obs_per_landmark=k_obs)
         other.prior = full.prior
 
-        def frame_costs(lib, reps):
+        def stats(v):
+            v = sorted(v)
+            return {"median": round(v[len(v) // 2], 4), "min": round(v[0], 4), "max": round(v[-1], 4), "n": len(v)}
+
+        def frame_costs(lib, reps, warm=2, windows=None):
+            """`reps` timed frames after `warm` untimed ones (one per window: first touches, buffers reaching their size).
+            A frame never repeats the one before (the library skips inputs it already holds)."""
+            wins = windows or (full, other)
             c = lib.context(**({"device": local_rank} if lib is hip else {}))
-            acc = {"set_ms": 0.0, "plan_upload_linearize_ms": 0.0, "solve10_ms": 0.0, "marginalize_ms": 0.0}
-            iters = 0
-            for r in range(reps + 1):
+            phases = ("set_ms", "plan_upload_linearize_ms", "solve10_ms", "marginalize_ms")
+            acc = {k: [] for k in phases}
+            acc["frame_ms"] = []
+            split = {"marg_device_us": [], "marg_tail_us": [], "marg_prepare_us": [], "activate_plan_us": [], "activate_push_us": []}
+            iters = live = 0
+            for r in range(reps + warm):
                 t0 = time.perf_counter()
-                c.load(full if r % 2 == 0 else other)      # a frame never repeats the one before: the library skips inputs it already holds
+                c.load(wins[r % len(wins)])
                 t1 = time.perf_counter()
                 c.linearize()
                 if lib is hip:
                     c.synchronize()
+                    ht_a = c.host_timing()
                 t2 = time.perf_counter()
                 rep = c.solve(10)
                 t3 = time.perf_counter()
@@ -239,21 +314,50 @@ def main():
                 if not xyz:
                     c.marginalize(vio.MARG_OLD)
                     t4 = time.perf_counter()
-                if r == 0:
-                    continue                # first pass: allocations, first touches
-                acc["set_ms"] += (t1 - t0) * 1e3; acc["plan_upload_linearize_ms"] += (t2 - t1) * 1e3
-                acc["solve10_ms"] += (t3 - t2) * 1e3; acc["marginalize_ms"] += (t4 - t3) * 1e3
+                if r < warm:
+                    continue
+                for k, v in zip(phases, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                    acc[k].append(v * 1e3)
+                acc["frame_ms"].append((t4 - t0) * 1e3)
                 iters = rep.iterations
-            out = {k: round(v / reps, 4) for k, v in acc.items()}
-            out["frame_ms"] = round(sum(out.values()), 4)
+                if lib is hip:
+                    ht = c.host_timing()
+                    for k in ("marg_device_us", "marg_tail_us", "marg_prepare_us"):
+                        split[k].append(ht[k])
+                    for k in ("activate_plan_us", "activate_push_us"):
+                        split[k].append(ht_a[k])
+                    live = int(ht["marg_live_rows"])
+            out = {k: stats(v)["median"] for k, v in acc.items()}
+            out["spread"] = {k: stats(v) for k, v in acc.items()}
             out["solve10_iterations"] = iters
+            if lib is hip:
+                out["host_split_us_median"] = {k: stats(v)["median"] for k, v in split.items()}
+                out["marginalize_live_rows_of_156"] = live
             if xyz:
-                out["marginalize_ms"] = None      # MargOldFrame is not defined for XYZ landmarks (include/vio_backend.h)
+                out["marginalize_ms"] = None
             return out
-        per_frame = {"gpu": frame_costs(hip, 5),
-                     "note": "host wall clock per call on the bench window; set = vio_set_window/landmarks/observations/imu/prior "
-                             "(host copies), plan_upload_linearize = pattern grouping + H2D + first linearisation, marginalize = "
-                             "MargOldFrame: GPU assembly + Schur, 171x171 D2H, eigen-decomposition tail on one host thread"}
+
+        per_frame = {"gpu": frame_costs(hip, 20),
+                     "note": "host wall clock per call on the bench window, median of 20 frames (spread: min / max); set = "
+                             "vio_set_window/landmarks/observations/imu/prior (host copies), plan_upload_linearize = pattern grouping + "
+                             "H2D + first linearisation, marginalize = MargOldFrame: GPU assembly + Schur, 171x171 D2H (marg_device_us), "
+                             "eigen-decomposition tail on one host thread (marg_tail_us; its plan is built under the solve: marg_prepare_us)"}
+        if not xyz:
+            # MargOldFrame's worst case: tracks that span all frames — every frame-0 landmark seen from frames 1..10 — and a prior of
+            # the same kind: all 156 rows of the reduced system are live, the eigen-decomposition pays its full O(n^3)
+            wd = [vio.synth.make_window(2000, seed=s_, t0=t_, obs_per_landmark=10) for s_, t_ in ((51, 1.0), (52, 1.0))]
+            cpd = hip.context(device=local_rank)
+            cpd.load(vio.synth.make_window(300, seed=50, t0=0.9, obs_per_landmark=10))
+            cpd.solve(10)
+            pd_ = cpd.marginalize(vio.MARG_OLD)
+            del cpd
+            for w_ in wd:
+                w_.prior = pd_
+            dense = frame_costs(hip, 20, windows=wd)
+            per_frame["dense_prior"] = {"marginalize_ms_dense_prior": dense["marginalize_ms"], "spread": dense["spread"]["marginalize_ms"],
+                                        "host_split_us_median": dense["host_split_us_median"],
+                                        "marginalize_live_rows_of_156": dense["marginalize_live_rows_of_156"],
+                                        "window": "2000 landmarks hosted in frame 0, each observed in frames 1..10, prior of the same kind"}
 
     # ---- B independent windows per launch (vio_batch_gn_iteration): the regime in which the device is full.  Same window
     #      size as the headline, different seeds; reported beside the single-window line, never instead of it
@@ -277,7 +381,7 @@ def main():
             hip.batch_gn_iteration(members, lam)
         lead.synchronize()
         tb = time.perf_counter() - tb
-        bytes_it = vio.synth.algorithmic_bytes(n, m)
+        bytes_it = it_bytes        # (the window kind's own count: XYZ windows move 24 M + 72 N + B_win)
         batched = {"windows": B, "steps": bsteps, "ms_per_batch_iteration": tb * 1e3 / bsteps,
                    "window_iterations_per_s": B * bsteps / tb, "us_per_window_iteration": tb * 1e6 / (bsteps * B),
                    "algorithmic_GBps": round(B * bytes_it * bsteps / tb / 1e9, 2), "hbm_frac": B * bytes_it * bsteps / tb / 8e12,
@@ -307,7 +411,7 @@ def main():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
         orc = vio.VioLib(os.path.join(ROOT, "oracle", "liboracle.so"), "vioo_")
         if per_frame is not None:
-            per_frame["cpu_port_1_thread"] = frame_costs(orc, 1)
+            per_frame["cpu_port_1_thread"] = frame_costs(orc, 1, warm=1)
         co = orc.context()
         co.load(full)
         co.gn_iteration(lam)        # warm-up / first touch
@@ -387,20 +491,34 @@ def main():
             cpu_reference = {"error": str(exc)}
 
     if rank == 0:
+        lm_kind = "XYZ landmarks (VertexPointXYZ, 3x3 blocks)" if xyz else "inverse-depth landmarks"
+        prior_txt = "no prior" if args.no_prior else "marginalisation prior of the preceding window"
+        if world == 1:
+            metric = "GN iterations/s, 11-frame (10-keyframe) window, 20k landmarks per GPU"
+            workload = ("synthetic 11-frame VIO window (SURVEY.md 8d; BASELINE.json configs[2]): %d landmarks x %d observations, "
+                        "10 IMU factors, %s, Cauchy loss, extrinsic fixed, fixed-lambda GN iteration, %s"
+                        % (n_total, k_obs + (1 if xyz else 0), prior_txt, lm_kind))
+            parallelism = "single GPU"
+        else:
+            metric = "GN iterations/s, 11-frame (10-keyframe) window, %dk landmarks sharded over the GPUs" % (n_total // 1000)
+            workload = ("synthetic 11-frame VIO window (SURVEY.md 8d; BASELINE.json configs[3]): ONE window of %d landmarks x %d "
+                        "observations, its landmarks block-sharded %d per GPU over %d GPUs (strong scaling: the window is the same "
+                        "at every N > 1), 10 IMU factors and prior replicated, %s, Cauchy loss, extrinsic fixed, fixed-lambda GN "
+                        "iteration, %s" % (n_total, k_obs + (1 if xyz else 0), n_per_gpu, world, prior_txt, lm_kind))
+            parallelism = ("landmark-sharded x%d; per iteration one all-gather of the shards' 24 KB partial reduced systems, added in "
+                           "rank order; the 171x171 pose solve replicated on every rank" % world)
         out = {
-            "metric": "GN iterations/s, 11-frame (10-keyframe) window, 20k landmarks per GPU",
+            "metric": metric,
             "value": value, "unit": "GN iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "synthetic 11-frame VIO window (SURVEY.md 8d): %d landmarks x %d observations per GPU, "
-                                   "10 IMU factors, %s, Cauchy loss, extrinsic fixed, fixed-lambda GN iteration, %s"
-                                   % (n_per_gpu, k_obs + (1 if xyz else 0), "no prior" if args.no_prior else "marginalisation prior of the preceding window",
-                                      "XYZ landmarks (VertexPointXYZ, 3x3 blocks)" if xyz else "inverse-depth landmarks"),
-                       "landmark_type": args.landmark_type,
-                       "landmarks_per_gpu": n_per_gpu, "observations_per_gpu": m, "landmarks_total": n_per_gpu * world,
-                       "lambda": lam, "parallelism": "landmark-sharded x%d, all-reduce of the 72x72 reduced system" % world
-                       if world > 1 else "single GPU", "exchange": sb.exchange},
+            "config": {"workload": workload, "landmark_type": args.landmark_type,
+                       "landmarks_per_gpu": n, "observations_per_gpu": m, "landmarks_total": n_total,
+                       "lambda": lam, "parallelism": parallelism, "exchange": sb.exchange,
+                       "all_ranks_on_one_device": bool(one_device)},
             "final_chi2": chi2,
+            "single_gpu_same_window_ms": single_gpu,
+            "speedup_vs_single_gpu_same_window": (single_gpu / ms_per_step) if single_gpu else None,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "per_frame": per_frame,

@@ -244,18 +244,26 @@ vio_status vio_get_schur_system(struct vio_ctx *ctx, double *H, double *b);
 vio_status vio_get_landmark_system(struct vio_ctx *ctx, int64_t n, double *hll, double *bl);
 vio_status vio_get_pose_gradient(struct vio_ctx *ctx, double *b_pose, double *diag_pose);
 
-/* ---- multi-GPU exchange ------------------------------------------- */
-/* Device pointer + element count of the packed fp64 buffer that must be summed over all shards
- * between vio_linearize and vio_solve_linear (one RCCL all-reduce), and of the scalar buffer
- * summed after vio_update_states (chi2 + gain-ratio scale). */
+/* ---- multi-GPU exchange -------------------------------------------
+ * The landmarks of a window are sharded over the ranks; what the ranks exchange per linearisation is every shard's packed
+ * partial reduced system (`reduced_system`, `reduced_count` fp64: 24 KB) and, on the stepwise path, two scalars per trial.
+ * The exchange is an ALL-GATHER into rank-major receive buffers (vio_gather_buffers: [shard_count][reduced_count] and
+ * [shard_count][scalar_count]), and the library itself adds the ranks' slabs in RANK ORDER wherever it reads a sum: every
+ * rank performs the same additions in the same order, so all ranks hold bit-identical systems and take bit-identical LM
+ * decisions whatever algorithm the collective library picks (an all-reduce would leave the summation order to it). */
+/* Device pointer + element count of the send side: this shard's packed fp64 slab (between vio_linearize and
+ * vio_solve_linear) and its two step scalars (after vio_update_states: chi2 + gain-ratio scale). */
 vio_status vio_exchange_buffers(struct vio_ctx *ctx, void **reduced_system, int64_t *reduced_count,
                                 void **step_scalars, int64_t *scalar_count);
-/* Hook called on the host, stream-ordered, wherever the LM loop needs an exchange
- * (which == 0: reduced system, 1: step scalars).  NULL (default) = unsharded. */
+/* The receive side: rank r's slab belongs at gathered_system + r * reduced_count, its scalars at gathered_scalars + r * scalar_count. */
+vio_status vio_gather_buffers(struct vio_ctx *ctx, void **gathered_system, void **gathered_scalars);
+/* Hook called on the host, stream-ordered, wherever the LM loop needs an exchange.  which == 0: all-gather the reduced
+ * systems, 1: all-gather the step scalars (both: send buffer -> receive buffers of ALL ranks, rank-major);
+ * which == 2 (CPU libraries only): all-reduce MAX of step_scalars[2] in place.  NULL (default) = unsharded. */
 typedef int (*vio_exchange_fn)(void *user, int which);
 vio_status vio_set_exchange_hook(struct vio_ctx *ctx, vio_exchange_fn fn, void *user);
 
-/* Native exchange: the library all-reduces its exchange buffers itself with RCCL (xGMI inside a node), in stream order
+/* Native exchange: the library all-gathers its exchange buffers itself with RCCL (xGMI inside a node), in stream order
  * on its own stream, with no host callback in the loop.  RCCL is dlopen'ed (librccl.so of the process, e.g. the one
  * PyTorch loaded); the caller only distributes the 128-byte id of rank 0 to all ranks (torch.distributed / MPI /
  * a socket) and every rank calls vio_comm_init with it.  Replaces the hook when both are set.
@@ -266,10 +274,12 @@ vio_status vio_comm_unique_id(void *id128);
 vio_status vio_comm_init(struct vio_ctx *ctx, const void *id128, int32_t rank, int32_t nranks);
 vio_status vio_comm_destroy(struct vio_ctx *ctx);
 
-/* Optional: make the library use caller-owned device memory for the two exchange buffers (e.g. torch tensors,
- * so that torch.distributed can all-reduce them in place).  reduced must hold >= the count reported by
- * vio_exchange_buffers + 8 doubles, scalars >= 8 doubles.  NULL restores the library's own buffer. */
+/* Optional: make the library use caller-owned device memory for the exchange buffers (e.g. torch tensors, so that
+ * torch.distributed can gather them in place).  reduced must hold >= the count reported by vio_exchange_buffers + 8
+ * doubles, scalars >= 8 doubles; gathered_system >= shard_count * reduced_count, gathered_scalars >= shard_count *
+ * scalar_count doubles.  NULL restores the library's own buffer. */
 vio_status vio_bind_exchange_buffers(struct vio_ctx *ctx, void *reduced_system, void *step_scalars);
+vio_status vio_bind_gather_buffers(struct vio_ctx *ctx, void *gathered_system, void *gathered_scalars);
 
 /* ---- measurement (HIP library only) ------------------------------------------------------------ */
 typedef enum {
@@ -284,6 +294,12 @@ vio_status vio_profile_begin_sampled(struct vio_ctx *ctx, int32_t which, int32_t
 /* Synchronise, sum the elapsed times of the recorded pairs, and stop profiling. */
 vio_status vio_profile_end(struct vio_ctx *ctx, double *total_ms, int64_t *launches);
 const char *vio_kernel_name(int32_t which);
+/* Where the host time of the context's last calls went, microseconds (wall clock inside the library):
+ *   out8[0..2]  the last activation of a plan: read-back of what the device held newer, plan build + its upload, state upload
+ *   out8[3]     the last vio_marginalize: activation + kernels + the 171x171 read-back      out8[4]  its dense host tail
+ *   out8[5]     rows of the reduced 156x156 system that were not exactly zero in that tail (the eigen-problem's size)
+ *   out8[6]     the marginalisation plan prepared under the last vio_solve (0: nothing to prepare) */
+vio_status vio_get_host_timing(struct vio_ctx *ctx, double *out8);
 
 #ifdef __cplusplus
 }

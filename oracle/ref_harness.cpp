@@ -80,6 +80,8 @@
 #undef vio_exchange_buffers
 #undef vio_set_exchange_hook
 #undef vio_bind_exchange_buffers
+#undef vio_gather_buffers
+#undef vio_bind_gather_buffers
 #undef vio_profile_begin
 #undef vio_profile_end
 #undef vio_kernel_name

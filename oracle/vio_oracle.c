@@ -979,6 +979,8 @@ struct vioo_ctx {
      * scalars are summed over all shards through the caller's hook; IMU + prior terms are replicated */
     double vis_own[VIS_N], step_own[8];
     double *vis, *step;
+    double *gath_own, *step_gath_own;    /* receive side of the all-gather: [shard_count][VIS_MAXH], [shard_count][2] */
+    double *gath, *step_gath;
     double Hv_dir[CD * CD];              /* un-Schur'd visual part (local shard only), for vioo_get_pose_hessian */
     vio_exchange_fn hook;
     void *hook_user;
@@ -1013,6 +1015,8 @@ vio_status vio_create(const vio_config *cfg, struct vioo_ctx **out) {
     c->ni = 2; c->lambda = -1;
     c->lm_dim = 1;
     c->vis = c->vis_own; c->step = c->step_own;
+    c->gath = c->gath_own = (double *)calloc((size_t)c->cfg.shard_count * VIS_MAXH, sizeof(double));
+    c->step_gath = c->step_gath_own = (double *)calloc((size_t)c->cfg.shard_count * 2, sizeof(double));
     for (int i = 0; i < NF; ++i) c->pose[7 * i + 6] = 1.0;
     c->ext[6] = 1.0;
     *out = c;
@@ -1021,8 +1025,17 @@ vio_status vio_create(const vio_config *cfg, struct vioo_ctx **out) {
 
 vio_status vio_set_config(struct vioo_ctx *c, const vio_config *cfg) {
     if (!c || !cfg) return VIO_ERR_BAD_ARG;
+    const int old_count = c->cfg.shard_count;
     c->cfg = *cfg;
     if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
+    if (c->cfg.shard_count != old_count) {
+        const int own_g = c->gath == c->gath_own, own_s = c->step_gath == c->step_gath_own;
+        free(c->gath_own); free(c->step_gath_own);
+        c->gath_own = (double *)calloc((size_t)c->cfg.shard_count * VIS_MAXH, sizeof(double));
+        c->step_gath_own = (double *)calloc((size_t)c->cfg.shard_count * 2, sizeof(double));
+        if (own_g) c->gath = c->gath_own;
+        if (own_s) c->step_gath = c->step_gath_own;
+    }
     c->linearized = 0;
     return VIO_OK;
 }
@@ -1031,6 +1044,7 @@ void vio_destroy(struct vioo_ctx *c) {
     if (!c) return;
     free(c->invd); free(c->invd_bak); free(c->lm); free(c->host); free(c->target);
     free(c->pts_i); free(c->pts_j); free(c->hll); free(c->bl); free(c->Hpl); free(c->dx_lm);
+    free(c->gath_own); free(c->step_gath_own);
     free(c);
 }
 
@@ -1411,8 +1425,26 @@ static void add_imu_terms(struct vioo_ctx *c, int marg_mode, double *H, double *
     }
 }
 
+/* The exchange (include/vio_backend.h): which 0 / 1 = the caller all-gathers every shard's vis[0 .. VIS_MAXH) resp. step[0 .. 2)
+ * into the rank-major receive buffers; the sum over the shards is then formed here, in rank order — the same additions in the
+ * same order on every rank.  which 2: max of step[2] over the shards, reduced in place by the caller. */
 static int run_hook(struct vioo_ctx *c, int which) {
-    return c->hook ? c->hook(c->hook_user, which) : 0;
+    if (!c->hook) return 0;
+    if (c->hook(c->hook_user, which) != 0) return 1;
+    const int R = c->cfg.shard_count;
+    if (which == 0)
+        for (int i = 0; i < VIS_MAXH; ++i) {
+            double s = c->gath[i];
+            for (int r = 1; r < R; ++r) s += c->gath[(size_t)r * VIS_MAXH + i];
+            c->vis[i] = s;
+        }
+    else if (which == 1)
+        for (int i = 0; i < 2; ++i) {
+            double s = c->step_gath[i];
+            for (int r = 1; r < R; ++r) s += c->step_gath[2 * r + i];
+            c->step[i] = s;
+        }
+    return 0;
 }
 
 /* SetOrdering + MakeHessian (problem.cc:256-285,303-389) + the lambda-free part of SolveLinearSystem (:412-429) */
@@ -1892,6 +1924,19 @@ vio_status vio_exchange_buffers(struct vioo_ctx *c, void **a, int64_t *na, void 
 vio_status vio_set_exchange_hook(struct vioo_ctx *c, vio_exchange_fn fn, void *user) {
     if (!c) return VIO_ERR_BAD_ARG;
     c->hook = fn; c->hook_user = user;
+    return VIO_OK;
+}
+vio_status vio_gather_buffers(struct vioo_ctx *c, void **gs, void **gc) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (gs) *gs = c->gath;
+    if (gc) *gc = c->step_gath;
+    return VIO_OK;
+}
+vio_status vio_bind_gather_buffers(struct vioo_ctx *c, void *gs, void *gc) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    c->gath = gs ? (double *)gs : c->gath_own;
+    c->step_gath = gc ? (double *)gc : c->step_gath_own;
+    c->linearized = 0;
     return VIO_OK;
 }
 vio_status vio_bind_exchange_buffers(struct vioo_ctx *c, void *reduced, void *scalars) {

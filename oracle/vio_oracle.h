@@ -41,6 +41,8 @@
 #define vio_exchange_buffers vioo_exchange_buffers
 #define vio_set_exchange_hook vioo_set_exchange_hook
 #define vio_bind_exchange_buffers vioo_bind_exchange_buffers
+#define vio_gather_buffers vioo_gather_buffers
+#define vio_bind_gather_buffers vioo_bind_gather_buffers
 #define vio_profile_begin vioo_profile_begin
 #define vio_profile_end vioo_profile_end
 #define vio_kernel_name vioo_kernel_name

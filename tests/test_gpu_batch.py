@@ -65,6 +65,54 @@ def test_batched_gn_equals_separate_runs(vio, hip_lib, oracle_lib):
             np.testing.assert_array_equal(x, y)
 
 
+def test_solo_calls_on_batch_members_between_batch_calls(vio, hip_lib, oracle_lib):
+    """A member's LmState.cur can move outside the batch — vio_gn_iteration, vio_solve, the stepwise flips on that one context —
+    without its tables changing; the batch's cached device array (every window's cur at build time, flipped by the parity of the
+    batch's own iteration count) must notice and be rebuilt.  Same bits as separate runs given the same call sequence."""
+    ws = windows(vio, oracle_lib)[:4]
+    lam = 5e5
+    lead = hip_lib.context()
+    batch = [lead] + [hip_lib.context(stream=lead.get_stream()) for _ in ws[1:]]
+    solo = [hip_lib.context() for _ in ws]
+    for c, r, w in zip(batch, solo, ws):
+        c.load(w)
+        r.load(w)
+
+    def both(fn_batch, fn_solo):
+        fn_batch()
+        fn_solo()
+
+    def batch_step():
+        hip_lib.batch_gn_iteration(batch, lam)
+        for r in solo:
+            r.gn_iteration(lam)
+
+    batch_step()
+    # ADVICE r02: one solo iteration on EVERY member — all steps still pending, all generations equal — then the batch again
+    for c, r in zip(batch, solo):
+        c.gn_iteration(lam)
+        r.gn_iteration(lam)
+    batch_step()
+    batch_step()
+    # one member only, an odd number of solo iterations; another through the stepwise entry points; a third through vio_solve
+    for _ in range(3):
+        batch[1].gn_iteration(lam)
+        solo[1].gn_iteration(lam)
+    for c in (batch[2], solo[2]):
+        c.linearize()
+        c.init_lm()
+        c.solve_linear(lam)
+        c.update_states()
+        c.eval_step()
+    ra, rb = batch[3].solve(3), solo[3].solve(3)
+    assert (ra.iterations, ra.trials, ra.final_chi2) == (rb.iterations, rb.trials, rb.final_chi2)
+    batch_step()
+    batch_step()
+    for c, r in zip(batch, solo):
+        for x, y in zip(state_of(c), state_of(r)):
+            np.testing.assert_array_equal(x, y)
+
+
 def test_batched_gn_xyz_windows(vio, hip_lib):
     """XYZ-landmark windows in one batch (k_linearize_xyz_b): equal to separate runs bit for bit, ragged sizes included."""
     ws = [vio.synth.make_window_xyz(600, seed=11, ragged=True), vio.synth.make_window_xyz(2000, seed=12), vio.synth.make_window_xyz(40, seed=13),
@@ -142,3 +190,18 @@ def test_batch_argument_checks(vio, hip_lib):
     c.load(vio.synth.make_window_xyz(50, seed=1))
     with pytest.raises(vio.VioError):
         hip_lib.batch_gn_iteration([a, c], 1e3)            # one kind of landmark per batch
+    d = hip_lib.context(stream=a.get_stream())
+    d.load(w)
+    with pytest.raises(vio.VioError) as ei:
+        hip_lib.batch_gn_iteration([a, d, a], 1e3)         # the same context twice: two windows of the grid on one set of buffers
+    assert "twice" in str(ei.value)
+    with pytest.raises(vio.VioError):
+        hip_lib.batch_solve([a, d, d], 3)
+    # a member's failure is reported where the caller looks: on the leader
+    e = hip_lib.context(stream=a.get_stream())
+    e.set_window(w.poses, w.speed_bias, w.ext)
+    e.set_landmarks(np.array([0.2, 0.3]))
+    e.set_observations([0], [0], [1], [[0.0, 0.0]], [[0.01, 0.0]])      # landmark 1 has no observation: its plan cannot be built
+    with pytest.raises(vio.VioError) as ei:
+        hip_lib.batch_gn_iteration([a, e], 1e3)
+    assert "window 1" in str(ei.value)

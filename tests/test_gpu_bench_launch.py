@@ -1,0 +1,49 @@
+"""bench.py --gpus N exactly as the driver starts it — `python bench.py --gpus N --steps K --warmup W`, no launcher, no
+WORLD_SIZE — on the one GPU a test box has: VIO_BENCH_ONE_DEVICE=1 puts both ranks on device 0 and stages the exchange
+through pinned host memory over gloo (RCCL refuses two ranks on one device).  Everything else is the N > 1 path of the
+bench: the parent spawns the rank processes before touching a GPU, the 200 000-landmark window of BASELINE.json configs[3]
+is sharded over the ranks, one all-gather per iteration with the rank-ordered sum in the kernels, the unsharded window on
+rank 0's GPU in the same run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+def test_two_ranks_launched_as_the_driver_would():
+    p, out = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2"], {"VIO_BENCH_ONE_DEVICE": "1"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out is not None, p.stdout[-2000:]
+    assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "strong"
+    cfg = out["config"]
+    assert cfg["landmarks_total"] == 200000 and cfg["landmarks_per_gpu"] == 100000 and cfg["observations_per_gpu"] == 400000
+    assert "configs[3]" in cfg["workload"] and cfg["exchange"] == "hook_host" and cfg["all_ranks_on_one_device"] is True
+    # one window's iterations per second, not ranks x iterations
+    assert abs(out["value"] * out["ms_per_step"] - 1e3) <= 1e-6 * 1e3
+    assert out["single_gpu_same_window_ms"] > 0 and out["speedup_vs_single_gpu_same_window"] > 0
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
+    assert out["final_chi2"] > 0 and out["final_chi2"] == out["final_chi2"]
+
+
+def test_single_gpu_line_is_the_headline_window():
+    p, out = run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--batch", "0", "--no-per-frame"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["landmarks_total"] == 20000 and out["config"]["observations_per_gpu"] == 80000
+    assert out["single_gpu_same_window_ms"] is None
+    assert abs(out["value"] * out["ms_per_step"] - 1e3) <= 1e-6 * 1e3

@@ -87,11 +87,12 @@ class VioLib:
                "set_exchange_hook", "bind_exchange_buffers", "set_landmarks_xyz", "set_observations_xyz",
                "get_landmarks_xyz", "set_config"]
     # outside the backend proper: the compiled-reference harness (vior_) has no FeatureManager
-    OPTIONAL = ["triangulate"]
+    # ... nor the receive side of the sharded exchange (it never shards)
+    OPTIONAL = ["triangulate", "gather_buffers", "bind_gather_buffers"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
-                "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration", "batch_solve"]
+                "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration", "batch_solve", "get_host_timing"]
     KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
@@ -385,6 +386,16 @@ class VioContext:
         self._ck(self.lib.fn["bind_exchange_buffers"](self.h, C.c_void_p(reduced_ptr), C.c_void_p(scalars_ptr)),
                  "bind_exchange_buffers")
 
+    def gather_buffers(self):
+        """Receive side of the sharded exchange (vio_gather_buffers): pointers of [shard_count][n_reduced], [shard_count][n_scalars]."""
+        p0, p1 = C.c_void_p(), C.c_void_p()
+        self._ck(self.lib.fn["gather_buffers"](self.h, C.byref(p0), C.byref(p1)), "gather_buffers")
+        return p0.value, p1.value
+
+    def bind_gather_buffers(self, gathered_ptr, gathered_scalars_ptr):
+        self._ck(self.lib.fn["bind_gather_buffers"](self.h, C.c_void_p(gathered_ptr), C.c_void_p(gathered_scalars_ptr)),
+                 "bind_gather_buffers")
+
     def set_exchange_hook(self, fn):
         """fn(which) -> 0 on success; kept alive on the context."""
         proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
@@ -422,6 +433,13 @@ class VioContext:
         ms, n = C.c_double(), C.c_int64()
         self._ck(self.lib.fn["profile_end"](self.h, C.byref(ms), C.byref(n)), "profile_end")
         return ms.value, n.value
+
+    def host_timing(self):
+        """vio_get_host_timing as a dict (microseconds; `marg_live_rows` is a count)."""
+        out = (C.c_double * 8)()
+        self._ck(self.lib.fn["get_host_timing"](self.h, out), "get_host_timing")
+        keys = ("activate_pull_us", "activate_plan_us", "activate_push_us", "marg_device_us", "marg_tail_us", "marg_live_rows", "marg_prepare_us")
+        return {k: out[i] for i, k in enumerate(keys)}
 
     def exchange_buffers(self):
         p0, n0, p1, n1 = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()

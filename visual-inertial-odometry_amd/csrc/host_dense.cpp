@@ -188,7 +188,7 @@ static void move_to_bottom(std::vector<double> &H, std::vector<double> &b, int n
 }
 
 __attribute__((target_clones("avx2", "default")))
-void marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *bout, double *errout, double *jtout) {
+int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *bout, double *errout, double *jtout) {
     const int n = 171, m2 = 15, n2 = n - m2;
     std::vector<double> H(Hin, Hin + (size_t)n * n), b(bin, bin + n);
     // larger index first: speed-bias, then pose (problem.cc:721-745)
@@ -279,6 +279,7 @@ void marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double 
             }
     }
     std::memcpy(bout, bp.data(), sizeof(double) * n2);
+    return nl;
 }
 
 // ---- IntegrationBase ---------------------------------------------------------------------------------------

@@ -15,7 +15,8 @@ bool symmetric_eigen(int n, const double *A, double *evals, double *V);
 // H (171x171 row-major) and b (171) hold H_marg/b_marg AFTER the landmark Schur complement and AFTER the old
 // prior has been added.  frame = index of the frame whose pose (6) and speed-bias (9) are marginalised.
 // Outputs: Hout 156x156, bout 156, errout 156, jtout 156x156.
-void marginalize_tail(double *H, double *b, int frame, double *Hout, double *bout, double *errout, double *jtout);
+// Returns the number of rows of the reduced 156x156 system that were not exactly zero (the size of the eigen-problem solved).
+int marginalize_tail(double *H, double *b, int frame, double *Hout, double *bout, double *errout, double *jtout);
 
 // IntegrationBase mid-point propagation (integration_base.h:54-158): count samples after (acc0, gyr0).
 // out_* : sum_dt, delta_p[3], delta_q[4] (xyzw), delta_v[3], jacobian[225], covariance[225] (row-major)

@@ -48,7 +48,7 @@ void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_step_sum(const DeviceTables &T, int mode, hipStream_t s);
 void vio_launch_triangulate(const TriTables &Q, hipStream_t s);
 void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStream_t s);
-void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s);
+void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
 void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int any_prior, size_t ps_lds, int what,
@@ -74,7 +74,9 @@ struct DevBuf {
     hipError_t resize(size_t count) {
         if (count == 0) count = 1;
         if (count <= n) return hipSuccess;
-        if (p) hipFree(p);
+        // hipFree waits for the whole device: a buffer that has had to grow once (the next frame's graph is a little larger than
+        // this one's) gets a quarter of headroom, so that a stream of frames stops reallocating after its first few
+        if (p) { hipFree(p); count += count / 4; }
         p = nullptr; n = 0;
         hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
         if (e == hipSuccess) n = count;
@@ -206,7 +208,7 @@ struct vio_ctx {
     Plan *active = nullptr;
     // device buffers independent of the topology
     DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
-        d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi;
+        d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi, d_gath, d_step_gath;
     DevBuf<int32_t> d_imu_valid, d_perm, d_rank, d_gather_map;
     DevBuf<double> d_Pg;
     DevBuf<LmState> d_lm;
@@ -220,6 +222,7 @@ struct vio_ctx {
     // a batch this context leads (vio_batch_gn_iteration): the members' tables as a device array + what it was built from
     std::vector<vio_ctx *> batch_members;
     std::vector<uint64_t> batch_gens;
+    std::vector<int> batch_cur0;                       // every member's LmState.cur when the array was built
     DevBuf<DeviceTables> d_batch_tabs;
     int batch_iters = 0;                               // iterations since the array was built (its parity flips every window's cur)
     vio_status flush_status = VIO_OK;                  // what the flush_decide inside the last make_tables returned
@@ -227,7 +230,9 @@ struct vio_ctx {
     void *hook_user = nullptr;
     double hessian_ms = 0;
     double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
+    double *ext_gath = nullptr, *ext_step_gath = nullptr;      // caller-owned receive buffers of the all-gather (vio_bind_gather_buffers)
     DevBuf<unsigned long long> d_dbg;                  // diagnostic builds only
+    double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // vio_get_host_timing
     int prof_which = -1;
     int prof_every = 1, prof_seen = 0;                 // event pairs around every prof_every-th launch only
     std::vector<hipEvent_t> prof_events;               // pairs
@@ -625,6 +630,7 @@ vio_status alloc_fixed(vio_ctx *c) {
     HIPCHK(c->d_Hs.resize(PD * PD)); HIPCHK(c->d_bs.resize(176)); HIPCHK(c->d_bfull.resize(2 * 176));
     HIPCHK(c->d_diagfull.resize(176)); HIPCHK(c->d_dx.resize(176)); HIPCHK(c->d_step_tot.resize(8));
     HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
+    HIPCHK(c->d_gath.resize((size_t)c->cfg.shard_count * VIS_SEND)); HIPCHK(c->d_step_gath.resize((size_t)c->cfg.shard_count * 2));
     HIPCHK(c->d_perm.resize(2 * 176)); HIPCHK(c->d_rank.resize(176)); HIPCHK(c->d_Pg.resize(2 * POSE_SOLVE_TILED));     // two sets (vio_solve's loop)
     HIPCHK(hipMemset(c->d_Pg.p, 0, 2 * POSE_SOLVE_TILED * sizeof(double)));   // tile padding (17th column) is never written again
     HIPCHK(hipMemsetAsync(c->d_vis.p, 0, VIS_COUNT * 8, c->stream));
@@ -655,6 +661,8 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) T.imu_mask |= (c->imu_valid[k] ? 1 : 0) << k;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
+    T.gath = c->ext_gath ? c->ext_gath : c->d_gath.p; T.step_gath = c->ext_step_gath ? c->ext_step_gath : c->d_step_gath.p;
+    T.n_shards = (c->hook != nullptr || c->comm != nullptr) ? c->cfg.shard_count : 0;
     T.list_off = pl.d_list_off.p; T.list = pl.d_list.p;
 #ifdef VIO_STAMPS
     (void)c->d_dbg.resize(16 * (size_t)(T.n_items + T.n_imu_items + 16));
@@ -808,10 +816,11 @@ vio_status activate(vio_ctx *c, Plan &pl, int marg) {
         const auto t2 = std::chrono::steady_clock::now();
         VIOCHK(push_to_device(c, pl));
         HIPCHK(c->arena.end(c->stream));
-        if (timing) {
+        {
             const auto t3 = std::chrono::steady_clock::now();
             auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-            std::fprintf(stderr, "[vio host timing] activate(marg=%d): pull %.0f us, build_plan+upload %.0f us, push %.0f us\n", marg, us(t0, t1), us(t1, t2), us(t2, t3));
+            c->timing[0] = us(t0, t1); c->timing[1] = us(t1, t2); c->timing[2] = us(t2, t3);
+            if (timing) std::fprintf(stderr, "[vio host timing] activate(marg=%d): pull %.0f us, build_plan+upload %.0f us, push %.0f us\n", marg, us(t0, t1), us(t1, t2), us(t2, t3));
         }
         ++c->tables_gen;
         c->active = &pl;
@@ -849,7 +858,7 @@ struct RcclApi {
     int (*GetUniqueId)(RcclId128 *id) = nullptr;
     int (*CommInitRank)(void **comm, int nranks, RcclId128 id, int rank) = nullptr;
     int (*CommDestroy)(void *comm) = nullptr;
-    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, hipStream_t s) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 
@@ -866,10 +875,10 @@ RcclApi *rccl_api(std::string &err) {
     *(void **)&api.GetUniqueId = dlsym(api.lib, "ncclGetUniqueId");
     *(void **)&api.CommInitRank = dlsym(api.lib, "ncclCommInitRank");
     *(void **)&api.CommDestroy = dlsym(api.lib, "ncclCommDestroy");
-    *(void **)&api.AllReduce = dlsym(api.lib, "ncclAllReduce");
+    *(void **)&api.AllGather = dlsym(api.lib, "ncclAllGather");
     *(void **)&api.GetErrorString = dlsym(api.lib, "ncclGetErrorString");
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) {
-        err = "librccl.so lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllReduce";
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
+        err = "librccl.so lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather";
         dlclose(api.lib); api.lib = nullptr;
         return nullptr;
     }
@@ -878,18 +887,20 @@ RcclApi *rccl_api(std::string &err) {
 
 inline bool sharded(const vio_ctx *c) { return c->hook != nullptr || c->comm != nullptr; }
 
-// which == 0: reduced visual system (sum), 1: the two step scalars (sum), 2: max |h_ll| (max, step buffer slot 2)
+// The exchange of a sharded window is an all-gather, not an all-reduce: every rank receives every rank's slab and the kernels
+// that read a sum form it in rank order (d_vis / d_step_tot of vio_kernels.hip) — identical bits on every rank by construction,
+// independent of the collective library's algorithm (an all-reduce leaves the order of the additions to RCCL).
+// which == 0: vis[0 .. VIS_SEND) of every shard -> gath[rank][..]   (24 KB per rank; max |h_ll| rides in its last slot)
+// which == 1: the two step scalars of the stepwise path -> step_gath[rank][0..1]
 vio_status run_exchange(vio_ctx *c, int which) {
     if (c->comm) {
         std::string err;
         RcclApi *api = rccl_api(err);
         if (!api) return fail(c, VIO_ERR_HIP, err);
-        double *vis = c->ext_vis ? c->ext_vis : c->d_vis.p;
-        double *step = c->ext_step ? c->ext_step : c->d_step_tot.p;
-        double *buf = which == 0 ? vis : (which == 1 ? step : step + 2);
-        const size_t count = which == 0 ? (size_t)VIS_MAXH : (which == 1 ? 2 : 1);
-        const int rc = api->AllReduce(buf, buf, count, /*ncclDouble*/ 8, which == 2 ? /*ncclMax*/ 2 : /*ncclSum*/ 0, c->comm, c->stream);
-        if (rc != 0) return fail(c, VIO_ERR_HIP, std::string("ncclAllReduce: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
+        const double *send = which == 0 ? (c->ext_vis ? c->ext_vis : c->d_vis.p) : (c->ext_step ? c->ext_step : c->d_step_tot.p);
+        double *recv = which == 0 ? (c->ext_gath ? c->ext_gath : c->d_gath.p) : (c->ext_step_gath ? c->ext_step_gath : c->d_step_gath.p);
+        const int rc = api->AllGather(send, recv, which == 0 ? (size_t)VIS_SEND : 2, /*ncclDouble*/ 8, c->comm, c->stream);
+        if (rc != 0) return fail(c, VIO_ERR_HIP, std::string("ncclAllGather: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error"));
         return VIO_OK;
     }
     if (!c->hook) return VIO_OK;
@@ -928,15 +939,9 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     return VIO_OK;
 }
 
-// ComputeLambdaInitLM; with shards, max |h_ll| is max-reduced through the hook (which == 2) in step_scalars[2]
+// ComputeLambdaInitLM; with shards, max |h_ll| of every rank came with its slab of the last exchange (k_init_lm takes the max)
 vio_status enqueue_init_lm(vio_ctx *c, const DeviceTables &T, int max_iter) {
-    const double *src = T.vis + VIS_MAXH;
-    if (sharded(c)) {
-        HIPCHK(hipMemcpyAsync(T.step_tot + 2, T.vis + VIS_MAXH, 8, hipMemcpyDeviceToDevice, c->stream));
-        VIOCHK(run_exchange(c, 2));
-        src = T.step_tot + 2;
-    }
-    vio_launch_init_lm(T, max_iter, src, c->stream);
+    vio_launch_init_lm(T, max_iter, c->stream);
     HIPCHK(hipGetLastError());
     return VIO_OK;
 }
@@ -1105,7 +1110,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
-    c->d_batch_tabs.release(); c->d_rank.release(); c->d_gather_map.release();
+    c->d_batch_tabs.release(); c->d_rank.release(); c->d_gather_map.release(); c->d_gath.release(); c->d_step_gath.release();
     c->arena.release(c->own_stream);
     if (c->pull_stage) hipHostFree(c->pull_stage);
     if (c->marg_stage) hipHostFree(c->marg_stage);
@@ -1378,7 +1383,11 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
             // host work under the device's; a failure here is vio_marginalize's to report (it tries again)
             if (status == VIO_OK) status = read_lm_begin(c);
             static const bool no_prepare = std::getenv("VIO_NO_MARG_PREPARE") != nullptr;      // diagnostic
-            if (status == VIO_OK && done == 0 && !sharded(c) && !no_prepare) (void)prepare_marg_plan(c);
+            if (status == VIO_OK && done == 0 && !sharded(c) && !no_prepare) {
+                const auto tp = std::chrono::steady_clock::now();
+                (void)prepare_marg_plan(c);
+                c->timing[6] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp).count();
+            }
             if (status == VIO_OK) status = read_lm_end(c);
             done = c->h_lm.iter;
             stop = c->h_lm.stop || done >= iterations;
@@ -1427,6 +1436,12 @@ vio_status vio_get_stream(vio_ctx *c, void **stream) {
     return VIO_OK;
 }
 
+static bool has_duplicates(vio_ctx *const *ctxs, int count) {
+    std::vector<const vio_ctx *> v(ctxs, ctxs + count);
+    std::sort(v.begin(), v.end());
+    return std::adjacent_find(v.begin(), v.end()) != v.end();
+}
+
 // B independent windows, one launch per kernel for all of them (grid.y = window): the regime in which the chip is full —
 // one window's k_pose_solve is a single workgroup on one of 256 CUs.  Every context keeps its own plan, buffers and
 // LmState; the leader (ctxs[0]) holds the device array of the members' tables.
@@ -1442,29 +1457,39 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         if (sharded(m)) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_gn_iteration: sharded contexts cannot be batched");
         if (m->lm_dim != c->lm_dim) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_gn_iteration: the windows of a batch hold one kind of landmark");
     }
+    if (has_duplicates(ctxs, count)) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_gn_iteration: a context appears twice (two windows of the grid would write the same buffers)");
+    // a member's failure is reported on the leader, which is where the caller looks (vio_last_error(ctxs[0]))
+    auto member = [&](int i, vio_status st) { return (st == VIO_OK || ctxs[i] == c) ? st : fail(c, st, "window " + std::to_string(i) + ": " + ctxs[i]->err); };
     bool rebuild = (int)c->batch_members.size() != count;
     for (int i = 0; i < count; ++i) {
         vio_ctx *m = ctxs[i];
         const uint64_t g0 = m->tables_gen;
-        vio_status st = activate(m, m->solve_plan, 0);
-        if (st != VIO_OK) return st == VIO_OK ? st : fail(c, st, "window " + std::to_string(i) + ": " + m->err);
+        vio_status st = member(i, activate(m, m->solve_plan, 0));
+        if (st != VIO_OK) return st;
         if (!rebuild && (c->batch_members[i] != m || c->batch_gens[i] != m->tables_gen || g0 != m->tables_gen)) rebuild = true;
         // a step waiting for its test belongs to the batch's own sequence only if the array is current; otherwise settle it
-        if (m->cur_host < 0 || (rebuild && m->decide_pending)) VIOCHK(read_lm(m));
+        if (m->cur_host < 0 || (rebuild && m->decide_pending)) { st = member(i, read_lm(m)); if (st != VIO_OK) return st; }
+        // The array holds every window's `cur` as it was when the array was built; the kernels flip it by the parity of the batch's
+        // own iteration count.  Anything that moved a member's `cur` outside the batch (vio_gn_iteration, vio_solve, the stepwise
+        // flips on that one context) leaves that bookkeeping behind: build the array again from the members as they are.
+        if (!rebuild && m->cur_host != (c->batch_cur0[i] ^ (c->batch_iters & 1))) rebuild = true;
         if (!m->pairtab_valid && m->lm_dim == 1) { DeviceTables T = make_tables_raw(m, m->solve_plan); T.cur_hint = m->cur_host; vio_launch_prepare(T, m->stream); m->pairtab_valid = true; }
         if (lambda != m->gn_lambda) { vio_launch_set_lambda(m->d_lm.p, lambda, m->stream); m->gn_lambda = lambda; }
     }
     if (!rebuild)
         for (int i = 0; i < count; ++i) if (ctxs[i]->decide_pending != ctxs[0]->decide_pending) rebuild = true;
     if (rebuild) {
-        for (int i = 0; i < count; ++i) if (ctxs[i]->decide_pending || ctxs[i]->cur_host < 0) VIOCHK(read_lm(ctxs[i]));
+        for (int i = 0; i < count; ++i)
+            if (ctxs[i]->decide_pending || ctxs[i]->cur_host < 0) { const vio_status st = member(i, read_lm(ctxs[i])); if (st != VIO_OK) return st; }
         std::vector<DeviceTables> tabs((size_t)count);
         c->batch_members.assign(ctxs, ctxs + count);
         c->batch_gens.resize((size_t)count);
+        c->batch_cur0.resize((size_t)count);
         for (int i = 0; i < count; ++i) {
             tabs[i] = make_tables_raw(ctxs[i], ctxs[i]->solve_plan);
             tabs[i].cur_hint = ctxs[i]->cur_host;         // this window's `cur` now; the kernels flip it by the iteration parity
             c->batch_gens[i] = ctxs[i]->tables_gen;
+            c->batch_cur0[i] = ctxs[i]->cur_host;
         }
         HIPCHK(c->d_batch_tabs.resize((size_t)count));
         HIPCHK(hipMemcpyAsync(c->d_batch_tabs.p, tabs.data(), (size_t)count * sizeof(DeviceTables), hipMemcpyHostToDevice, c->stream));
@@ -1514,6 +1539,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         for (int k = 0; k < VIO_WINDOW_SIZE; ++k) any_imu |= m->imu_valid[k];
         if (m->h_olm.empty() && !any_imu) return fail(c, VIO_ERR_EMPTY, "window " + std::to_string(i) + ": Cannot solve problem without edges or verticies");
     }
+    if (has_duplicates(ctxs, count)) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_solve: a context appears twice (two windows of the grid would write the same buffers)");
     std::vector<DeviceTables> tabs((size_t)count);
     int max_blocks = 1, any_prior = 0;
     size_t lds = 0;
@@ -1522,7 +1548,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         vio_status st = activate(m, m->solve_plan, 0);
         if (st != VIO_OK) return m == c ? st : fail(c, st, "window " + std::to_string(i) + ": " + m->err);
         st = flush_decide(m);
-        if (st != VIO_OK) return st;
+        if (st != VIO_OK) return m == c ? st : fail(c, st, "window " + std::to_string(i) + ": " + m->err);
         m->cur_host = -1;
         tabs[i] = make_tables_raw(m, m->solve_plan);         // cur_hint = -1: the kernels take `cur` from the window's LmState
         if (!m->pairtab_valid && m->lm_dim == 1) { vio_launch_prepare(tabs[i], m->stream); m->pairtab_valid = true; }
@@ -1643,10 +1669,13 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
         std::memcpy(bm, c->h_bprior.data(), (size_t)PD * 8);
     }
     const auto t1 = std::chrono::steady_clock::now();
-    vio_host::marginalize_tail(Hm, bm, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, H, b, err, jt);
-    if (timing) {
+    const int live_rows = vio_host::marginalize_tail(Hm, bm, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, H, b, err, jt);
+    {
         const auto t2 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[vio host timing] vio_marginalize(kind=%d): activate + kernels + read-back %.0f us, host tail %.0f us\n", kind,
+        c->timing[3] = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        c->timing[4] = std::chrono::duration<double, std::micro>(t2 - t1).count();
+        c->timing[5] = live_rows;
+        if (timing) std::fprintf(stderr, "[vio host timing] vio_marginalize(kind=%d): activate + kernels + read-back %.0f us, host tail %.0f us\n", kind,
                      std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count());
     }
     return VIO_OK;
@@ -1764,7 +1793,7 @@ vio_status vio_get_pose_gradient(vio_ctx *c, double *b, double *diag) {
 vio_status vio_exchange_buffers(vio_ctx *c, void **reduced, int64_t *n_reduced, void **scalars, int64_t *n_scalars) {
     if (!c) return VIO_ERR_BAD_ARG;
     if (reduced) *reduced = c->ext_vis ? c->ext_vis : c->d_vis.p;
-    if (n_reduced) *n_reduced = VIS_MAXH;       // everything before the max-|h_ll| slot is summed across shards
+    if (n_reduced) *n_reduced = VIS_SEND;       // the slots summed over the shards, then max |h_ll|
     if (scalars) *scalars = c->ext_step ? c->ext_step : c->d_step_tot.p;
     if (n_scalars) *n_scalars = 2;
     return VIO_OK;
@@ -1856,6 +1885,22 @@ vio_status vio_preintegrate(const double *acc0, const double *gyr0, const double
     return VIO_OK;
 }
 
+vio_status vio_gather_buffers(vio_ctx *c, void **gathered_system, void **gathered_scalars) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (gathered_system) *gathered_system = c->ext_gath ? c->ext_gath : c->d_gath.p;
+    if (gathered_scalars) *gathered_scalars = c->ext_step_gath ? c->ext_step_gath : c->d_step_gath.p;
+    return VIO_OK;
+}
+
+vio_status vio_bind_gather_buffers(vio_ctx *c, void *gathered_system, void *gathered_scalars) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    c->ext_gath = (double *)gathered_system;
+    c->ext_step_gath = (double *)gathered_scalars;
+    ++c->tables_gen;
+    c->linearized = false;
+    return VIO_OK;
+}
+
 vio_status vio_bind_exchange_buffers(vio_ctx *c, void *reduced, void *scalars) {
     if (!c) return VIO_ERR_BAD_ARG;
     c->ext_vis = (double *)reduced;
@@ -1879,6 +1924,12 @@ vio_status vio_debug_stamps(vio_ctx *c, unsigned long long *out, int64_t n_block
 const char *vio_kernel_name(int32_t which) {
     static const char *names[VIO_K_COUNT] = {"k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"};
     return (which >= 0 && which < VIO_K_COUNT) ? names[which] : "";
+}
+
+vio_status vio_get_host_timing(vio_ctx *c, double *out8) {
+    if (!c || !out8) return VIO_ERR_BAD_ARG;
+    std::memcpy(out8, c->timing, sizeof(c->timing));
+    return VIO_OK;
 }
 
 vio_status vio_profile_begin_sampled(vio_ctx *c, int32_t which, int32_t every) {

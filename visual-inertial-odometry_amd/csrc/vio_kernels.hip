@@ -78,6 +78,31 @@ __device__ __forceinline__ int full_to_cam(int i) {
     return o < 6 ? 6 + 6 * f + o : -1;
 }
 
+// Entry idx of the reduced visual system summed over the shards: unsharded, the window's own sums (k_reduce); sharded, the
+// all-gathered slabs of all ranks added in RANK ORDER — the same additions in the same order on every rank, so every rank
+// holds the identical bits whatever algorithm the collective library chose ("fixed reduction order").
+// The loads of the ranks do not depend on each other: one round trip, as for the single read.
+__device__ __forceinline__ double d_vis(const DeviceTables &T, int idx) {
+    if (T.n_shards == 0) return T.vis[idx];
+    const double *g = T.gath + idx;
+    double s = g[0];
+#pragma unroll 8
+    for (int r = 1; r < T.n_shards; ++r) s += g[(size_t)r * VIS_SEND];
+    return s;
+}
+__device__ __forceinline__ double d_vis_maxh(const DeviceTables &T) {       // max |h_ll| over all shards
+    if (T.n_shards == 0) return T.vis[VIS_MAXH];
+    double m = T.gath[VIS_MAXH];
+    for (int r = 1; r < T.n_shards; ++r) m = fmax(m, T.gath[(size_t)r * VIS_SEND + VIS_MAXH]);
+    return m;
+}
+__device__ __forceinline__ double d_step_tot(const DeviceTables &T, int i) {    // the two step scalars of the stepwise path, the same way
+    if (T.n_shards == 0) return T.step_tot[i];
+    double s = T.step_gath[i];
+    for (int r = 1; r < T.n_shards; ++r) s += T.step_gath[2 * r + i];
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // pair table: for every ordered frame pair (h,t) the composed maps of the reprojection chain
 //   p_cj = C * p_ci + d   with C = ric^T Rt^T Rh ric,  d = ric^T (Rt^T (Rh tic + Ph - Pt) - tic)
@@ -1110,7 +1135,7 @@ __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int
     if (ci >= 0 && cj >= 0) {
         int P = ci / 6, a = ci - 6 * P, Q = cj / 6, bq = cj - 6 * Q;
         if (P > Q) { const int t0 = P; P = Q; Q = t0; const int t1 = a; a = bq; bq = t1; }
-        vv = T.vis[VIS_H + VIS_PAIR(P, Q) * 36 + a * 6 + bq];
+        vv = d_vis(T, VIS_H + VIS_PAIR(P, Q) * 36 + a * 6 + bq);
     }
     if (i >= 6 && j >= 6) {
         const int fi = (i - 6) / 15;
@@ -1136,7 +1161,7 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid
     const int ci = full_to_cam(i);
     const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
     double bred = 0.0, bdir = 0.0, dv, dr;
-    if (ci >= 0) { bred = T.vis[VIS_BRED + ci]; bdir = T.vis[VIS_BDIR + ci]; }
+    if (ci >= 0) { bred = d_vis(T, VIS_BRED + ci); bdir = d_vis(T, VIS_BDIR + ci); }
     double extra = 0.0;
     if (i >= 6) {
         const int fi = (i - 6) / 15;
@@ -1152,7 +1177,7 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid
     T.bs[i] = bred + extra;
     T.bfull[wset * 176 + i] = bdir + extra;
     d_hs_entry(T, valid, i, i, dv, dr);
-    T.diagfull[i] = ((ci >= 0) ? T.vis[VIS_DIAG + ci] : 0.0) + dr;
+    T.diagfull[i] = ((ci >= 0) ? d_vis(T, VIS_DIAG + ci) : 0.0) + dr;
     return bred + extra;
 }
 
@@ -1209,7 +1234,7 @@ __device__ __forceinline__ void d_assemble_body(const DeviceTables &T) {
         if (t < VIO_PD) { p_dx = T.dx[t]; p_bf = T.bfull[rset * 176 + t]; }          // b_ of the previous linearisation: read before d_rhs_entries replaces it
         if (T.has_prior && t < VIO_PRD) p_er = T.errprior[cur * 160 + t];
         if (t == 0) {
-            p_chi = T.vis[VIS_CHI]; p_step = T.vis[VIS_STEP + 1]; p_lmchi = T.lm->chi;
+            p_chi = d_vis(T, VIS_CHI); p_step = d_vis(T, VIS_STEP + 1); p_lmchi = T.lm->chi;
 #pragma unroll
             for (int k = 0; k < 10; ++k) p_imu[k] = ((valid >> k) & 1) ? T.imu_out[k * IMU_OUT + IMU_CHI] : 0.0;
         }
@@ -2081,12 +2106,12 @@ __device__ void d_lm_decide(const DeviceTables &T, int mode, int sum_local, doub
     if (tid != 0) return;
     double chi_imu = 0.0;
     for (int k = 0; k < T.n_imu_items; ++k) chi_imu += sImu[k];
-    double total = (sum_local ? c : T.step_tot[0]) + chi_imu;
+    double total = (sum_local ? c : d_step_tot(T, 0)) + chi_imu;
     if (T.has_prior) total += sqrt(en2);            // err_prior_.norm(), not squared (problem.cc:554-556)
     const double tempChi = 0.5 * total;
     lm->chi_try = tempChi;
     if (mode == 2) return;
-    double scale = 0.5 * ((sum_local ? s : T.step_tot[1]) + scale_p);
+    double scale = 0.5 * ((sum_local ? s : d_step_tot(T, 1)) + scale_p);
     scale += 1e-6;
     LmRegs regs;
     d_lm_load(lm, regs);
@@ -2110,7 +2135,7 @@ __global__ __launch_bounds__(256) void k_lm_decide_b(BatchArgs a, int mode) {
 }
 
 // ComputeLambdaInitLM (problem.cc:497-522)
-__device__ __forceinline__ void d_init_lm_body(const DeviceTables &T, int max_iter, const double *maxh_src) {
+__device__ __forceinline__ void d_init_lm_body(const DeviceTables &T, int max_iter) {
     __shared__ double s0[256];
     const int tid = threadIdx.x;
     LmState *lm = T.lm;
@@ -2122,11 +2147,11 @@ __device__ __forceinline__ void d_init_lm_body(const DeviceTables &T, int max_it
     const double en2 = d_block_sum<256>(e, s0, tid);
     const double maxd = d_block_max<256>(md, s0, tid);
     if (tid != 0) return;
-    double total = T.vis[VIS_CHI];
+    double total = d_vis(T, VIS_CHI);
     for (int k = 0; k < 10; ++k) if (T.imu_valid[k]) total += T.imu_out[k * IMU_OUT + IMU_CHI];
     if (T.has_prior) total += sqrt(en2);
     const double chi = 0.5 * total;
-    double maxDiagonal = fmax(maxd, *maxh_src);     // max |h_ll| over all shards
+    double maxDiagonal = fmax(maxd, d_vis_maxh(T));     // max |h_ll| over all shards
     maxDiagonal = fmin(5e10, maxDiagonal);
     lm->ni = 2.;
     lm->chi = chi;
@@ -2137,10 +2162,10 @@ __device__ __forceinline__ void d_init_lm_body(const DeviceTables &T, int max_it
     lm->finite = 1; lm->max_iter = max_iter; lm->accepted = 0; lm->need_linearize = 0; lm->pending = 0; lm->sys = 0;
     lm->chi_trace[0] = chi; lm->lambda_trace[0] = lm->lambda;
 }
-__global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter, const double *maxh_src) { d_init_lm_body(T, max_iter, maxh_src); }
+__global__ __launch_bounds__(256) void k_init_lm(DeviceTables T, int max_iter) { d_init_lm_body(T, max_iter); }
 __global__ __launch_bounds__(256) void k_init_lm_b(BatchArgs a, int max_iter) {
     const DeviceTables T = d_batch_tables(a);
-    d_init_lm_body(T, max_iter, T.vis + VIS_MAXH);
+    d_init_lm_body(T, max_iter);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2365,8 +2390,8 @@ __global__ void k_flip(LmState *lm) {
     if (threadIdx.x == 0) lm->cur ^= 1;
 }
 void vio_launch_flip(LmState *lm, hipStream_t s) { hipLaunchKernelGGL(k_flip, dim3(1), dim3(64), 0, s, lm); }
-void vio_launch_init_lm(const DeviceTables &T, int max_iter, const double *maxh_src, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter, maxh_src);
+void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s) {
+    hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter);
 }
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext) {
     return lin_lds_doubles(G, K, nb, use_ext);

@@ -53,6 +53,7 @@
 #define VIS_STEP (VIS_CHI + 1)               // 2 slots; [1]: landmark part of the previous GN step's gain-ratio denominator (k_reduce)
 #define VIS_MAXH (VIS_STEP + 2)              // max |h_ll| — first slot that is NOT summed across shards
 #define VIS_COUNT (VIS_MAXH + 1 + 4)         // padded to a multiple of 8
+#define VIS_SEND (VIS_MAXH + 1)              // what a shard sends: the slots summed in rank order, then max |h_ll| (max over the ranks)
 
 #define IMU_T 0
 #define IMU_G 900
@@ -176,6 +177,13 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     const int32_t *list_off;     // k_reduce's inverted lists (a batched launch builds its ReduceTables from here)
     const int32_t *list;
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
+    // Sharded windows (multi-GPU): the exchange is an ALL-GATHER of every shard's vis[0 .. VIS_SEND) resp. step_tot[0 .. 2) into
+    // these rank-major buffers, and whoever reads a sum forms it in rank order (d_vis, d_step_tot): every rank computes the
+    // identical bits whatever algorithm the collective library picks.  n_shards == 0: unsharded, vis / step_tot are read directly.
+    const double *gath;          // [n_shards][VIS_SEND]
+    const double *step_gath;     // [n_shards][2]
+    int32_t n_shards;
+    int32_t pad1_;
     LmState *lm;
     unsigned long long *dbg;     // diagnostic builds only (-DVIO_STAMPS): [block][16] s_memtime stamps
 };

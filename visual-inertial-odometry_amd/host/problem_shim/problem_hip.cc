@@ -214,13 +214,17 @@ FlatWindow flatten(Problem &p) {
 
 struct Ctx {
     struct vio_ctx *h = nullptr;
-    ~Ctx() { if (h) ABI(destroy)(h); }
 };
 
-// the one backend context of the process, created at the first graph and re-configured for every later one
+// The one backend context of the process, created at the first graph and re-configured for every later one.  It is never
+// destroyed: a static destructor would call into the HIP runtime (stream synchronise, frees) at process exit, in an order
+// relative to the runtime's own teardown that depends on how the host application was linked; the process's exit releases
+// the device.  Like the reference's Problem (process-global vertex / edge id counters, VM/src/backend/vertex.cc:7,
+// edge.cc:11; one caller thread under m_estimator, VM/src/System.cpp:358-441), Problems must not be solved or marginalised
+// from several threads at once: they share this context.
 Ctx &shared_ctx() {
-    static Ctx c;
-    return c;
+    static Ctx *c = new Ctx();
+    return *c;
 }
 
 // window + landmarks + observations + IMU edges + prior into the backend context

@@ -1,15 +1,20 @@
 """Landmark-sharded solve over the GPUs of one node.
 
 One process per GPU.  Every rank holds a block of the landmarks with all their observations; poses,
-speed-biases, extrinsic, pre-integrations and prior are replicated.  Per linearisation one all-reduce (sum) of the
-packed reduced visual system (the 78 upper blocks of the 72x72 H, reduced b, direct b, direct diagonal, chi2, the step's
-gain-ratio partial: 3027 fp64 = 24 KB; the library says how many, vio_exchange_buffers) and, on the stepwise path only, per
-trial step one all-reduce of two scalars (chi2 of the trial state, landmark part of the gain-ratio
-denominator); every rank then runs the identical damped LDLT and updates its own landmarks.  The collective is
-RCCL over xGMI on the GPU box: by default the library calls ncclAllReduce itself on its own stream (vio_comm_init; the
-communicator id is broadcast once through torch.distributed).  The portable alternative — and the gloo path of the CPU
-tests — is vio_set_exchange_hook: the library calls back at the two points of the LM loop where the exchange belongs
-and the hook runs torch.distributed.all_reduce on the bound exchange buffers.
+speed-biases, extrinsic, pre-integrations and prior are replicated.  Per linearisation ONE exchange of the packed
+partial reduced visual system (the 78 upper blocks of the 72x72 H, reduced b, direct b, direct diagonal, chi2, the step's
+gain-ratio partial, max |h_ll|: 3028 fp64 = 24 KB per rank; the library says how many, vio_exchange_buffers) and, on the
+stepwise path only, per trial step one of two scalars (chi2 of the trial state, landmark part of the gain-ratio
+denominator); every rank then runs the identical damped LDLT and updates its own landmarks.
+
+The exchange is an ALL-GATHER into rank-major receive buffers (vio_gather_buffers), and the library adds the ranks' slabs in
+rank order wherever it reads a sum: the same additions in the same order on every rank, so all ranks hold bit-identical
+systems and take bit-identical LM decisions by construction — not because the collective library happens to pick an
+algorithm that returns the same bits everywhere.  The collective is RCCL over xGMI on the GPU box: by default the library
+calls ncclAllGather itself on its own stream (vio_comm_init; the communicator id is broadcast once through
+torch.distributed).  The portable alternative — and the gloo path of the CPU tests — is vio_set_exchange_hook: the library
+calls back at the points of the LM loop where the exchange belongs and the hook runs torch.distributed.all_gather on the
+bound buffers.
 """
 import numpy as np
 
@@ -19,9 +24,9 @@ from . import synth
 class ShardedBackend:
     def __init__(self, lib, window, rank, world, dist=None, torch_device="cuda", ctx_kwargs=None, force_hook=False,
                  exchange=None):
-        """exchange: "native" — the library all-reduces with RCCL itself, in stream order, no Python in the loop
+        """exchange: "native" — the library all-gathers with RCCL itself, in stream order, no Python in the loop
         (HIP library on GPUs; the 128-byte communicator id travels through torch.distributed once);
-        "hook" — torch.distributed.all_reduce from the library's exchange hook (any backend: gloo in the CPU tests);
+        "hook" — torch.distributed.all_gather_into_tensor from the library's exchange hook (any backend: gloo in the CPU tests);
         "hook_host" — the same hook staging the buffers through pinned host memory: gloo between processes whose tensors
         live on a GPU (RCCL refuses two ranks on one device; this is how the two-rank protocol runs on a one-GPU box).
         Default: native when the library exports it and the device is a GPU, unless VIO_EXCHANGE says otherwise."""
@@ -45,11 +50,17 @@ class ShardedBackend:
         self.ctx = lib.context(**kw)
         self.ctx.load(self.shard)
         (_, self.n_red), (_, self.n_sc) = self.ctx.exchange_buffers()
-        # caller-owned exchange buffers so that the collective runs in place on them
+        # caller-owned exchange buffers so that the collective runs in place on them: send side ...
         self.red = torch.zeros(self.n_red + 8, dtype=torch.float64, device=torch_device)
         self.sca = torch.zeros(8, dtype=torch.float64, device=torch_device)
         self.ctx.bind_exchange_buffers(self.red.data_ptr(), self.sca.data_ptr())
-        self._views = (self.red[:self.n_red], self.sca[:self.n_sc], self.sca[2:3])
+        # ... and receive side, rank-major: [world][n_red], [world][n_sc]
+        self.gred = torch.zeros(world * self.n_red, dtype=torch.float64, device=torch_device)
+        self.gsca = torch.zeros(world * self.n_sc, dtype=torch.float64, device=torch_device)
+        self.ctx.bind_gather_buffers(self.gred.data_ptr(), self.gsca.data_ptr())
+        self._send = (self.red[:self.n_red], self.sca[:self.n_sc])
+        self._recv = (self.gred, self.gsca)
+        self._max_view = self.sca[2:3]
         self.exchange = exchange if (world > 1 or force_hook) else "none"
         if self.exchange == "native":
             idt = torch.zeros(128, dtype=torch.uint8, device=torch_device)
@@ -61,18 +72,30 @@ class ShardedBackend:
         elif self.exchange == "hook":     # force_hook: exercise the exchange path on a single rank (tests)
             self.ctx.set_exchange_hook(self._exchange)
         elif self.exchange == "hook_host":
-            self._host = [torch.zeros(v.shape, dtype=v.dtype).pin_memory() for v in self._views]
+            self._hsend = [torch.zeros(v.shape, dtype=v.dtype).pin_memory() for v in self._send]
+            self._hrecv = [torch.zeros(v.shape, dtype=v.dtype).pin_memory() for v in self._recv]
+            self._hmax = torch.zeros(1, dtype=torch.float64).pin_memory()
             self.ctx.set_exchange_hook(self._exchange_host)
 
     def _on_stream(self):
         import contextlib
         return self.torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
+    def _all_gather(self, recv, send):
+        """recv[r * n : (r + 1) * n] = rank r's send, on every rank."""
+        if self.world == 1 or self.dist is None:
+            recv.copy_(send)
+        else:
+            self.dist.all_gather_into_tensor(recv, send)
+
     def _exchange(self, which):
         try:
-            op = self.dist.ReduceOp.MAX if which == 2 else self.dist.ReduceOp.SUM
             with self._on_stream():
-                self.dist.all_reduce(self._views[which], op=op)
+                if which == 2:      # CPU libraries: max |h_ll| over the shards, in place (the HIP library carries it in the slab)
+                    if self.world > 1:
+                        self.dist.all_reduce(self._max_view, op=self.dist.ReduceOp.MAX)
+                else:
+                    self._all_gather(self._recv[which], self._send[which])
             return 0
         except Exception as exc:      # the C side turns a non-zero return into VIO_ERR_HIP
             print("exchange hook failed:", exc)
@@ -80,12 +103,17 @@ class ShardedBackend:
 
     def _exchange_host(self, which):
         try:
-            v, h = self._views[which], self._host[which]
             with self._on_stream():
-                h.copy_(v)              # D2H on the stream the library enqueues on: waits for the kernels before it
-                if self.world > 1:
-                    self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX if which == 2 else self.dist.ReduceOp.SUM)
-                v.copy_(h)
+                if which == 2:
+                    self._hmax.copy_(self._max_view)
+                    if self.world > 1:
+                        self.dist.all_reduce(self._hmax, op=self.dist.ReduceOp.MAX)
+                    self._max_view.copy_(self._hmax)
+                else:
+                    hs, hr = self._hsend[which], self._hrecv[which]
+                    hs.copy_(self._send[which])     # D2H on the stream the library enqueues on: waits for the kernels before it
+                    self._all_gather(hr, hs)
+                    self._recv[which].copy_(hr)
             return 0
         except Exception as exc:
             print("exchange hook failed:", exc)
@@ -99,7 +127,7 @@ class ShardedBackend:
 
     def marginalize(self, kind):
         """Problem::Marginalize over the shards (SURVEY.md section 8e): every rank forms the partial Schur system of
-        its own frame-0-hosted landmarks, the same all-reduce as a linearisation sums them, and every rank runs the
+        its own frame-0-hosted landmarks, the same exchange as a linearisation's sums them in rank order, and every rank runs the
         identical eigen-decomposition tail on the identical 171x171 system — the new prior needs no broadcast."""
         return self.ctx.marginalize(kind)
 
