@@ -144,9 +144,13 @@ vio_status vio_set_observations(struct vio_ctx *ctx, int64_t m, const int32_t *l
  *      extrinsic vertex first) is unchanged; the extrinsic is a constant of these edges (SetTranslationImuFromCamera,
  *      edge_reprojection.cc:142-145), not one of their vertices, so it gets no visual information.
  *      In this mode the landmark arrays of vio_get_delta / vio_get_landmark_system hold 3 (bl, delta) resp. 9 (H_ll,
- *      row-major 3x3) doubles per landmark.  vio_marginalize(VIO_MARG_OLD) is VIO_ERR_UNSUPPORTED: Problem::Marginalize
- *      keeps only the edges connected to the marginalised pose (problem.cc:621), which leaves every 3x3 landmark block
- *      with the rank 2 of a single observation — the reference has no caller for it either. */
+ *      row-major 3x3) doubles per landmark.  vio_marginalize(VIO_MARG_OLD) is Problem::Marginalize({pose_0, sb_0}) on the
+ *      window's graph (generic over the landmark dimension, problem.cc:617-795; the reference's Estimator has no caller
+ *      for it): it keeps the edges connected to the marginalised pose (:621) — IMU edge 0 -> 1 and the frame-0 observation
+ *      of every landmark seen from there — so every landmark block it eliminates has the rank 2 of a single observation
+ *      and is inverted all the same (:697-700).  The visual part of the result is therefore what rounding leaves of a term
+ *      that is zero in exact arithmetic, in the reference as here; a block whose elimination meets an
+ *      exact zero gives the reference's NaN prior and VIO_ERR_NOT_FINITE. */
 /* VertexPointXYZ x N: world coordinates xyz[n][3] */
 vio_status vio_set_landmarks_xyz(struct vio_ctx *ctx, int64_t n, const double *xyz);
 /* EdgeReprojectionXYZ x M: edge e connects landmark lm[e] and the pose of frame[e]; pts_xy is the normalised
@@ -224,7 +228,12 @@ vio_status vio_triangulate(struct vio_ctx *ctx, int64_t n_tracks, const int32_t 
 
 /* ---- marginalisation: Marg{Old,New}Frame + Problem::Marginalize  problem.cc:617-795 ------ */
 /* Uses the window/landmarks/observations/IMU/prior currently set.  Outputs the new prior
- * (VIO_PRIOR_DIM): H dim x dim, b, err, jt_inv dim x dim. */
+ * (VIO_PRIOR_DIM): H dim x dim, b, err, jt_inv dim x dim.
+ * VIO_ERR_NOT_FINITE: a landmark of the marginalisation graph has a block without an inverse (every edge weighted to zero
+ * by the loss; a rank-deficient 3x3 block whose elimination met an exact zero pivot).  The reference's dense
+ * Hpm * Hmm^-1 (problem.cc:701-703) is then NaN throughout, its eigen-solvers return NaN spectra, every `> eps` test fails
+ * and Marginalize returns true with H_prior_ = 0 and b_prior_, err_prior_, Jt_prior_inv_ all NaN: the outputs hold exactly
+ * that, and the status says so. */
 vio_status vio_marginalize(struct vio_ctx *ctx, int32_t kind, double *H, double *b, double *err,
                            double *jt_inv);
 

@@ -1211,9 +1211,8 @@ static void accum_edge(struct vioo_ctx *c, int64_t e, int fixed, double *Hv, dou
 }
 
 /* one landmark's Schur terms: S += Hpm Hmm^-1 Hmp, sb += Hpm Hmm^-1 b_l (problem.cc:419-429) */
-static void accum_schur(struct vioo_ctx *c, int64_t l, int marg_mode, double *S, double *sb, double *maxh, int *degenerate) {
+static void accum_schur(struct vioo_ctx *c, int64_t l, double *S, double *sb, double *maxh, int *degenerate) {
     const double *w = &c->Hpl[(size_t)l * CD];
-    if (marg_mode && c->hll[l] == 0.0) return;         /* landmark not in the marginalisation graph */
     *maxh = fmax(*maxh, fabs(c->hll[l]));
     double hinv = 1.0 / c->hll[l];                      /* Hmm_inv (problem.cc:419-425) */
     /* a landmark without information (every edge weighted to zero by the loss): the reference's dense tempH = Hpm *
@@ -1272,7 +1271,12 @@ static void accum_schur_xyz(struct vioo_ctx *c, int64_t l, double *S, double *sb
     }
 }
 
-static void linearize_visual_xyz(struct vioo_ctx *c) {
+/* marg_mode: Problem::Marginalize of an XYZ graph (problem.cc:617-715): only the edges connected to the marginalised pose
+ * (GetConnectedEdges(margVertexs[0]), :621) — a landmark seen from frame 0 enters with that ONE observation, whatever else
+ * observes it — and only the landmarks those edges touch (:627-637).  One EdgeReprojectionXYZ leaves a 3x3 Hmm block of rank
+ * 2; the reference inverts it all the same (:697-700, Eigen's PartialPivLU of the dynamic block: the third pivot is what
+ * rounding left of an exact zero), and so does this: bug-compatible, and documented as such in DESIGN.md section 2. */
+static void linearize_visual_xyz(struct vioo_ctx *c, int marg_mode) {
     double *Hv = c->Hv_dir;
     double bv[CD], sb[CD];
     memset(Hv, 0, sizeof(double) * CD * CD); memset(bv, 0, sizeof(bv)); memset(sb, 0, sizeof(sb));
@@ -1282,8 +1286,14 @@ static void linearize_visual_xyz(struct vioo_ctx *c) {
     double chi = 0, maxh = 0;
     double *S = (double *)calloc(CD * CD, sizeof(double));
     int degenerate = 0;
-    for (int64_t e = 0; e < c->M; ++e) accum_edge_xyz(c, e, Hv, bv, &chi);
-    for (int64_t l = 0; l < c->N; ++l) accum_schur_xyz(c, l, S, sb, &maxh, &degenerate);
+    unsigned char *in_graph = (unsigned char *)calloc(nn, 1);       /* the landmarks the graph's edges touch (problem.cc:627-637) */
+    for (int64_t e = 0; e < c->M; ++e) {
+        if (marg_mode && c->target[e] != 0) continue;
+        in_graph[c->lm[e]] = 1;
+        accum_edge_xyz(c, e, Hv, bv, &chi);
+    }
+    for (int64_t l = 0; l < c->N; ++l) if (!marg_mode || in_graph[l]) accum_schur_xyz(c, l, S, sb, &maxh, &degenerate);
+    free(in_graph);
     for (int a = 0; a < CD; ++a) {
         for (int b2 = 0; b2 < CD; ++b2) c->vis[VIS_H + a * CD + b2] = Hv[a * CD + b2] - S[a * CD + b2];
         c->vis[VIS_BRED + a] = bv[a] - sb[a];
@@ -1301,7 +1311,7 @@ static void linearize_visual_xyz(struct vioo_ctx *c) {
 }
 
 static void linearize_visual(struct vioo_ctx *c, int marg_mode) {
-    if (c->lm_dim == 3) { linearize_visual_xyz(c); return; }
+    if (c->lm_dim == 3) { linearize_visual_xyz(c, marg_mode); return; }
     const int fixed = marg_mode ? 0 : c->cfg.ext_fixed;
     double *Hv = c->Hv_dir;
     double bv[CD];
@@ -1340,7 +1350,7 @@ static void linearize_visual(struct vioo_ctx *c, int marg_mode) {
             if (l1 > l0) memset(c->Hpl + (size_t)l0 * CD, 0, sizeof(double) * (size_t)(l1 - l0) * CD);
             for (int64_t l = l0; l < l1; ++l) {
                 for (int64_t q = off[l]; q < off[l + 1]; ++q) accum_edge(c, idx[q], fixed, Hv_t, bv_t, &sc[0]);
-                accum_schur(c, l, marg_mode, S_t, sb_t, &sc[1], &deg);
+                if (!marg_mode || off[l + 1] > off[l]) accum_schur(c, l, S_t, sb_t, &sc[1], &deg);     /* (a landmark no marginalisation edge touches is not in that graph) */
             }
             sc[2] = deg;
         }
@@ -1354,12 +1364,17 @@ static void linearize_visual(struct vioo_ctx *c, int marg_mode) {
         free(Hp); free(fill); free(idx); free(off);
     }
 #else
+    /* the marginalisation graph holds the landmarks its edges touch (problem.cc:627-637) — also one whose every edge the loss
+     * weights to zero: its Hmm block is 0 and its "inverse" poisons the dense products, in the reference as here */
+    unsigned char *in_graph = (unsigned char *)calloc((size_t)(c->N > 0 ? c->N : 1), 1);
     for (int64_t e = 0; e < c->M; ++e) {
         if (marg_mode && c->host[e] != 0) continue;
+        in_graph[c->lm[e]] = 1;
         accum_edge(c, e, fixed, Hv, bv, &chi);
     }
     /* Schur terms, landmarks in index order */
-    for (int64_t l = 0; l < c->N; ++l) accum_schur(c, l, marg_mode, S, sb, &maxh, &degenerate);
+    for (int64_t l = 0; l < c->N; ++l) if (!marg_mode || in_graph[l]) accum_schur(c, l, S, sb, &maxh, &degenerate);
+    free(in_graph);
 #endif
     for (int a = 0; a < CD; ++a) {
         for (int b2 = 0; b2 < CD; ++b2) c->vis[VIS_H + a * CD + b2] = Hv[a * CD + b2] - S[a * CD + b2];
@@ -1793,10 +1808,6 @@ void vioo_schur_pinv(int n, int m2, const double *H, const double *b, double *Hp
 vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, double *bout, double *errout, double *jtout) {
     if (!c || !Hout || !bout || !errout || !jtout) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
-    if (kind == VIO_MARG_OLD && c->lm_dim == 3) {
-        snprintf(c->err, sizeof(c->err), "MargOldFrame is not defined for XYZ landmarks (include/vio_backend.h)");
-        return VIO_ERR_UNSUPPORTED;
-    }
     const int n = PD;
     double *H = (double *)calloc(n * n, sizeof(double));
     double b[PD];
@@ -1848,6 +1859,13 @@ vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, doubl
     }
     memcpy(bout, bp, sizeof(double) * n2);
     free(H); free(Hp); free(ev2); free(V2);
+    /* a landmark block without an inverse: the reference's Marginalize returns true with H_prior_ = 0 and b_prior_, err_prior_,
+     * Jt_prior_inv_ all NaN (the arithmetic above has just produced that); the status says so */
+    for (int i = 0; i < n2; ++i)
+        if (!isfinite(bout[i])) {
+            snprintf(c->err, sizeof(c->err), "vio_marginalize: a landmark block has no inverse; the prior is the reference's outcome for that case");
+            return VIO_ERR_NOT_FINITE;
+        }
     return VIO_OK;
 }
 

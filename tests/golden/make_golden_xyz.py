@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates the XYZ-landmark fixtures tests/golden/window_xyz_*.npz, reproj_xyz_edges.npz and inverse3.npz from the
+"""Generates the XYZ-landmark fixtures tests/golden/window_xyz_*.npz, marg0_xyz_*.npz, reproj_xyz_edges.npz and inverse3.npz from the
 COMPILED REFERENCE (oracle/_ref/libvio_ref.so): VertexPointXYZ (vertex_point_xyz.h) + EdgeReprojectionXYZ
 (edge_reprojection.cc:130-180) inside the reference's own Problem, graphs built by oracle/ref_harness.cpp.
 
@@ -76,6 +76,59 @@ wL = vio.synth.make_window_xyz(200, seed=54, outlier_fraction=0.05, pos_noise=0.
                                xyz_noise=0.003)
 for loss, nm in ((vio.LOSS_TUKEY, "tukey"), (vio.LOSS_TRIVIAL, "trivial")):
     window_case("window_xyz_n200_s54_" + nm, wL, loss=loss, solve=False)
+# Problem::Marginalize on an XYZ graph (generic over the landmark dimension, problem.cc:617-795; no caller in Estimator): only the
+# edges connected to pose 0 enter (:621), so every landmark seen from frame 0 has ONE observation and a 3x3 block of rank 2, which
+# the reference inverts all the same (:697-700).  What comes out is the marginalisation of the graph WITHOUT reprojection edges
+# (a single view of a free point says nothing about the pose) plus whatever rounding leaves of H_pl H_ll^-1 H_lp - H_pp(direct) —
+# noise of the size of the visual information itself — or NaN when an elimination meets an exact zero pivot (about one landmark
+# in eight).  Fixtures: two finite cases with the reference's own edge-free result beside them (the size of its noise), and one
+# whose frame-0 observation of a landmark is an outlier beyond Tukey's delta: weight exactly 0, H_ll exactly 0, NaN by construction.
+def edge_free(w):
+    w0 = w.copy()
+    w0.xyz, w0.xyz_gt = np.zeros((0, 3)), np.zeros((0, 3))
+    w0.lm, w0.frame, w0.pts = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2))
+    w0.n_landmarks = w0.n_observations = 0
+    return w0
+
+
+def marg0_case(name, w, **kw):
+    d = tu.window_to_arrays(w)
+    for k, v in kw.items():
+        d["cfg_" + k] = np.int32(v) if isinstance(v, int) else np.float64(v)
+    ctx = ref.context(**kw)
+    ctx.load(w)
+    m = ctx.marginalize(vio.MARG_OLD, allow_nonfinite=True)
+    d.update({"marg0_" + k: v for k, v in m.items()})
+    ctx = ref.context(**kw)
+    ctx.load(edge_free(w))
+    e = ctx.marginalize(vio.MARG_OLD)
+    d.update({"marg0_free_" + k: e[k] for k in ("H", "b")})
+    d["marg0_finite"] = np.int32(np.isfinite(m["b"]).all())
+    save(name, **d)
+    return m, e
+
+
+prior_A = {k: zA["marg0_" + k] for k in tu.PRIOR_FIELDS}
+n_fin = 0
+for seed in range(61, 100):
+    w = vio.synth.make_window_xyz(20, seed=seed, t0=1.1)
+    w.prior = prior_A
+    c_ = ref.context()
+    c_.load(w)
+    if not np.isfinite(c_.marginalize(vio.MARG_OLD, allow_nonfinite=True)["b"]).all():
+        continue
+    m, e = marg0_case("marg0_xyz_n20_s%d" % seed, w)
+    print("   frame-0 landmarks %d, |H - H_edge_free|max %.3g (prior max %.3g)" % (len(np.unique(w.lm[w.frame == 0])), np.abs(m["H"] - e["H"]).max(), np.abs(e["H"]).max()))
+    n_fin += 1
+    if n_fin == 4:
+        break
+wN = vio.synth.make_window_xyz(40, seed=71, t0=1.1)
+wN.prior = prior_A
+first0 = int(np.flatnonzero(wN.frame == 0)[0])
+wN.pts[first0] += np.array([0.3, -0.2])            # e = s |r| ~ 100 >> delta = 1: Tukey's rho' is exactly 0 out there
+m, _ = marg0_case("marg0_xyz_n40_s71_tukey_nan", wN, loss_type=vio.LOSS_TUKEY)
+assert not np.isfinite(m["b"]).any() and (m["H"] == 0).all()
+
 # delta_x only at N = 2000 (the dense reference needs (171 + 6000)^2 doubles = 305 MB here)
 wF = vio.synth.make_window_xyz(2000, seed=42)
 ctx = ref.context()

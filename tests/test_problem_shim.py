@@ -101,6 +101,29 @@ def test_window_chain_through_reference_objects(vio, oracle_lib, shim_lib, ref_l
         np.testing.assert_allclose(ns[k], no[k], rtol=0, atol=1e-9 * max(1.0, np.abs(no[k]).max()))
 
 
+def test_xyz_graph_marginalize_through_reference_objects(vio, oracle_lib, shim_lib):
+    """Problem::Marginalize of a graph of VertexPointXYZ / EdgeReprojectionXYZ objects (generic over the landmark dimension,
+    problem.cc:617-795): the harness hands the shim the whole graph, the backend keeps the edges connected to pose 0 as
+    Marginalize does (:621).  Same backend arithmetic behind the shim as called directly: the same prior; and the reference's
+    NaN outcome (a landmark block without an inverse) comes back through Problem's getters as it does from the reference."""
+    import os
+    from conftest import GOLDEN_DIR
+    import vio_testutil as tu
+    z = np.load(os.path.join(GOLDEN_DIR, "marg0_xyz_n20_s61.npz"))
+    w = tu.arrays_to_window(vio, z)
+    cs, co = shim_lib.context(), oracle_lib.context()
+    cs.load(w)
+    co.load(w)
+    ms, mo = cs.marginalize(vio.MARG_OLD), co.marginalize(vio.MARG_OLD)
+    for k in ("H", "b", "err", "jt_inv"):
+        np.testing.assert_allclose(ms[k], mo[k], rtol=0, atol=1e-9 * max(1.0, np.abs(mo[k]).max()))
+    zn = np.load(os.path.join(GOLDEN_DIR, "marg0_xyz_n40_s71_tukey_nan.npz"))
+    cs = shim_lib.context(loss_type=int(zn["cfg_loss_type"]))
+    cs.load(tu.arrays_to_window(vio, zn))
+    mn = cs.marginalize(vio.MARG_OLD, allow_nonfinite=True)
+    assert (mn["H"] == 0).all() and np.isnan(mn["b"]).all() and np.isnan(mn["jt_inv"]).all()
+
+
 def test_shim_rejects_what_the_window_cannot_express(vio, shim_lib):
     w = vio.synth.make_window(0, seed=5)
     w.preint = [None] * 10

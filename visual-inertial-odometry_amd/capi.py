@@ -328,12 +328,15 @@ class VioContext:
         self._ck(self.lib.fn["get_stream"](self.h, C.byref(st)), "get_stream")
         return st.value
 
-    def marginalize(self, kind):
+    def marginalize(self, kind, allow_nonfinite=False):
+        """The new prior.  allow_nonfinite: VIO_ERR_NOT_FINITE (a landmark block without an inverse) hands back what the reference
+        leaves in that case — H_prior 0, the rest NaN — instead of raising."""
         H = np.zeros((PRIOR_DIM, PRIOR_DIM))
         b, err = np.zeros(PRIOR_DIM), np.zeros(PRIOR_DIM)
         jt = np.zeros((PRIOR_DIM, PRIOR_DIM))
-        self._ck(self.lib.fn["marginalize"](self.h, C.c_int32(kind), _dp(H), _dp(b), _dp(err), _dp(jt)),
-                 "marginalize")
+        st = self.lib.fn["marginalize"](self.h, C.c_int32(kind), _dp(H), _dp(b), _dp(err), _dp(jt))
+        if not (st == -3 and allow_nonfinite):
+            self._ck(st, "marginalize")
         return {"H": H, "b": b, "err": err, "jt_inv": jt}
 
     # ---- read back ------------------------------------------------------------------------

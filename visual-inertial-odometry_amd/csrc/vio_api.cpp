@@ -291,13 +291,16 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *
 
 // The plan of a window of XYZ landmarks (vio_kernels_xyz.h): a pattern is the set of frames a landmark is seen from,
 // one pattern block per frame, no host frame and no extrinsic block.
-vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
+// marg: Problem::Marginalize's graph (problem.cc:617-637): the edges connected to the pose of frame 0 and the landmarks they touch —
+// a landmark seen from frame 0 enters with that one observation, whatever else observes it.
+vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
     pl.valid = false;
-    pl.marg = 0; pl.use_ext = 0; pl.lm_dim = 3;
+    pl.marg = marg; pl.use_ext = 0; pl.lm_dim = 3;
     const int64_t N = (int64_t)c->h_invd.size() / 3, M = (int64_t)c->h_olm.size();
     // observation of landmark l in frame f: obs_at[l * NF + f] (or -1)
     std::vector<int32_t> obs_at((size_t)std::max<int64_t>(N, 1) * NF, -1);
     for (int64_t e = 0; e < M; ++e) {
+        if (marg && c->h_otarget[e] != 0) continue;
         int32_t &slot = obs_at[(size_t)c->h_olm[e] * NF + c->h_otarget[e]];
         if (slot >= 0) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
         slot = (int32_t)e;
@@ -307,7 +310,10 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
     for (int64_t l = 0; l < N; ++l) {
         int m = 0;
         for (int f = 0; f < NF; ++f) if (obs_at[(size_t)l * NF + f] >= 0) m |= 1 << f;
-        if (m == 0) return fail(c, VIO_ERR_UNSUPPORTED, "landmark without observations (its 3x3 Hessian block would be singular)");
+        if (m == 0) {
+            if (marg) continue;
+            return fail(c, VIO_ERR_UNSUPPORTED, "landmark without observations (its 3x3 Hessian block would be singular)");
+        }
         mask[l] = m;
         if (pat_of_mask[m] < 0) {
             pat_of_mask[m] = (int)pl.patterns.size();
@@ -333,15 +339,15 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
     }
     {   // counting sort: pattern-major, original index inside a pattern
         std::vector<int64_t> start(pl.patterns.size() + 1, 0);
-        for (int64_t l = 0; l < N; ++l) ++start[lm_pattern[l] + 1];
+        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) ++start[lm_pattern[l] + 1];
         for (size_t q = 0; q < pl.patterns.size(); ++q) start[q + 1] += start[q];
-        pl.sorted_to_orig.assign((size_t)N, 0);
-        for (int64_t l = 0; l < N; ++l) pl.sorted_to_orig[start[lm_pattern[l]]++] = (int32_t)l;
+        pl.sorted_to_orig.assign((size_t)start[pl.patterns.size()], 0);
+        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) pl.sorted_to_orig[start[lm_pattern[l]]++] = (int32_t)l;
     }
-    pl.Ns = N;
+    pl.Ns = (int64_t)pl.sorted_to_orig.size();
     {   // landmarks per item: whole rounds of the device's CUs, as build_plan does, within what the LDS holds per pattern
         std::vector<int64_t> n_of(pl.patterns.size(), 0);
-        for (int64_t l = 0; l < N; ++l) ++n_of[lm_pattern[l]];
+        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) ++n_of[lm_pattern[l]];
         const int cus = std::max(1, c->n_cus);
         int best_g = 0;
         double best_cost = 0.0;
@@ -408,7 +414,7 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl) {
 
 vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     c->marg_map_valid = false;
-    if (c->lm_dim == 3) return build_plan_xyz(c, pl);
+    if (c->lm_dim == 3) return build_plan_xyz(c, pl, marg);
     pl.valid = false;
     pl.marg = marg; pl.lm_dim = 1;
     pl.use_ext = marg ? 1 : (c->cfg.ext_fixed ? 0 : 1);
@@ -1633,7 +1639,6 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
     if (!c || !H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
     enter_device(c);
-    if (kind == VIO_MARG_OLD && c->lm_dim == 3) return fail(c, VIO_ERR_UNSUPPORTED, "MargOldFrame is not defined for XYZ landmarks (include/vio_backend.h)");
     static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     if (!c->marg_stage) HIPCHK(hipHostMalloc((void **)&c->marg_stage, ((size_t)PD * PD + PD) * 8, hipHostMallocDefault));      // pinned: the 234 KB come back by DMA
@@ -1669,7 +1674,19 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
         std::memcpy(bm, c->h_bprior.data(), (size_t)PD * 8);
     }
     const auto t1 = std::chrono::steady_clock::now();
-    const int live_rows = vio_host::marginalize_tail(Hm, bm, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, H, b, err, jt);
+    // A landmark block without an inverse (h_ll == 0; a 3x3 block of XYZ landmarks that the marginalisation graph left at rank 2 and
+    // whose elimination hit an exact zero pivot) makes the reference's dense Hpm * Hmm^-1 (problem.cc:701-703) non-finite everywhere;
+    // its two eigen-solvers then return NaN spectra, every `> eps` test fails (:747-769), the 1e-9 cut zeroes H_prior_ (:778) and
+    // b_prior_, err_prior_, Jt_prior_inv_ are NaN.  The same outcome here, said in the status as well.
+    bool finite_in = true;
+    for (size_t i = 0; i < (size_t)PD * PD + PD && finite_in; ++i) finite_in = std::isfinite(Hm[i]);
+    int live_rows = 0;
+    if (finite_in) live_rows = vio_host::marginalize_tail(Hm, bm, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, H, b, err, jt);
+    else {
+        const double nan = std::nan("");
+        std::fill(H, H + (size_t)PRD * PRD, 0.0); std::fill(jt, jt + (size_t)PRD * PRD, nan);
+        std::fill(b, b + PRD, nan); std::fill(err, err + PRD, nan);
+    }
     {
         const auto t2 = std::chrono::steady_clock::now();
         c->timing[3] = std::chrono::duration<double, std::micro>(t1 - t0).count();
@@ -1678,6 +1695,7 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
         if (timing) std::fprintf(stderr, "[vio host timing] vio_marginalize(kind=%d): activate + kernels + read-back %.0f us, host tail %.0f us\n", kind,
                      std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count());
     }
+    if (!finite_in) return fail(c, VIO_ERR_NOT_FINITE, "vio_marginalize: a landmark block has no inverse; the prior is the reference's outcome for that case (H_prior 0, the rest NaN)");
     return VIO_OK;
 }
 

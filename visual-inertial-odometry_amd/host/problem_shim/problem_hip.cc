@@ -350,7 +350,10 @@ bool Problem::Marginalize(const std::vector<std::shared_ptr<Vertex>> margVertexs
     Ctx &c = shared_ctx();
     if (!upload(*this, w, c)) return false;
     std::vector<double> H((size_t)PRD * PRD), J((size_t)PRD * PRD), b(PRD), err(PRD);
-    if (ABI(marginalize)(c.h, k == 0 ? VIO_MARG_OLD : VIO_MARG_SECOND_NEW, H.data(), b.data(), err.data(), J.data()) != VIO_OK) {
+    // (VIO_ERR_NOT_FINITE: a landmark block without an inverse — the backend has filled the outputs with what the reference's
+    // Marginalize leaves in that case, H_prior_ = 0 and NaN elsewhere, and the reference returns true: so does this)
+    const vio_status mst = ABI(marginalize)(c.h, k == 0 ? VIO_MARG_OLD : VIO_MARG_SECOND_NEW, H.data(), b.data(), err.data(), J.data());
+    if (mst != VIO_OK && mst != VIO_ERR_NOT_FINITE) {
         std::cerr << "vio_marginalize: " << ABI(last_error)(c.h) << std::endl;
         return false;
     }
