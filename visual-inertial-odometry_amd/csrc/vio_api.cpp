@@ -57,6 +57,7 @@ void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_bl
                          size_t ps_lds, hipStream_t s);
 int vio_set_kernel_attributes();
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext);
+int lin_threads_host();
 int xyz_lds_doubles_host(int G, int K);
 
 namespace {
@@ -280,9 +281,9 @@ void build_pattern_tables(Pattern &pt, int g_max) {
     }
     for (int k = 0; k < K; ++k) kof[pt.tslot[k]] = k;
     pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
-    int G = std::max(1, std::min(g_max, 1024 / K));          // one thread per observation in k_linearize's phase 1
+    int G = std::max(1, std::min(g_max, lin_threads_host() / K));          // one thread per observation in k_linearize's phase 1
     while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext) > LDS_BUDGET_DOUBLES) --G;
-    while (G > 1 && (6 * nb + 2) * G > 7 * 1024) --G;        // k_linearize stages the item's Schur rows with 7 loads per thread
+    while (G > 1 && (6 * nb + 2) * G > 7 * lin_threads_host()) --G;        // k_linearize stages the item's Schur rows with 7 loads per thread
     pt.G = G;
     pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
 }
@@ -329,7 +330,7 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
             }
             pt.K = pt.nb = p;
             pt.n_rows = item_nbp(pt.nb) * 6 + 3 * pt.nb;
-            int G = std::max(1, std::min(c->g_max > 0 ? c->g_max : 128, 1024 / pt.K));
+            int G = std::max(1, std::min(c->g_max > 0 ? c->g_max : 128, lin_threads_host() / pt.K));
             while (G > 1 && xyz_lds_doubles_host(G, pt.K) > LDS_BUDGET_DOUBLES) --G;
             pt.G = G;
             pt.lds_doubles = xyz_lds_doubles_host(G, pt.K);

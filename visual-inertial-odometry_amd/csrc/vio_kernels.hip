@@ -26,7 +26,11 @@
 #include "vio_device_math.h"
 #include "vio_types.h"
 
+// threads of a k_linearize / k_linearize_xyz workgroup.  One workgroup holds a CU (its LDS), so the register budget of a thread is
+// 512 / (LIN_THREADS / 256): 128 at 1024 threads (16 waves, 4 per SIMD), 170 at 768 (12 waves, 3 per SIMD).
+#ifndef LIN_THREADS
 #define LIN_THREADS 1024
+#endif
 
 // In-kernel stamps exist only in the diagnostic build (-DVIO_STAMPS -> libvio_hip_stamps.so, never shipped or timed)
 #ifdef VIO_STAMPS
@@ -2393,6 +2397,7 @@ void vio_launch_flip(LmState *lm, hipStream_t s) { hipLaunchKernelGGL(k_flip, di
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter);
 }
+int lin_threads_host() { return LIN_THREADS; }
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext) {
     return lin_lds_doubles(G, K, nb, use_ext);
 }
