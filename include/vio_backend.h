@@ -236,6 +236,15 @@ vio_status vio_triangulate(struct vio_ctx *ctx, int64_t n_tracks, const int32_t 
  * that, and the status says so. */
 vio_status vio_marginalize(struct vio_ctx *ctx, int32_t kind, double *H, double *b, double *err,
                            double *jt_inv);
+/* The same in two halves: vio_marginalize == vio_marginalize_begin + vio_marginalize_end.
+ * begin returns when the device part is done (graph assembly, landmark Schur complement, the 171x171 read-back) and the dense
+ * tail (problem.cc:717-779: two eigen-decompositions and three products, 0.2 - 0.5 ms on a host core) runs on a helper thread of
+ * the library; end waits for it and hands the prior out.  In between the context is the caller's as usual: the frame loop calls
+ * begin where MargOldFrame stood (estimator.cpp:1088-1092), goes on with slideWindow, the next image, the next window's
+ * vio_set_window / landmarks / observations / imu, and calls end where the new prior is first needed — in front of vio_set_prior
+ * (estimator.cpp:1023-1034).  A second begin, or vio_destroy, waits for an unfinished tail itself. */
+vio_status vio_marginalize_begin(struct vio_ctx *ctx, int32_t kind);
+vio_status vio_marginalize_end(struct vio_ctx *ctx, double *H, double *b, double *err, double *jt_inv);
 
 /* ---- read back ------------------------------------------------------------------------------ */
 vio_status vio_get_window(struct vio_ctx *ctx, double *poses, double *speed_bias, double *ext);

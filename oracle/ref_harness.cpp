@@ -70,6 +70,8 @@
 #undef vio_gn_iteration
 #undef vio_synchronize
 #undef vio_marginalize
+#undef vio_marginalize_begin
+#undef vio_marginalize_end
 #undef vio_get_window
 #undef vio_get_landmarks
 #undef vio_get_prior

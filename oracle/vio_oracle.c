@@ -985,6 +985,9 @@ struct vioo_ctx {
     vio_exchange_fn hook;
     void *hook_user;
     int nonfinite;               /* a trial chi2 was not finite during the last vio_solve (reported as VIO_ERR_NOT_FINITE) */
+    double *mo_H, *mo_jt, mo_b[PRD], mo_err[PRD];      /* vio_marginalize_begin's result, kept for vio_marginalize_end */
+    int mo_pending;
+    vio_status mo_status;
 };
 
 static int cam_to_full(int c) { return c < 6 ? c : 6 + 15 * ((c - 6) / 6) + (c - 6) % 6; }
@@ -1044,7 +1047,7 @@ void vio_destroy(struct vioo_ctx *c) {
     if (!c) return;
     free(c->invd); free(c->invd_bak); free(c->lm); free(c->host); free(c->target);
     free(c->pts_i); free(c->pts_j); free(c->hll); free(c->bl); free(c->Hpl); free(c->dx_lm);
-    free(c->gath_own); free(c->step_gath_own);
+    free(c->gath_own); free(c->step_gath_own); free(c->mo_H); free(c->mo_jt);
     free(c);
 }
 
@@ -1867,6 +1870,22 @@ vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, doubl
             return VIO_ERR_NOT_FINITE;
         }
     return VIO_OK;
+}
+
+/* the two halves of include/vio_backend.h (here: begin computes, end copies; nothing runs in the background) */
+vio_status vio_marginalize_begin(struct vioo_ctx *c, int32_t kind) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (!c->mo_H) { c->mo_H = (double *)malloc(sizeof(double) * PRD * PRD); c->mo_jt = (double *)malloc(sizeof(double) * PRD * PRD); }
+    c->mo_status = vio_marginalize(c, kind, c->mo_H, c->mo_b, c->mo_err, c->mo_jt);
+    c->mo_pending = (c->mo_status == VIO_OK || c->mo_status == VIO_ERR_NOT_FINITE);
+    return c->mo_pending ? VIO_OK : c->mo_status;
+}
+vio_status vio_marginalize_end(struct vioo_ctx *c, double *H, double *b, double *err, double *jt) {
+    if (!c || !H || !b || !err || !jt || !c->mo_pending) return VIO_ERR_BAD_ARG;
+    c->mo_pending = 0;
+    memcpy(H, c->mo_H, sizeof(double) * PRD * PRD); memcpy(jt, c->mo_jt, sizeof(double) * PRD * PRD);
+    memcpy(b, c->mo_b, sizeof(c->mo_b)); memcpy(err, c->mo_err, sizeof(c->mo_err));
+    return c->mo_status;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -31,6 +31,8 @@
 #define vio_gn_iteration vioo_gn_iteration
 #define vio_synchronize vioo_synchronize
 #define vio_marginalize vioo_marginalize
+#define vio_marginalize_begin vioo_marginalize_begin
+#define vio_marginalize_end vioo_marginalize_end
 #define vio_get_window vioo_get_window
 #define vio_get_landmarks vioo_get_landmarks
 #define vio_get_prior vioo_get_prior

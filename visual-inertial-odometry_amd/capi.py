@@ -88,7 +88,8 @@ class VioLib:
                "get_landmarks_xyz", "set_config"]
     # outside the backend proper: the compiled-reference harness (vior_) has no FeatureManager
     # ... nor the receive side of the sharded exchange (it never shards)
-    OPTIONAL = ["triangulate", "gather_buffers", "bind_gather_buffers"]
+    # ... nor the two-halves marginalisation (vio_marginalize_begin / _end)
+    OPTIONAL = ["triangulate", "gather_buffers", "bind_gather_buffers", "marginalize_begin", "marginalize_end"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
@@ -337,6 +338,19 @@ class VioContext:
         st = self.lib.fn["marginalize"](self.h, C.c_int32(kind), _dp(H), _dp(b), _dp(err), _dp(jt))
         if not (st == -3 and allow_nonfinite):
             self._ck(st, "marginalize")
+        return {"H": H, "b": b, "err": err, "jt_inv": jt}
+
+    def marginalize_begin(self, kind):
+        """Device part of the marginalisation; its dense tail goes on in the background (vio_marginalize_begin)."""
+        self._ck(self.lib.fn["marginalize_begin"](self.h, C.c_int32(kind)), "marginalize_begin")
+
+    def marginalize_end(self, allow_nonfinite=False):
+        H = np.zeros((PRIOR_DIM, PRIOR_DIM))
+        b, err = np.zeros(PRIOR_DIM), np.zeros(PRIOR_DIM)
+        jt = np.zeros((PRIOR_DIM, PRIOR_DIM))
+        st = self.lib.fn["marginalize_end"](self.h, _dp(H), _dp(b), _dp(err), _dp(jt))
+        if not (st == -3 and allow_nonfinite):
+            self._ck(st, "marginalize_end")
         return {"H": H, "b": b, "err": err, "jt_inv": jt}
 
     # ---- read back ------------------------------------------------------------------------

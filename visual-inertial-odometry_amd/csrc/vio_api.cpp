@@ -16,6 +16,7 @@
 #include <map>
 #include <unordered_map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vio_backend.h"
@@ -172,6 +173,13 @@ struct Plan {
 
 }  // namespace
 
+struct MargResult {                 // what the helper thread of vio_marginalize_begin leaves for vio_marginalize_end
+    std::vector<double> H, b, err, jt;
+    int kind = 0, live_rows = 0;
+    bool finite = true;
+    double tail_us = 0;
+};
+
 struct vio_ctx {
     vio_config cfg;
     std::string err;
@@ -188,6 +196,9 @@ struct vio_ctx {
     std::vector<double> h_Hprior, h_bprior, h_errprior, h_Jtinv;
     HostArena arena;                           // pinned staging of the uploads
     double *marg_stage = nullptr;              // pinned: H_marg (171 x 171) and b_marg for the host tail of vio_marginalize
+    std::thread marg_thread;                   // the dense tail of a marginalisation in flight (vio_marginalize_begin / _end)
+    bool marg_pending = false;
+    MargResult marg_out;
     double *pull_stage = nullptr;              // pinned staging of the landmark read-back (pull_from_device)
     size_t pull_cap = 0;
     bool prior_dirty = true, imu_dirty = true; // h_Hprior / h_Jtinv resp. h_pre newer than their device copies
@@ -1106,6 +1117,7 @@ vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
 
 void vio_destroy(vio_ctx *c) {
     if (!c) return;
+    if (c->marg_thread.joinable()) c->marg_thread.join();
     enter_device(c);
     // A stream the caller supplied (vio_config.stream, e.g. the leader's of a batch) may be gone already when this context
     // goes: it is not touched here.  hipFree waits for the device itself, so nothing in flight loses its buffers.
@@ -1636,11 +1648,40 @@ vio_status vio_synchronize(vio_ctx *c) {
     return VIO_OK;
 }
 
-vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, double *err, double *jt) {
-    if (!c || !H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
+// The marginalisation in two halves (include/vio_backend.h).  begin: the device part — plan, kernels, the 171x171 read-back — and
+// the hand-over of the dense tail (problem.cc:717-779: two eigen-decompositions, three products) to a helper thread; end: wait for
+// it and copy the prior out.  Between the two the caller owns the context as usual (the helper touches host memory of its own only).
+static void marg_tail_job(vio_ctx *c, int frame) {
+    const auto t1 = std::chrono::steady_clock::now();
+    double *Hm = c->marg_stage, *bm = c->marg_stage + (size_t)PD * PD;
+    MargResult &r = c->marg_out;
+    // A landmark block without an inverse (h_ll == 0; a 3x3 block of XYZ landmarks that the marginalisation graph left at rank 2 and
+    // whose elimination hit an exact zero pivot) makes the reference's dense Hpm * Hmm^-1 (problem.cc:701-703) non-finite everywhere;
+    // its two eigen-solvers then return NaN spectra, every `> eps` test fails (:747-769), the 1e-9 cut zeroes H_prior_ (:778) and
+    // b_prior_, err_prior_, Jt_prior_inv_ are NaN.  The same outcome here, said in the status as well.
+    bool finite_in = true;
+    for (size_t i = 0; i < (size_t)PD * PD + PD && finite_in; ++i) finite_in = std::isfinite(Hm[i]);
+    r.live_rows = 0;
+    if (finite_in) r.live_rows = vio_host::marginalize_tail(Hm, bm, frame, r.H.data(), r.b.data(), r.err.data(), r.jt.data());
+    else {
+        const double nan = std::nan("");
+        std::fill(r.H.begin(), r.H.end(), 0.0); std::fill(r.jt.begin(), r.jt.end(), nan);
+        std::fill(r.b.begin(), r.b.end(), nan); std::fill(r.err.begin(), r.err.end(), nan);
+    }
+    r.finite = finite_in;
+    r.tail_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+}
+
+static void marg_join(vio_ctx *c) {
+    if (c->marg_thread.joinable()) c->marg_thread.join();
+}
+
+vio_status vio_marginalize_begin(vio_ctx *c, int32_t kind) {
+    if (!c) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
     enter_device(c);
-    static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
+    marg_join(c);                     // (a marginalisation nobody asked the result of: its buffers are about to be reused)
+    c->marg_pending = false;
     const auto t0 = std::chrono::steady_clock::now();
     if (!c->marg_stage) HIPCHK(hipHostMalloc((void **)&c->marg_stage, ((size_t)PD * PD + PD) * 8, hipHostMallocDefault));      // pinned: the 234 KB come back by DMA
     double *Hm = c->marg_stage, *bm = c->marg_stage + (size_t)PD * PD;
@@ -1674,30 +1715,35 @@ vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, doubl
         std::memcpy(Hm, c->h_Hprior.data(), (size_t)PD * PD * 8);
         std::memcpy(bm, c->h_bprior.data(), (size_t)PD * 8);
     }
-    const auto t1 = std::chrono::steady_clock::now();
-    // A landmark block without an inverse (h_ll == 0; a 3x3 block of XYZ landmarks that the marginalisation graph left at rank 2 and
-    // whose elimination hit an exact zero pivot) makes the reference's dense Hpm * Hmm^-1 (problem.cc:701-703) non-finite everywhere;
-    // its two eigen-solvers then return NaN spectra, every `> eps` test fails (:747-769), the 1e-9 cut zeroes H_prior_ (:778) and
-    // b_prior_, err_prior_, Jt_prior_inv_ are NaN.  The same outcome here, said in the status as well.
-    bool finite_in = true;
-    for (size_t i = 0; i < (size_t)PD * PD + PD && finite_in; ++i) finite_in = std::isfinite(Hm[i]);
-    int live_rows = 0;
-    if (finite_in) live_rows = vio_host::marginalize_tail(Hm, bm, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, H, b, err, jt);
-    else {
-        const double nan = std::nan("");
-        std::fill(H, H + (size_t)PRD * PRD, 0.0); std::fill(jt, jt + (size_t)PRD * PRD, nan);
-        std::fill(b, b + PRD, nan); std::fill(err, err + PRD, nan);
-    }
-    {
-        const auto t2 = std::chrono::steady_clock::now();
-        c->timing[3] = std::chrono::duration<double, std::micro>(t1 - t0).count();
-        c->timing[4] = std::chrono::duration<double, std::micro>(t2 - t1).count();
-        c->timing[5] = live_rows;
-        if (timing) std::fprintf(stderr, "[vio host timing] vio_marginalize(kind=%d): activate + kernels + read-back %.0f us, host tail %.0f us\n", kind,
-                     std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(t2 - t1).count());
-    }
-    if (!finite_in) return fail(c, VIO_ERR_NOT_FINITE, "vio_marginalize: a landmark block has no inverse; the prior is the reference's outcome for that case (H_prior 0, the rest NaN)");
+    MargResult &r = c->marg_out;
+    r.H.resize((size_t)PRD * PRD); r.jt.resize((size_t)PRD * PRD); r.b.resize(PRD); r.err.resize(PRD);
+    r.kind = kind;
+    c->timing[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    c->marg_pending = true;
+    c->marg_thread = std::thread(marg_tail_job, c, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1);
     return VIO_OK;
+}
+
+vio_status vio_marginalize_end(vio_ctx *c, double *H, double *b, double *err, double *jt) {
+    if (!c || !H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
+    if (!c->marg_pending) return fail(c, VIO_ERR_BAD_ARG, "vio_marginalize_end without vio_marginalize_begin");
+    marg_join(c);
+    c->marg_pending = false;
+    const MargResult &r = c->marg_out;
+    std::memcpy(H, r.H.data(), (size_t)PRD * PRD * 8); std::memcpy(jt, r.jt.data(), (size_t)PRD * PRD * 8);
+    std::memcpy(b, r.b.data(), PRD * 8); std::memcpy(err, r.err.data(), PRD * 8);
+    c->timing[4] = r.tail_us;
+    c->timing[5] = r.live_rows;
+    static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
+    if (timing) std::fprintf(stderr, "[vio host timing] vio_marginalize(kind=%d): activate + kernels + read-back %.0f us, host tail %.0f us\n", r.kind, c->timing[3], r.tail_us);
+    if (!r.finite) return fail(c, VIO_ERR_NOT_FINITE, "vio_marginalize: a landmark block has no inverse; the prior is the reference's outcome for that case (H_prior 0, the rest NaN)");
+    return VIO_OK;
+}
+
+vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, double *err, double *jt) {
+    if (!c || !H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
+    VIOCHK(vio_marginalize_begin(c, kind));
+    return vio_marginalize_end(c, H, b, err, jt);
 }
 
 vio_status vio_get_window(vio_ctx *c, double *poses, double *sb, double *ext) {

@@ -170,6 +170,7 @@ bool EstimatorBackend::uploadWindow(bool graph_unchanged) {
         // and the prior's vectors
         // (the depths went through setDepth / getDepthVector, 1 / (1 / x): sent again, the library keeps what is bitwise the same)
         if (vio_set_landmarks(ctx_, (int64_t)para_Feature.size(), para_Feature.data()) != VIO_OK) return false;
+        if (!waitMarginalization()) return false;
         if (!Hprior_.empty()) {
             if (vio_set_prior(ctx_, VIO_PRIOR_DIM, Hprior_.data(), bprior_.data(), errprior_.data(), Jprior_inv_.data()) != VIO_OK) return false;
         } else if (vio_set_prior(ctx_, 0, nullptr, nullptr, nullptr, nullptr) != VIO_OK) return false;
@@ -207,6 +208,9 @@ bool EstimatorBackend::uploadWindow(bool graph_unchanged) {
         const vio_preint *p = pre_integrations[i + 1];
         if (vio_set_imu(ctx_, i, (p && p->sum_dt <= 10.0) ? p : nullptr) != VIO_OK) return false;
     }
+    // (the prior of the marginalisation the frame before left running — async_marginalization — is needed from here on: its dense
+    // tail has had slideWindow, the front-end and the uploads above to finish under)
+    if (!waitMarginalization()) return false;
     if (!Hprior_.empty()) {                                                   // estimator.cpp:1023-1034
         if (vio_set_prior(ctx_, VIO_PRIOR_DIM, Hprior_.data(), bprior_.data(), errprior_.data(), Jprior_inv_.data()) != VIO_OK)
             return false;
@@ -236,25 +240,35 @@ bool EstimatorBackend::problemSolve() {
     return true;
 }
 
-static bool marginalize(vio_ctx *ctx, int kind, std::vector<double> &H, std::vector<double> &b, std::vector<double> &e,
-                        std::vector<double> &J) {
-    H.assign((size_t)VIO_PRIOR_DIM * VIO_PRIOR_DIM, 0.0); J.assign((size_t)VIO_PRIOR_DIM * VIO_PRIOR_DIM, 0.0);
-    b.assign(VIO_PRIOR_DIM, 0.0); e.assign(VIO_PRIOR_DIM, 0.0);
-    return vio_marginalize(ctx, kind, H.data(), b.data(), e.data(), J.data()) == VIO_OK;
+// Problem::Marginalize + the four getters (estimator.cpp:821-828, :893-900).  With async_marginalization the device part runs here
+// and the dense host tail on the library's helper thread; Hprior_ / bprior_ / errprior_ / Jprior_inv_ are filled by
+// waitMarginalization(), which uploadWindow() calls where the next window needs its prior.
+bool EstimatorBackend::marginalize(int kind) {
+    if (vio_marginalize_begin(ctx_, kind) != VIO_OK) return false;
+    marg_pending_ = true;
+    return async_marginalization ? true : waitMarginalization();
+}
+
+bool EstimatorBackend::waitMarginalization() {
+    if (!marg_pending_) return true;
+    marg_pending_ = false;
+    Hprior_.assign((size_t)VIO_PRIOR_DIM * VIO_PRIOR_DIM, 0.0); Jprior_inv_.assign((size_t)VIO_PRIOR_DIM * VIO_PRIOR_DIM, 0.0);
+    bprior_.assign(VIO_PRIOR_DIM, 0.0); errprior_.assign(VIO_PRIOR_DIM, 0.0);
+    return vio_marginalize_end(ctx_, Hprior_.data(), bprior_.data(), errprior_.data(), Jprior_inv_.data()) == VIO_OK;
 }
 
 bool EstimatorBackend::MargOldFrame() {
     const bool same = graph_uploaded_;
     graph_uploaded_ = false;
     if (!uploadWindow(same)) return false;
-    return marginalize(ctx_, VIO_MARG_OLD, Hprior_, bprior_, errprior_, Jprior_inv_);      // estimator.cpp:821-828
+    return marginalize(VIO_MARG_OLD);
 }
 
 bool EstimatorBackend::MargNewFrame() {
     const bool same = graph_uploaded_;
     graph_uploaded_ = false;
     if (!uploadWindow(same)) return false;
-    return marginalize(ctx_, VIO_MARG_SECOND_NEW, Hprior_, bprior_, errprior_, Jprior_inv_);   // estimator.cpp:893-900
+    return marginalize(VIO_MARG_SECOND_NEW);
 }
 
 void EstimatorBackend::backendOptimization(MarginalizationFlag marginalization_flag) {
@@ -267,7 +281,7 @@ void EstimatorBackend::backendOptimization(MarginalizationFlag marginalization_f
         vector2double();
         graph_uploaded_ = true;
         MargOldFrame();
-    } else if (!Hprior_.empty()) {                      // :1107-1114
+    } else if (!Hprior_.empty()) {                      // :1107-1114 (problemSolve has collected a marginalisation that was still running)
         vector2double();
         graph_uploaded_ = true;
         MargNewFrame();

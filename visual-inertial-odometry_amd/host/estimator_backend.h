@@ -65,12 +65,19 @@ public:
     bool MargOldFrame();
     bool MargNewFrame();
     void backendOptimization(MarginalizationFlag marginalization_flag);   // vector2double .. double2vector (estimator.cpp:1075-1141)
+    // Marg*Frame return once the device part of Problem::Marginalize is done and leave its dense tail (two eigen-decompositions,
+    // 0.2 - 0.5 ms) to a helper thread of the library (vio_marginalize_begin / _end): the prior members are valid after
+    // waitMarginalization(), which the next problemSolve calls itself where it hands the prior over.  Off: as the reference.
+    bool async_marginalization = false;
+    bool waitMarginalization();
     const char *last_error() const;
 
 private:
     // graph_unchanged: landmarks, observations and IMU factors are the ones of the upload before (backendOptimization's second
     // upload, for the marginalisation of the frame it has just solved): only the states and the prior are sent
     bool uploadWindow(bool graph_unchanged = false);
+    bool marginalize(int kind);
+    bool marg_pending_ = false;
     bool graph_uploaded_ = false;                     // set by problemSolve inside backendOptimization, used by the Marg*Frame that follows
 public:
     vio_ctx *context() { return ctx_; }               // for FeatureManager::triangulate
