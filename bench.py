@@ -365,7 +365,10 @@ def main():
             per_frame["gpu_marginalisation_tail_in_the_background"] = {k: pf[k] for k in ("set_ms", "plan_upload_linearize_ms", "solve10_ms", "marginalize_ms", "frame_ms", "spread")}
         if not xyz:
             # MargOldFrame's worst case: tracks that span all frames — every frame-0 landmark seen from frames 1..10 — and a prior of
-            # the same kind: all 156 rows of the reduced system are live, the eigen-decomposition pays its full O(n^3)
+            # the same kind.  75 of the 156 rows of the reduced system are live then, and that is the most there can be: ext (6) + the ten
+            # remaining poses (60) + the speed-bias of the FIRST remaining frame (9) — a speed-bias gets information from IMU factors
+            # only, MargOldFrame's graph holds the one between frames 0 and 1 (estimator.cpp:735-747), and the prior it leaves hands
+            # that block on to the next marginalisation: the other nine speed-bias blocks of a prior are exactly zero, always
             wd = [vio.synth.make_window(2000, seed=s_, t0=t_, obs_per_landmark=10) for s_, t_ in ((51, 1.0), (52, 1.0))]
             # (a prior reaches the speed-bias rows of a frame only through the IMU edge 0 -> 1 of the marginalisation that removed the
             # frame before it: a chain of 11 marginalisations, each handing its prior to the next window, fills all of them)
