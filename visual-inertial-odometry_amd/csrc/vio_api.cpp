@@ -24,7 +24,8 @@
 #include "vio_types.h"
 
 struct ReduceTables {
-    const int32_t *tab;
+    const int32_t *list_off;
+    const int32_t *list;
     const double *slab;
     double *vis;
     const double *step_part;
@@ -156,14 +157,14 @@ struct Plan {
     std::vector<int32_t> sorted_to_orig;       // landmark permutation
     std::vector<ItemDesc> items;
     std::vector<Pattern> patterns;
-    std::vector<int32_t> red_tab, dst_tab;     // k_reduce's arrays in the slab, the items' places in them (vio_types.h)
+    std::vector<int32_t> list_off, list;
     size_t slab_doubles = 0, lw_doubles = 0;
     int max_lds_doubles = 0;
     DevBuf<ItemDesc> d_items;
-    DevBuf<int32_t> d_red_tab, d_dst_tab;
+    DevBuf<int32_t> d_list_off, d_list;
     DevBuf<double> d_pts_i, d_pts_j, d_invd, d_slab, d_lw, d_dxl, d_step_part;
     void release() {
-        d_items.release(); d_red_tab.release(); d_dst_tab.release();
+        d_items.release(); d_list_off.release(); d_list.release();
         d_pts_i.release(); d_pts_j.release(); d_invd.release(); d_slab.release(); d_lw.release(); d_dxl.release();
         d_step_part.release();
         valid = false;
@@ -398,13 +399,15 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
         std::memset(&it, 0, sizeof(it));
         it.lm_base = (int32_t)s; it.G = (int32_t)(e - s); it.K = pt.K; it.nb = pt.nb; it.host = -1;
         it.host_slot = -1; it.use_ext = 0; it.obs_base = (int32_t)obs_base;
-        it.dst_base = 0; it.lw_base = (int32_t)pl.lw_doubles;      // (dst_base: upload_plan)
+        it.out_base = (int32_t)pl.slab_doubles; it.lw_base = (int32_t)pl.lw_doubles;
         std::memcpy(it.target, pt.target, sizeof(it.target)); std::memcpy(it.tslot, pt.tslot, sizeof(it.tslot));
         std::memcpy(it.cam_block, pt.cam_block, sizeof(it.cam_block));
         for (int p = 0; p < pt.nb; ++p) { it.btype[p] = 2; it.bk[p] = (int8_t)p; }
         it.n_rows = pt.n_rows; it.lds_doubles = pt.lds_doubles;
         pl.items.push_back(it);
         pl.max_lds_doubles = std::max(pl.max_lds_doubles, pt.lds_doubles);
+        pl.slab_doubles += (size_t)item_out_count(pt.nb);
+        pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
         pl.lw_doubles += (size_t)9 * it.G;            // H_ll (6), b_l (3): W is formed again where it is needed
         for (int g = 0; g < it.G; ++g) {
             const int32_t l = pl.sorted_to_orig[s + g];
@@ -556,13 +559,15 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         std::memset(&it, 0, sizeof(it));
         it.lm_base = (int32_t)s; it.G = (int32_t)(e - s); it.K = pt.K; it.nb = pt.nb; it.host = pt.host;
         it.host_slot = pt.host_slot; it.use_ext = pt.use_ext; it.obs_base = (int32_t)obs_base;
-        it.dst_base = 0; it.lw_base = (int32_t)pl.lw_doubles;      // (dst_base: upload_plan)
+        it.out_base = (int32_t)pl.slab_doubles; it.lw_base = (int32_t)pl.lw_doubles;
         std::memcpy(it.target, pt.target, sizeof(it.target)); std::memcpy(it.tslot, pt.tslot, sizeof(it.tslot));
         std::memcpy(it.cam_block, pt.cam_block, sizeof(it.cam_block));
         for (int p = 0; p < pt.nb; ++p) { it.btype[p] = (int8_t)pt.btype_i[p]; it.bk[p] = (int8_t)pt.bk_i[p]; }
         it.n_rows = pt.n_rows; it.lds_doubles = pt.lds_doubles;
         pl.items.push_back(it);
         pl.max_lds_doubles = std::max(pl.max_lds_doubles, pt.lds_doubles);
+        pl.slab_doubles += (size_t)item_out_count(pt.nb);
+        pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
         pl.lw_doubles += (size_t)item_lw_fields(pt.nb) * it.G;
         for (int g = 0; g < it.G; ++g) {
             const int32_t l = pl.sorted_to_orig[s + g];
@@ -587,50 +592,34 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     return upload_plan(c, pl, pts_i, pts_j);
 }
 
-// the slab's arrays for k_reduce, device buffers, upload: common to both kinds of landmark
+// inverted lists for k_reduce, device buffers, upload: common to both kinds of landmark
 vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j) {
-    // The items' partial blocks go where k_reduce streams them (vio_types.h): one contiguous array per camera-block pair, one per
-    // camera block, one [items][2].  Count, lay the arrays out one after the other, then give every item its places in item order:
-    // the order k_reduce adds them in.
-    int32_t cnt_pair[VIO_NPAIR] = {0}, cnt_vec[VIO_NCB] = {0};
-    size_t n_dst = 0;
+    const int n_lists = VIO_NPAIR + VIO_NCB + 1;
+    std::vector<std::vector<int32_t>> lists(n_lists);
     for (const ItemDesc &it : pl.items) {
         for (int p = 0; p < it.nb; ++p) {
-            ++cnt_vec[it.cam_block[p]];
-            for (int q = p; q < it.nb; ++q) ++cnt_pair[VIS_PAIR(it.cam_block[p], it.cam_block[q])];
-        }
-        n_dst += (size_t)item_nbp(it.nb) + it.nb;
-    }
-    pl.red_tab.assign(RED_COUNT, 0);
-    size_t off = 0;
-    for (int b = 0; b < VIO_NPAIR; ++b) { pl.red_tab[RED_PAIR_BASE + b] = (int32_t)off; pl.red_tab[RED_PAIR_CNT + b] = cnt_pair[b]; off += (size_t)cnt_pair[b] * RED_PAIR_STRIDE; }
-    for (int P = 0; P < VIO_NCB; ++P) { pl.red_tab[RED_VEC_BASE + P] = (int32_t)off; pl.red_tab[RED_VEC_CNT + P] = cnt_vec[P]; off += (size_t)cnt_vec[P] * RED_VEC_STRIDE; }
-    pl.red_tab[RED_CHI_BASE] = (int32_t)off;
-    off += (size_t)RED_CHI_STRIDE * pl.items.size();
-    if (off >= ((size_t)1 << 31)) return fail(c, VIO_ERR_UNSUPPORTED, "window too large for the 32-bit offsets of the partial sums");
-    pl.slab_doubles = (off + 1) & ~(size_t)1;
-    pl.dst_tab.assign(std::max<size_t>(n_dst, 1), 0);
-    {
-        int32_t fill_pair[VIO_NPAIR] = {0}, fill_vec[VIO_NCB] = {0};
-        size_t d = 0;
-        for (ItemDesc &it : pl.items) {
-            it.dst_base = (int32_t)d;
-            const int nbp = item_nbp(it.nb);
-            for (int p = 0; p < it.nb; ++p) {
-                const int P = it.cam_block[p];
-                for (int q = p; q < it.nb; ++q) {
-                    const int bidx = VIS_PAIR(P, it.cam_block[q]);
-                    pl.dst_tab[d + item_pair_index(it.nb, p, q)] = pl.red_tab[RED_PAIR_BASE + bidx] + RED_PAIR_STRIDE * fill_pair[bidx]++;
-                }
-                pl.dst_tab[d + nbp + p] = pl.red_tab[RED_VEC_BASE + P] + RED_VEC_STRIDE * fill_vec[P]++;
+            const int P = it.cam_block[p];
+            for (int q = p; q < it.nb; ++q) {
+                const int Q = it.cam_block[q];
+                const int bidx = P * VIO_NCB - P * (P - 1) / 2 + (Q - P);
+                lists[bidx].push_back(it.out_base + item_pair_index(it.nb, p, q) * 36);
             }
-            d += (size_t)nbp + it.nb;
+            lists[VIO_NPAIR + P].push_back(it.out_base + item_nbp(it.nb) * 36 + p * 6);
+            lists[VIO_NPAIR + P].push_back(it.nb * 6);
         }
+        lists[n_lists - 1].push_back(it.out_base + it.n_rows * 6);
     }
+    pl.list_off.assign(n_lists + 1, 0);
+    pl.list.clear();
+    for (int b = 0; b < n_lists; ++b) {
+        pl.list_off[b] = (int32_t)pl.list.size();
+        pl.list.insert(pl.list.end(), lists[b].begin(), lists[b].end());
+    }
+    pl.list_off[n_lists] = (int32_t)pl.list.size();
     // upload
     const size_t ni = pl.items.size();
     HIPCHK(pl.d_items.resize(ni));
-    HIPCHK(pl.d_red_tab.resize(pl.red_tab.size())); HIPCHK(pl.d_dst_tab.resize(pl.dst_tab.size()));
+    HIPCHK(pl.d_list_off.resize(pl.list_off.size())); HIPCHK(pl.d_list.resize(pl.list.size()));
     const size_t ld = (size_t)pl.lm_dim;
     HIPCHK(pl.d_pts_i.resize(2 * (size_t)pl.Ns)); HIPCHK(pl.d_pts_j.resize(2 * (size_t)pl.Ms));
     HIPCHK(pl.d_invd.resize(2 * ld * (size_t)std::max<int64_t>(pl.Ns, 1))); HIPCHK(pl.d_slab.resize(pl.slab_doubles));
@@ -639,11 +628,11 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *
     hipStream_t st = c->stream;
     // everything leaves from the pinned staging: no wait here (activate() marks the staging busy until these copies are done)
     const ItemDesc *s_items = c->arena.put(pl.items.data(), ni);
-    const int32_t *s_off = c->arena.put(pl.red_tab.data(), pl.red_tab.size()), *s_list = c->arena.put(pl.dst_tab.data(), pl.dst_tab.size());
+    const int32_t *s_off = c->arena.put(pl.list_off.data(), pl.list_off.size()), *s_list = c->arena.put(pl.list.data(), pl.list.size());
     if (!s_items || !s_off || !s_list) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
     if (ni) HIPCHK(hipMemcpyAsync(pl.d_items.p, s_items, ni * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(pl.d_red_tab.p, s_off, pl.red_tab.size() * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(pl.d_dst_tab.p, s_list, pl.dst_tab.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(pl.d_list_off.p, s_off, pl.list_off.size() * 4, hipMemcpyHostToDevice, st));
+    if (!pl.list.empty()) HIPCHK(hipMemcpyAsync(pl.d_list.p, s_list, pl.list.size() * 4, hipMemcpyHostToDevice, st));
     if (pl.Ns && pl.lm_dim == 1) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i, 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
     if (pl.Ms) HIPCHK(hipMemcpyAsync(pl.d_pts_j.p, pts_j, 2 * (size_t)pl.Ms * 8, hipMemcpyHostToDevice, st));
     pl.valid = true;
@@ -678,7 +667,7 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     T.state = c->d_state.p; T.invd = pl.d_invd.p; T.pts_i = pl.d_pts_i.p; T.pts_j = pl.d_pts_j.p;
     T.pairtab = c->d_pairtab.p; T.slab = pl.d_slab.p; T.lw = pl.d_lw.p; T.lw_set = (int64_t)pl.lw_doubles; T.vis = c->ext_vis ? c->ext_vis : c->d_vis.p; T.pre = c->d_pre.p;
     T.imu_valid = c->d_imu_valid.p; T.imu_out = c->d_imu_out.p; T.imu_chi_try = c->d_imu_chi.p;
-    T.dst_tab = pl.d_dst_tab.p;
+    T.pair_slot = nullptr; T.blk_slot = nullptr;
     T.Hprior = c->d_Hprior.p; T.bprior = c->d_bprior.p; T.errprior = c->d_errprior.p; T.Jtinv = c->d_Jtinv.p;
     // Problem always carries a 171x171 prior block (zero before the first marginalisation); err_prior_ exists
     // only once a prior has been set (problem.cc:466,505,554)
@@ -692,7 +681,7 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
     T.gath = c->ext_gath ? c->ext_gath : c->d_gath.p; T.step_gath = c->ext_step_gath ? c->ext_step_gath : c->d_step_gath.p;
     T.n_shards = (c->hook != nullptr || c->comm != nullptr) ? c->cfg.shard_count : 0;
-    T.red_tab = pl.d_red_tab.p;
+    T.list_off = pl.d_list_off.p; T.list = pl.d_list.p;
 #ifdef VIO_STAMPS
     (void)c->d_dbg.resize(16 * (size_t)(T.n_items + T.n_imu_items + 16));
     T.dbg = c->d_dbg.p;
@@ -955,7 +944,7 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     // sharded + gated slot: the all-reduce below runs whether the slot is live or not (every rank enqueues the same
     // collectives), in place on vis; k_reduce therefore always runs and puts this rank's own sums back first (a skipped
     // re-linearisation leaves the slabs as they were), so the buffer never accumulates the sum of sums
-    ReduceTables R{pl.d_red_tab.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items, sharded(c) ? 0 : gate, T.lm,
+    ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items, sharded(c) ? 0 : gate, T.lm,
                    err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + c->cur_host * 176 : nullptr,
                    err_prev ? T.errprior + c->cur_host * 160 : nullptr};
     { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
@@ -1026,7 +1015,7 @@ vio_status enqueue_lm_slot(vio_ctx *c, Plan &pl, bool first) {
         T.gn_flags = 2;
         { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
         // (sharded: k_reduce always runs, see enqueue_linearize)
-        ReduceTables R{pl.d_red_tab.p, pl.d_slab.p, T.vis, T.step_part, T.n_items, sharded(c) ? 0 : 2, T.lm,
+        ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, T.step_part, T.n_items, sharded(c) ? 0 : 2, T.lm,
                        T.has_prior ? T.Jtinv : nullptr, T.has_prior ? T.bprior : nullptr, T.has_prior ? T.errprior : nullptr, 1};
         { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
         VIOCHK(run_exchange(c, 0));

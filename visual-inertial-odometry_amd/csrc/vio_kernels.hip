@@ -443,18 +443,6 @@ __device__ __forceinline__ void d_bprior_rows(const DeviceTables &T, int from, i
     }
 }
 
-// Where element e of an item's partial sums goes (vio_types.h: one contiguous array per camera-block pair / camera block).
-// sDst: the item's dst_tab entries, in LDS.
-__device__ __forceinline__ double *d_slab_dst(const DeviceTables &T, const int32_t *sDst, int n_pair, int D, int e) {
-    if (e < n_pair) {
-        const int pi = e / 36;
-        return T.slab + sDst[pi] + (e - 36 * pi);
-    }
-    const int ve = e - n_pair, which = ve / D, a = ve - which * D, p = a / 6;
-    return T.slab + sDst[n_pair / 36 + p] + which * 6 + (a - 6 * p);
-}
-#define LIN_DST_MAX (VIO_NPAIR + VIO_MAXNB)
-
 __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -472,7 +460,6 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         return;
     }
     __shared__ ItemDesc sIt;        // kept in LDS: its small arrays are indexed at run time
-    __shared__ int32_t sDst[LIN_DST_MAX];     // where the item's blocks go in the slab (combine phase)
     const int cur = d_cur(T);      // requested together with the descriptor: both are cold after the kernel boundary
     const int64_t lw_r = d_set_r(T) * T.lw_set, lw_w = d_set_w(T) * T.lw_set;
     if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
@@ -513,8 +500,6 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         pv = ptab[(it.host * 11 + it.target[k]) * PAIR_STRIDE + o];
     }
     if (tid < 12) cv = ptab[121 * PAIR_STRIDE + tid];
-    // (the item's places in the slab: wanted by the combine phase only — requested here, with everything else that is cold)
-    if (tid >= 64 && tid < 64 + item_nbp(nb) + nb) sDst[tid - 64] = T.dst_tab[it.dst_base + tid - 64];
     // GN mode (gn_flags bit 1): the landmarks still owe the back-substitution of the PREVIOUS step (problem.cc:445):
     // delta_lambda = (b_l - w . dx_pose) / h from the rows this item's workgroup stored at the end of the previous
     // linearisation.  The new inverse depth goes to the current copy of invd and, through the landmark record, to
@@ -855,9 +840,9 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     // ---------------- combine: thread per slab element ----------------
     STAMP(T, 4);
     {
+        double *out = T.slab + it.out_base;
         const int n_out = it.n_rows * 6;
         const int n_pair = (nb * (nb + 1) / 2) * 36;
-        double *out_chi = T.slab + T.red_tab[RED_CHI_BASE] + RED_CHI_STRIDE * b;
         // the block totals from the wave partials of phase 1.5 (fixed order: wave 0 first)
         double chi = 0.0, sc = 0.0, mh = 0.0;
         if (tid == 0 || tid == 64) {
@@ -905,10 +890,10 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
                     else v = cdir(it.bk[p], 6 + i, 6 + i);
                 }
             }
-            *d_slab_dst(T, sDst, n_pair, D, e) = v;
+            out[e] = v;
         }
         STAMP(T, 13);
-        if (tid == 0) { out_chi[0] = chi; out_chi[1] = mh; }
+        if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
         if (owe && tid == 64) { T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0; }
         if (owe && tid < G) {               // the landmark update of the head, out to HBM now
             const size_t li = (size_t)it.lm_base + tid;
@@ -952,13 +937,14 @@ __global__ __launch_bounds__(LIN_THREADS) void k_linearize_b(BatchArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_reduce: fixed-order sum of the items' partial blocks.  The items write them where this kernel streams them (vio_types.h):
-//   workgroup b < 78      camera block pair (P,Q): [items that touch the pair, in item order][36]
-//   workgroup 78 + P      camera block P's vectors: [items][18: b_dir, b_corr, diag]
-//   workgroup 90          chi / max h: [items][2]
+// k_reduce: fixed-order sum of the item slabs through inverted lists built at upload time.
+//   list b < 78           camera block pair (P,Q): entries = slab offset of that 6x6 block
+//   list 78 + P           camera block P vectors: entries = (offset of b_dir block, 6*nb)
+//   list 90               chi / max h: entries = offset
 // ---------------------------------------------------------------------------------------------------------
 struct ReduceTables {
-    const int32_t *tab;          // [RED_COUNT] offsets and lengths of the slab's arrays (vio_types.h)
+    const int32_t *list_off;     // [92]
+    const int32_t *list;         // offsets (pairs: 1 int per entry; vectors: 2 ints per entry)
     const double *slab;
     double *vis;
     const double *step_part;     // GN mode: per-item partials of the previous step (k_backsub), or null
@@ -992,10 +978,9 @@ __device__ __forceinline__ void d_errprior_row(const double *jt, const double *b
 }
 
 __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
-    // The blocks of one camera pair (one camera block's vectors) lie one after the other, in item order.  The array is cut into
-    // interleaved slots (entry e belongs to slot e mod nslots); a group of 36 (18) threads owns a slot and sums its entries with 8
-    // loads in flight, then the slots are added in slot order: the summation order is fixed by the item order, not by timing.
-    // Two dependent round trips (the array's place, its entries), every load of a wave contiguous, whatever the number of items.
+    // A list is cut into interleaved slots (entry e belongs to slot e mod nslots); a group of 36 (18) threads owns a
+    // slot and sums its entries with 8 gathers in flight, then the slots are added in slot order: the summation order
+    // is fixed by the list, not by timing.  Three dependent round trips (offsets, list, slab) whatever the list length.
     __shared__ double sV[56 * 18 + 8];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (d_gated_off(R.lm, R.gate)) return;
@@ -1006,27 +991,33 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
         if (row < VIO_PRD && step_owed) d_errprior_row(R.jtinv, R.bprior + copy * 176, R.errprior + copy * 160, row, tid & 63);
         return;
     }
+    const int lo = R.list_off[b], hi = R.list_off[b + 1];
     if (b < VIO_NPAIR) {
         constexpr int W = 36, NS = RED_THREADS / W;           // 28 slots
         const int s = tid / W, t = tid - s * W;
-        const int n = R.tab[RED_PAIR_CNT + b];
-        const double *blk = R.slab + R.tab[RED_PAIR_BASE + b] + t;
+        const int n = hi - lo;
         if (s < NS) {
             double acc = 0.0;
             int e = s;
             for (; e + 7 * NS < n; e += 8 * NS) {
+                int off[8];
                 double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = blk[(size_t)(e + u * NS) * RED_PAIR_STRIDE];
+                for (int u = 0; u < 8; ++u) off[u] = R.list[lo + e + u * NS];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = R.slab[(size_t)off[u] + t];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc += v[u];
             }
             {   // tail: up to 7 entries, still all in flight together
+                int off[7];
                 double v[7];
 #pragma unroll
-                for (int u = 0; u < 7; ++u) v[u] = (e + u * NS < n) ? blk[(size_t)(e + u * NS) * RED_PAIR_STRIDE] : 0.0;
+                for (int u = 0; u < 7; ++u) off[u] = (e + u * NS < n) ? R.list[lo + e + u * NS] : -1;
 #pragma unroll
-                for (int u = 0; u < 7; ++u) if (e + u * NS < n) acc += v[u];
+                for (int u = 0; u < 7; ++u) v[u] = off[u] >= 0 ? R.slab[(size_t)off[u] + t] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 7; ++u) if (off[u] >= 0) acc += v[u];
             }
             sV[s * W + t] = acc;
         }
@@ -1041,16 +1032,23 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
         constexpr int W = 18, NS = RED_THREADS / W;           // 56 slots
         const int P = b - VIO_NPAIR;
         const int s = tid / W, t = tid - s * W;
-        const int n = R.tab[RED_VEC_CNT + P];
-        const double *vec = R.slab + R.tab[RED_VEC_BASE + P] + t;     // t = kind * 6 + i: b_dir, b_corr, diag
+        const int kind = t / 6, i = t % 6;
+        const int n = (hi - lo) / 2;
         if (s < NS) {
             double acc = 0.0;
             for (int e = s; e < n; e += 4 * NS) {
+                int off[4], str[4];
                 double v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = (e + u * NS < n) ? vec[(size_t)(e + u * NS) * RED_VEC_STRIDE] : 0.0;
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = e + u * NS < n;
+                    off[u] = ok ? R.list[lo + 2 * (e + u * NS)] : -1;
+                    str[u] = ok ? R.list[lo + 2 * (e + u * NS) + 1] : 0;
+                }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if (e + u * NS < n) acc += v[u];
+                for (int u = 0; u < 4; ++u) v[u] = off[u] >= 0 ? R.slab[(size_t)off[u] + kind * str[u] + i] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (off[u] >= 0) acc += v[u];
             }
             sV[s * W + t] = acc;
         }
@@ -1064,13 +1062,13 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
             R.vis[VIS_DIAG + 6 * P + tid] = dg;
         }
     } else {
-        // chi2 and max|h_ll| over the items: threads stride the items, then a fixed tree
+        // chi2 and max|h_ll| over the items: threads stride the list, then a fixed tree
         __shared__ double sC[RED_THREADS], sM[RED_THREADS];
-        const double *cm = R.slab + R.tab[RED_CHI_BASE];
         double chi = 0.0, mh = 0.0;
-        for (int e = tid; e < R.n_step; e += RED_THREADS) {
-            chi += cm[RED_CHI_STRIDE * e];
-            mh = fmax(mh, cm[RED_CHI_STRIDE * e + 1]);
+        for (int e = lo + tid; e < hi; e += RED_THREADS) {
+            const size_t o = (size_t)R.list[e];
+            chi += R.slab[o];
+            mh = fmax(mh, R.slab[o + 1]);
         }
         sC[tid] = chi; sM[tid] = mh;
         __syncthreads();
@@ -1100,7 +1098,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_b(BatchArgs a) {
     const bool test_prev = (a.gn_flags & 1) != 0, err_prev = test_prev && T.has_prior;
     if ((int)blockIdx.x >= VIO_NPAIR + VIO_NCB + 1 && !err_prev) return;
     const int loop = T.cur_hint == -2, cur = loop ? 0 : T.cur_hint;
-    ReduceTables R{T.red_tab, T.slab, T.vis, test_prev ? T.step_part : nullptr, T.n_items, a.gate, T.lm,
+    ReduceTables R{T.list_off, T.list, T.slab, T.vis, test_prev ? T.step_part : nullptr, T.n_items, a.gate, T.lm,
                    err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + cur * 176 : nullptr, err_prev ? T.errprior + cur * 160 : nullptr, loop};
     d_reduce_body(R);
 }

@@ -244,14 +244,12 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
         return;
     }
     __shared__ ItemDesc sIt;
-    __shared__ int32_t sDst[LIN_DST_MAX];                  // where the item's blocks go in the slab (combine phase)
     const int cur = d_cur(T);
     const int64_t lw_r = d_set_r(T) * T.lw_set, lw_w = d_set_w(T) * T.lw_set;
     if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
     __syncthreads();
     const ItemDesc &it = sIt;
     const int G = it.G, K = it.K, nb = it.nb;              // nb == K: one pattern block per observing frame
-    if (tid >= 64 && tid < 64 + item_nbp(nb) + nb) sDst[tid - 64] = T.dst_tab[it.dst_base + tid - 64];
     const int LREC = xyz_lrec(nb), PLANE = xyz_plane(G), NTD = xyz_ntd(K);
     const int offW = 0, offH = 18 * nb, offHI = offH + 6, offBL = offH + 15, offV = offH + 18, offPW = offH + 21, offDL = offH + 24, offSC = offH + 27;
 
@@ -506,9 +504,9 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     STAMP(T, 4);
     // ---------------- combine: thread per slab element ----------------
     {
+        double *out = T.slab + it.out_base;
         const int n_out = it.n_rows * 6;
         const int n_pair = (nb * (nb + 1) / 2) * 36;
-        double *out_chi = T.slab + T.red_tab[RED_CHI_BASE] + RED_CHI_STRIDE * b;
         double chi = 0.0, mh = 0.0;
         if (tid == 0) {
 #pragma unroll
@@ -542,9 +540,9 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
                     v = cdir(p, i, i);
                 }
             }
-            *d_slab_dst(T, sDst, n_pair, D, e) = v;
+            out[e] = v;
         }
-        if (tid == 0) { out_chi[0] = chi; out_chi[1] = mh; }
+        if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
         if (owe && tid == 64) {
             double sc = 0.0;
 #pragma unroll

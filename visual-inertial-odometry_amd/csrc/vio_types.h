@@ -8,8 +8,7 @@
 //   pts_j[M][2]              target observations, item-major, inside an item k-major: obs_base + k*G + g
 //   items[n_items]           ItemDesc: <= G_MAX landmarks sharing (host, targets) — the unit of work of a workgroup
 //   pairtab[2][121][PAIR_STRIDE]   per ordered frame pair (h,t): composed rotations of the reprojection chain
-//   slab[...]                the items' partial sums, one contiguous array per camera-block pair / camera block (below):
-//                            k_reduce streams them in item order (deterministic two-pass reduction, no float atomics)
+//   slab[...]                per-item compact partial sums (deterministic two-pass reduction, no float atomics)
 //   lw[...]                  per-landmark Schur row w (Hpl), 1/h_ll, b_l kept for back-substitution
 //   vis[VIS_COUNT]           reduced visual system in the 72-dim camera space (the multi-GPU exchange buffer)
 //   imu_out[10][IMU_OUT]     J^T*Info*J (30x30), J^T*Info*r (30), r^T*Info*r per IMU edge
@@ -73,7 +72,7 @@ struct ItemDesc {
     int32_t host_slot;           // pattern-local index of the host block
     int32_t use_ext;             // 1: pattern-local block 0 is the extrinsic
     int32_t obs_base;            // first observation (item-major storage)
-    int32_t dst_base;            // offset into dst_tab: where in the slab this item's blocks go (see RED_* below)
+    int32_t out_base;            // offset into slab (doubles)
     int32_t lw_base;             // offset into lw (doubles)
     int8_t target[VIO_MAXK];     // target frame of observation k
     int8_t tslot[VIO_MAXK];      // pattern-local block of observation k's target
@@ -85,25 +84,7 @@ struct ItemDesc {
 };
 
 
-// An item's partial sums, element e of item_out_count(nb): pair blocks [nbp][36] | b_dir[6nb] | b_corr[6nb] | diag_dir[6nb] | chi | maxh.
-// They are not stored item by item but where k_reduce wants to stream them: the slab is one contiguous array per camera-block
-// pair (P <= Q) — [items that touch the pair, in item order][36] —, one per camera block P — [items][18: b_dir 6, b_corr 6,
-// diag 6] —, and [items][2: chi, max h_ll].  dst_tab[it.dst_base + ...] holds the item's places: [pi < nbp] the offset of its
-// pair block pi, [nbp + p] of the 18 vector entries of its pattern block p; chi / max h_ll sit at red_tab[RED_CHI_BASE] + 2 item.
-// red_tab (per plan, RED_COUNT ints): the arrays' offsets and lengths.
-#define RED_PAIR_BASE 0                                   // [78] offset of the array of pair (P, Q), index VIS_PAIR(P, Q)
-#define RED_VEC_BASE VIO_NPAIR                            // [12] offset of the array of camera block P
-#define RED_CHI_BASE (VIO_NPAIR + VIO_NCB)                // offset of the [items][2] array
-#define RED_PAIR_CNT (RED_CHI_BASE + 1)                   // [78] items in the pair's array
-#define RED_VEC_CNT (RED_PAIR_CNT + VIO_NPAIR)            // [12]
-#define RED_COUNT (RED_VEC_CNT + VIO_NCB)
-// strides of the arrays' entries (doubles): an entry starts on a 128-byte line of its own, so that no line is shared by the
-// workgroups of two items (which run on different XCDs: partial lines from two L2s)
-#ifndef RED_PAIR_STRIDE
-#define RED_PAIR_STRIDE 48                                // 36 used
-#define RED_VEC_STRIDE 32                                 // 18 used
-#define RED_CHI_STRIDE 16                                 // 2 used
-#endif
+// per-item slab layout (doubles): pair blocks [nbp][36] | b_dir[6nb] | b_corr[6nb] | diag_dir[6nb] | chi | maxh
 __host__ __device__ inline int item_nbp(int nb) { return nb * (nb + 1) / 2; }
 __host__ __device__ inline int item_pair_index(int nb, int p, int q) { return p * nb - p * (p - 1) / 2 + (q - p); }
 __host__ __device__ inline int item_out_count(int nb) { return item_nbp(nb) * 36 + 18 * nb + 2; }
@@ -163,7 +144,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     const int32_t *imu_valid;    // [10]
     double *imu_out;             // [10][IMU_OUT]
     double *imu_chi_try;         // [10]
-    const int32_t *dst_tab;      // the items' places in the slab (see ItemDesc.dst_base)
+    const int16_t *pair_slot;    // [n_items][78]
+    const int8_t *blk_slot;      // [n_items][12]
     const double *Hprior;        // [171x171]
     double *bprior;              // [2][176]
     double *errprior;            // [2][160]
@@ -192,7 +174,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
                                  // count only while lm->pending
     int32_t imu_mask;            // bit k: IMU edge k exists (the host's copy of imu_valid: saves the kernels a dependent load)
     int32_t lm_gate;             // device-driven LM loop: 0 run; 2: skip if lm->stop; 3: skip unless lm->need_linearize && !lm->stop
-    const int32_t *red_tab;      // [RED_COUNT] k_reduce's arrays (a batched launch builds its ReduceTables from here)
+    const int32_t *list_off;     // k_reduce's inverted lists (a batched launch builds its ReduceTables from here)
+    const int32_t *list;
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
     // Sharded windows (multi-GPU): the exchange is an ALL-GATHER of every shard's vis[0 .. VIS_SEND) resp. step_tot[0 .. 2) into
     // these rank-major buffers, and whoever reads a sum forms it in rank order (d_vis, d_step_tot): every rank computes the
