@@ -405,21 +405,10 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
 extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
 typedef double ps_v4d __attribute__((ext_vector_type(4)));      // accumulator of v_mfma_f64_16x16x4_f64
 
-// LDS layout of an item: everything per landmark / per observation is stored field-major ("rows" of GS doubles, element g of a
-// row = landmark g).  Why: the operand streams of phase 2 then advance by a CONSTANT 16 / 32 bytes per matrix-core step, whatever
-// the pattern, so their loads are `ds_read_b64 v, base offset:imm` with no address arithmetic in the loop — a VALU instruction
-// behind a chain of dependent v_mfma waits until the last of them has started, and with per-step address computations every
-// product cost 97 cycles instead of the matrix core's 64-67 (tools/microbench/mfma_lds_stream.hip); phase 1 writes and the sums
-// over the landmarks read runs of consecutive doubles (no bank conflicts).
-//   row stride GS = (G + 1) | 1: odd (rows of different columns fall on different banks), and one past G is addressable
-//   sRows  K planes x NR rows: whitened Jacobian rows L*J of the k-th observations, row (2 col + r): col = host 0..5 | target 6..11
-//          (| extrinsic 12..17), r = which of the residual's two rows
-//   sL     (12 nb + 7) rows: w = Hpl (6 nb) | drho J^T Info r per block (6 nb) | 1/h | -b_l | h | the GN head's lambda', scale term, delta | spare
-//   sAux   QA rows of G*K: per-observation partials of the host / extrinsic sums (dead after phase 1.5: the tiles' place)
-__host__ __device__ inline int lin_gs(int G) { return (G + 1) | 1; }
-__host__ __device__ inline int lin_nr(int use_ext) { return use_ext ? 36 : 24; }        // rows of a plane
-__host__ __device__ inline int lin_qa(int use_ext) { return use_ext ? 26 : 14; }        // per-observation partials
-__host__ __device__ inline int lin_lrows(int nb) { return 12 * nb + 7; }
+__host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles)
+__host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 27 : 15; }      // per-observation partials (odd stride)
+__host__ __device__ inline int lin_plane(int G, int use_ext) { return G * lin_rrow(use_ext) + 6; }
+__host__ __device__ inline int lin_lrec(int nb) { return 12 * nb + 7; }                 // landmark record stride (odd): w, b, 1/h.., lambda, GN terms
 #define LIN_VS 8            // landmark splits of the vector sums of phase 2
 // tiles of phase 2: K direct products (1 tile of 16x16, 3 with the extrinsic) + the lower tiles of the 6nb x 6nb Schur term
 __host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
@@ -428,83 +417,10 @@ __host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
 }
 // total dynamic LDS of an item (doubles); must match the carve-up in k_linearize
 __host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext) {
-    int aux = G * K * lin_qa(use_ext), part = lin_tiles(K, nb, use_ext) * 256 + 2 * 6 * nb * LIN_VS;
+    int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256 + 2 * 6 * nb * LIN_VS;
     int shared = aux > part ? aux : part;
     shared = (shared + 1) & ~1;
-    const int rows = (K * lin_nr(use_ext) + lin_lrows(nb) + 1) * lin_gs(G);         // (+ 1 row of zeros)
-    return VIO_MAXK * PAIR_STRIDE + 16 + 3 * (LIN_THREADS / 64) + rows + (rows & 1) + shared;
-}
-
-// The two operand-streaming chains of k_linearize's phase 2, out of line: inside the kernel's body — at its 128-register cap, with
-// spills — the compiler schedules them for register pressure and sinks every load to its use (ds_read, s_waitcnt lgkmcnt(0),
-// v_mfma: an LDS round trip per product); as functions of their own they keep the software pipeline they are written with.
-// Operand element of MFMA step s at p[STEP * s] (field-major LDS rows: a constant stride, immediate offsets in the loads).
-typedef __attribute__((address_space(3))) const double lds_cdouble;
-__device__ __noinline__ ps_v4d lin_chain_direct(lds_cdouble *pa, lds_cdouble *pb, int chunks_full_v) {
-    const int chunks_full = __builtin_amdgcn_readfirstlane(chunks_full_v);      // (arguments travel in vector registers: a scalar loop counter again)
-    ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
-    double va[4], vb[4], xa[4], xb[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { va[u] = pa[2 * u]; vb[u] = pb[2 * u]; }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    int ch = 0;
-    for (; ch + 2 <= chunks_full; ch += 2) {          // two chunks per trip, the operand registers taking turns (no copies)
-        // (the sched_barriers pin "the next chunk's loads, then this chunk's products": the scheduler's own choice is to sink half of
-        // the loads to their uses)
-        pa += 8; pb += 8;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { xa[u] = pa[2 * u]; xb[u] = pb[2 * u]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
-        const int nx = ch + 2 < chunks_full ? 8 : 0;   // a load that would run past the last full chunk re-reads the chunk before it
-        pa += nx; pb += nx;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { va[u] = pa[2 * u]; vb[u] = pb[2 * u]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xb[u], acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ch < chunks_full) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
-    }
-    return acc;
-}
-__device__ __noinline__ ps_v4d lin_chain_schur(lds_cdouble *pa, lds_cdouble *pb, lds_cdouble *ph, int chunks_full_v) {
-    const int chunks_full = __builtin_amdgcn_readfirstlane(chunks_full_v);
-    ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
-    double va[4], vb[4], vh[4], xa[4], xb[4], xh[4];
-    if (chunks_full > 0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { va[u] = pa[4 * u]; vb[u] = pb[4 * u]; vh[u] = ph[4 * u]; }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    int ch = 0;
-    for (; ch + 2 <= chunks_full; ch += 2) {
-        pa += 16; pb += 16; ph += 16;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { xa[u] = pa[4 * u]; xb[u] = pb[4 * u]; xh[u] = ph[4 * u]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], -(vb[u] * vh[u]), acc, 0, 0, 0);
-        const int nx = ch + 2 < chunks_full ? 16 : 0;
-        pa += nx; pb += nx; ph += nx;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { va[u] = pa[4 * u]; vb[u] = pb[4 * u]; vh[u] = ph[4 * u]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], -(xb[u] * xh[u]), acc, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ch < chunks_full) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], -(vb[u] * vh[u]), acc, 0, 0, 0);
-    }
-    return acc;
+    return VIO_MAXK * PAIR_STRIDE + 16 + 3 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
 }
 
 // b_prior'[i] = b_prior[i] - (H_prior dx)[i]  (problem.cc:473), one wave per row; the same sum whoever calls it
@@ -550,24 +466,19 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     __syncthreads();
     const ItemDesc &it = sIt;
     STAMP(T, 0);
-    // (the descriptor comes out of LDS into vector registers; these are the same in every lane: scalar registers, scalar loop
-    // control and address arithmetic from here on)
-    const int G = __builtin_amdgcn_readfirstlane(it.G), K = __builtin_amdgcn_readfirstlane(it.K), nb = __builtin_amdgcn_readfirstlane(it.nb),
-              use_ext = __builtin_amdgcn_readfirstlane(it.use_ext);
-    const int GS = lin_gs(G), NR = lin_nr(use_ext), PLANE = NR * GS, GK = G * K;
-    const int colH = 0, colT = 6, colE = 12;                        // columns of a plane: row (2 col + r)
-    // per-observation partials of the landmark quantities (rows of sAux): host w (6), host b (6), h, b_l, [ext w (6), ext b (6)]
+    const int G = it.G, K = it.K, nb = it.nb, use_ext = it.use_ext;
+    const int RROW = lin_rrow(use_ext), RAUX = lin_raux(use_ext), PLANE = lin_plane(G, use_ext), LREC = lin_lrec(nb);
+    const int offH = 0, offT = 12, offE = 24;                       // inside a row record
+    // per-observation partials of the landmark quantities (sAux record): host w (6), host b (6), h, b_l, [ext w (6), ext b (6)]
     const int pkWH = 0, pkBH = 6, pkH = 12, pkBL = 13, pkWE = 14, pkBE = 20;
-    // rows of sL
-    const int rW = 0, rB = 6 * nb, rHinv = 12 * nb, rBl = 12 * nb + 1, rH = 12 * nb + 2, rLam = 12 * nb + 3, rSc = 12 * nb + 4, rDl = 12 * nb + 5;
 
     double *sPair = dyn_smem;                         // VIO_MAXK * PAIR_STRIDE
     double *sCam = sPair + VIO_MAXK * PAIR_STRIDE;    // ric, tic
+    double *sZero = sCam + 12;                        // a zero for the padding lanes of phase 2 (sCam holds 12 values)
     double *sRed = sCam + 16;                         // 3 * waves
-    double *sRows = sRed + 3 * (LIN_THREADS / 64);    // K planes of NR rows
-    double *sL = sRows + K * PLANE;                   // 12 nb + 7 rows
-    double *sZero = sL + lin_lrows(nb) * GS;          // a row of zeros: what the padding lanes of phase 2 stream
-    double *sAux = sZero + GS + ((K * NR + lin_lrows(nb) + 1) * GS & 1);      // QA rows of G*K, dead after phase 1.5 ... (kept 16-byte aligned)
+    double *sRows = sRed + 3 * (LIN_THREADS / 64);    // K * PLANE
+    double *sL = sRows + K * PLANE;                   // G * LREC
+    double *sAux = sL + G * LREC;                     // G*K*RAUX, dead after phase 1.5 ...
     double *sTile = sAux;                             // ... then the 16x16 tiles of phase 2 and the vector partials
 
     const double *invd = T.invd + (size_t)cur * T.Ns + it.lm_base;
@@ -624,15 +535,16 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
             const double lam = inv_prev + dl;
             // dxl and the new inverse depth go out to HBM at the end of the kernel: a global store in front of a barrier
             // costs the store's whole round trip
-            sL[rLam * GS + g] = lam;
-            sL[rSc * GS + g] = dl * (lambda_lm * dl + bl);
-            sL[rDl * GS + g] = dl;
+            double *L = sL + (size_t)g * LREC;
+            L[12 * nb + 3] = lam;
+            L[12 * nb + 4] = dl * (lambda_lm * dl + bl);
+            L[12 * nb + 5] = dl;
         }
         __syncthreads();
     }
     if (tid < K * PAIR_STRIDE) sPair[tid] = pv;
     if (tid < 12) sCam[tid] = cv;
-    if (tid >= 64 && tid < 64 + GS) sZero[tid - 64] = 0.0;            // (G <= 128: one pass)
+    if (tid >= 12 && tid < 16) sCam[tid] = 0.0;
     __syncthreads();
 
     const double s_info = T.sqrt_info, info = s_info * s_info;
@@ -646,7 +558,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         const int k = o / G, g = o - k * G;
         const double *PA = sPair + k * PAIR_STRIDE;
         const bool first = o == tid;
-        const double lam = owe ? sL[rLam * GS + g] : (first ? pf_lam : invd[g]);
+        const double lam = owe ? sL[(size_t)g * LREC + 12 * nb + 3] : (first ? pf_lam : invd[g]);
         const double il = 1.0 / lam;
         const double x = first ? pf_x : pts_i[2 * g], y = first ? pf_y : pts_i[2 * g + 1];
         const double u = first ? pf_u : pts_j[2 * o], v = first ? pf_v : pts_j[2 * o + 1];
@@ -703,25 +615,24 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         // The landmark quantities of phase 1.5 are sums over the landmark's observations; this thread has its own
         // term of each in registers.  Target-block terms have one contributor: they go straight to the landmark
         // record; host (and extrinsic) terms go to the per-observation partials and are summed in phase 1.5.
-        // (every store below is to element g resp. o of a row: the lanes of a wave write consecutive doubles)
-        double *rec = sRows + k * PLANE + g;              // row (2 col + r) at rec[(2 col + r) * GS]
-        double *pk = sAux + o;                            // partial q at pk[q * GK]
-        double *Lg = sL + g;                              // row r at Lg[r * GS]
+        double *rec = sRows + k * PLANE + g * RROW;
+        double *pk = sAux + (size_t)o * RAUX;
+        double *Lg = sL + (size_t)g * LREC;
         const int pT = it.tslot[k];
         const double a0 = L00 * Jl0 + L01 * Jl1, a1 = L01 * Jl0 + L11 * Jl1;      // whitened d r / d lambda
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const double lh0 = L00 * Jh0[c] + L01 * Jh1[c], lh1 = L01 * Jh0[c] + L11 * Jh1[c];
             const double lt0 = L00 * Jt0[c] + L01 * Jt1[c], lt1 = L01 * Jt0[c] + L11 * Jt1[c];
-            rec[(2 * (colH + c)) * GS] = lh0; rec[(2 * (colH + c) + 1) * GS] = lh1;
-            rec[(2 * (colT + c)) * GS] = lt0; rec[(2 * (colT + c) + 1) * GS] = lt1;
-            pk[(pkWH + c) * GK] = lh0 * a0 + lh1 * a1;          // Hpm column of this landmark, host block
-            pk[(pkBH + c) * GK] = Jh0[c] * c0 + Jh1[c] * c1;    // drho J^T Info r  (b gets the minus sign in phase 2)
-            Lg[(rW + 6 * pT + c) * GS] = lt0 * a0 + lt1 * a1;
-            Lg[(rB + 6 * pT + c) * GS] = Jt0[c] * c0 + Jt1[c] * c1;
+            rec[offH + c] = lh0; rec[offH + 6 + c] = lh1;
+            rec[offT + c] = lt0; rec[offT + 6 + c] = lt1;
+            pk[pkWH + c] = lh0 * a0 + lh1 * a1;                 // Hpm column of this landmark, host block
+            pk[pkBH + c] = Jh0[c] * c0 + Jh1[c] * c1;           // drho J^T Info r  (b gets the minus sign in phase 2)
+            Lg[6 * pT + c] = lt0 * a0 + lt1 * a1;
+            Lg[6 * nb + 6 * pT + c] = Jt0[c] * c0 + Jt1[c] * c1;
         }
-        pk[pkH * GK] = a0 * a0 + a1 * a1;
-        pk[pkBL * GK] = Jl0 * c0 + Jl1 * c1;
+        pk[pkH] = a0 * a0 + a1 * a1;
+        pk[pkBL] = Jl0 * c0 + Jl1 * c1;
         if (use_ext) {
             // J_ext = reduce * [El | -C hat(pc_i) + hat(C pc_i) + hat(d)] = [reduce*El | pc_i x (reduce*C)rows + red_rows x pc_j]
             double Je0[6], Je1[6], RC0[3], RC1[3];
@@ -740,9 +651,9 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const double le0 = L00 * Je0[c] + L01 * Je1[c], le1 = L01 * Je0[c] + L11 * Je1[c];
-                rec[(2 * (colE + c)) * GS] = le0; rec[(2 * (colE + c) + 1) * GS] = le1;
-                pk[(pkWE + c) * GK] = le0 * a0 + le1 * a1;
-                pk[(pkBE + c) * GK] = Je0[c] * c0 + Je1[c] * c1;
+                rec[offE + c] = le0; rec[offE + 6 + c] = le1;
+                pk[pkWE + c] = le0 * a0 + le1 * a1;
+                pk[pkBE + c] = Je0[c] * c0 + Je1[c] * c1;
             }
         }
     }
@@ -752,21 +663,19 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     STAMP(T, 2);
     double maxh = 0.0;
     {
-        // (quantity-major: the lanes of a wave take consecutive landmarks of one quantity — contiguous reads and writes, and the
-        // branch below is uniform but for the wave that straddles two quantities)
-        const int Q = lin_qa(use_ext);
+        const int Q = use_ext ? 26 : 14;
         const int hs = it.host_slot;
         for (int e = tid; e < G * Q; e += LIN_THREADS) {
-            const int q = e / G, g = e - q * G;
+            const int g = e / Q, q = e - g * Q;
             double sum = 0.0;
-            for (int k = 0; k < K; ++k) sum += sAux[q * GK + k * G + g];
-            double *L = sL + g;
-            if (q < pkBH) L[(rW + 6 * hs + q) * GS] = sum;
-            else if (q < pkH) L[(rB + 6 * hs + (q - pkBH)) * GS] = sum;
-            else if (q == pkH) { L[rHinv * GS] = 1.0 / sum; L[rH * GS] = sum; maxh = fmax(maxh, fabs(sum)); }   // Hmm_inv (problem.cc:419-425)
-            else if (q == pkBL) L[rBl * GS] = -sum;
-            else if (q < pkBE) L[(rW + q - pkWE) * GS] = sum;       // the extrinsic is pattern-local block 0
-            else L[(rB + (q - pkBE)) * GS] = sum;
+            for (int k = 0; k < K; ++k) sum += sAux[(size_t)(k * G + g) * RAUX + q];
+            double *L = sL + (size_t)g * LREC;
+            if (q < pkBH) L[6 * hs + q] = sum;
+            else if (q < pkH) L[6 * nb + 6 * hs + (q - pkBH)] = sum;
+            else if (q == pkH) { L[12 * nb] = 1.0 / sum; L[12 * nb + 2] = sum; maxh = fmax(maxh, fabs(sum)); }   // Hmm_inv (problem.cc:419-425)
+            else if (q == pkBL) L[12 * nb + 1] = -sum;
+            else if (q < pkBE) L[q - pkWE] = sum;                   // the extrinsic is pattern-local block 0
+            else L[6 * nb + (q - pkBE)] = sum;
         }
     }
     // The item's chi2, max |h_ll| and (GN) the previous step's gain-ratio partial: the wave partials go to LDS now, while the
@@ -775,7 +684,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     // thread g holds landmark g's term, so the sum is the one k_backsub forms — DPP inside waves 0 and 1, then wave 0 +
     // wave 1 — bit for bit.
     {
-        double sc = (owe && tid < G) ? sL[rSc * GS + tid] : 0.0;
+        double sc = (owe && tid < G) ? sL[(size_t)tid * LREC + 12 * nb + 4] : 0.0;
         const double ws = d_wave_sum_to_lane63(chi_acc), wsc = d_wave_sum_to_lane63(sc), wm = d_wave_max_to_lane63(maxh);
         if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
     }
@@ -801,30 +710,58 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
             if (wk < K * ntd) {
                 const int k = wk / ntd, t = wk - k * ntd;          // t: 0 -> tile (0,0), 1 -> (1,0), 2 -> (1,1)
                 const int Dk = use_ext ? 18 : 12;
-                const int ca = 16 * (t == 0 ? 0 : 1) + cl, cb = 16 * (t == 2 ? 1 : 0) + cl;      // column = host 0..5 | target 6..11 | extrinsic 12..17
-                // Per-lane operand stream: element (landmark 2 s + (rg >> 1), row rg & 1 of the residual, this lane's column) of MFMA step
-                // s sits at pa + 2 s: a constant 16 bytes per step, so the loads carry immediate offsets and the loop holds no address
-                // arithmetic but one pointer bump per chunk.  A padding column (>= Dk) streams the row of zeros the same way; the
-                // loads of chunk ch+1 are issued before the MFMAs of chunk ch and nothing touches them until the next iteration.
-                const double *plane = sRows + k * PLANE + (rg >> 1);
-                const double *pa = ca < Dk ? plane + (2 * ca + (rg & 1)) * GS : sZero;
-                const double *pb = cb < Dk ? plane + (2 * cb + (rg & 1)) * GS : sZero;
+                const int ca = 16 * (t == 0 ? 0 : 1) + cl, cb = 16 * (t == 2 ? 1 : 0) + cl;
+                const int cac = min(ca, Dk - 1), cbc = min(cb, Dk - 1);
+                // column -> offset inside a row record (host 0..5, target 6..11, extrinsic 12..17), + which of the 2 rows
+                const int oa = (cac < 6 ? offH + cac : (cac < 12 ? offT + cac - 6 : offE + cac - 12)) + (rg & 1) * 6;
+                const int ob = (cbc < 6 ? offH + cbc : (cbc < 12 ? offT + cbc - 6 : offE + cbc - 12)) + (rg & 1) * 6;
+                // Per-lane operand stream: element (landmark g, this lane's row of the pair, this lane's column) sits at
+                // pa + g * sa.  A padding column (>= Dk) streams a zero with stride 0 instead of being masked, so the
+                // steady state is loads and MFMAs only; the loads of chunk ch+1 are issued before the MFMAs of chunk ch
+                // and nothing touches them until the next iteration (no s_waitcnt in front of the matrix core).
+                const double *plane = sRows + k * PLANE + (rg >> 1) * RROW;
+                const double *pa = ca < Dk ? plane + oa : sZero;
+                const double *pb = cb < Dk ? plane + ob : sZero;
+                const int sa = ca < Dk ? 2 * RROW : 0, sb = cb < Dk ? 2 * RROW : 0;      // 2 landmarks per MFMA step
                 // (on a diagonal tile B is A: both streams are read all the same — a branch-free loop of loads and MFMAs
                 // is worth more than the four reads it would save)
                 const int steps_full = G >> 1;                       // steps whose two landmarks both exist
                 const int chunks_full = steps_full >> 2;
-                acc = lin_chain_direct((lds_cdouble *)pa, (lds_cdouble *)pb, chunks_full);
+                double va[4], vb[4], xa[4], xb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; }      // (G >= 1: in range even if unused)
+                // lgkmcnt(0) here, by hand: left to itself the compiler puts a partial wait on the loop header, i.e. in front
+                // of every chunk's MFMAs and on the loads just issued for the next one (an LDS latency per chunk)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                // two chunks per trip, the operand registers taking turns (no copies); a load that would run past the last
+                // full chunk re-reads the chunk before it instead of branching
+                int ch = 0;
+                for (; ch + 2 <= chunks_full; ch += 2) {
+                    pa += 4 * sa; pb += 4 * sb;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; xb[u] = pb[u * sb]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+                    const int nx = ch + 2 < chunks_full ? 4 : 0;
+                    pa += nx * sa; pb += nx * sb;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xb[u], acc, 0, 0, 0);
+                }
+                if (ch < chunks_full) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
+                }
                 STAMP(T, 14);
                 // the remaining steps (fewer than 4 full ones, plus the half step of an odd G), landmark by landmark masked
-                {
-                    const double *ra = ca < Dk ? sRows + k * PLANE + (2 * ca + (rg & 1)) * GS : sZero;
-                    const double *rb = cb < Dk ? sRows + k * PLANE + (2 * cb + (rg & 1)) * GS : sZero;
-                    for (int st = 4 * chunks_full; 2 * st < G; ++st) {
-                        const int g = 2 * st + (rg >> 1);
-                        const double m = g < G ? 1.0 : 0.0;
-                        const int gc = min(g, G - 1);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[gc] * m, rb[gc], acc, 0, 0, 0);
-                    }
+                for (int st = 4 * chunks_full; 2 * st < G; ++st) {
+                    const int g = 2 * st + (rg >> 1);
+                    const double m = g < G ? 1.0 : 0.0;
+                    const int gc = min(g, G - 1) - (rg >> 1);        // pa already points at landmark (rg >> 1)
+                    const double *qa = ca < Dk ? sRows + k * PLANE + (rg >> 1) * RROW + oa + (size_t)gc * RROW : sZero;
+                    const double *qb = cb < Dk ? sRows + k * PLANE + (rg >> 1) * RROW + ob + (size_t)gc * RROW : sZero;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0] * m, qb[0], acc, 0, 0, 0);
                 }
             } else {
                 const int ts = wk - K * ntd;
@@ -832,26 +769,50 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
                 while ((ta + 1) * (ta + 2) / 2 <= ts) ++ta;
                 const int tb = ts - ta * (ta + 1) / 2;
                 const int a = 16 * ta + cl, bq = 16 * tb + cl;
-                // same streaming as above: element (landmark 4 s + rg, column) at pa + 4 s: 32 bytes per MFMA step;
+                const int ac = min(a, D - 1), bc = min(bq, D - 1);
+                // same streaming as above: element (landmark g, column) at pa + g * LREC, 4 landmarks per MFMA step;
                 // B carries the -1/h_g of the landmark
-                const double *pa = a < D ? sL + (rW + a) * GS + rg : sZero;
-                const double *pb = bq < D ? sL + (rW + bq) * GS + rg : sZero;
-                const double *ph = sL + rHinv * GS + rg;
+                const double *pa = a < D ? sL + (size_t)rg * LREC + ac : sZero;
+                const double *pb = bq < D ? sL + (size_t)rg * LREC + bc : sZero;
+                const double *ph = sL + (size_t)rg * LREC + 12 * nb;
+                const int sa = a < D ? 4 * LREC : 0, sb = bq < D ? 4 * LREC : 0, sh = 4 * LREC;
                 const int chunks_full = (G >> 2) >> 2;               // chunks whose 16 landmarks all exist
+                double va[4], vb[4], vh[4], xa[4], xb[4], xh[4];
 #ifdef VIO_STAMPS
                 if (tid == 256) g_stamps[12] = __builtin_amdgcn_s_memtime();
 #endif
-                acc = lin_chain_schur((lds_cdouble *)pa, (lds_cdouble *)pb, (lds_cdouble *)ph, chunks_full);
+                if (chunks_full > 0) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; vh[u] = ph[u * sh]; }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                int ch = 0;
+                for (; ch + 2 <= chunks_full; ch += 2) {             // as above: two chunks per trip, registers taking turns
+                    pa += 4 * sa; pb += 4 * sb; ph += 4 * sh;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; xb[u] = pb[u * sb]; xh[u] = ph[u * sh]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], -(vb[u] * vh[u]), acc, 0, 0, 0);
+                    const int nx = ch + 2 < chunks_full ? 4 : 0;
+                    pa += nx * sa; pb += nx * sb; ph += nx * sh;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; vh[u] = ph[u * sh]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], -(xb[u] * xh[u]), acc, 0, 0, 0);
+                }
+                if (ch < chunks_full) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], -(vb[u] * vh[u]), acc, 0, 0, 0);
+                }
 #ifdef VIO_STAMPS
                 if (tid == 256) g_stamps[13] = __builtin_amdgcn_s_memtime();
 #endif
-                {
-                    const double *ra = a < D ? sL + (rW + a) * GS : sZero, *rb = bq < D ? sL + (rW + bq) * GS : sZero, *rh = sL + rHinv * GS;
-                    for (int st = 16 * chunks_full; st < G; st += 4) {   // the remaining landmarks, masked
-                        const int g = st + rg, gc = min(g, G - 1);
-                        const double m = g < G ? 1.0 : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[gc] * m, -(rb[gc] * rh[gc]), acc, 0, 0, 0);
-                    }
+                for (int st = 16 * chunks_full; st < G; st += 4) {   // the remaining landmarks, masked
+                    const int g = st + rg, gc = min(g, G - 1);
+                    const double m = g < G ? 1.0 : 0.0;
+                    const double *Lg = sL + (size_t)gc * LREC;
+                    const double wa = a < D ? Lg[ac] : 0.0, wb = bq < D ? Lg[bc] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa * m, -(wb * Lg[12 * nb]), acc, 0, 0, 0);
                 }
             }
             STAMP(T, 15);
@@ -866,8 +827,10 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         for (int e = tid - v0; e >= 0 && e < 2 * D * LIN_VS; e += LIN_THREADS - v0) {
             const int part = e % LIN_VS, a = (e / LIN_VS) % D, which = e / (LIN_VS * D);
             double sum = 0.0;
-            for (int g = part; g < G; g += LIN_VS)
-                sum += which == 0 ? -sL[(rB + a) * GS + g] : (sL[rHinv * GS + g] * sL[rBl * GS + g]) * sL[(rW + a) * GS + g];
+            for (int g = part; g < G; g += LIN_VS) {
+                const double *Lg = sL + (size_t)g * LREC;
+                sum += which == 0 ? -Lg[D + a] : (Lg[12 * nb] * Lg[12 * nb + 1]) * Lg[a];
+            }
             sVec[e] = sum;
         }
         STAMP(T, 7);
@@ -934,14 +897,16 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         if (owe && tid == 64) { T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0; }
         if (owe && tid < G) {               // the landmark update of the head, out to HBM now
             const size_t li = (size_t)it.lm_base + tid;
-            T.dxl[li] = sL[rDl * GS + tid];
-            T.invd[(size_t)cur * T.Ns + li] = sL[rLam * GS + tid];
+            const double *L = sL + (size_t)tid * LREC;
+            T.dxl[li] = L[12 * nb + 5];
+            T.invd[(size_t)cur * T.Ns + li] = L[12 * nb + 3];
         }
         // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
         double *lw = T.lw + lw_w + it.lw_base;
         for (int e = tid; e < (6 * nb + 2) * G; e += LIN_THREADS) {
             const int r = e / G, g = e - r * G;
-            lw[e] = sL[((r < 6 * nb) ? rW + r : (r == 6 * nb ? rH : rBl)) * GS + g];
+            const double *L = sL + (size_t)g * LREC;
+            lw[e] = (r < 6 * nb) ? L[r] : (r == 6 * nb ? L[12 * nb + 2] : L[12 * nb + 1]);
         }
     }
     STAMP(T, 5);
