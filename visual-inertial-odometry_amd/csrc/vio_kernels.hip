@@ -395,29 +395,30 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
 //   phase 1   thread per observation (k-major: a wave shares one target frame): residual, Jacobians, robust
 //             weight; the whitened rows L*J go to sRows (one plane per k), the thread's own terms of the
 //             per-landmark sums go to sAux (host/extrinsic blocks) or straight to the landmark record (target block)
-//   phase 1.5 thread per (landmark, quantity): sums the K per-observation terms: h_ll, b_l, Schur row w = Hpl, direct b
+//   phase 1.5 thread per (landmark, quantity): sums the K per-observation terms: h_ll, b_l, Schur row w = Hpl
 //   phase 2   one wave per 16x16 product on the matrix cores (v_mfma_f64_16x16x4_f64): C_k = V_k^T V_k for the
 //             whitened rows of every observation index k, and the Schur term - sum_g w_g w_g^T / h_g; the b vectors
-//             are plain sums over the landmarks; fixed summation order
+//             ride in the products' padding: the pose part of b as one more column z of V_k (L z = drho Info r), its
+//             Schur correction as one more row b_l of w; fixed summation order
 //   combine   thread per slab element picks its direct and Schur entries out of the tiles; coalesced store to the
 //             slab; w/h/b_l go to HBM last (the back-substitution reads them)
 // ---------------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
 typedef double ps_v4d __attribute__((ext_vector_type(4)));      // accumulator of v_mfma_f64_16x16x4_f64
 
-__host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles)
-__host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 27 : 15; }      // per-observation partials (odd stride)
+__host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles): 2 x 6 per block + (z0, z1)
+__host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 15 : 9; }       // per-observation partials (odd stride)
 __host__ __device__ inline int lin_plane(int G, int use_ext) { return G * lin_rrow(use_ext) + 6; }
-__host__ __device__ inline int lin_lrec(int nb) { return 12 * nb + 7; }                 // landmark record stride (odd): w, b, 1/h.., lambda, GN terms
+__host__ __device__ inline int lin_lrec(int nb) { return 6 * nb + 7; }                  // landmark record stride (odd): w, 1/h, b_l, h, lambda, GN terms
 #define LIN_VS 8            // landmark splits of the vector sums of phase 2
 // tiles of phase 2: K direct products (1 tile of 16x16, 3 with the extrinsic) + the lower tiles of the 6nb x 6nb Schur term
 __host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
-    const int ts = (6 * nb + 15) >> 4;
+    const int ts = (6 * nb + 16) >> 4;         // (one row past the 6 nb columns: the Schur correction of b rides there)
     return K * (use_ext ? 3 : 1) + ts * (ts + 1) / 2;
 }
 // total dynamic LDS of an item (doubles); must match the carve-up in k_linearize
 __host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext) {
-    int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256 + 2 * 6 * nb * LIN_VS;
+    int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256;
     int shared = aux > part ? aux : part;
     shared = (shared + 1) & ~1;
     return VIO_MAXK * PAIR_STRIDE + 16 + 3 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
@@ -466,11 +467,16 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     __syncthreads();
     const ItemDesc &it = sIt;
     STAMP(T, 0);
-    const int G = it.G, K = it.K, nb = it.nb, use_ext = it.use_ext;
+    // (the descriptor comes out of LDS into vector registers; these are the same in every lane: scalar registers, scalar loop
+    // control and address arithmetic from here on)
+    const int G = __builtin_amdgcn_readfirstlane(it.G), K = __builtin_amdgcn_readfirstlane(it.K), nb = __builtin_amdgcn_readfirstlane(it.nb),
+              use_ext = __builtin_amdgcn_readfirstlane(it.use_ext);
     const int RROW = lin_rrow(use_ext), RAUX = lin_raux(use_ext), PLANE = lin_plane(G, use_ext), LREC = lin_lrec(nb);
-    const int offH = 0, offT = 12, offE = 24;                       // inside a row record
-    // per-observation partials of the landmark quantities (sAux record): host w (6), host b (6), h, b_l, [ext w (6), ext b (6)]
-    const int pkWH = 0, pkBH = 6, pkH = 12, pkBL = 13, pkWE = 14, pkBE = 20;
+    const int offH = 0, offT = 12, offE = 24, offZ = RROW - 2;      // inside a row record; (z0, z1) at its end
+    // per-observation partials of the landmark quantities (sAux record): host w (6), h, b_l, [ext w (6)]
+    const int pkWH = 0, pkH = 6, pkBL = 7, pkWE = 8;
+    // inside a landmark record
+    const int lHinv = 6 * nb, lBl = 6 * nb + 1, lH = 6 * nb + 2, lLam = 6 * nb + 3, lSc = 6 * nb + 4, lDl = 6 * nb + 5;
 
     double *sPair = dyn_smem;                         // VIO_MAXK * PAIR_STRIDE
     double *sCam = sPair + VIO_MAXK * PAIR_STRIDE;    // ric, tic
@@ -536,9 +542,9 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
             // dxl and the new inverse depth go out to HBM at the end of the kernel: a global store in front of a barrier
             // costs the store's whole round trip
             double *L = sL + (size_t)g * LREC;
-            L[12 * nb + 3] = lam;
-            L[12 * nb + 4] = dl * (lambda_lm * dl + bl);
-            L[12 * nb + 5] = dl;
+            L[lLam] = lam;
+            L[lSc] = dl * (lambda_lm * dl + bl);
+            L[lDl] = dl;
         }
         __syncthreads();
     }
@@ -558,7 +564,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         const int k = o / G, g = o - k * G;
         const double *PA = sPair + k * PAIR_STRIDE;
         const bool first = o == tid;
-        const double lam = owe ? sL[(size_t)g * LREC + 12 * nb + 3] : (first ? pf_lam : invd[g]);
+        const double lam = owe ? sL[(size_t)g * LREC + lLam] : (first ? pf_lam : invd[g]);
         const double il = 1.0 / lam;
         const double x = first ? pf_x : pts_i[2 * g], y = first ? pf_y : pts_i[2 * g + 1];
         const double u = first ? pf_u : pts_j[2 * o], v = first ? pf_v : pts_j[2 * o + 1];
@@ -615,6 +621,10 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         // The landmark quantities of phase 1.5 are sums over the landmark's observations; this thread has its own
         // term of each in registers.  Target-block terms have one contributor: they go straight to the landmark
         // record; host (and extrinsic) terms go to the per-observation partials and are summed in phase 1.5.
+        // The pose part of b, -drho J^T Info r (problem.cc:357), is not formed per block at all: with z = L^-1 (drho Info r) it is
+        // -(L J)^T z, i.e. one more column of the product V_k^T V_k phase 2 forms anyway (the tile has 16 columns, V_k 12 or 18).
+        // drho Info r is parallel to r, an eigenvector of L = s (al I + (be - al) r r^T / |r|^2) with eigenvalue s be:
+        // z = drho Info r / (s be)   (be = 0 only where drho = 0: no contribution).
         double *rec = sRows + k * PLANE + g * RROW;
         double *pk = sAux + (size_t)o * RAUX;
         double *Lg = sL + (size_t)g * LREC;
@@ -627,9 +637,11 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
             rec[offH + c] = lh0; rec[offH + 6 + c] = lh1;
             rec[offT + c] = lt0; rec[offT + 6 + c] = lt1;
             pk[pkWH + c] = lh0 * a0 + lh1 * a1;                 // Hpm column of this landmark, host block
-            pk[pkBH + c] = Jh0[c] * c0 + Jh1[c] * c1;           // drho J^T Info r  (b gets the minus sign in phase 2)
             Lg[6 * pT + c] = lt0 * a0 + lt1 * a1;
-            Lg[6 * nb + 6 * pT + c] = Jt0[c] * c0 + Jt1[c] * c1;
+        }
+        {
+            const double zs = be > 0.0 ? 1.0 / (s_info * be) : 0.0;
+            rec[offZ] = c0 * zs; rec[offZ + 1] = c1 * zs;
         }
         pk[pkH] = a0 * a0 + a1 * a1;
         pk[pkBL] = Jl0 * c0 + Jl1 * c1;
@@ -653,7 +665,6 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
                 const double le0 = L00 * Je0[c] + L01 * Je1[c], le1 = L01 * Je0[c] + L11 * Je1[c];
                 rec[offE + c] = le0; rec[offE + 6 + c] = le1;
                 pk[pkWE + c] = le0 * a0 + le1 * a1;
-                pk[pkBE + c] = Je0[c] * c0 + Je1[c] * c1;
             }
         }
     }
@@ -663,19 +674,17 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     STAMP(T, 2);
     double maxh = 0.0;
     {
-        const int Q = use_ext ? 26 : 14;
-        const int hs = it.host_slot;
+        const int Q = use_ext ? 14 : 8;
+        const int hs = __builtin_amdgcn_readfirstlane(it.host_slot);
         for (int e = tid; e < G * Q; e += LIN_THREADS) {
             const int g = e / Q, q = e - g * Q;
             double sum = 0.0;
             for (int k = 0; k < K; ++k) sum += sAux[(size_t)(k * G + g) * RAUX + q];
             double *L = sL + (size_t)g * LREC;
-            if (q < pkBH) L[6 * hs + q] = sum;
-            else if (q < pkH) L[6 * nb + 6 * hs + (q - pkBH)] = sum;
-            else if (q == pkH) { L[12 * nb] = 1.0 / sum; L[12 * nb + 2] = sum; maxh = fmax(maxh, fabs(sum)); }   // Hmm_inv (problem.cc:419-425)
-            else if (q == pkBL) L[12 * nb + 1] = -sum;
-            else if (q < pkBE) L[q - pkWE] = sum;                   // the extrinsic is pattern-local block 0
-            else L[6 * nb + (q - pkBE)] = sum;
+            if (q < pkH) L[6 * hs + q] = sum;
+            else if (q == pkH) { L[lHinv] = 1.0 / sum; L[lH] = sum; maxh = fmax(maxh, fabs(sum)); }   // Hmm_inv (problem.cc:419-425)
+            else if (q == pkBL) L[lBl] = -sum;
+            else L[q - pkWE] = sum;                                 // the extrinsic is pattern-local block 0
         }
     }
     // The item's chi2, max |h_ll| and (GN) the previous step's gain-ratio partial: the wave partials go to LDS now, while the
@@ -684,7 +693,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     // thread g holds landmark g's term, so the sum is the one k_backsub forms — DPP inside waves 0 and 1, then wave 0 +
     // wave 1 — bit for bit.
     {
-        double sc = (owe && tid < G) ? sL[(size_t)tid * LREC + 12 * nb + 4] : 0.0;
+        double sc = (owe && tid < G) ? sL[(size_t)tid * LREC + lSc] : 0.0;
         const double ws = d_wave_sum_to_lane63(chi_acc), wsc = d_wave_sum_to_lane63(sc), wm = d_wave_max_to_lane63(maxh);
         if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
     }
@@ -700,8 +709,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     STAMP(T, 3);
     const int D = 6 * nb;
     const int ntd = use_ext ? 3 : 1;
-    const int TS = (D + 15) >> 4, nts = TS * (TS + 1) / 2;
-    double *sVec = sTile + (size_t)(K * ntd + nts) * 256;
+    const int TS = (D + 16) >> 4, nts = TS * (TS + 1) / 2;      // (row D of the Schur tiles carries the correction of b)
     {
         const int wave = tid >> 6, lane = tid & 63, cl = lane & 15, rg = lane >> 4;
         const int nwork = K * ntd + nts;
@@ -719,10 +727,12 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
                 // pa + g * sa.  A padding column (>= Dk) streams a zero with stride 0 instead of being masked, so the
                 // steady state is loads and MFMAs only; the loads of chunk ch+1 are issued before the MFMAs of chunk ch
                 // and nothing touches them until the next iteration (no s_waitcnt in front of the matrix core).
+                // Column Dk — the first padding column — is z (the row record's last two doubles): row Dk of the product is then
+                // sum_g (L J)^T z = sum_g drho J^T Info r, the pose part of b per block, at no extra instruction.
                 const double *plane = sRows + k * PLANE + (rg >> 1) * RROW;
-                const double *pa = ca < Dk ? plane + oa : sZero;
-                const double *pb = cb < Dk ? plane + ob : sZero;
-                const int sa = ca < Dk ? 2 * RROW : 0, sb = cb < Dk ? 2 * RROW : 0;      // 2 landmarks per MFMA step
+                const double *pa = ca < Dk ? plane + oa : (ca == Dk ? plane + offZ + (rg & 1) : sZero);
+                const double *pb = cb < Dk ? plane + ob : (cb == Dk ? plane + offZ + (rg & 1) : sZero);
+                const int sa = ca <= Dk ? 2 * RROW : 0, sb = cb <= Dk ? 2 * RROW : 0;      // 2 landmarks per MFMA step
                 // (on a diagonal tile B is A: both streams are read all the same — a branch-free loop of loads and MFMAs
                 // is worth more than the four reads it would save)
                 const int steps_full = G >> 1;                       // steps whose two landmarks both exist
@@ -759,8 +769,9 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
                     const int g = 2 * st + (rg >> 1);
                     const double m = g < G ? 1.0 : 0.0;
                     const int gc = min(g, G - 1) - (rg >> 1);        // pa already points at landmark (rg >> 1)
-                    const double *qa = ca < Dk ? sRows + k * PLANE + (rg >> 1) * RROW + oa + (size_t)gc * RROW : sZero;
-                    const double *qb = cb < Dk ? sRows + k * PLANE + (rg >> 1) * RROW + ob + (size_t)gc * RROW : sZero;
+                    const double *rec0 = sRows + k * PLANE + (rg >> 1) * RROW + (size_t)gc * RROW;
+                    const double *qa = ca < Dk ? rec0 + oa : (ca == Dk ? rec0 + offZ + (rg & 1) : sZero);
+                    const double *qb = cb < Dk ? rec0 + ob : (cb == Dk ? rec0 + offZ + (rg & 1) : sZero);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0] * m, qb[0], acc, 0, 0, 0);
                 }
             } else {
@@ -772,10 +783,12 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
                 const int ac = min(a, D - 1), bc = min(bq, D - 1);
                 // same streaming as above: element (landmark g, column) at pa + g * LREC, 4 landmarks per MFMA step;
                 // B carries the -1/h_g of the landmark
-                const double *pa = a < D ? sL + (size_t)rg * LREC + ac : sZero;
-                const double *pb = bq < D ? sL + (size_t)rg * LREC + bc : sZero;
-                const double *ph = sL + (size_t)rg * LREC + 12 * nb;
-                const int sa = a < D ? 4 * LREC : 0, sb = bq < D ? 4 * LREC : 0, sh = 4 * LREC;
+                // Row / column D — the first padding index — is b_l: row D of the product is then - sum_g b_l w_g / h_g, the Schur
+                // correction of b (problem.cc:429), at no extra instruction.
+                const double *pa = a < D ? sL + (size_t)rg * LREC + ac : (a == D ? sL + (size_t)rg * LREC + lBl : sZero);
+                const double *pb = bq < D ? sL + (size_t)rg * LREC + bc : (bq == D ? sL + (size_t)rg * LREC + lBl : sZero);
+                const double *ph = sL + (size_t)rg * LREC + lHinv;
+                const int sa = a <= D ? 4 * LREC : 0, sb = bq <= D ? 4 * LREC : 0, sh = 4 * LREC;
                 const int chunks_full = (G >> 2) >> 2;               // chunks whose 16 landmarks all exist
                 double va[4], vb[4], vh[4], xa[4], xb[4], xh[4];
 #ifdef VIO_STAMPS
@@ -811,8 +824,8 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
                     const int g = st + rg, gc = min(g, G - 1);
                     const double m = g < G ? 1.0 : 0.0;
                     const double *Lg = sL + (size_t)gc * LREC;
-                    const double wa = a < D ? Lg[ac] : 0.0, wb = bq < D ? Lg[bc] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa * m, -(wb * Lg[12 * nb]), acc, 0, 0, 0);
+                    const double wa = a < D ? Lg[ac] : (a == D ? Lg[lBl] : 0.0), wb = bq < D ? Lg[bc] : (bq == D ? Lg[lBl] : 0.0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa * m, -(wb * Lg[lHinv]), acc, 0, 0, 0);
                 }
             }
             STAMP(T, 15);
@@ -821,18 +834,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
             for (int v = 0; v < 4; ++v) tl[64 * v] = acc[v];
         }
         STAMP(T, 6);
-        // b vectors: which 0: direct b = - sum_g bvec_g;  1: Schur correction = sum_g (b_l/h)_g w_g   (fixed order)
-        // (by the waves that had no product to form, when there are any)
-        const int v0 = min(nwork, LIN_THREADS / 64 - 1) * 64;
-        for (int e = tid - v0; e >= 0 && e < 2 * D * LIN_VS; e += LIN_THREADS - v0) {
-            const int part = e % LIN_VS, a = (e / LIN_VS) % D, which = e / (LIN_VS * D);
-            double sum = 0.0;
-            for (int g = part; g < G; g += LIN_VS) {
-                const double *Lg = sL + (size_t)g * LREC;
-                sum += which == 0 ? -Lg[D + a] : (Lg[12 * nb] * Lg[12 * nb + 1]) * Lg[a];
-            }
-            sVec[e] = sum;
-        }
+        // (the b vectors need no sums of their own: row Dk of the direct products, row D of the Schur term)
         STAMP(T, 7);
     }
     __syncthreads();
@@ -880,12 +882,15 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
                 }
             } else {
                 const int ve = e - n_pair, which = ve / D, a = ve - which * D;
-                if (which < 2) {
-                    const double *pv = sVec + (size_t)(which * D + a) * LIN_VS;
-#pragma unroll
-                    for (int q = 0; q < LIN_VS; ++q) v += pv[q];
+                const int p = a / 6, i = a - 6 * p, ty = it.btype[p];
+                const int Dk = use_ext ? 18 : 12;
+                if (which == 0) {                               // pose part of b = - sum drho J^T Info r (problem.cc:357): row Dk of the direct products
+                    if (ty != 2) { for (int k = 0; k < K; ++k) v -= cdir(k, Dk, colof(ty, i)); }
+                    else v = -cdir(it.bk[p], Dk, 6 + i);
+                } else if (which == 1) {                        // its Schur correction sum_g (b_l / h)_g w_g: minus row D of the Schur term
+                    const int ta = D >> 4, tb = a >> 4;
+                    v = -sTile[(size_t)(K * ntd + ta * (ta + 1) / 2 + tb) * 256 + (D & 15) * 16 + (a & 15)];
                 } else {                                        // direct diagonal (diag(Hessian_) before the Schur complement)
-                    const int p = a / 6, i = a - 6 * p, ty = it.btype[p];
                     if (ty != 2) { for (int k = 0; k < K; ++k) v += cdir(k, colof(ty, i), colof(ty, i)); }
                     else v = cdir(it.bk[p], 6 + i, 6 + i);
                 }
@@ -898,15 +903,15 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         if (owe && tid < G) {               // the landmark update of the head, out to HBM now
             const size_t li = (size_t)it.lm_base + tid;
             const double *L = sL + (size_t)tid * LREC;
-            T.dxl[li] = L[12 * nb + 5];
-            T.invd[(size_t)cur * T.Ns + li] = L[12 * nb + 3];
+            T.dxl[li] = L[lDl];
+            T.invd[(size_t)cur * T.Ns + li] = L[lLam];
         }
         // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
         double *lw = T.lw + lw_w + it.lw_base;
         for (int e = tid; e < (6 * nb + 2) * G; e += LIN_THREADS) {
             const int r = e / G, g = e - r * G;
             const double *L = sL + (size_t)g * LREC;
-            lw[e] = (r < 6 * nb) ? L[r] : (r == 6 * nb ? L[12 * nb + 2] : L[12 * nb + 1]);
+            lw[e] = (r < 6 * nb) ? L[r] : (r == 6 * nb ? L[lH] : L[lBl]);
         }
     }
     STAMP(T, 5);
