@@ -397,8 +397,9 @@ def main():
     batched = None
     if rank == 0 and world == 1 and args.batch > 0:
         B = args.batch
-        lead = hip.context(device=local_rank)
-        members = [lead] + [hip.context(device=local_rank, stream=lead.get_stream()) for _ in range(B - 1)]
+        # (many windows share the device: items as large as the LDS holds, vio_config.item_policy)
+        lead = hip.context(device=local_rank, item_policy=vio.capi.ITEMS_THROUGHPUT)
+        members = [lead] + [hip.context(device=local_rank, stream=lead.get_stream(), item_policy=vio.capi.ITEMS_THROUGHPUT) for _ in range(B - 1)]
         wbs = []
         for i, cb in enumerate(members):
             wb = (vio.synth.make_window_xyz if xyz else vio.synth.make_window)(n_per_gpu, seed=100 + i, obs_per_landmark=k_obs)
@@ -419,8 +420,9 @@ def main():
                    "window_iterations_per_s": B * bsteps / tb, "us_per_window_iteration": tb * 1e6 / (bsteps * B),
                    "algorithmic_GBps": round(B * bytes_it * bsteps / tb / 1e9, 2), "hbm_frac": B * bytes_it * bsteps / tb / 8e12,
                    "final_chi2_window0": lead.chi2(),
-                   "note": "B independent 20k-landmark windows (seeds 100..), one launch per kernel for all of them (grid.y = window); "
-                           "bit-identical to B separate vio_gn_iteration runs (tests/test_gpu_batch.py)"}
+                   "note": "B independent 20k-landmark windows (seeds 100..), one launch per kernel for all of them (grid.y = window), contexts "
+                           "created with item_policy = VIO_ITEMS_THROUGHPUT; bit-identical to B separate vio_gn_iteration runs of such contexts "
+                           "(tests/test_gpu_batch.py)"}
         # Problem::Solve(10) of the same B windows in one batched call (vio_batch_solve), from their initial states; the uploads
         # in front of it are not timed (per_frame has those)
         ts, its = [], 0

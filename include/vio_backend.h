@@ -65,6 +65,8 @@ typedef enum {                 /* VM/include/backend/loss_function.h:23-91 */
     VIO_LOSS_TUKEY = 3
 } vio_loss_type;
 
+typedef enum { VIO_ITEMS_LATENCY = 0, VIO_ITEMS_THROUGHPUT = 1 } vio_item_policy;
+
 typedef enum {
     VIO_MARG_OLD = 0,          /* Estimator::MargOldFrame  estimator.cpp:693-829 */
     VIO_MARG_SECOND_NEW = 1    /* Estimator::MargNewFrame  estimator.cpp:830-901 */
@@ -74,7 +76,11 @@ typedef struct vio_config {
     int32_t device;            /* HIP device ordinal (ignored by the CPU libraries) */
     int32_t ext_fixed;         /* 1 == vertexExt->SetFixed(), i.e. ESTIMATE_EXTRINSIC == 0 (estimator.cpp:921-926) */
     int32_t loss_type;         /* vio_loss_type applied to every reprojection edge */
-    int32_t reserved0;
+    int32_t item_policy;       /* how the landmarks are cut into workgroup items: VIO_ITEMS_LATENCY (0, default) — the fewest rounds of
+                                * workgroups on the device's compute units, then the smallest items: what one window alone wants;
+                                * VIO_ITEMS_THROUGHPUT (1) — the largest items the LDS holds: fewer, longer workgroups, 17 % less time
+                                * per window when many windows share the device (vio_batch_*).  Results differ in the last bits
+                                * between the two (another grouping of the same sums). */
     double loss_delta;         /* CauchyLoss(1.0) in the reference */
     double reproj_sqrt_info;   /* s in project_sqrt_info_ = s*I2, reference s = 460/1.5; the edge information is
                                   s^2*I2 (estimator.cpp:42,1012) */

@@ -113,6 +113,38 @@ def test_solo_calls_on_batch_members_between_batch_calls(vio, hip_lib, oracle_li
             np.testing.assert_array_equal(x, y)
 
 
+def test_throughput_item_policy(vio, hip_lib, oracle_lib):
+    """vio_config.item_policy = VIO_ITEMS_THROUGHPUT: the largest items the LDS holds (what a batch wants).  Another grouping of the
+    same sums: batch and solo runs of such contexts agree bit for bit, and with the default policy to rounding."""
+    ws = [vio.synth.make_window(3000, seed=41), vio.synth.make_window(1200, seed=42, ragged=True)]
+    lam = 5e5
+    pol = vio.capi.ITEMS_THROUGHPUT
+    lead = hip_lib.context(item_policy=pol)
+    batch = [lead, hip_lib.context(stream=lead.get_stream(), item_policy=pol)]
+    solo = [hip_lib.context(item_policy=pol) for _ in ws]
+    dflt = [hip_lib.context() for _ in ws]
+    for c, r, d, w in zip(batch, solo, dflt, ws):
+        c.load(w)
+        r.load(w)
+        d.load(w)
+    for _ in range(3):
+        hip_lib.batch_gn_iteration(batch, lam)
+        for r in solo + dflt:
+            r.gn_iteration(lam)
+    for c, r, d in zip(batch, solo, dflt):
+        for x, y, z in zip(state_of(c), state_of(r), state_of(d)):
+            np.testing.assert_array_equal(x, y)
+            assert np.abs(np.asarray(x) - np.asarray(z)).max() <= 1e-9 * max(1.0, np.abs(np.asarray(z)).max())
+    # the policy can be changed on a living context (the plan is rebuilt)
+    dflt[0].set_config(item_policy=pol)
+    dflt[0].load(ws[0])
+    solo[0].load(ws[0])
+    dflt[0].gn_iteration(lam)
+    solo[0].gn_iteration(lam)
+    for x, y in zip(state_of(dflt[0]), state_of(solo[0])):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_batched_gn_xyz_windows(vio, hip_lib):
     """XYZ-landmark windows in one batch (k_linearize_xyz_b): equal to separate runs bit for bit, ragged sizes included."""
     ws = [vio.synth.make_window_xyz(600, seed=11, ragged=True), vio.synth.make_window_xyz(2000, seed=12), vio.synth.make_window_xyz(40, seed=13),

@@ -16,8 +16,9 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 its = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 xyz = len(sys.argv) > 4 and sys.argv[4] == "xyz"
 make = vio.synth.make_window_xyz if xyz else vio.synth.make_window
-lead = hip.context()
-members = [lead] + [hip.context(stream=lead.get_stream()) for _ in range(B - 1)]
+policy = int(os.environ.get("VIO_ITEM_POLICY", "1"))          # 1: VIO_ITEMS_THROUGHPUT (what a batch wants), 0: the single-window default
+lead = hip.context(item_policy=policy)
+members = [lead] + [hip.context(stream=lead.get_stream(), item_policy=policy) for _ in range(B - 1)]
 for i, c in enumerate(members):
     c.load(make(n, seed=100 + i))
 lam = 5e5

@@ -18,6 +18,7 @@ CAM_DIM = 6 + 6 * NUM_FRAMES       # 72
 
 LOSS_TRIVIAL, LOSS_HUBER, LOSS_CAUCHY, LOSS_TUKEY = 0, 1, 2, 3
 MARG_OLD, MARG_SECOND_NEW = 0, 1
+ITEMS_LATENCY, ITEMS_THROUGHPUT = 0, 1
 
 STATUS = {0: "VIO_OK", -1: "VIO_ERR_BAD_ARG", -2: "VIO_ERR_HIP", -3: "VIO_ERR_NOT_FINITE",
           -4: "VIO_ERR_EMPTY", -5: "VIO_ERR_UNSUPPORTED", -6: "VIO_ERR_NO_DEVICE"}
@@ -25,7 +26,7 @@ STATUS = {0: "VIO_OK", -1: "VIO_ERR_BAD_ARG", -2: "VIO_ERR_HIP", -3: "VIO_ERR_NO
 
 class VioConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("ext_fixed", C.c_int32), ("loss_type", C.c_int32),
-                ("reserved0", C.c_int32), ("loss_delta", C.c_double), ("reproj_sqrt_info", C.c_double),
+                ("item_policy", C.c_int32), ("loss_delta", C.c_double), ("reproj_sqrt_info", C.c_double),
                 ("gravity", C.c_double * 3), ("stream", C.c_void_p), ("shard_rank", C.c_int32),
                 ("shard_count", C.c_int32)]
 

@@ -363,7 +363,7 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
         const int cus = std::max(1, c->n_cus);
         int best_g = 0;
         double best_cost = 0.0;
-        for (int g = c->g_min; g <= 128; ++g) {
+        for (int g = (c->cfg.item_policy == VIO_ITEMS_THROUGHPUT ? 128 : c->g_min); g <= 128; ++g) {      // (throughput: the largest items the LDS holds)
             int64_t blocks = VIO_WINDOW_SIZE;
             int g_eff = 1;
             for (size_t q = 0; q < pl.patterns.size(); ++q) {
@@ -521,7 +521,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         const int cus = std::max(1, c->n_cus);
         int best_g = 0;
         double best_cost = 0.0;
-        for (int g = c->g_min; g <= 128; ++g) {
+        for (int g = (c->cfg.item_policy == VIO_ITEMS_THROUGHPUT ? 128 : c->g_min); g <= 128; ++g) {      // (throughput: the largest items the LDS holds)
             int64_t blocks = VIO_WINDOW_SIZE;
             int g_eff = 1;
             for (size_t q = 0; q < pl.patterns.size(); ++q) {
@@ -1106,7 +1106,7 @@ vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
     enter_device(c);
     VIOCHK(pull_from_device(c));
     void *keep_stream = c->cfg.stream;
-    const bool replan = cfg->ext_fixed != c->cfg.ext_fixed;     // the patterns carry an extrinsic block or not
+    const bool replan = cfg->ext_fixed != c->cfg.ext_fixed || cfg->item_policy != c->cfg.item_policy;     // the patterns carry an extrinsic block or not; the items' size
     c->cfg = *cfg;
     c->cfg.stream = keep_stream;
     if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
