@@ -569,39 +569,15 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         const double x = first ? pf_x : pts_i[2 * g], y = first ? pf_y : pts_i[2 * g + 1];
         const double u = first ? pf_u : pts_j[2 * o], v = first ? pf_v : pts_j[2 * o + 1];
         const double pci[3] = {x * il, y * il, il};
-        double Cp[3], pcj[3], pbi[3], pbj[3];
+        double Cp[3], pcj[3];
         d_m3_vec(PA + PAIR_C, pci, Cp);
 #pragma unroll
         for (int m = 0; m < 3; ++m) pcj[m] = Cp[m] + PA[PAIR_D + m];
-        d_m3_vec(ric, pci, pbi);
-        d_m3_vec(ric, pcj, pbj);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { pbi[m] += tic[m]; pbj[m] += tic[m]; }
         const double iz = 1.0 / pcj[2];
         const double r0 = pcj[0] * iz - u, r1 = pcj[1] * iz - v;
         const double ra = -pcj[0] * (iz * iz), rb = -pcj[1] * (iz * iz);     // reduce = [iz 0 ra; 0 iz rb]
         // J_lambda = reduce * C*pts_i * (-1/lam^2) = reduce * (C*pc_i) * (-1/lam)
         const double Jl0 = (iz * Cp[0] + ra * Cp[2]) * (-il), Jl1 = (iz * Cp[1] + rb * Cp[2]) * (-il);
-        // reduce*A, reduce*B, reduce*ric^T
-        double RA0[3], RA1[3], RB0[3], RB1[3], RR0[3], RR1[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            RA0[c] = iz * PA[PAIR_A + c] + ra * PA[PAIR_A + 6 + c];
-            RA1[c] = iz * PA[PAIR_A + 3 + c] + rb * PA[PAIR_A + 6 + c];
-            RB0[c] = iz * PA[PAIR_B + c] + ra * PA[PAIR_B + 6 + c];
-            RB1[c] = iz * PA[PAIR_B + 3 + c] + rb * PA[PAIR_B + 6 + c];
-            RR0[c] = iz * ric[3 * c] + ra * ric[3 * c + 2];
-            RR1[c] = iz * ric[3 * c + 1] + rb * ric[3 * c + 2];
-        }
-        // J_pose_i = [reduce*A | pb_i x (reduce*B)rows]   (row * hat(v) = row x v; -row x v = v x row)
-        double Jh0[6], Jh1[6], Jt0[6], Jt1[6];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { Jh0[c] = RA0[c]; Jh1[c] = RA1[c]; Jt0[c] = -RA0[c]; Jt1[c] = -RA1[c]; }
-        Jh0[3] = pbi[1] * RB0[2] - pbi[2] * RB0[1]; Jh0[4] = pbi[2] * RB0[0] - pbi[0] * RB0[2]; Jh0[5] = pbi[0] * RB0[1] - pbi[1] * RB0[0];
-        Jh1[3] = pbi[1] * RB1[2] - pbi[2] * RB1[1]; Jh1[4] = pbi[2] * RB1[0] - pbi[0] * RB1[2]; Jh1[5] = pbi[0] * RB1[1] - pbi[1] * RB1[0];
-        // J_pose_j = [-reduce*A | (reduce*ric^T)rows x pb_j]
-        Jt0[3] = RR0[1] * pbj[2] - RR0[2] * pbj[1]; Jt0[4] = RR0[2] * pbj[0] - RR0[0] * pbj[2]; Jt0[5] = RR0[0] * pbj[1] - RR0[1] * pbj[0];
-        Jt1[3] = RR1[1] * pbj[2] - RR1[2] * pbj[1]; Jt1[4] = RR1[2] * pbj[0] - RR1[0] * pbj[2]; Jt1[5] = RR1[0] * pbj[1] - RR1[1] * pbj[0];
 
         // robust weight: Edge::RobustInfo (edge.cc:48-74) with information = s^2 I
         const double e2 = r0 * (info * r0) + r1 * (info * r1);
@@ -617,6 +593,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         const double gm = (be - al) * irn2;
         const double L00 = s_info * (al + gm * r0 * r0), L01 = s_info * (gm * r0 * r1), L11 = s_info * (al + gm * r1 * r1);
         const double c0 = rho1 * (info * r0), c1 = rho1 * (info * r1);         // drho * Information * residual
+        const double a0 = L00 * Jl0 + L01 * Jl1, a1 = L01 * Jl0 + L11 * Jl1;      // whitened d r / d lambda
 
         // The landmark quantities of phase 1.5 are sums over the landmark's observations; this thread has its own
         // term of each in registers.  Target-block terms have one contributor: they go straight to the landmark
@@ -629,22 +606,61 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         double *pk = sAux + (size_t)o * RAUX;
         double *Lg = sL + (size_t)g * LREC;
         const int pT = it.tslot[k];
-        const double a0 = L00 * Jl0 + L01 * Jl1, a1 = L01 * Jl0 + L11 * Jl1;      // whitened d r / d lambda
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const double lh0 = L00 * Jh0[c] + L01 * Jh1[c], lh1 = L01 * Jh0[c] + L11 * Jh1[c];
-            const double lt0 = L00 * Jt0[c] + L01 * Jt1[c], lt1 = L01 * Jt0[c] + L11 * Jt1[c];
-            rec[offH + c] = lh0; rec[offH + 6 + c] = lh1;
-            rec[offT + c] = lt0; rec[offT + 6 + c] = lt1;
-            pk[pkWH + c] = lh0 * a0 + lh1 * a1;                 // Hpm column of this landmark, host block
-            Lg[6 * pT + c] = lt0 * a0 + lt1 * a1;
-        }
         {
             const double zs = be > 0.0 ? 1.0 / (s_info * be) : 0.0;
             rec[offZ] = c0 * zs; rec[offZ + 1] = c1 * zs;
         }
         pk[pkH] = a0 * a0 + a1 * a1;
         pk[pkBL] = Jl0 * c0 + Jl1 * c1;
+        // The two 2x6 Jacobians one after the other, each whitened and stored before the next is formed: all four rows alive at once,
+        // with what they are made of, is what pushed this loop over its 128 registers (65 spilled; now none on this path).
+        // reduce*A: first three columns of J_pose_i, negated those of J_pose_j
+        double RA0[3], RA1[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            RA0[c] = iz * PA[PAIR_A + c] + ra * PA[PAIR_A + 6 + c];
+            RA1[c] = iz * PA[PAIR_A + 3 + c] + rb * PA[PAIR_A + 6 + c];
+        }
+        {   // J_pose_i = [reduce*A | pb_i x (reduce*B)rows]   (row * hat(v) = row x v; -row x v = v x row)
+            double pbi[3], RB0[3], RB1[3], Jh0[6], Jh1[6];
+            d_m3_vec(ric, pci, pbi);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) pbi[m] += tic[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                RB0[c] = iz * PA[PAIR_B + c] + ra * PA[PAIR_B + 6 + c];
+                RB1[c] = iz * PA[PAIR_B + 3 + c] + rb * PA[PAIR_B + 6 + c];
+                Jh0[c] = RA0[c]; Jh1[c] = RA1[c];
+            }
+            Jh0[3] = pbi[1] * RB0[2] - pbi[2] * RB0[1]; Jh0[4] = pbi[2] * RB0[0] - pbi[0] * RB0[2]; Jh0[5] = pbi[0] * RB0[1] - pbi[1] * RB0[0];
+            Jh1[3] = pbi[1] * RB1[2] - pbi[2] * RB1[1]; Jh1[4] = pbi[2] * RB1[0] - pbi[0] * RB1[2]; Jh1[5] = pbi[0] * RB1[1] - pbi[1] * RB1[0];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double lh0 = L00 * Jh0[c] + L01 * Jh1[c], lh1 = L01 * Jh0[c] + L11 * Jh1[c];
+                rec[offH + c] = lh0; rec[offH + 6 + c] = lh1;
+                pk[pkWH + c] = lh0 * a0 + lh1 * a1;                 // Hpm column of this landmark, host block
+            }
+        }
+        {   // J_pose_j = [-reduce*A | (reduce*ric^T)rows x pb_j]
+            double pbj[3], RR0[3], RR1[3], Jt0[6], Jt1[6];
+            d_m3_vec(ric, pcj, pbj);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) pbj[m] += tic[m];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                RR0[c] = iz * ric[3 * c] + ra * ric[3 * c + 2];
+                RR1[c] = iz * ric[3 * c + 1] + rb * ric[3 * c + 2];
+                Jt0[c] = -RA0[c]; Jt1[c] = -RA1[c];
+            }
+            Jt0[3] = RR0[1] * pbj[2] - RR0[2] * pbj[1]; Jt0[4] = RR0[2] * pbj[0] - RR0[0] * pbj[2]; Jt0[5] = RR0[0] * pbj[1] - RR0[1] * pbj[0];
+            Jt1[3] = RR1[1] * pbj[2] - RR1[2] * pbj[1]; Jt1[4] = RR1[2] * pbj[0] - RR1[0] * pbj[2]; Jt1[5] = RR1[0] * pbj[1] - RR1[1] * pbj[0];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double lt0 = L00 * Jt0[c] + L01 * Jt1[c], lt1 = L01 * Jt0[c] + L11 * Jt1[c];
+                rec[offT + c] = lt0; rec[offT + 6 + c] = lt1;
+                Lg[6 * pT + c] = lt0 * a0 + lt1 * a1;
+            }
+        }
         if (use_ext) {
             // J_ext = reduce * [El | -C hat(pc_i) + hat(C pc_i) + hat(d)] = [reduce*El | pc_i x (reduce*C)rows + red_rows x pc_j]
             double Je0[6], Je1[6], RC0[3], RC1[3];
@@ -674,12 +690,20 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     STAMP(T, 2);
     double maxh = 0.0;
     {
+        // quantity q = tid / 128 (+ 8 per pass), landmark g = tid % 128 (G <= 128): a wave works on ONE quantity — the branch below
+        // is uniform, only the two waves of h_ll pay for the division — and no index needs an integer division
         const int Q = use_ext ? 14 : 8;
         const int hs = __builtin_amdgcn_readfirstlane(it.host_slot);
-        for (int e = tid; e < G * Q; e += LIN_THREADS) {
-            const int g = e / Q, q = e - g * Q;
+        const int g = tid & 127;
+        for (int q = __builtin_amdgcn_readfirstlane(tid >> 7); q < Q; q += LIN_THREADS / 128) {
+            if (g >= G) continue;
+            // (one pointer stepped by a scalar stride: the compiler's own 8-fold unrolling of the indexed form spent more on its eight
+            // 16-cycle address multiplications than the phase spends on the sums)
             double sum = 0.0;
-            for (int k = 0; k < K; ++k) sum += sAux[(size_t)(k * G + g) * RAUX + q];
+            const double *pq = sAux + (size_t)g * RAUX + q;
+            const int stp = G * RAUX;
+#pragma unroll 2
+            for (int k = 0; k < K; ++k) { sum += *pq; pq += stp; }
             double *L = sL + (size_t)g * LREC;
             if (q < pkH) L[6 * hs + q] = sum;
             else if (q == pkH) { L[lHinv] = 1.0 / sum; L[lH] = sum; maxh = fmax(maxh, fabs(sum)); }   // Hmm_inv (problem.cc:419-425)
@@ -693,8 +717,14 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     // thread g holds landmark g's term, so the sum is the one k_backsub forms — DPP inside waves 0 and 1, then wave 0 +
     // wave 1 — bit for bit.
     {
+        // (only the waves that hold terms run the DPP trees — 20 instructions each, three of them on all 16 waves were 1 k cycles of
+        // this phase —: chi2 lives in the observation threads, the step partial in the first G, max h_ll in the waves of quantity h)
+        const int wv64 = (tid >> 6) * 64;
         double sc = (owe && tid < G) ? sL[(size_t)tid * LREC + lSc] : 0.0;
-        const double ws = d_wave_sum_to_lane63(chi_acc), wsc = d_wave_sum_to_lane63(sc), wm = d_wave_max_to_lane63(maxh);
+        double ws = 0.0, wsc = 0.0, wm = 0.0;
+        if (wv64 < G * K) ws = d_wave_sum_to_lane63(chi_acc);
+        if (owe && wv64 < G) wsc = d_wave_sum_to_lane63(sc);
+        if ((tid >> 7) == pkH) wm = d_wave_max_to_lane63(maxh);
         if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
     }
     __syncthreads();
@@ -846,8 +876,11 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         const int n_out = it.n_rows * 6;
         const int n_pair = (nb * (nb + 1) / 2) * 36;
         // the block totals from the wave partials of phase 1.5 (fixed order: wave 0 first)
+        // (by two threads of the last wave, which has no slab element to form: on wave 0 these 48 dependent LDS reads and adds
+        // sat in front of its share of the elements)
+        const int tA = LIN_THREADS - 64, tB = LIN_THREADS - 32;
         double chi = 0.0, sc = 0.0, mh = 0.0;
-        if (tid == 0 || tid == 64) {
+        if (tid == tA || tid == tB) {
 #pragma unroll
             for (int w = 0; w < LIN_THREADS / 64; ++w) {
                 chi += sRed[w]; sc += sRed[LIN_THREADS / 64 + w]; mh = fmax(mh, sRed[2 * (LIN_THREADS / 64) + w]);
@@ -898,8 +931,8 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
             out[e] = v;
         }
         STAMP(T, 13);
-        if (tid == 0) { out[n_out] = chi; out[n_out + 1] = mh; }
-        if (owe && tid == 64) { T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0; }
+        if (tid == tA) { out[n_out] = chi; out[n_out + 1] = mh; }
+        if (owe && tid == tB) { T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0; }
         if (owe && tid < G) {               // the landmark update of the head, out to HBM now
             const size_t li = (size_t)it.lm_base + tid;
             const double *L = sL + (size_t)tid * LREC;
