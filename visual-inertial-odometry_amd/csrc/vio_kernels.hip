@@ -31,6 +31,11 @@
 #ifndef LIN_THREADS
 #define LIN_THREADS 1024
 #endif
+#ifdef LIN_MIN_WAVES            // (experiments with smaller workgroups, several to a CU: waves per SIMD the register allocation must leave room for)
+#define LIN_BOUNDS __launch_bounds__(LIN_THREADS, LIN_MIN_WAVES)
+#else
+#define LIN_BOUNDS __launch_bounds__(LIN_THREADS)
+#endif
 
 // In-kernel stamps exist only in the diagnostic build (-DVIO_STAMPS -> libvio_hip_stamps.so, never shipped or timed)
 #ifdef VIO_STAMPS
@@ -950,7 +955,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     STAMP(T, 5);
     STAMP_FLUSH(T);
 }
-__global__ __launch_bounds__(LIN_THREADS) void k_linearize(DeviceTables T) { d_linearize_body(T); }
+__global__ LIN_BOUNDS void k_linearize(DeviceTables T) { d_linearize_body(T); }
 
 // Batched launches (vio_batch_gn_iteration): B independent windows in one launch, blockIdx.y = window.  The windows'
 // tables sit in a device array built once per batch; what changes from iteration to iteration travels as kernel
@@ -968,7 +973,7 @@ __device__ __forceinline__ DeviceTables d_batch_tables(const BatchArgs &a) {
     T.lm_gate = a.gate;
     return T;
 }
-__global__ __launch_bounds__(LIN_THREADS) void k_linearize_b(BatchArgs a) {
+__global__ LIN_BOUNDS void k_linearize_b(BatchArgs a) {
     const DeviceTables T = d_batch_tables(a);
     if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;       // the grid is the widest window's
     d_linearize_body(T);
