@@ -40,7 +40,7 @@ struct ReduceTables {
 };
 void vio_launch_errprior(const DeviceTables &T, hipStream_t s);
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s);
-void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s);
+void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, int threads, hipStream_t s);
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
 void vio_launch_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map, hipStream_t s);
@@ -52,19 +52,21 @@ void vio_launch_lm_decide(const DeviceTables &T, int mode, int sum_local, hipStr
 void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
-void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int any_prior, size_t ps_lds, int what,
-                         int max_iter, hipStream_t s);
-void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
-                         size_t ps_lds, hipStream_t s);
+void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int any_prior, size_t ps_lds,
+                         int what, int max_iter, hipStream_t s);
+void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int test_prev, int any_prior,
+                         int parity, size_t ps_lds, hipStream_t s);
 int vio_set_kernel_attributes();
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext);
 int lin_threads_host();
+int lin_threads_half_host();
 int xyz_lds_doubles_host(int G, int K);
 
 namespace {
 
 constexpr int NF = VIO_NUM_FRAMES, PD = VIO_POSE_DIM, PRD = VIO_PRIOR_DIM;
 constexpr int LDS_BUDGET_DOUBLES = (160 * 1024 - 512) / 8;   // per linearize workgroup: 160 KiB per CU on gfx950, 112 bytes of it static
+constexpr int LDS_BUDGET_HALF_DOUBLES = (80 * 1024 - 512) / 8;   // two workgroups to a CU (k_linearize_h: plans of the throughput policy)
 constexpr int POSE_SOLVE_TILED = 66 * 272 + 192;   // PS_PACKED of vio_kernels.hip: 66 tiles of 16x17 + the rhs row
 constexpr int POSE_SOLVE_LDS = (POSE_SOLVE_TILED + 176 + 272 + 272 + 192 + 176 + 112 + 176 + 184) * 8 + 176 * 4 + 64;
 constexpr int IMU_ITEM_LDS_DOUBLES = 450 + 225 + 450 + 32;
@@ -160,6 +162,7 @@ struct Plan {
     std::vector<int32_t> list_off, list;
     size_t slab_doubles = 0, lw_doubles = 0;
     int max_lds_doubles = 0;
+    int lin_threads = 0;                       // k_linearize's workgroup width for this plan: lin_threads_host(), or lin_threads_half_host() (two workgroups to a CU)
     DevBuf<ItemDesc> d_items;
     DevBuf<int32_t> d_list_off, d_list;
     DevBuf<double> d_pts_i, d_pts_j, d_invd, d_slab, d_lw, d_dxl, d_step_part;
@@ -283,7 +286,7 @@ vio_status fail(vio_ctx *c, vio_status s, const std::string &msg) {
 // Block types of a pattern, its slab size and the largest G that fits the LDS budget.  The slab of an item holds,
 // in this order: the 6x6 blocks of the pattern-local pairs (p <= q, p-major), then per block the direct b, the Schur
 // correction of b and the direct diagonal, then chi2 and max h_ll (k_linearize writes it, k_reduce's lists index it).
-void build_pattern_tables(Pattern &pt, int g_max) {
+void build_pattern_tables(Pattern &pt, int g_max, int threads, int lds_budget) {
     const int nb = pt.nb, K = pt.K;
     int *type = pt.btype_i, *kof = pt.bk_i;
     for (int p = 0; p < nb; ++p) {
@@ -292,9 +295,9 @@ void build_pattern_tables(Pattern &pt, int g_max) {
     }
     for (int k = 0; k < K; ++k) kof[pt.tslot[k]] = k;
     pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
-    int G = std::max(1, std::min(g_max, lin_threads_host() / K));          // one thread per observation in k_linearize's phase 1
-    while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext) > LDS_BUDGET_DOUBLES) --G;
-    while (G > 1 && (6 * nb + 2) * G > 7 * lin_threads_host()) --G;        // k_linearize stages the item's Schur rows with 7 loads per thread
+    int G = std::max(1, std::min(g_max, threads / K));                     // one thread per observation in k_linearize's phase 1
+    while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext) > lds_budget) --G;
+    while (G > 1 && (6 * nb + 2) * G > 7 * threads) --G;                   // k_linearize stages the item's Schur rows with 7 loads per thread
     pt.G = G;
     pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
 }
@@ -308,6 +311,7 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *
 vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
     pl.valid = false;
     pl.marg = marg; pl.use_ext = 0; pl.lm_dim = 3;
+    pl.lin_threads = lin_threads_host();
     const int64_t N = (int64_t)c->h_invd.size() / 3, M = (int64_t)c->h_olm.size();
     // observation of landmark l in frame f: obs_at[l * NF + f] (or -1)
     std::vector<int32_t> obs_at((size_t)std::max<int64_t>(N, 1) * NF, -1);
@@ -430,6 +434,9 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     pl.valid = false;
     pl.marg = marg; pl.lm_dim = 1;
     pl.use_ext = marg ? 1 : (c->cfg.ext_fixed ? 0 : 1);
+    // the throughput policy's plans run on k_linearize_h: half the threads, half the LDS, two workgroups to a CU
+    const bool half = c->cfg.item_policy == VIO_ITEMS_THROUGHPUT && !std::getenv("VIO_NO_HALF_WIDTH");
+    pl.lin_threads = half ? lin_threads_half_host() : lin_threads_host();
     const int64_t N = (int64_t)c->h_invd.size(), M = (int64_t)c->h_olm.size();
     static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -495,7 +502,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
                 pt.target[k] = key[1 + k];
                 for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + key[1 + k]) pt.tslot[k] = (int8_t)q;
             }
-            build_pattern_tables(pt, c->g_max > 0 ? c->g_max : 128);      // pt.G = the most landmarks the LDS holds
+            build_pattern_tables(pt, c->g_max > 0 ? c->g_max : 128, pl.lin_threads, half ? LDS_BUDGET_HALF_DOUBLES : LDS_BUDGET_DOUBLES);      // pt.G = the most landmarks the LDS holds
             pl.patterns.push_back(pt);
         } else id = itp->second;
         lm_pattern[l] = id;
@@ -938,7 +945,7 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     if (gn) T.cur_hint = c->cur_host;
     if (test_prev) T.gn_flags = 2;
     if (!c->pairtab_valid && pl.lm_dim == 1) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
-    { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
+    { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, pl.lin_threads, c->stream); }
     // with a prior, the previous GN step left err_prior to this k_reduce (k_pose_solve wrote b_prior' only)
     const bool err_prev = test_prev && T.has_prior;
     // sharded + gated slot: the all-reduce below runs whether the slot is live or not (every rank enqueues the same
@@ -1013,7 +1020,7 @@ vio_status enqueue_lm_slot(vio_ctx *c, Plan &pl, bool first) {
     T.lm_gate = 2;
     if (!first) {
         T.gn_flags = 2;
-        { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, c->stream); }
+        { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, pl.lin_threads, c->stream); }
         // (sharded: k_reduce always runs, see enqueue_linearize)
         ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, T.step_part, T.n_items, sharded(c) ? 0 : 2, T.lm,
                        T.has_prior ? T.Jtinv : nullptr, T.has_prior ? T.bprior : nullptr, T.has_prior ? T.errprior : nullptr, 1};
@@ -1516,15 +1523,17 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         c->batch_iters = 0;
     }
     int max_blocks = 1, any_prior = 0;
+    int lin_threads = lin_threads_half_host();               // half-width workgroups only if every window's plan was sized for them
     size_t lds = 0;
     for (int i = 0; i < count; ++i) {
         const Plan &pl = ctxs[i]->solve_plan;
+        if (pl.lin_threads != lin_threads_half_host()) lin_threads = lin_threads_host();
         max_blocks = std::max<int>(max_blocks, (int)pl.items.size() + VIO_WINDOW_SIZE);
         lds = std::max(lds, (size_t)pl.max_lds_doubles * 8);
         any_prior |= ctxs[i]->has_prior;
     }
     const int test_prev = ctxs[0]->decide_pending ? 1 : 0;
-    vio_launch_batch_gn(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, c->stream);
+    vio_launch_batch_gn(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, c->stream);
     HIPCHK(hipGetLastError());
     ++c->batch_iters;
     for (int i = 0; i < count; ++i) {
@@ -1561,6 +1570,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
     if (has_duplicates(ctxs, count)) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_solve: a context appears twice (two windows of the grid would write the same buffers)");
     std::vector<DeviceTables> tabs((size_t)count);
     int max_blocks = 1, any_prior = 0;
+    int lin_threads = lin_threads_half_host();
     size_t lds = 0;
     for (int i = 0; i < count; ++i) {
         vio_ctx *m = ctxs[i];
@@ -1572,6 +1582,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         tabs[i] = make_tables_raw(m, m->solve_plan);         // cur_hint = -1: the kernels take `cur` from the window's LmState
         if (!m->pairtab_valid && m->lm_dim == 1) { vio_launch_prepare(tabs[i], m->stream); m->pairtab_valid = true; }
         const Plan &pl = m->solve_plan;
+        if (pl.lin_threads != lin_threads_half_host()) lin_threads = lin_threads_host();
         max_blocks = std::max<int>(max_blocks, (int)pl.items.size() + VIO_WINDOW_SIZE);
         lds = std::max(lds, (size_t)pl.max_lds_doubles * 8);
         any_prior |= m->has_prior;
@@ -1590,8 +1601,8 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         return VIO_OK;
     };
     static const bool classic = std::getenv("VIO_LM_CLASSIC") != nullptr;
-    vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, 0, iterations, c->stream);
-    if (!classic && iterations > 0) vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, 3, iterations, c->stream);
+    vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, 0, iterations, c->stream);
+    if (!classic && iterations > 0) vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, 3, iterations, c->stream);
     HIPCHK(hipGetLastError());
     if (classic || iterations <= 0) VIOCHK(read_all());
     else for (int i = 0; i < count; ++i) { ctxs[i]->h_lm.stop = 0; ctxs[i]->h_lm.iter = 0; }
@@ -1613,7 +1624,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         }
         const int batch = std::min(left, 10);
         for (int sl = 0; sl < batch; ++sl)
-            vio_launch_batch_lm(c->d_batch_tabs.p, (int)live.size(), c->lm_dim, max_blocks, lds, any_prior, POSE_SOLVE_LDS, classic ? 1 : 2, iterations, c->stream);
+            vio_launch_batch_lm(c->d_batch_tabs.p, (int)live.size(), c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, classic ? 1 : 2, iterations, c->stream);
         HIPCHK(hipGetLastError());
         VIOCHK(read_all());
     }

@@ -330,7 +330,7 @@ __device__ void d_imu_jac_block(int blk, const double *pre, const double *G, con
 }
 
 // T = J^T Info J (30x30), g = J^T Info r, chi = r^T Info r  for IMU edge k
-__device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
+template <int NT> __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
     const int tid = threadIdx.x;
     double *sJ = smem;               // 450
     double *sI = sJ + 450;           // 225 information
@@ -339,15 +339,15 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
     double *sIr = sr + 16;           // 15
     double *out = T.imu_out + k * IMU_OUT;
     if (!T.imu_valid[k]) {
-        for (int e = tid; e < IMU_OUT; e += LIN_THREADS) out[e] = 0.0;
+        for (int e = tid; e < IMU_OUT; e += NT) out[e] = 0.0;
         return;
     }
     const int cur = d_cur(T);
     const double *st = T.state + cur * STATE_STRIDE;
     const double *pre = T.pre + k * PRE_STRIDE;
     const double *pi = st + STATE_POSE + 7 * k, *pj = pi + 7, *si = st + STATE_SB + 9 * k, *sj = si + 9;
-    for (int e = tid; e < 450; e += LIN_THREADS) sJ[e] = 0.0;
-    for (int e = tid; e < 225; e += LIN_THREADS) sI[e] = pre[PRE_INFO + e];
+    for (int e = tid; e < 450; e += NT) sJ[e] = 0.0;
+    for (int e = tid; e < 225; e += NT) sI[e] = pre[PRE_INFO + e];
     __syncthreads();
     if (tid < 16) {
         ImuCommon c;
@@ -365,7 +365,7 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
         }
     }
     __syncthreads();
-    for (int e = tid; e < 450; e += LIN_THREADS) {      // JtI[a][j] = sum_i J[i][a] * I[i][j]
+    for (int e = tid; e < 450; e += NT) {      // JtI[a][j] = sum_i J[i][a] * I[i][j]
         const int a = e / 15, j = e % 15;
         double s = 0;
         for (int i = 0; i < 15; ++i) s += sJ[30 * i + a] * sI[15 * i + j];
@@ -377,7 +377,7 @@ __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
         sIr[tid] = s;
     }
     __syncthreads();
-    for (int e = tid; e < 900; e += LIN_THREADS) {
+    for (int e = tid; e < 900; e += NT) {
         const int a = e / 30, b = e % 30;
         double s = 0;
         for (int j = 0; j < 15; ++j) s += sJtI[15 * a + j] * sJ[30 * j + b];
@@ -449,7 +449,7 @@ __device__ __forceinline__ void d_bprior_rows(const DeviceTables &T, int from, i
     }
 }
 
-__device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
+template <int NT> __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (d_gated_off(T.lm, T.lm_gate)) return;
@@ -459,8 +459,8 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     const bool owe_prior = owe && T.has_prior;
     if (b >= T.n_items) {
         STAMP(T, 0);
-        if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
-        d_imu_item(T, b - T.n_items, dyn_smem);
+        if (owe_prior && (tid >> 6) == NT / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
+        d_imu_item<NT>(T, b - T.n_items, dyn_smem);
         STAMP(T, 5);
         STAMP_FLUSH(T);
         return;
@@ -519,17 +519,17 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     // one round trip instead of one per pattern block — into LDS that phase 1 only needs later (sAux, sPair).
     if (owe) {
         const double *lw = T.lw + lw_r + it.lw_base;
-        const int nlw = (6 * nb + 2) * G;                  // <= 7 * LIN_THREADS: nb <= 12, G <= 86
+        const int nlw = (6 * nb + 2) * G;                  // <= 7 * NT: nb <= 12, G <= 86
         double *sStage = sAux, *sDxS = sPair;
         double stv[7];
 #pragma unroll
-        for (int q = 0; q < 7; ++q) { const int e = tid + q * LIN_THREADS; stv[q] = e < nlw ? lw[e] : 0.0; }
+        for (int q = 0; q < 7; ++q) { const int e = tid + q * NT; stv[q] = e < nlw ? lw[e] : 0.0; }
         const double dxv = tid < VIO_PD ? T.dx[tid] : 0.0;
         // (what the update itself reads from HBM is requested here too, not behind the barrier)
         const double inv_prev = tid < G ? T.invd[(size_t)(cur ^ 1) * T.Ns + it.lm_base + tid] : 0.0;
         const double lambda_lm = T.lm->lambda;
 #pragma unroll
-        for (int q = 0; q < 7; ++q) { const int e = tid + q * LIN_THREADS; if (e < nlw) sStage[e] = stv[q]; }
+        for (int q = 0; q < 7; ++q) { const int e = tid + q * NT; if (e < nlw) sStage[e] = stv[q]; }
         if (tid < 176) sDxS[tid] = dxv;
         __syncthreads();
         if (tid < G) {
@@ -563,9 +563,9 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
 
     // ---------------- phase 1 ----------------
     STAMP(T, 1);
-    if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, T.n_step_blocks, tid & 63);
+    if (owe_prior && (tid >> 6) == NT / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, T.n_step_blocks, tid & 63);
     double chi_acc = 0.0;
-    for (int o = tid; o < G * K; o += LIN_THREADS) {
+    for (int o = tid; o < G * K; o += NT) {
         const int k = o / G, g = o - k * G;
         const double *PA = sPair + k * PAIR_STRIDE;
         const bool first = o == tid;
@@ -700,7 +700,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         const int Q = use_ext ? 14 : 8;
         const int hs = __builtin_amdgcn_readfirstlane(it.host_slot);
         const int g = tid & 127;
-        for (int q = __builtin_amdgcn_readfirstlane(tid >> 7); q < Q; q += LIN_THREADS / 128) {
+        for (int q = __builtin_amdgcn_readfirstlane(tid >> 7); q < Q; q += NT / 128) {
             if (g >= G) continue;
             // (one pointer stepped by a scalar stride: the compiler's own 8-fold unrolling of the indexed form spent more on its eight
             // 16-cycle address multiplications than the phase spends on the sums)
@@ -730,7 +730,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         if (wv64 < G * K) ws = d_wave_sum_to_lane63(chi_acc);
         if (owe && wv64 < G) wsc = d_wave_sum_to_lane63(sc);
         if ((tid >> 7) == pkH) wm = d_wave_max_to_lane63(maxh);
-        if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
+        if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[NT / 64 + (tid >> 6)] = wsc; sRed[2 * (NT / 64) + (tid >> 6)] = wm; }
     }
     __syncthreads();
 
@@ -748,7 +748,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     {
         const int wave = tid >> 6, lane = tid & 63, cl = lane & 15, rg = lane >> 4;
         const int nwork = K * ntd + nts;
-        for (int wk = wave; wk < nwork; wk += LIN_THREADS / 64) {
+        for (int wk = wave; wk < nwork; wk += NT / 64) {
             ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
             if (wk < K * ntd) {
                 const int k = wk / ntd, t = wk - k * ntd;          // t: 0 -> tile (0,0), 1 -> (1,0), 2 -> (1,1)
@@ -883,12 +883,12 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         // the block totals from the wave partials of phase 1.5 (fixed order: wave 0 first)
         // (by two threads of the last wave, which has no slab element to form: on wave 0 these 48 dependent LDS reads and adds
         // sat in front of its share of the elements)
-        const int tA = LIN_THREADS - 64, tB = LIN_THREADS - 32;
+        const int tA = NT - 64, tB = NT - 32;
         double chi = 0.0, sc = 0.0, mh = 0.0;
         if (tid == tA || tid == tB) {
 #pragma unroll
-            for (int w = 0; w < LIN_THREADS / 64; ++w) {
-                chi += sRed[w]; sc += sRed[LIN_THREADS / 64 + w]; mh = fmax(mh, sRed[2 * (LIN_THREADS / 64) + w]);
+            for (int w = 0; w < NT / 64; ++w) {
+                chi += sRed[w]; sc += sRed[NT / 64 + w]; mh = fmax(mh, sRed[2 * (NT / 64) + w]);
             }
         }
         STAMP(T, 12);
@@ -899,7 +899,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
             return sTile[(size_t)(k * ntd + t) * 256 + (hi & 15) * 16 + (lo & 15)];
         };
         auto colof = [&](int ty, int i) { return ty == 1 ? i : (ty == 2 ? 6 + i : 12 + i); };
-        for (int e = tid; e < n_out; e += LIN_THREADS) {
+        for (int e = tid; e < n_out; e += NT) {
             double v = 0.0;
             if (e < n_pair) {
                 const int pi = e / 36, rem = e - 36 * pi, i = rem / 6, j = rem - 6 * i;
@@ -946,7 +946,7 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
         }
         // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
         double *lw = T.lw + lw_w + it.lw_base;
-        for (int e = tid; e < (6 * nb + 2) * G; e += LIN_THREADS) {
+        for (int e = tid; e < (6 * nb + 2) * G; e += NT) {
             const int r = e / G, g = e - r * G;
             const double *L = sL + (size_t)g * LREC;
             lw[e] = (r < 6 * nb) ? L[r] : (r == 6 * nb ? L[lH] : L[lBl]);
@@ -955,7 +955,14 @@ __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     STAMP(T, 5);
     STAMP_FLUSH(T);
 }
-__global__ LIN_BOUNDS void k_linearize(DeviceTables T) { d_linearize_body(T); }
+__global__ LIN_BOUNDS void k_linearize(DeviceTables T) { d_linearize_body<LIN_THREADS>(T); }
+// The same kernel with half the threads and two workgroups to a CU (items of at most half the LDS): what the throughput policy's
+// plans run on (vio_config.item_policy = VIO_ITEMS_THROUGHPUT).  When every CU has workgroup after workgroup to run, a CU sits
+// idle for 1.7 us between two of them and a workgroup's head is two dependent round trips that overlap nothing
+// (tools/diag_batch_stamps.py, profiles/r03h_*); two co-resident workgroups fill each other's gaps.  For one window in one
+// round of workgroups it is slower (twice the fixed part of a workgroup): the latency policy keeps the 1024-thread kernel.
+#define LIN_THREADS_H 512
+__global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_h(DeviceTables T) { d_linearize_body<LIN_THREADS_H>(T); }
 
 // Batched launches (vio_batch_gn_iteration): B independent windows in one launch, blockIdx.y = window.  The windows'
 // tables sit in a device array built once per batch; what changes from iteration to iteration travels as kernel
@@ -976,7 +983,12 @@ __device__ __forceinline__ DeviceTables d_batch_tables(const BatchArgs &a) {
 __global__ LIN_BOUNDS void k_linearize_b(BatchArgs a) {
     const DeviceTables T = d_batch_tables(a);
     if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;       // the grid is the widest window's
-    d_linearize_body(T);
+    d_linearize_body<LIN_THREADS>(T);
+}
+__global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_hb(BatchArgs a) {
+    const DeviceTables T = d_batch_tables(a);
+    if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;
+    d_linearize_body<LIN_THREADS_H>(T);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2322,16 +2334,22 @@ void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
 // host-callable launchers (C++ linkage inside the library)
 // ---------------------------------------------------------------------------------------------------------
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(128), 0, s, T); }
-void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, hipStream_t s) {
+// threads: the plan's workgroup width (lin_threads_host(): one workgroup per CU; lin_threads_half_host(): two, inverse-depth plans of the throughput policy)
+void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, int threads, hipStream_t s) {
     if (T.lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
+    else if (threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_h, dim3(n_blocks), dim3(LIN_THREADS_H), lds_bytes, s, T);
     else hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
-// batched GN iteration (windows of one landmark kind): grid.y = window
-void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int test_prev, int any_prior, int parity,
-                         size_t ps_lds, hipStream_t s) {
-    BatchArgs a{tabs, test_prev ? 2 : 0, parity, 0};
+static void launch_linearize_b(const BatchArgs &a, int lm_dim, int max_blocks, int B, size_t lin_lds, int threads, hipStream_t s) {
     if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+    else if (threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_hb, dim3(max_blocks, B), dim3(LIN_THREADS_H), lin_lds, s, a);
     else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+}
+// batched GN iteration (windows of one landmark kind): grid.y = window
+void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int test_prev, int any_prior,
+                         int parity, size_t ps_lds, hipStream_t s) {
+    BatchArgs a{tabs, test_prev ? 2 : 0, parity, 0};
+    launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
     a.gn_flags = test_prev ? 1 : 0;
     hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
     hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
@@ -2343,12 +2361,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_errprior_b(BatchArgs a);
 // Batched LM solve (vio_batch_solve): the kernels of vio_solve's device-driven loop with grid.y = window;
 // every window follows its own LmState (parity -1: `cur` from LmState; gate as in the single-window loop).
 //   what 0: first linearisation + ComputeLambdaInitLM      what 1: one slot = trial (gate 2) + re-linearisation (gate 3)
-void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int any_prior, size_t ps_lds, int what,
-                         int max_iter, hipStream_t s) {
+void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int any_prior, size_t ps_lds,
+                         int what, int max_iter, hipStream_t s) {
     auto linearize = [&](int gate) {
         BatchArgs a{tabs, 0, -1, gate};
-        if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
-        else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+        launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
         hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1, B), dim3(RED_THREADS), 0, s, a);
         hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
         hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(192), 0, s, a);
@@ -2364,8 +2381,7 @@ void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_bl
         // (its landmark back-substitution first), sum, assemble (chi2 and gain-ratio terms of the step), then k_pose_solve: verdict, next step
         BatchArgs a{tabs, 2, -2, 2};
         if (what == 2) {
-            if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
-            else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+            launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
             a.gn_flags = 1;
             hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + (any_prior ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
             hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
@@ -2441,6 +2457,7 @@ void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s) {
     hipLaunchKernelGGL(k_init_lm, dim3(1), dim3(256), 0, s, T, max_iter);
 }
 int lin_threads_host() { return LIN_THREADS; }
+int lin_threads_half_host() { return LIN_THREADS_H; }
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext) {
     return lin_lds_doubles(G, K, nb, use_ext);
 }
@@ -2449,6 +2466,8 @@ int vio_set_kernel_attributes() {
     hipError_t e1 = hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     hipError_t e2 = hipFuncSetAttribute((const void *)k_pose_solve, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     if (hipFuncSetAttribute((const void *)k_linearize_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_linearize_h, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_linearize_hb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_pose_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     hipError_t e3 = hipFuncSetAttribute((const void *)k_linearize_xyz, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);

@@ -240,7 +240,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     const bool owe = d_step_owed(T, 2), owe_prior = owe && T.has_prior;
     if (b >= T.n_items) {
         if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
-        d_imu_item(T, b - T.n_items, dyn_smem);
+        d_imu_item<LIN_THREADS>(T, b - T.n_items, dyn_smem);
         return;
     }
     __shared__ ItemDesc sIt;
