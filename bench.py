@@ -118,6 +118,7 @@ def main():
                     help="invdepth: VertexInverseDepth + EdgeReprojection (what Estimator builds, the headline); "
                          "xyz: VertexPointXYZ + EdgeReprojectionXYZ (3x3 landmark blocks)")
     ap.add_argument("--batch", type=int, default=64, help="windows of the batched block (vio_batch_gn_iteration); 0 skips it")
+    ap.add_argument("--batch-full", type=int, default=256, help="windows of the batched block's full-device figure (one pose solve per CU); 0 skips it")
     ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame cost block (set / plan+upload / Solve(10) / marginalise)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=0, help="0 = sized for about 10-20 s")
     args = ap.parse_args()
@@ -438,7 +439,31 @@ def main():
         batched["solve10_ms_per_batch"] = min(ts) * 1e3
         batched["solve10_ms_per_window"] = min(ts) * 1e3 / B
         batched["solve10_mean_iterations"] = its
-        del cb, members, lead          # (members first: they run on the leader's stream)
+        # the same with one window per CU (k_pose_solve_b is one workgroup per window: 64 windows leave 192 CUs idle for 40 us of every
+        # batch iteration); the extra contexts hold copies of the same 64 windows' data
+        extra = []
+        if args.batch_full > B:
+            Bf = args.batch_full
+            extra = [hip.context(device=local_rank, stream=lead.get_stream(), item_policy=vio.capi.ITEMS_THROUGHPUT) for _ in range(Bf - B)]
+            for cb, wb in zip(members, wbs):
+                cb.load(wb)
+            for i, cb in enumerate(extra):
+                cb.load(wbs[i % B])
+            allm = members + extra
+            for _ in range(3):
+                hip.batch_gn_iteration(allm, lam)
+            lead.synchronize()
+            fsteps = max(10, bsteps // 2)
+            tb = time.perf_counter()
+            for _ in range(fsteps):
+                hip.batch_gn_iteration(allm, lam)
+            lead.synchronize()
+            tb = time.perf_counter() - tb
+            batched["full_device"] = {"windows": Bf, "steps": fsteps, "ms_per_batch_iteration": tb * 1e3 / fsteps,
+                                      "window_iterations_per_s": Bf * fsteps / tb, "us_per_window_iteration": tb * 1e6 / (fsteps * Bf),
+                                      "algorithmic_GBps": round(Bf * bytes_it * fsteps / tb / 1e9, 2), "hbm_frac": Bf * bytes_it * fsteps / tb / 8e12}
+            del allm
+        del cb, extra, members, lead          # (members first: they run on the leader's stream)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -70,6 +70,13 @@ def test_against_reference_golden_vectors(vio, hip_lib, path):
     check_window_against_golden(vio, hip_lib, path, dx_tol=1e-8, state_tol=3e-6, lambda_rtol=3e-4)
 
 
+@pytest.mark.parametrize("path", WINDOW_FILES, ids=[os.path.basename(p)[:-4] for p in WINDOW_FILES])
+def test_golden_vectors_with_half_width_workgroups(vio, hip_lib, path):
+    """The same fixtures through the plans of the throughput policy (vio_config.item_policy = VIO_ITEMS_THROUGHPUT): k_linearize_h,
+    512 threads, two workgroups to a CU, the largest items half the LDS holds — another grouping of the same sums."""
+    check_window_against_golden(vio, hip_lib, path, dx_tol=1e-8, state_tol=3e-6, lambda_rtol=3e-4, extra_cfg={"item_policy": vio.capi.ITEMS_THROUGHPUT})
+
+
 def test_solve_trace_against_the_reference_iteration_by_iteration(vio, hip_lib):
     """tests/golden/solve_trace.npz: the compiled reference's state, lambda and chi2 after every outer iteration of
     Solve(10) at full precision (its printout has 6 digits).  HIP, through the single-step entry points."""

@@ -169,11 +169,12 @@ def test_window_against_reference(vio, oracle_lib, path):
     check_window_against_golden(vio, oracle_lib, path)
 
 
-def check_window_against_golden(vio, lib, path, dx_tol=1e-9, state_tol=1e-6, lambda_rtol=2e-5):
+def check_window_against_golden(vio, lib, path, dx_tol=1e-9, state_tol=1e-6, lambda_rtol=2e-5, extra_cfg=None):
     """Shared with the GPU tests: `lib` is the oracle here and the HIP library there."""
     z = dict(np.load(path))
     w = tu.arrays_to_window(vio, z)
     kw = cfg_of(z)
+    kw.update(extra_cfg or {})
     ctx = lib.context(**kw)
     ctx.load(w)
     if "step_dx_pose" in z and "step_bs" not in z:          # the N = 2000 file: delta_x only
