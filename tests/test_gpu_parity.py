@@ -454,6 +454,26 @@ def test_native_rccl_exchange_on_one_rank(vio, hip_lib):
     sb.ctx.comm_destroy()
 
 
+def test_native_exchange_falls_back_to_the_hook(vio, hip_lib, monkeypatch):
+    """If the library cannot build its own RCCL communicator (librccl.so not resolvable, ncclCommInitRank refused), every rank
+    takes the portable path instead — the same all-gather from the library's hook — and the results are the same bits."""
+    import torch
+    def refuse(self, *a, **k):
+        raise vio.VioError(-2, "injected: no communicator")
+    monkeypatch.setattr(type(hip_lib.context()), "comm_init", refuse)
+    torch.cuda.set_device(0)
+    w = vio.synth.make_window(500, seed=31, ragged=True)
+    sb = vio.sharded.ShardedBackend(hip_lib, w, 0, 1, dist=None, torch_device="cuda", force_hook=True, exchange="native")
+    assert sb.exchange == "hook"
+    rep = sb.solve(10)
+    ref = hip_lib.context()
+    ref.load(w)
+    rr = ref.solve(10)
+    assert rep.iterations == rr.iterations and rep.trials == rr.trials and rep.final_chi2 == rr.final_chi2
+    np.testing.assert_array_equal(sb.ctx.get_window()[0], ref.get_window()[0])
+    np.testing.assert_array_equal(sb.ctx.get_landmarks(), ref.get_landmarks())
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("k_obs,ext_fixed,n", [(10, 0, 600), (10, 1, 3000), (7, 0, 1500), (1, 1, 200)])
 def test_long_tracks_and_free_extrinsic(vio, oracle_lib, hip_lib, k_obs, ext_fixed, n):

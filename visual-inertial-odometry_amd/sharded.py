@@ -68,7 +68,24 @@ class ShardedBackend:
                 idt.copy_(torch.frombuffer(bytearray(lib.comm_unique_id()), dtype=torch.uint8))
             if world > 1:
                 dist.broadcast(idt, src=0)
-            self.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            ok, why = 1, None
+            try:
+                self.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+            except Exception as exc:      # librccl.so not resolvable, ncclCommInitRank refused, ...
+                ok, why = 0, exc
+            if world > 1:                 # every rank takes the same path
+                flag = torch.tensor([ok], dtype=torch.int32, device=torch_device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                # the portable exchange instead: the same all-gather issued by torch.distributed from the library's hook (the
+                # context has to sit on an explicit torch stream for that: built again)
+                import sys
+                if rank == 0 or why is not None:
+                    print("[sharded] rank %d: native RCCL exchange unavailable (%s): falling back to the torch.distributed hook" % (rank, why), file=sys.stderr)
+                del self.ctx
+                self.__init__(lib, window, rank, world, dist=dist, torch_device=torch_device, ctx_kwargs=ctx_kwargs, force_hook=force_hook, exchange="hook")
+                return
         elif self.exchange == "hook":     # force_hook: exercise the exchange path on a single rank (tests)
             self.ctx.set_exchange_hook(self._exchange)
         elif self.exchange == "hook_host":
