@@ -24,9 +24,9 @@ def windows(vio, oracle_lib):
     return ws
 
 
-def state_of(ctx):
+def state_of(ctx, xyz=False):
     p, s, e = ctx.get_window()
-    return p, s, e, ctx.get_landmarks(), ctx.chi2()
+    return p, s, e, (ctx.get_landmarks_xyz() if xyz else ctx.get_landmarks()), ctx.chi2()
 
 
 def test_batched_gn_equals_separate_runs(vio, hip_lib, oracle_lib):
@@ -113,11 +113,15 @@ def test_solo_calls_on_batch_members_between_batch_calls(vio, hip_lib, oracle_li
             np.testing.assert_array_equal(x, y)
 
 
-def test_throughput_item_policy(vio, hip_lib, oracle_lib):
-    """vio_config.item_policy = VIO_ITEMS_THROUGHPUT: the largest items the LDS holds (what a batch wants).  Another grouping of the
-    same sums: batch and solo runs of such contexts agree bit for bit, and with the default policy to rounding."""
-    ws = [vio.synth.make_window(3000, seed=41), vio.synth.make_window(1200, seed=42, ragged=True)]
-    lam = 5e5
+@pytest.mark.parametrize("kind", ["invdepth", "xyz"])
+def test_throughput_item_policy(vio, hip_lib, oracle_lib, kind):
+    """vio_config.item_policy = VIO_ITEMS_THROUGHPUT: the largest items half the LDS holds, half-width workgroups (k_linearize_h /
+    k_linearize_xyz_h), two to a CU — what a batch wants.  Another grouping of the same sums: batch and solo runs of such contexts
+    agree bit for bit, and with the default policy to rounding."""
+    xyz = kind == "xyz"
+    make = vio.synth.make_window if kind == "invdepth" else vio.synth.make_window_xyz
+    ws = [make(3000, seed=41), make(1200, seed=42, ragged=True)]
+    lam = 5e5 if kind == "invdepth" else 2e5
     pol = vio.capi.ITEMS_THROUGHPUT
     lead = hip_lib.context(item_policy=pol)
     batch = [lead, hip_lib.context(stream=lead.get_stream(), item_policy=pol)]
@@ -132,7 +136,7 @@ def test_throughput_item_policy(vio, hip_lib, oracle_lib):
         for r in solo + dflt:
             r.gn_iteration(lam)
     for c, r, d in zip(batch, solo, dflt):
-        for x, y, z in zip(state_of(c), state_of(r), state_of(d)):
+        for x, y, z in zip(state_of(c, xyz), state_of(r, xyz), state_of(d, xyz)):
             np.testing.assert_array_equal(x, y)
             assert np.abs(np.asarray(x) - np.asarray(z)).max() <= 1e-9 * max(1.0, np.abs(np.asarray(z)).max())
     # the policy can be changed on a living context (the plan is rebuilt)
@@ -141,7 +145,7 @@ def test_throughput_item_policy(vio, hip_lib, oracle_lib):
     solo[0].load(ws[0])
     dflt[0].gn_iteration(lam)
     solo[0].gn_iteration(lam)
-    for x, y in zip(state_of(dflt[0]), state_of(solo[0])):
+    for x, y in zip(state_of(dflt[0], xyz), state_of(solo[0], xyz)):
         np.testing.assert_array_equal(x, y)
 
 

@@ -311,7 +311,8 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *
 vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
     pl.valid = false;
     pl.marg = marg; pl.use_ext = 0; pl.lm_dim = 3;
-    pl.lin_threads = lin_threads_host();
+    const bool half = c->cfg.item_policy == VIO_ITEMS_THROUGHPUT && !std::getenv("VIO_NO_HALF_WIDTH");      // as build_plan: k_linearize_xyz_h
+    pl.lin_threads = half ? lin_threads_half_host() : lin_threads_host();
     const int64_t N = (int64_t)c->h_invd.size() / 3, M = (int64_t)c->h_olm.size();
     // observation of landmark l in frame f: obs_at[l * NF + f] (or -1)
     std::vector<int32_t> obs_at((size_t)std::max<int64_t>(N, 1) * NF, -1);
@@ -346,7 +347,7 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
             pt.K = pt.nb = p;
             pt.n_rows = item_nbp(pt.nb) * 6 + 3 * pt.nb;
             int G = std::max(1, std::min(c->g_max > 0 ? c->g_max : 128, lin_threads_host() / pt.K));
-            while (G > 1 && xyz_lds_doubles_host(G, pt.K) > LDS_BUDGET_DOUBLES) --G;
+            while (G > 1 && xyz_lds_doubles_host(G, pt.K) > (half ? LDS_BUDGET_HALF_DOUBLES : LDS_BUDGET_DOUBLES)) --G;
             pt.G = G;
             pt.lds_doubles = xyz_lds_doubles_host(G, pt.K);
             pl.patterns.push_back(pt);

@@ -2336,12 +2336,14 @@ void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(128), 0, s, T); }
 // threads: the plan's workgroup width (lin_threads_host(): one workgroup per CU; lin_threads_half_host(): two, inverse-depth plans of the throughput policy)
 void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, int threads, hipStream_t s) {
-    if (T.lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
+    if (T.lm_dim == 3 && threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_xyz_h, dim3(n_blocks), dim3(LIN_THREADS_H), lds_bytes, s, T);
+    else if (T.lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
     else if (threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_h, dim3(n_blocks), dim3(LIN_THREADS_H), lds_bytes, s, T);
     else hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
 static void launch_linearize_b(const BatchArgs &a, int lm_dim, int max_blocks, int B, size_t lin_lds, int threads, hipStream_t s) {
-    if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+    if (lm_dim == 3 && threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_xyz_hb, dim3(max_blocks, B), dim3(LIN_THREADS_H), lin_lds, s, a);
+    else if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
     else if (threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_hb, dim3(max_blocks, B), dim3(LIN_THREADS_H), lin_lds, s, a);
     else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
 }
@@ -2471,5 +2473,7 @@ int vio_set_kernel_attributes() {
     if (hipFuncSetAttribute((const void *)k_pose_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     hipError_t e3 = hipFuncSetAttribute((const void *)k_linearize_xyz, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_h, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_hb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     return (e1 == hipSuccess && e2 == hipSuccess && e3 == hipSuccess) ? 0 : -1;
 }

@@ -232,15 +232,15 @@ __device__ __forceinline__ double d_xyz_landmark_step(const double *h, const dou
 }
 
 
-__device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
+template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (d_gated_off(T.lm, T.lm_gate)) return;
     // GN mode (gn_flags bit 1), as in k_linearize: the previous step's b_prior' rows and landmark back-substitution come first
     const bool owe = d_step_owed(T, 2), owe_prior = owe && T.has_prior;
     if (b >= T.n_items) {
-        if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
-        d_imu_item<LIN_THREADS>(T, b - T.n_items, dyn_smem);
+        if (owe_prior && (tid >> 6) == NT / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
+        d_imu_item<NT>(T, b - T.n_items, dyn_smem);
         return;
     }
     __shared__ ItemDesc sIt;
@@ -266,11 +266,12 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     const double *xyz = T.invd + (size_t)cur * 3 * T.Ns + it.lm_base;
     const double *pts = T.pts_j + 2 * (size_t)it.obs_base;
     const double s_info = T.sqrt_info;
-    if (owe_prior && (tid >> 6) == LIN_THREADS / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, T.n_step_blocks, tid & 63);
+    if (owe_prior && (tid >> 6) == NT / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, T.n_step_blocks, tid & 63);
     STAMP(T, 0);
     // phase 0: camera maps (their loads leave together with the head's: one global round trip for both)
-    if (tid >= 896 && tid < 896 + K) {                       // wave 14: no head loads of its own in front of these
-        const int k = tid - 896;
+    constexpr int kCamWave = (NT / 64 - 2) * 64;             // the last wave but one (wave 14 of 16): no head loads of its own in front of these
+    if (tid >= kCamWave && tid < kCamWave + K) {
+        const int k = tid - kCamWave;
         double ric[9], o[12];
         d_quat_to_R(st + STATE_EXT + 3, ric);
         d_xyz_frame(st, it.cam_block[k] - 1, ric, o);            // K may be 11: the frame comes from cam_block, not target[10]
@@ -286,7 +287,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     if (tid >= 128 && tid < 132) sCam[12 + (tid - 128)] = 0.0;        // zeros for the padding lanes of phase 2 to stream
     if (tid >= 256 && tid < 256 + XYZ_BP_TAB) sBp[tid - 256] = 0.0;
     // an odd K leaves the second half of the last plane unused: the direct products read it, so it holds zeros
-    if (K & 1) for (int e = tid; e < G * 12; e += LIN_THREADS) sRows[(NTD - 1) * PLANE + (e / 12) * 24 + 12 + e % 12] = 0.0;
+    if (K & 1) for (int e = tid; e < G * 12; e += NT) sRows[(NTD - 1) * PLANE + (e / 12) * 24 + 12 + e % 12] = 0.0;
     // ---------------- GN head: delta_l of the PREVIOUS step (problem.cc:445) ----------------
     // W is not kept in HBM: every observation forms its block again at the state it was linearised at (the other copy of the
     // state and of the points) and multiplies it by the pose step; H_ll and b_l (9 values per landmark) come from lw.
@@ -297,7 +298,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
         const double *xyzo = T.invd + (size_t)(cur ^ 1) * 3 * T.Ns + it.lm_base;
         const double *lw = T.lw + lw_r + it.lw_base;
         double *sHb = sDx + 176;                           // 12 per landmark: H_ll (6), b_l (3), the old point
-        for (int e = tid; e < 12 * G; e += LIN_THREADS) {
+        for (int e = tid; e < 12 * G; e += NT) {
             const int q = e / G, g = e - q * G;
             sHb[12 * g + q] = q < 9 ? lw[e] : xyzo[(size_t)(q - 9) * T.Ns + g];
         }
@@ -318,7 +319,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
             }
         }
         __syncthreads();
-        for (int o = tid; o < G * K; o += LIN_THREADS) {
+        for (int o = tid; o < G * K; o += NT) {
             const int k = o / G, g = o - k * G;
             const double pw[3] = {sHb[12 * g + 9], sHb[12 * g + 10], sHb[12 * g + 11]};
             double t[3];
@@ -352,7 +353,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     // pose part of b, - sum_g drho J_pose^T Info r, is a sum inside the wave (it had 6 doubles per observation in LDS)
     double chi_acc = 0.0;
     const int Gp = ((G + 63) >> 6) << 6;
-    for (int o2 = tid; o2 < K * Gp; o2 += LIN_THREADS) {
+    for (int o2 = tid; o2 < K * Gp; o2 += NT) {
         const int k = o2 / Gp, g = o2 - k * Gp;
         const bool act = g < G;
         double bpv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -424,7 +425,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
         // (GN) the previous step's gain-ratio partial: thread g holds landmark g's term, summed as k_backsub_xyz sums it
         const double sc = (owe && tid < G) ? sL[(size_t)tid * LREC + offSC] : 0.0;
         const double ws = d_wave_sum_to_lane63(chi_acc), wsc = d_wave_sum_to_lane63(sc), wm = d_wave_max_to_lane63(maxh);
-        if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[LIN_THREADS / 64 + (tid >> 6)] = wsc; sRed[2 * (LIN_THREADS / 64) + (tid >> 6)] = wm; }
+        if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[NT / 64 + (tid >> 6)] = wsc; sRed[2 * (NT / 64) + (tid >> 6)] = wm; }
     }
     __syncthreads();
     STAMP(T, 3);
@@ -435,7 +436,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     {
         const int wave = tid >> 6, lane = tid & 63, cl = lane & 15, rg = lane >> 4;
         const int nwork = NTD + nts;
-        for (int wk = wave; wk < nwork; wk += LIN_THREADS / 64) {
+        for (int wk = wave; wk < nwork; wk += NT / 64) {
             ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
             if (wk < NTD) {
                 // C = V^T V, V = the 2G whitened pose rows of observation indices 2 wk and 2 wk + 1 side by side (12 columns);
@@ -489,7 +490,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
             for (int v = 0; v < 4; ++v) tl[64 * v] = acc[v];
         }
         // Schur correction of b = sum_g Y_g b_l,g = sum_g W_g (H_ll^-1 b_l)_g   (fixed order)
-        for (int e = tid; e < D * LIN_VS; e += LIN_THREADS) {
+        for (int e = tid; e < D * LIN_VS; e += NT) {
             const int part = e % LIN_VS, a = e / LIN_VS;
             double sum = 0.0;
             for (int g = part; g < G; g += LIN_VS) {
@@ -510,11 +511,11 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
         double chi = 0.0, mh = 0.0;
         if (tid == 0) {
 #pragma unroll
-            for (int w = 0; w < LIN_THREADS / 64; ++w) { chi += sRed[w]; mh = fmax(mh, sRed[2 * (LIN_THREADS / 64) + w]); }
+            for (int w = 0; w < NT / 64; ++w) { chi += sRed[w]; mh = fmax(mh, sRed[2 * (NT / 64) + w]); }
         }
         // entry (i, j) of the direct block of pattern block p
         auto cdir = [&](int p, int i, int j) -> double { return sTile[(size_t)(p >> 1) * 256 + ((p & 1) * 6 + i) * 16 + (p & 1) * 6 + j]; };
-        for (int e = tid; e < n_out; e += LIN_THREADS) {
+        for (int e = tid; e < n_out; e += NT) {
             double v = 0.0;
             if (e < n_pair) {
                 const int pi = e / 36, rem = e - 36 * pi, i = rem / 6, j = rem - 6 * i;
@@ -546,7 +547,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
         if (owe && tid == 64) {
             double sc = 0.0;
 #pragma unroll
-            for (int w = 0; w < BS_THREADS / 64; ++w) sc += sRed[LIN_THREADS / 64 + w];
+            for (int w = 0; w < BS_THREADS / 64; ++w) sc += sRed[NT / 64 + w];
             T.step_part[2 * b + STEP_SCALE] = sc; T.step_part[2 * b + STEP_CHI] = 0.0;
         }
         if (owe && tid < G) {               // the landmark update of the head, out to HBM now
@@ -560,7 +561,7 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
         }
         // H_ll (6 distinct entries) and b_l of the item's landmarks for the back-substitution
         double *lw = T.lw + lw_w + it.lw_base;
-        for (int e = tid; e < 9 * G; e += LIN_THREADS) {
+        for (int e = tid; e < 9 * G; e += NT) {
             const int r = e / G, g = e - r * G;
             const double *Lg = sL + (size_t)g * LREC;
             lw[e] = r < 6 ? Lg[offH + r] : Lg[offBL + (r - 6)];
@@ -570,11 +571,18 @@ __device__ __forceinline__ void d_linearize_xyz_body(const DeviceTables &T) {
     STAMP_FLUSH(T);
 }
 
-__global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) { d_linearize_xyz_body(T); }
+__global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz(DeviceTables T) { d_linearize_xyz_body<LIN_THREADS>(T); }
 __global__ __launch_bounds__(LIN_THREADS) void k_linearize_xyz_b(BatchArgs a) {
     const DeviceTables T = d_batch_tables(a);
     if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;       // the grid is the widest window's
-    d_linearize_xyz_body(T);
+    d_linearize_xyz_body<LIN_THREADS>(T);
+}
+// half width, two workgroups to a CU: plans of the throughput policy (see k_linearize_h)
+__global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_xyz_h(DeviceTables T) { d_linearize_xyz_body<LIN_THREADS_H>(T); }
+__global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_xyz_hb(BatchArgs a) {
+    const DeviceTables T = d_batch_tables(a);
+    if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;
+    d_linearize_xyz_body<LIN_THREADS_H>(T);
 }
 
 // ---------------------------------------------------------------------------------------------------------
