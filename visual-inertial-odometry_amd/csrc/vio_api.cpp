@@ -40,7 +40,7 @@ struct ReduceTables {
 };
 void vio_launch_errprior(const DeviceTables &T, hipStream_t s);
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s);
-void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, int threads, hipStream_t s);
+void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, int threads, int use_ext, hipStream_t s);
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
 void vio_launch_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map, hipStream_t s);
@@ -946,7 +946,7 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     if (gn) T.cur_hint = c->cur_host;
     if (test_prev) T.gn_flags = 2;
     if (!c->pairtab_valid && pl.lm_dim == 1) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
-    { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, pl.lin_threads, c->stream); }
+    { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, pl.lin_threads, pl.use_ext, c->stream); }
     // with a prior, the previous GN step left err_prior to this k_reduce (k_pose_solve wrote b_prior' only)
     const bool err_prev = test_prev && T.has_prior;
     // sharded + gated slot: the all-reduce below runs whether the slot is live or not (every rank enqueues the same
@@ -1021,7 +1021,7 @@ vio_status enqueue_lm_slot(vio_ctx *c, Plan &pl, bool first) {
     T.lm_gate = 2;
     if (!first) {
         T.gn_flags = 2;
-        { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, pl.lin_threads, c->stream); }
+        { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, pl.lin_threads, pl.use_ext, c->stream); }
         // (sharded: k_reduce always runs, see enqueue_linearize)
         ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, T.step_part, T.n_items, sharded(c) ? 0 : 2, T.lm,
                        T.has_prior ? T.Jtinv : nullptr, T.has_prior ? T.bprior : nullptr, T.has_prior ? T.errprior : nullptr, 1};
@@ -1523,16 +1523,18 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         HIPCHK(hipStreamSynchronize(c->stream));           // `tabs` goes out of scope
         c->batch_iters = 0;
     }
-    int max_blocks = 1, any_prior = 0;
+    int max_blocks = 1, any_prior = 0, any_ext = 0;
     int lin_threads = lin_threads_half_host();               // half-width workgroups only if every window's plan was sized for them
     size_t lds = 0;
     for (int i = 0; i < count; ++i) {
         const Plan &pl = ctxs[i]->solve_plan;
         if (pl.lin_threads != lin_threads_half_host()) lin_threads = lin_threads_host();
+        any_ext |= pl.use_ext;
         max_blocks = std::max<int>(max_blocks, (int)pl.items.size() + VIO_WINDOW_SIZE);
         lds = std::max(lds, (size_t)pl.max_lds_doubles * 8);
         any_prior |= ctxs[i]->has_prior;
     }
+    if (any_ext) lin_threads = -lin_threads;                 // (the launchers' sign convention: kernels that read the extrinsic block from the item)
     const int test_prev = ctxs[0]->decide_pending ? 1 : 0;
     vio_launch_batch_gn(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, c->stream);
     HIPCHK(hipGetLastError());
@@ -1570,7 +1572,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
     }
     if (has_duplicates(ctxs, count)) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_solve: a context appears twice (two windows of the grid would write the same buffers)");
     std::vector<DeviceTables> tabs((size_t)count);
-    int max_blocks = 1, any_prior = 0;
+    int max_blocks = 1, any_prior = 0, any_ext = 0;
     int lin_threads = lin_threads_half_host();
     size_t lds = 0;
     for (int i = 0; i < count; ++i) {
@@ -1584,6 +1586,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         if (!m->pairtab_valid && m->lm_dim == 1) { vio_launch_prepare(tabs[i], m->stream); m->pairtab_valid = true; }
         const Plan &pl = m->solve_plan;
         if (pl.lin_threads != lin_threads_half_host()) lin_threads = lin_threads_host();
+        any_ext |= pl.use_ext;
         max_blocks = std::max<int>(max_blocks, (int)pl.items.size() + VIO_WINDOW_SIZE);
         lds = std::max(lds, (size_t)pl.max_lds_doubles * 8);
         any_prior |= m->has_prior;
@@ -1602,6 +1605,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         return VIO_OK;
     };
     static const bool classic = std::getenv("VIO_LM_CLASSIC") != nullptr;
+    if (any_ext) lin_threads = -lin_threads;                 // (the launchers' sign convention, as in vio_batch_gn_iteration)
     vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, 0, iterations, c->stream);
     if (!classic && iterations > 0) vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, 3, iterations, c->stream);
     HIPCHK(hipGetLastError());

@@ -449,7 +449,9 @@ __device__ __forceinline__ void d_bprior_rows(const DeviceTables &T, int from, i
     }
 }
 
-template <int NT> __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
+// NT: threads of the workgroup.  UE = 0: the plan has no extrinsic block (vio_config.ext_fixed, the reference's ESTIMATE_EXTRINSIC = 0) —
+// row-record sizes and operand-stream strides are compile-time constants (phase 2: 7.3 k -> 6.8 k cycles); UE = 1: read from the item.
+template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     if (d_gated_off(T.lm, T.lm_gate)) return;
@@ -475,7 +477,7 @@ template <int NT> __device__ __forceinline__ void d_linearize_body(const DeviceT
     // (the descriptor comes out of LDS into vector registers; these are the same in every lane: scalar registers, scalar loop
     // control and address arithmetic from here on)
     const int G = __builtin_amdgcn_readfirstlane(it.G), K = __builtin_amdgcn_readfirstlane(it.K), nb = __builtin_amdgcn_readfirstlane(it.nb),
-              use_ext = __builtin_amdgcn_readfirstlane(it.use_ext);
+              use_ext = UE == 0 ? 0 : __builtin_amdgcn_readfirstlane(it.use_ext);
     const int RROW = lin_rrow(use_ext), RAUX = lin_raux(use_ext), PLANE = lin_plane(G, use_ext), LREC = lin_lrec(nb);
     const int offH = 0, offT = 12, offE = 24, offZ = RROW - 2;      // inside a row record; (z0, z1) at its end
     // per-observation partials of the landmark quantities (sAux record): host w (6), h, b_l, [ext w (6)]
@@ -955,14 +957,16 @@ template <int NT> __device__ __forceinline__ void d_linearize_body(const DeviceT
     STAMP(T, 5);
     STAMP_FLUSH(T);
 }
-__global__ LIN_BOUNDS void k_linearize(DeviceTables T) { d_linearize_body<LIN_THREADS>(T); }
+__global__ LIN_BOUNDS void k_linearize(DeviceTables T) { d_linearize_body<LIN_THREADS, 0>(T); }
+__global__ LIN_BOUNDS void k_linearize_g(DeviceTables T) { d_linearize_body<LIN_THREADS, 1>(T); }      // plans with an extrinsic block (free extrinsic, marginalisation)
 // The same kernel with half the threads and two workgroups to a CU (items of at most half the LDS): what the throughput policy's
 // plans run on (vio_config.item_policy = VIO_ITEMS_THROUGHPUT).  When every CU has workgroup after workgroup to run, a CU sits
 // idle for 1.7 us between two of them and a workgroup's head is two dependent round trips that overlap nothing
 // (tools/diag_batch_stamps.py, profiles/r03h_*); two co-resident workgroups fill each other's gaps.  For one window in one
 // round of workgroups it is slower (twice the fixed part of a workgroup): the latency policy keeps the 1024-thread kernel.
 #define LIN_THREADS_H 512
-__global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_h(DeviceTables T) { d_linearize_body<LIN_THREADS_H>(T); }
+__global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_h(DeviceTables T) { d_linearize_body<LIN_THREADS_H, 0>(T); }
+__global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_gh(DeviceTables T) { d_linearize_body<LIN_THREADS_H, 1>(T); }
 
 // Batched launches (vio_batch_gn_iteration): B independent windows in one launch, blockIdx.y = window.  The windows'
 // tables sit in a device array built once per batch; what changes from iteration to iteration travels as kernel
@@ -983,12 +987,22 @@ __device__ __forceinline__ DeviceTables d_batch_tables(const BatchArgs &a) {
 __global__ LIN_BOUNDS void k_linearize_b(BatchArgs a) {
     const DeviceTables T = d_batch_tables(a);
     if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;       // the grid is the widest window's
-    d_linearize_body<LIN_THREADS>(T);
+    d_linearize_body<LIN_THREADS, 0>(T);
 }
 __global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_hb(BatchArgs a) {
     const DeviceTables T = d_batch_tables(a);
     if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;
-    d_linearize_body<LIN_THREADS_H>(T);
+    d_linearize_body<LIN_THREADS_H, 0>(T);
+}
+__global__ LIN_BOUNDS void k_linearize_gb(BatchArgs a) {            // (a batch with an extrinsic block in some window's plan)
+    const DeviceTables T = d_batch_tables(a);
+    if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;
+    d_linearize_body<LIN_THREADS, 1>(T);
+}
+__global__ __launch_bounds__(LIN_THREADS_H, 4) void k_linearize_ghb(BatchArgs a) {
+    const DeviceTables T = d_batch_tables(a);
+    if ((int)blockIdx.x >= T.n_items + T.n_imu_items) return;
+    d_linearize_body<LIN_THREADS_H, 1>(T);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2335,17 +2349,24 @@ void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_prepare, dim3(1), dim3(128), 0, s, T); }
 // threads: the plan's workgroup width (lin_threads_host(): one workgroup per CU; lin_threads_half_host(): two, inverse-depth plans of the throughput policy)
-void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, int threads, hipStream_t s) {
+void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, int threads, int use_ext, hipStream_t s) {
     if (T.lm_dim == 3 && threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_xyz_h, dim3(n_blocks), dim3(LIN_THREADS_H), lds_bytes, s, T);
     else if (T.lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
-    else if (threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_h, dim3(n_blocks), dim3(LIN_THREADS_H), lds_bytes, s, T);
-    else hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
+    else if (threads == LIN_THREADS_H && !use_ext) hipLaunchKernelGGL(k_linearize_h, dim3(n_blocks), dim3(LIN_THREADS_H), lds_bytes, s, T);
+    else if (threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_gh, dim3(n_blocks), dim3(LIN_THREADS_H), lds_bytes, s, T);
+    else if (!use_ext) hipLaunchKernelGGL(k_linearize, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
+    else hipLaunchKernelGGL(k_linearize_g, dim3(n_blocks), dim3(LIN_THREADS), lds_bytes, s, T);
 }
+// threads < 0: some window's plan has an extrinsic block (the kernels that read it from the item)
 static void launch_linearize_b(const BatchArgs &a, int lm_dim, int max_blocks, int B, size_t lin_lds, int threads, hipStream_t s) {
+    const bool ext = threads < 0;
+    if (ext) threads = -threads;
     if (lm_dim == 3 && threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_xyz_hb, dim3(max_blocks, B), dim3(LIN_THREADS_H), lin_lds, s, a);
     else if (lm_dim == 3) hipLaunchKernelGGL(k_linearize_xyz_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
-    else if (threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_hb, dim3(max_blocks, B), dim3(LIN_THREADS_H), lin_lds, s, a);
-    else hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+    else if (threads == LIN_THREADS_H && !ext) hipLaunchKernelGGL(k_linearize_hb, dim3(max_blocks, B), dim3(LIN_THREADS_H), lin_lds, s, a);
+    else if (threads == LIN_THREADS_H) hipLaunchKernelGGL(k_linearize_ghb, dim3(max_blocks, B), dim3(LIN_THREADS_H), lin_lds, s, a);
+    else if (!ext) hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
+    else hipLaunchKernelGGL(k_linearize_gb, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
 }
 // batched GN iteration (windows of one landmark kind): grid.y = window
 void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int test_prev, int any_prior,
@@ -2470,6 +2491,10 @@ int vio_set_kernel_attributes() {
     if (hipFuncSetAttribute((const void *)k_linearize_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_linearize_h, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_linearize_hb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_linearize_g, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_linearize_gh, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_linearize_gb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_linearize_ghb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_pose_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     hipError_t e3 = hipFuncSetAttribute((const void *)k_linearize_xyz, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
