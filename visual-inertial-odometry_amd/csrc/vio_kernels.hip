@@ -767,9 +767,12 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
                 // Column Dk — the first padding column — is z (the row record's last two doubles): row Dk of the product is then
                 // sum_g (L J)^T z = sum_g drho J^T Info r, the pose part of b per block, at no extra instruction.
                 const double *plane = sRows + k * PLANE + (rg >> 1) * RROW;
-                const double *pa = ca < Dk ? plane + oa : (ca == Dk ? plane + offZ + (rg & 1) : sZero);
-                const double *pb = cb < Dk ? plane + ob : (cb == Dk ? plane + offZ + (rg & 1) : sZero);
-                const int sa = ca <= Dk ? 2 * RROW : 0, sb = cb <= Dk ? 2 * RROW : 0;      // 2 landmarks per MFMA step
+                // (A column past Dk streams its clamped neighbour instead of zeros: what lands in the tile's unused rows / columns is never
+                // read, and ONE stride for all lanes — a compile-time constant without an extrinsic block — lets the loads carry
+                // immediate offsets: no address arithmetic between the matrix-core instructions.)
+                const double *pa = ca == Dk ? plane + offZ + (rg & 1) : plane + oa;
+                const double *pb = cb == Dk ? plane + offZ + (rg & 1) : plane + ob;
+                const int sa = 2 * RROW, sb = 2 * RROW;             // 2 landmarks per MFMA step
                 // (on a diagonal tile B is A: both streams are read all the same — a branch-free loop of loads and MFMAs
                 // is worth more than the four reads it would save)
                 const int steps_full = G >> 1;                       // steps whose two landmarks both exist
@@ -783,18 +786,24 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
                 // two chunks per trip, the operand registers taking turns (no copies); a load that would run past the last
                 // full chunk re-reads the chunk before it instead of branching
                 int ch = 0;
+                // (the scheduling barriers keep the loads of the next chunk IN FRONT of this chunk's products: left alone the compiler
+                // sinks every load to its use — fewer live registers — and each product then waits for an LDS latency)
                 for (; ch + 2 <= chunks_full; ch += 2) {
                     pa += 4 * sa; pb += 4 * sb;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; xb[u] = pb[u * sb]; }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], vb[u], acc, 0, 0, 0);
                     const int nx = ch + 2 < chunks_full ? 4 : 0;
                     pa += nx * sa; pb += nx * sb;
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xb[u], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (ch < chunks_full) {
 #pragma unroll
@@ -807,8 +816,8 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
                     const double m = g < G ? 1.0 : 0.0;
                     const int gc = min(g, G - 1) - (rg >> 1);        // pa already points at landmark (rg >> 1)
                     const double *rec0 = sRows + k * PLANE + (rg >> 1) * RROW + (size_t)gc * RROW;
-                    const double *qa = ca < Dk ? rec0 + oa : (ca == Dk ? rec0 + offZ + (rg & 1) : sZero);
-                    const double *qb = cb < Dk ? rec0 + ob : (cb == Dk ? rec0 + offZ + (rg & 1) : sZero);
+                    const double *qa = ca == Dk ? rec0 + offZ + (rg & 1) : rec0 + oa;
+                    const double *qb = cb == Dk ? rec0 + offZ + (rg & 1) : rec0 + ob;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0] * m, qb[0], acc, 0, 0, 0);
                 }
             } else {
@@ -822,10 +831,11 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
                 // B carries the -1/h_g of the landmark
                 // Row / column D — the first padding index — is b_l: row D of the product is then - sum_g b_l w_g / h_g, the Schur
                 // correction of b (problem.cc:429), at no extra instruction.
-                const double *pa = a < D ? sL + (size_t)rg * LREC + ac : (a == D ? sL + (size_t)rg * LREC + lBl : sZero);
-                const double *pb = bq < D ? sL + (size_t)rg * LREC + bc : (bq == D ? sL + (size_t)rg * LREC + lBl : sZero);
+                // (columns past D: the clamped neighbour, one stride for all lanes, as above)
+                const double *pa = sL + (size_t)rg * LREC + (a == D ? lBl : ac);
+                const double *pb = sL + (size_t)rg * LREC + (bq == D ? lBl : bc);
                 const double *ph = sL + (size_t)rg * LREC + lHinv;
-                const int sa = a <= D ? 4 * LREC : 0, sb = bq <= D ? 4 * LREC : 0, sh = 4 * LREC;
+                const int sa = 4 * LREC, sb = 4 * LREC, sh = 4 * LREC;
                 const int chunks_full = (G >> 2) >> 2;               // chunks whose 16 landmarks all exist
                 double va[4], vb[4], vh[4], xa[4], xb[4], xh[4];
 #ifdef VIO_STAMPS
@@ -841,14 +851,18 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
                     pa += 4 * sa; pb += 4 * sb; ph += 4 * sh;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { xa[u] = pa[u * sa]; xb[u] = pb[u * sb]; xh[u] = ph[u * sh]; }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], -(vb[u] * vh[u]), acc, 0, 0, 0);
                     const int nx = ch + 2 < chunks_full ? 4 : 0;
                     pa += nx * sa; pb += nx * sb; ph += nx * sh;
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) { va[u] = pa[u * sa]; vb[u] = pb[u * sb]; vh[u] = ph[u * sh]; }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], -(xb[u] * xh[u]), acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (ch < chunks_full) {
 #pragma unroll
@@ -861,7 +875,7 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
                     const int g = st + rg, gc = min(g, G - 1);
                     const double m = g < G ? 1.0 : 0.0;
                     const double *Lg = sL + (size_t)gc * LREC;
-                    const double wa = a < D ? Lg[ac] : (a == D ? Lg[lBl] : 0.0), wb = bq < D ? Lg[bc] : (bq == D ? Lg[lBl] : 0.0);
+                    const double wa = a == D ? Lg[lBl] : Lg[ac], wb = bq == D ? Lg[lBl] : Lg[bc];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa * m, -(wb * Lg[lHinv]), acc, 0, 0, 0);
                 }
             }
