@@ -149,6 +149,34 @@ def test_throughput_item_policy(vio, hip_lib, oracle_lib, kind):
         np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("policy", [0, 1])
+def test_batch_with_a_free_extrinsic(vio, hip_lib, policy):
+    """Windows whose plans carry an extrinsic block (vio_config.ext_fixed = 0) run on the kernels that read the block layout from the
+    item (k_linearize_gb / k_linearize_ghb), also when only one window of the batch has one: bit-identical to separate runs."""
+    ws = [vio.synth.make_window(900, seed=51, ragged=True), vio.synth.make_window(1500, seed=52)]
+    lam = 5e5
+    lead = hip_lib.context(item_policy=policy, ext_fixed=0)
+    batch = [lead, hip_lib.context(stream=lead.get_stream(), item_policy=policy, ext_fixed=1)]
+    solo = [hip_lib.context(item_policy=policy, ext_fixed=0), hip_lib.context(item_policy=policy, ext_fixed=1)]
+    for c, r, w in zip(batch, solo, ws):
+        c.load(w)
+        r.load(w)
+    for _ in range(3):
+        hip_lib.batch_gn_iteration(batch, lam)
+        for r in solo:
+            r.gn_iteration(lam)
+    for c, r in zip(batch, solo):
+        for x, y in zip(state_of(c), state_of(r)):
+            np.testing.assert_array_equal(x, y)
+    reps_b = hip_lib.batch_solve(batch, 5)
+    reps_s = [r.solve(5) for r in solo]
+    for a, b in zip(reps_b, reps_s):
+        assert (a.iterations, a.trials, a.final_chi2) == (b.iterations, b.trials, b.final_chi2)
+    for c, r in zip(batch, solo):
+        for x, y in zip(state_of(c), state_of(r)):
+            np.testing.assert_array_equal(x, y)
+
+
 def test_batched_gn_xyz_windows(vio, hip_lib):
     """XYZ-landmark windows in one batch (k_linearize_xyz_b): equal to separate runs bit for bit, ragged sizes included."""
     ws = [vio.synth.make_window_xyz(600, seed=11, ragged=True), vio.synth.make_window_xyz(2000, seed=12), vio.synth.make_window_xyz(40, seed=13),
