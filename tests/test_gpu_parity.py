@@ -454,6 +454,32 @@ def test_native_rccl_exchange_on_one_rank(vio, hip_lib):
     sb.ctx.comm_destroy()
 
 
+@pytest.mark.parametrize("k_obs,ragged,policy", [(1, False, 1), (2, True, 1), (2, False, 0), (1, False, 0)])
+def test_short_tracks_in_large_items(vio, oracle_lib, hip_lib, k_obs, ragged, policy):
+    """Tracks of one or two observations in items of 100+ landmarks (the throughput policy; or a window large enough for the latency
+    policy to choose them): the head of k_linearize stages (6 nb + 2) G doubles of Schur rows where the per-observation records of
+    K G x 9 doubles will live — more than those hold for K <= 2.  Found by tools/fuzz_parity.py under VIO_DEFAULT_ITEM_POLICY=1:
+    the LM loop rejected every first trial (Solve(10): 20 trials, chi2 7e5 instead of 565)."""
+    n = 2500 if policy == 1 else 40000
+    w = vio.synth.make_window(n, seed=1058 + k_obs, ragged=ragged, obs_per_landmark=k_obs)
+    ch, co = hip_lib.context(loss_type=vio.LOSS_TRIVIAL, item_policy=policy), oracle_lib.context(loss_type=vio.LOSS_TRIVIAL)
+    ch.load(w)
+    co.load(w)
+    rh, ro = ch.solve(6), co.solve(6)
+    assert (rh.iterations, rh.trials) == (ro.iterations, ro.trials)
+    assert abs(rh.final_chi2 - ro.final_chi2) <= 1e-7 * ro.final_chi2
+    assert np.abs(ch.get_window()[0] - co.get_window()[0]).max() <= 1e-6
+    ch.load(w)
+    co.load(w)
+    ch.linearize()
+    _, lam = ch.init_lm()
+    for _ in range(3):
+        ch.gn_iteration(lam)
+        co.gn_iteration(lam)
+    assert np.abs(ch.get_window()[0] - co.get_window()[0]).max() <= 1e-9
+    assert np.abs(ch.get_landmarks() - co.get_landmarks()).max() <= 1e-8
+
+
 def test_native_exchange_falls_back_to_the_hook(vio, hip_lib, monkeypatch):
     """If the library cannot build its own RCCL communicator (librccl.so not resolvable, ncclCommInitRank refused), every rank
     takes the portable path instead — the same all-gather from the library's hook — and the results are the same bits."""

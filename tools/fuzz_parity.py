@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (diagnostic; the fixed cases live in tests/): HIP against the oracle on windows of random size,
 track structure, loss, extrinsic mode and prior; one stepwise LM step, a few GN iterations and Solve(10) each.
-  python tools/fuzz_parity.py [cases] [seed]"""
+  python tools/fuzz_parity.py [cases] [seed]          (VIO_FUZZ_ONLY=<case>: that case alone, in detail; VIO_DEFAULT_ITEM_POLICY=1: throughput-policy contexts)"""
 import os
 import sys
 
@@ -16,6 +16,7 @@ vio = load_package()
 hip = vio.load_hip()
 orc = vio.VioLib(os.path.join(ORACLE_DIR, "liboracle.so"), "vioo_")
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+only = int(os.environ.get("VIO_FUZZ_ONLY", "-1"))          # one case of the sequence, with more detail
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 w0 = vio.synth.make_window(300, seed=41, t0=0.9)
 c0 = orc.context(); c0.load(w0); c0.solve(10)
@@ -44,8 +45,20 @@ for case in range(cases):
         w.preint = list(w.preint)
         for k in rng.choice(10, size=int(rng.randint(1, 4)), replace=False):
             w.preint[int(k)] = None
+    if only >= 0 and case != only:
+        continue
     ch, co = hip.context(ext_fixed=ext_fixed, loss_type=loss), orc.context(ext_fixed=ext_fixed, loss_type=loss)
     ch.load(w); co.load(w)
+    if only >= 0 and not os.environ.get("VIO_FUZZ_NODETAIL"):                                   # one case in detail: the system, then the GN loop iteration by iteration
+        ch.linearize(); co.linearize()
+        (Hh, bh), (Ho, bo) = ch.get_schur_system(), co.get_schur_system()
+        print("system: H %.2e b %.2e (relative to the largest entry)" % (np.abs(Hh - Ho).max() / np.abs(Ho).max(), np.abs(bh - bo).max() / np.abs(bo).max()))
+        _, lam_d = ch.init_lm(); co.init_lm()
+        for it in range(4):
+            ch.gn_iteration(lam_d); co.gn_iteration(lam_d)
+            print("GN iteration %d: poses %.2e landmarks %.2e chi2 %.9g / %.9g" % (it, np.abs(ch.get_window()[0] - co.get_window()[0]).max(),
+                  np.abs(ch.get_landmarks() - co.get_landmarks()).max(), ch.chi2(), co.chi2()))
+        ch.load(w); co.load(w)
     a, b = tu.run_stepwise(ch), tu.run_stepwise(co)
     if not np.isfinite(b["dx_pose"]).all():       # a landmark without information: NaN in the reference, the oracle and here
         okd = not np.isfinite(a["dx_pose"]).all()
@@ -62,6 +75,8 @@ for case in range(cases):
     ch.linearize(); _, lam = ch.init_lm()
     for _ in range(3):
         ch.gn_iteration(lam); co.gn_iteration(lam)
+        if only >= 0:
+            print("   main path GN: nan hip %d nan oracle %d lam %g" % (np.isnan(ch.get_window()[0]).sum(), np.isnan(co.get_window()[0]).sum(), lam))
     gn = np.abs(ch.get_window()[0] - co.get_window()[0]).max()
     ok = ok and gn <= 1e-7
     ch.load(w); co.load(w)

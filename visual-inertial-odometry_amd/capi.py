@@ -174,6 +174,10 @@ class VioLib:
 
     def context(self, cfg=None, **overrides):
         cfg = cfg or self.default_config()
+        # (diagnostics: VIO_DEFAULT_ITEM_POLICY=1 makes every context of a tool a throughput-policy one — the randomised sweeps of
+        # tools/fuzz_*.py through the half-width kernels — unless the caller says otherwise)
+        if "item_policy" not in overrides and os.environ.get("VIO_DEFAULT_ITEM_POLICY"):
+            cfg.item_policy = int(os.environ["VIO_DEFAULT_ITEM_POLICY"])
         for k, v in overrides.items():
             if k == "gravity":
                 cfg.gravity[:] = list(v)

@@ -425,6 +425,8 @@ __host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
 __host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext) {
     int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256;
     int shared = aux > part ? aux : part;
+    const int stage = (6 * nb + 2) * G;         // the GN / LM head stages the item's Schur rows here (more than the per-observation
+    if (stage > shared) shared = stage;         // records of K <= 2 observations hold)
     shared = (shared + 1) & ~1;
     return VIO_MAXK * PAIR_STRIDE + 16 + 3 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
 }
