@@ -178,8 +178,9 @@ bool EstimatorBackend::uploadWindow(bool graph_unchanged) {
     }
     size_t n_obs = 0;
     for (const auto &it_per_id : feature) n_obs += it_per_id.feature_per_frame.size();
-    std::vector<int32_t> lm, host, target;
-    std::vector<double> pi, pj;
+    std::vector<int32_t> &lm = up_lm_, &host = up_host_, &target = up_target_;
+    std::vector<double> &pi = up_pi_, &pj = up_pj_;
+    lm.clear(); host.clear(); target.clear(); pi.clear(); pj.clear();
     lm.reserve(n_obs); host.reserve(n_obs); target.reserve(n_obs); pi.reserve(2 * n_obs); pj.reserve(2 * n_obs);
     int feature_index = -1;
     for (auto &it_per_id : feature) {                                         // estimator.cpp:975-1016
