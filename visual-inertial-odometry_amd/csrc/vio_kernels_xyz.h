@@ -441,15 +441,43 @@ template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const Dev
             if (wk < NTD) {
                 // C = V^T V, V = the 2G whitened pose rows of observation indices 2 wk and 2 wk + 1 side by side (12 columns);
                 // one MFMA step takes two landmarks (lane row group rg: landmark rg >> 1, row rg & 1)
-                // A padding lane (column >= 12) streams a zero with stride 0 and a step past the last landmark re-reads the last one
-                // with its A operand multiplied by 0: the loop is loads and matrix instructions, no masks, no branches
-                const bool live = cl < 12;
-                const int off = (cl < 6 ? 0 : 12) + (rg & 1) * 6 + (cl < 6 ? cl : cl - 6);
-                const double *plane = live ? sRows + wk * PLANE + off : sCam + 12;
-                const int sp = live ? 24 : 0;
-                for (int st2 = 0; 2 * st2 < G; ++st2) {
+                // (a padding lane (column >= 12) streams its clamped neighbour: the tile's columns 12..15 are never read; one stride for
+                // all lanes, the pointer only steps; chunks of 4 steps with the next chunk's loads pinned in front of this chunk's products)
+                const int clc = min(cl, 11);
+                const int off = (clc < 6 ? 0 : 12) + (rg & 1) * 6 + (clc < 6 ? clc : clc - 6);
+                const double *pv = sRows + wk * PLANE + off + (rg >> 1) * 24;
+                const int sp = 2 * 24;                                  // two landmarks per step
+                const int chunks = (G >> 1) >> 2;                       // chunks of 4 steps whose landmarks all exist
+                double va[4], xa[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) va[u] = pv[u * sp];          // (G >= 1: in range even if unused)
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                int ch = 0;
+                for (; ch + 2 <= chunks; ch += 2) {
+                    pv += 4 * sp;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) xa[u] = pv[u * sp];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], va[u], acc, 0, 0, 0);
+                    pv += ch + 2 < chunks ? 4 * sp : 0;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) va[u] = pv[u * sp];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xa[u], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ch < chunks) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[u], va[u], acc, 0, 0, 0);
+                }
+                // the remaining steps (fewer than 4 full ones, plus the half step of an odd G), masked
+                const double *pl0 = sRows + wk * PLANE + off;
+                for (int st2 = 4 * chunks; 2 * st2 < G; ++st2) {
                     const int g = 2 * st2 + (rg >> 1);
-                    const double vv = plane[min(g, G - 1) * sp];
+                    const double vv = pl0[min(g, G - 1) * 24];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(g < G ? vv : 0.0, vv, acc, 0, 0, 0);
                 }
             } else {
@@ -458,30 +486,67 @@ template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const Dev
                 while ((ta + 1) * (ta + 2) / 2 <= ts) ++ta;
                 const int tb = ts - ta * (ta + 1) / 2;
                 const int a = 16 * ta + cl, bq = 16 * tb + cl;
-                const bool la = a < D, lb = bq < D;
                 // one group of 4 landmarks (k index rg) per step, three matrix instructions (coordinate c) per group:
-                // A = W[a][c], B = -Y[bq][c] with Y = W H_ll^-1 formed here from the three W of the row and H_ll^-1
-                // (branch-free as above: a padding row streams zeros with stride 0, a group past the last landmark re-reads the
-                // last one with its A operand multiplied by 0)
-                const double *pa = la ? sL + offW + a * 3 : sCam + 12, *pb = lb ? sL + offW + bq * 3 : sCam + 12;
-                const int sa = la ? LREC : 0, sb = lb ? LREC : 0;
-                const bool diag = ta == tb;
-                for (int st4 = 0; 4 * st4 < G; ++st4) {
-                    const int g = 4 * st4 + rg, gc = min(g, G - 1);
-                    const double m = g < G ? 1.0 : 0.0;
-                    const double *Lg = sL + (size_t)gc * LREC + offHI;
-                    double wb[3], wa[3], hi[9];
+                // A = W[a][c], B = -Y[bq][c] with Y = W H_ll^-1 formed here from the three W of the row and H_ll^-1.
+                // A row past D streams its clamped neighbour (what lands in the tile's unused rows / columns is never read): one
+                // stride for all lanes, pointers that only step.  Two groups per trip, the operand registers taking turns, the loads
+                // of the next group pinned in front of this group's products (left alone the compiler sinks every load to its use and
+                // each group waits for an LDS latency and three 16-cycle address multiplications).
+                const int ac = min(a, D - 1), bc = min(bq, D - 1);
+                const double *pa = sL + (size_t)rg * LREC + offW + ac * 3, *pb = sL + (size_t)rg * LREC + offW + bc * 3;
+                const double *ph = sL + (size_t)rg * LREC + offHI;
+                const int sg = 4 * LREC;
+                const int nfull = G >> 2;                              // groups whose four landmarks all exist
+                double wa[3], wb[3], hi[9], xa[3], xb[3], xh[9];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) wb[c] = pb[gc * sb + c];
+                for (int c = 0; c < 3; ++c) { wa[c] = pa[c]; wb[c] = pb[c]; }
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) wa[c] = pa[gc * sa + c];
+                for (int q = 0; q < 9; ++q) hi[q] = ph[q];
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                int st4 = 0;
+                for (; st4 + 2 <= nfull; st4 += 2) {
+                    pa += sg; pb += sg; ph += sg;
 #pragma unroll
-                    for (int q = 0; q < 9; ++q) hi[q] = Lg[q];
-                    (void)diag;
+                    for (int c = 0; c < 3; ++c) { xa[c] = pa[c]; xb[c] = pb[c]; }
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) xh[q] = ph[q];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const double yb = wb[0] * hi[c] + wb[1] * hi[3 + c] + wb[2] * hi[6 + c];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[c] * m, -yb, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[c], -yb, acc, 0, 0, 0);
+                    }
+                    const int nx = st4 + 2 < nfull ? sg : 0;           // (past the last full group: the same group again, unused)
+                    pa += nx; pb += nx; ph += nx;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { wa[c] = pa[c]; wb[c] = pb[c]; }
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) hi[q] = ph[q];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double yb = xb[0] * xh[c] + xb[1] * xh[3 + c] + xb[2] * xh[6 + c];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c], -yb, acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (st4 < nfull) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double yb = wb[0] * hi[c] + wb[1] * hi[3 + c] + wb[2] * hi[6 + c];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[c], -yb, acc, 0, 0, 0);
+                    }
+                }
+                if (G & 3) {                                            // the last, partial group: masked
+                    const int g = 4 * nfull + rg, gc = min(g, G - 1);
+                    const double m = g < G ? 1.0 : 0.0;
+                    const double *La = sL + (size_t)gc * LREC + offW + ac * 3, *Lb = sL + (size_t)gc * LREC + offW + bc * 3;
+                    const double *Lh = sL + (size_t)gc * LREC + offHI;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const double yb = Lb[0] * Lh[c] + Lb[1] * Lh[3 + c] + Lb[2] * Lh[6 + c];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(La[c] * m, -yb, acc, 0, 0, 0);
                     }
                 }
             }
