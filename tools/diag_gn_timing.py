@@ -1,4 +1,4 @@
-"""Wall-clock time of the GN loop without any profiling events in the stream (python tools/diag_gn_timing.py [landmarks] [iterations]);
+"""Wall-clock time of the GN loop without any profiling events in the stream (python tools/diag_gn_timing.py [landmarks] [iterations] [xyz]);
 VIO_GN_GRAPH=1 runs the steady-state iteration as an instantiated hipGraph (experiment)."""
 import os
 import sys
@@ -12,7 +12,8 @@ vio = load_package()
 hip = vio.load_hip()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 its = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
-w = vio.synth.make_window(n, seed=42)
+xyz = len(sys.argv) > 3 and sys.argv[3] == "xyz"
+w = (vio.synth.make_window_xyz if xyz else vio.synth.make_window)(n, seed=42)
 ctx = hip.context()
 ctx.load(w)
 ctx.linearize()

@@ -35,8 +35,18 @@ __host__ __device__ inline int xyz_plane(int G) { return G * 24 + 8; }
 __host__ __device__ inline int xyz_tiles(int K) { const int ts = (6 * K + 15) >> 4; return xyz_ntd(K) + ts * (ts + 1) / 2; }
 #define XYZ_FRAME_TAB (VIO_NF * 12 + 16)        // A_k (9), d_k (3) per frame, then ric (9), tic (3)
 #define XYZ_BP_TAB (VIO_NF * 2 * 6)             // pose part of b: per frame index, per 64-landmark chunk (G <= 128)
+// Phase 2 has few, long chains (K = 5: three direct tiles of 41 products and three Schur tiles of 62 on 16 waves: 103 products on
+// each of two SIMDs, 41 and 62 on the others).  Where the space the per-observation records leave behind holds them, every Schur
+// tile is formed in three parts over a third of the landmarks each (83 / 83 / 83 / 63) and the combine phase adds the parts in order.
+__host__ __device__ inline int xyz_split(int G, int K) {
+    const int ts = (6 * K + 15) >> 4, nts = ts * (ts + 1) / 2;
+    const int aux = G * K * 9, head = 3 * G * K + 12 * K + 12 + 176 + 12 * G;
+    const int room = aux > head ? aux : head;
+    return ((xyz_ntd(K) + 3 * nts) * 256 + 6 * K * LIN_VS <= room && G >= 64) ? 3 : 1;      // (items of the half-width kernel stay whole: 12 chains on 8 waves wrap)
+}
 __host__ __device__ inline int xyz_lds_doubles(int G, int K) {
-    int aux = G * K * 9, part = xyz_tiles(K) * 256 + 6 * K * LIN_VS;
+    const int ts_ = (6 * K + 15) >> 4, nts_ = ts_ * (ts_ + 1) / 2;
+    int aux = G * K * 9, part = (xyz_ntd(K) + xyz_split(G, K) * nts_) * 256 + 6 * K * LIN_VS;
     int head = 3 * G * K + 12 * K + 12 + 176 + 12 * G;      // GN head: W^T dx per observation, the old camera maps, dx, (H_ll, b_l, point) per landmark
     int shared = aux > part ? aux : part;
     if (head > shared) shared = head;
@@ -432,10 +442,13 @@ template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const Dev
     // ---------------- phase 2: tiles on the matrix cores ----------------
     const int D = 6 * nb;
     const int TS = (D + 15) >> 4, nts = TS * (TS + 1) / 2;
-    double *sVec = sTile + (size_t)(NTD + nts) * 256;
+    // parts a Schur tile is formed in (the half-width instances keep whole tiles at compile time: their 8 waves have the chains they
+    // can carry, and the plain code is 2 % faster for them; the LDS size the host computed covers either)
+    const int SPL = NT == LIN_THREADS ? xyz_split(G, K) : 1;
+    double *sVec = sTile + (size_t)(NTD + SPL * nts) * 256;
     {
         const int wave = tid >> 6, lane = tid & 63, cl = lane & 15, rg = lane >> 4;
-        const int nwork = NTD + nts;
+        const int nwork = NTD + SPL * nts;
         for (int wk = wave; wk < nwork; wk += NT / 64) {
             ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
             if (wk < NTD) {
@@ -481,7 +494,7 @@ template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const Dev
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(g < G ? vv : 0.0, vv, acc, 0, 0, 0);
                 }
             } else {
-                const int ts = wk - NTD;
+                const int ts = (wk - NTD) / SPL, part = (wk - NTD) - ts * SPL;
                 int ta = 0;
                 while ((ta + 1) * (ta + 2) / 2 <= ts) ++ta;
                 const int tb = ts - ta * (ta + 1) / 2;
@@ -496,7 +509,9 @@ template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const Dev
                 const double *pa = sL + (size_t)rg * LREC + offW + ac * 3, *pb = sL + (size_t)rg * LREC + offW + bc * 3;
                 const double *ph = sL + (size_t)rg * LREC + offHI;
                 const int sg = 4 * LREC;
-                const int nfull = G >> 2;                              // groups whose four landmarks all exist
+                const int ngr = G >> 2;                                // groups whose four landmarks all exist
+                const int glo = part * ngr / SPL, nfull = (part + 1) * ngr / SPL - glo;      // this part's groups
+                pa += (size_t)glo * sg; pb += (size_t)glo * sg; ph += (size_t)glo * sg;
                 double wa[3], wb[3], hi[9], xa[3], xb[3], xh[9];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) { wa[c] = pa[c]; wb[c] = pb[c]; }
@@ -538,8 +553,8 @@ template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const Dev
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[c], -yb, acc, 0, 0, 0);
                     }
                 }
-                if (G & 3) {                                            // the last, partial group: masked
-                    const int g = 4 * nfull + rg, gc = min(g, G - 1);
+                if ((G & 3) && part == SPL - 1) {                       // the last, partial group: masked
+                    const int g = 4 * ngr + rg, gc = min(g, G - 1);
                     const double m = g < G ? 1.0 : 0.0;
                     const double *La = sL + (size_t)gc * LREC + offW + ac * 3, *Lb = sL + (size_t)gc * LREC + offW + bc * 3;
                     const double *Lh = sL + (size_t)gc * LREC + offHI;
@@ -590,7 +605,9 @@ template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const Dev
                 const int a = 6 * p + i, bq = 6 * q + j;
                 const int hi = (a >> 4) >= (bq >> 4) ? a : bq, lo = (a >> 4) >= (bq >> 4) ? bq : a;
                 const int ta = hi >> 4, tb = lo >> 4;
-                v = sTile[(size_t)(NTD + ta * (ta + 1) / 2 + tb) * 256 + (hi & 15) * 16 + (lo & 15)];
+                const double *pt = sTile + (size_t)(NTD + SPL * (ta * (ta + 1) / 2 + tb)) * 256 + (hi & 15) * 16 + (lo & 15);
+                v = pt[0];
+                for (int sp_ = 1; sp_ < SPL; ++sp_) v += pt[sp_ * 256];      // the tile's parts, in order
                 if (p == q) v += cdir(p, i, j);
             } else {
                 const int ve = e - n_pair, which = ve / D, a = ve - which * D;
