@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: world_size 2 over gloo.  Each process runs the sharded LM loop of
+"""The N > 1 path on CPU: world_size 2 and 3 over gloo.  Each process runs the sharded LM loop of
 visual-inertial-odometry_amd/sharded.py with the CPU oracle standing in for the GPU library (same C ABI, same
 exchange hooks), and the result must equal the unsharded solve."""
 import os
@@ -41,12 +41,14 @@ def _worker(rank, world, port, out_dir, n, ragged):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,ragged", [(90, False), (61, True)])
-def test_sharded_solve_equals_unsharded(vio, oracle_lib, tmp_path, n, ragged):
+@pytest.mark.parametrize("n,ragged,world", [(90, False, 2), (61, True, 2), (100, True, 3)])
+def test_sharded_solve_equals_unsharded(vio, oracle_lib, tmp_path, n, ragged, world):
+    """(world 3: uneven shards, and a rank-ordered sum of more than two terms: (a + b) + c on every rank)"""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), n, ragged), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    mp.spawn(_worker, args=(world, port, str(tmp_path), n, ragged), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    r0 = ranks[0]
     w = vio.synth.make_window(n, seed=21, ragged=ragged)
     ctx = oracle_lib.context()
     ctx.load(w)
@@ -58,7 +60,7 @@ def test_sharded_solve_equals_unsharded(vio, oracle_lib, tmp_path, n, ragged):
     invd = ctx.get_landmarks()
     marg = ctx.marginalize(vio.capi.MARG_OLD)
     mscale = np.abs(marg["H"]).max()
-    for r in (r0, r1):
+    for r in ranks:
         # marginalisation of the old frame: partial Schur systems summed over the shards, identical tail on every rank
         # (tolerance of tests/test_oracle_golden.py::check_prior: the Schur complement cancels O(1e16) terms, so a
         # different summation order moves the prior by O(1e-6) of its largest entry)
@@ -74,7 +76,8 @@ def test_sharded_solve_equals_unsharded(vio, oracle_lib, tmp_path, n, ragged):
         assert abs(float(r["final_chi2"]) - rep.final_chi2) <= 1e-7 * rep.final_chi2
         assert np.abs(r["poses"] - poses).max() <= 1e-7 and np.abs(r["sb"] - sbias).max() <= 1e-6
         assert np.abs(r["invd"] - invd).max() <= 1e-7
-    np.testing.assert_array_equal(r0["Hs"], r1["Hs"])      # bitwise identical on both ranks
-    np.testing.assert_array_equal(r0["poses"], r1["poses"])
-    for k in ("marg_H", "marg_b", "marg_err", "marg_jt"):
-        np.testing.assert_array_equal(r0[k], r1[k])
+    for r1 in ranks[1:]:
+        np.testing.assert_array_equal(r0["Hs"], r1["Hs"])      # bitwise identical on every rank
+        np.testing.assert_array_equal(r0["poses"], r1["poses"])
+        for k in ("marg_H", "marg_b", "marg_err", "marg_jt"):
+            np.testing.assert_array_equal(r0[k], r1[k])
