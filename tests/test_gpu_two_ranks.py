@@ -79,11 +79,17 @@ def _worker(rank, world, port, out_dir, kind, n, ragged):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind,n,ragged", [("invdepth", 900, True), ("invdepth", 5000, False), ("xyz", 700, True)])
-def test_two_hip_ranks_equal_the_unsharded_run(vio, hip_lib, tmp_path, kind, n, ragged):
+@pytest.mark.parametrize("kind,n,ragged,world", [("invdepth", 900, True, 2), ("invdepth", 5000, False, 2), ("xyz", 700, True, 2), ("invdepth", 3000, True, 4)])
+def test_two_hip_ranks_equal_the_unsharded_run(vio, hip_lib, tmp_path, kind, n, ragged, world):
+    """(world 4: the rank-ordered sums of the kernels over four gathered slabs — what N = 4 / 8 GPUs run — still on the one device)"""
+    run_ranks_case(vio, hip_lib, tmp_path, kind, n, ragged, world)
+
+
+def run_ranks_case(vio, hip_lib, tmp_path, kind, n, ragged, world=2):
     import torch.multiprocessing as mp
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), kind, n, ragged), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), kind, n, ragged), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    r0 = ranks[0]
     w = _make(vio, kind, n, ragged)
     ctx = hip_lib.context()
     ctx.load(w)
@@ -99,7 +105,7 @@ def test_two_hip_ranks_equal_the_unsharded_run(vio, hip_lib, tmp_path, kind, n, 
         ctx.gn_iteration(lam0)
     gp, gs, _ = ctx.get_window()
     gchi = ctx.chi2()
-    for r in (r0, r1):
+    for r in ranks:
         assert abs(float(r["chi0"]) - chi0) <= 1e-12 * abs(chi0) and float(r["lam0"]) == lam0
         d = np.sqrt(np.abs(np.diag(Hs)) + 1e-300)
         assert (np.abs(r["Hs"] - Hs) / np.outer(d, d)).max() <= 1e-12
@@ -115,5 +121,6 @@ def test_two_hip_ranks_equal_the_unsharded_run(vio, hip_lib, tmp_path, kind, n, 
             evs, evr = np.linalg.eigvalsh(r["marg_H"]), np.linalg.eigvalsh(marg["H"])
             assert np.abs(evs - evr).max() <= 2e-5 * evr.max()
             assert np.abs(r["marg_b"] - marg["b"]).max() <= 1e-6 * max(1.0, np.abs(marg["b"]).max())
-    for k in r0.files:          # every rank holds the identical reduced system and takes the identical steps
-        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    for r1 in ranks[1:]:
+        for k in r0.files:          # every rank holds the identical reduced system and takes the identical steps
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)

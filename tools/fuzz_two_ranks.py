@@ -34,7 +34,7 @@ def main():
         os.environ["VIO_TWO_RANK_PRIOR"] = "1" if with_prior else "0"
         try:
             with tempfile.TemporaryDirectory() as tmp:
-                t.test_two_hip_ranks_equal_the_unsharded_run(vio, hip, Path(tmp), kind, n, ragged)
+                t.run_ranks_case(vio, hip, Path(tmp), kind, n, ragged)
             print("ok   case %d: %s n=%d ragged=%d seed=%d prior=%d" % (case, kind, n, ragged, seed, with_prior))
         except AssertionError as exc:
             bad += 1
