@@ -17,12 +17,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 its = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 lam = 5e5
+POL = int(os.environ.get("VIO_ITEM_POLICY", "1"))          # 1: VIO_ITEMS_THROUGHPUT (what a batch wants)
 ws = [vio.synth.make_window(n, seed=100 + i) for i in range(B)]
 
 
 def group(windows):
-    lead = hip.context()
-    members = [lead] + [hip.context(stream=lead.get_stream()) for _ in windows[1:]]
+    lead = hip.context(item_policy=POL, )
+    members = [lead] + [hip.context(item_policy=POL, stream=lead.get_stream()) for _ in windows[1:]]
     for c, w in zip(members, windows):
         c.load(w)
     return members
