@@ -264,6 +264,28 @@ def test_headline_window_is_bitwise_reproducible(vio, hip_lib, big_window):
     assert outs[0][2] == outs[1][2]
 
 
+def test_headline_window_under_both_item_policies(vio, hip_lib, big_window):
+    """The same 20 000-landmark window cut into items the latency way (82 landmarks, 1024-thread workgroups) and the throughput way
+    (56, half-width workgroups, two to a CU): another grouping of the same sums — the reduced systems agree to rounding, Solve(10)
+    takes the same decisions, and each is bitwise reproducible."""
+    res = []
+    for pol in (vio.capi.ITEMS_LATENCY, vio.capi.ITEMS_THROUGHPUT, vio.capi.ITEMS_THROUGHPUT):
+        ctx = hip_lib.context(item_policy=pol)
+        ctx.load(big_window)
+        ctx.linearize()
+        H, b = ctx.get_schur_system()
+        rep = ctx.solve(10)
+        res.append((H, b, rep.iterations, rep.trials, rep.final_chi2, ctx.get_window()[0], ctx.get_landmarks()))
+    (H0, b0, it0, tr0, c0, p0, l0), (H1, b1, it1, tr1, c1, p1, l1), (H2, b2, it2, tr2, c2, p2, l2) = res
+    assert tu.scaled_sym_err(H1, H0) <= 1e-11 and np.abs(b1 - b0).max() <= 1e-11 * np.abs(b0).max()
+    assert (it1, tr1) == (it0, tr0) and abs(c1 - c0) <= 1e-9 * c0
+    assert np.abs(p1 - p0).max() <= 1e-8 and np.abs(l1 - l0).max() <= 1e-7
+    np.testing.assert_array_equal(H1, H2)
+    np.testing.assert_array_equal(p1, p2)
+    np.testing.assert_array_equal(l1, l2)
+    assert (it1, tr1, c1) == (it2, tr2, c2)
+
+
 def test_headline_window_linearity_over_landmark_shards(vio, hip_lib, big_window):
     """The reduced visual system is a sum over landmarks: the two half-window systems add up to the full one.
     (This is the property the multi-GPU all-reduce relies on.)"""
