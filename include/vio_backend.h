@@ -66,6 +66,14 @@ typedef enum {                 /* VM/include/backend/loss_function.h:23-91 */
 } vio_loss_type;
 
 typedef enum { VIO_ITEMS_LATENCY = 0, VIO_ITEMS_THROUGHPUT = 1 } vio_item_policy;
+/* Elimination order of the damped pose solve (H_pp_schur + lambda I).ldlt().solve(b), VM/src/backend/problem.cc:434-439
+ * (vio_set_solve_order; HIP library only):
+ *   VIO_ORDER_EIGEN (0)  Eigen's LDLT pivot order (a sort of the diagonal, Cholesky/LDLT.h:317-320), operation for operation;
+ *   VIO_ORDER_CHAIN (1)  default: a static order that follows the structure of the system — the 11 speed-bias blocks as a
+ *                        block-tridiagonal chain eliminated from both ends, then the dense 72-variable camera block — unpivoted,
+ *                        with correctly rounded quotients.  Same answer to the solver's rounding (closer to the exact solution
+ *                        than Eigen's own vectors on the golden systems, tests/golden/ldlt_exact.npz); 40 % less time. */
+typedef enum { VIO_ORDER_EIGEN = 0, VIO_ORDER_CHAIN = 1 } vio_solve_order;
 
 typedef enum {
     VIO_MARG_OLD = 0,          /* Estimator::MargOldFrame  estimator.cpp:693-829 */
@@ -324,6 +332,18 @@ const char *vio_kernel_name(int32_t which);
  *   out8[5]     rows of the reduced 156x156 system that were not exactly zero in that tail (the eigen-problem's size)
  *   out8[6]     the marginalisation plan prepared under the last vio_solve (0: nothing to prepare) */
 vio_status vio_get_host_timing(struct vio_ctx *ctx, double *out8);
+
+/* ---- elimination order of the pose solve (HIP library only) -------------------------------------- */
+/* Choose vio_solve_order for the context's solves from now on (default VIO_ORDER_CHAIN; the environment variable
+ * VIO_SOLVE_ORDER=eigen|chain sets the default of new contexts).  A prior whose H couples two speed-bias blocks that are not
+ * neighbours — no Problem::Marginalize output does (problem.cc:617-795 reaches the speed-bias of frame 1 only) — is solved in
+ * Eigen's order whatever was asked for; vio_get_solve_order reports the order asked for and the one in effect. */
+vio_status vio_set_solve_order(struct vio_ctx *ctx, int32_t order);
+vio_status vio_get_solve_order(struct vio_ctx *ctx, int32_t *requested, int32_t *effective);
+/* Diagnostic: x = (H + lambda I)^-1 b by the chain-order kernel alone on a caller-supplied 171 x 171 row-major H (natural order of
+ * H_pp_schur_; only its lower triangle is read).  lds_dump: NULL, or room for the factor as the kernel leaves it
+ * (tools/chain_solve_model.py documents the layout). */
+vio_status vio_debug_chain_solve(struct vio_ctx *ctx, const double *H, const double *b, double lambda, double *x, double *lds_dump);
 
 #ifdef __cplusplus
 }

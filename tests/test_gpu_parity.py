@@ -95,6 +95,70 @@ def test_solve_trace_against_the_reference_iteration_by_iteration(vio, hip_lib):
         assert max(abs(t[2] - l) / l for t, l in zip(tr, rl)) <= 3e-4, name
 
 
+def restart_states(vio, z, zr, name, k):
+    """the window of fixture z with the reference's states (and prior vectors) after outer iteration k of its Solve(10); k = 0: the input"""
+    w = tu.arrays_to_window(vio, z)
+    if k == 0:
+        return w
+    st = zr[name + "_state"][k - 1]
+    w.poses, w.speed_bias, w.ext = st[:77].reshape(11, 7).copy(), st[77:176].reshape(11, 9).copy(), st[176:183].copy()
+    if getattr(w, "xyz", None) is not None:
+        w.xyz = st[183:].reshape(-1, 3).copy()
+    else:
+        w.inv_depth = st[183:].copy()
+    if w.prior is not None:
+        w.prior = dict(w.prior)
+        w.prior["b"], w.prior["err"] = zr[name + "_bprior"][k - 1][:156].copy(), zr[name + "_errprior"][k - 1].copy()
+    return w
+
+
+def per_step_differences(vio, lib, order=None):
+    """SURVEY.md section 7 states the tolerance per trial step at the reference's own lambda sequence: for every golden window and
+    every outer iteration k of the reference's Solve(10) (tests/golden/solve_trace.npz holds its state, prior vectors and lambda
+    after each), restart from the REFERENCE's state k, take the one accepted trial of iteration k + 1 at the reference's lambda
+    (after t - 1 rejections lambda has been multiplied by 2, 4, 8, ...: problem.cc:569-570) and compare the state it leads to with
+    the reference's own state k + 1."""
+    from test_oracle_golden import cfg_of
+    zr = np.load(os.path.join(GOLDEN_DIR, "solve_trace.npz"))
+    out = {}
+    for path in WINDOW_FILES:
+        z = dict(np.load(path))
+        name = os.path.basename(path)[:-4]
+        if name + "_state" not in zr:
+            continue
+        c = lib.context(**cfg_of(z))
+        if order is not None:
+            c.set_solve_order(order)
+        rs, rl, rt = zr[name + "_state"], zr[name + "_lam"], zr[name + "_trials"]
+        d = []
+        for k in range(len(rs)):
+            lam = float(zr[name + "_lam0"]) if k == 0 else float(rl[k - 1])
+            t = int(rt[k])
+            if t > 10 or (t == 10 and k + 1 == len(rs) and np.array_equal(rs[k], rs[k - 1] if k else rs[k])):
+                continue                                        # (ten rejections: the state did not move)
+            lam *= 2.0 ** ((t - 1) * t // 2)
+            c.load(restart_states(vio, z, zr, name, k))
+            c.linearize()
+            c.solve_linear(lam)
+            c.update_states()
+            p, s, e = c.get_window()
+            lm = c.get_landmarks() if c.lm_dim == 1 else c.get_landmarks_xyz().ravel()
+            d.append(float(np.abs(np.concatenate([p.ravel(), s.ravel(), e.ravel(), lm]) - rs[k]).max()))
+        out[name] = d
+    return out
+
+
+def test_every_step_from_the_reference_state_within_1e_6(vio, hip_lib):
+    """the per-step figure of SURVEY.md section 7 (1e-6 per trial step at the reference's lambda sequence), for both elimination
+    orders of the pose solve; the accumulated end state of Solve(10) is bounded by the tests above"""
+    for order in (vio.capi.ORDER_CHAIN, vio.capi.ORDER_EIGEN):
+        d = per_step_differences(vio, hip_lib, order)
+        assert len(d) >= 8
+        worst = {k: max(v) for k, v in d.items()}
+        assert max(worst.values()) <= 1e-6, (order, worst)
+        assert all(v[0] <= 1e-9 for v in d.values()), (order, {k: v[0] for k, v in d.items()})
+
+
 @pytest.mark.parametrize("n,seed,ragged,ext_fixed", [(50, 11, False, 1), (300, 12, True, 1), (400, 13, False, 0), (2000, 14, False, 1)])
 def test_full_solve_against_oracle(vio, oracle_lib, hip_lib, n, seed, ragged, ext_fixed):
     w = vio.synth.make_window(n, seed=seed, ragged=ragged)

@@ -272,6 +272,14 @@ def solve_trace_stepwise(lib, w, kw, iterations=10):
     return out
 
 
+def test_every_step_from_the_reference_state(vio, oracle_lib):
+    """the per-step figure of SURVEY.md section 7 for the oracle: one trial from the reference's own state k at the reference's
+    lambda against the reference's state k + 1 (harness: tests/test_gpu_parity.py, which runs it on the HIP library)"""
+    from test_gpu_parity import per_step_differences
+    d = per_step_differences(vio, oracle_lib)
+    assert len(d) >= 8 and max(max(v) for v in d.values()) <= 1e-6, {k: max(v) for k, v in d.items()}
+
+
 def test_solve_trace_against_the_reference_iteration_by_iteration(vio, oracle_lib):
     """The oracle stays within 1e-13 of the reference while lambda is large; the difference appears where lambda has walked
     down to O(10..100) (cond(H + lambda I) ~ 1e15) and stays below 1e-6 (measured 1.9e-7, profiles/parity_trace.json)."""

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic only: where k_pose_solve_c (the chain-order pose solve) spends its cycles, from the -DVIO_STAMPS build
+(csrc/diag/libvio_hip_stamps.so; tools/build_diag.sh stamps).  Stamps are s_memtime ticks since the kernel's start, taken by wave 0
+(the chain wave) and wave 2 (a worker); they change the schedule a little: read the shares."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_package  # noqa: E402
+
+vio = load_package()
+lib = vio.VioLib(os.path.join(ROOT, "visual-inertial-odometry_amd", "csrc", "diag", os.environ.get("VIO_DIAG_LIB", "libvio_hip_stamps.so")), "vio_")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+w = vio.synth.make_window(n, seed=42)
+ctx = lib.context()
+ctx.load(w)
+ctx.linearize()
+_, lam = ctx.init_lm()
+for _ in range(3):
+    ctx.solve_linear(lam)
+ctx.synchronize()
+buf = np.zeros((16, 16), dtype=np.uint64)
+f = lib.dll.vio_debug_stamps
+f.restype = C.c_int
+assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(16)) == 0
+s = buf.astype(np.int64).ravel()
+print("copy-in + lambda done %d | factor + solve done %d | end %d" % (s[0], s[2], s[3]))
+base = s[0]
+print("speed-bias chain (ticks relative to the start of ch_factor_solve; wave 0):")
+prev = 0
+for lev in range(6):
+    a = s[64 + 4 * lev:68 + 4 * lev]
+    print("  level %d: F done %6d (+%5d) | past B1 %6d (+%4d) | S done %6d (+%5d) | past B2 %6d (+%4d)   worker: U of this level done at %6d, its S at %6d"
+          % (lev, a[0], a[0] - prev, a[1], a[1] - a[0], a[2], a[2] - a[1], a[3], a[3] - a[2], s[112 + lev] if lev < 5 else s[117], s[120 + lev]))
+    prev = a[3]
+print("camera block:")
+print("  CC(0,0) update + F(0) done %6d (+%5d) | past barrier %6d" % (s[88], s[88] - prev, s[89]))
+prev = s[89]
+for K in range(5):
+    a = s[90 + 4 * K:94 + 4 * K]
+    if K < 4:
+        print("  K = %d: S done %6d (+%5d) | past B %6d (+%4d) | F(K+1) done %6d (+%5d) | past B %6d (+%4d)   worker: U done at %6d"
+              % (K, a[0], a[0] - prev, a[1], a[1] - a[0], a[2], a[2] - a[1], a[3], a[3] - a[2], s[128 + K]))
+        prev = a[3]
+    else:
+        print("  K = 4: S done %6d (+%5d) | past B %6d" % (a[0], a[0] - prev, a[1]))
+        prev = a[1]
+print("back-substitution: starts %6d | camera rounds done %6d (+%5d) | chains done %6d (+%5d)" % (s[110], s[111], s[111] - s[110], s[63], s[63] - s[111]))

@@ -31,6 +31,7 @@ def solve_trace(lib, w, kw, iterations=10):
     c.linearize()
     chi, lam = c.init_lm()
     out, last = [], 1e20
+    solve_trace.lam0 = lam
     for it in range(iterations):
         ok, false_cnt, trials = False, 0, 0
         while not ok and false_cnt < 10:
@@ -45,7 +46,8 @@ def solve_trace(lib, w, kw, iterations=10):
                 c.rollback_states()
         p, s, e = c.get_window()
         lm = c.get_landmarks() if c.lm_dim == 1 else c.get_landmarks_xyz().ravel()
-        out.append(dict(state=np.concatenate([p.ravel(), s.ravel(), e.ravel(), lm]), chi=chi, lam=lam, trials=trials))
+        bp, ep = c.get_prior()
+        out.append(dict(state=np.concatenate([p.ravel(), s.ravel(), e.ravel(), lm]), chi=chi, lam=lam, trials=trials, bprior=bp, errprior=ep))
         if last - chi < 1e-5:
             break
         last = chi
@@ -74,6 +76,11 @@ if "--make-reference" in sys.argv:
         d[name + "_chi"] = np.array([t["chi"] for t in tr])
         d[name + "_lam"] = np.array([t["lam"] for t in tr])
         d[name + "_trials"] = np.array([t["trials"] for t in tr], dtype=np.int32)
+        # what a restart from iteration k needs beside the states (tests/test_gpu_parity.py: every step from the reference's own state)
+        d[name + "_lam0"] = np.float64(solve_trace.lam0)
+        if "in_prior_H" in z:
+            d[name + "_bprior"] = np.stack([t["bprior"] for t in tr])
+            d[name + "_errprior"] = np.stack([t["errprior"] for t in tr])
         # the stepwise loop must be Problem::Solve: same end state as the golden file's Solve(10)
         endz = np.concatenate([z["solve_posesF"].ravel(), z["solve_sbF"].ravel(), z["solve_extF"].ravel(), z["solve_invdF"].ravel()])
         assert np.abs(tr[-1]["state"] - endz).max() == 0.0, (name, np.abs(tr[-1]["state"] - endz).max())

@@ -19,6 +19,7 @@ CAM_DIM = 6 + 6 * NUM_FRAMES       # 72
 LOSS_TRIVIAL, LOSS_HUBER, LOSS_CAUCHY, LOSS_TUKEY = 0, 1, 2, 3
 MARG_OLD, MARG_SECOND_NEW = 0, 1
 ITEMS_LATENCY, ITEMS_THROUGHPUT = 0, 1
+ORDER_EIGEN, ORDER_CHAIN = 0, 1          # vio_solve_order: elimination order of the damped pose solve
 
 STATUS = {0: "VIO_OK", -1: "VIO_ERR_BAD_ARG", -2: "VIO_ERR_HIP", -3: "VIO_ERR_NOT_FINITE",
           -4: "VIO_ERR_EMPTY", -5: "VIO_ERR_UNSUPPORTED", -6: "VIO_ERR_NO_DEVICE"}
@@ -94,7 +95,8 @@ class VioLib:
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
-                "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration", "batch_solve", "get_host_timing"]
+                "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration", "batch_solve", "get_host_timing",
+                "set_solve_order", "get_solve_order", "debug_chain_solve"]
     KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
@@ -455,6 +457,24 @@ class VioContext:
         ms, n = C.c_double(), C.c_int64()
         self._ck(self.lib.fn["profile_end"](self.h, C.byref(ms), C.byref(n)), "profile_end")
         return ms.value, n.value
+
+    def set_solve_order(self, order):
+        """vio_set_solve_order: ORDER_EIGEN (Eigen's LDLT pivot order) or ORDER_CHAIN (the static structured order, default)."""
+        self._ck(self.lib.fn["set_solve_order"](self.h, C.c_int32(order)), "set_solve_order")
+
+    def get_solve_order(self):
+        """(requested, effective): a prior outside the chain pattern is solved in Eigen's order whatever was asked for."""
+        a, b = C.c_int32(), C.c_int32()
+        self._ck(self.lib.fn["get_solve_order"](self.h, C.byref(a), C.byref(b)), "get_solve_order")
+        return a.value, b.value
+
+    def debug_chain_solve(self, H, b, lam, dump=False):
+        """vio_debug_chain_solve: (H + lam I)^-1 b by the chain-order kernel alone; with dump, also the factor as left in LDS."""
+        H, b = _f64(H, (POSE_DIM, POSE_DIM)), _f64(b, (POSE_DIM,))
+        x = np.zeros(POSE_DIM)
+        d = np.zeros(1 << 15) if dump else None
+        self._ck(self.lib.fn["debug_chain_solve"](self.h, _dp(H), _dp(b), C.c_double(lam), _dp(x), _dp(d) if dump else None), "debug_chain_solve")
+        return (x, d) if dump else x
 
     def host_timing(self):
         """vio_get_host_timing as a dict (microseconds; `marg_live_rows` is a count)."""

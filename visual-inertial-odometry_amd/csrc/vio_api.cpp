@@ -53,9 +53,14 @@ void vio_launch_init_lm(const DeviceTables &T, int max_iter, hipStream_t s);
 void vio_launch_set_lambda(LmState *lm, double lambda, hipStream_t s);
 void vio_launch_flip(LmState *lm, hipStream_t s);
 void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int any_prior, size_t ps_lds,
-                         int what, int max_iter, hipStream_t s);
+                         int what, int max_iter, int order, hipStream_t s);
 void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int test_prev, int any_prior,
-                         int parity, size_t ps_lds, hipStream_t s);
+                         int parity, size_t ps_lds, int order, hipStream_t s);
+void vio_launch_chain_solve_test(const double *img, double lambda, double *x_nat, double *lds_dump, hipStream_t s);
+int vio_chain_image_doubles();
+int vio_chain_lds_core_doubles();
+void vio_chain_entry_pos(int i, int j, int *p1, int *p2);
+int vio_chain_dim(int i);
 int vio_set_kernel_attributes();
 int lin_lds_doubles_host(int G, int K, int nb, int use_ext);
 int lin_threads_host();
@@ -213,6 +218,9 @@ struct vio_ctx {
     bool pairtab_valid = false;
     bool stepwise_updated = false;
     double gn_lambda = -1.0;
+    int solve_order = VIO_ORDER_CHAIN;         // vio_set_solve_order (VIO_SOLVE_ORDER=eigen|chain overrides the default at creation)
+    bool prior_chain_ok = true;                // H_prior couples no two speed-bias blocks that are not neighbours (the chain order's storage)
+    int pg_layout = -1;                        // which order's image d_Pg holds (the two layouts rely on different never-written zeros)
     bool want_natural_hs = false;              // set by vio_get_schur_system: re-run k_assemble with the natural-order copy
     bool natural_hs_valid = false;
     int g_max = 0;                             // landmarks per item; 0 = automatic (VIO_G_MAX overrides; <= 128: k_backsub has one thread per landmark)
@@ -658,11 +666,26 @@ vio_status alloc_fixed(vio_ctx *c) {
     HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
     HIPCHK(c->d_gath.resize((size_t)c->cfg.shard_count * VIS_SEND)); HIPCHK(c->d_step_gath.resize((size_t)c->cfg.shard_count * 2));
     HIPCHK(c->d_perm.resize(2 * 176)); HIPCHK(c->d_rank.resize(176)); HIPCHK(c->d_Pg.resize(2 * POSE_SOLVE_TILED));     // two sets (vio_solve's loop)
-    HIPCHK(hipMemset(c->d_Pg.p, 0, 2 * POSE_SOLVE_TILED * sizeof(double)));   // tile padding (17th column) is never written again
+    HIPCHK(hipMemset(c->d_Pg.p, 0, 2 * POSE_SOLVE_TILED * sizeof(double)));   // tile padding (17th column) is never written again (use_pg_layout)
     HIPCHK(hipMemsetAsync(c->d_vis.p, 0, VIS_COUNT * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_step_tot.p, 0, 8 * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_dx.p, 0, 176 * 8, c->stream));
     return VIO_OK;
+}
+
+// The chain order (vio_pose_solve_chain.h) stores the speed-bias blocks as a block-tridiagonal chain; a prior that couples two
+// blocks that are not neighbours (no reference caller produces one: Marginalize reaches the speed-bias of frame 1 only) is
+// solved in Eigen's pivot order instead.
+inline int effective_order(const vio_ctx *c) {
+    return (c->solve_order == VIO_ORDER_CHAIN && (!c->has_prior || c->prior_chain_ok)) ? VIO_ORDER_CHAIN : VIO_ORDER_EIGEN;
+}
+
+// Both images of the pose system keep padding that no kernel ever writes (the 17th column of a tile, the identity rows, the unused
+// rows of the chain's right-hand side): cleared when the buffer changes hands, in stream order
+inline void use_pg_layout(vio_ctx *c, int order) {
+    if (c->pg_layout == order) return;
+    (void)hipMemsetAsync(c->d_Pg.p, 0, 2 * (size_t)POSE_SOLVE_TILED * sizeof(double), c->stream);
+    c->pg_layout = order;
 }
 
 DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
@@ -689,6 +712,8 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
     T.gath = c->ext_gath ? c->ext_gath : c->d_gath.p; T.step_gath = c->ext_step_gath ? c->ext_step_gath : c->d_step_gath.p;
     T.n_shards = (c->hook != nullptr || c->comm != nullptr) ? c->cfg.shard_count : 0;
+    T.solve_order = effective_order(c);
+    use_pg_layout(c, T.solve_order);
     T.list_off = pl.d_list_off.p; T.list = pl.d_list.p;
 #ifdef VIO_STAMPS
     (void)c->d_dbg.resize(16 * (size_t)(T.n_items + T.n_imu_items + 16));
@@ -1098,6 +1123,7 @@ vio_status vio_create(const vio_config *cfg, vio_ctx **out) {
     if (const char *e = std::getenv("VIO_G_MAX")) { int v = std::atoi(e); if (v >= 1 && v <= 128) c->g_max = v; }
     if (const char *e = std::getenv("VIO_G_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 128) c->g_min = v; }
     if (c->g_max > 0) c->g_min = c->g_max;     // a forced size is exactly that size (LDS permitting)
+    if (const char *e = std::getenv("VIO_SOLVE_ORDER")) c->solve_order = (e[0] == 'e' || e[0] == 'E' || e[0] == '0') ? VIO_ORDER_EIGEN : VIO_ORDER_CHAIN;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->cfg.device) == hipSuccess && v > 0) c->n_cus = v; }
     if (vio_set_kernel_attributes() != 0) { c->err = "hipFuncSetAttribute failed"; }
     vio_status s = alloc_fixed(c);
@@ -1270,7 +1296,67 @@ vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double 
             std::memcpy(c->h_Jtinv.data(), jt, (size_t)PRD * PRD * 8);
         }
     }
+    if (!same_mats) {
+        // speed-bias block f occupies rows 12 + 15 f .. 20 + 15 f
+        bool ok = true;
+        for (int f = 0; ok && f < NF; ++f)
+            for (int g2 = 0; ok && g2 < NF; ++g2) {
+                if (g2 >= f - 1 && g2 <= f + 1) continue;
+                for (int a = 0; ok && a < 9; ++a)
+                    for (int b2 = 0; b2 < 9; ++b2)
+                        if (c->h_Hprior[(size_t)(12 + 15 * f + a) * PD + 12 + 15 * g2 + b2] != 0.0) { ok = false; break; }
+            }
+        c->prior_chain_ok = ok;
+    }
     c->dirty_inputs = true;
+    return VIO_OK;
+}
+
+vio_status vio_set_solve_order(vio_ctx *c, int32_t order) {
+    if (!c || (order != VIO_ORDER_EIGEN && order != VIO_ORDER_CHAIN)) return VIO_ERR_BAD_ARG;
+    if (order == c->solve_order) return VIO_OK;
+    enter_device(c);
+    VIOCHK(flush_decide(c));
+    c->solve_order = order;
+    c->linearized = false;          // the assembled system on the device is in the other order's layout
+    c->natural_hs_valid = false;
+    ++c->tables_gen;
+    return VIO_OK;
+}
+
+vio_status vio_get_solve_order(vio_ctx *c, int32_t *requested, int32_t *effective) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (requested) *requested = c->solve_order;
+    if (effective) *effective = effective_order(c);
+    return VIO_OK;
+}
+
+// Diagnostic: (H + lambda I) x = b by the chain-order kernel alone, on a matrix the caller supplies (171 x 171 row-major, natural
+// order of H_pp_schur_).  lds_dump (optional, vio_chain_lds_core_doubles() doubles): the factor as the kernel left it in LDS.
+vio_status vio_debug_chain_solve(vio_ctx *c, const double *H, const double *b, double lambda, double *x, double *lds_dump) {
+    if (!c || !H || !b || !x) return VIO_ERR_BAD_ARG;
+    enter_device(c);
+    const int n_img = vio_chain_image_doubles(), n_lds = vio_chain_lds_core_doubles();
+    std::vector<double> img((size_t)n_img, 0.0);
+    for (int i = 0; i < PD; ++i) {
+        img[(size_t)n_img - 256 + vio_chain_dim(i)] = b[i];
+        for (int j = 0; j <= i; ++j) {
+            int p1, p2;
+            vio_chain_entry_pos(i, j, &p1, &p2);
+            const double v = H[(size_t)i * PD + j];
+            if (p1 < 0) { if (v != 0.0) return fail(c, VIO_ERR_BAD_ARG, "vio_debug_chain_solve: entry outside the chain pattern"); continue; }
+            img[p1] = v;
+            if (p2 >= 0) img[p2] = v;
+        }
+    }
+    DevBuf<double> d_img, d_x, d_dump;
+    HIPCHK(d_img.resize(img.size())); HIPCHK(d_x.resize(176)); HIPCHK(d_dump.resize((size_t)n_lds));
+    HIPCHK(hipMemcpyAsync(d_img.p, img.data(), img.size() * 8, hipMemcpyHostToDevice, c->stream));
+    vio_launch_chain_solve_test(d_img.p, lambda, d_x.p, lds_dump ? d_dump.p : nullptr, c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(x, d_x.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
+    if (lds_dump) HIPCHK(hipMemcpyAsync(lds_dump, d_dump.p, (size_t)n_lds * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return VIO_OK;
 }
 
@@ -1536,7 +1622,10 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
     }
     if (any_ext) lin_threads = -lin_threads;                 // (the launchers' sign convention: kernels that read the extrinsic block from the item)
     const int test_prev = ctxs[0]->decide_pending ? 1 : 0;
-    vio_launch_batch_gn(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, c->stream);
+    int order = VIO_ORDER_CHAIN;                             // the chain order if every window can take it (one kernel for the whole batch)
+    for (int i = 0; i < count; ++i) if (effective_order(ctxs[i]) != VIO_ORDER_CHAIN) order = VIO_ORDER_EIGEN;
+    for (int i = 0; i < count; ++i) use_pg_layout(ctxs[i], order);
+    vio_launch_batch_gn(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, order, c->stream);
     HIPCHK(hipGetLastError());
     ++c->batch_iters;
     for (int i = 0; i < count; ++i) {
@@ -1544,7 +1633,7 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
         m->decide_pending = true;
         m->cur_host ^= 1;
         m->ahead = 7u;
-        m->linearized = true;
+        m->linearized = order == effective_order(m);       // (a window solved in the batch's order, not its own: its image is the other layout)
         m->natural_hs_valid = false;
     }
     return VIO_OK;
@@ -1606,8 +1695,11 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
     };
     static const bool classic = std::getenv("VIO_LM_CLASSIC") != nullptr;
     if (any_ext) lin_threads = -lin_threads;                 // (the launchers' sign convention, as in vio_batch_gn_iteration)
-    vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, 0, iterations, c->stream);
-    if (!classic && iterations > 0) vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, 3, iterations, c->stream);
+    int order = VIO_ORDER_CHAIN;
+    for (int i = 0; i < count; ++i) if (effective_order(ctxs[i]) != VIO_ORDER_CHAIN) order = VIO_ORDER_EIGEN;
+    for (int i = 0; i < count; ++i) use_pg_layout(ctxs[i], order);
+    vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, 0, iterations, order, c->stream);
+    if (!classic && iterations > 0) vio_launch_batch_lm(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, 3, iterations, order, c->stream);
     HIPCHK(hipGetLastError());
     if (classic || iterations <= 0) VIOCHK(read_all());
     else for (int i = 0; i < count; ++i) { ctxs[i]->h_lm.stop = 0; ctxs[i]->h_lm.iter = 0; }
@@ -1629,7 +1721,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
         }
         const int batch = std::min(left, 10);
         for (int sl = 0; sl < batch; ++sl)
-            vio_launch_batch_lm(c->d_batch_tabs.p, (int)live.size(), c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, classic ? 1 : 2, iterations, c->stream);
+            vio_launch_batch_lm(c->d_batch_tabs.p, (int)live.size(), c->lm_dim, max_blocks, lds, lin_threads, any_prior, POSE_SOLVE_LDS, classic ? 1 : 2, iterations, order, c->stream);
         HIPCHK(hipGetLastError());
         VIOCHK(read_all());
     }

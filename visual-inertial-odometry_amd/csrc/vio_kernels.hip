@@ -2354,6 +2354,7 @@ __global__ __launch_bounds__(256) void k_triangulate(TriTables Q) {
     Q.depth[i] = dep;
 }
 
+#include "vio_pose_solve_chain.h"
 #include "vio_kernels_xyz.h"
 
 void vio_launch_triangulate(const TriTables &Q, hipStream_t s) {
@@ -2384,30 +2385,38 @@ static void launch_linearize_b(const BatchArgs &a, int lm_dim, int max_blocks, i
     else if (!ext) hipLaunchKernelGGL(k_linearize_b, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
     else hipLaunchKernelGGL(k_linearize_gb, dim3(max_blocks, B), dim3(LIN_THREADS), lin_lds, s, a);
 }
+// order 1: the chain order for every window of the batch (no rank kernel: every entry's place is static)
+static void launch_assemble_b(const BatchArgs &a, int B, int order, hipStream_t s) {
+    if (order == 1) { hipLaunchKernelGGL(k_assemble_cb, dim3(ASMC_BLOCKS, B), dim3(ASMC_THREADS), 0, s, a); return; }
+    hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
+    hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(192), 0, s, a);
+}
+static void launch_pose_solve_b(const BatchArgs &a, int B, size_t ps_lds, int order, hipStream_t s) {
+    if (order == 1) hipLaunchKernelGGL(k_pose_solve_cb, dim3(1, B), dim3(PS_THREADS), CH_LDS_DOUBLES * sizeof(double), s, a);
+    else hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
+}
 // batched GN iteration (windows of one landmark kind): grid.y = window
 void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int test_prev, int any_prior,
-                         int parity, size_t ps_lds, hipStream_t s) {
+                         int parity, size_t ps_lds, int order, hipStream_t s) {
     BatchArgs a{tabs, test_prev ? 2 : 0, parity, 0};
     launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
     a.gn_flags = test_prev ? 1 : 0;
     hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
-    hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(192), 0, s, a);
+    launch_assemble_b(a, B, order, s);
     a.gn_flags = 4;
-    hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
+    launch_pose_solve_b(a, B, ps_lds, order, s);
 }
 __global__ __launch_bounds__(RED_THREADS) void k_errprior_b(BatchArgs a);
 // Batched LM solve (vio_batch_solve): the kernels of vio_solve's device-driven loop with grid.y = window;
 // every window follows its own LmState (parity -1: `cur` from LmState; gate as in the single-window loop).
 //   what 0: first linearisation + ComputeLambdaInitLM      what 1: one slot = trial (gate 2) + re-linearisation (gate 3)
 void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int any_prior, size_t ps_lds,
-                         int what, int max_iter, hipStream_t s) {
+                         int what, int max_iter, int order, hipStream_t s) {
     auto linearize = [&](int gate) {
         BatchArgs a{tabs, 0, -1, gate};
         launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
         hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1, B), dim3(RED_THREADS), 0, s, a);
-        hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
-        hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(192), 0, s, a);
+        launch_assemble_b(a, B, order, s);
     };
     if (what == 0) {
         linearize(0);
@@ -2423,15 +2432,14 @@ void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_bl
             launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
             a.gn_flags = 1;
             hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + (any_prior ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
-            hipLaunchKernelGGL(k_rank_b, dim3(1, B), dim3(ASM_THREADS), 0, s, a);
-            hipLaunchKernelGGL(k_assemble_b, dim3(PS_NP + 1, B), dim3(192), 0, s, a);
+            launch_assemble_b(a, B, order, s);
         }
         a.gn_flags = 4;
-        hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
+        launch_pose_solve_b(a, B, ps_lds, order, s);
         return;
     }
     BatchArgs a{tabs, 4, -1, 2};
-    hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
+    launch_pose_solve_b(a, B, ps_lds, order, s);
     a.gn_flags = 8;
     if (lm_dim == 3) hipLaunchKernelGGL(k_backsub_xyz_b, dim3(max_blocks, B), dim3(BS_THREADS), 0, s, a, 0);
     else hipLaunchKernelGGL(k_backsub_b, dim3(max_blocks, B), dim3(BS_THREADS), 0, s, a, 0);
@@ -2470,10 +2478,23 @@ __global__ __launch_bounds__(256) void k_gather_landmarks(const LmState *lm, con
 void vio_launch_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map, hipStream_t s) {
     hipLaunchKernelGGL(k_gather_landmarks, dim3((ns_dst + 255) / 256), dim3(256), 0, s, lm, src, ns_src, dst, ns_dst, map);
 }
-void vio_launch_assemble(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_assemble, dim3(PS_NP + 1), dim3(ASM_THREADS), 0, s, T); }
-void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
+void vio_launch_assemble(const DeviceTables &T, hipStream_t s) {
+    if (T.solve_order == 1) hipLaunchKernelGGL(k_assemble_c, dim3(ASMC_BLOCKS), dim3(ASMC_THREADS), 0, s, T);
+    else hipLaunchKernelGGL(k_assemble, dim3(PS_NP + 1), dim3(ASM_THREADS), 0, s, T);
 }
+// lds_bytes: what the Eigen-order kernel needs (the chain kernel's size is its own)
+void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
+    if (T.solve_order == 1) hipLaunchKernelGGL(k_pose_solve_c, dim3(1), dim3(PS_THREADS), CH_LDS_DOUBLES * sizeof(double), s, T);
+    else hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
+}
+// test entry of the chain solve: one image, one lambda (tests/test_gpu_chain_solve.py)
+void vio_launch_chain_solve_test(const double *img, double lambda, double *x_nat, double *lds_dump, hipStream_t s) {
+    hipLaunchKernelGGL(k_chain_solve_test, dim3(1), dim3(PS_THREADS), CH_LDS_CORE * sizeof(double), s, img, lambda, x_nat, lds_dump);
+}
+int vio_chain_image_doubles() { return CH_PACKED; }
+int vio_chain_lds_core_doubles() { return CH_LDS_CORE; }
+void vio_chain_entry_pos(int i, int j, int *p1, int *p2) { ch_entry_pos(i, j, *p1, *p2); }
+int vio_chain_dim(int i) { return ch_dim(i); }
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s) {
     if (T.lm_dim == 3) hipLaunchKernelGGL(k_backsub_xyz, dim3(T.n_items + T.n_imu_items), dim3(BS_THREADS), 0, s, T, mode);
     else hipLaunchKernelGGL(k_backsub, dim3(T.n_items + T.n_imu_items), dim3(BS_THREADS), 0, s, T, mode);
@@ -2512,6 +2533,9 @@ int vio_set_kernel_attributes() {
     if (hipFuncSetAttribute((const void *)k_linearize_gb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_linearize_ghb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_pose_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_pose_solve_c, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_pose_solve_cb, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_chain_solve_test, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     hipError_t e3 = hipFuncSetAttribute((const void *)k_linearize_xyz, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_h, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);

@@ -1,0 +1,846 @@
+// vio_pose_solve_chain.h — the structure-exploiting pose solve ("chain order"), included by vio_kernels.hip.
+//
+// (H_pp_schur_ + lambda I) dx = b_pp_schur_ (VM/src/backend/problem.cc:434-439) solved by an UNPIVOTED blocked LDL^T in a STATIC
+// elimination order that follows the structure of the reduced system instead of Eigen's sort of the diagonal:
+//
+//   1. the 11 speed-bias blocks S_f (9 variables each, inside a block in the order bg, ba, v) — a block-tridiagonal chain
+//      (the IMU factor f couples S_f with S_f+1 and with the poses f, f+1; the marginalisation prior adds S_0 <-> everything
+//      in the camera block, never S_f <-> S_g for |f - g| > 1) — eliminated from BOTH ENDS towards the middle
+//      ("twisted" order 0,10,1,9,2,8,3,7,4,6,5): two independent chains of 9-pivot factorisations, 6 levels deep instead of 11,
+//      no fill inside the chain;
+//   2. the camera block C = [pose 0 .. pose 10 | ext] (72 variables, 5 tiles of 16: 16,16,16,16,8), dense, blocked as before.
+//
+// Accuracy (tests/golden/ldlt.npz against the 50-digit solutions of ldlt_exact.npz, tools/chain_solve_model.py): this order with
+// true divisions is 4.7e-14 / 1.4e-9 / 4.2e-5 from the exact solution at lambda = 5e5 / 1e3 / 1, where Eigen's pivoted LDLT is
+// 4.1e-12 / 1.2e-7 / 1.4e-4.  The divisions matter: the bias random walk makes blocks [[W, -W], [-W, W]] with W ~ 1e16, and
+// l = u / d comes out as exactly -1 only when it is a correctly rounded quotient (a reciprocal-multiply leaves eps * 1e16 in the
+// Schur complement, 40x the error).  Hence: the tiles keep L (scaled columns, l = u / d by d_div), updates are formed as
+// (L D) L^T.
+//
+// Storage (doubles; the image k_assemble_chain writes to T.Pg and this kernel copies into LDS):
+//   SC[e][t]   16 x 9 (row stride 10)   camera tile t (rows) x speed-bias block e (columns)          55 tiles
+//   SO[e]       9 x 9 (row stride 10)   succ(e) (rows) x e (columns), succ(e) = e + 1 (e < 5), e - 1 (e > 5)   10 tiles
+//   SD[e]       9 x 9 (row stride 10)   diagonal block of S_e                                         11 tiles
+//   CC[I][J]   16 x 16 (row stride 17)  camera tiles, I >= J                                          15 tiles
+//   Y          yS[11][16] | yC[80]      right-hand side in "chain dimension" order
+// Row stride 10 keeps both MFMA operand images of a 9-column tile free of LDS bank conflicts (A image: rows * 10 are 16
+// distinct even residues mod 32; C image: two rows of 9 at distance 10).
+#ifndef VIO_POSE_SOLVE_CHAIN_H
+#define VIO_POSE_SOLVE_CHAIN_H
+
+#define CH_NS 11
+#define CH_TS 10
+#define CH_SCSZ 160
+#define CH_S9SZ 90
+#define CH_OFF_SC 0
+#define CH_OFF_SO (CH_OFF_SC + CH_NS * 5 * CH_SCSZ)        // 8800
+#define CH_OFF_SD (CH_OFF_SO + 10 * CH_S9SZ)                // 9700
+#define CH_OFF_CC (CH_OFF_SD + CH_NS * CH_S9SZ)             // 10690
+#define CH_OFF_Y (CH_OFF_CC + 15 * PS_TS)                   // 14770
+#define CH_YC 176                                           // dimension index of camera variable 0
+#define CH_NDIM 256
+#define CH_PACKED (CH_OFF_Y + CH_NDIM)                      // 15026: what travels through HBM
+#define CH_SET_STRIDE 15040
+#define CH_OFF_SM CH_PACKED                                 // LDS only: M_e = L_ee^-T of every speed-bias block, 9 x 9 (stride 10)
+#define CH_OFF_MC (CH_OFF_SM + CH_NS * CH_S9SZ)             // 16 x 17: M_K of the camera tile being factored
+#define CH_OFF_D (CH_OFF_MC + PS_TS)                        // [256] pivots by dimension
+#define CH_OFF_X (CH_OFF_D + CH_NDIM)                       // [256] solution by dimension
+#define CH_OFF_I9 (CH_OFF_X + CH_NDIM)                      // 9 x 9 identity (stride 10): the rows F's second half-row of lanes starts from
+#define CH_OFF_I16 (CH_OFF_I9 + CH_S9SZ)                    // 16 x 16 identity (stride 17)
+#define CH_LDS_CORE (CH_OFF_I16 + PS_TS)                    // 17162
+static_assert(CH_PACKED % 2 == 0 && CH_SET_STRIDE >= CH_PACKED && CH_SET_STRIDE <= PS_SET_STRIDE, "chain image fits a set of Pg");
+
+__host__ __device__ inline int ch_sc(int e, int t) { return CH_OFF_SC + (e * 5 + t) * CH_SCSZ; }
+__host__ __device__ inline int ch_so(int e) { return CH_OFF_SO + (e < 5 ? e : e - 1) * CH_S9SZ; }
+__host__ __device__ inline int ch_sd(int e) { return CH_OFF_SD + e * CH_S9SZ; }
+__host__ __device__ inline int ch_sm(int e) { return CH_OFF_SM + e * CH_S9SZ; }
+__host__ __device__ inline int ch_tix(int I, int J) { return (I * (I + 1) / 2 + J) * (16 * 17); }
+__host__ __device__ inline int ch_cc(int I, int J) { return CH_OFF_CC + ch_tix(I, J); }
+__host__ __device__ inline int ch_cc_elem(int r, int c) { return ch_cc(r >> 4, c >> 4) + (r & 15) * 17 + (c & 15); }
+// natural index of H_pp_schur_ (0 .. 170: ext | (pose, v, ba, bg) x 11) -> chain dimension
+__host__ __device__ inline int ch_dim(int i) {
+    if (i < 6) return CH_YC + 66 + i;
+    const int f = (i - 6) / 15, r = (i - 6) % 15;
+    if (r < 6) return CH_YC + 6 * f + r;
+    const int c = r - 6;                                    // v 0..2, ba 3..5, bg 6..8  ->  bg 0..2, ba 3..5, v 6..8
+    return f * 16 + (c < 3 ? 6 + c : (c < 6 ? c : c - 6));
+}
+// where entry (i, j) of the symmetric matrix lives in the image: p1 (and p2, the mirror image inside a diagonal block), or -1 when
+// the pair has no storage (speed-bias blocks that are not neighbours: must be zero, checked by the host before this path is chosen)
+__host__ __device__ inline void ch_entry_pos(int i, int j, int &p1, int &p2) {
+    const int di = ch_dim(i), dj = ch_dim(j);
+    p1 = -1; p2 = -1;
+    const bool ci = di >= CH_YC, cj = dj >= CH_YC;
+    if (ci && cj) {
+        int a = di - CH_YC, b = dj - CH_YC;
+        if (a < b) { const int t = a; a = b; b = t; }
+        p1 = ch_cc_elem(a, b);
+        if (a != b && (a >> 4) == (b >> 4)) p2 = ch_cc_elem(b, a);
+    } else if (ci != cj) {
+        const int c = (ci ? di : dj) - CH_YC, s = ci ? dj : di;
+        p1 = ch_sc(s >> 4, c >> 4) + (c & 15) * CH_TS + (s & 15);
+    } else {
+        const int ei = di >> 4, ki = di & 15, ej = dj >> 4, kj = dj & 15;
+        if (ei == ej) {
+            p1 = ch_sd(ei) + ki * CH_TS + kj;
+            if (ki != kj) p2 = ch_sd(ei) + kj * CH_TS + ki;
+        } else if (ei - ej == 1 || ej - ei == 1) {
+            // the column block is the one eliminated first: the one farther from block 5
+            const int ai = ei > 5 ? ei - 5 : 5 - ei, aj = ej > 5 ? ej - 5 : 5 - ej;
+            if (ai > aj) p1 = ch_so(ei) + kj * CH_TS + ki;      // rows: block ej, columns: block ei
+            else p1 = ch_so(ej) + ki * CH_TS + kj;
+        }
+    }
+}
+
+#ifdef __HIPCC__
+#ifndef CH_TRUE_DIV
+#define CH_TRUE_DIV 1
+#endif
+// a / d with r = d_fast_rcp(d): one correction step makes the quotient correctly rounded in all but rare cases, and exact
+// whenever a / d is representable (the -1 of the random-walk blocks); 0 for d == 0
+__device__ __forceinline__ double d_div(double a, double d, double r) {
+#if CH_TRUE_DIV
+    const double q = a * r;
+    const double rem = fma(-d, q, a);
+    return fma(rem, r, q);
+#else
+    return a * r;
+#endif
+}
+
+// F: factor the NP x NP diagonal block `tile` (row stride TS) in place, one wave; ps_factor_diag's scheme (see there) with true
+// divisions and a pivot count: lanes 16..31 carry the rows of the identity (read from sI, row stride TS) and end up with M = L^-T
+// (written to M, row stride MS, entries [r][c] for r, c < NP only).  After it: tile[TS j + c] = U(c, j) = L(c, j) d_j for c >= j
+// (the pivots on the diagonal).
+template <int NP, int TS, int MS>
+__device__ __noinline__ void ch_factor(lds_double *tile, lds_double *sI, lds_double *M, int lane) {
+    asm volatile("" : "+v"(tile));
+    const bool ident = (lane >> 4) == 1;
+    const int row = min(lane & 15, NP - 1);           // lanes past the block repeat its last row (identical stores)
+    lds_double *p0 = (ident ? sI : tile) + row * TS;
+    double a0[NP], u[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) a0[j] = p0[j];
+    lds_double *wp = ident ? M + row * MS : tile + row;
+    const int ws = ident ? 1 : TS;
+    __builtin_amdgcn_sched_barrier(0);   // every row is in registers before the first publish overwrites the tile
+    wp[0] = a0[0];
+    double d = d_readlane(a0[0], 0);
+#pragma unroll
+    for (int c = 1; c < NP; ++c) u[c] = tile[c];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        __builtin_amdgcn_sched_barrier(0);
+        const double l0 = d_div(a0[j], d, d_fast_rcp(d));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+        if (j + 1 < NP) {
+            a0[j + 1] = fma(-l0, u[j + 1], a0[j + 1]);
+            wp += ws;
+            wp[0] = a0[j + 1];
+            d = d_readlane(a0[j + 1], j + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = j + 2; c < NP; ++c) {
+            a0[c] = fma(-l0, u[c], a0[c]);
+            if (((c - j - 2) & 3) == 3 || c + 1 == NP) {
+#pragma unroll
+                for (int e = c - ((c - j - 2) & 3); e <= c; ++e) u[e] = tile[(j + 1) * TS + e];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// out = init + sum_{j < 9} arr[j] v_j, v_j from lane j of the 16-lane row (DPP row_newbcast), two chains
+#define CH_DOT9(out, init, vin, arr) do { double x__ = (init), x2__ = 0.0; const double v__ = (vin); \
+            asm volatile("s_nop 1\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %3 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %5 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %7 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %1, %2, %10 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t" \
+                         "v_fmac_f64_dpp %0, %2, %11 row_newbcast:8 row_mask:0xf bank_mask:0xf" \
+                         : "+v"(x__), "+v"(x2__) \
+                         : "v"(v__), "v"(arr[0]), "v"(arr[1]), "v"(arr[2]), "v"(arr[3]), "v"(arr[4]), "v"(arr[5]), "v"(arr[6]), "v"(arr[7]), "v"(arr[8])); \
+            (out) = x__ + x2__; } while (0)
+
+// The whole factorisation and solve on the image in LDS (lambda already on the diagonal, pad diagonal of CC = 1).
+// On return sX = P + CH_OFF_X holds the solution by chain dimension.  All 1024 threads call; ends with a barrier.
+#ifdef VIO_STAMPS
+#define CH_STAMP(slot) do { if (dbg && (tid & 63) == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[slot] = __builtin_amdgcn_s_memtime() - t_start__; } } while (0)
+#else
+#define CH_STAMP(slot) do { } while (0)
+#endif
+__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsigned long long *dbg = nullptr) {
+#ifdef VIO_STAMPS
+    const unsigned long long t_start__ = __builtin_amdgcn_s_memtime();
+#endif
+    const int lane = tid & 63;
+    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    double *sD = P + CH_OFF_D, *sX = P + CH_OFF_X, *sY = P + CH_OFF_Y, *sMc = P + CH_OFF_MC;
+    const bool r9 = r16 < 9;
+
+    // ---- building blocks (one wave each) ----
+    // S-type operand images: A image = tile[row r16][k = g + 4q], q < 3, k < 9 (rows < nrows)
+    auto ld_a9 = [&](const double *t, int nrows, double v[3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const int k = g + 4 * q; const double x = t[r16 * CH_TS + k]; v[q] = (k < 9 && r16 < nrows) ? x : 0.0; }
+    };
+    // B image of M_e: M[k = g + 4q][n = r16]
+    auto ld_m9 = [&](const double *m, double v[3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const int k = g + 4 * q; const double x = m[min(k, 8) * CH_TS + r16]; v[q] = (k < 9 && r9) ? x : 0.0; }
+    };
+    // L = (A M_e) / d of a tile with `nrows` rows in column block e; result stored in place (C image)
+    auto sprod9 = [&](double *t, int nrows, int e) {
+        double av[3], bv[3];
+        ld_a9(t, nrows, av);
+        ld_m9(P + ch_sm(e), bv);
+        const double dd = P[ch_sd(e) + min(r16, 8) * (CH_TS + 1)];
+        ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+        const double rr = d_fast_rcp(dd);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int row = g + 4 * v;
+            if (r9 && row < nrows) t[row * CH_TS + r16] = d_div(acc[v], dd, rr);
+        }
+    };
+    // the chain wave's product: L_SO[e] = (SO[e] M_e) / d formed transposed — the accumulator is the operand image of the update that
+    // follows — and, with upd, SD[n] -= (L D) L^T from registers
+    auto chain_step = [&](int e, int n, bool upd) {
+        double *tt = P + ch_so(e);
+        double av[3], bv[3], pv[3], lv[3];
+        ld_a9(tt, 9, av);
+        ld_m9(P + ch_sm(e), bv);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pv[q] = P[ch_sd(e) + min(g + 4 * q, 8) * (CH_TS + 1)];
+        double *td = P + ch_sd(n);
+        ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { const int row = g + 4 * v; const double x = td[min(row, 8) * CH_TS + min(r16, 8)]; acc2[v] = (row < 9 && r9) ? x : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[q], av[q], acc, 0, 0, 0);     // (A M)^T: [k = g + 4v][row r16]
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int k = g + 4 * q;
+            lv[q] = (k < 9 && r9) ? d_div(acc[q], pv[q], d_fast_rcp(pv[q])) : 0.0;
+            if (k < 9 && r9) tt[r16 * CH_TS + k] = lv[q];
+        }
+        if (upd) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q], -lv[q], acc2, 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { const int row = g + 4 * v; if (row < 9 && r9) td[row * CH_TS + r16] = acc2[v]; }
+        }
+    };
+    // acc -= (L_a D_e) L_b^T, both operands S-type tiles of column block e (rows: na / nb)
+    auto upd9 = [&](ps_v4d &acc, const double *ta, int na, const double *tb, int nb, int e) {
+        double av[3], bv[3];
+        ld_a9(ta, na, av);
+        ld_a9(tb, nb, bv);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { const double dk = sD[e * 16 + min(g + 4 * q, 8)]; av[q] *= dk; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], -bv[q], acc, 0, 0, 0);
+    };
+    // U work of speed-bias level `lev` (its blocks eA = lev, eB = 10 - lev are factored, their L tiles and sD are final):
+    // tasks 0..14 CC(I,J) | 15..19 SC[nA][t] | 20..24 SC[nB][t] | 25 the right-hand side.  `first`: first task of this wave, `step`: stride.
+    auto s_level_update = [&](int lev, int first, int step, int skip_cc00) {
+        const int eA = lev, eB = 10 - lev;
+        const bool two = lev < 5;
+        for (int task = first; task < 26; task += step) {
+            if (task < 15) {
+                if (task == 0 && skip_cc00) continue;
+                int I = 0;
+                while ((I + 1) * (I + 2) / 2 <= task) ++I;
+                const int J = task - I * (I + 1) / 2;
+                double *tc = P + ch_cc(I, J) + g * PS_TROW + r16;
+                ps_v4d acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v] = tc[4 * PS_TROW * v];
+                upd9(acc, P + ch_sc(eA, I), 16, P + ch_sc(eA, J), 16, eA);
+                if (two) upd9(acc, P + ch_sc(eB, I), 16, P + ch_sc(eB, J), 16, eB);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) tc[4 * PS_TROW * v] = acc[v];
+            } else if (task < 25) {
+                if (lev >= 5) continue;
+                const bool chainB = task >= 20;
+                if (chainB && lev == 4) continue;                   // (both chains end in block 5: the first five tasks add both terms)
+                const int t = task - (chainB ? 20 : 15);
+                const int e = chainB ? eB : eA, n = chainB ? eB - 1 : eA + 1;
+                double *tc = P + ch_sc(n, t);
+                ps_v4d acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { const double x = tc[(g + 4 * v) * CH_TS + min(r16, 8)]; acc[v] = r9 ? x : 0.0; }
+                upd9(acc, P + ch_sc(e, t), 16, P + ch_so(e), 9, e);
+                if (lev == 4) upd9(acc, P + ch_sc(eB, t), 16, P + ch_so(eB), 9, eB);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) if (r9) tc[(g + 4 * v) * CH_TS + r16] = acc[v];
+            } else {
+                // y_C -= L_SC[e] w_e (both chains, A first), y_n -= L_SO[e] w_e
+                double wA[9], wB[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { wA[k] = sY[eA * 16 + k]; wB[k] = sY[eB * 16 + k]; }
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int i = pass * 64 + lane;
+                    if (i < 80) {
+                        const double *la = P + ch_sc(eA, i >> 4) + (i & 15) * CH_TS, *lb = P + ch_sc(eB, i >> 4) + (i & 15) * CH_TS;
+                        double y = sY[CH_YC + i];
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) y = fma(-la[k], wA[k], y);
+                        if (two) {
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) y = fma(-lb[k], wB[k], y);
+                        }
+                        sY[CH_YC + i] = y;
+                    } else if (two && i >= 96 && i < 96 + 9) {          // successor of chain A (at level 4: block 5, both terms)
+                        const int r = i - 96;
+                        double y = sY[(eA + 1) * 16 + r];
+                        const double *la = P + ch_so(eA) + r * CH_TS, *lb = P + ch_so(eB) + r * CH_TS;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) y = fma(-la[k], wA[k], y);
+                        if (lev == 4) {
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) y = fma(-lb[k], wB[k], y);
+                        }
+                        sY[(eA + 1) * 16 + r] = y;
+                    } else if (two && lev < 4 && i >= 112 && i < 112 + 9) {
+                        const int r = i - 112;
+                        double y = sY[(eB - 1) * 16 + r];
+                        const double *lb = P + ch_so(eB) + r * CH_TS;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) y = fma(-lb[k], wB[k], y);
+                        sY[(eB - 1) * 16 + r] = y;
+                    }
+                }
+            }
+        }
+    };
+
+    // ================= speed-bias chain: levels 0..5 =================
+    for (int lev = 0; lev < 6; ++lev) {
+        const int eA = lev, eB = 10 - lev;
+        if (uwave == 0) {
+            if (lev == 5) {     // chain B's last term of SD[5] (chain A's was applied from registers at level 4)
+                double *td = P + ch_sd(5);
+                ps_v4d acc;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { const int row = g + 4 * v; const double x = td[min(row, 8) * CH_TS + min(r16, 8)]; acc[v] = (row < 9 && r9) ? x : 0.0; }
+                upd9(acc, P + ch_so(6), 9, P + ch_so(6), 9, 6);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { const int row = g + 4 * v; if (row < 9 && r9) td[row * CH_TS + r16] = acc[v]; }
+            }
+            ch_factor<9, CH_TS, CH_TS>((lds_double *)(P + ch_sd(eA)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(eA)), lane);
+        } else if (uwave == 1) {
+            if (lev < 5) ch_factor<9, CH_TS, CH_TS>((lds_double *)(P + ch_sd(eB)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(eB)), lane);
+        } else if (lev > 0) {
+            s_level_update(lev - 1, uwave - 2, 14, 0);
+            if (uwave == 2) CH_STAMP(112 + lev - 1);
+        }
+        if (uwave == 0) CH_STAMP(64 + 4 * lev);
+        __syncthreads();                                                                 // B1: M_e and the pivots are out
+        if (uwave == 0) CH_STAMP(65 + 4 * lev);
+        if (uwave == 0) {
+            if (lev < 5) chain_step(eA, eA + 1, true);
+        } else if (uwave == 1) {
+            if (lev < 5) chain_step(eB, eB - 1, lev < 4);
+        } else {
+            const int wi = uwave - 2;
+            if (wi < 5) sprod9(P + ch_sc(eA, wi), 16, eA);
+            else if (wi < 10) { if (lev < 5) sprod9(P + ch_sc(eB, wi - 5), 16, eB); }
+            else if (wi == 10) {
+                if (lane < 9) sD[eA * 16 + lane] = P[ch_sd(eA) + lane * (CH_TS + 1)];
+                else if (lane >= 16 && lane < 25 && lev < 5) sD[eB * 16 + lane - 16] = P[ch_sd(eB) + (lane - 16) * (CH_TS + 1)];
+            } else if (wi == 11) {
+                // w_e = M_e^T y_e = L_ee^-1 y_e
+                const int e = (lane < 16) ? eA : eB, k = lane & 15;
+                double y = 0.0;
+                if (k < 9 && lane < 32) {
+                    const double *m = P + ch_sm(e);
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) y = fma(sY[e * 16 + j], (j <= k) ? m[j * CH_TS + k] : 0.0, y);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (k < 9 && (lane < 16 || (lane < 32 && lev < 5))) sY[e * 16 + k] = y;
+            }
+        }
+        if (uwave == 0) CH_STAMP(66 + 4 * lev);
+        if (uwave == 2) CH_STAMP(120 + lev);
+        __syncthreads();                                                                 // B2: L tiles of this level are out
+        if (uwave == 0) CH_STAMP(67 + 4 * lev);
+    }
+
+    // ================= camera block: 5 tiles (16, 16, 16, 16, 8) =================
+    const int lofs = r16 * PS_TROW + g;      // A image of a 16 x 17 tile: row r16, k = g + 4q
+    const int cofs = g * PS_TROW + r16;      // C / B image: row g + 4v, column r16
+    if (uwave == 0) {
+        // CC(0,0) -= (L D) L^T of block 5 first: it is what F(0) waits for
+        double *tc = P + ch_cc(0, 0) + cofs;
+        ps_v4d acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = tc[4 * PS_TROW * v];
+        upd9(acc, P + ch_sc(5, 0), 16, P + ch_sc(5, 0), 16, 5);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) tc[4 * PS_TROW * v] = acc[v];
+        ch_factor<16, PS_TROW, PS_TROW>((lds_double *)(P + ch_cc(0, 0)), (lds_double *)(P + CH_OFF_I16), (lds_double *)sMc, lane);
+    } else if (uwave >= 2) {
+        s_level_update(5, uwave - 2, 14, 1);
+        if (uwave == 2) CH_STAMP(117);
+    }
+    if (uwave == 0) CH_STAMP(88);
+    __syncthreads();
+    if (uwave == 0) CH_STAMP(89);
+    for (int K = 0; K < 5; ++K) {
+        const int nk = 4 - K;                                   // tiles below the diagonal
+        const int d0 = CH_YC + 16 * K;
+        // ---- S phase ----
+        if (uwave == 0 && nk > 0) {
+            double *tt = P + ch_cc(K + 1, K);
+            double *td = P + ch_cc(K + 1, K + 1) + cofs;
+            const double *pd = P + ch_cc(K, K) + g * (PS_TROW + 1);
+            double av[4], bv[4], pv[4], lv[4];
+            ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = tt[lofs + 4 * q]; bv[q] = sMc[cofs + 4 * PS_TROW * q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pv[q] = pd[4 * q * (PS_TROW + 1)]; acc2[q] = td[4 * PS_TROW * q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[q], av[q], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { lv[q] = d_div(acc[q], pv[q], d_fast_rcp(pv[q])); tt[lofs + 4 * q] = lv[q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q], -lv[q], acc2, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) td[4 * PS_TROW * q] = acc2[q];
+        } else if (uwave >= 1 && uwave < nk) {
+            double *tt = P + ch_cc(K + 1 + uwave, K);
+            double av[4], bv[4];
+            ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = tt[lofs + 4 * q]; bv[q] = sMc[cofs + 4 * PS_TROW * q]; }
+            const double dd = P[ch_cc(K, K) + r16 * (PS_TROW + 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+            const double rr = d_fast_rcp(dd);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tt[cofs + 4 * PS_TROW * q] = d_div(acc[q], dd, rr);
+        } else if (uwave == 14) {
+            // the pivots by dimension; then M_K takes the factored tile's place (not its diagonal: M_K's is 1, and the pivots stay readable)
+            double dd = 0.0, mk[4];
+            if (lane < 16) dd = P[ch_cc(K, K) + lane * (PS_TROW + 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mk[q] = sMc[(g + 4 * q) * PS_TROW + r16];
+            __builtin_amdgcn_sched_barrier(0);
+            if (lane < 16) sD[d0 + lane] = dd;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (g + 4 * q != r16) P[ch_cc(K, K) + (g + 4 * q) * PS_TROW + r16] = mk[q];
+        } else if (uwave == 15) {
+            double y = 0.0;
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) y = fma(sY[d0 + j], sMc[j * PS_TROW + lane], y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) sY[d0 + lane] = y;
+        }
+        if (uwave == 0) CH_STAMP(90 + 4 * K);
+        __syncthreads();
+        if (uwave == 0) CH_STAMP(91 + 4 * K);
+        if (nk == 0) break;
+        // ---- U (+ F(K+1) on wave 0): tiles 1 .. ntile-1 of the trailing triangle in row-major order (tile 0 = (K+1,K+1) is wave 0's),
+        //      then the right-hand side ----
+        if (uwave == 0) {
+            if (K + 1 == 4) {
+                // the last tile has 8 variables: M starts as the identity, rows / columns 8..15 stay that way
+                for (int i = lane; i < PS_TS; i += 64) sMc[i] = (i / PS_TROW == i % PS_TROW) ? 1.0 : 0.0;
+                ch_factor<8, PS_TROW, PS_TROW>((lds_double *)(P + ch_cc(4, 4)), (lds_double *)(P + CH_OFF_I16), (lds_double *)sMc, lane);
+            } else {
+                ch_factor<16, PS_TROW, PS_TROW>((lds_double *)(P + ch_cc(K + 1, K + 1)), (lds_double *)(P + CH_OFF_I16), (lds_double *)sMc, lane);
+            }
+        } else {
+            const int ntile = nk * (nk + 1) / 2;
+            const int nitem = ntile + 1;
+            double dk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dk[q] = sD[d0 + g + 4 * q];
+            for (int t = uwave; t < nitem; t += 15) {
+                if (t < ntile) {
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                    const int jj = t - ii * (ii + 1) / 2;
+                    const double *ta = P + ch_cc(K + 1 + ii, K) + lofs, *tb = P + ch_cc(K + 1 + jj, K) + lofs;
+                    double *tc = P + ch_cc(K + 1 + ii, K + 1 + jj) + cofs;
+                    double av[4], bv[4];
+                    ps_v4d acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { av[q] = ta[4 * q]; bv[q] = tb[4 * q]; acc[q] = tc[4 * PS_TROW * q]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q] * dk[q], -bv[q], acc, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tc[4 * PS_TROW * q] = acc[q];
+                } else {
+                    // y_I -= L_IK w_K for the rows below
+                    const int c = 16 * (K + 1) + lane;
+                    if (c < 80) {
+                        const double *l = P + ch_cc(c >> 4, K) + (c & 15) * PS_TROW;
+                        double y = sY[CH_YC + c];
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) y = fma(-l[kk], sY[d0 + kk], y);
+                        sY[CH_YC + c] = y;
+                    }
+                }
+            }
+            if (uwave == 2) CH_STAMP(128 + K);
+        }
+        if (uwave == 0) CH_STAMP(92 + 4 * K);
+        __syncthreads();
+        if (uwave == 0) CH_STAMP(93 + 4 * K);
+    }
+    if (uwave == 0) CH_STAMP(110);
+
+    // ================= back-substitution =================
+    // x_col = M_col (w_col / d_col - sum_{J after col} L_{J,col}^T x_J).  16 block columns, one wave each: wave e < 11 owns speed-bias
+    // block e, wave 11 + K camera tile K; lanes 0..15 work (lane = column of the block).  Camera tiles first, from the bottom, one barrier
+    // per tile; every owner adds the tile's term to its running sum as soon as x_J is out.
+    {
+        const bool isC = uwave >= 11;
+        const int K = uwave - 11, e = uwave;
+        const bool work = lane < 16;
+        const int k9 = min(r16, 8);
+        double acc = 0.0, mw[16], ucol[16], own_v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { mw[j] = 0.0; ucol[j] = 0.0; }
+#define CH_LOAD_COL_C(I_, K_) do { const double *src__ = P + ch_cc((I_), (K_)) + r16; _Pragma("unroll") for (int r = 0; r < 16; ++r) ucol[r] = src__[r * PS_TROW]; } while (0)
+#define CH_LOAD_COL_S(e_, t_) do { const double *src__ = P + ch_sc((e_), (t_)) + k9; _Pragma("unroll") for (int r = 0; r < 16; ++r) ucol[r] = src__[r * CH_TS]; } while (0)
+        if (work) {
+            if (isC) {
+                const double *src = P + ch_cc(K, K) + r16 * PS_TROW;                 // row r16 of M_K (the tile's diagonal still holds the pivots)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mw[j] = (j == r16) ? 1.0 : src[j];
+                const double dd = sD[CH_YC + 16 * K + r16];
+                own_v = d_div(sY[CH_YC + 16 * K + r16], dd, d_fast_rcp(dd));
+                if (K == 4) { double x; PS_DOT16(x, 0.0, own_v, mw); sX[CH_YC + 64 + r16] = x; }
+                else CH_LOAD_COL_C(4, K);
+            } else {
+                const double *src = P + ch_sm(e) + k9 * CH_TS;                        // row k of M_e (upper triangular, unit diagonal)
+#pragma unroll
+                for (int j = 0; j < 9; ++j) mw[j] = (j < k9) ? 0.0 : src[j];
+                const double dd = sD[e * 16 + k9];
+                own_v = d_div(sY[e * 16 + k9], dd, d_fast_rcp(dd));
+                CH_LOAD_COL_S(e, 4);
+            }
+        }
+        __syncthreads();                                                             // x of tile 4 is out
+        for (int J = 4; J >= 0; --J) {
+            if (work) {
+                if (isC) {
+                    if (K < J) {
+                        PS_DOT16(acc, acc, sX[CH_YC + 16 * J + r16], ucol);
+                        if (J > K + 1) CH_LOAD_COL_C(J - 1, K);
+                        else { double x; PS_DOT16(x, 0.0, own_v - acc, mw); sX[CH_YC + 16 * K + r16] = x; }
+                    }
+                } else {
+                    PS_DOT16(acc, acc, sX[CH_YC + 16 * J + r16], ucol);
+                    if (J > 0) CH_LOAD_COL_S(e, J - 1);
+                    else if (e == 5) { double x; CH_DOT9(x, 0.0, own_v - acc, mw); if (r9) sX[5 * 16 + r16] = x; }     // the middle block: x_5 = M_5 v_5
+                    else if (r9) sX[e * 16 + r16] = own_v - acc;                    // v_e: what the chains below start from
+                }
+            }
+            __syncthreads();
+        }
+#undef CH_LOAD_COL_C
+#undef CH_LOAD_COL_S
+        if (uwave == 0) CH_STAMP(111);
+        // the two chains, one wave each, no barriers: x_e = M_e (v_e - L_SO[e]^T x_succ(e)), e = 4..0 on wave 0, 6..10 on wave 1
+        if (uwave < 2 && work) {
+            double m9[9], l9[9];
+            double xs = sX[5 * 16 + k9];
+            for (int s = 1; s <= 5; ++s) {
+                const int eb = (uwave == 0) ? 5 - s : 5 + s;
+                const double *src = P + ch_sm(eb) + k9 * CH_TS, *lso = P + ch_so(eb) + k9;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { m9[j] = (j < k9) ? 0.0 : src[j]; l9[j] = lso[j * CH_TS]; }        // row k of M, column k of L_SO[eb]
+                const double vv = sX[eb * 16 + k9];
+                double t, xn;
+                CH_DOT9(t, 0.0, xs, l9);
+                CH_DOT9(xn, 0.0, vv - t, m9);
+                if (r9) sX[eb * 16 + r16] = xn;
+                xs = xn;
+            }
+        }
+        if (uwave == 0) CH_STAMP(112 - 112 + 63);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_assemble_c: H_pp_schur_ (reduced visual system + IMU blocks + prior, problem.cc:365-384) written straight into the chain
+// image: every entry's place is a function of its indices (ch_entry_pos), no rank sort, no permutation.  Workgroup b < 171 owns
+// natural row b (entries (b, t), t <= b); workgroup 171 the right-hand sides and, in the GN / LM loops, the step test's sums.
+// ---------------------------------------------------------------------------------------------------------
+#define ASMC_THREADS 192
+#define ASMC_BLOCKS (VIO_PD + 1)
+__device__ __forceinline__ void d_assemble_chain_body(const DeviceTables &T) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (d_gated_off(T.lm, T.lm_gate)) return;
+    const int cur = d_cur(T);
+    const int valid = d_imu_mask(T);
+    const int wset = d_set_w(T);
+    double *Pg = T.Pg + wset * CH_SET_STRIDE;
+    if (b < VIO_PD) {
+        if (t < VIO_PD && (t <= b || T.natural_hs)) {
+            double wv, wr;
+            d_hs_entry(T, valid, max(b, t), min(b, t), wv, wr);
+            const double v = wv + wr;
+            if (T.natural_hs) T.Hs[b * VIO_PD + t] = v;
+            if (t <= b) {
+                int p1, p2;
+                ch_entry_pos(b, t, p1, p2);
+                if (p1 >= 0) Pg[p1] = v;
+                if (p2 >= 0) Pg[p2] = v;
+            }
+        }
+        return;
+    }
+    // the last workgroup: right-hand sides + the step test of the PREVIOUS iteration (see d_assemble_body)
+    __shared__ double sSum[8];
+    const bool test_prev = d_step_owed(T, 1);
+    const int rset = d_set_r(T);
+    double p_dx = 0.0, p_bf = 0.0, p_er = 0.0, p_lambda = 0.0, p_chi = 0.0, p_step = 0.0, p_lmchi = 0.0, p_imu[10];
+    if (test_prev) {
+        p_lambda = T.lm->lambda;
+        if (t < VIO_PD) { p_dx = T.dx[t]; p_bf = T.bfull[rset * 176 + t]; }
+        if (T.has_prior && t < VIO_PRD) p_er = T.errprior[cur * 160 + t];
+        if (t == 0) {
+            p_chi = d_vis(T, VIS_CHI); p_step = d_vis(T, VIS_STEP + 1); p_lmchi = T.lm->chi;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) p_imu[k] = ((valid >> k) & 1) ? T.imu_out[k * IMU_OUT + IMU_CHI] : 0.0;
+        }
+    }
+    if (t < VIO_PD) Pg[CH_OFF_Y + ch_dim(t)] = d_rhs_entries(T, valid, t, cur, wset);
+    if (test_prev) {
+        double sp = 0.0, e2 = 0.0;
+        if (t < VIO_PD) sp = p_dx * (p_lambda * p_dx + p_bf);
+        if (T.has_prior && t < VIO_PRD) e2 = p_er * p_er;
+        d_block_sum2<ASMC_THREADS>(sp, e2, sSum, t);
+        if (t == 0) {
+            LmState *lm = T.lm;
+            double chi_imu = 0.0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) if ((valid >> k) & 1) chi_imu += p_imu[k];
+            double total = p_chi + chi_imu;
+            if (T.has_prior) total += sqrt(e2);             // err_prior_.norm(), not squared (problem.cc:554-556)
+            const double tempChi = 0.5 * total;
+            const double scale = 0.5 * (p_step + sp) + 1e-6;
+            lm->chi_try = tempChi;
+            lm->scale = scale;
+            if (T.cur_hint != -2) {
+                lm->rho = (p_lmchi - tempChi) / scale;
+                lm->trials += 1;
+                lm->chi = tempChi;
+                lm->cur = cur;
+                lm->accepted = 1;
+                lm->naccepted += 1;
+                lm->need_linearize = 1;
+                lm->false_cnt = 0;
+                if (!isfinite(tempChi)) lm->finite = 0;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(ASMC_THREADS) void k_assemble_c(DeviceTables T) { d_assemble_chain_body(T); }
+__global__ __launch_bounds__(ASMC_THREADS) void k_assemble_cb(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_assemble_chain_body(T); }
+
+// ---------------------------------------------------------------------------------------------------------
+// k_pose_solve_c: k_pose_solve's frame (the verdict of vio_solve's loop, the two sets, the trial states, the pair table, the
+// stepwise prior update) around ch_factor_solve.
+// ---------------------------------------------------------------------------------------------------------
+#define CH_OFF_DX CH_LDS_CORE                       // 176 solution in natural order
+#define CH_OFF_R (CH_OFF_DX + 176)                  // 112 rotations
+#define CH_OFF_B (CH_OFF_R + 112)                   // 176 trial b_prior
+#define CH_OFF_STATE (CH_OFF_B + 176)               // 184
+#define CH_LDS_DOUBLES (CH_OFF_STATE + 184)         // 17448
+__device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
+    double *P = dyn_smem;
+    double *sX = P + CH_OFF_X, *sDx = P + CH_OFF_DX, *sR = P + CH_OFF_R, *sB = P + CH_OFF_B, *sState = P + CH_OFF_STATE;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LmState *lm = T.lm;
+    __shared__ LmRegs sLm;
+    if (d_gated_off(lm, T.lm_gate)) return;
+    const bool lm_loop = T.cur_hint == -2;
+    int cur = lm_loop ? 0 : d_cur(T);
+    double lambda = lm_loop ? 0.0 : lm->lambda;
+    const int n = PS_N;
+#ifdef VIO_STAMPS
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#define CH_OUT(slot) do { if (tid == 0 && T.dbg) T.dbg[slot] = __builtin_amdgcn_s_memtime() - t_start; } while (0)
+#else
+#define CH_OUT(slot) do { } while (0)
+#endif
+    // the image k_assemble_c wrote (vio_solve's loop: the set of the trial state first; a rejected step solves the other set again)
+    int set = lm_loop ? (lm->sys ^ lm->pending) : 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double2 *src = reinterpret_cast<const double2 *>(T.Pg + set * CH_SET_STRIDE);
+        double2 *dst = reinterpret_cast<double2 *>(P);
+        static_assert((CH_PACKED / 2 + PS_THREADS - 1) / PS_THREADS == 8, "copy below is written for 8 rounds");
+#define CH_LD(q) const double2 v##q = src[min(tid + q * PS_THREADS, CH_PACKED / 2 - 1)];
+#define CH_ST(q) dst[min(tid + q * PS_THREADS, CH_PACKED / 2 - 1)] = v##q;
+        CH_LD(0) CH_LD(1) CH_LD(2) CH_LD(3) CH_LD(4) CH_LD(5) CH_LD(6) CH_LD(7)
+        if (pass == 0) {
+            double stv = (tid < STATE_STRIDE) ? T.state[cur * STATE_STRIDE + tid] : 0.0;
+            const double stv1 = (lm_loop && tid < STATE_STRIDE) ? T.state[STATE_STRIDE + tid] : 0.0;
+            if (lm_loop && tid == 0) {
+                int go = 1, rej = 0, sys = lm->sys;
+                d_lm_load(lm, sLm);
+                if (lm->pending) {
+                    d_lm_verdict(sLm, lm, 0, lm->chi_try, lm->scale, sLm.cur);
+                    if (sLm.accepted) sys ^= 1; else rej = 1;
+                    go = !sLm.stop;
+                }
+                sX[0] = go ? 1.0 : 0.0; sX[1] = (double)sLm.cur; sX[2] = sLm.lambda; sX[3] = (double)sys; sX[4] = (double)rej;
+            }
+            CH_ST(0) CH_ST(1) CH_ST(2) CH_ST(3) CH_ST(4) CH_ST(5) CH_ST(6) CH_ST(7)
+            __syncthreads();
+            int set_now = 0;
+            if (lm_loop) {
+                if (tid == 0) { d_lm_store(lm, sLm); lm->sys = (int)sX[3]; lm->pending = sX[0] != 0.0 ? 1 : 0; }
+                if (sX[0] == 0.0) return;
+                cur = (int)sX[1]; lambda = sX[2]; set_now = (int)sX[3];
+                if (cur) stv = stv1;
+            }
+            if (tid < STATE_STRIDE) sState[tid] = stv;
+            if (set_now == set) break;
+            set = set_now;
+            __syncthreads();
+        } else {
+            CH_ST(0) CH_ST(1) CH_ST(2) CH_ST(3) CH_ST(4) CH_ST(5) CH_ST(6) CH_ST(7)
+            __syncthreads();
+        }
+#undef CH_LD
+#undef CH_ST
+    }
+    const int trial = cur ^ 1;
+    // lambda on the 171 pivots (problem.cc:434-436); the 8 padding variables of the last camera tile are identity rows
+    if (tid < n) {
+        const int d = ch_dim(tid);
+        if (d >= CH_YC) P[ch_cc_elem(d - CH_YC, d - CH_YC)] += lambda;
+        else P[ch_sd(d >> 4) + (d & 15) * (CH_TS + 1)] += lambda;
+    } else if (tid < n + 8) {
+        P[ch_cc_elem(72 + tid - n, 72 + tid - n)] = 1.0;
+    } else if (tid >= 256 && tid < 256 + CH_S9SZ + PS_TS) {
+        const int i = tid - 256;
+        P[CH_OFF_I9 + i] = (i < CH_S9SZ) ? ((i / CH_TS == i % CH_TS) ? 1.0 : 0.0) : (((i - CH_S9SZ) / PS_TROW == (i - CH_S9SZ) % PS_TROW) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    CH_OUT(0);
+    ch_factor_solve(P, tid, T.dbg);
+    CH_OUT(2);
+    for (int i = tid; i < n; i += PS_THREADS) sDx[i] = sX[ch_dim(i)];
+    __syncthreads();
+
+    // what follows is k_pose_solve's tail (see there)
+    const bool prior_here = T.has_prior && !(T.gn_flags & 4);
+    if (uwave < 2) {
+        if (tid < 12) {
+            double *p = (tid == 0) ? sState + STATE_EXT : sState + STATE_POSE + 7 * (tid - 1);
+            const double *d = (tid == 0) ? sDx : sDx + 6 + 15 * (tid - 1);
+            double tmp[7];
+            d_pose_plus(p, d, tmp);
+            for (int k = 0; k < 7; ++k) p[k] = tmp[k];
+        } else if (tid >= 16 && tid < 16 + 99) {
+            const int e = tid - 16, f = e / 9, k = e % 9;
+            sState[STATE_SB + e] = sState[STATE_SB + e] + sDx[12 + 15 * f + k];
+        }
+        __syncthreads();
+        if (T.lm_dim != 3) d_pair_rotations(sState, sR, tid);
+        __syncthreads();
+    } else {
+        if (prior_here) {
+            double hp[PS_PRIOR_ROWS][3], bp[PS_PRIOR_ROWS];
+#pragma unroll
+            for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
+                const int i = (uwave - 2) + 14 * r;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int j = lane + 64 * q;
+                    hp[r][q] = (i < n && j < n) ? T.Hprior[i * n + j] : 0.0;
+                }
+                bp[r] = (i < n) ? T.bprior[cur * 176 + i] : 0.0;
+            }
+            const double x0 = sDx[lane], x1 = sDx[lane + 64], x2 = (lane + 128 < n) ? sDx[lane + 128] : 0.0;
+#pragma unroll
+            for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
+                const int i = (uwave - 2) + 14 * r;
+                const double v = d_bprior_dot(hp[r][0], hp[r][1], hp[r][2], x0, x1, x2, bp[r]);
+                if (lane == 63 && i < n) { sB[i] = v; T.bprior[trial * 176 + i] = v; }
+            }
+        }
+        __syncthreads();
+        double jp[PS_JT_ROWS][3];
+        if (prior_here) {
+#pragma unroll
+            for (int r = 0; r < PS_JT_ROWS; ++r) {
+                const int i = (uwave - 2) + 14 * r;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int j = lane + 64 * q;
+                    jp[r][q] = (i < VIO_PRD && j < VIO_PRD) ? T.Jtinv[i * VIO_PRD + j] : 0.0;
+                }
+            }
+        }
+        __syncthreads();
+        if (prior_here) {
+            const double y0 = sB[lane], y1 = sB[lane + 64], y2 = (lane + 128 < VIO_PRD) ? sB[lane + 128] : 0.0;
+#pragma unroll
+            for (int r = 0; r < PS_JT_ROWS; ++r) {
+                const int i = (uwave - 2) + 14 * r;
+                const double s = d_errprior_dot(jp[r][0], jp[r][1], jp[r][2], y0, y1, y2);
+                if (lane == 63 && i < VIO_PRD) T.errprior[trial * 160 + i] = s;
+            }
+        }
+    }
+    if (T.lm_dim != 3) d_pair_rows(sState, T.pairtab + trial * PAIRTAB_STRIDE, sR, tid, PS_THREADS);
+    if (tid >= 192 && tid < 192 + n) T.dx[tid - 192] = sDx[tid - 192];
+    if (tid >= 384 && tid < 384 + STATE_STRIDE) T.state[trial * STATE_STRIDE + (tid - 384)] = sState[tid - 384];
+    CH_OUT(3);
+}
+__global__ __launch_bounds__(PS_THREADS) void k_pose_solve_c(DeviceTables T) { d_pose_solve_chain_body(T); }
+__global__ __launch_bounds__(PS_THREADS) void k_pose_solve_cb(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_pose_solve_chain_body(T); }
+
+// Diagnostic / test entry: solve one image (CH_PACKED doubles, lambda NOT yet on its diagonal) and return x by natural index;
+// lds_dump (optional): the first CH_LDS_CORE doubles of LDS after the solve (L tiles, M, pivots, x) for tools/chain_solve_model.py
+__global__ __launch_bounds__(PS_THREADS) void k_chain_solve_test(const double *img, double lambda, double *x_nat, double *lds_dump) {
+    double *P = dyn_smem;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < CH_PACKED; i += PS_THREADS) P[i] = img[i];
+    for (int i = CH_PACKED + tid; i < CH_LDS_CORE; i += PS_THREADS) P[i] = 0.0;
+    __syncthreads();
+    if (tid < PS_N) {
+        const int d = ch_dim(tid);
+        if (d >= CH_YC) P[ch_cc_elem(d - CH_YC, d - CH_YC)] += lambda;
+        else P[ch_sd(d >> 4) + (d & 15) * (CH_TS + 1)] += lambda;
+    } else if (tid < PS_N + 8) {
+        P[ch_cc_elem(72 + tid - PS_N, 72 + tid - PS_N)] = 1.0;
+    } else if (tid >= 256 && tid < 256 + CH_S9SZ + PS_TS) {
+        const int i = tid - 256;
+        P[CH_OFF_I9 + i] = (i < CH_S9SZ) ? ((i / CH_TS == i % CH_TS) ? 1.0 : 0.0) : (((i - CH_S9SZ) / PS_TROW == (i - CH_S9SZ) % PS_TROW) ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    ch_factor_solve(P, tid);
+    if (tid < PS_N) x_nat[tid] = P[CH_OFF_X + ch_dim(tid)];
+    if (lds_dump) for (int i = tid; i < CH_LDS_CORE; i += PS_THREADS) lds_dump[i] = P[i];
+}
+#endif  // __HIPCC__
+#endif

@@ -183,7 +183,7 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     const double *gath;          // [n_shards][VIS_SEND]
     const double *step_gath;     // [n_shards][2]
     int32_t n_shards;
-    int32_t pad1_;
+    int32_t solve_order;         // 0: Eigen's pivot order (k_assemble / k_pose_solve); 1: the static chain order (k_assemble_c / k_pose_solve_c, vio_pose_solve_chain.h)
     LmState *lm;
     unsigned long long *dbg;     // diagnostic builds only (-DVIO_STAMPS): [block][16] s_memtime stamps
 };
