@@ -28,7 +28,7 @@ OFF_SM = PACKED
 OFF_MC = OFF_SM + NS * S9SZ
 OFF_D = OFF_MC + 272
 OFF_X = OFF_D + 256
-LDS_CORE = OFF_X + 256 + 90 + 272
+LDS_CORE = OFF_X + 256 + 90 + 272 + 11 * 64
 
 
 def sc(e, t):
@@ -184,7 +184,8 @@ class ChainModel:
                 tile = dump[sc(e, t):sc(e, t) + SCSZ].reshape(16, TS)[:, :9]
                 w.append(rel(tile, self.SC[e, 16 * t:16 * t + 16]))
         out["L_SC"] = max(w)
-        out["L_SO"] = max(rel(dump[so(e):so(e) + S9SZ].reshape(9, TS)[:, :9], self.SO[e]) for e in range(NS) if e != 5)
+        # (the kernel's back-substitution leaves G_e = M_e L_SO[e]^T in the place of L_SO[e]: x_e = M_e v_e - G_e x_succ(e))
+        out["G_SO"] = max(rel(dump[so(e):so(e) + S9SZ].reshape(9, TS)[:, :9], self.M[e] @ self.SO[e].T) for e in range(NS) if e != 5)
         out["M_S"] = max(rel(dump[sm(e):sm(e) + S9SZ].reshape(9, TS)[:, :9], self.M[e]) for e in range(NS))
         out["D_S"] = max(rel(dump[OFF_D + 16 * e:OFF_D + 16 * e + 9], self.D[e]) for e in range(NS))
         out["D_C"] = rel(dump[OFF_D + YC:OFF_D + YC + 80], self.Dc)

@@ -30,13 +30,14 @@ assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(16)) == 0
 s = buf.astype(np.int64).ravel()
 print("copy-in + lambda done %d | factor + solve done %d | end %d" % (s[0], s[2], s[3]))
 base = s[0]
-print("speed-bias chain (ticks relative to the start of ch_factor_solve; wave 0):")
+print("speed-bias chain (ticks relative to the start of ch_factor_solve): wave 0 = F + chain step of the level, then the barrier; wave 2 = a worker's phase")
 prev = 0
 for lev in range(6):
-    a = s[64 + 4 * lev:68 + 4 * lev]
-    print("  level %d: F done %6d (+%5d) | past B1 %6d (+%4d) | S done %6d (+%5d) | past B2 %6d (+%4d)   worker: U of this level done at %6d, its S at %6d"
-          % (lev, a[0], a[0] - prev, a[1], a[1] - a[0], a[2], a[2] - a[1], a[3], a[3] - a[2], s[112 + lev] if lev < 5 else s[117], s[120 + lev]))
-    prev = a[3]
+    a = s[64 + 4 * lev:66 + 4 * lev]
+    print("  level %d: wave 0 done %6d (+%5d) | past the barrier %6d (+%5d)      worker: phase %d done at %6d" % (lev, a[0], a[0] - prev, a[1], a[1] - a[0], lev, s[112 + lev]))
+    prev = a[1]
+print("  phase 5 + barrier: %6d (+%5d)" % (s[87], s[87] - prev))
+prev = s[87]
 print("camera block:")
 print("  CC(0,0) update + F(0) done %6d (+%5d) | past barrier %6d" % (s[88], s[88] - prev, s[89]))
 prev = s[89]

@@ -1,0 +1,547 @@
+// vio_chain_core.h — ch_factor_solve: the factorisation and solve of the chain-order pose system on its LDS image
+// (included by vio_pose_solve_chain.h, which documents the layout).
+//
+// Schedule (16 waves; "level" l = 0..5 of the speed-bias chain, blocks eA = l on wave 0 and eB = 10 - l on wave 1):
+//   waves 0, 1   F(e) -> pivots -> L_SO[e] = (SO[e] M_e) / d formed transposed, SD[succ] -= (L D) L^T from registers -> barrier l.
+//                They never wait for anybody: what they read (SD, SO) nobody else writes.
+//   waves 2..15  after barrier l ("phase l"): one fused task per (chain, camera tile t): L_SC[e][t] = (SC[e][t] M_e) / d, again
+//                transposed, and the fill SC[succ][t] -= (L D) L_SO[e]^T from registers — no cross-wave dependency inside a phase;
+//                the camera-block updates CC(I,J) -= (L_SC[e][I] D) L_SC[e][J]^T of the PREVIOUS level (they need two waves' tiles:
+//                one barrier later) fill the rest of the phase; wave 15 carries the right-hand side.
+//   then the camera block (5 tiles, F on wave 0 with look-ahead, two barriers per tile) and the back-substitution.
+// Operand images of a 9-column tile (row stride 10): the k index of the matrix core runs 0..11 in three steps; the third step's
+// lanes with k > 8 read the tile's padding column (column 9, zero in the image and never written), so no load is predicated.
+#ifndef VIO_CHAIN_CORE_H
+#define VIO_CHAIN_CORE_H
+
+#ifdef VIO_STAMPS
+#define CH_STAMP(slot) do { if (dbg && (tid & 63) == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[slot] = __builtin_amdgcn_s_memtime() - t_start__; } } while (0)
+#else
+#define CH_STAMP(slot) do { } while (0)
+#endif
+
+struct ChLane {         // per-lane offsets (doubles) inside a tile
+    int oA0, oA2;       // A image of a 9-column tile: [row r16][k = g], + 4 for the second step, [row r16][8 or the padding column]
+    int oM0, oM2;       // B image of M_e / C image of a 9-column tile: [k = g][r16], + 40 per step; third step [8][r16] or M's padding
+    int r16, g;
+    bool r9;
+};
+
+// the chain wave's work of one level: F(e), pivots, L_SO[e] = (SO[e] M_e) / d formed transposed — the accumulator is the operand
+// image of the update that follows — and (upd) SD[n] -= (L D) L^T from registers.  e == 5: F only.
+__device__ __forceinline__ void ch_chain_level(double *P, const ChLane &L, int e, int n, bool upd, int lane) {
+    double *sD = P + CH_OFF_D;
+    ch_factor<9, CH_TS, CH_TS>((lds_double *)(P + ch_sd(e)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(e)), lane);
+    if (lane < 9) sD[e * 16 + lane] = P[ch_sd(e) + lane * (CH_TS + 1)];
+    if (e == 5) return;
+    double *tt = P + ch_so(e);
+    const double *mm = P + ch_sm(e);
+    double *td = P + ch_sd(n);
+    const double a0 = tt[L.oA0], a1 = tt[L.oA0 + 4], a2 = tt[L.oA2];
+    const double b0 = mm[L.oM0], b1 = mm[L.oM0 + 40], b2 = mm[L.oM2];
+    const double p0 = sD[e * 16 + L.g], p1 = sD[e * 16 + L.g + 4], p2 = sD[e * 16 + L.g + 8];
+    ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {td[L.oM0], td[L.oM0 + 40], td[L.oM0 + 80], 0.0};
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc, 0, 0, 0);       // (A M)^T: [k = g + 4v][row r16]
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b2, a2, acc, 0, 0, 0);
+    const double q0 = d_fast_rcp(p0), q1 = d_fast_rcp(p1), q2 = d_fast_rcp(p2);
+    const double l0 = d_div(acc[0], p0, q0), l1 = d_div(acc[1], p1, q1);
+    const double l2 = (L.g == 0) ? d_div(acc[2], p2, q2) : 0.0, u2 = (L.g == 0) ? acc[2] : 0.0;
+    if (L.r9) { tt[L.oA0] = l0; tt[L.oA0 + 4] = l1; tt[L.oA2] = l2; }
+    if (upd) {
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[0], -l0, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[1], -l1, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u2, -l2, acc2, 0, 0, 0);
+        if (L.r9) { td[L.oM0] = acc2[0]; td[L.oM0 + 40] = acc2[1]; if (L.g == 0) td[L.oM0 + 80] = acc2[2]; }
+    }
+}
+// F on a camera tile (np = 16, or 8 for the last one): M to sM, the pivots to sDp[0 .. np)
+__device__ __forceinline__ void ch_factor_tile(double *tile, double *sM, double *sDp, int np, int lane) {
+    if (np == 16) ch_factor<16, PS_TROW, PS_TROW>((lds_double *)tile, (lds_double *)(dyn_smem + CH_OFF_I16), (lds_double *)sM, lane);
+    else ch_factor<8, PS_TROW, PS_TROW>((lds_double *)tile, (lds_double *)(dyn_smem + CH_OFF_I16), (lds_double *)sM, lane);
+    if (lane < np) sDp[lane] = tile[lane * (PS_TROW + 1)];
+}
+
+// a worker's fused task: L_SC[E][t] = (SC[E][t] M_E) / d (transposed product), stored; with FILL, acc2 (the C image of SC[N][t],
+// loaded by the caller) -= (L D) L_SO[E]^T
+template <int E, bool FILL>
+__device__ __forceinline__ void ch_fused(double *P, const ChLane &L, int t, ps_v4d &acc2) {
+    const double *sD = P + CH_OFF_D;
+    double *tt = P + ch_sc(E, 0) + t * CH_SCSZ;
+    const double *mm = P + ch_sm(E);
+    const double a0 = tt[L.oA0], a1 = tt[L.oA0 + 4], a2 = tt[L.oA2];
+    const double b0 = mm[L.oM0], b1 = mm[L.oM0 + 40], b2 = mm[L.oM2];
+    const double p0 = sD[E * 16 + L.g], p1 = sD[E * 16 + L.g + 4], p2 = sD[E * 16 + L.g + 8];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    if (FILL) { const double *so = P + ch_so(E); s0 = so[L.oA0]; s1 = so[L.oA0 + 4]; s2 = so[L.oA2]; }
+    __builtin_amdgcn_sched_barrier(0);
+    ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b2, a2, acc, 0, 0, 0);
+    const double q0 = d_fast_rcp(p0), q1 = d_fast_rcp(p1), q2 = d_fast_rcp(p2);
+    const double l0 = d_div(acc[0], p0, q0), l1 = d_div(acc[1], p1, q1);
+    const double l2 = (L.g == 0) ? d_div(acc[2], p2, q2) : 0.0, u2 = (L.g == 0) ? acc[2] : 0.0;
+    tt[L.oA0] = l0; tt[L.oA0 + 4] = l1; tt[L.oA2] = l2;
+    if (FILL) {
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[0], -s0, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[1], -s1, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u2, -s2, acc2, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void ch_ld_c9(const double *tc, const ChLane &L, ps_v4d &acc) {        // C image of a 16 x 9 tile
+    acc[0] = tc[L.oM0]; acc[1] = tc[L.oM0 + 40]; acc[2] = tc[L.oM0 + 80]; acc[3] = tc[L.oM0 + 120];
+}
+__device__ __forceinline__ void ch_st_c9(double *tc, const ChLane &L, const ps_v4d &acc) {
+    if (L.r9) { tc[L.oM0] = acc[0]; tc[L.oM0 + 40] = acc[1]; tc[L.oM0 + 80] = acc[2]; tc[L.oM0 + 120] = acc[3]; }
+}
+// acc (C image of CC(I,J)) -= (L_SC[E][I] D_E) L_SC[E][J]^T
+template <int E>
+__device__ __forceinline__ void ch_cc_term(const double *P, const ChLane &L, int I, int J, ps_v4d &acc) {
+    const double *sD = P + CH_OFF_D;
+    const double *ta = P + ch_sc(E, 0) + I * CH_SCSZ, *tb = P + ch_sc(E, 0) + J * CH_SCSZ;
+    const double a0 = ta[L.oA0], a1 = ta[L.oA0 + 4], a2 = ta[L.oA2];
+    const double b0 = tb[L.oA0], b1 = tb[L.oA0 + 4], b2 = tb[L.oA2];
+    const double p0 = sD[E * 16 + L.g], p1 = sD[E * 16 + L.g + 4], p2 = sD[E * 16 + L.g + 8];
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * p0, -b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * p1, -b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * p2, -b2, acc, 0, 0, 0);
+}
+// CC(I,J) -= the terms of level PL (blocks PL and 10 - PL; PL == 5: block 5 alone), task = I (I + 1) / 2 + J
+template <int PL>
+__device__ __forceinline__ void ch_cc_task(double *P, const ChLane &L, int task) {
+    const int I = (task >= 1) + (task >= 3) + (task >= 6) + (task >= 10), J = task - I * (I + 1) / 2;
+    double *tc = P + ch_cc(0, 0) + task * PS_TS + L.g * PS_TROW + L.r16;
+    ps_v4d acc;
+    acc[0] = tc[0]; acc[1] = tc[4 * PS_TROW]; acc[2] = tc[8 * PS_TROW]; acc[3] = tc[12 * PS_TROW];
+    ch_cc_term<PL>(P, L, I, J, acc);
+    if (PL < 5) ch_cc_term<10 - PL>(P, L, I, J, acc);
+    tc[0] = acc[0]; tc[4 * PS_TROW] = acc[1]; tc[8 * PS_TROW] = acc[2]; tc[12 * PS_TROW] = acc[3];
+}
+// y_C -= L_SC[E] w_E for the rows of this lane (80 rows: lane, and 64 + lane for lane < 16)
+template <int E>
+__device__ __forceinline__ void ch_yc_term(double *P, int lane) {
+    double *sY = P + CH_OFF_Y;
+    double w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = sY[E * 16 + k];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int i = pass * 64 + lane;
+        if (i < 80) {
+            const double *l = P + ch_sc(E, 0) + (i >> 4) * CH_SCSZ + (i & 15) * CH_TS;
+            double y = sY[CH_YC + i];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) y = fma(-l[k], w[k], y);
+            sY[CH_YC + i] = y;
+        }
+    }
+}
+// the right-hand side of phase LEV (one wave): w_e = M_e^T y_e for the level's blocks, y_succ -= L_SO[e] w_e, and y_C -= L_SC w of the
+// previous level's blocks
+template <int LEV>
+__device__ __forceinline__ void ch_rhs_phase(double *P, int lane) {
+    double *sY = P + CH_OFF_Y;
+    constexpr int eA = LEV, eB = 10 - LEV;
+    const int k = lane & 15, half = lane >> 4;           // half 0: chain A, half 1: chain B
+    const int e = half == 0 ? eA : eB;
+    const bool on = k < 9 && (half == 0 || (half == 1 && LEV < 5));
+    double w = 0.0;
+    if (on) {
+        const double *m = P + ch_sm(e) + k;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) w = fma(sY[e * 16 + j], m[j * CH_TS], w);        // column k of M_e (zero below its diagonal)
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (on) sY[e * 16 + k] = w;
+    __builtin_amdgcn_wave_barrier();
+    if (LEV < 5) {
+        if (LEV < 4) {
+            const int n = half == 0 ? eA + 1 : eB - 1;
+            if (on) {
+                const double *l = P + ch_so(e) + k * CH_TS;
+                double y = sY[n * 16 + k];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) y = fma(-l[j], sY[e * 16 + j], y);
+                sY[n * 16 + k] = y;
+            }
+        } else if (lane < 9) {          // both chains end in block 5
+            const double *la = P + ch_so(4) + k * CH_TS, *lb = P + ch_so(6) + k * CH_TS;
+            double y = sY[5 * 16 + k];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) y = fma(-la[j], sY[4 * 16 + j], y);
+#pragma unroll
+            for (int j = 0; j < 9; ++j) y = fma(-lb[j], sY[6 * 16 + j], y);
+            sY[5 * 16 + k] = y;
+        }
+    }
+    if (LEV > 0) {
+        ch_yc_term<LEV - 1>(P, lane);
+        ch_yc_term<11 - LEV>(P, lane);
+    }
+}
+
+// what the workers (waves 2..15, wi = wave - 2) do after barrier LEV
+template <int LEV>
+__device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int wi, int lane) {
+    constexpr int eA = LEV, eB = 10 - LEV;
+    if (wi == 13) { ch_rhs_phase<LEV>(P, lane); return; }
+    int first_cc, busy;
+    if (LEV < 4) {
+        busy = wi < 10;
+        if (wi < 5) {
+            ps_v4d acc2;
+            ch_ld_c9(P + ch_sc(eA + 1, 0) + wi * CH_SCSZ, L, acc2);
+            ch_fused<eA, true>(P, L, wi, acc2);
+            ch_st_c9(P + ch_sc(eA + 1, 0) + wi * CH_SCSZ, L, acc2);
+        } else if (wi < 10) {
+            ps_v4d acc2;
+            ch_ld_c9(P + ch_sc(eB - 1, 0) + (wi - 5) * CH_SCSZ, L, acc2);
+            ch_fused<eB, true>(P, L, wi - 5, acc2);
+            ch_st_c9(P + ch_sc(eB - 1, 0) + (wi - 5) * CH_SCSZ, L, acc2);
+        }
+        first_cc = wi >= 10 ? wi - 10 : wi + 3;           // the three idle workers take the first tasks, and 13 / 14 after them
+    } else {
+        busy = wi < 5;
+        if (wi < 5) {
+            if (LEV == 4) {                               // both chains fill SC[5][t]: one wave, chain A's term first
+                ps_v4d acc2;
+                ch_ld_c9(P + ch_sc(5, 0) + wi * CH_SCSZ, L, acc2);
+                ch_fused<4, true>(P, L, wi, acc2);
+                ch_fused<6, true>(P, L, wi, acc2);
+                ch_st_c9(P + ch_sc(5, 0) + wi * CH_SCSZ, L, acc2);
+            } else {
+                ps_v4d dummy = {0.0, 0.0, 0.0, 0.0};
+                ch_fused<5, false>(P, L, wi, dummy);
+            }
+        }
+        first_cc = wi >= 5 ? wi - 5 : wi + 8;             // eight idle workers: tasks 0..7 and 8..14 after them
+    }
+    if (LEV > 0) {
+        // the camera-block terms of the previous level
+        if (LEV < 4) {
+            ch_cc_task<LEV - 1>(P, L, first_cc);
+            if (wi == 10 || wi == 11) ch_cc_task<LEV - 1>(P, L, wi + 3);
+        } else {
+            if (!busy) {
+                ch_cc_task<LEV - 1>(P, L, first_cc);
+                if (first_cc + 8 < 15) ch_cc_task<LEV - 1>(P, L, first_cc + 8);
+            }
+        }
+    }
+    (void)busy;
+}
+
+__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsigned long long *dbg = nullptr) {
+#ifdef VIO_STAMPS
+    const unsigned long long t_start__ = __builtin_amdgcn_s_memtime();
+#endif
+    const int lane = tid & 63;
+    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    double *sD = P + CH_OFF_D, *sX = P + CH_OFF_X, *sY = P + CH_OFF_Y, *sMc = P + CH_OFF_MC;
+    const bool r9 = r16 < 9;
+    ChLane L;
+    L.r16 = r16; L.g = g; L.r9 = r9;
+    L.oA0 = r16 * CH_TS + g; L.oA2 = r16 * CH_TS + (g == 0 ? 8 : 9);
+    L.oM0 = g * CH_TS + r16; L.oM2 = (g == 0) ? 8 * CH_TS + r16 : 8 * CH_TS + 9;
+
+    // ================= speed-bias chain =================
+    if (uwave < 2) {
+        // the two chain waves: wave 0 blocks 0..4 and then 5, wave 1 blocks 10..6 (one copy of the code, the block a run-time value)
+        const int dir = uwave == 0 ? 1 : -1;
+        int e = uwave == 0 ? 0 : 10;
+        for (int lev = 0; lev < 6; ++lev, e += dir) {
+            if (lev < 5 || uwave == 0) {
+                if (lev == 5) {
+                    // chain B's term of SD[5] (chain A's went in from registers)
+                    double *td = P + ch_sd(5);
+                    const double *so = P + ch_so(6);
+                    const double a0 = so[L.oA0], a1 = so[L.oA0 + 4], a2 = so[L.oA2];
+                    const double p0 = sD[6 * 16 + g], p1 = sD[6 * 16 + g + 4], p2 = sD[6 * 16 + g + 8];
+                    ps_v4d acc = {td[L.oM0], td[L.oM0 + 40], td[L.oM0 + 80], 0.0};
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * p0, -a0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * p1, -a1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * p2, -a2, acc, 0, 0, 0);
+                    if (r9) { td[L.oM0] = acc[0]; td[L.oM0 + 40] = acc[1]; if (g == 0) td[L.oM0 + 80] = acc[2]; }
+                }
+                ch_chain_level(P, L, e, e + dir, !(uwave == 1 && lev == 4), lane);
+                if (uwave == 0) CH_STAMP(64 + 4 * lev);
+            }
+            __syncthreads();
+            if (uwave == 0) CH_STAMP(65 + 4 * lev);
+        }
+        __syncthreads();
+    } else {
+        const int wi = uwave - 2;
+        __syncthreads();                                           // barrier 0: level 0 is out
+        ch_worker_phase<0>(P, L, wi, lane); if (uwave == 2) CH_STAMP(112);
+        __syncthreads();
+        ch_worker_phase<1>(P, L, wi, lane); if (uwave == 2) CH_STAMP(113);
+        __syncthreads();
+        ch_worker_phase<2>(P, L, wi, lane); if (uwave == 2) CH_STAMP(114);
+        __syncthreads();
+        ch_worker_phase<3>(P, L, wi, lane); if (uwave == 2) CH_STAMP(115);
+        __syncthreads();
+        ch_worker_phase<4>(P, L, wi, lane); if (uwave == 2) CH_STAMP(116);
+        __syncthreads();
+        ch_worker_phase<5>(P, L, wi, lane); if (uwave == 2) CH_STAMP(117);
+        __syncthreads();
+    }
+    if (uwave == 0) CH_STAMP(87);
+
+    // ================= camera block: 5 tiles (16, 16, 16, 16, 8) =================
+    const int lofs = r16 * PS_TROW + g;      // A image of a 16 x 17 tile: row r16, k = g + 4q
+    const int cofs = g * PS_TROW + r16;      // C / B image: row g + 4v, column r16
+    if (uwave == 0) {
+        // CC(0,0) -= (L D) L^T of block 5 first: it is what F(0) waits for
+        double *tc = P + ch_cc(0, 0) + cofs;
+        ps_v4d acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = tc[4 * PS_TROW * v];
+        ch_cc_term<5>(P, L, 0, 0, acc);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) tc[4 * PS_TROW * v] = acc[v];
+        ch_factor_tile(P + ch_cc(0, 0), sMc, sD + CH_YC, 16, lane);
+    } else if (uwave == 15) {
+        ch_yc_term<5>(P, lane);
+    } else if (uwave >= 1) {
+        ch_cc_task<5>(P, L, uwave);            // tasks 1..14
+    }
+    if (uwave == 0) CH_STAMP(88);
+    __syncthreads();
+    if (uwave == 0) CH_STAMP(89);
+    for (int K = 0; K < 5; ++K) {
+        const int nk = 4 - K;                                   // tiles below the diagonal
+        const int d0 = CH_YC + 16 * K;
+        // ---- S phase ----
+        if (uwave == 0 && nk > 0) {
+            double *tt = P + ch_cc(K + 1, K);
+            double *td = P + ch_cc(K + 1, K + 1) + cofs;
+            const double *pd = sD + d0 + g;
+            double av[4], bv[4], pv[4], lv[4], qv[4];
+            ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = tt[lofs + 4 * q]; bv[q] = sMc[cofs + 4 * PS_TROW * q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pv[q] = pd[4 * q]; acc2[q] = td[4 * PS_TROW * q]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[q], av[q], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) qv[q] = d_fast_rcp(pv[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { lv[q] = d_div(acc[q], pv[q], qv[q]); tt[lofs + 4 * q] = lv[q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q], -lv[q], acc2, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) td[4 * PS_TROW * q] = acc2[q];
+        } else if (uwave >= 1 && uwave < nk) {
+            double *tt = P + ch_cc(K + 1 + uwave, K);
+            double av[4], bv[4];
+            ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[q] = tt[lofs + 4 * q]; bv[q] = sMc[cofs + 4 * PS_TROW * q]; }
+            const double dd = sD[d0 + r16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+            const double rr = d_fast_rcp(dd);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tt[cofs + 4 * PS_TROW * q] = d_div(acc[q], dd, rr);
+        } else if (uwave == 14) {
+            // M_K takes the diagonal tile's place (the back-substitution multiplies by it; the pivots are in sD)
+            double mk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mk[q] = sMc[(g + 4 * q) * PS_TROW + r16];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) P[ch_cc(K, K) + (g + 4 * q) * PS_TROW + r16] = mk[q];
+        } else if (uwave == 15) {
+            double y = 0.0;
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) y = fma(sY[d0 + j], sMc[j * PS_TROW + lane], y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 16) sY[d0 + lane] = y;
+        }
+        if (uwave == 0) CH_STAMP(90 + 4 * K);
+        __syncthreads();
+        if (uwave == 0) CH_STAMP(91 + 4 * K);
+        if (nk == 0) break;
+        // ---- U (+ F(K+1) on wave 0): tiles 1 .. ntile-1 of the trailing triangle in row-major order (tile 0 = (K+1,K+1) is wave 0's),
+        //      then the right-hand side ----
+        if (uwave == 0) {
+            if (K + 1 == 4) {
+                // the last tile has 8 variables: M starts as the identity, rows / columns 8..15 stay that way
+                for (int i = lane; i < PS_TS; i += 64) sMc[i] = (i / PS_TROW == i % PS_TROW) ? 1.0 : 0.0;
+                ch_factor_tile(P + ch_cc(4, 4), sMc, sD + CH_YC + 64, 8, lane);
+            } else {
+                ch_factor_tile(P + ch_cc(K + 1, K + 1), sMc, sD + d0 + 16, 16, lane);
+            }
+        } else {
+            const int ntile = nk * (nk + 1) / 2;
+            const int nitem = ntile + 1;
+            for (int t = uwave; t < nitem; t += 15) {
+                if (t < ntile) {
+                    const int ii = (t >= 1) + (t >= 3) + (t >= 6), jj = t - ii * (ii + 1) / 2;
+                    const double *ta = P + ch_cc(K + 1 + ii, K) + lofs, *tb = P + ch_cc(K + 1 + jj, K) + lofs;
+                    double *tc = P + ch_cc(K + 1 + ii, K + 1 + jj) + cofs;
+                    double av[4], bv[4], dk[4];
+                    ps_v4d acc;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { av[q] = ta[4 * q]; bv[q] = tb[4 * q]; acc[q] = tc[4 * PS_TROW * q]; dk[q] = sD[d0 + g + 4 * q]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q] * dk[q], -bv[q], acc, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tc[4 * PS_TROW * q] = acc[q];
+                } else {
+                    // y_I -= L_IK w_K for the rows below
+                    const int c = 16 * (K + 1) + lane;
+                    if (c < 80) {
+                        const double *l = P + ch_cc(c >> 4, K) + (c & 15) * PS_TROW;
+                        double y = sY[CH_YC + c];
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) y = fma(-l[kk], sY[d0 + kk], y);
+                        sY[CH_YC + c] = y;
+                    }
+                }
+            }
+            if (uwave == 2) CH_STAMP(128 + K);
+        }
+        if (uwave == 0) CH_STAMP(92 + 4 * K);
+        __syncthreads();
+        if (uwave == 0) CH_STAMP(93 + 4 * K);
+    }
+    if (uwave == 0) CH_STAMP(110);
+
+    // ================= back-substitution =================
+    // x_col = M_col (w_col / d_col - sum_{J after col} L_{J,col}^T x_J).
+    // Camera tiles from the bottom: wave 11 + K owns tile K (lanes 0..15, lane = column), one barrier per tile.  Meanwhile wave e < 11
+    // owns speed-bias block e: with every x_J that comes out it adds its quarter of L_SC[e][J]^T x_J to a running sum (lane = (k, rows
+    // r = q mod 4)); at the end the four quarters are added, x_5 is finished by its owner, and waves 0 / 1 walk the two chains.
+    {
+        const bool isC = uwave >= 11;
+        const int K = uwave - 11, e = uwave;
+        const bool work = lane < 16;
+        const int k9 = min(r16, 8);
+        double acc = 0.0, mw[16], ucol[16], own_v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { mw[j] = 0.0; ucol[j] = 0.0; }
+#define CH_LOAD_COL_C(I_, K_) do { const double *src__ = P + ch_cc((I_), (K_)) + r16; _Pragma("unroll") for (int r = 0; r < 16; ++r) ucol[r] = src__[r * PS_TROW]; } while (0)
+        if (isC && work) {
+            const double *src = P + ch_cc(K, K) + r16 * PS_TROW;                 // row r16 of M_K (the tile's diagonal still holds the pivots)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mw[j] = (j == r16) ? 1.0 : src[j];
+            const double dd = sD[CH_YC + 16 * K + r16];
+            own_v = d_div(sY[CH_YC + 16 * K + r16], dd, d_fast_rcp(dd));
+            if (K == 4) { double x; PS_DOT16(x, 0.0, own_v, mw); sX[CH_YC + 64 + r16] = x; }
+            else CH_LOAD_COL_C(4, K);
+        }
+        // speed-bias owners: rows r = g, g + 4, g + 8, g + 12 of the tile, column k9
+        double sacc = 0.0, lq[4], gk[3];
+        if (!isC) {
+            const double *src = P + ch_sc(e, 4) + g * CH_TS + k9;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) lq[v] = src[4 * v * CH_TS];
+            if (e != 5) {
+                // G_e = M_e L_SO[e]^T (x_e = M_e v_e - G_e x_succ): entries (k9, j = g, g + 4, g + 8), formed while the camera tiles resolve
+                const double *m = P + ch_sm(e) + k9 * CH_TS, *so = P + ch_so(e);
+#pragma unroll
+                for (int v = 0; v < 3; ++v) {
+                    const int j = min(g + 4 * v, 8);
+                    double sum = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) sum = fma(m[i], so[j * CH_TS + i], sum);
+                    gk[v] = sum;
+                }
+            }
+        }
+        __syncthreads();                                                             // x of tile 4 is out
+        if (!isC && e != 5 && r9) {         // (every lane has read L_SO[e]: the barrier above) G_e takes its place
+            double *so = P + ch_so(e) + k9 * CH_TS;
+            so[g] = gk[0]; so[g + 4] = gk[1];
+            if (g == 0) so[8] = gk[2];
+        }
+        for (int J = 4; J >= 0; --J) {
+            if (isC) {
+                if (work && K < J) {
+                    PS_DOT16(acc, acc, sX[CH_YC + 16 * J + r16], ucol);
+                    if (J > K + 1) CH_LOAD_COL_C(J - 1, K);
+                    else { double x; PS_DOT16(x, 0.0, own_v - acc, mw); sX[CH_YC + 16 * K + r16] = x; }
+                }
+            } else {
+                const double *xj = sX + CH_YC + 16 * J + g;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sacc = fma(lq[v], xj[4 * v], sacc);
+                if (J > 0) {
+                    const double *src = P + ch_sc(e, J - 1) + g * CH_TS + k9;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) lq[v] = src[4 * v * CH_TS];
+                }
+            }
+            __syncthreads();
+        }
+#undef CH_LOAD_COL_C
+        if (uwave == 0) CH_STAMP(111);
+        // the four quarters of every block's sum meet in LDS: lanes k, 16 + k, 32 + k, 48 + k of the
+        // owner, added in that order; then v_e = w_e / d_e - sum and g_e = M_e v_e (x_5 = g_5)
+        double *scr = P + CH_OFF_SCR;
+        if (!isC) {
+            scr[e * 64 + lane] = sacc;
+            __builtin_amdgcn_wave_barrier();
+            double gv = 0.0;
+            if (work) {
+                const double c = ((scr[e * 64 + r16] + scr[e * 64 + 16 + r16]) + scr[e * 64 + 32 + r16]) + scr[e * 64 + 48 + r16];
+                const double dd = sD[e * 16 + k9];
+                const double v = d_div(sY[e * 16 + k9], dd, d_fast_rcp(dd)) - c;
+                const double *src = P + ch_sm(e) + k9 * CH_TS;
+                double m9[9];
+#pragma unroll
+                for (int j = 0; j < 9; ++j) m9[j] = (j < k9) ? 0.0 : src[j];
+                CH_DOT9(gv, 0.0, v, m9);
+                if (r9) sX[e * 16 + r16] = gv;
+            }
+        }
+        __syncthreads();
+        // the two chains, one wave each, no barriers: x_e = g_e - G_e x_succ(e), e = 4..0 on wave 0, 6..10 on wave 1; the rows of G and
+        // g_e of the next block are requested before the current product
+        if (uwave < 2 && work) {
+            double xs = sX[5 * 16 + k9];
+            double gc[9], gn[9], vc, vn = 0.0;
+            {
+                const int eb = (uwave == 0) ? 4 : 6;
+                const double *src = P + ch_so(eb) + k9 * CH_TS;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) gc[j] = src[j];
+                vc = sX[eb * 16 + k9];
+            }
+#pragma unroll
+            for (int s2 = 1; s2 <= 5; ++s2) {
+                const int eb = (uwave == 0) ? 5 - s2 : 5 + s2;
+                if (s2 < 5) {
+                    const int en = (uwave == 0) ? eb - 1 : eb + 1;
+                    const double *src = P + ch_so(en) + k9 * CH_TS;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) gn[j] = src[j];
+                    vn = sX[en * 16 + k9];
+                }
+                double t;
+                CH_DOT9(t, 0.0, xs, gc);
+                const double xn = vc - t;
+                if (r9) sX[eb * 16 + r16] = xn;
+                xs = xn;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) gc[j] = gn[j];
+                vc = vn;
+            }
+        }
+        if (uwave == 0) CH_STAMP(63);
+        __syncthreads();
+    }
+}
+#endif

@@ -47,7 +47,8 @@
 #define CH_OFF_X (CH_OFF_D + CH_NDIM)                       // [256] solution by dimension
 #define CH_OFF_I9 (CH_OFF_X + CH_NDIM)                      // 9 x 9 identity (stride 10): the rows F's second half-row of lanes starts from
 #define CH_OFF_I16 (CH_OFF_I9 + CH_S9SZ)                    // 16 x 16 identity (stride 17)
-#define CH_LDS_CORE (CH_OFF_I16 + PS_TS)                    // 17162
+#define CH_OFF_SCR (CH_OFF_I16 + PS_TS)                     // 11 x 64: the quarters of the speed-bias blocks' back-substitution sums
+#define CH_LDS_CORE (CH_OFF_SCR + CH_NS * 64)               // 17866
 static_assert(CH_PACKED % 2 == 0 && CH_SET_STRIDE >= CH_PACKED && CH_SET_STRIDE <= PS_SET_STRIDE, "chain image fits a set of Pg");
 
 __host__ __device__ inline int ch_sc(int e, int t) { return CH_OFF_SC + (e * 5 + t) * CH_SCSZ; }
@@ -170,418 +171,7 @@ __device__ __noinline__ void ch_factor(lds_double *tile, lds_double *sI, lds_dou
                          : "v"(v__), "v"(arr[0]), "v"(arr[1]), "v"(arr[2]), "v"(arr[3]), "v"(arr[4]), "v"(arr[5]), "v"(arr[6]), "v"(arr[7]), "v"(arr[8])); \
             (out) = x__ + x2__; } while (0)
 
-// The whole factorisation and solve on the image in LDS (lambda already on the diagonal, pad diagonal of CC = 1).
-// On return sX = P + CH_OFF_X holds the solution by chain dimension.  All 1024 threads call; ends with a barrier.
-#ifdef VIO_STAMPS
-#define CH_STAMP(slot) do { if (dbg && (tid & 63) == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[slot] = __builtin_amdgcn_s_memtime() - t_start__; } } while (0)
-#else
-#define CH_STAMP(slot) do { } while (0)
-#endif
-__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsigned long long *dbg = nullptr) {
-#ifdef VIO_STAMPS
-    const unsigned long long t_start__ = __builtin_amdgcn_s_memtime();
-#endif
-    const int lane = tid & 63;
-    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, g = lane >> 4;
-    double *sD = P + CH_OFF_D, *sX = P + CH_OFF_X, *sY = P + CH_OFF_Y, *sMc = P + CH_OFF_MC;
-    const bool r9 = r16 < 9;
-
-    // ---- building blocks (one wave each) ----
-    // S-type operand images: A image = tile[row r16][k = g + 4q], q < 3, k < 9 (rows < nrows)
-    auto ld_a9 = [&](const double *t, int nrows, double v[3]) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { const int k = g + 4 * q; const double x = t[r16 * CH_TS + k]; v[q] = (k < 9 && r16 < nrows) ? x : 0.0; }
-    };
-    // B image of M_e: M[k = g + 4q][n = r16]
-    auto ld_m9 = [&](const double *m, double v[3]) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { const int k = g + 4 * q; const double x = m[min(k, 8) * CH_TS + r16]; v[q] = (k < 9 && r9) ? x : 0.0; }
-    };
-    // L = (A M_e) / d of a tile with `nrows` rows in column block e; result stored in place (C image)
-    auto sprod9 = [&](double *t, int nrows, int e) {
-        double av[3], bv[3];
-        ld_a9(t, nrows, av);
-        ld_m9(P + ch_sm(e), bv);
-        const double dd = P[ch_sd(e) + min(r16, 8) * (CH_TS + 1)];
-        ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
-        const double rr = d_fast_rcp(dd);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int row = g + 4 * v;
-            if (r9 && row < nrows) t[row * CH_TS + r16] = d_div(acc[v], dd, rr);
-        }
-    };
-    // the chain wave's product: L_SO[e] = (SO[e] M_e) / d formed transposed — the accumulator is the operand image of the update that
-    // follows — and, with upd, SD[n] -= (L D) L^T from registers
-    auto chain_step = [&](int e, int n, bool upd) {
-        double *tt = P + ch_so(e);
-        double av[3], bv[3], pv[3], lv[3];
-        ld_a9(tt, 9, av);
-        ld_m9(P + ch_sm(e), bv);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) pv[q] = P[ch_sd(e) + min(g + 4 * q, 8) * (CH_TS + 1)];
-        double *td = P + ch_sd(n);
-        ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { const int row = g + 4 * v; const double x = td[min(row, 8) * CH_TS + min(r16, 8)]; acc2[v] = (row < 9 && r9) ? x : 0.0; }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[q], av[q], acc, 0, 0, 0);     // (A M)^T: [k = g + 4v][row r16]
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int k = g + 4 * q;
-            lv[q] = (k < 9 && r9) ? d_div(acc[q], pv[q], d_fast_rcp(pv[q])) : 0.0;
-            if (k < 9 && r9) tt[r16 * CH_TS + k] = lv[q];
-        }
-        if (upd) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q], -lv[q], acc2, 0, 0, 0);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) { const int row = g + 4 * v; if (row < 9 && r9) td[row * CH_TS + r16] = acc2[v]; }
-        }
-    };
-    // acc -= (L_a D_e) L_b^T, both operands S-type tiles of column block e (rows: na / nb)
-    auto upd9 = [&](ps_v4d &acc, const double *ta, int na, const double *tb, int nb, int e) {
-        double av[3], bv[3];
-        ld_a9(ta, na, av);
-        ld_a9(tb, nb, bv);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { const double dk = sD[e * 16 + min(g + 4 * q, 8)]; av[q] *= dk; }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], -bv[q], acc, 0, 0, 0);
-    };
-    // U work of speed-bias level `lev` (its blocks eA = lev, eB = 10 - lev are factored, their L tiles and sD are final):
-    // tasks 0..14 CC(I,J) | 15..19 SC[nA][t] | 20..24 SC[nB][t] | 25 the right-hand side.  `first`: first task of this wave, `step`: stride.
-    auto s_level_update = [&](int lev, int first, int step, int skip_cc00) {
-        const int eA = lev, eB = 10 - lev;
-        const bool two = lev < 5;
-        for (int task = first; task < 26; task += step) {
-            if (task < 15) {
-                if (task == 0 && skip_cc00) continue;
-                int I = 0;
-                while ((I + 1) * (I + 2) / 2 <= task) ++I;
-                const int J = task - I * (I + 1) / 2;
-                double *tc = P + ch_cc(I, J) + g * PS_TROW + r16;
-                ps_v4d acc;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[v] = tc[4 * PS_TROW * v];
-                upd9(acc, P + ch_sc(eA, I), 16, P + ch_sc(eA, J), 16, eA);
-                if (two) upd9(acc, P + ch_sc(eB, I), 16, P + ch_sc(eB, J), 16, eB);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) tc[4 * PS_TROW * v] = acc[v];
-            } else if (task < 25) {
-                if (lev >= 5) continue;
-                const bool chainB = task >= 20;
-                if (chainB && lev == 4) continue;                   // (both chains end in block 5: the first five tasks add both terms)
-                const int t = task - (chainB ? 20 : 15);
-                const int e = chainB ? eB : eA, n = chainB ? eB - 1 : eA + 1;
-                double *tc = P + ch_sc(n, t);
-                ps_v4d acc;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { const double x = tc[(g + 4 * v) * CH_TS + min(r16, 8)]; acc[v] = r9 ? x : 0.0; }
-                upd9(acc, P + ch_sc(e, t), 16, P + ch_so(e), 9, e);
-                if (lev == 4) upd9(acc, P + ch_sc(eB, t), 16, P + ch_so(eB), 9, eB);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) if (r9) tc[(g + 4 * v) * CH_TS + r16] = acc[v];
-            } else {
-                // y_C -= L_SC[e] w_e (both chains, A first), y_n -= L_SO[e] w_e
-                double wA[9], wB[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { wA[k] = sY[eA * 16 + k]; wB[k] = sY[eB * 16 + k]; }
-                for (int pass = 0; pass < 2; ++pass) {
-                    const int i = pass * 64 + lane;
-                    if (i < 80) {
-                        const double *la = P + ch_sc(eA, i >> 4) + (i & 15) * CH_TS, *lb = P + ch_sc(eB, i >> 4) + (i & 15) * CH_TS;
-                        double y = sY[CH_YC + i];
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) y = fma(-la[k], wA[k], y);
-                        if (two) {
-#pragma unroll
-                            for (int k = 0; k < 9; ++k) y = fma(-lb[k], wB[k], y);
-                        }
-                        sY[CH_YC + i] = y;
-                    } else if (two && i >= 96 && i < 96 + 9) {          // successor of chain A (at level 4: block 5, both terms)
-                        const int r = i - 96;
-                        double y = sY[(eA + 1) * 16 + r];
-                        const double *la = P + ch_so(eA) + r * CH_TS, *lb = P + ch_so(eB) + r * CH_TS;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) y = fma(-la[k], wA[k], y);
-                        if (lev == 4) {
-#pragma unroll
-                            for (int k = 0; k < 9; ++k) y = fma(-lb[k], wB[k], y);
-                        }
-                        sY[(eA + 1) * 16 + r] = y;
-                    } else if (two && lev < 4 && i >= 112 && i < 112 + 9) {
-                        const int r = i - 112;
-                        double y = sY[(eB - 1) * 16 + r];
-                        const double *lb = P + ch_so(eB) + r * CH_TS;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) y = fma(-lb[k], wB[k], y);
-                        sY[(eB - 1) * 16 + r] = y;
-                    }
-                }
-            }
-        }
-    };
-
-    // ================= speed-bias chain: levels 0..5 =================
-    for (int lev = 0; lev < 6; ++lev) {
-        const int eA = lev, eB = 10 - lev;
-        if (uwave == 0) {
-            if (lev == 5) {     // chain B's last term of SD[5] (chain A's was applied from registers at level 4)
-                double *td = P + ch_sd(5);
-                ps_v4d acc;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { const int row = g + 4 * v; const double x = td[min(row, 8) * CH_TS + min(r16, 8)]; acc[v] = (row < 9 && r9) ? x : 0.0; }
-                upd9(acc, P + ch_so(6), 9, P + ch_so(6), 9, 6);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) { const int row = g + 4 * v; if (row < 9 && r9) td[row * CH_TS + r16] = acc[v]; }
-            }
-            ch_factor<9, CH_TS, CH_TS>((lds_double *)(P + ch_sd(eA)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(eA)), lane);
-        } else if (uwave == 1) {
-            if (lev < 5) ch_factor<9, CH_TS, CH_TS>((lds_double *)(P + ch_sd(eB)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(eB)), lane);
-        } else if (lev > 0) {
-            s_level_update(lev - 1, uwave - 2, 14, 0);
-            if (uwave == 2) CH_STAMP(112 + lev - 1);
-        }
-        if (uwave == 0) CH_STAMP(64 + 4 * lev);
-        __syncthreads();                                                                 // B1: M_e and the pivots are out
-        if (uwave == 0) CH_STAMP(65 + 4 * lev);
-        if (uwave == 0) {
-            if (lev < 5) chain_step(eA, eA + 1, true);
-        } else if (uwave == 1) {
-            if (lev < 5) chain_step(eB, eB - 1, lev < 4);
-        } else {
-            const int wi = uwave - 2;
-            if (wi < 5) sprod9(P + ch_sc(eA, wi), 16, eA);
-            else if (wi < 10) { if (lev < 5) sprod9(P + ch_sc(eB, wi - 5), 16, eB); }
-            else if (wi == 10) {
-                if (lane < 9) sD[eA * 16 + lane] = P[ch_sd(eA) + lane * (CH_TS + 1)];
-                else if (lane >= 16 && lane < 25 && lev < 5) sD[eB * 16 + lane - 16] = P[ch_sd(eB) + (lane - 16) * (CH_TS + 1)];
-            } else if (wi == 11) {
-                // w_e = M_e^T y_e = L_ee^-1 y_e
-                const int e = (lane < 16) ? eA : eB, k = lane & 15;
-                double y = 0.0;
-                if (k < 9 && lane < 32) {
-                    const double *m = P + ch_sm(e);
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) y = fma(sY[e * 16 + j], (j <= k) ? m[j * CH_TS + k] : 0.0, y);
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (k < 9 && (lane < 16 || (lane < 32 && lev < 5))) sY[e * 16 + k] = y;
-            }
-        }
-        if (uwave == 0) CH_STAMP(66 + 4 * lev);
-        if (uwave == 2) CH_STAMP(120 + lev);
-        __syncthreads();                                                                 // B2: L tiles of this level are out
-        if (uwave == 0) CH_STAMP(67 + 4 * lev);
-    }
-
-    // ================= camera block: 5 tiles (16, 16, 16, 16, 8) =================
-    const int lofs = r16 * PS_TROW + g;      // A image of a 16 x 17 tile: row r16, k = g + 4q
-    const int cofs = g * PS_TROW + r16;      // C / B image: row g + 4v, column r16
-    if (uwave == 0) {
-        // CC(0,0) -= (L D) L^T of block 5 first: it is what F(0) waits for
-        double *tc = P + ch_cc(0, 0) + cofs;
-        ps_v4d acc;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc[v] = tc[4 * PS_TROW * v];
-        upd9(acc, P + ch_sc(5, 0), 16, P + ch_sc(5, 0), 16, 5);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) tc[4 * PS_TROW * v] = acc[v];
-        ch_factor<16, PS_TROW, PS_TROW>((lds_double *)(P + ch_cc(0, 0)), (lds_double *)(P + CH_OFF_I16), (lds_double *)sMc, lane);
-    } else if (uwave >= 2) {
-        s_level_update(5, uwave - 2, 14, 1);
-        if (uwave == 2) CH_STAMP(117);
-    }
-    if (uwave == 0) CH_STAMP(88);
-    __syncthreads();
-    if (uwave == 0) CH_STAMP(89);
-    for (int K = 0; K < 5; ++K) {
-        const int nk = 4 - K;                                   // tiles below the diagonal
-        const int d0 = CH_YC + 16 * K;
-        // ---- S phase ----
-        if (uwave == 0 && nk > 0) {
-            double *tt = P + ch_cc(K + 1, K);
-            double *td = P + ch_cc(K + 1, K + 1) + cofs;
-            const double *pd = P + ch_cc(K, K) + g * (PS_TROW + 1);
-            double av[4], bv[4], pv[4], lv[4];
-            ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { av[q] = tt[lofs + 4 * q]; bv[q] = sMc[cofs + 4 * PS_TROW * q]; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { pv[q] = pd[4 * q * (PS_TROW + 1)]; acc2[q] = td[4 * PS_TROW * q]; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[q], av[q], acc, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { lv[q] = d_div(acc[q], pv[q], d_fast_rcp(pv[q])); tt[lofs + 4 * q] = lv[q]; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[q], -lv[q], acc2, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) td[4 * PS_TROW * q] = acc2[q];
-        } else if (uwave >= 1 && uwave < nk) {
-            double *tt = P + ch_cc(K + 1 + uwave, K);
-            double av[4], bv[4];
-            ps_v4d acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { av[q] = tt[lofs + 4 * q]; bv[q] = sMc[cofs + 4 * PS_TROW * q]; }
-            const double dd = P[ch_cc(K, K) + r16 * (PS_TROW + 1)];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
-            const double rr = d_fast_rcp(dd);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) tt[cofs + 4 * PS_TROW * q] = d_div(acc[q], dd, rr);
-        } else if (uwave == 14) {
-            // the pivots by dimension; then M_K takes the factored tile's place (not its diagonal: M_K's is 1, and the pivots stay readable)
-            double dd = 0.0, mk[4];
-            if (lane < 16) dd = P[ch_cc(K, K) + lane * (PS_TROW + 1)];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) mk[q] = sMc[(g + 4 * q) * PS_TROW + r16];
-            __builtin_amdgcn_sched_barrier(0);
-            if (lane < 16) sD[d0 + lane] = dd;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (g + 4 * q != r16) P[ch_cc(K, K) + (g + 4 * q) * PS_TROW + r16] = mk[q];
-        } else if (uwave == 15) {
-            double y = 0.0;
-            if (lane < 16) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) y = fma(sY[d0 + j], sMc[j * PS_TROW + lane], y);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 16) sY[d0 + lane] = y;
-        }
-        if (uwave == 0) CH_STAMP(90 + 4 * K);
-        __syncthreads();
-        if (uwave == 0) CH_STAMP(91 + 4 * K);
-        if (nk == 0) break;
-        // ---- U (+ F(K+1) on wave 0): tiles 1 .. ntile-1 of the trailing triangle in row-major order (tile 0 = (K+1,K+1) is wave 0's),
-        //      then the right-hand side ----
-        if (uwave == 0) {
-            if (K + 1 == 4) {
-                // the last tile has 8 variables: M starts as the identity, rows / columns 8..15 stay that way
-                for (int i = lane; i < PS_TS; i += 64) sMc[i] = (i / PS_TROW == i % PS_TROW) ? 1.0 : 0.0;
-                ch_factor<8, PS_TROW, PS_TROW>((lds_double *)(P + ch_cc(4, 4)), (lds_double *)(P + CH_OFF_I16), (lds_double *)sMc, lane);
-            } else {
-                ch_factor<16, PS_TROW, PS_TROW>((lds_double *)(P + ch_cc(K + 1, K + 1)), (lds_double *)(P + CH_OFF_I16), (lds_double *)sMc, lane);
-            }
-        } else {
-            const int ntile = nk * (nk + 1) / 2;
-            const int nitem = ntile + 1;
-            double dk[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dk[q] = sD[d0 + g + 4 * q];
-            for (int t = uwave; t < nitem; t += 15) {
-                if (t < ntile) {
-                    int ii = 0;
-                    while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-                    const int jj = t - ii * (ii + 1) / 2;
-                    const double *ta = P + ch_cc(K + 1 + ii, K) + lofs, *tb = P + ch_cc(K + 1 + jj, K) + lofs;
-                    double *tc = P + ch_cc(K + 1 + ii, K + 1 + jj) + cofs;
-                    double av[4], bv[4];
-                    ps_v4d acc;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { av[q] = ta[4 * q]; bv[q] = tb[4 * q]; acc[q] = tc[4 * PS_TROW * q]; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q] * dk[q], -bv[q], acc, 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) tc[4 * PS_TROW * q] = acc[q];
-                } else {
-                    // y_I -= L_IK w_K for the rows below
-                    const int c = 16 * (K + 1) + lane;
-                    if (c < 80) {
-                        const double *l = P + ch_cc(c >> 4, K) + (c & 15) * PS_TROW;
-                        double y = sY[CH_YC + c];
-#pragma unroll
-                        for (int kk = 0; kk < 16; ++kk) y = fma(-l[kk], sY[d0 + kk], y);
-                        sY[CH_YC + c] = y;
-                    }
-                }
-            }
-            if (uwave == 2) CH_STAMP(128 + K);
-        }
-        if (uwave == 0) CH_STAMP(92 + 4 * K);
-        __syncthreads();
-        if (uwave == 0) CH_STAMP(93 + 4 * K);
-    }
-    if (uwave == 0) CH_STAMP(110);
-
-    // ================= back-substitution =================
-    // x_col = M_col (w_col / d_col - sum_{J after col} L_{J,col}^T x_J).  16 block columns, one wave each: wave e < 11 owns speed-bias
-    // block e, wave 11 + K camera tile K; lanes 0..15 work (lane = column of the block).  Camera tiles first, from the bottom, one barrier
-    // per tile; every owner adds the tile's term to its running sum as soon as x_J is out.
-    {
-        const bool isC = uwave >= 11;
-        const int K = uwave - 11, e = uwave;
-        const bool work = lane < 16;
-        const int k9 = min(r16, 8);
-        double acc = 0.0, mw[16], ucol[16], own_v = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { mw[j] = 0.0; ucol[j] = 0.0; }
-#define CH_LOAD_COL_C(I_, K_) do { const double *src__ = P + ch_cc((I_), (K_)) + r16; _Pragma("unroll") for (int r = 0; r < 16; ++r) ucol[r] = src__[r * PS_TROW]; } while (0)
-#define CH_LOAD_COL_S(e_, t_) do { const double *src__ = P + ch_sc((e_), (t_)) + k9; _Pragma("unroll") for (int r = 0; r < 16; ++r) ucol[r] = src__[r * CH_TS]; } while (0)
-        if (work) {
-            if (isC) {
-                const double *src = P + ch_cc(K, K) + r16 * PS_TROW;                 // row r16 of M_K (the tile's diagonal still holds the pivots)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) mw[j] = (j == r16) ? 1.0 : src[j];
-                const double dd = sD[CH_YC + 16 * K + r16];
-                own_v = d_div(sY[CH_YC + 16 * K + r16], dd, d_fast_rcp(dd));
-                if (K == 4) { double x; PS_DOT16(x, 0.0, own_v, mw); sX[CH_YC + 64 + r16] = x; }
-                else CH_LOAD_COL_C(4, K);
-            } else {
-                const double *src = P + ch_sm(e) + k9 * CH_TS;                        // row k of M_e (upper triangular, unit diagonal)
-#pragma unroll
-                for (int j = 0; j < 9; ++j) mw[j] = (j < k9) ? 0.0 : src[j];
-                const double dd = sD[e * 16 + k9];
-                own_v = d_div(sY[e * 16 + k9], dd, d_fast_rcp(dd));
-                CH_LOAD_COL_S(e, 4);
-            }
-        }
-        __syncthreads();                                                             // x of tile 4 is out
-        for (int J = 4; J >= 0; --J) {
-            if (work) {
-                if (isC) {
-                    if (K < J) {
-                        PS_DOT16(acc, acc, sX[CH_YC + 16 * J + r16], ucol);
-                        if (J > K + 1) CH_LOAD_COL_C(J - 1, K);
-                        else { double x; PS_DOT16(x, 0.0, own_v - acc, mw); sX[CH_YC + 16 * K + r16] = x; }
-                    }
-                } else {
-                    PS_DOT16(acc, acc, sX[CH_YC + 16 * J + r16], ucol);
-                    if (J > 0) CH_LOAD_COL_S(e, J - 1);
-                    else if (e == 5) { double x; CH_DOT9(x, 0.0, own_v - acc, mw); if (r9) sX[5 * 16 + r16] = x; }     // the middle block: x_5 = M_5 v_5
-                    else if (r9) sX[e * 16 + r16] = own_v - acc;                    // v_e: what the chains below start from
-                }
-            }
-            __syncthreads();
-        }
-#undef CH_LOAD_COL_C
-#undef CH_LOAD_COL_S
-        if (uwave == 0) CH_STAMP(111);
-        // the two chains, one wave each, no barriers: x_e = M_e (v_e - L_SO[e]^T x_succ(e)), e = 4..0 on wave 0, 6..10 on wave 1
-        if (uwave < 2 && work) {
-            double m9[9], l9[9];
-            double xs = sX[5 * 16 + k9];
-            for (int s = 1; s <= 5; ++s) {
-                const int eb = (uwave == 0) ? 5 - s : 5 + s;
-                const double *src = P + ch_sm(eb) + k9 * CH_TS, *lso = P + ch_so(eb) + k9;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) { m9[j] = (j < k9) ? 0.0 : src[j]; l9[j] = lso[j * CH_TS]; }        // row k of M, column k of L_SO[eb]
-                const double vv = sX[eb * 16 + k9];
-                double t, xn;
-                CH_DOT9(t, 0.0, xs, l9);
-                CH_DOT9(xn, 0.0, vv - t, m9);
-                if (r9) sX[eb * 16 + r16] = xn;
-                xs = xn;
-            }
-        }
-        if (uwave == 0) CH_STAMP(112 - 112 + 63);
-        __syncthreads();
-    }
-}
+#include "vio_chain_core.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // k_assemble_c: H_pp_schur_ (reduced visual system + IMU blocks + prior, problem.cc:365-384) written straight into the chain
@@ -742,7 +332,10 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     } else if (tid >= 256 && tid < 256 + CH_S9SZ + PS_TS) {
         const int i = tid - 256;
         P[CH_OFF_I9 + i] = (i < CH_S9SZ) ? ((i / CH_TS == i % CH_TS) ? 1.0 : 0.0) : (((i - CH_S9SZ) / PS_TROW == (i - CH_S9SZ) % PS_TROW) ? 1.0 : 0.0);
+    } else if (tid >= 640 && tid < 640 + CH_NDIM) {
+        P[CH_OFF_D + tid - 640] = 1.0;                  // pivots of padding dimensions
     }
+    for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) P[CH_OFF_SM + i] = 0.0;      // (the padding column of every M_e must read as zero)
     __syncthreads();
     CH_OUT(0);
     ch_factor_solve(P, tid, T.dbg);
@@ -836,7 +429,10 @@ __global__ __launch_bounds__(PS_THREADS) void k_chain_solve_test(const double *i
     } else if (tid >= 256 && tid < 256 + CH_S9SZ + PS_TS) {
         const int i = tid - 256;
         P[CH_OFF_I9 + i] = (i < CH_S9SZ) ? ((i / CH_TS == i % CH_TS) ? 1.0 : 0.0) : (((i - CH_S9SZ) / PS_TROW == (i - CH_S9SZ) % PS_TROW) ? 1.0 : 0.0);
+    } else if (tid >= 640 && tid < 640 + CH_NDIM) {
+        P[CH_OFF_D + tid - 640] = 1.0;                  // pivots of padding dimensions
     }
+    for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) P[CH_OFF_SM + i] = 0.0;      // (the padding column of every M_e must read as zero)
     __syncthreads();
     ch_factor_solve(P, tid);
     if (tid < PS_N) x_nat[tid] = P[CH_OFF_X + ch_dim(tid)];
