@@ -16,19 +16,19 @@ import sys
 
 import numpy as np
 
-NS, TS, SCSZ, S9SZ = 11, 10, 160, 90
+NS, TS, SCSZ, S9SZ = 11, 11, 176, 99
 OFF_SC = 0
 OFF_SO = OFF_SC + NS * 5 * SCSZ
 OFF_SD = OFF_SO + 10 * S9SZ
 OFF_CC = OFF_SD + NS * S9SZ
 OFF_Y = OFF_CC + 15 * 272
 YC = 176
-PACKED = OFF_Y + 256
+PACKED = (OFF_Y + 256 + 1) & ~1
 OFF_SM = PACKED
 OFF_MC = OFF_SM + NS * S9SZ
 OFF_D = OFF_MC + 272
 OFF_X = OFF_D + 256
-LDS_CORE = OFF_X + 256 + 90 + 272 + 11 * 64
+LDS_CORE = OFF_X + 256 + S9SZ + 272
 
 
 def sc(e, t):

@@ -36,6 +36,7 @@ for lev in range(6):
     a = s[64 + 4 * lev:66 + 4 * lev]
     print("  level %d: wave 0 done %6d (+%5d) | past the barrier %6d (+%5d)      worker: phase %d done at %6d" % (lev, a[0], a[0] - prev, a[1], a[1] - a[0], lev, s[112 + lev]))
     prev = a[1]
+print("  phase 2, every worker (waves 2..15) done at:", [int(v) for v in s[142:156]])
 print("  phase 5 + barrier: %6d (+%5d)" % (s[87], s[87] - prev))
 prev = s[87]
 print("camera block:")
@@ -50,4 +51,5 @@ for K in range(5):
     else:
         print("  K = 4: S done %6d (+%5d) | past B %6d" % (a[0], a[0] - prev, a[1]))
         prev = a[1]
+print("  deferred terms of tile (4,4): start %d, after 3 blocks %d, after 7 %d, after 11 (issued) %d" % tuple(int(v) for v in s[160:164]))
 print("back-substitution: starts %6d | camera rounds done %6d (+%5d) | chains done %6d (+%5d)" % (s[110], s[111], s[111] - s[110], s[63], s[63] - s[111]))

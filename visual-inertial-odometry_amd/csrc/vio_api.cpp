@@ -58,6 +58,7 @@ void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_bl
                          int parity, size_t ps_lds, int order, hipStream_t s);
 void vio_launch_chain_solve_test(const double *img, double lambda, double *x_nat, double *lds_dump, hipStream_t s);
 int vio_chain_image_doubles();
+int vio_chain_y_offset();
 int vio_chain_lds_core_doubles();
 void vio_chain_entry_pos(int i, int j, int *p1, int *p2);
 int vio_chain_dim(int i);
@@ -1339,7 +1340,7 @@ vio_status vio_debug_chain_solve(vio_ctx *c, const double *H, const double *b, d
     const int n_img = vio_chain_image_doubles(), n_lds = vio_chain_lds_core_doubles();
     std::vector<double> img((size_t)n_img, 0.0);
     for (int i = 0; i < PD; ++i) {
-        img[(size_t)n_img - 256 + vio_chain_dim(i)] = b[i];
+        img[(size_t)vio_chain_y_offset() + vio_chain_dim(i)] = b[i];
         for (int j = 0; j <= i; ++j) {
             int p1, p2;
             vio_chain_entry_pos(i, j, &p1, &p2);

@@ -20,12 +20,52 @@
 #define CH_STAMP(slot) do { } while (0)
 #endif
 
+#ifdef VIO_STAMPS
+__device__ unsigned long long *g_ch_dbg = nullptr;
+__device__ unsigned long long g_ch_t0 = 0;
+#define CH_TSTAMP(cond, slot) do { if ((cond) && g_ch_dbg && (threadIdx.x & 63) == 0) { g_ch_dbg[slot] = __builtin_amdgcn_s_memtime() - g_ch_t0; } } while (0)
+#else
+#define CH_TSTAMP(cond, slot) do { } while (0)
+#endif
 struct ChLane {         // per-lane offsets (doubles) inside a tile
     int oA0, oA2;       // A image of a 9-column tile: [row r16][k = g], + 4 for the second step, [row r16][8 or the padding column]
-    int oM0, oM2;       // B image of M_e / C image of a 9-column tile: [k = g][r16], + 40 per step; third step [8][r16] or M's padding
+    int oM0, oM2;       // B image of M_e / C image of a 9-column tile: [k = g][r16], + 4 rows per step; third step [8][r16] or M's padding
     int r16, g;
     bool r9;
 };
+
+// ---- structural zeros ----
+// SC[e][t] (camera tile t x speed-bias block e) is zero in the image unless the IMU factors or the prior couple them: block e reaches
+// the poses e-1, e, e+1 (two tiles), the prior's speed-bias block everything it was marginalised against.  The workers, idle during
+// level 0, test the 55 tiles (ch_scan_tiles); after barrier 0 every wave derives the tiles that are non-zero WHEN BLOCK e IS
+// ELIMINATED — its own and, through the fill, those of the blocks before it in its chain — as one 64-bit mask (bit 5 e + t) in scalar
+// registers (ch_eff_mask).  A zero tile has a zero L: its product, its fill, its camera-block terms, its right-hand-side term and its
+// back-substitution term are skipped, exactly.
+__device__ __forceinline__ void ch_scan_tiles(double *P, int wi, int lane) {
+    int *sNZ = (int *)(P + CH_OFF_NZ);
+    for (int tile = wi; tile < 55; tile += 14) {
+        const double *t = P + CH_OFF_SC + tile * CH_SCSZ;
+        bool nz = t[lane] != 0.0 || t[lane + 64] != 0.0;
+        if (lane + 128 < CH_SCSZ) nz = nz || t[lane + 128] != 0.0;
+        const unsigned long long any = __ballot(nz);
+        if (lane == 0) sNZ[tile] = any != 0ull ? 1 : 0;
+    }
+}
+__device__ __forceinline__ unsigned long long ch_eff_mask(const double *P, int lane) {
+    const int *sNZ = (const int *)(P + CH_OFF_NZ);
+    const unsigned long long nz = __ballot(lane < 55 && sNZ[min(lane, 54)] != 0);
+    unsigned long long eff = 0ull;
+    unsigned a = 0, b = 0;
+    for (int e = 0; e < 5; ++e) {
+        a |= (unsigned)(nz >> (5 * e)) & 31u;
+        b |= (unsigned)(nz >> (5 * (10 - e))) & 31u;
+        eff |= (unsigned long long)a << (5 * e);
+        eff |= (unsigned long long)b << (5 * (10 - e));
+    }
+    eff |= (unsigned long long)(((unsigned)(nz >> 25) & 31u) | a | b) << 25;
+    return eff;
+}
+__device__ __forceinline__ bool ch_bit(unsigned long long eff, int e, int t) { return (eff >> (5 * e + t)) & 1ull; }
 
 // the chain wave's work of one level: F(e), pivots, L_SO[e] = (SO[e] M_e) / d formed transposed — the accumulator is the operand
 // image of the update that follows — and (upd) SD[n] -= (L D) L^T from registers.  e == 5: F only.
@@ -38,9 +78,9 @@ __device__ __forceinline__ void ch_chain_level(double *P, const ChLane &L, int e
     const double *mm = P + ch_sm(e);
     double *td = P + ch_sd(n);
     const double a0 = tt[L.oA0], a1 = tt[L.oA0 + 4], a2 = tt[L.oA2];
-    const double b0 = mm[L.oM0], b1 = mm[L.oM0 + 40], b2 = mm[L.oM2];
+    const double b0 = mm[L.oM0], b1 = mm[L.oM0 + 4 * CH_TS], b2 = mm[L.oM2];
     const double p0 = sD[e * 16 + L.g], p1 = sD[e * 16 + L.g + 4], p2 = sD[e * 16 + L.g + 8];
-    ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {td[L.oM0], td[L.oM0 + 40], td[L.oM0 + 80], 0.0};
+    ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {td[L.oM0], td[L.oM0 + 4 * CH_TS], td[L.oM0 + 8 * CH_TS], 0.0};
     __builtin_amdgcn_sched_barrier(0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc, 0, 0, 0);       // (A M)^T: [k = g + 4v][row r16]
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc, 0, 0, 0);
@@ -53,7 +93,7 @@ __device__ __forceinline__ void ch_chain_level(double *P, const ChLane &L, int e
         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[0], -l0, acc2, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[1], -l1, acc2, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u2, -l2, acc2, 0, 0, 0);
-        if (L.r9) { td[L.oM0] = acc2[0]; td[L.oM0 + 40] = acc2[1]; if (L.g == 0) td[L.oM0 + 80] = acc2[2]; }
+        if (L.r9) { td[L.oM0] = acc2[0]; td[L.oM0 + 4 * CH_TS] = acc2[1]; if (L.g == 0) td[L.oM0 + 8 * CH_TS] = acc2[2]; }
     }
 }
 // F on a camera tile (np = 16, or 8 for the last one): M to sM, the pivots to sDp[0 .. np)
@@ -71,7 +111,7 @@ __device__ __forceinline__ void ch_fused(double *P, const ChLane &L, int t, ps_v
     double *tt = P + ch_sc(E, 0) + t * CH_SCSZ;
     const double *mm = P + ch_sm(E);
     const double a0 = tt[L.oA0], a1 = tt[L.oA0 + 4], a2 = tt[L.oA2];
-    const double b0 = mm[L.oM0], b1 = mm[L.oM0 + 40], b2 = mm[L.oM2];
+    const double b0 = mm[L.oM0], b1 = mm[L.oM0 + 4 * CH_TS], b2 = mm[L.oM2];
     const double p0 = sD[E * 16 + L.g], p1 = sD[E * 16 + L.g + 4], p2 = sD[E * 16 + L.g + 8];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     if (FILL) { const double *so = P + ch_so(E); s0 = so[L.oA0]; s1 = so[L.oA0 + 4]; s2 = so[L.oA2]; }
@@ -91,34 +131,90 @@ __device__ __forceinline__ void ch_fused(double *P, const ChLane &L, int t, ps_v
     }
 }
 __device__ __forceinline__ void ch_ld_c9(const double *tc, const ChLane &L, ps_v4d &acc) {        // C image of a 16 x 9 tile
-    acc[0] = tc[L.oM0]; acc[1] = tc[L.oM0 + 40]; acc[2] = tc[L.oM0 + 80]; acc[3] = tc[L.oM0 + 120];
+    acc[0] = tc[L.oM0]; acc[1] = tc[L.oM0 + 4 * CH_TS]; acc[2] = tc[L.oM0 + 8 * CH_TS]; acc[3] = tc[L.oM0 + 12 * CH_TS];
 }
 __device__ __forceinline__ void ch_st_c9(double *tc, const ChLane &L, const ps_v4d &acc) {
-    if (L.r9) { tc[L.oM0] = acc[0]; tc[L.oM0 + 40] = acc[1]; tc[L.oM0 + 80] = acc[2]; tc[L.oM0 + 120] = acc[3]; }
+    if (L.r9) { tc[L.oM0] = acc[0]; tc[L.oM0 + 4 * CH_TS] = acc[1]; tc[L.oM0 + 8 * CH_TS] = acc[2]; tc[L.oM0 + 12 * CH_TS] = acc[3]; }
 }
-// acc (C image of CC(I,J)) -= (L_SC[E][I] D_E) L_SC[E][J]^T
-template <int E>
-__device__ __forceinline__ void ch_cc_term(const double *P, const ChLane &L, int I, int J, ps_v4d &acc) {
-    const double *sD = P + CH_OFF_D;
-    const double *ta = P + ch_sc(E, 0) + I * CH_SCSZ, *tb = P + ch_sc(E, 0) + J * CH_SCSZ;
+// acc (C image of CC(I,J)) -= (L_SC[e][I] D_e) L_SC[e][J]^T
+__device__ __forceinline__ void ch_cc_term(const double *P, const ChLane &L, int e, int I, int J, ps_v4d &acc) {
+    const double *sD = P + CH_OFF_D + e * 16;
+    const double *ta = P + ch_sc(e, 0) + I * CH_SCSZ, *tb = P + ch_sc(e, 0) + J * CH_SCSZ;
     const double a0 = ta[L.oA0], a1 = ta[L.oA0 + 4], a2 = ta[L.oA2];
     const double b0 = tb[L.oA0], b1 = tb[L.oA0 + 4], b2 = tb[L.oA2];
-    const double p0 = sD[E * 16 + L.g], p1 = sD[E * 16 + L.g + 4], p2 = sD[E * 16 + L.g + 8];
+    const double p0 = sD[L.g], p1 = sD[L.g + 4], p2 = sD[L.g + 8];
     __builtin_amdgcn_sched_barrier(0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * p0, -b0, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * p1, -b1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * p2, -b2, acc, 0, 0, 0);
 }
-// CC(I,J) -= the terms of level PL (blocks PL and 10 - PL; PL == 5: block 5 alone), task = I (I + 1) / 2 + J
-template <int PL>
-__device__ __forceinline__ void ch_cc_task(double *P, const ChLane &L, int task) {
-    const int I = (task >= 1) + (task >= 3) + (task >= 6) + (task >= 10), J = task - I * (I + 1) / 2;
+// Which camera tiles take the chain's terms level by level, and which later.  A tile (I,J) is first CONSUMED at the S phase of
+// camera step K = J (I > J: multiplied by M_J) or K = J - 1 (I == J: wave 0 updates it from registers and factors it); until then
+// additions to it commute.  Only the six tiles consumed by step 0 — column 0 and (1,1) — take the speed-bias chain's terms during
+// the chain (ch_cc_early: tasks 0..5); the other nine take all eleven blocks' terms in one go in the U phase before their
+// consumption (ch_cc_deferred), when fourteen waves have nothing else to do while wave 0 factors a 16 x 16 tile.
+__device__ __forceinline__ int ch_early_tile(int q) { return q == 0 ? 0 : (q == 1 ? 1 : (q == 2 ? 2 : (q == 3 ? 3 : (q == 4 ? 6 : 10)))); }    // (0,0) (1,0) (1,1) (2,0) (3,0) (4,0)
+__device__ __forceinline__ void ch_tile_ij(int task, int &I, int &J) { I = (task >= 1) + (task >= 3) + (task >= 6) + (task >= 10); J = task - I * (I + 1) / 2; }
+// early tile q: the terms of level pl (blocks pl and 10 - pl; pl == 5: block 5 alone), those whose two L tiles are non-zero
+__device__ __forceinline__ void ch_cc_early(double *P, const ChLane &L, int q, int pl, unsigned long long eff) {
+    const int task = ch_early_tile(q);
+    int I, J;
+    ch_tile_ij(task, I, J);
+    const bool ta = ch_bit(eff, pl, I) && ch_bit(eff, pl, J), tb = pl < 5 && ch_bit(eff, 10 - pl, I) && ch_bit(eff, 10 - pl, J);
+    if (!ta && !tb) return;
     double *tc = P + ch_cc(0, 0) + task * PS_TS + L.g * PS_TROW + L.r16;
     ps_v4d acc;
     acc[0] = tc[0]; acc[1] = tc[4 * PS_TROW]; acc[2] = tc[8 * PS_TROW]; acc[3] = tc[12 * PS_TROW];
-    ch_cc_term<PL>(P, L, I, J, acc);
-    if (PL < 5) ch_cc_term<10 - PL>(P, L, I, J, acc);
+    if (ta) ch_cc_term(P, L, pl, I, J, acc);
+    if (tb) ch_cc_term(P, L, 10 - pl, I, J, acc);
     tc[0] = acc[0]; tc[4 * PS_TROW] = acc[1]; tc[8 * PS_TROW] = acc[2]; tc[12 * PS_TROW] = acc[3];
+}
+// acc (C image of tile (I,J)) -= the terms of the speed-bias blocks whose L tiles I and J are both non-zero, in elimination order
+// (0, 10, 1, 9, ..., 4, 6, 5).  The blocks are compacted into a list (4 bits each, scalar); the operands of block i + 2 are requested
+// before the products of block i are issued (three register sets: an LDS round trip takes longer than one block's three products).
+__device__ __forceinline__ void ch_cc_deferred_terms(const double *P, const ChLane &L, int I, int J, ps_v4d &acc, unsigned long long eff) {
+    const double *sD = P + CH_OFF_D;
+    const double *pa = P + ch_sc(0, 0) + I * CH_SCSZ, *pb = P + ch_sc(0, 0) + J * CH_SCSZ;
+    unsigned long long list = 0ull;
+    int n = 0;
+    for (int i = 0; i < 11; ++i) {
+        const int e = (i == 10) ? 5 : ((i & 1) ? 10 - (i >> 1) : (i >> 1));
+        if (ch_bit(eff, e, I) && ch_bit(eff, e, J)) { list |= (unsigned long long)e << (4 * n); ++n; }
+    }
+    if (n == 0) return;
+    double a[3][3], b[3][3], p[3][3];
+#define CH_DEF_E(i) ((int)((list >> (4 * (i))) & 15ull))
+#define CH_DEF_LD(S, E) do { const int e__ = (E); const double *ta__ = pa + e__ * 5 * CH_SCSZ, *tb__ = pb + e__ * 5 * CH_SCSZ;  \
+        a[S][0] = ta__[L.oA0]; a[S][1] = ta__[L.oA0 + 4]; a[S][2] = ta__[L.oA2];                                                \
+        b[S][0] = tb__[L.oA0]; b[S][1] = tb__[L.oA0 + 4]; b[S][2] = tb__[L.oA2];                                                \
+        p[S][0] = sD[e__ * 16 + L.g]; p[S][1] = sD[e__ * 16 + L.g + 4]; p[S][2] = sD[e__ * 16 + L.g + 8]; } while (0)
+#define CH_DEF_MM(S) do {                                                                                                       \
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[S][0] * p[S][0], -b[S][0], acc, 0, 0, 0);                                  \
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[S][1] * p[S][1], -b[S][1], acc, 0, 0, 0);                                  \
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[S][2] * p[S][2], -b[S][2], acc, 0, 0, 0); } while (0)
+    CH_DEF_LD(0, CH_DEF_E(0));
+    if (n > 1) CH_DEF_LD(1, CH_DEF_E(1));
+    for (int i = 0; i < n; i += 3) {
+        if (i + 2 < n) CH_DEF_LD(2, CH_DEF_E(i + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        CH_DEF_MM(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < n) {
+            if (i + 3 < n) CH_DEF_LD(0, CH_DEF_E(i + 3));
+            __builtin_amdgcn_sched_barrier(0);
+            CH_DEF_MM(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (i + 2 < n) {
+            if (i + 4 < n) CH_DEF_LD(1, CH_DEF_E(i + 4));
+            __builtin_amdgcn_sched_barrier(0);
+            CH_DEF_MM(2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef CH_DEF_E
+#undef CH_DEF_LD
+#undef CH_DEF_MM
 }
 // y_C -= L_SC[E] w_E for the rows of this lane (80 rows: lane, and 64 + lane for lane < 16)
 template <int E>
@@ -177,66 +273,82 @@ __device__ __forceinline__ void ch_rhs_phase(double *P, int lane) {
             sY[5 * 16 + k] = y;
         }
     }
-    if (LEV > 0) {
-        ch_yc_term<LEV - 1>(P, lane);
-        ch_yc_term<11 - LEV>(P, lane);
+}
+// y_C -= L_SC[e] w_e for the 16 rows of camera tile t (lanes 0..15)
+__device__ __forceinline__ void ch_yc_tile(double *P, int e, int t, int lane) {
+    if (lane < 16) {
+        double *sY = P + CH_OFF_Y;
+        const double *l = P + ch_sc(e, 0) + t * CH_SCSZ + lane * CH_TS;
+        double y = sY[CH_YC + 16 * t + lane];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) y = fma(-l[k], sY[e * 16 + k], y);
+        sY[CH_YC + 16 * t + lane] = y;
     }
 }
 
 // what the workers (waves 2..15, wi = wave - 2) do after barrier LEV
 template <int LEV>
-__device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int wi, int lane) {
+__device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int wi, int lane, unsigned long long eff) {
     constexpr int eA = LEV, eB = 10 - LEV;
     if (wi == 13) { ch_rhs_phase<LEV>(P, lane); return; }
     int first_cc, busy;
     if (LEV < 4) {
         busy = wi < 10;
         if (wi < 5) {
-            ps_v4d acc2;
-            ch_ld_c9(P + ch_sc(eA + 1, 0) + wi * CH_SCSZ, L, acc2);
-            ch_fused<eA, true>(P, L, wi, acc2);
-            ch_st_c9(P + ch_sc(eA + 1, 0) + wi * CH_SCSZ, L, acc2);
+            if (ch_bit(eff, eA, wi)) {
+                ps_v4d acc2;
+                ch_ld_c9(P + ch_sc(eA + 1, 0) + wi * CH_SCSZ, L, acc2);
+                ch_fused<eA, true>(P, L, wi, acc2);
+                ch_st_c9(P + ch_sc(eA + 1, 0) + wi * CH_SCSZ, L, acc2);
+            }
         } else if (wi < 10) {
-            ps_v4d acc2;
-            ch_ld_c9(P + ch_sc(eB - 1, 0) + (wi - 5) * CH_SCSZ, L, acc2);
-            ch_fused<eB, true>(P, L, wi - 5, acc2);
-            ch_st_c9(P + ch_sc(eB - 1, 0) + (wi - 5) * CH_SCSZ, L, acc2);
+            if (ch_bit(eff, eB, wi - 5)) {
+                ps_v4d acc2;
+                ch_ld_c9(P + ch_sc(eB - 1, 0) + (wi - 5) * CH_SCSZ, L, acc2);
+                ch_fused<eB, true>(P, L, wi - 5, acc2);
+                ch_st_c9(P + ch_sc(eB - 1, 0) + (wi - 5) * CH_SCSZ, L, acc2);
+            }
         }
         first_cc = wi >= 10 ? wi - 10 : wi + 3;           // the three idle workers take the first tasks, and 13 / 14 after them
     } else {
         busy = wi < 5;
         if (wi < 5) {
             if (LEV == 4) {                               // both chains fill SC[5][t]: one wave, chain A's term first
-                ps_v4d acc2;
-                ch_ld_c9(P + ch_sc(5, 0) + wi * CH_SCSZ, L, acc2);
-                ch_fused<4, true>(P, L, wi, acc2);
-                ch_fused<6, true>(P, L, wi, acc2);
-                ch_st_c9(P + ch_sc(5, 0) + wi * CH_SCSZ, L, acc2);
-            } else {
+                if (ch_bit(eff, 4, wi) || ch_bit(eff, 6, wi)) {
+                    ps_v4d acc2;
+                    ch_ld_c9(P + ch_sc(5, 0) + wi * CH_SCSZ, L, acc2);
+                    if (ch_bit(eff, 4, wi)) ch_fused<4, true>(P, L, wi, acc2);
+                    if (ch_bit(eff, 6, wi)) ch_fused<6, true>(P, L, wi, acc2);
+                    ch_st_c9(P + ch_sc(5, 0) + wi * CH_SCSZ, L, acc2);
+                }
+            } else if (ch_bit(eff, 5, wi)) {
                 ps_v4d dummy = {0.0, 0.0, 0.0, 0.0};
                 ch_fused<5, false>(P, L, wi, dummy);
             }
         }
         first_cc = wi >= 5 ? wi - 5 : wi + 8;             // eight idle workers: tasks 0..7 and 8..14 after them
     }
+    if (LEV > 0 && wi < 5) {
+        // the right-hand side rows of camera tile wi: the terms of the previous level's blocks (their w came out one phase ago)
+        if (ch_bit(eff, LEV - 1, wi)) ch_yc_tile(P, LEV - 1, wi, lane);
+        if (ch_bit(eff, 11 - LEV, wi)) ch_yc_tile(P, 11 - LEV, wi, lane);
+    }
     if (LEV > 0) {
-        // the camera-block terms of the previous level
-        if (LEV < 4) {
-            ch_cc_task<LEV - 1>(P, L, first_cc);
-            if (wi == 10 || wi == 11) ch_cc_task<LEV - 1>(P, L, wi + 3);
-        } else {
-            if (!busy) {
-                ch_cc_task<LEV - 1>(P, L, first_cc);
-                if (first_cc + 8 < 15) ch_cc_task<LEV - 1>(P, L, first_cc + 8);
-            }
+        // the camera-block terms of the previous level, for the six tiles step 0 consumes: two each on three waves without a fused task
+        const int idle0 = (LEV < 4) ? 10 : 5;
+        if (wi >= idle0 && wi < idle0 + 3) {
+            ch_cc_early(P, L, 2 * (wi - idle0), LEV - 1, eff);
+            ch_cc_early(P, L, 2 * (wi - idle0) + 1, LEV - 1, eff);
         }
     }
+    (void)first_cc;
     (void)busy;
 }
 
 __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsigned long long *dbg = nullptr) {
 #ifdef VIO_STAMPS
     const unsigned long long t_start__ = __builtin_amdgcn_s_memtime();
+    if (tid == 0) { g_ch_dbg = dbg; g_ch_t0 = t_start__; }
 #endif
     const int lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -249,6 +361,7 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
     L.oM0 = g * CH_TS + r16; L.oM2 = (g == 0) ? 8 * CH_TS + r16 : 8 * CH_TS + 9;
 
     // ================= speed-bias chain =================
+    unsigned long long eff = 0ull;
     if (uwave < 2) {
         // the two chain waves: wave 0 blocks 0..4 and then 5, wave 1 blocks 10..6 (one copy of the code, the block a run-time value)
         const int dir = uwave == 0 ? 1 : -1;
@@ -261,11 +374,11 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
                     const double *so = P + ch_so(6);
                     const double a0 = so[L.oA0], a1 = so[L.oA0 + 4], a2 = so[L.oA2];
                     const double p0 = sD[6 * 16 + g], p1 = sD[6 * 16 + g + 4], p2 = sD[6 * 16 + g + 8];
-                    ps_v4d acc = {td[L.oM0], td[L.oM0 + 40], td[L.oM0 + 80], 0.0};
+                    ps_v4d acc = {td[L.oM0], td[L.oM0 + 4 * CH_TS], td[L.oM0 + 8 * CH_TS], 0.0};
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * p0, -a0, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * p1, -a1, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * p2, -a2, acc, 0, 0, 0);
-                    if (r9) { td[L.oM0] = acc[0]; td[L.oM0 + 40] = acc[1]; if (g == 0) td[L.oM0 + 80] = acc[2]; }
+                    if (r9) { td[L.oM0] = acc[0]; td[L.oM0 + 4 * CH_TS] = acc[1]; if (g == 0) td[L.oM0 + 8 * CH_TS] = acc[2]; }
                 }
                 ch_chain_level(P, L, e, e + dir, !(uwave == 1 && lev == 4), lane);
                 if (uwave == 0) CH_STAMP(64 + 4 * lev);
@@ -273,21 +386,24 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
             __syncthreads();
             if (uwave == 0) CH_STAMP(65 + 4 * lev);
         }
+        eff = ch_eff_mask(P, lane);
         __syncthreads();
     } else {
         const int wi = uwave - 2;
+        ch_scan_tiles(P, wi, lane);                                // (nothing else to do during level 0)
         __syncthreads();                                           // barrier 0: level 0 is out
-        ch_worker_phase<0>(P, L, wi, lane); if (uwave == 2) CH_STAMP(112);
+        eff = ch_eff_mask(P, lane);
+        ch_worker_phase<0>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(112);
         __syncthreads();
-        ch_worker_phase<1>(P, L, wi, lane); if (uwave == 2) CH_STAMP(113);
+        ch_worker_phase<1>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(113);
         __syncthreads();
-        ch_worker_phase<2>(P, L, wi, lane); if (uwave == 2) CH_STAMP(114);
+        ch_worker_phase<2>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(114); CH_STAMP(140 + uwave);
         __syncthreads();
-        ch_worker_phase<3>(P, L, wi, lane); if (uwave == 2) CH_STAMP(115);
+        ch_worker_phase<3>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(115);
         __syncthreads();
-        ch_worker_phase<4>(P, L, wi, lane); if (uwave == 2) CH_STAMP(116);
+        ch_worker_phase<4>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(116);
         __syncthreads();
-        ch_worker_phase<5>(P, L, wi, lane); if (uwave == 2) CH_STAMP(117);
+        ch_worker_phase<5>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(117);
         __syncthreads();
     }
     if (uwave == 0) CH_STAMP(87);
@@ -301,14 +417,14 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
         ps_v4d acc;
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[v] = tc[4 * PS_TROW * v];
-        ch_cc_term<5>(P, L, 0, 0, acc);
+        if (ch_bit(eff, 5, 0)) ch_cc_term(P, L, 5, 0, 0, acc);
 #pragma unroll
         for (int v = 0; v < 4; ++v) tc[4 * PS_TROW * v] = acc[v];
         ch_factor_tile(P + ch_cc(0, 0), sMc, sD + CH_YC, 16, lane);
     } else if (uwave == 15) {
         ch_yc_term<5>(P, lane);
-    } else if (uwave >= 1) {
-        ch_cc_task<5>(P, L, uwave);            // tasks 1..14
+    } else if (uwave >= 1 && uwave <= 5) {
+        ch_cc_early(P, L, uwave, 5, eff);      // (1,0) (1,1) (2,0) (3,0) (4,0)
     }
     if (uwave == 0) CH_STAMP(88);
     __syncthreads();
@@ -388,12 +504,15 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
             for (int t = uwave; t < nitem; t += 15) {
                 if (t < ntile) {
                     const int ii = (t >= 1) + (t >= 3) + (t >= 6), jj = t - ii * (ii + 1) / 2;
-                    const double *ta = P + ch_cc(K + 1 + ii, K) + lofs, *tb = P + ch_cc(K + 1 + jj, K) + lofs;
-                    double *tc = P + ch_cc(K + 1 + ii, K + 1 + jj) + cofs;
+                    const int ti = K + 1 + ii, tj = K + 1 + jj;
+                    const double *ta = P + ch_cc(ti, K) + lofs, *tb = P + ch_cc(tj, K) + lofs;
+                    double *tc = P + ch_cc(ti, tj) + cofs;
                     double av[4], bv[4], dk[4];
                     ps_v4d acc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { av[q] = ta[4 * q]; bv[q] = tb[4 * q]; acc[q] = tc[4 * PS_TROW * q]; dk[q] = sD[d0 + g + 4 * q]; }
+                    // the speed-bias chain's terms, if this tile is consumed next (off-diagonal: at step tj; diagonal: at step tj - 1)
+                    if (tj >= 1 && !(ti == 1 && tj == 1) && K == (ti == tj ? tj - 2 : tj - 1)) ch_cc_deferred_terms(P, L, ti, tj, acc, eff);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q] * dk[q], -bv[q], acc, 0, 0, 0);
@@ -447,7 +566,7 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
         if (!isC) {
             const double *src = P + ch_sc(e, 4) + g * CH_TS + k9;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) lq[v] = src[4 * v * CH_TS];
+            for (int v = 0; v < 4; ++v) lq[v] = ch_bit(eff, e, 4) ? src[4 * v * CH_TS] : 0.0;
             if (e != 5) {
                 // G_e = M_e L_SO[e]^T (x_e = M_e v_e - G_e x_succ): entries (k9, j = g, g + 4, g + 8), formed while the camera tiles resolve
                 const double *m = P + ch_sm(e) + k9 * CH_TS, *so = P + ch_so(e);
@@ -475,10 +594,12 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
                     else { double x; PS_DOT16(x, 0.0, own_v - acc, mw); sX[CH_YC + 16 * K + r16] = x; }
                 }
             } else {
-                const double *xj = sX + CH_YC + 16 * J + g;
+                if (ch_bit(eff, e, J)) {
+                    const double *xj = sX + CH_YC + 16 * J + g;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) sacc = fma(lq[v], xj[4 * v], sacc);
-                if (J > 0) {
+                    for (int v = 0; v < 4; ++v) sacc = fma(lq[v], xj[4 * v], sacc);
+                }
+                if (J > 0 && ch_bit(eff, e, J - 1)) {
                     const double *src = P + ch_sc(e, J - 1) + g * CH_TS + k9;
 #pragma unroll
                     for (int v = 0; v < 4; ++v) lq[v] = src[4 * v * CH_TS];
@@ -490,7 +611,7 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
         if (uwave == 0) CH_STAMP(111);
         // the four quarters of every block's sum meet in LDS: lanes k, 16 + k, 32 + k, 48 + k of the
         // owner, added in that order; then v_e = w_e / d_e - sum and g_e = M_e v_e (x_5 = g_5)
-        double *scr = P + CH_OFF_SCR;
+        double *scr = P + CH_OFF_SD;           // (the diagonal blocks of the chain are dead by now)
         if (!isC) {
             scr[e * 64 + lane] = sacc;
             __builtin_amdgcn_wave_barrier();

@@ -2492,6 +2492,7 @@ void vio_launch_chain_solve_test(const double *img, double lambda, double *x_nat
     hipLaunchKernelGGL(k_chain_solve_test, dim3(1), dim3(PS_THREADS), CH_LDS_CORE * sizeof(double), s, img, lambda, x_nat, lds_dump);
 }
 int vio_chain_image_doubles() { return CH_PACKED; }
+int vio_chain_y_offset() { return CH_OFF_Y; }
 int vio_chain_lds_core_doubles() { return CH_LDS_CORE; }
 void vio_chain_entry_pos(int i, int j, int *p1, int *p2) { ch_entry_pos(i, j, *p1, *p2); }
 int vio_chain_dim(int i) { return ch_dim(i); }

@@ -18,20 +18,21 @@
 // (L D) L^T.
 //
 // Storage (doubles; the image k_assemble_chain writes to T.Pg and this kernel copies into LDS):
-//   SC[e][t]   16 x 9 (row stride 10)   camera tile t (rows) x speed-bias block e (columns)          55 tiles
-//   SO[e]       9 x 9 (row stride 10)   succ(e) (rows) x e (columns), succ(e) = e + 1 (e < 5), e - 1 (e > 5)   10 tiles
-//   SD[e]       9 x 9 (row stride 10)   diagonal block of S_e                                         11 tiles
+//   SC[e][t]   16 x 9 (row stride 11)   camera tile t (rows) x speed-bias block e (columns)          55 tiles
+//   SO[e]       9 x 9 (row stride 11)   succ(e) (rows) x e (columns), succ(e) = e + 1 (e < 5), e - 1 (e > 5)   10 tiles
+//   SD[e]       9 x 9 (row stride 11)   diagonal block of S_e                                         11 tiles
 //   CC[I][J]   16 x 16 (row stride 17)  camera tiles, I >= J                                          15 tiles
 //   Y          yS[11][16] | yC[80]      right-hand side in "chain dimension" order
-// Row stride 10 keeps both MFMA operand images of a 9-column tile free of LDS bank conflicts (A image: rows * 10 are 16
-// distinct even residues mod 32; C image: two rows of 9 at distance 10).
+// Row stride 11 (odd) keeps both MFMA operand images of a 9-column tile free of LDS bank conflicts: a quarter-wave of an A-image
+// read is 16 rows of one column, 11 r mod 16 distinct (stride 10 put rows r and r + 8 into the same banks: measured, round 4);
+// a C-image access is 16 consecutive columns of one row.  Columns 9 and 10 are padding: zero in the image, never written.
 #ifndef VIO_POSE_SOLVE_CHAIN_H
 #define VIO_POSE_SOLVE_CHAIN_H
 
 #define CH_NS 11
-#define CH_TS 10
-#define CH_SCSZ 160
-#define CH_S9SZ 90
+#define CH_TS 11            // row stride of a 9-column tile: odd, so that the 16 rows of an operand image fall into 16 different bank pairs
+#define CH_SCSZ (16 * CH_TS)
+#define CH_S9SZ (9 * CH_TS)
 #define CH_OFF_SC 0
 #define CH_OFF_SO (CH_OFF_SC + CH_NS * 5 * CH_SCSZ)        // 8800
 #define CH_OFF_SD (CH_OFF_SO + 10 * CH_S9SZ)                // 9700
@@ -39,16 +40,17 @@
 #define CH_OFF_Y (CH_OFF_CC + 15 * PS_TS)                   // 14770
 #define CH_YC 176                                           // dimension index of camera variable 0
 #define CH_NDIM 256
-#define CH_PACKED (CH_OFF_Y + CH_NDIM)                      // 15026: what travels through HBM
-#define CH_SET_STRIDE 15040
-#define CH_OFF_SM CH_PACKED                                 // LDS only: M_e = L_ee^-T of every speed-bias block, 9 x 9 (stride 10)
+#define CH_PACKED ((CH_OFF_Y + CH_NDIM + 1) & ~1)             // what travels through HBM (an even count: copied as double2)
+#define CH_SET_STRIDE 16128
+#define CH_OFF_SM CH_PACKED                                 // LDS only: M_e = L_ee^-T of every speed-bias block, 9 x 9 (stride 11)
 #define CH_OFF_MC (CH_OFF_SM + CH_NS * CH_S9SZ)             // 16 x 17: M_K of the camera tile being factored
 #define CH_OFF_D (CH_OFF_MC + PS_TS)                        // [256] pivots by dimension
 #define CH_OFF_X (CH_OFF_D + CH_NDIM)                       // [256] solution by dimension
 #define CH_OFF_I9 (CH_OFF_X + CH_NDIM)                      // 9 x 9 identity (stride 10): the rows F's second half-row of lanes starts from
 #define CH_OFF_I16 (CH_OFF_I9 + CH_S9SZ)                    // 16 x 16 identity (stride 17)
-#define CH_OFF_SCR (CH_OFF_I16 + PS_TS)                     // 11 x 64: the quarters of the speed-bias blocks' back-substitution sums
-#define CH_LDS_CORE (CH_OFF_SCR + CH_NS * 64)               // 17866
+#define CH_OFF_NZ (CH_OFF_I16 + PS_TS)                      // 64 ints: which SC tiles of the image hold a non-zero
+#define CH_LDS_CORE (CH_OFF_NZ + 32)
+static_assert(CH_NS * CH_S9SZ >= CH_NS * 64, "the back-substitution's scratch (11 x 64) lives in the SD tiles");
 static_assert(CH_PACKED % 2 == 0 && CH_SET_STRIDE >= CH_PACKED && CH_SET_STRIDE <= PS_SET_STRIDE, "chain image fits a set of Pg");
 
 __host__ __device__ inline int ch_sc(int e, int t) { return CH_OFF_SC + (e * 5 + t) * CH_SCSZ; }
