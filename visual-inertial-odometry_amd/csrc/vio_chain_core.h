@@ -540,88 +540,106 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
 
     // ================= back-substitution =================
     // x_col = M_col (w_col / d_col - sum_{J after col} L_{J,col}^T x_J).
-    // Camera tiles from the bottom: wave 11 + K owns tile K (lanes 0..15, lane = column), one barrier per tile.  Meanwhile wave e < 11
-    // owns speed-bias block e: with every x_J that comes out it adds its quarter of L_SC[e][J]^T x_J to a running sum (lane = (k, rows
-    // r = q mod 4)); at the end the four quarters are added, x_5 is finished by its owner, and waves 0 / 1 walk the two chains.
+    //   phase X   wave 15 alone resolves the camera tiles from the bottom, no barriers: 16-lane row K of the wave owns tile K (tile 4 first,
+    //             by row 3), x_J goes through LDS to the other rows (one write + one read per tile, in order inside a wave) and into the
+    //             16-term products by DPP.  Meanwhile wave e < 11 (owner of speed-bias block e) forms G_e = M_e L_SO[e]^T in the place of
+    //             L_SO[e] (only it reads or writes that tile now): x_e = M_e v_e - G_e x_succ(e).
+    //   phase Y   the owners: v_e = w_e / d_e - sum_t L_SC[e][t]^T x_C[t] (lane = (k, rows q mod 4), the quarters added in a fixed order),
+    //             g_e = M_e v_e (x_5 = g_5); waves 11 / 12 request the rows of G of their chain.
+    //   phase Z   waves 11 / 12 walk the two chains x_e = g_e - G_e x_succ(e) (e = 4..0, 6..10) out of registers, no barriers.
     {
-        const bool isC = uwave >= 11;
-        const int K = uwave - 11, e = uwave;
-        const bool work = lane < 16;
         const int k9 = min(r16, 8);
-        double acc = 0.0, mw[16], ucol[16], own_v = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { mw[j] = 0.0; ucol[j] = 0.0; }
-#define CH_LOAD_COL_C(I_, K_) do { const double *src__ = P + ch_cc((I_), (K_)) + r16; _Pragma("unroll") for (int r = 0; r < 16; ++r) ucol[r] = src__[r * PS_TROW]; } while (0)
-        if (isC && work) {
-            const double *src = P + ch_cc(K, K) + r16 * PS_TROW;                 // row r16 of M_K (the tile's diagonal still holds the pivots)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) mw[j] = (j == r16) ? 1.0 : src[j];
+        if (uwave == 15) {
+            const int K = g;                                                         // the tile of this 16-lane row (0..3)
+            double mw[16], ucol[16];
             const double dd = sD[CH_YC + 16 * K + r16];
-            own_v = d_div(sY[CH_YC + 16 * K + r16], dd, d_fast_rcp(dd));
-            if (K == 4) { double x; PS_DOT16(x, 0.0, own_v, mw); sX[CH_YC + 64 + r16] = x; }
-            else CH_LOAD_COL_C(4, K);
-        }
-        // speed-bias owners: rows r = g, g + 4, g + 8, g + 12 of the tile, column k9
-        double sacc = 0.0, lq[4], gk[3];
-        if (!isC) {
-            const double *src = P + ch_sc(e, 4) + g * CH_TS + k9;
+            const double own_v = d_div(sY[CH_YC + 16 * K + r16], dd, d_fast_rcp(dd));
+            double acc = 0.0;
+            {   // x of tile 4, by row 3
+                const double *m4 = P + ch_cc(4, 4) + r16 * PS_TROW;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) lq[v] = ch_bit(eff, e, 4) ? src[4 * v * CH_TS] : 0.0;
-            if (e != 5) {
-                // G_e = M_e L_SO[e]^T (x_e = M_e v_e - G_e x_succ): entries (k9, j = g, g + 4, g + 8), formed while the camera tiles resolve
-                const double *m = P + ch_sm(e) + k9 * CH_TS, *so = P + ch_so(e);
+                for (int j = 0; j < 16; ++j) mw[j] = m4[j];
+                const double d4 = sD[CH_YC + 64 + r16];
+                const double v4 = d_div(sY[CH_YC + 64 + r16], d4, d_fast_rcp(d4));
+                double x;
+                PS_DOT16(x, 0.0, v4, mw);
+                if (g == 3) sX[CH_YC + 64 + r16] = x;
+                __builtin_amdgcn_wave_barrier();         // (other lanes read it: LDS is in order inside a wave, the compiler must keep it so)
+                asm volatile("" ::: "memory");
+            }
+            {
+                const double *src = P + ch_cc(K, K) + r16 * PS_TROW;                 // row r16 of M_K
 #pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    const int j = min(g + 4 * v, 8);
-                    double sum = 0.0;
+                for (int j = 0; j < 16; ++j) mw[j] = src[j];
+            }
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) sum = fma(m[i], so[j * CH_TS + i], sum);
-                    gk[v] = sum;
+            for (int J = 4; J >= 1; --J) {
+                // column r16 of L(J, K) for the rows K < J (the others read a valid tile and discard)
+                const double *src = P + ch_cc(J, min(K, J - 1)) + r16;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ucol[r] = src[r * PS_TROW];
+                const double xj = sX[CH_YC + 16 * J + r16];
+                PS_DOT16(acc, acc, xj, ucol);
+                if (J >= 1) {
+                    double x;
+                    PS_DOT16(x, 0.0, own_v - acc, mw);
+                    if (K == J - 1) sX[CH_YC + 16 * K + r16] = x;                    // tile J - 1 is complete
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
                 }
             }
-        }
-        __syncthreads();                                                             // x of tile 4 is out
-        if (!isC && e != 5 && r9) {         // (every lane has read L_SO[e]: the barrier above) G_e takes its place
-            double *so = P + ch_so(e) + k9 * CH_TS;
-            so[g] = gk[0]; so[g + 4] = gk[1];
-            if (g == 0) so[8] = gk[2];
-        }
-        for (int J = 4; J >= 0; --J) {
-            if (isC) {
-                if (work && K < J) {
-                    PS_DOT16(acc, acc, sX[CH_YC + 16 * J + r16], ucol);
-                    if (J > K + 1) CH_LOAD_COL_C(J - 1, K);
-                    else { double x; PS_DOT16(x, 0.0, own_v - acc, mw); sX[CH_YC + 16 * K + r16] = x; }
-                }
-            } else {
-                if (ch_bit(eff, e, J)) {
-                    const double *xj = sX + CH_YC + 16 * J + g;
+        } else if (uwave < 11 && uwave != 5) {
+            const int e = uwave;
+            const double *m = P + ch_sm(e) + k9 * CH_TS, *so = P + ch_so(e);
+            double gk[3];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) sacc = fma(lq[v], xj[4 * v], sacc);
-                }
-                if (J > 0 && ch_bit(eff, e, J - 1)) {
-                    const double *src = P + ch_sc(e, J - 1) + g * CH_TS + k9;
+            for (int v = 0; v < 3; ++v) {
+                const int j = min(g + 4 * v, 8);
+                double sum = 0.0;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) lq[v] = src[4 * v * CH_TS];
-                }
+                for (int i = 0; i < 9; ++i) sum = fma(m[i], so[j * CH_TS + i], sum);
+                gk[v] = sum;
             }
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (r9) {
+                double *sg = P + ch_so(e) + k9 * CH_TS;
+                sg[g] = gk[0]; sg[g + 4] = gk[1];
+                if (g == 0) sg[8] = gk[2];
+            }
         }
-#undef CH_LOAD_COL_C
         if (uwave == 0) CH_STAMP(111);
-        // the four quarters of every block's sum meet in LDS: lanes k, 16 + k, 32 + k, 48 + k of the
-        // owner, added in that order; then v_e = w_e / d_e - sum and g_e = M_e v_e (x_5 = g_5)
-        double *scr = P + CH_OFF_SD;           // (the diagonal blocks of the chain are dead by now)
-        if (!isC) {
+        __syncthreads();
+        // ---- phase Y ----
+        double gc[5][9], vc[5];
+        if (uwave == 11 || uwave == 12) {
+#pragma unroll
+            for (int s2 = 0; s2 < 5; ++s2) {
+                const int eb = (uwave == 11) ? 4 - s2 : 6 + s2;
+                const double *src = P + ch_so(eb) + k9 * CH_TS;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) gc[s2][j] = src[j];
+            }
+        } else if (uwave < 11) {
+            const int e = uwave;
+            double sacc = 0.0;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (ch_bit(eff, e, t)) {
+                    const double *src = P + ch_sc(e, t) + g * CH_TS + k9;
+                    const double *xj = sX + CH_YC + 16 * t + g;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) sacc = fma(src[4 * v * CH_TS], xj[4 * v], sacc);
+                }
+            }
+            double *scr = P + CH_OFF_SD;           // (the diagonal blocks of the chain are dead by now)
             scr[e * 64 + lane] = sacc;
             __builtin_amdgcn_wave_barrier();
-            double gv = 0.0;
-            if (work) {
+            if (lane < 16) {
                 const double c = ((scr[e * 64 + r16] + scr[e * 64 + 16 + r16]) + scr[e * 64 + 32 + r16]) + scr[e * 64 + 48 + r16];
                 const double dd = sD[e * 16 + k9];
                 const double v = d_div(sY[e * 16 + k9], dd, d_fast_rcp(dd)) - c;
                 const double *src = P + ch_sm(e) + k9 * CH_TS;
-                double m9[9];
+                double m9[9], gv;
 #pragma unroll
                 for (int j = 0; j < 9; ++j) m9[j] = (j < k9) ? 0.0 : src[j];
                 CH_DOT9(gv, 0.0, v, m9);
@@ -629,36 +647,19 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
             }
         }
         __syncthreads();
-        // the two chains, one wave each, no barriers: x_e = g_e - G_e x_succ(e), e = 4..0 on wave 0, 6..10 on wave 1; the rows of G and
-        // g_e of the next block are requested before the current product
-        if (uwave < 2 && work) {
+        // ---- phase Z ----
+        if ((uwave == 11 || uwave == 12) && lane < 16) {
             double xs = sX[5 * 16 + k9];
-            double gc[9], gn[9], vc, vn = 0.0;
-            {
-                const int eb = (uwave == 0) ? 4 : 6;
-                const double *src = P + ch_so(eb) + k9 * CH_TS;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) gc[j] = src[j];
-                vc = sX[eb * 16 + k9];
-            }
+            for (int s2 = 0; s2 < 5; ++s2) vc[s2] = sX[((uwave == 11) ? 4 - s2 : 6 + s2) * 16 + k9];
 #pragma unroll
-            for (int s2 = 1; s2 <= 5; ++s2) {
-                const int eb = (uwave == 0) ? 5 - s2 : 5 + s2;
-                if (s2 < 5) {
-                    const int en = (uwave == 0) ? eb - 1 : eb + 1;
-                    const double *src = P + ch_so(en) + k9 * CH_TS;
-#pragma unroll
-                    for (int j = 0; j < 9; ++j) gn[j] = src[j];
-                    vn = sX[en * 16 + k9];
-                }
+            for (int s2 = 0; s2 < 5; ++s2) {
+                const int eb = (uwave == 11) ? 4 - s2 : 6 + s2;
                 double t;
-                CH_DOT9(t, 0.0, xs, gc);
-                const double xn = vc - t;
+                CH_DOT9(t, 0.0, xs, gc[s2]);
+                const double xn = vc[s2] - t;
                 if (r9) sX[eb * 16 + r16] = xn;
                 xs = xn;
-#pragma unroll
-                for (int j = 0; j < 9; ++j) gc[j] = gn[j];
-                vc = vn;
             }
         }
         if (uwave == 0) CH_STAMP(63);
