@@ -51,5 +51,5 @@ for K in range(5):
     else:
         print("  K = 4: S done %6d (+%5d) | past B %6d" % (a[0], a[0] - prev, a[1]))
         prev = a[1]
-print("  deferred terms of tile (4,4): start %d, after 3 blocks %d, after 7 %d, after 11 (issued) %d" % tuple(int(v) for v in s[160:164]))
+print("  back-substitution detail: wave 15 camera tiles done %d | wave 13 trial poses + rotations done %d | wave 0 sums done %d, past barrier %d, pair rows issued %d | chain wave done %d" % tuple(int(v) for v in s[170:176]))
 print("back-substitution: starts %6d | camera rounds done %6d (+%5d) | chains done %6d (+%5d)" % (s[110], s[111], s[111] - s[110], s[63], s[63] - s[111]))

@@ -345,7 +345,11 @@ __device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int 
     (void)busy;
 }
 
-__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsigned long long *dbg = nullptr) {
+// What follows the solve for the camera variables (trial poses, pair table) need not wait for the speed-bias part of the solution:
+// mid1(lane) is called by wave 13 once the camera part is out (sX[CH_YC ..]; phase Y: it has nothing else to do), mid2(index, lane) one
+// barrier later by the fourteen waves that do not walk the chains (phase Z), index 0..13.
+template <typename Mid1, typename Mid2>
+__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 mid1, Mid2 mid2, unsigned long long *dbg = nullptr) {
 #ifdef VIO_STAMPS
     const unsigned long long t_start__ = __builtin_amdgcn_s_memtime();
     if (tid == 0) { g_ch_dbg = dbg; g_ch_t0 = t_start__; }
@@ -608,10 +612,11 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
             }
         }
         if (uwave == 0) CH_STAMP(111);
+        if (uwave == 15) CH_STAMP(170);
         __syncthreads();
-        // ---- phase Y ----
-        double gc[5][9], vc[5];
+        // ---- phases Y and Z (the two chain waves apart: their registers hold the rows of G) ----
         if (uwave == 11 || uwave == 12) {
+            double gc[5][9], vc[5];
 #pragma unroll
             for (int s2 = 0; s2 < 5; ++s2) {
                 const int eb = (uwave == 11) ? 4 - s2 : 6 + s2;
@@ -619,48 +624,58 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, unsign
 #pragma unroll
                 for (int j = 0; j < 9; ++j) gc[s2][j] = src[j];
             }
-        } else if (uwave < 11) {
-            const int e = uwave;
-            double sacc = 0.0;
+            __syncthreads();
+            if (lane < 16) {
+                double xs = sX[5 * 16 + k9];
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                if (ch_bit(eff, e, t)) {
-                    const double *src = P + ch_sc(e, t) + g * CH_TS + k9;
-                    const double *xj = sX + CH_YC + 16 * t + g;
+                for (int s2 = 0; s2 < 5; ++s2) vc[s2] = sX[((uwave == 11) ? 4 - s2 : 6 + s2) * 16 + k9];
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) sacc = fma(src[4 * v * CH_TS], xj[4 * v], sacc);
+                for (int s2 = 0; s2 < 5; ++s2) {
+                    const int eb = (uwave == 11) ? 4 - s2 : 6 + s2;
+                    double t;
+                    CH_DOT9(t, 0.0, xs, gc[s2]);
+                    const double xn = vc[s2] - t;
+                    if (r9) sX[eb * 16 + r16] = xn;
+                    xs = xn;
                 }
             }
-            double *scr = P + CH_OFF_SD;           // (the diagonal blocks of the chain are dead by now)
-            scr[e * 64 + lane] = sacc;
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 16) {
-                const double c = ((scr[e * 64 + r16] + scr[e * 64 + 16 + r16]) + scr[e * 64 + 32 + r16]) + scr[e * 64 + 48 + r16];
-                const double dd = sD[e * 16 + k9];
-                const double v = d_div(sY[e * 16 + k9], dd, d_fast_rcp(dd)) - c;
-                const double *src = P + ch_sm(e) + k9 * CH_TS;
-                double m9[9], gv;
+            if (uwave == 11) CH_STAMP(175);
+        } else {
+            if (uwave == 13) {
+                mid1(lane);
+                CH_STAMP(171);
+            } else if (uwave < 11) {
+                const int e = uwave;
+                double sacc = 0.0;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) m9[j] = (j < k9) ? 0.0 : src[j];
-                CH_DOT9(gv, 0.0, v, m9);
-                if (r9) sX[e * 16 + r16] = gv;
+                for (int t = 0; t < 5; ++t) {
+                    if (ch_bit(eff, e, t)) {
+                        const double *src = P + ch_sc(e, t) + g * CH_TS + k9;
+                        const double *xj = sX + CH_YC + 16 * t + g;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) sacc = fma(src[4 * v * CH_TS], xj[4 * v], sacc);
+                    }
+                }
+                double *scr = P + CH_OFF_SD;           // (the diagonal blocks of the chain are dead by now)
+                scr[e * 64 + lane] = sacc;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 16) {
+                    const double c = ((scr[e * 64 + r16] + scr[e * 64 + 16 + r16]) + scr[e * 64 + 32 + r16]) + scr[e * 64 + 48 + r16];
+                    const double dd = sD[e * 16 + k9];
+                    const double v = d_div(sY[e * 16 + k9], dd, d_fast_rcp(dd)) - c;
+                    const double *src = P + ch_sm(e) + k9 * CH_TS;
+                    double m9[9], gv;
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) m9[j] = (j < k9) ? 0.0 : src[j];
+                    CH_DOT9(gv, 0.0, v, m9);
+                    if (r9) sX[e * 16 + r16] = gv;
+                }
             }
-        }
-        __syncthreads();
-        // ---- phase Z ----
-        if ((uwave == 11 || uwave == 12) && lane < 16) {
-            double xs = sX[5 * 16 + k9];
-#pragma unroll
-            for (int s2 = 0; s2 < 5; ++s2) vc[s2] = sX[((uwave == 11) ? 4 - s2 : 6 + s2) * 16 + k9];
-#pragma unroll
-            for (int s2 = 0; s2 < 5; ++s2) {
-                const int eb = (uwave == 11) ? 4 - s2 : 6 + s2;
-                double t;
-                CH_DOT9(t, 0.0, xs, gc[s2]);
-                const double xn = vc[s2] - t;
-                if (r9) sX[eb * 16 + r16] = xn;
-                xs = xn;
-            }
+            if (uwave == 0) CH_STAMP(172);
+            __syncthreads();
+            if (uwave == 0) CH_STAMP(173);
+            mid2(uwave < 11 ? uwave : uwave - 2, lane);
+            if (uwave == 0) CH_STAMP(174);
         }
         if (uwave == 0) CH_STAMP(63);
         __syncthreads();

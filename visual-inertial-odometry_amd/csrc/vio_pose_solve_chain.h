@@ -340,13 +340,51 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) P[CH_OFF_SM + i] = 0.0;      // (the padding column of every M_e must read as zero)
     __syncthreads();
     CH_OUT(0);
-    ch_factor_solve(P, tid, T.dbg);
+    // The camera part of the step (poses, extrinsic) is known two phases before the speed-bias part: wave 13 forms the trial poses
+    // (UpdateStates, problem.cc:456-463; vertex_pose.cc:7-19) and their rotations while the speed-bias owners finish their sums, and the
+    // fourteen waves that do not walk the chains form the pair table of the trial states meanwhile (in the camera tiles' space, free once
+    // the camera part is solved).  The stepwise path (prior update here) keeps k_pose_solve's serial tail.
+    const bool prior_here = T.has_prior && !(T.gn_flags & 4);
+    const int lm_dim = T.lm_dim;
+    double *pairtab_trial = T.pairtab + trial * PAIRTAB_STRIDE;
+    double *pw = P + CH_OFF_CC;                                 // trial ext + poses at [0, 84), rotations at [96, 204)
+    auto mid1 = [&](int ln) {
+        if (prior_here) return;
+        if (ln < 12) {
+            const double *p = (ln == 0) ? sState + STATE_EXT : sState + STATE_POSE + 7 * (ln - 1);
+            const double *d = (ln == 0) ? sX + CH_YC + 66 : sX + CH_YC + 6 * (ln - 1);
+            double dd[6], tmp[7];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dd[k] = d[k];
+            d_pose_plus(p, dd, tmp);
+            double *q = (ln == 0) ? pw + STATE_EXT : pw + STATE_POSE + 7 * (ln - 1);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) q[k] = tmp[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        if (lm_dim != 3) d_pair_rotations(pw, pw + 96, ln);
+    };
+    auto mid2 = [&](int idx, int ln) {
+        if (prior_here || lm_dim == 3) return;
+        d_pair_rows(pw, pairtab_trial, pw + 96, ln + 64 * idx, 14 * 64);
+    };
+    ch_factor_solve(P, tid, mid1, mid2, T.dbg);
     CH_OUT(2);
     for (int i = tid; i < n; i += PS_THREADS) sDx[i] = sX[ch_dim(i)];
+    if (!prior_here) {
+        // the trial states: poses from wave 13's copy, speed-bias = current + dx
+        if (tid >= 128 && tid < 128 + 84) sState[tid - 128] = P[CH_OFF_CC + tid - 128];
+        else if (tid >= 256 && tid < 256 + 99) { const int e = tid - 256; sState[STATE_SB + e] += sX[(e / 9) * 16 + (e % 9 < 3 ? 6 + e % 9 : (e % 9 < 6 ? e % 9 : e % 9 - 6))]; }
+        __syncthreads();
+        if (tid >= 192 && tid < 192 + n) T.dx[tid - 192] = sDx[tid - 192];
+        if (tid >= 384 && tid < 384 + STATE_STRIDE) T.state[trial * STATE_STRIDE + (tid - 384)] = sState[tid - 384];
+        CH_OUT(3);
+        return;
+    }
     __syncthreads();
 
-    // what follows is k_pose_solve's tail (see there)
-    const bool prior_here = T.has_prior && !(T.gn_flags & 4);
+    // the stepwise path: k_pose_solve's tail (see there)
     if (uwave < 2) {
         if (tid < 12) {
             double *p = (tid == 0) ? sState + STATE_EXT : sState + STATE_POSE + 7 * (tid - 1);
@@ -362,7 +400,7 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         if (T.lm_dim != 3) d_pair_rotations(sState, sR, tid);
         __syncthreads();
     } else {
-        if (prior_here) {
+        {
             double hp[PS_PRIOR_ROWS][3], bp[PS_PRIOR_ROWS];
 #pragma unroll
             for (int r = 0; r < PS_PRIOR_ROWS; ++r) {
@@ -384,19 +422,17 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         }
         __syncthreads();
         double jp[PS_JT_ROWS][3];
-        if (prior_here) {
 #pragma unroll
-            for (int r = 0; r < PS_JT_ROWS; ++r) {
-                const int i = (uwave - 2) + 14 * r;
+        for (int r = 0; r < PS_JT_ROWS; ++r) {
+            const int i = (uwave - 2) + 14 * r;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int j = lane + 64 * q;
-                    jp[r][q] = (i < VIO_PRD && j < VIO_PRD) ? T.Jtinv[i * VIO_PRD + j] : 0.0;
-                }
+            for (int q = 0; q < 3; ++q) {
+                const int j = lane + 64 * q;
+                jp[r][q] = (i < VIO_PRD && j < VIO_PRD) ? T.Jtinv[i * VIO_PRD + j] : 0.0;
             }
         }
         __syncthreads();
-        if (prior_here) {
+        {
             const double y0 = sB[lane], y1 = sB[lane + 64], y2 = (lane + 128 < VIO_PRD) ? sB[lane + 128] : 0.0;
 #pragma unroll
             for (int r = 0; r < PS_JT_ROWS; ++r) {
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(PS_THREADS) void k_chain_solve_test(const double *i
     }
     for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) P[CH_OFF_SM + i] = 0.0;      // (the padding column of every M_e must read as zero)
     __syncthreads();
-    ch_factor_solve(P, tid);
+    ch_factor_solve(P, tid, [](int) {}, [](int, int) {});
     if (tid < PS_N) x_nat[tid] = P[CH_OFF_X + ch_dim(tid)];
     if (lds_dump) for (int i = tid; i < CH_LDS_CORE; i += PS_THREADS) lds_dump[i] = P[i];
 }
