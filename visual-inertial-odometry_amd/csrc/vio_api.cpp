@@ -42,6 +42,7 @@ void vio_launch_errprior(const DeviceTables &T, hipStream_t s);
 void vio_launch_prepare(const DeviceTables &T, hipStream_t s);
 void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes, int threads, int use_ext, hipStream_t s);
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
+void vio_launch_reduce_assemble(const ReduceTables &R, const DeviceTables &T, hipStream_t s);
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
 void vio_launch_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map, hipStream_t s);
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s);
@@ -221,6 +222,7 @@ struct vio_ctx {
     double gn_lambda = -1.0;
     int solve_order = VIO_ORDER_CHAIN;         // vio_set_solve_order (VIO_SOLVE_ORDER=eigen|chain overrides the default at creation)
     bool prior_chain_ok = true;                // H_prior couples no two speed-bias blocks that are not neighbours (the chain order's storage)
+    bool test_in_solve = false;                // three-launch path: the step test owed by the last k_reduce_c goes to the next k_pose_solve_c
     int pg_layout = -1;                        // which order's image d_Pg holds (the two layouts rely on different never-written zeros)
     bool want_natural_hs = false;              // set by vio_get_schur_system: re-run k_assemble with the natural-order copy
     bool natural_hs_valid = false;
@@ -232,7 +234,7 @@ struct vio_ctx {
     Plan *active = nullptr;
     // device buffers independent of the topology
     DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
-        d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi, d_gath, d_step_gath;
+        d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi, d_gath, d_step_gath, d_sp_part;
     DevBuf<int32_t> d_imu_valid, d_perm, d_rank, d_gather_map;
     DevBuf<double> d_Pg;
     DevBuf<LmState> d_lm;
@@ -663,7 +665,7 @@ vio_status alloc_fixed(vio_ctx *c) {
     HIPCHK(c->d_imu_out.resize(VIO_WINDOW_SIZE * IMU_OUT)); HIPCHK(c->d_Hprior.resize(PD * PD));
     HIPCHK(c->d_bprior.resize(2 * 176)); HIPCHK(c->d_errprior.resize(2 * 160)); HIPCHK(c->d_Jtinv.resize(PRD * PRD));
     HIPCHK(c->d_Hs.resize(PD * PD)); HIPCHK(c->d_bs.resize(176)); HIPCHK(c->d_bfull.resize(2 * 176));
-    HIPCHK(c->d_diagfull.resize(176)); HIPCHK(c->d_dx.resize(176)); HIPCHK(c->d_step_tot.resize(8));
+    HIPCHK(c->d_diagfull.resize(176)); HIPCHK(c->d_dx.resize(176)); HIPCHK(c->d_step_tot.resize(8)); HIPCHK(c->d_sp_part.resize(8));
     HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
     HIPCHK(c->d_gath.resize((size_t)c->cfg.shard_count * VIS_SEND)); HIPCHK(c->d_step_gath.resize((size_t)c->cfg.shard_count * 2));
     HIPCHK(c->d_perm.resize(2 * 176)); HIPCHK(c->d_rank.resize(176)); HIPCHK(c->d_Pg.resize(2 * POSE_SOLVE_TILED));     // two sets (vio_solve's loop)
@@ -710,7 +712,7 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     T.imu_mask = 0;
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) T.imu_mask |= (c->imu_valid[k] ? 1 : 0) << k;
     T.chi_part = pl.d_step_part.p + 2 * (size_t)T.n_step_blocks;
-    T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p;
+    T.step_tot = c->ext_step ? c->ext_step : c->d_step_tot.p; T.lm = c->d_lm.p; T.sp_part = c->d_sp_part.p;
     T.gath = c->ext_gath ? c->ext_gath : c->d_gath.p; T.step_gath = c->ext_step_gath ? c->ext_step_gath : c->d_step_gath.p;
     T.n_shards = (c->hook != nullptr || c->comm != nullptr) ? c->cfg.shard_count : 0;
     T.solve_order = effective_order(c);
@@ -938,6 +940,12 @@ RcclApi *rccl_api(std::string &err) {
 }
 
 inline bool sharded(const vio_ctx *c) { return c->hook != nullptr || c->comm != nullptr; }
+// k_reduce_c + k_pose_solve_c instead of k_reduce, k_assemble_c, k_pose_solve_c: unsharded, chain order, no natural-order copy wanted
+// (VIO_FOUR_LAUNCHES=1: the four-launch path, for A/B)
+inline bool three_launch(const vio_ctx *c, const DeviceTables &T) {
+    static const bool off = std::getenv("VIO_FOUR_LAUNCHES") != nullptr;
+    return !off && !sharded(c) && T.solve_order == VIO_ORDER_CHAIN && !T.natural_hs && !T.marg_mode;
+}
 
 // The exchange of a sharded window is an all-gather, not an all-reduce: every rank receives every rank's slab and the kernels
 // that read a sum form it in rank order (d_vis / d_step_tot of vio_kernels.hip) — identical bits on every rank by construction,
@@ -981,6 +989,18 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, test_prev ? T.step_part : nullptr, T.n_items, sharded(c) ? 0 : gate, T.lm,
                    err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + c->cur_host * 176 : nullptr,
                    err_prev ? T.errprior + c->cur_host * 160 : nullptr};
+    // Three launches per iteration where nothing sits between the sums and the assembly: the GN loop of an unsharded window in the
+    // chain order, nobody waiting for the natural-order matrix.  k_reduce_c writes the image; the step test moves to the head of the
+    // k_pose_solve_c that follows (enqueue_trial).
+    c->test_in_solve = false;
+    if (gn && three_launch(c, T)) {
+        { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce_assemble(R, T, c->stream); }
+        if (test_prev) { c->test_in_solve = true; c->decide_pending = false; }
+        HIPCHK(hipGetLastError());
+        c->linearized = true;
+        c->natural_hs_valid = false;
+        return VIO_OK;
+    }
     { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
     VIOCHK(run_exchange(c, 0));
     if (test_prev) { T.gn_flags = 1; c->decide_pending = false; }
@@ -1004,6 +1024,7 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int ga
     T.lm_gate = gate;
     T.gn_flags = 4;         // bit 2: k_pose_solve leaves the prior update to the kernels that follow (all paths now)
     if (gn) T.cur_hint = c->cur_host;      // GN: the update rides with the next k_linearize / k_reduce (or with flush_decide)
+    if (gn && c->test_in_solve) { T.gn_flags |= 1; c->test_in_solve = false; }      // three-launch path: the previous step's test at this kernel's head
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     if (gn) {
         // the step is accepted whatever chi2 turns out to be: the landmark back-substitution, the chi2 of the new state and
@@ -1043,6 +1064,7 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int ga
 // state again, which a rejected trial costs here instead of a second evaluation).  `first`: the step from the initial linearisation.
 vio_status enqueue_lm_slot(vio_ctx *c, Plan &pl, bool first) {
     DeviceTables T = make_tables_raw(c, pl);
+    bool test_in_solve = false;
     T.cur_hint = -2;
     T.lm_gate = 2;
     if (!first) {
@@ -1051,12 +1073,17 @@ vio_status enqueue_lm_slot(vio_ctx *c, Plan &pl, bool first) {
         // (sharded: k_reduce always runs, see enqueue_linearize)
         ReduceTables R{pl.d_list_off.p, pl.d_list.p, pl.d_slab.p, T.vis, T.step_part, T.n_items, sharded(c) ? 0 : 2, T.lm,
                        T.has_prior ? T.Jtinv : nullptr, T.has_prior ? T.bprior : nullptr, T.has_prior ? T.errprior : nullptr, 1};
-        { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
-        VIOCHK(run_exchange(c, 0));
-        T.gn_flags = 1;
-        { ProfScope ps(c, VIO_K_ASSEMBLE); vio_launch_assemble(T, c->stream); }
+        if (three_launch(c, T)) {
+            { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce_assemble(R, T, c->stream); }
+            test_in_solve = true;
+        } else {
+            { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce(R, c->stream); }
+            VIOCHK(run_exchange(c, 0));
+            T.gn_flags = 1;
+            { ProfScope ps(c, VIO_K_ASSEMBLE); vio_launch_assemble(T, c->stream); }
+        }
     }
-    T.gn_flags = 4;
+    T.gn_flags = 4 | (test_in_solve ? 1 : 0);
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     HIPCHK(hipGetLastError());
     c->ahead = 7u;
@@ -1162,7 +1189,7 @@ void vio_destroy(vio_ctx *c) {
     c->solve_plan.release(); c->marg_plan.release();
     c->d_state.release(); c->d_pairtab.release(); c->d_vis.release(); c->d_pre.release(); c->d_imu_out.release();
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
-    c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release();
+    c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release(); c->d_sp_part.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
     c->d_batch_tabs.release(); c->d_rank.release(); c->d_gather_map.release(); c->d_gath.release(); c->d_step_gath.release();
     c->arena.release(c->own_stream);

@@ -1062,7 +1062,15 @@ __device__ __forceinline__ void d_errprior_row(const double *jt, const double *b
     if (lane == 63) err[i] = s;
 }
 
-__device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
+// FUSED (the three-launch path of the chain order, vio_pose_solve_chain.h): the workgroup that has summed a block also adds the IMU and
+// prior terms and writes the entries straight into the image of the pose system — k_assemble_c's work without its launch; 99 more
+// workgroups write the rows of the speed-bias variables (no visual part).  The hooks are defined with the chain layout.
+__device__ void d_fused_pair(const DeviceTables &T, int b, int tid, double tot);
+__device__ void d_fused_vec(const DeviceTables &T, int P, int tid, double bd, double bc, double dg);
+__device__ void d_fused_sb_row(const DeviceTables &T, int r, int tid);
+#define RED_SB_BLOCKS 99
+template <bool FUSED>
+__device__ __forceinline__ void d_reduce_body(const ReduceTables &R, const DeviceTables *Tp = nullptr) {
     // A list is cut into interleaved slots (entry e belongs to slot e mod nslots); a group of 36 (18) threads owns a
     // slot and sums its entries with 8 gathers in flight, then the slots are added in slot order: the summation order
     // is fixed by the list, not by timing.  Three dependent round trips (offsets, list, slab) whatever the list length.
@@ -1070,8 +1078,12 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (d_gated_off(R.lm, R.gate)) return;
     const bool step_owed = !R.lm_loop || R.lm->pending != 0;
+    if (FUSED && b >= VIO_NPAIR + VIO_NCB + 1 && b < VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS) {
+        d_fused_sb_row(*Tp, b - (VIO_NPAIR + VIO_NCB + 1), tid);
+        return;
+    }
     if (b >= VIO_NPAIR + VIO_NCB + 1) {          // GN mode: err_prior of the step k_pose_solve took (it left b_prior' only)
-        const int row = (b - (VIO_NPAIR + VIO_NCB + 1)) * (RED_THREADS / 64) + (tid >> 6);
+        const int row = (b - (VIO_NPAIR + VIO_NCB + 1) - (FUSED ? RED_SB_BLOCKS : 0)) * (RED_THREADS / 64) + (tid >> 6);
         const int copy = R.lm_loop ? (R.lm->cur ^ 1) : 0;
         if (row < VIO_PRD && step_owed) d_errprior_row(R.jtinv, R.bprior + copy * 176, R.errprior + copy * 160, row, tid & 63);
         return;
@@ -1112,6 +1124,7 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) tot += sV[q * W + tid];
             R.vis[VIS_H + b * 36 + tid] = tot;         // block b = VIS_PAIR(P, Q), entry (i, j) = tid: the mirror image is not stored
+            if (FUSED) d_fused_pair(*Tp, b, tid, tot);
         }
     } else if (b < VIO_NPAIR + VIO_NCB) {
         constexpr int W = 18, NS = RED_THREADS / W;           // 56 slots
@@ -1145,6 +1158,7 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
             R.vis[VIS_BDIR + 6 * P + tid] = bd;
             R.vis[VIS_BRED + 6 * P + tid] = bd - bc;     // bpp - (Hpm*Hmm^-1)*bmm (problem.cc:429)
             R.vis[VIS_DIAG + 6 * P + tid] = dg;
+            if (FUSED) d_fused_vec(*Tp, P, tid, bd, bc, dg);
         }
     } else {
         // chi2 and max|h_ll| over the items: threads stride the list, then a fixed tree
@@ -1176,7 +1190,7 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R) {
         }
     }
 }
-__global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) { d_reduce_body(R); }
+__global__ __launch_bounds__(RED_THREADS) void k_reduce(ReduceTables R) { d_reduce_body<false>(R); }
 // batched: the tables of k_reduce are made of the window's DeviceTables; bit 0 of gn_flags here = "a step is waiting for its test"
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_b(BatchArgs a) {
     const DeviceTables T = d_batch_tables(a);
@@ -1185,7 +1199,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_b(BatchArgs a) {
     const int loop = T.cur_hint == -2, cur = loop ? 0 : T.cur_hint;
     ReduceTables R{T.list_off, T.list, T.slab, T.vis, test_prev ? T.step_part : nullptr, T.n_items, a.gate, T.lm,
                    err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + cur * 176 : nullptr, err_prev ? T.errprior + cur * 160 : nullptr, loop};
-    d_reduce_body(R);
+    d_reduce_body<false>(R);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1218,14 +1232,9 @@ __device__ __forceinline__ int d_imu_mask(const DeviceTables &T) { return T.imu_
 // key of the pivot rank sort: |d|, with NaN mapped to +inf — the ranks must be a permutation whatever the matrix holds
 // (a landmark without information makes 1/h_ll infinite in the reference too; its NaNs must not become wild indices here)
 __device__ __forceinline__ double d_rank_key(double d) { const double a = fabs(d); return a == a ? a : __builtin_huge_val(); }
-__device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int i, int j, double &vv, double &vr) {
-    vv = 0.0; vr = 0.0;                 // reduced visual part, IMU + prior part
-    const int ci = full_to_cam(i), cj = full_to_cam(j);
-    if (ci >= 0 && cj >= 0) {
-        int P = ci / 6, a = ci - 6 * P, Q = cj / 6, bq = cj - 6 * Q;
-        if (P > Q) { const int t0 = P; P = Q; Q = t0; const int t1 = a; a = bq; bq = t1; }
-        vv = d_vis(T, VIS_H + VIS_PAIR(P, Q) * 36 + a * 6 + bq);
-    }
+// the IMU + prior part of entry (i,j), i >= j
+__device__ __forceinline__ double d_hs_rest(const DeviceTables &T, int valid, int i, int j) {
+    double vr = 0.0;
     if (i >= 6 && j >= 6) {
         const int fi = (i - 6) / 15;
         for (int k = fi - 1; k <= fi; ++k) {
@@ -1242,15 +1251,23 @@ __device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int
         const bool mask = T.ext_fixed && !T.marg_mode && (i < 6 || j < 6);
         if (!mask) vr += T.Hprior[i * VIO_PD + j];
     }
+    return vr;
+}
+__device__ __forceinline__ void d_hs_entry(const DeviceTables &T, int valid, int i, int j, double &vv, double &vr) {
+    vv = 0.0;                           // reduced visual part; vr: IMU + prior part
+    const int ci = full_to_cam(i), cj = full_to_cam(j);
+    if (ci >= 0 && cj >= 0) {
+        int P = ci / 6, a = ci - 6 * P, Q = cj / 6, bq = cj - 6 * Q;
+        if (P > Q) { const int t0 = P; P = Q; Q = t0; const int t1 = a; a = bq; bq = t1; }
+        vv = d_vis(T, VIS_H + VIS_PAIR(P, Q) * 36 + a * 6 + bq);
+    }
+    vr = d_hs_rest(T, valid, i, j);
 }
 
 // Row i of the right-hand sides: b_pp_schur_ (returned and stored in T.bs), the pose part of b_ (T.bfull, for the
 // gain ratio) and diag(Hessian_) before the Schur complement (T.diagfull, for ComputeLambdaInitLM, problem.cc:511-516)
-__device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid, int i, int cur, int wset) {
-    const int ci = full_to_cam(i);
+__device__ __forceinline__ double d_rhs_rest(const DeviceTables &T, int valid, int i, int cur) {     // the IMU + prior part of row i of b
     const bool mask_i = T.ext_fixed && !T.marg_mode && i < 6;
-    double bred = 0.0, bdir = 0.0, dv, dr;
-    if (ci >= 0) { bred = d_vis(T, VIS_BRED + ci); bdir = d_vis(T, VIS_BDIR + ci); }
     double extra = 0.0;
     if (i >= 6) {
         const int fi = (i - 6) / 15;
@@ -1263,6 +1280,13 @@ __device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid
         }
     }
     if (T.has_prior && !mask_i) extra += T.bprior[cur * 176 + i];
+    return extra;
+}
+__device__ __forceinline__ double d_rhs_entries(const DeviceTables &T, int valid, int i, int cur, int wset) {
+    const int ci = full_to_cam(i);
+    double bred = 0.0, bdir = 0.0, dv, dr;
+    if (ci >= 0) { bred = d_vis(T, VIS_BRED + ci); bdir = d_vis(T, VIS_BDIR + ci); }
+    const double extra = d_rhs_rest(T, valid, i, cur);
     T.bs[i] = bred + extra;
     T.bfull[wset * 176 + i] = bdir + extra;
     d_hs_entry(T, valid, i, i, dv, dr);
@@ -2401,6 +2425,13 @@ void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_bl
     BatchArgs a{tabs, test_prev ? 2 : 0, parity, 0};
     launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
     a.gn_flags = test_prev ? 1 : 0;
+    if (order == 1) {
+        // three launches: the sums, the assembly of the chain image and (k_pose_solve_cb, bit 0) the previous step's test
+        hipLaunchKernelGGL(k_reduce_cb, dim3(VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
+        a.gn_flags = 4 | (test_prev ? 1 : 0);
+        launch_pose_solve_b(a, B, ps_lds, order, s);
+        return;
+    }
     hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
     launch_assemble_b(a, B, order, s);
     a.gn_flags = 4;
@@ -2415,6 +2446,7 @@ void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_bl
     auto linearize = [&](int gate) {
         BatchArgs a{tabs, 0, -1, gate};
         launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
+        if (order == 1) { hipLaunchKernelGGL(k_reduce_cb, dim3(VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS, B), dim3(RED_THREADS), 0, s, a); return; }
         hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1, B), dim3(RED_THREADS), 0, s, a);
         launch_assemble_b(a, B, order, s);
     };
@@ -2431,6 +2463,12 @@ void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_bl
         if (what == 2) {
             launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
             a.gn_flags = 1;
+            if (order == 1) {
+                hipLaunchKernelGGL(k_reduce_cb, dim3(VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS + (any_prior ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
+                a.gn_flags = 4 | 1;
+                launch_pose_solve_b(a, B, ps_lds, order, s);
+                return;
+            }
             hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + (any_prior ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
             launch_assemble_b(a, B, order, s);
         }
@@ -2450,6 +2488,10 @@ void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_bl
 }
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s) {
     hipLaunchKernelGGL(k_reduce, dim3(VIO_NPAIR + VIO_NCB + 1 + (R.errprior ? RED_ERR_BLOCKS : 0)), dim3(RED_THREADS), 0, s, R);
+}
+// the three-launch path (chain order, unsharded): k_reduce + k_assemble_c in one launch
+void vio_launch_reduce_assemble(const ReduceTables &R, const DeviceTables &T, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_c, dim3(VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS + (R.errprior ? RED_ERR_BLOCKS : 0)), dim3(RED_THREADS), 0, s, R, T);
 }
 // err_prior of a trial step (an LM trial, or a GN step whose test is flushed the classic way): the trial slot, before
 // k_lm_decide reads it

@@ -251,6 +251,65 @@ __device__ __forceinline__ void d_assemble_chain_body(const DeviceTables &T) {
     }
 }
 __global__ __launch_bounds__(ASMC_THREADS) void k_assemble_c(DeviceTables T) { d_assemble_chain_body(T); }
+
+// ---- the three-launch path: k_reduce_c = k_reduce + k_assemble_c (hooks of d_reduce_body<true>) ----
+__device__ __forceinline__ void d_fused_store(const DeviceTables &T, int i, int j, double v) {      // entry (i, j), i >= j, into the image
+    double *Pg = T.Pg + d_set_w(T) * CH_SET_STRIDE;
+    int p1, p2;
+    ch_entry_pos(i, j, p1, p2);
+    if (p1 >= 0) Pg[p1] = v;
+    if (p2 >= 0) Pg[p2] = v;
+}
+__device__ void d_fused_pair(const DeviceTables &T, int b, int tid, double tot) {
+    // block b = VIS_PAIR(P, Q), P <= Q; thread = entry (a, bq) of the 6 x 6 block.  A diagonal block holds both halves: the lower one is
+    // what d_hs_entry reads
+    int P = 0;
+    while (VIS_PAIR(P + 1, P + 1) <= b) ++P;
+    const int Q = P + (b - VIS_PAIR(P, P));
+    const int a = tid / 6, bq = tid - 6 * a;
+    if (P == Q && a < bq) return;
+    const int i = cam_to_full(6 * P + a), j = cam_to_full(6 * Q + bq);
+    const int I = max(i, j), J = min(i, j);
+    d_fused_store(T, I, J, tot + d_hs_rest(T, d_imu_mask(T), I, J));
+}
+__device__ void d_fused_vec(const DeviceTables &T, int P, int tid, double bd, double bc, double dg) {
+    const int valid = d_imu_mask(T), cur = d_cur(T), wset = d_set_w(T);
+    const int i = cam_to_full(6 * P + tid);
+    const double extra = d_rhs_rest(T, valid, i, cur);
+    const double bred = bd - bc;
+    T.bs[i] = bred + extra;
+    T.bfull[wset * 176 + i] = bd + extra;
+    T.diagfull[i] = dg + d_hs_rest(T, valid, i, i);
+    T.Pg[wset * CH_SET_STRIDE + CH_OFF_Y + ch_dim(i)] = bred + extra;
+}
+__device__ void d_fused_sb_row(const DeviceTables &T, int r, int tid) {
+    // natural row i of speed-bias variable r (frame r / 9, component r % 9): the entries (i, t) towards every camera variable and towards
+    // the speed-bias variables t <= i; no visual part
+    if (tid >= VIO_PD) return;
+    const int valid = d_imu_mask(T), cur = d_cur(T), wset = d_set_w(T);
+    const int i = 12 + 15 * (r / 9) + r % 9, t = tid;
+    if (full_to_cam(t) >= 0 || t <= i) {
+        const int I = max(i, t), J = min(i, t);
+        d_fused_store(T, I, J, d_hs_rest(T, valid, I, J));
+    }
+    if (t == i) {
+        const double extra = d_rhs_rest(T, valid, i, cur);
+        T.bs[i] = extra;
+        T.bfull[wset * 176 + i] = extra;
+        T.diagfull[i] = d_hs_rest(T, valid, i, i);
+        T.Pg[wset * CH_SET_STRIDE + CH_OFF_Y + ch_dim(i)] = extra;
+    }
+}
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_c(ReduceTables R, DeviceTables T) { d_reduce_body<true>(R, &T); }
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_cb(BatchArgs a) {
+    const DeviceTables T = d_batch_tables(a);
+    const bool test_prev = (a.gn_flags & 1) != 0, err_prev = test_prev && T.has_prior;
+    if ((int)blockIdx.x >= VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS && !err_prev) return;
+    const int loop = T.cur_hint == -2, cur = loop ? 0 : T.cur_hint;
+    ReduceTables R{T.list_off, T.list, T.slab, T.vis, test_prev ? T.step_part : nullptr, T.n_items, a.gate, T.lm,
+                   err_prev ? T.Jtinv : nullptr, err_prev ? T.bprior + cur * 176 : nullptr, err_prev ? T.errprior + cur * 160 : nullptr, loop};
+    d_reduce_body<true>(R, &T);
+}
 __global__ __launch_bounds__(ASMC_THREADS) void k_assemble_cb(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_assemble_chain_body(T); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -293,7 +352,26 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         if (pass == 0) {
             double stv = (tid < STATE_STRIDE) ? T.state[cur * STATE_STRIDE + tid] : 0.0;
             const double stv1 = (lm_loop && tid < STATE_STRIDE) ? T.state[STATE_STRIDE + tid] : 0.0;
-            if (lm_loop && tid == 0) {
+            // Three-launch path (gn_flags bit 0): the test of the PREVIOUS step, which k_assemble's last workgroup runs in the four-launch
+            // path, is formed here: chi2 of the state that step led to (this linearisation's, summed by k_reduce_c, + IMU + ||err_prior||)
+            // and the gain ratio's denominator (the landmark part from k_reduce_c, the pose part left by the previous k_pose_solve_c
+            // in sp_part).  The sums are k_assemble's: three wave partials added in wave order.
+            const bool test_here = d_step_owed(T, 1);
+            double t_chi = 0.0, t_step = 0.0, t_lmchi = 0.0, t_imu = 0.0, t_sp = 0.0;
+            if (test_here) {
+                const int lc = lm_loop ? (lm->cur ^ lm->pending) : cur;          // the copy this linearisation was made at
+                double e2 = 0.0;
+                if (T.has_prior && tid < VIO_PRD) { const double er = T.errprior[lc * 160 + tid]; e2 = er * er; }
+                if (tid < 192) { const double w = d_wave_sum_to_lane63(e2); if (lane == 63) sB[tid >> 6] = w; }
+                if (tid == 0) {
+                    const int valid = d_imu_mask(T);
+                    t_chi = T.vis[VIS_CHI]; t_step = T.vis[VIS_STEP + 1]; t_lmchi = lm->chi;
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) if ((valid >> k) & 1) t_imu += T.imu_out[k * IMU_OUT + IMU_CHI];
+                    t_sp = (T.sp_part[0] + T.sp_part[1]) + T.sp_part[2];
+                }
+            }
+            if (lm_loop && tid == 0 && !test_here) {
                 int go = 1, rej = 0, sys = lm->sys;
                 d_lm_load(lm, sLm);
                 if (lm->pending) {
@@ -305,6 +383,37 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
             }
             CH_ST(0) CH_ST(1) CH_ST(2) CH_ST(3) CH_ST(4) CH_ST(5) CH_ST(6) CH_ST(7)
             __syncthreads();
+            if (test_here) {
+                if (tid == 0) {
+                    double total = t_chi + t_imu;
+                    if (T.has_prior) total += sqrt((sB[0] + sB[1]) + sB[2]);       // err_prior_.norm(), not squared (problem.cc:554-556)
+                    const double tempChi = 0.5 * total;
+                    const double scale = 0.5 * (t_step + t_sp) + 1e-6;
+                    lm->chi_try = tempChi;
+                    lm->scale = scale;
+                    if (!lm_loop) {
+                        lm->rho = (t_lmchi - tempChi) / scale;
+                        lm->trials += 1;
+                        lm->chi = tempChi;
+                        lm->cur = cur;
+                        lm->accepted = 1;
+                        lm->naccepted += 1;
+                        lm->need_linearize = 1;
+                        lm->false_cnt = 0;
+                        if (!isfinite(tempChi)) lm->finite = 0;
+                    } else {
+                        int go = 1, rej = 0, sys = lm->sys;
+                        d_lm_load(lm, sLm);
+                        if (lm->pending) {
+                            d_lm_verdict(sLm, lm, 0, tempChi, scale, sLm.cur);
+                            if (sLm.accepted) sys ^= 1; else rej = 1;
+                            go = !sLm.stop;
+                        }
+                        sX[0] = go ? 1.0 : 0.0; sX[1] = (double)sLm.cur; sX[2] = sLm.lambda; sX[3] = (double)sys; sX[4] = (double)rej;
+                    }
+                }
+                if (lm_loop) __syncthreads();
+            }
             int set_now = 0;
             if (lm_loop) {
                 if (tid == 0) { d_lm_store(lm, sLm); lm->sys = (int)sX[3]; lm->pending = sX[0] != 0.0 ? 1 : 0; }
@@ -372,6 +481,13 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     ch_factor_solve(P, tid, mid1, mid2, T.dbg);
     CH_OUT(2);
     for (int i = tid; i < n; i += PS_THREADS) sDx[i] = sX[ch_dim(i)];
+    if (tid < 192 && T.sp_part) {
+        // sum_i dx_i (lambda dx_i + b_i), b_ of the system just solved: three wave partials, as k_assemble's step test sums them
+        const double dxi = (tid < n) ? sX[ch_dim(min(tid, n - 1))] : 0.0;
+        const double bi = (tid < n) ? T.bfull[set * 176 + tid] : 0.0;
+        const double w = d_wave_sum_to_lane63((tid < n) ? dxi * (lambda * dxi + bi) : 0.0);
+        if (lane == 63) T.sp_part[tid >> 6] = w;
+    }
     if (!prior_here) {
         // the trial states: poses from wave 13's copy, speed-bias = current + dx
         if (tid >= 128 && tid < 128 + 84) sState[tid - 128] = P[CH_OFF_CC + tid - 128];

@@ -177,6 +177,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     const int32_t *list_off;     // k_reduce's inverted lists (a batched launch builds its ReduceTables from here)
     const int32_t *list;
     double *step_tot;            // [8] exchange buffer: chi2 of the trial state, gain-ratio scale
+    double *sp_part;             // [4] three-launch path: the wave partials of sum dx (lambda dx + b) of the step k_pose_solve_c just took
+                                 //     (the pose part of the gain ratio's denominator), read by the next launch's step test
     // Sharded windows (multi-GPU): the exchange is an ALL-GATHER of every shard's vis[0 .. VIS_SEND) resp. step_tot[0 .. 2) into
     // these rank-major buffers, and whoever reads a sum forms it in rank order (d_vis, d_step_tot): every rank computes the
     // identical bits whatever algorithm the collective library picks.  n_shards == 0: unsharded, vis / step_tot are read directly.
