@@ -1063,12 +1063,12 @@ __device__ __forceinline__ void d_errprior_row(const double *jt, const double *b
 }
 
 // FUSED (the three-launch path of the chain order, vio_pose_solve_chain.h): the workgroup that has summed a block also adds the IMU and
-// prior terms and writes the entries straight into the image of the pose system — k_assemble_c's work without its launch; 99 more
-// workgroups write the rows of the speed-bias variables (no visual part).  The hooks are defined with the chain layout.
+// prior terms and writes the entries straight into the image of the pose system — k_assemble_c's work without its launch; 20 more
+// workgroups write the 99 rows of the speed-bias variables (no visual part).  The hooks are defined with the chain layout.
 __device__ void d_fused_pair(const DeviceTables &T, int b, int tid, double tot);
 __device__ void d_fused_vec(const DeviceTables &T, int P, int tid, double bd, double bc, double dg);
 __device__ void d_fused_sb_row(const DeviceTables &T, int r, int tid);
-#define RED_SB_BLOCKS 99
+#define RED_SB_BLOCKS 20          // five rows of speed-bias variables per workgroup (5 x 171 threads)
 template <bool FUSED>
 __device__ __forceinline__ void d_reduce_body(const ReduceTables &R, const DeviceTables *Tp = nullptr) {
     // A list is cut into interleaved slots (entry e belongs to slot e mod nslots); a group of 36 (18) threads owns a

@@ -282,12 +282,13 @@ __device__ void d_fused_vec(const DeviceTables &T, int P, int tid, double bd, do
     T.diagfull[i] = dg + d_hs_rest(T, valid, i, i);
     T.Pg[wset * CH_SET_STRIDE + CH_OFF_Y + ch_dim(i)] = bred + extra;
 }
-__device__ void d_fused_sb_row(const DeviceTables &T, int r, int tid) {
-    // natural row i of speed-bias variable r (frame r / 9, component r % 9): the entries (i, t) towards every camera variable and towards
-    // the speed-bias variables t <= i; no visual part
-    if (tid >= VIO_PD) return;
+__device__ void d_fused_sb_row(const DeviceTables &T, int blk, int tid) {
+    // natural row i of speed-bias variable r (frame r / 9, component r % 9), five rows per workgroup: the entries (i, t) towards every
+    // camera variable and towards the speed-bias variables t <= i; no visual part
+    const int r = 5 * blk + tid / VIO_PD, t = tid % VIO_PD;
+    if (tid >= 5 * VIO_PD || r >= 99) return;
     const int valid = d_imu_mask(T), cur = d_cur(T), wset = d_set_w(T);
-    const int i = 12 + 15 * (r / 9) + r % 9, t = tid;
+    const int i = 12 + 15 * (r / 9) + r % 9;
     if (full_to_cam(t) >= 0 || t <= i) {
         const int I = max(i, t), J = min(i, t);
         d_fused_store(T, I, J, d_hs_rest(T, valid, I, J));
