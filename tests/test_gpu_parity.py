@@ -246,6 +246,31 @@ def test_damped_solve_against_eigen_ldlt_vectors(vio, hip_lib):
         assert float((np.abs(r[ok]) / den[ok]).max()) <= 5e-15 and float(np.abs(r[~ok]).max() if (~ok).any() else 0.0) == 0.0, (i, float((np.abs(r[ok]) / den[ok]).max()))
 
 
+def test_initial_lambda_sees_the_landmark_diagonal_under_both_item_policies(vio, oracle_lib, hip_lib):
+    """ComputeLambdaInitLM takes the maximum over the WHOLE diagonal, landmarks included (problem.cc:511-516).  With IMU factors their
+    information (capped at 5e10) decides; without them the largest h_ll does — which the half-width kernels of the throughput policy
+    dropped until round 4 (the wave that held it never ran the reduction: ADVICE r03)."""
+    for n, seed in ((6, 17), (8, 3), (10, 5)):
+        # few, far landmarks, no IMU factors, no loss: the largest diagonal entry of the Hessian is a landmark's
+        w = vio.synth.make_window(n, seed=seed)
+        w.preint = [None] * 10
+        w.inv_depth = w.inv_depth * (0.2 if n == 10 else 0.1)
+        co = oracle_lib.context(loss_type=0)
+        co.load(w)
+        co.linearize()
+        chi_o, lam_o = co.init_lm()
+        hll, _ = co.get_landmark_system()
+        _, diag = co.get_pose_gradient()
+        assert np.abs(hll).max() > np.abs(diag).max() and abs(lam_o - 1e-5 * np.abs(hll).max()) <= 1e-12 * lam_o
+        for policy in (vio.capi.ITEMS_LATENCY, vio.capi.ITEMS_THROUGHPUT):
+            ch = hip_lib.context(item_policy=policy, loss_type=0)
+            ch.load(w)
+            ch.linearize()
+            chi_h, lam_h = ch.init_lm()
+            assert abs(lam_h - lam_o) <= 1e-12 * lam_o, (n, policy, lam_h, lam_o)
+            assert abs(chi_h - chi_o) <= 1e-9 * chi_o
+
+
 def test_imu_only_and_missing_edges(vio, oracle_lib, hip_lib):
     w = vio.synth.make_window(0, seed=5)
     ch, co = hip_lib.context(), oracle_lib.context()

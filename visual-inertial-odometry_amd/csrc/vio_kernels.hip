@@ -733,7 +733,7 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
         double ws = 0.0, wsc = 0.0, wm = 0.0;
         if (wv64 < G * K) ws = d_wave_sum_to_lane63(chi_acc);
         if (owe && wv64 < G) wsc = d_wave_sum_to_lane63(sc);
-        if ((tid >> 7) == pkH) wm = d_wave_max_to_lane63(maxh);
+        if ((tid >> 7) == pkH % (NT / 128)) wm = d_wave_max_to_lane63(maxh);      // (the waves that handled quantity h_ll: q = tid / 128 + pass * NT / 128)
         if ((tid & 63) == 63) { sRed[tid >> 6] = ws; sRed[NT / 64 + (tid >> 6)] = wsc; sRed[2 * (NT / 64) + (tid >> 6)] = wm; }
     }
     __syncthreads();
