@@ -92,15 +92,32 @@ def spawn_ranks(n):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    # poll all of them: a rank that dies leaves the others inside a collective, where they would sit until the backend's own
+    # timeout — the first non-zero exit ends the rest within a second (waiting for the children in order blocked on rank 0)
+    import time
     rc = 0
-    for p in procs:
-        p.wait()
-        if p.returncode != 0 and rc == 0:
-            rc = p.returncode
-    if rc != 0:                 # a rank that died leaves the others in a collective: end them
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+        if rc != 0:
+            for p in live:
+                p.terminate()
+            t_end = time.time() + 5.0
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        if live:
+            time.sleep(0.05)
     return rc
 
 
@@ -121,10 +138,19 @@ def main():
     ap.add_argument("--batch-full", type=int, default=256, help="windows of the batched block's full-device figure (one pose solve per CU); 0 skips it")
     ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame cost block (set / plan+upload / Solve(10) / marginalise)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=0, help="0 = sized for about 10-20 s")
+    ap.add_argument("--replica-windows", type=int, default=16, help="N > 1: independent windows per GPU of the `replicas` block (0 skips it)")
+    ap.add_argument("--replica-landmarks", type=int, default=20000)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))          # before anything here has touched a GPU (torch is not even imported yet)
+    # test hook of the launcher (tests/test_bench_launcher.py, no GPU needed): rank VIO_BENCH_FAIL_RANK leaves with code 3 at once, the
+    # others sit still as if inside a collective — the parent has to end them
+    if "VIO_BENCH_FAIL_RANK" in os.environ and "RANK" in os.environ:
+        if os.environ["RANK"] == os.environ["VIO_BENCH_FAIL_RANK"]:
+            sys.exit(3)
+        time.sleep(600)
+        sys.exit(0)
 
     import numpy as np
     import torch
@@ -255,6 +281,36 @@ def main():
             single_gpu = (time.perf_counter() - t) * 1e3 / n1
             del c1
         barrier()
+
+    # N > 1, the regime that scales: every GPU runs its own batch of independent windows (vio_batch_gn_iteration), no collective in
+    # the data path; the job's figure is the sum over the ranks of windows x iterations / the slowest rank's time
+    replicas = None
+    if world > 1 and args.replica_windows > 0:
+        rw, rn = args.replica_windows, args.replica_landmarks
+        rkw = dict(device=local_rank, item_policy=vio.capi.ITEMS_THROUGHPUT)
+        lead = hip.context(**rkw)
+        rkw["stream"] = lead.get_stream()
+        members = [lead] + [hip.context(**rkw) for _ in range(rw - 1)]
+        for i, cx in enumerate(members):
+            cx.load(make(rn, seed=1000 + 97 * rank + i, obs_per_landmark=k_obs))
+        for _ in range(3):
+            hip.batch_gn_iteration(members, lam)
+        lead.synchronize()
+        barrier()
+        t = time.perf_counter()
+        rsteps = 20
+        for _ in range(rsteps):
+            hip.batch_gn_iteration(members, lam)
+        lead.synchronize()
+        barrier()
+        rel = time.perf_counter() - t
+        tt = torch.tensor([rel], dtype=torch.float64, device="cpu" if one_device else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        rel = float(tt.item())
+        replicas = {"windows_per_gpu": rw, "landmarks_per_window": rn, "steps": rsteps,
+                    "window_iterations_per_s": world * rw * rsteps / rel, "us_per_window_iteration_per_gpu": rel * 1e6 / (rw * rsteps),
+                    "scaling": "weak", "note": "independent windows, one batch per GPU, no collective in the data path"}
+        del members, lead
 
     dom_launch_s = (dom_ms / max(dom_cnt, 1)) * 1e-3
     alg_bytes = kernel_algorithmic_bytes(dominant, n, m, xyz)
@@ -466,6 +522,26 @@ def main():
         del cb, extra, members, lead          # (members first: they run on the leader's stream)
 
     cpu_baseline = None
+    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+        # the CPU port on the WHOLE window the ranks share (the reference's dense solver would need 320 GB for it): a bounded sample
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+        orc = vio.VioLib(os.path.join(ROOT, "oracle", "liboracle.so"), "vioo_")
+        co = orc.context()
+        co.load(full)
+        co.gn_iteration(lam)
+        t = time.perf_counter()
+        co.gn_iteration(lam)
+        one = time.perf_counter() - t
+        steps = args.cpu_baseline_steps or max(2, min(100, int(12.0 / max(one, 1e-3))))
+        t = time.perf_counter()
+        for _ in range(steps):
+            co.gn_iteration(lam)
+        dt = time.perf_counter() - t
+        cpu_baseline = {"value": steps / dt, "unit": "GN iter/s", "cores": 1, "kind": "port", "ms_per_iter": dt * 1e3 / steps,
+                        "sample": "%d GN iterations of the whole %d-landmark / %d-observation window the %d ranks share, "
+                                  "oracle/vio_oracle.c (plain C, -O2, 1 thread), rank 0's host" % (steps, full.n_landmarks, full.n_observations, world)}
+        del co
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
@@ -581,6 +657,7 @@ def main():
             "speedup_vs_single_gpu_same_window": (single_gpu / ms_per_step) if single_gpu else None,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "replicas": replicas,
             "per_frame": per_frame,
             "batched": batched,
             "cpu_baseline_all_cores": cpu_baseline_all_cores,

@@ -26,7 +26,8 @@ def run_bench(extra, env_extra=None, timeout=900):
 
 
 def test_two_ranks_launched_as_the_driver_would():
-    p, out = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2"], {"VIO_BENCH_ONE_DEVICE": "1"})
+    p, out = run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--replica-windows", "3", "--replica-landmarks", "4000", "--cpu-baseline-steps", "2"],
+                       {"VIO_BENCH_ONE_DEVICE": "1"})
     assert p.returncode == 0, p.stderr[-3000:]
     assert out is not None, p.stdout[-2000:]
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["scaling"] == "strong"
@@ -38,6 +39,17 @@ def test_two_ranks_launched_as_the_driver_would():
     assert out["single_gpu_same_window_ms"] > 0 and out["speedup_vs_single_gpu_same_window"] > 0
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
     assert out["final_chi2"] > 0 and out["final_chi2"] == out["final_chi2"]
+    # the CPU port on the whole shared window, and the regime that scales with GPUs: independent batches, no collective
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0 and "200000" in out["cpu_baseline"]["sample"]
+    rep = out["replicas"]
+    assert rep["windows_per_gpu"] == 3 and rep["scaling"] == "weak" and rep["window_iterations_per_s"] > 0
+
+
+def test_a_rank_that_dies_ends_the_whole_run():
+    import time
+    t0 = time.time()
+    p, out = run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1"], {"VIO_BENCH_ONE_DEVICE": "1", "VIO_BENCH_FAIL_RANK": "1"}, timeout=120)
+    assert p.returncode == 3 and out is None and time.time() - t0 < 60.0
 
 
 def test_single_gpu_line_is_the_headline_window():
