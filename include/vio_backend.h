@@ -75,6 +75,9 @@ typedef enum { VIO_ITEMS_LATENCY = 0, VIO_ITEMS_THROUGHPUT = 1 } vio_item_policy
  *                        than Eigen's own vectors on the golden systems, tests/golden/ldlt_exact.npz); 40 % less time. */
 typedef enum { VIO_ORDER_EIGEN = 0, VIO_ORDER_CHAIN = 1 } vio_solve_order;
 
+/* Version of this interface: 3 = the sharded exchange is an all-gather (round 3); 4 = vio_set_solve_order (round 4). */
+#define VIO_ABI_VERSION 4
+
 typedef enum {
     VIO_MARG_OLD = 0,          /* Estimator::MargOldFrame  estimator.cpp:693-829 */
     VIO_MARG_SECOND_NEW = 1    /* Estimator::MargNewFrame  estimator.cpp:830-901 */
@@ -293,7 +296,11 @@ vio_status vio_gather_buffers(struct vio_ctx *ctx, void **gathered_system, void 
  * systems, 1: all-gather the step scalars (both: send buffer -> receive buffers of ALL ranks, rank-major);
  * which == 2 (CPU libraries only): all-reduce MAX of step_scalars[2] in place.  NULL (default) = unsharded. */
 typedef int (*vio_exchange_fn)(void *user, int which);
+/* The hook's contract changed with VIO_ABI_VERSION 3 (an in-place all-reduce before, the all-gather above since): a caller checks
+ * vio_abi_version() >= 3, and the library refuses to run a hook (VIO_ERR_BAD_ARG at the first exchange) until the caller has called
+ * vio_gather_buffers or vio_bind_gather_buffers on the context — which a hook of the old contract never does. */
 vio_status vio_set_exchange_hook(struct vio_ctx *ctx, vio_exchange_fn fn, void *user);
+int32_t vio_abi_version(void);
 
 /* Native exchange: the library all-gathers its exchange buffers itself with RCCL (xGMI inside a node), in stream order
  * on its own stream, with no host callback in the loop.  RCCL is dlopen'ed (librccl.so of the process, e.g. the one

@@ -43,6 +43,14 @@ def test_hip_library_exports_every_declared_symbol(vio):
     assert not missing, missing
 
 
+def test_abi_version(vio):
+    import ctypes as C
+    f = vio.load_hip().dll.vio_abi_version
+    f.restype = C.c_int32
+    txt = open(os.path.join(ROOT, "include", "vio_backend.h")).read()
+    assert f() == int(re.search(r"#define VIO_ABI_VERSION (\d+)", txt).group(1)) >= 4
+
+
 def test_hip_library_fails_loudly_without_a_gpu(vio):
     import torch
     if torch.cuda.is_available():
@@ -60,7 +68,7 @@ def test_oracle_exports_the_same_surface(vio, oracle_lib):
             continue
         if f in ("vio_profile_begin", "vio_profile_begin_sampled", "vio_profile_end", "vio_kernel_name",
                  "vio_comm_unique_id", "vio_comm_init", "vio_comm_destroy", "vio_get_stream", "vio_batch_gn_iteration", "vio_batch_solve",
-                 "vio_get_host_timing", "vio_set_solve_order", "vio_get_solve_order", "vio_debug_chain_solve"):
+                 "vio_get_host_timing", "vio_set_solve_order", "vio_get_solve_order", "vio_debug_chain_solve", "vio_abi_version"):
             continue        # measurement hooks, the native RCCL exchange, streams, batched launches and the choice of the GPU
                             # solver's elimination order exist on the HIP library only
         assert oracle_lib.has(f[len("vio_"):]), f

@@ -16,6 +16,8 @@
 #include <map>
 #include <unordered_map>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -206,7 +208,7 @@ struct vio_ctx {
     std::vector<double> h_Hprior, h_bprior, h_errprior, h_Jtinv;
     HostArena arena;                           // pinned staging of the uploads
     double *marg_stage = nullptr;              // pinned: H_marg (171 x 171) and b_marg for the host tail of vio_marginalize
-    std::thread marg_thread;                   // the dense tail of a marginalisation in flight (vio_marginalize_begin / _end)
+    struct MargWorker *marg_worker = nullptr;  // parked helper thread for the dense tail of a marginalisation (vio_marginalize_begin / _end)
     bool marg_pending = false;
     MargResult marg_out;
     double *pull_stage = nullptr;              // pinned staging of the landmark read-back (pull_from_device)
@@ -257,6 +259,7 @@ struct vio_ctx {
     double hessian_ms = 0;
     double *ext_vis = nullptr, *ext_step = nullptr;    // caller-owned exchange buffers (vio_bind_exchange_buffers)
     double *ext_gath = nullptr, *ext_step_gath = nullptr;      // caller-owned receive buffers of the all-gather (vio_bind_gather_buffers)
+    bool gather_known = false;                         // the caller has asked for / bound the receive buffers: its hook is an all-gather
     DevBuf<unsigned long long> d_dbg;                  // diagnostic builds only
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // vio_get_host_timing
     int prof_which = -1;
@@ -964,6 +967,12 @@ vio_status run_exchange(vio_ctx *c, int which) {
         return VIO_OK;
     }
     if (!c->hook) return VIO_OK;
+    // Since ABI version 3 the hook is an ALL-GATHER into the receive buffers (it was an in-place all-reduce before).  A hook written
+    // against the old contract would return 0 and leave the receive buffers empty: refused until the caller has shown that it knows
+    // where the receive side is (vio_gather_buffers / vio_bind_gather_buffers).
+    if (!c->gather_known)
+        return fail(c, VIO_ERR_BAD_ARG, "exchange hook: the exchange is an all-gather into the buffers of vio_gather_buffers (VIO_ABI_VERSION >= 3); "
+                                        "call vio_gather_buffers or vio_bind_gather_buffers before the first exchange");
     if (c->hook(c->hook_user, which) != 0) return fail(c, VIO_ERR_HIP, "exchange hook failed");
     return VIO_OK;
 }
@@ -1177,9 +1186,10 @@ vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
     return VIO_OK;
 }
 
+static void marg_worker_stop(vio_ctx *c);
 void vio_destroy(vio_ctx *c) {
     if (!c) return;
-    if (c->marg_thread.joinable()) c->marg_thread.join();
+    marg_worker_stop(c);
     enter_device(c);
     // A stream the caller supplied (vio_config.stream, e.g. the leader's of a batch) may be gone already when this context
     // goes: it is not touched here.  hipFree waits for the device itself, so nothing in flight loses its buffers.
@@ -1808,8 +1818,63 @@ static void marg_tail_job(vio_ctx *c, int frame) {
     r.tail_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
 }
 
+// One helper thread per context, created with the first marginalisation and parked on a condition variable between jobs (a thread
+// per frame cost 30-60 us of the 0.14 ms the caller spends in vio_marginalize_begin).  If it cannot be created the tail
+// runs on the caller's thread: no exception crosses the C boundary.
+struct MargWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    int job = -1;               // frame of the job waiting to be taken, -1: none
+    bool busy = false, quit = false;
+};
+static void marg_worker_loop(vio_ctx *c, MargWorker *w) {
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->job >= 0 || w->quit; });
+        if (w->quit) return;
+        const int frame = w->job;
+        w->job = -1;
+        lk.unlock();
+        marg_tail_job(c, frame);
+        lk.lock();
+        w->busy = false;
+        w->cv_done.notify_all();
+    }
+}
 static void marg_join(vio_ctx *c) {
-    if (c->marg_thread.joinable()) c->marg_thread.join();
+    MargWorker *w = c->marg_worker;
+    if (!w) return;
+    std::unique_lock<std::mutex> lk(w->mu);
+    w->cv_done.wait(lk, [&] { return !w->busy; });
+}
+static void marg_submit(vio_ctx *c, int frame) {
+    if (!c->marg_worker) {
+        MargWorker *w = nullptr;
+        try {
+            w = new MargWorker;
+            w->th = std::thread(marg_worker_loop, c, w);
+            c->marg_worker = w;
+        } catch (...) {
+            delete w;
+            c->marg_worker = nullptr;
+        }
+    }
+    MargWorker *w = c->marg_worker;
+    if (!w) { marg_tail_job(c, frame); return; }            // (the result is ready when vio_marginalize_begin returns)
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->job = frame;
+    w->busy = true;
+    w->cv.notify_one();
+}
+static void marg_worker_stop(vio_ctx *c) {
+    MargWorker *w = c->marg_worker;
+    if (!w) return;
+    marg_join(c);
+    { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_one(); }
+    if (w->th.joinable()) w->th.join();
+    delete w;
+    c->marg_worker = nullptr;
 }
 
 vio_status vio_marginalize_begin(vio_ctx *c, int32_t kind) {
@@ -1856,7 +1921,7 @@ vio_status vio_marginalize_begin(vio_ctx *c, int32_t kind) {
     r.kind = kind;
     c->timing[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     c->marg_pending = true;
-    c->marg_thread = std::thread(marg_tail_job, c, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1);
+    marg_submit(c, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1);
     return VIO_OK;
 }
 
@@ -2000,6 +2065,8 @@ vio_status vio_exchange_buffers(vio_ctx *c, void **reduced, int64_t *n_reduced, 
     return VIO_OK;
 }
 
+int32_t vio_abi_version(void) { return VIO_ABI_VERSION; }
+
 vio_status vio_set_exchange_hook(vio_ctx *c, vio_exchange_fn fn, void *user) {
     if (!c) return VIO_ERR_BAD_ARG;
     c->hook = fn;
@@ -2090,6 +2157,7 @@ vio_status vio_gather_buffers(vio_ctx *c, void **gathered_system, void **gathere
     if (!c) return VIO_ERR_BAD_ARG;
     if (gathered_system) *gathered_system = c->ext_gath ? c->ext_gath : c->d_gath.p;
     if (gathered_scalars) *gathered_scalars = c->ext_step_gath ? c->ext_step_gath : c->d_step_gath.p;
+    c->gather_known = true;
     return VIO_OK;
 }
 
@@ -2097,6 +2165,7 @@ vio_status vio_bind_gather_buffers(vio_ctx *c, void *gathered_system, void *gath
     if (!c) return VIO_ERR_BAD_ARG;
     c->ext_gath = (double *)gathered_system;
     c->ext_step_gath = (double *)gathered_scalars;
+    c->gather_known = true;
     ++c->tables_gen;
     c->linearized = false;
     return VIO_OK;

@@ -63,20 +63,32 @@ class ShardedBackend:
         self._max_view = self.sca[2:3]
         self.exchange = exchange if (world > 1 or force_hook) else "none"
         if self.exchange == "native":
-            idt = torch.zeros(128, dtype=torch.uint8, device=torch_device)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(lib.comm_unique_id()), dtype=torch.uint8))
-            if world > 1:
-                dist.broadcast(idt, src=0)
-            ok, why = 1, None
+            # ncclCommInitRank is collective: a rank that cannot even enter it (librccl.so not resolvable) would leave the others
+            # inside it.  So availability is agreed on FIRST — every rank probes locally (dlopen + ncclGetUniqueId, no communication)
+            # and the flags are MIN-reduced — and only then does anybody call comm_init.
+            ok, why, uid = 1, None, None
             try:
-                self.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
-            except Exception as exc:      # librccl.so not resolvable, ncclCommInitRank refused, ...
+                uid = lib.comm_unique_id()
+            except Exception as exc:
                 ok, why = 0, exc
-            if world > 1:                 # every rank takes the same path
+            if world > 1:
                 flag = torch.tensor([ok], dtype=torch.int32, device=torch_device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
+            if ok:
+                idt = torch.zeros(128, dtype=torch.uint8, device=torch_device)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+                if world > 1:
+                    dist.broadcast(idt, src=0)
+                try:
+                    self.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+                except Exception as exc:      # ncclCommInitRank itself refused (every rank is inside or past it: no one is left waiting)
+                    ok, why = 0, exc
+                if world > 1:                 # every rank takes the same path
+                    flag = torch.tensor([ok], dtype=torch.int32, device=torch_device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    ok = int(flag.item())
             if not ok:
                 # the portable exchange instead: the same all-gather issued by torch.distributed from the library's hook (the
                 # context has to sit on an explicit torch stream for that: built again)
