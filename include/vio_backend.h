@@ -325,7 +325,8 @@ typedef enum {
     VIO_K_LINEARIZE = 0, VIO_K_REDUCE = 1, VIO_K_ASSEMBLE = 2, VIO_K_POSE_SOLVE = 3, VIO_K_BACKSUB = 4,
     VIO_K_LM_DECIDE = 5, VIO_K_COUNT = 6
 } vio_kernel_id;
-/* Wrap every launch of kernel `which` in a hipEvent pair recorded on the context's stream (which < 0: off). */
+/* Wrap every launch of kernel `which` in a hipEvent pair recorded on the context's stream (which < 0: off).  On the
+ * leader of a batch the pairs go around that kernel's batched launch in vio_batch_gn_iteration. */
 vio_status vio_profile_begin(struct vio_ctx *ctx, int32_t which);
 /* The same, but only every `every`-th launch gets its event pair (every >= 1).  An event record drains the stream
  * (about 7 us each on MI355X), so bench.py samples inside its timed region instead of bracketing every launch. */

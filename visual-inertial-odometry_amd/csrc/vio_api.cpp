@@ -58,7 +58,7 @@ void vio_launch_flip(LmState *lm, hipStream_t s);
 void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int any_prior, size_t ps_lds,
                          int what, int max_iter, int order, hipStream_t s);
 void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int test_prev, int any_prior,
-                         int parity, size_t ps_lds, int order, hipStream_t s);
+                         int parity, size_t ps_lds, int order, hipStream_t s, int ev_kernel, hipEvent_t *ev);
 void vio_launch_chain_solve_test(const double *img, double lambda, double *x_nat, double *lds_dump, hipStream_t s);
 int vio_chain_image_doubles();
 int vio_chain_y_offset();
@@ -1663,7 +1663,16 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
     int order = VIO_ORDER_CHAIN;                             // the chain order if every window can take it (one kernel for the whole batch)
     for (int i = 0; i < count; ++i) if (effective_order(ctxs[i]) != VIO_ORDER_CHAIN) order = VIO_ORDER_EIGEN;
     for (int i = 0; i < count; ++i) use_pg_layout(ctxs[i], order);
-    vio_launch_batch_gn(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, order, c->stream);
+    // vio_profile_begin on the leader: an event pair around that kernel's batched launch (every prof_every-th iteration)
+    int ev_kernel = -1;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (c->prof_which >= 0 && c->prof_seen++ % c->prof_every == 0) {
+        bool ok = true;
+        while (ok && c->prof_used + 2 > c->prof_events.size()) { hipEvent_t e; ok = hipEventCreate(&e) == hipSuccess; if (ok) c->prof_events.push_back(e); }
+        if (ok) { ev[0] = c->prof_events[c->prof_used]; ev[1] = c->prof_events[c->prof_used + 1]; ev_kernel = c->prof_which; c->prof_used += 2; }
+    }
+    vio_launch_batch_gn(c->d_batch_tabs.p, count, c->lm_dim, max_blocks, lds, lin_threads, test_prev, any_prior, c->batch_iters & 1, POSE_SOLVE_LDS, order, c->stream,
+                        ev_kernel, ev);
     HIPCHK(hipGetLastError());
     ++c->batch_iters;
     for (int i = 0; i < count; ++i) {

@@ -2420,22 +2420,36 @@ static void launch_pose_solve_b(const BatchArgs &a, int B, size_t ps_lds, int or
     else hipLaunchKernelGGL(k_pose_solve_b, dim3(1, B), dim3(PS_THREADS), ps_lds, s, a);
 }
 // batched GN iteration (windows of one landmark kind): grid.y = window
+// ev_kernel (VIO_K_* of vio_profile_begin, -1: none): an event pair around that kernel's launch (bench.py's batched roofline)
 void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int test_prev, int any_prior,
-                         int parity, size_t ps_lds, int order, hipStream_t s) {
+                         int parity, size_t ps_lds, int order, hipStream_t s, int ev_kernel, hipEvent_t *ev) {
     BatchArgs a{tabs, test_prev ? 2 : 0, parity, 0};
+    auto mark = [&](int k, int which) { if (ev_kernel == k) (void)hipEventRecord(ev[which], s); };
+    mark(0, 0);
     launch_linearize_b(a, lm_dim, max_blocks, B, lin_lds, lin_threads, s);
+    mark(0, 1);
     a.gn_flags = test_prev ? 1 : 0;
     if (order == 1) {
         // three launches: the sums, the assembly of the chain image and (k_pose_solve_cb, bit 0) the previous step's test
+        mark(1, 0);
         hipLaunchKernelGGL(k_reduce_cb, dim3(VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
+        mark(1, 1);
         a.gn_flags = 4 | (test_prev ? 1 : 0);
+        mark(3, 0);
         launch_pose_solve_b(a, B, ps_lds, order, s);
+        mark(3, 1);
         return;
     }
+    mark(1, 0);
     hipLaunchKernelGGL(k_reduce_b, dim3(VIO_NPAIR + VIO_NCB + 1 + ((test_prev && any_prior) ? RED_ERR_BLOCKS : 0), B), dim3(RED_THREADS), 0, s, a);
+    mark(1, 1);
+    mark(2, 0);
     launch_assemble_b(a, B, order, s);
+    mark(2, 1);
     a.gn_flags = 4;
+    mark(3, 0);
     launch_pose_solve_b(a, B, ps_lds, order, s);
+    mark(3, 1);
 }
 __global__ __launch_bounds__(RED_THREADS) void k_errprior_b(BatchArgs a);
 // Batched LM solve (vio_batch_solve): the kernels of vio_solve's device-driven loop with grid.y = window;
