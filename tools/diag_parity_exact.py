@@ -43,6 +43,9 @@ for name in names:
         row = {"lambda": lam, "dx_inf": float(np.abs(xe).max()), "hip_minus_exact": float(np.abs(x_hh - xe).max()),
                "eigen_minus_exact": float(np.abs(x_he - xe).max()), "hip_minus_eigen": float(np.abs(x_hh - x_he).max()),
                "hip_backward_error": backward(x_hh), "eigen_backward_error": backward(x_he)}
+        if key + "hp" in z.files:       # round 4: the HIP kernel in Eigen's pivot order beside the chain order that ships (x_hh)
+            row["hip_pivoted_minus_exact"] = float(np.abs(z[key + "hp"] - xe).max())
+            row["hip_pivoted_backward_error"] = backward(z[key + "hp"])
         rows.append(row)
         print("%-32s lambda %9.3g  hip-exact %.2e  eigen-exact %.2e  hip-eigen %.2e   backward: hip %.1e eigen %.1e" % (
             name, lam, row["hip_minus_exact"], row["eigen_minus_exact"], row["hip_minus_eigen"], row["hip_backward_error"], row["eigen_backward_error"]))

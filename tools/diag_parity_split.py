@@ -4,7 +4,8 @@ k_assemble: another summation order than Problem::MakeHessian's) or its solution
 cores instead of Eigen's column-by-column one)?
 
 For a golden window and a list of lambdas:
-    x_hh   HIP system, HIP solve                       (what ships)
+    x_hh   HIP system, HIP solve                       (what ships: the chain order since round 4)
+    x_hp   HIP system, HIP solve in Eigen's pivot order (vio_set_solve_order(VIO_ORDER_EIGEN): round 3's kernel)
     x_he   HIP system, Eigen's LDLT arithmetic         (oracle/vio_oracle.c: vioo_ldlt_solve restates Cholesky/LDLT.h operation for operation)
     x_oe   oracle system, Eigen's LDLT arithmetic      (the oracle's own delta_x: 4e-15 from the reference's)
     |x_hh - x_he|  = the solver's share,   |x_he - x_oe| = the system's share
@@ -55,13 +56,27 @@ for name in ("window_n50_s42", "window_n300_s45_prior", "window_n300_s43", "wind
     _, lam0 = co.init_lm()
     ch.init_lm()
     rows = []
+    # round 4: what ships is the chain order (static structured elimination, csrc/vio_pose_solve_chain.h); the kernel in Eigen's pivot
+    # order (vio_set_solve_order) is solved beside it: x_hp
+    x_pivoted = {}
+    ch.set_solve_order(vio.capi.ORDER_EIGEN)
+    ch.linearize()
+    ch.init_lm()
+    for lam in (lam0, 1e3, 240.0, 15.0, 1.0):
+        ch.solve_linear(lam)
+        x_pivoted[lam] = ch.get_delta()[0]
+    ch.set_solve_order(vio.capi.ORDER_CHAIN)
+    ch.linearize()
+    ch.init_lm()
     for lam in (lam0, 1e3, 240.0, 15.0, 1.0):
         ch.solve_linear(lam)
         co.solve_linear(lam)
         x_hh, x_oe = ch.get_delta()[0], co.get_delta()[0]
+        dump["%s_lam%g_x_hp" % (name, lam)] = x_pivoted[lam]
         x_he = eigen_ldlt(Hh + lam * np.eye(171), bh)
         row = {"lambda": lam, "dx_inf": float(np.abs(x_oe).max()), "solver_share": float(np.abs(x_hh - x_he).max()),
-               "system_share": float(np.abs(x_he - x_oe).max()), "hip_vs_oracle": float(np.abs(x_hh - x_oe).max())}
+               "system_share": float(np.abs(x_he - x_oe).max()), "hip_vs_oracle": float(np.abs(x_hh - x_oe).max()),
+               "solver_share_pivoted_kernel": float(np.abs(x_pivoted[lam] - x_he).max())}
         if name == "window_n50_s42":
             for i in range(3):
                 if abs(float(zl["lambda_%d" % i]) - lam) <= 1e-9 * lam:
