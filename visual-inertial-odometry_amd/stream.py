@@ -83,23 +83,7 @@ class SyntheticStream:
                                  gyr=[m.gyro for m in ms[1:]]))
             self.preint.append(synth.preintegrate(ms[0].acc, ms[0].gyro, np.zeros(3), np.zeros(3), [dt] * n_sub,
                                                   [m.acc for m in ms[1:]], [m.gyro for m in ms[1:]]))
-        # landmarks: hosted in frame h, seen in h+1 .. h+track_len
-        self.lm_host, self.lm_px, self.lm_depth, self.lm_obs = [], [], [], []
-        for h in range(n_frames - 1):
-            for _ in range(landmarks_per_frame):
-                px = rng.uniform(-0.5, 0.5, 2)
-                depth = rng.uniform(4.0, 10.0)
-                pw = self.R[h] @ (synth.R_IC @ (np.array([px[0], px[1], 1.0]) * depth) + synth.T_IC) + self.P[h]
-                obs = {}
-                for j in range(h + 1, min(h + 1 + track_len, n_frames)):
-                    pc = synth.R_IC.T @ (self.R[j].T @ (pw - self.P[j]) - synth.T_IC)
-                    pc[2] = max(pc[2], 0.5)
-                    obs[j] = pc[0:2] / pc[2] + rng.normal(0.0, pixel_noise, 2)
-                self.lm_host.append(h)
-                self.lm_px.append(px)
-                self.lm_depth.append(depth)
-                self.lm_obs.append(obs)
-        self.init_noise = rng.normal(size=(len(self.lm_host),))
+        make_tracks(self, rng, landmarks_per_frame, track_len, pixel_noise)
 
 
 IMU_COLUMNS = ("timestamp", "q_w", "q_x", "q_y", "q_z", "p_x", "p_y", "p_z", "gyro_x", "gyro_y", "gyro_z", "acc_x", "acc_y", "acc_z")
@@ -166,6 +150,98 @@ def _read_csv(path, wanted, optional=()):
     return np.array(data, dtype=np.float64).reshape(-1, len(wanted)), np.array(extra, dtype=np.float64).reshape(-1, len(optional))
 
 
+def cut_imu_intervals(t_imu, meas, times, noise=None):
+    """IMU samples (stamps t_imu, rows acc | gyro) cut into per-frame intervals the way System::ProcessBackEnd does
+    (System.cpp:363-401): every sample up to the image stamp, then one sample linearly interpolated to the stamp itself, which also
+    opens the next interval (Estimator::processIMU: acc_0 / gyr_0).  Returns (raw intervals, their pre-integrations at zero bias)."""
+    def at(t):
+        j = int(np.clip(np.searchsorted(t_imu, t), 1, len(t_imu) - 1))
+        w = (t - t_imu[j - 1]) / (t_imu[j] - t_imu[j - 1])
+        w = min(max(w, 0.0), 1.0)
+        return (1.0 - w) * meas[j - 1] + w * meas[j]
+
+    ivs, pres = [], []
+    for k in range(len(times) - 1):
+        ta, tb = times[k], times[k + 1]
+        first = at(ta)
+        dts, accs, gyrs, cur = [], [], [], ta
+        for j in np.nonzero((t_imu > ta) & (t_imu <= tb))[0]:
+            if t_imu[j] - cur > 0:
+                dts.append(float(t_imu[j] - cur)); accs.append(meas[j, 0:3].copy()); gyrs.append(meas[j, 3:6].copy())
+                cur = float(t_imu[j])
+        if tb - cur > 1e-12:
+            last = at(tb)
+            dts.append(float(tb - cur)); accs.append(last[0:3].copy()); gyrs.append(last[3:6].copy())
+        ivs.append(dict(acc0=first[0:3].copy(), gyr0=first[3:6].copy(), dt=dts, acc=accs, gyr=gyrs))
+        pres.append(synth.preintegrate(first[0:3], first[3:6], np.zeros(3), np.zeros(3), dts, accs, gyrs, **(noise or {})))
+    return ivs, pres
+
+
+def make_tracks(st, rng, landmarks_per_frame, track_len, pixel_noise, ric=None, tic=None):
+    """Synthetic vision on a stream's ground-truth poses: landmarks hosted in frame h, seen in h+1 .. h+track_len."""
+    ric = synth.R_IC if ric is None else ric
+    tic = synth.T_IC if tic is None else tic
+    st.lm_host, st.lm_px, st.lm_depth, st.lm_obs = [], [], [], []
+    for h in range(st.n_frames - 1):
+        for _ in range(landmarks_per_frame):
+            px = rng.uniform(-0.5, 0.5, 2)
+            depth = rng.uniform(4.0, 10.0)
+            pw = st.R[h] @ (ric @ (np.array([px[0], px[1], 1.0]) * depth) + tic) + st.P[h]
+            obs = {}
+            for j in range(h + 1, min(h + 1 + track_len, st.n_frames)):
+                pc = ric.T @ (st.R[j].T @ (pw - st.P[j]) - tic)
+                pc[2] = max(pc[2], 0.5)
+                obs[j] = pc[0:2] / pc[2] + rng.normal(0.0, pixel_noise, 2)
+            st.lm_host.append(h)
+            st.lm_px.append(px)
+            st.lm_depth.append(depth)
+            st.lm_obs.append(obs)
+    st.init_noise = rng.normal(size=(len(st.lm_host),))
+
+
+class RealImuStream:
+    """Real inertial data, synthetic vision: the nearest runnable stand-in for the reference's EuRoC runs (VM/test/run_euroc.cpp:26-110
+    feeds MH_05_imu0.txt and the images of MH_05_cam0.txt; the images and the OpenCV front-end are not in the tree, the IMU file
+    and the stamps are).  `data` = tests/golden/mh05_imu_stretch.npz: the samples are cut at the frame stamps as System::ProcessBackEnd
+    does and pre-integrated with the noise parameters of euroc_config.yaml; the "ground truth" is the trajectory those
+    pre-integrations define from a gravity-aligned start at rest (P_j = P_i + V_i dt - g dt^2 / 2 + R_i delta_p, ...: the IMU
+    factors' own model, integration_base.h:160-186, so the inertial residuals vanish on it), and the landmarks are drawn in front of
+    its camera poses with the sequence's extrinsic.  Same attributes as SyntheticStream: StreamDriver runs on it."""
+
+    def __init__(self, data, n_frames=None, landmarks_per_frame=30, track_len=5, seed=0, pixel_noise=1.0 / 460.0):
+        rng = np.random.RandomState(seed)
+        cam_t = np.asarray(data["cam_t"], dtype=np.float64)
+        self.n_frames = int(n_frames or len(cam_t))
+        self.times = [float(t) for t in cam_t[:self.n_frames]]
+        self.t0, self.frame_dt = self.times[0], (self.times[-1] - self.times[0]) / max(1, self.n_frames - 1)
+        self.noise = dict(acc_n=float(data["acc_n"]), gyr_n=float(data["gyr_n"]), acc_w=float(data["acc_w"]), gyr_w=float(data["gyr_w"]))
+        self.g_norm = float(data["g_norm"])
+        self.ric, self.tic = np.asarray(data["ric"], dtype=np.float64), np.asarray(data["tic"], dtype=np.float64)
+        self.ext = np.concatenate([self.tic, synth.rot_to_quat(self.ric)])
+        meas = np.concatenate([np.asarray(data["imu_acc"]), np.asarray(data["imu_gyr"])], axis=1)
+        self.imu, self.preint = cut_imu_intervals(np.asarray(data["imu_t"], dtype=np.float64), meas, self.times, self.noise)
+        # start: at rest, the first accelerometer sample straight up (R_0 a_0 || +z: the specific force of a body at rest is -g)
+        a0 = self.imu[0]["acc0"] / np.linalg.norm(self.imu[0]["acc0"])
+        z = np.array([0.0, 0.0, 1.0])
+        v = np.cross(a0, z)
+        c = float(a0 @ z)
+        K = synth.skew(v)
+        R0 = np.eye(3) + K + K @ K / (1.0 + c)
+        g = np.array([0.0, 0.0, self.g_norm])
+        self.R, self.P, self.V = np.zeros((self.n_frames, 3, 3)), np.zeros((self.n_frames, 3)), np.zeros((self.n_frames, 3))
+        self.Q = np.zeros((self.n_frames, 4))
+        self.R[0], self.Q[0] = R0, synth.rot_to_quat(R0)
+        for k, pre in enumerate(self.preint):
+            dt = pre["sum_dt"]
+            self.P[k + 1] = self.P[k] + self.V[k] * dt - 0.5 * g * dt * dt + self.R[k] @ pre["delta_p"]
+            self.V[k + 1] = self.V[k] - g * dt + self.R[k] @ pre["delta_v"]
+            q = synth.quat_mul(self.Q[k], pre["delta_q"])
+            self.Q[k + 1] = q / np.linalg.norm(q)
+            self.R[k + 1] = synth.quat_to_rot(self.Q[k + 1])
+        self.has_ground_truth = True
+        make_tracks(self, rng, landmarks_per_frame, track_len, pixel_noise, self.ric, self.tic)
+
+
 class SimulatorFileStream:
     """A stream read from the reference simulator's files (see write_simulator_files): the same attributes as
     SyntheticStream, so StreamDriver runs on either.  IMU samples are cut into per-frame intervals the way
@@ -225,21 +301,8 @@ class SimulatorFileStream:
                 self.V[k] = (at(t + h, extra)[4:7] - at(t - h, extra)[4:7]) / (2.0 * h)
         self.has_ground_truth = bool(have_gt)
         # IMU intervals
-        self.imu, self.preint = [], []
         meas = imu[:, [4, 5, 6, 1, 2, 3]]                  # acc, gyro
-        for k in range(self.n_frames - 1):
-            ta, tb = self.times[k], self.times[k + 1]
-            first = at(ta, meas)
-            dts, accs, gyrs, cur = [], [], [], ta
-            for j in np.nonzero((t_imu > ta) & (t_imu <= tb))[0]:
-                if t_imu[j] - cur > 0:
-                    dts.append(float(t_imu[j] - cur)); accs.append(meas[j, 0:3].copy()); gyrs.append(meas[j, 3:6].copy())
-                    cur = float(t_imu[j])
-            if tb - cur > 1e-12:
-                last = at(tb, meas)
-                dts.append(float(tb - cur)); accs.append(last[0:3].copy()); gyrs.append(last[3:6].copy())
-            self.imu.append(dict(acc0=first[0:3].copy(), gyr0=first[3:6].copy(), dt=dts, acc=accs, gyr=gyrs))
-            self.preint.append(synth.preintegrate(first[0:3], first[3:6], np.zeros(3), np.zeros(3), dts, accs, gyrs))
+        self.imu, self.preint = cut_imu_intervals(t_imu, meas, self.times)
         # tracks: a feature id is hosted by the first frame that sees it
         index = {}
         self.lm_host, self.lm_px, self.lm_depth, self.lm_obs, self.lm_id = [], [], [], [], []
@@ -271,7 +334,12 @@ class StreamDriver:
         nonkey_every=n > 0: every n-th frame is not a keyframe: when it is the second-newest frame of the window it is
         marginalised (MARGIN_SECOND_NEW) instead of the oldest one."""
         self.lib, self.s = lib, stream
-        self.ctx = lib.context(**(ctx_kwargs or {}))
+        self.noise = dict(getattr(stream, "noise", None) or {})      # sensor noise of re-integrated intervals (default: synth's)
+        self.g_norm = float(getattr(stream, "g_norm", synth.G_NORM))
+        kw = dict(ctx_kwargs or {})
+        if hasattr(stream, "g_norm"):
+            kw.setdefault("gravity", (0.0, 0.0, self.g_norm))
+        self.ctx = lib.context(**kw)
         rng = np.random.RandomState(seed)
         st = stream
         self.frames = list(range(NUM_FRAMES))              # global index of the frame in each window slot
@@ -450,7 +518,7 @@ class StreamDriver:
         merged = dict(acc0=a["acc0"], gyr0=a["gyr0"], dt=a["dt"] + b["dt"], acc=a["acc"] + b["acc"], gyr=a["gyr"] + b["gyr"])
         self.intervals[WINDOW_SIZE - 2:] = [merged]
         self.preint[WINDOW_SIZE - 2:] = [synth.preintegrate(merged["acc0"], merged["gyr0"], np.zeros(3), np.zeros(3),
-                                                           merged["dt"], merged["acc"], merged["gyr"])]
+                                                           merged["dt"], merged["acc"], merged["gyr"], **self.noise)]
         self.frames.pop(WINDOW_SIZE - 1)
         self.poses[WINDOW_SIZE - 1], self.sb[WINDOW_SIZE - 1] = self.poses[WINDOW_SIZE].copy(), self.sb[WINDOW_SIZE].copy()
 
@@ -469,7 +537,7 @@ class StreamDriver:
         dt = pre["sum_dt"]
         i = WINDOW_SIZE - 1
         Ri = synth.quat_to_rot(self.poses[i, 3:7])
-        g = np.array([0.0, 0.0, synth.G_NORM])
+        g = np.array([0.0, 0.0, self.g_norm])
         Pi, Vi = self.poses[i, 0:3], self.sb[i, 0:3]
         self.poses[WINDOW_SIZE, 0:3] = Pi + Vi * dt - 0.5 * g * dt * dt + Ri @ pre["delta_p"]
         self.poses[WINDOW_SIZE, 3:7] = synth.quat_mul(self.poses[i, 3:7], pre["delta_q"])
