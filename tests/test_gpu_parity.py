@@ -314,6 +314,55 @@ def test_error_paths(vio, hip_lib):
     assert e.value.status == -5
 
 
+def test_observation_list_in_any_order(vio, oracle_lib, hip_lib):
+    """The reference's loop emits the edges landmark by landmark (estimator.cpp:975-1016) and the library has a fast path for such
+    lists (the list is its own CSR, the consistency of a landmark's edges is checked while they are copied, the observations go to the
+    device as listed and a kernel puts them into item order); the ABI takes any order.  The same window listed observation-index-major
+    (every landmark's edges far apart, their order inside a landmark kept) gives the same bits; a fully shuffled list (another order
+    of a landmark's edges = another pattern, another summation order) the same step to rounding; both agree with the oracle."""
+    w = vio.synth.make_window(700, seed=31, ragged=True)
+    first = np.concatenate([[0], np.cumsum(np.bincount(w.lm, minlength=w.n_landmarks))[:-1]])
+    kidx = np.arange(w.n_observations) - first[w.lm]
+    rng = np.random.RandomState(3)
+
+    def relisted(order):
+        v = w.copy()
+        for f in ("lm", "host", "target", "pts_i", "pts_j"):
+            setattr(v, f, np.ascontiguousarray(getattr(w, f)[order]))
+        return v
+
+    def step(lib, win):
+        c = lib.context()
+        c.load(win)
+        c.linearize()
+        _, lam = c.init_lm()
+        c.solve_linear(lam)
+        dx, dl = c.get_delta()
+        return c.chi2(), lam, dx, dl
+
+    base = step(hip_lib, w)
+    kmajor = step(hip_lib, relisted(np.lexsort((w.lm, kidx))))
+    assert kmajor[0] == base[0] and kmajor[1] == base[1] and np.array_equal(kmajor[2], base[2]) and np.array_equal(kmajor[3], base[3])
+    shuffled = relisted(rng.permutation(w.n_observations))
+    sh, so = step(hip_lib, shuffled), step(oracle_lib, shuffled)
+    assert abs(sh[0] - base[0]) <= 1e-9 * base[0]
+    np.testing.assert_allclose(sh[2], base[2], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sh[2], so[2], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(sh[3], so[3], rtol=0, atol=1e-8 * max(1.0, np.abs(so[3]).max()))
+    # a landmark whose edges disagree about its host observation: refused whatever the order of the list
+    for order in (np.arange(w.n_observations), np.lexsort((w.lm, kidx))):
+        bad = relisted(order)
+        two = int(np.nonzero(np.bincount(w.lm) >= 2)[0][3])          # a landmark with at least two edges
+        e = int(np.nonzero(bad.lm == two)[0][-1])
+        bad.pts_i = bad.pts_i.copy()
+        bad.pts_i[e, 0] += 1e-3
+        c = hip_lib.context()
+        c.load(bad)
+        with pytest.raises(vio.VioError) as err:
+            c.linearize()
+        assert err.value.status == -5
+
+
 def test_rollback_restores_the_states(vio, hip_lib):
     w = vio.synth.make_window(120, seed=9)
     ctx = hip_lib.context()

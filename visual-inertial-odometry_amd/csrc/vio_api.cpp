@@ -46,6 +46,7 @@ void vio_launch_linearize(const DeviceTables &T, int n_blocks, size_t lds_bytes,
 void vio_launch_reduce(const ReduceTables &R, hipStream_t s);
 void vio_launch_reduce_assemble(const ReduceTables &R, const DeviceTables &T, hipStream_t s);
 void vio_launch_assemble(const DeviceTables &T, hipStream_t s);
+void vio_launch_gather_obs(const ItemDesc *items, int n_items, const int32_t *first, const int32_t *obs_idx, const double *raw, double *out, hipStream_t s);
 void vio_launch_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map, hipStream_t s);
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s);
 void vio_launch_backsub(const DeviceTables &T, int mode, hipStream_t s);
@@ -153,6 +154,31 @@ struct HostArena {
     }
 };
 
+// A host mirror the DMA engine reads directly: the observations of a window are uploaded as the caller listed them, straight out
+// of this buffer, and put into item order by a kernel (k_gather_obs) instead of by a host loop over 80 000 observations.
+struct PinnedVec {
+    double *p = nullptr;
+    size_t n = 0, cap = 0;
+    const double *data() const { return p; }
+    size_t size() const { return n; }
+    double operator[](size_t i) const { return p[i]; }
+    void clear() { n = 0; }
+    bool assign(const double *a, const double *b) {
+        const size_t k = (size_t)(b - a);
+        if (k > cap) {
+            double *q = nullptr;
+            const size_t c2 = k + k / 4;
+            if (hipHostMalloc((void **)&q, std::max<size_t>(c2, 1) * 8, hipHostMallocDefault) != hipSuccess) return false;
+            if (p) hipHostFree(p);
+            p = q; cap = c2;
+        }
+        if (k) std::memcpy(p, a, k * 8);
+        n = k;
+        return true;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; n = cap = 0; }
+};
+
 struct Pattern {
     int use_ext, host, K, nb, host_slot, G;
     int btype_i[VIO_MAXNB], bk_i[VIO_MAXNB];
@@ -173,10 +199,10 @@ struct Plan {
     int max_lds_doubles = 0;
     int lin_threads = 0;                       // k_linearize's workgroup width for this plan: lin_threads_host(), or lin_threads_half_host() (two workgroups to a CU)
     DevBuf<ItemDesc> d_items;
-    DevBuf<int32_t> d_list_off, d_list;
+    DevBuf<int32_t> d_list_off, d_list, d_first, d_obs_idx;      // d_first / d_obs_idx: k_gather_obs's view of the caller's observation list
     DevBuf<double> d_pts_i, d_pts_j, d_invd, d_slab, d_lw, d_dxl, d_step_part;
     void release() {
-        d_items.release(); d_list_off.release(); d_list.release();
+        d_items.release(); d_list_off.release(); d_list.release(); d_first.release(); d_obs_idx.release();
         d_pts_i.release(); d_pts_j.release(); d_invd.release(); d_slab.release(); d_lw.release(); d_dxl.release();
         d_step_part.release();
         valid = false;
@@ -200,7 +226,9 @@ struct vio_ctx {
     // host mirrors of the inputs (original landmark order)
     double h_state[STATE_STRIDE];
     int lm_dim = 1;                            // 1: inverse depths; 3: XYZ points (h_invd [N][3], h_otarget = observing frame, h_pts_j = observation)
-    std::vector<double> h_invd, h_pts_i, h_pts_j;
+    std::vector<double> h_invd, h_pts_i, h_pts_i_lm;      // h_pts_i_lm [N][2]: the host observation by landmark (lists vio_set_observations vouches for)
+    PinnedVec h_pts_j;                         // pinned: uploaded as it is (raw_pts_valid: the device copy d_raw_pts_j is current)
+    bool raw_pts_valid = false;
     std::vector<int32_t> h_olm, h_ohost, h_otarget;   // observation -> landmark / host frame / target frame
     bool imu_valid[VIO_WINDOW_SIZE];
     std::vector<double> h_pre;                 // [10][PRE_STRIDE]
@@ -218,6 +246,8 @@ struct vio_ctx {
     bool dirty_inputs = true;                  // host mirrors newer than the device
     unsigned ahead = 0;                        // what the device holds newer than the host mirrors: 1 states, 2 landmarks, 4 b_prior / err_prior
     bool topo_dirty = true;
+    bool obs_consistent = false;               // ... and vio_set_observations has seen that they share host frame and host observation
+    bool obs_lm_major = false;                 // the observations of a landmark are consecutive and the landmarks ascend (vio_set_observations)
     bool linearized = false;
     bool pairtab_valid = false;
     bool stepwise_updated = false;
@@ -238,6 +268,7 @@ struct vio_ctx {
     DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
         d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi, d_gath, d_step_gath, d_sp_part;
     DevBuf<int32_t> d_imu_valid, d_perm, d_rank, d_gather_map;
+    DevBuf<double> d_raw_pts_j;                // the target observations in the caller's order (k_gather_obs reads them)
     DevBuf<double> d_Pg;
     DevBuf<LmState> d_lm;
     LmState h_lm;
@@ -316,7 +347,7 @@ void build_pattern_tables(Pattern &pt, int g_max, int threads, int lds_budget) {
     pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
 }
 
-vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j);
+vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j, const int32_t *first = nullptr, const int32_t *obs_idx = nullptr, int64_t n_obs_idx = 0);
 
 // The plan of a window of XYZ landmarks (vio_kernels_xyz.h): a pattern is the set of frames a landmark is seen from,
 // one pattern block per frame, no host frame and no extrinsic block.
@@ -457,24 +488,37 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto tus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     const auto tp0 = tnow();
+    // the observations leave for the device as the caller listed them, now: the copy runs under the host work below
+    if (M && !c->raw_pts_valid) {
+        HIPCHK(c->d_raw_pts_j.resize(2 * (size_t)M));
+        HIPCHK(hipMemcpyAsync(c->d_raw_pts_j.p, c->h_pts_j.data(), 2 * (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
+        c->raw_pts_valid = true;
+    }
     // observations of each landmark, in the caller's order (CSR; this runs once per frame on the host, so no
     // per-landmark allocations and no tree lookups: 20 000 landmarks take well under a millisecond)
-    struct ObsRange { const int32_t *p; size_t n; size_t size() const { return n; } bool empty() const { return n == 0; }
-                      int32_t operator[](size_t i) const { return p[i]; } const int32_t *begin() const { return p; } const int32_t *end() const { return p + n; } };
+    // (a landmark-major list — what the reference's loop emits — is its own CSR: observation k of landmark l is obs_off[l] + k)
+    struct ObsRange { const int32_t *p; size_t n; int32_t base; size_t size() const { return n; } bool empty() const { return n == 0; }
+                      int32_t operator[](size_t i) const { return p ? p[i] : base + (int32_t)i; } };
     std::vector<int64_t> obs_off(N + 1, 0);
     for (int64_t e = 0; e < M; ++e) ++obs_off[c->h_olm[e] + 1];
     for (int64_t l = 0; l < N; ++l) obs_off[l + 1] += obs_off[l];
-    std::vector<int32_t> obs_idx(std::max<int64_t>(M, 1));
-    {
+    const bool lm_major = c->obs_lm_major;
+    std::vector<int32_t> obs_idx;
+    if (!lm_major) {
+        obs_idx.resize(std::max<int64_t>(M, 1));
         std::vector<int64_t> fill(obs_off.begin(), obs_off.end() - 1);
         for (int64_t e = 0; e < M; ++e) obs_idx[fill[c->h_olm[e]]++] = (int32_t)e;
     }
-    auto obs_of = [&](int64_t l) { return ObsRange{obs_idx.data() + obs_off[l], (size_t)(obs_off[l + 1] - obs_off[l])}; };
+    auto obs_of = [&](int64_t l) { return ObsRange{lm_major ? nullptr : obs_idx.data() + obs_off[l], (size_t)(obs_off[l + 1] - obs_off[l]), (int32_t)obs_off[l]}; };
     const auto tp1 = tnow();
     // pattern of each landmark: (host, targets in observation order) packed 4 bits a frame
     std::unordered_map<uint64_t, int> pattern_id;
+    uint64_t pat_cache_key[256];
+    int pat_cache_id[256];
+    for (int q = 0; q < 256; ++q) pat_cache_id[q] = -1;
     pl.patterns.clear();
     std::vector<int32_t> lm_pattern(N, -1);
+    const bool vouched = lm_major && c->obs_consistent;
     for (int64_t l = 0; l < N; ++l) {
         const ObsRange ob = obs_of(l);
         if (ob.empty()) {
@@ -490,8 +534,9 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         uint64_t packed = (uint64_t)ob.size() | ((uint64_t)h << 4);
         bool seen[NF] = {false};
         seen[h] = true;
-        for (int32_t e : ob) {
-            if (c->h_ohost[e] != h || c->h_pts_i[2 * e] != c->h_pts_i[2 * ob[0]] || c->h_pts_i[2 * e + 1] != c->h_pts_i[2 * ob[0] + 1])
+        for (size_t oi = 0; oi < ob.size(); ++oi) {
+            const int32_t e = ob[oi];
+            if (!vouched && (c->h_ohost[e] != h || c->h_pts_i[2 * e] != c->h_pts_i[2 * ob[0]] || c->h_pts_i[2 * e + 1] != c->h_pts_i[2 * ob[0] + 1]))
                 return fail(c, VIO_ERR_UNSUPPORTED, "edges of one landmark must share host frame and host observation");
             const int t = c->h_otarget[e];
             if (seen[t]) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
@@ -499,11 +544,17 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
             packed |= (uint64_t)t << (4 * (nkey + 1));
             key[nkey++] = (int8_t)t;
         }
-        auto itp = pattern_id.find(packed);
-        int id;
-        if (itp == pattern_id.end()) {
+        int id = -1;
+        const unsigned hslot = (unsigned)((packed * 0x9E3779B97F4A7C15ull) >> 56);      // 256 slots in front of the map
+        if (pat_cache_id[hslot] >= 0 && pat_cache_key[hslot] == packed) id = pat_cache_id[hslot];
+        else {
+            auto itp = pattern_id.find(packed);
+            if (itp != pattern_id.end()) { id = itp->second; pat_cache_key[hslot] = packed; pat_cache_id[hslot] = id; }
+        }
+        if (id < 0) {
             id = (int)pl.patterns.size();
             pattern_id[packed] = id;
+            pat_cache_key[hslot] = packed; pat_cache_id[hslot] = id;
             Pattern pt;
             std::memset(&pt, 0, sizeof(pt));
             pt.use_ext = pl.use_ext; pt.host = h; pt.K = (int)ob.size();
@@ -519,7 +570,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
             }
             build_pattern_tables(pt, c->g_max > 0 ? c->g_max : 128, pl.lin_threads, half ? LDS_BUDGET_HALF_DOUBLES : LDS_BUDGET_DOUBLES);      // pt.G = the most landmarks the LDS holds
             pl.patterns.push_back(pt);
-        } else id = itp->second;
+        }
         lm_pattern[l] = id;
     }
     const auto tp2 = tnow();
@@ -568,8 +619,8 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     pl.items.clear();
     // host observations / observations in item order, written straight into the pinned staging
     double *pts_i = (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>(pl.Ns, 1) * 8);
-    double *pts_j = (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>(M, 1) * 8);
-    if (!pts_i || !pts_j) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+    int32_t *first = (int32_t *)c->arena.alloc((size_t)std::max<int64_t>(pl.Ns, 1) * 4);
+    if (!pts_i || !first) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
     pl.slab_doubles = 0; pl.lw_doubles = 0; pl.max_lds_doubles = IMU_ITEM_LDS_DOUBLES;
     int64_t s = 0, obs_base = 0;
     while (s < pl.Ns) {
@@ -594,11 +645,9 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
         for (int g = 0; g < it.G; ++g) {
             const int32_t l = pl.sorted_to_orig[s + g];
             const ObsRange ob = obs_of(l);
-            pts_i[2 * (s + g)] = c->h_pts_i[2 * ob[0]]; pts_i[2 * (s + g) + 1] = c->h_pts_i[2 * ob[0] + 1];
-            for (int k = 0; k < it.K; ++k) {
-                const int64_t o = obs_base + (int64_t)k * it.G + g;
-                pts_j[2 * o] = c->h_pts_j[2 * ob[k]]; pts_j[2 * o + 1] = c->h_pts_j[2 * ob[k] + 1];
-            }
+            const double *hp = vouched ? &c->h_pts_i_lm[2 * (size_t)l] : &c->h_pts_i[2 * (size_t)ob[0]];
+            pts_i[2 * (s + g)] = hp[0]; pts_i[2 * (s + g) + 1] = hp[1];
+            first[s + g] = (int32_t)obs_off[l];          // (the target observations follow on the device: k_gather_obs)
         }
         obs_base += (int64_t)it.G * it.K;
         s = e;
@@ -607,15 +656,21 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     if (timing) {
         const auto tb = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[vio host timing] build_plan: obs lists %.0f us, patterns %.0f us, sort + sizing %.0f us, items + gather %.0f us\n", tus(tp0, tp1), tus(tp1, tp2), tus(tp2, tp3), tus(tp3, tb));
-        const vio_status st = upload_plan(c, pl, pts_i, pts_j);
+        const int32_t *s_idx0 = lm_major ? nullptr : c->arena.put(obs_idx.data(), obs_idx.size());
+        if (!lm_major && !s_idx0) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+        const vio_status st = upload_plan(c, pl, pts_i, nullptr, first, s_idx0, (int64_t)obs_idx.size());
         std::fprintf(stderr, "[vio host timing] build_plan: upload_plan %.0f us of it\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count());
         return st;
     }
-    return upload_plan(c, pl, pts_i, pts_j);
+    const int32_t *s_idx = lm_major ? nullptr : c->arena.put(obs_idx.data(), obs_idx.size());
+    if (!lm_major && !s_idx) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+    return upload_plan(c, pl, pts_i, nullptr, first, s_idx, (int64_t)obs_idx.size());
 }
 
 // inverted lists for k_reduce, device buffers, upload: common to both kinds of landmark
-vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j) {
+// pts_j == nullptr: the observations are on the device in the caller's order (d_raw_pts_j) and k_gather_obs puts them into item order:
+// first[s] = place of sorted landmark s's first observation in that list (landmark-major lists), or in obs_idx (the CSR of any other list)
+vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j, const int32_t *first, const int32_t *obs_idx, int64_t n_obs_idx) {
     const int n_lists = VIO_NPAIR + VIO_NCB + 1;
     std::vector<std::vector<int32_t>> lists(n_lists);
     for (const ItemDesc &it : pl.items) {
@@ -656,7 +711,17 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *
     HIPCHK(hipMemcpyAsync(pl.d_list_off.p, s_off, pl.list_off.size() * 4, hipMemcpyHostToDevice, st));
     if (!pl.list.empty()) HIPCHK(hipMemcpyAsync(pl.d_list.p, s_list, pl.list.size() * 4, hipMemcpyHostToDevice, st));
     if (pl.Ns && pl.lm_dim == 1) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i, 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
-    if (pl.Ms) HIPCHK(hipMemcpyAsync(pl.d_pts_j.p, pts_j, 2 * (size_t)pl.Ms * 8, hipMemcpyHostToDevice, st));
+    if (pl.Ms && pts_j) HIPCHK(hipMemcpyAsync(pl.d_pts_j.p, pts_j, 2 * (size_t)pl.Ms * 8, hipMemcpyHostToDevice, st));
+    else if (pl.Ms) {
+        HIPCHK(pl.d_first.resize((size_t)pl.Ns));
+        HIPCHK(hipMemcpyAsync(pl.d_first.p, first, (size_t)pl.Ns * 4, hipMemcpyHostToDevice, st));
+        if (obs_idx) {
+            HIPCHK(pl.d_obs_idx.resize((size_t)n_obs_idx));
+            HIPCHK(hipMemcpyAsync(pl.d_obs_idx.p, obs_idx, (size_t)n_obs_idx * 4, hipMemcpyHostToDevice, st));
+        }
+        vio_launch_gather_obs(pl.d_items.p, (int)ni, pl.d_first.p, obs_idx ? pl.d_obs_idx.p : nullptr, c->d_raw_pts_j.p, pl.d_pts_j.p, st);
+        HIPCHK(hipGetLastError());
+    }
     pl.valid = true;
     return VIO_OK;
 }
@@ -1203,6 +1268,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
     c->d_batch_tabs.release(); c->d_rank.release(); c->d_gather_map.release(); c->d_gath.release(); c->d_step_gath.release();
     c->arena.release(c->own_stream);
+    c->h_pts_j.release(); c->d_raw_pts_j.release();
     if (c->pull_stage) hipHostFree(c->pull_stage);
     if (c->marg_stage) hipHostFree(c->marg_stage);
     if (c->h_lm_pin) hipHostFree(c->h_lm_pin);
@@ -1258,8 +1324,12 @@ vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, co
     if ((int64_t)c->h_olm.size() == m && (m == 0 || (std::memcmp(c->h_olm.data(), lm, (size_t)m * 4) == 0 && std::memcmp(c->h_otarget.data(), frame, (size_t)m * 4) == 0 &&
                                                      std::memcmp(c->h_pts_j.data(), pts, (size_t)m * 16) == 0)))
         return VIO_OK;               // the graph the context already holds: its plans stay
+    enter_device(c);
+    if (c->arena.pending) { HIPCHK(hipEventSynchronize(c->arena.ev)); c->arena.pending = false; }
     c->h_olm.assign(lm, lm + m); c->h_otarget.assign(frame, frame + m); c->h_ohost.assign((size_t)m, 0);
-    c->h_pts_j.assign(pts, pts + 2 * m); c->h_pts_i.assign(2 * (size_t)m, 0.0);
+    if (!c->h_pts_j.assign(pts, pts + 2 * m)) return fail(c, VIO_ERR_HIP, "hipHostMalloc (observations)");
+    c->h_pts_i.assign(2 * (size_t)m, 0.0);
+    c->raw_pts_valid = false;
     c->topo_dirty = true;
     c->dirty_inputs = true;
     return VIO_OK;
@@ -1270,15 +1340,41 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
     if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
     if (c->lm_dim == 3) return fail(c, VIO_ERR_BAD_ARG, "the context holds XYZ landmarks: use vio_set_observations_xyz");
     const int64_t N = (int64_t)c->h_invd.size();
-    for (int64_t e = 0; e < m; ++e)
-        if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
-            return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
+    {   // one pass over the list: any index out of range?  is it landmark-major, as estimator.cpp:975-1016 emits it?  and if so: do the
+        // edges of a landmark — neighbours in such a list — share host frame and host observation (edge_reprojection.cc:24: pts_i is
+        // the landmark's)?  The landmark's host observation is noted by landmark on the way (h_pts_i_lm), for build_plan, which repeats
+        // the consistency check per landmark only for the lists this pass does not vouch for (and names the offender).
+        unsigned bad = 0, unsorted = 0, incons = 0;
+        const uint32_t un = (uint32_t)std::min<int64_t>(N, INT32_MAX);
+        c->h_pts_i_lm.resize(2 * (size_t)N);
+        double *pl = c->h_pts_i_lm.data();
+        int32_t prev = -1;
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t l = lm[e];
+            bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)host[e] >= (uint32_t)NF) | (unsigned)((uint32_t)target[e] >= (uint32_t)NF) |
+                   (unsigned)(host[e] == target[e]);
+            unsorted |= (unsigned)(l < prev);
+            if (l == prev) incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
+            else if ((uint32_t)l < un) { pl[2 * (size_t)l] = pi[2 * e]; pl[2 * (size_t)l + 1] = pi[2 * e + 1]; }
+            prev = l;
+        }
+        if (bad)
+            for (int64_t e = 0; e < m; ++e)
+                if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
+                    return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
+        c->obs_lm_major = !unsorted;
+        c->obs_consistent = !unsorted && !incons;
+    }
     if ((int64_t)c->h_olm.size() == m && (m == 0 || (std::memcmp(c->h_olm.data(), lm, (size_t)m * 4) == 0 && std::memcmp(c->h_ohost.data(), host, (size_t)m * 4) == 0 &&
                                                      std::memcmp(c->h_otarget.data(), target, (size_t)m * 4) == 0 && std::memcmp(c->h_pts_i.data(), pi, (size_t)m * 16) == 0 &&
                                                      std::memcmp(c->h_pts_j.data(), pj, (size_t)m * 16) == 0)))
         return VIO_OK;               // the graph the context already holds: its plans stay
+    enter_device(c);
+    if (c->arena.pending) { HIPCHK(hipEventSynchronize(c->arena.ev)); c->arena.pending = false; }      // an upload out of h_pts_j still in flight (long done)
     c->h_olm.assign(lm, lm + m); c->h_ohost.assign(host, host + m); c->h_otarget.assign(target, target + m);
-    c->h_pts_i.assign(pi, pi + 2 * m); c->h_pts_j.assign(pj, pj + 2 * m);
+    c->h_pts_i.assign(pi, pi + 2 * m);
+    if (!c->h_pts_j.assign(pj, pj + 2 * m)) return fail(c, VIO_ERR_HIP, "hipHostMalloc (observations)");
+    c->raw_pts_valid = false;
     c->topo_dirty = true;
     c->dirty_inputs = true;
     return VIO_OK;

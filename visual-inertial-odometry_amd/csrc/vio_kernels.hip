@@ -2525,6 +2525,24 @@ __global__ __launch_bounds__(RED_THREADS) void k_errprior_b(BatchArgs a) {
 void vio_launch_errprior(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_errprior, dim3(RED_ERR_BLOCKS), dim3(RED_THREADS), 0, s, T); }
 // the landmarks of one plan out of another's, at the current slot of both double buffers (MargOldFrame straight after a solve:
 // dst = the landmarks hosted in frame 0, map = their places in the solve plan's order)
+// The target observations of a window from the caller's list (raw, (x, y) pairs) into item order (pts_j: obs_base + k G + g, the
+// layout k_linearize reads coalesced): one workgroup per item.  first[s]: where sorted landmark s's observations start — in the
+// list itself when it is landmark-major (what estimator.cpp:975-1016 emits), else in obs_idx, the list's CSR by landmark.
+__global__ __launch_bounds__(256) void k_gather_obs(const ItemDesc *items, const int32_t *first, const int32_t *obs_idx, const double2 *raw, double2 *out) {
+    const ItemDesc *it = items + blockIdx.x;
+    const int G = it->G, n = G * it->K, s = it->lm_base;
+    double2 *o = out + it->obs_base;
+    for (int t = threadIdx.x; t < n; t += 256) {
+        const int k = t / G, g = t - k * G;
+        int src = first[s + g] + k;
+        if (obs_idx) src = obs_idx[src];
+        o[t] = raw[src];
+    }
+}
+void vio_launch_gather_obs(const ItemDesc *items, int n_items, const int32_t *first, const int32_t *obs_idx, const double *raw, double *out, hipStream_t s) {
+    if (n_items > 0) hipLaunchKernelGGL(k_gather_obs, dim3(n_items), dim3(256), 0, s, items, first, obs_idx, (const double2 *)raw, (double2 *)out);
+}
+
 __global__ __launch_bounds__(256) void k_gather_landmarks(const LmState *lm, const double *src, int ns_src, double *dst, int ns_dst, const int32_t *map) {
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= ns_dst) return;
