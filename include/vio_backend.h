@@ -75,8 +75,9 @@ typedef enum { VIO_ITEMS_LATENCY = 0, VIO_ITEMS_THROUGHPUT = 1 } vio_item_policy
  *                        than Eigen's own vectors on the golden systems, tests/golden/ldlt_exact.npz); 40 % less time. */
 typedef enum { VIO_ORDER_EIGEN = 0, VIO_ORDER_CHAIN = 1 } vio_solve_order;
 
-/* Version of this interface: 3 = the sharded exchange is an all-gather (round 3); 4 = vio_set_solve_order (round 4). */
-#define VIO_ABI_VERSION 4
+/* Version of this interface: 3 = the sharded exchange is an all-gather (round 3); 4 = vio_set_solve_order (round 4);
+ * 5 = vio_map_observations / vio_commit_observations. */
+#define VIO_ABI_VERSION 5
 
 typedef enum {
     VIO_MARG_OLD = 0,          /* Estimator::MargOldFrame  estimator.cpp:693-829 */
@@ -152,6 +153,14 @@ vio_status vio_set_landmarks(struct vio_ctx *ctx, int64_t n, const double *inv_d
 vio_status vio_set_observations(struct vio_ctx *ctx, int64_t m, const int32_t *lm,
                                 const int32_t *host, const int32_t *target,
                                 const double *pts_i_xy, const double *pts_j_xy);
+/* The same list, written in place: vio_map_observations hands out the library's own arrays for m edges (the HIP library's are the
+ * ones its uploads leave from: pts_j_xy is pinned host memory) for the caller's loop over its tracks (estimator.cpp:975-1016) to fill,
+ * vio_commit_observations checks and adopts what was written — one copy of the 44 bytes per edge instead of two.  The arrays are the
+ * library's; they stay valid until the next vio_set_observations / vio_map_observations / vio_set_landmarks* / vio_destroy.  Between
+ * map and commit the context holds no observation list (any call that needs one fails with VIO_ERR_BAD_ARG).  (VIO_ABI_VERSION 5.) */
+vio_status vio_map_observations(struct vio_ctx *ctx, int64_t m, int32_t **lm, int32_t **host, int32_t **target,
+                                double **pts_i_xy, double **pts_j_xy);
+vio_status vio_commit_observations(struct vio_ctx *ctx);
 /* ---- 3-D landmarks: VertexPointXYZ (VM/include/backend/vertex_point_xyz.h:16) observed through EdgeReprojectionXYZ
  *      (VM/src/backend/edge_reprojection.cc:130-180; VM/include/backend/edge_reprojection.h:56-83) instead of inverse
  *      depths in a host frame.  The landmark blocks of Hmm are 3x3; Problem inverts them with the generic

@@ -954,6 +954,7 @@ struct vioo_ctx {
     double pose[NF * 7], sb[NF * 9], ext[7];
     double pose_bak[NF * 7], sb_bak[NF * 9], ext_bak[7];
     int64_t N, M;
+    int64_t M_mapped;              /* >= 0 between vio_map_observations and vio_commit_observations */
     int lm_dim;                 /* 1: VertexInverseDepth (invd[N]); 3: VertexPointXYZ (invd[N][3] holds the world points,
                                  * target[] the observing frame, pts_j the observation; hll 3x3, bl 3, Hpl 72x3 per landmark) */
     double *invd, *invd_bak;
@@ -1017,6 +1018,7 @@ vio_status vio_create(const vio_config *cfg, struct vioo_ctx **out) {
     if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
     c->ni = 2; c->lambda = -1;
     c->lm_dim = 1;
+    c->M_mapped = -1;
     c->vis = c->vis_own; c->step = c->step_own;
     c->gath = c->gath_own = (double *)calloc((size_t)c->cfg.shard_count * VIS_MAXH, sizeof(double));
     c->step_gath = c->step_gath_own = (double *)calloc((size_t)c->cfg.shard_count * 2, sizeof(double));
@@ -1127,6 +1129,37 @@ vio_status vio_set_observations(struct vioo_ctx *c, int64_t m, const int32_t *lm
         memcpy(c->pts_i, pi, sizeof(double) * 2 * m); memcpy(c->pts_j, pj, sizeof(double) * 2 * m);
     }
     c->linearized = 0;
+    return VIO_OK;
+}
+
+/* vio_map_observations / vio_commit_observations (include/vio_backend.h): the context's arrays written in place */
+vio_status vio_map_observations(struct vioo_ctx *c, int64_t m, int32_t **lm, int32_t **host, int32_t **target, double **pi, double **pj) {
+    if (!c || m < 0 || !lm || !host || !target || !pi || !pj) return VIO_ERR_BAD_ARG;
+    if (c->lm_dim == 3) { snprintf(c->err, sizeof(c->err), "the context holds XYZ landmarks: use vio_set_observations_xyz"); return VIO_ERR_BAD_ARG; }
+    free(c->lm); free(c->host); free(c->target); free(c->pts_i); free(c->pts_j);
+    size_t mm = (size_t)(m > 0 ? m : 1);
+    c->lm = (int32_t *)calloc(mm, sizeof(int32_t)); c->host = (int32_t *)calloc(mm, sizeof(int32_t));
+    c->target = (int32_t *)calloc(mm, sizeof(int32_t));
+    c->pts_i = (double *)calloc(2 * mm, sizeof(double)); c->pts_j = (double *)calloc(2 * mm, sizeof(double));
+    c->M = 0;                      /* no list until the commit */
+    c->M_mapped = m;
+    c->linearized = 0;
+    *lm = c->lm; *host = c->host; *target = c->target; *pi = c->pts_i; *pj = c->pts_j;
+    return VIO_OK;
+}
+vio_status vio_commit_observations(struct vioo_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (c->M_mapped < 0) { snprintf(c->err, sizeof(c->err), "vio_commit_observations without vio_map_observations"); return VIO_ERR_BAD_ARG; }
+    const int64_t m = c->M_mapped;
+    c->M_mapped = -1;
+    for (int64_t e = 0; e < m; ++e) {
+        if (c->lm[e] < 0 || c->lm[e] >= c->N || c->host[e] < 0 || c->host[e] >= NF || c->target[e] < 0 || c->target[e] >= NF ||
+            c->host[e] == c->target[e]) {
+            snprintf(c->err, sizeof(c->err), "observation %lld out of range", (long long)e);
+            return VIO_ERR_BAD_ARG;
+        }
+    }
+    c->M = m;
     return VIO_OK;
 }
 
@@ -1467,6 +1500,7 @@ static int run_hook(struct vioo_ctx *c, int which) {
 
 /* SetOrdering + MakeHessian (problem.cc:256-285,303-389) + the lambda-free part of SolveLinearSystem (:412-429) */
 vio_status vio_linearize(struct vioo_ctx *c) {
+    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;
     double t0 = now_ms();
     linearize_visual(c, 0);
@@ -1699,6 +1733,7 @@ vio_status vio_eval_step(struct vioo_ctx *c, int32_t *accepted, double *chi2, do
 
 /* Problem::Solve, problem.cc:169-250 */
 vio_status vio_solve(struct vioo_ctx *c, int32_t iterations, vio_solve_report *rep) {
+    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;
     if (c->M == 0 && c->N == 0) {
         int any = 0;
@@ -1741,6 +1776,7 @@ vio_status vio_solve(struct vioo_ctx *c, int32_t iterations, vio_solve_report *r
 }
 
 vio_status vio_gn_iteration(struct vioo_ctx *c, double lambda) {
+    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;
     vio_linearize(c);
     vio_solve_linear(c, lambda);
@@ -1809,6 +1845,7 @@ void vioo_schur_pinv(int n, int m2, const double *H, const double *b, double *Hp
 }
 
 vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, double *bout, double *errout, double *jtout) {
+    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c || !Hout || !bout || !errout || !jtout) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
     const int n = PD;
@@ -1874,6 +1911,7 @@ vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, doubl
 
 /* the two halves of include/vio_backend.h (here: begin computes, end copies; nothing runs in the background) */
 vio_status vio_marginalize_begin(struct vioo_ctx *c, int32_t kind) {
+    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;
     if (!c->mo_H) { c->mo_H = (double *)malloc(sizeof(double) * PRD * PRD); c->mo_jt = (double *)malloc(sizeof(double) * PRD * PRD); }
     c->mo_status = vio_marginalize(c, kind, c->mo_H, c->mo_b, c->mo_err, c->mo_jt);

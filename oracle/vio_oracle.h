@@ -52,6 +52,8 @@
 #define vio_triangulate vioo_triangulate
 #define vio_set_landmarks_xyz vioo_set_landmarks_xyz
 #define vio_set_observations_xyz vioo_set_observations_xyz
+#define vio_map_observations vioo_map_observations
+#define vio_commit_observations vioo_commit_observations
 #define vio_get_landmarks_xyz vioo_get_landmarks_xyz
 #include "../include/vio_backend.h"
 

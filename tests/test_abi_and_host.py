@@ -154,3 +154,31 @@ def test_abi_preintegration_matches_numpy_and_oracle(vio, oracle_lib):
         np.testing.assert_allclose(np.array(got.delta_v[:]), np.asarray(ref["delta_v"]).reshape(-1), rtol=0, atol=1e-14)
         np.testing.assert_allclose(np.array(got.jacobian[:]), np.asarray(ref["jacobian"]).reshape(-1), rtol=1e-12, atol=1e-15)
         np.testing.assert_allclose(np.array(got.covariance[:]), np.asarray(ref["covariance"]).reshape(-1), rtol=1e-11, atol=1e-30)
+
+
+def test_observation_list_written_in_place(vio, oracle_lib):
+    """vio_map_observations / vio_commit_observations (the library's own arrays filled by the caller's loop, one copy instead of two):
+    the same window as through vio_set_observations, and the protocol's error paths — on the CPU restatement; the HIP library's
+    arrays are pinned memory, its test is tests/test_gpu_parity.py::test_observation_list_written_in_place_on_the_gpu."""
+    w = vio.synth.make_window(120, seed=8, ragged=True)
+    a, b = oracle_lib.context(), oracle_lib.context()
+    a.load(w)
+    b.set_window(w.poses, w.speed_bias, w.ext)
+    b.set_landmarks(w.inv_depth)
+    lm, host, target, pi, pj = b.map_observations(w.n_observations)
+    lm[:], host[:], target[:], pi[:], pj[:] = w.lm, w.host, w.target, w.pts_i, w.pts_j
+    with pytest.raises(vio.VioError):
+        b.linearize()                       # no list between map and commit
+    b.commit_observations()
+    for k, p in enumerate(w.preint):
+        b.set_imu(k, p)
+    b.set_prior(None)
+    ra, rb = a.solve(10), b.solve(10)
+    assert ra.final_chi2 == rb.final_chi2 and ra.iterations == rb.iterations
+    assert np.array_equal(a.get_landmarks(), b.get_landmarks())
+    with pytest.raises(vio.VioError):
+        b.commit_observations()             # nothing mapped
+    lm, host, target, pi, pj = b.map_observations(3)
+    lm[:], host[:], target[:] = (0, 1, 500), (0, 0, 0), (1, 1, 1)
+    with pytest.raises(vio.VioError):
+        b.commit_observations()             # landmark index out of range

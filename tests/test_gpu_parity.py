@@ -363,6 +363,36 @@ def test_observation_list_in_any_order(vio, oracle_lib, hip_lib):
         assert err.value.status == -5
 
 
+def test_observation_list_written_in_place_on_the_gpu(vio, hip_lib):
+    """vio_map_observations hands out the HIP library's own arrays (pts_j: the pinned buffer its upload leaves from); filled in place and
+    committed they give the bits vio_set_observations gives, frame after frame on one context (the arrays are re-used), also when a
+    frame has more or fewer edges than the one before; between map and commit the context holds no list."""
+    ws = [vio.synth.make_window(n, seed=60 + i, ragged=(i % 2 == 1)) for i, n in enumerate((400, 900, 250))]
+    a, b = hip_lib.context(), hip_lib.context()
+    for w in ws:
+        a.load(w)
+        b.set_window(w.poses, w.speed_bias, w.ext)
+        b.set_landmarks(w.inv_depth)
+        lm, host, target, pi, pj = b.map_observations(w.n_observations)
+        lm[:], host[:], target[:], pi[:], pj[:] = w.lm, w.host, w.target, w.pts_i, w.pts_j
+        with pytest.raises(vio.VioError):
+            b.linearize()
+        b.commit_observations()
+        for k, p in enumerate(w.preint):
+            b.set_imu(k, p)
+        b.set_prior(None)
+        ra, rb = a.solve(10), b.solve(10)
+        assert ra.final_chi2 == rb.final_chi2 and ra.iterations == rb.iterations
+        assert np.array_equal(a.get_landmarks(), b.get_landmarks())
+        assert np.array_equal(a.get_window()[0], b.get_window()[0])
+    with pytest.raises(vio.VioError):
+        b.commit_observations()
+    lm, host, target, pi, pj = b.map_observations(2)
+    lm[:], host[:], target[:] = (0, 1), (0, 3), (1, 3)          # host == target
+    with pytest.raises(vio.VioError):
+        b.commit_observations()
+
+
 def test_rollback_restores_the_states(vio, hip_lib):
     w = vio.synth.make_window(120, seed=9)
     ctx = hip_lib.context()

@@ -91,7 +91,9 @@ class VioLib:
     # outside the backend proper: the compiled-reference harness (vior_) has no FeatureManager
     # ... nor the receive side of the sharded exchange (it never shards)
     # ... nor the two-halves marginalisation (vio_marginalize_begin / _end)
-    OPTIONAL = ["triangulate", "gather_buffers", "bind_gather_buffers", "marginalize_begin", "marginalize_end"]
+    # ... nor the in-place observation list (vio_map_observations / vio_commit_observations)
+    OPTIONAL = ["triangulate", "gather_buffers", "bind_gather_buffers", "marginalize_begin", "marginalize_end",
+                "map_observations", "commit_observations"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
@@ -260,6 +262,23 @@ class VioContext:
         pi, pj = _f64(pts_i, (self.m, 2)), _f64(pts_j, (self.m, 2))
         self._ck(self.lib.fn["set_observations"](self.h, C.c_int64(self.m), _ip(lm), _ip(host), _ip(target),
                                                  _dp(pi), _dp(pj)), "set_observations")
+
+    def map_observations(self, m):
+        """vio_map_observations: the library's own arrays for m edges as numpy views (lm, host, target [m] int32; pts_i, pts_j [m][2]
+        float64) to be filled in place, then commit_observations()."""
+        ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+        lm, host, target, pi, pj = ip(), ip(), ip(), dp(), dp()
+        self._ck(self.lib.fn["map_observations"](self.h, C.c_int64(m), C.byref(lm), C.byref(host), C.byref(target), C.byref(pi), C.byref(pj)),
+                 "map_observations")
+        self.m = int(m)
+        if m == 0:
+            z = np.zeros(0, dtype=np.int32)
+            return z, z.copy(), z.copy(), np.zeros((0, 2)), np.zeros((0, 2))
+        view = np.ctypeslib.as_array
+        return (view(lm, (m,)), view(host, (m,)), view(target, (m,)), view(pi, (2 * m,)).reshape(m, 2), view(pj, (2 * m,)).reshape(m, 2))
+
+    def commit_observations(self):
+        self._ck(self.lib.fn["commit_observations"](self.h), "commit_observations")
 
     def set_imu(self, k, pre):
         if pre is None:

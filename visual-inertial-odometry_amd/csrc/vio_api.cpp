@@ -163,6 +163,17 @@ struct PinnedVec {
     size_t size() const { return n; }
     double operator[](size_t i) const { return p[i]; }
     void clear() { n = 0; }
+    bool resize_uninitialized(size_t k) {
+        if (k > cap) {
+            double *q = nullptr;
+            const size_t c2 = k + k / 4;
+            if (hipHostMalloc((void **)&q, std::max<size_t>(c2, 1) * 8, hipHostMallocDefault) != hipSuccess) return false;
+            if (p) hipHostFree(p);
+            p = q; cap = c2;
+        }
+        n = k;
+        return true;
+    }
     bool assign(const double *a, const double *b) {
         const size_t k = (size_t)(b - a);
         if (k > cap) {
@@ -246,6 +257,7 @@ struct vio_ctx {
     bool dirty_inputs = true;                  // host mirrors newer than the device
     unsigned ahead = 0;                        // what the device holds newer than the host mirrors: 1 states, 2 landmarks, 4 b_prior / err_prior
     bool topo_dirty = true;
+    bool obs_mapped = false;                   // between vio_map_observations and vio_commit_observations: no list
     bool obs_consistent = false;               // ... and vio_set_observations has seen that they share host frame and host observation
     bool obs_lm_major = false;                 // the observations of a landmark are consecutive and the landmarks ascend (vio_set_observations)
     bool linearized = false;
@@ -923,6 +935,7 @@ vio_status push_to_device(vio_ctx *c, Plan &pl) {
 
 // make `pl` the active plan with the host mirrors uploaded
 vio_status activate(vio_ctx *c, Plan &pl, int marg) {
+    if (c->obs_mapped) return fail(c, VIO_ERR_BAD_ARG, "vio_map_observations without vio_commit_observations: the context holds no observation list");
     const bool need_build = !pl.valid || c->topo_dirty;
     const bool switching = c->active != &pl;
     if (need_build || switching || c->dirty_inputs) {
@@ -1335,36 +1348,41 @@ vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, co
     return VIO_OK;
 }
 
+// One pass over an observation list: any index out of range?  is it landmark-major, as estimator.cpp:975-1016 emits it?  and if so: do the
+// edges of a landmark — neighbours in such a list — share host frame and host observation (edge_reprojection.cc:24: pts_i is the
+// landmark's)?  The landmark's host observation is noted by landmark on the way (h_pts_i_lm), for build_plan, which repeats the
+// consistency check per landmark only for the lists this pass does not vouch for (and names the offender).
+static vio_status scan_observations(vio_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi) {
+    const int64_t N = (int64_t)c->h_invd.size();
+    unsigned bad = 0, unsorted = 0, incons = 0;
+    const uint32_t un = (uint32_t)std::min<int64_t>(N, INT32_MAX);
+    c->h_pts_i_lm.resize(2 * (size_t)N);
+    double *pl = c->h_pts_i_lm.data();
+    int32_t prev = -1;
+    for (int64_t e = 0; e < m; ++e) {
+        const int32_t l = lm[e];
+        bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)host[e] >= (uint32_t)NF) | (unsigned)((uint32_t)target[e] >= (uint32_t)NF) |
+               (unsigned)(host[e] == target[e]);
+        unsorted |= (unsigned)(l < prev);
+        if (l == prev) incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
+        else if ((uint32_t)l < un) { pl[2 * (size_t)l] = pi[2 * e]; pl[2 * (size_t)l + 1] = pi[2 * e + 1]; }
+        prev = l;
+    }
+    if (bad)
+        for (int64_t e = 0; e < m; ++e)
+            if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
+                return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
+    c->obs_lm_major = !unsorted;
+    c->obs_consistent = !unsorted && !incons;
+    return VIO_OK;
+}
+
 vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target,
                                 const double *pi, const double *pj) {
     if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
     if (c->lm_dim == 3) return fail(c, VIO_ERR_BAD_ARG, "the context holds XYZ landmarks: use vio_set_observations_xyz");
-    const int64_t N = (int64_t)c->h_invd.size();
-    {   // one pass over the list: any index out of range?  is it landmark-major, as estimator.cpp:975-1016 emits it?  and if so: do the
-        // edges of a landmark — neighbours in such a list — share host frame and host observation (edge_reprojection.cc:24: pts_i is
-        // the landmark's)?  The landmark's host observation is noted by landmark on the way (h_pts_i_lm), for build_plan, which repeats
-        // the consistency check per landmark only for the lists this pass does not vouch for (and names the offender).
-        unsigned bad = 0, unsorted = 0, incons = 0;
-        const uint32_t un = (uint32_t)std::min<int64_t>(N, INT32_MAX);
-        c->h_pts_i_lm.resize(2 * (size_t)N);
-        double *pl = c->h_pts_i_lm.data();
-        int32_t prev = -1;
-        for (int64_t e = 0; e < m; ++e) {
-            const int32_t l = lm[e];
-            bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)host[e] >= (uint32_t)NF) | (unsigned)((uint32_t)target[e] >= (uint32_t)NF) |
-                   (unsigned)(host[e] == target[e]);
-            unsorted |= (unsigned)(l < prev);
-            if (l == prev) incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
-            else if ((uint32_t)l < un) { pl[2 * (size_t)l] = pi[2 * e]; pl[2 * (size_t)l + 1] = pi[2 * e + 1]; }
-            prev = l;
-        }
-        if (bad)
-            for (int64_t e = 0; e < m; ++e)
-                if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
-                    return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
-        c->obs_lm_major = !unsorted;
-        c->obs_consistent = !unsorted && !incons;
-    }
+    if (c->obs_mapped) return fail(c, VIO_ERR_BAD_ARG, "vio_map_observations without vio_commit_observations");
+    VIOCHK(scan_observations(c, m, lm, host, target, pi));
     if ((int64_t)c->h_olm.size() == m && (m == 0 || (std::memcmp(c->h_olm.data(), lm, (size_t)m * 4) == 0 && std::memcmp(c->h_ohost.data(), host, (size_t)m * 4) == 0 &&
                                                      std::memcmp(c->h_otarget.data(), target, (size_t)m * 4) == 0 && std::memcmp(c->h_pts_i.data(), pi, (size_t)m * 16) == 0 &&
                                                      std::memcmp(c->h_pts_j.data(), pj, (size_t)m * 16) == 0)))
@@ -1378,6 +1396,32 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
     c->topo_dirty = true;
     c->dirty_inputs = true;
     return VIO_OK;
+}
+
+// The list written in place (include/vio_backend.h): the context's own mirrors go out to the caller, commit scans and adopts them.
+vio_status vio_map_observations(vio_ctx *c, int64_t m, int32_t **lm, int32_t **host, int32_t **target, double **pi, double **pj) {
+    if (!c || m < 0 || !lm || !host || !target || !pi || !pj) return VIO_ERR_BAD_ARG;
+    if (c->lm_dim == 3) return fail(c, VIO_ERR_BAD_ARG, "the context holds XYZ landmarks: use vio_set_observations_xyz");
+    enter_device(c);
+    if (c->arena.pending) { HIPCHK(hipEventSynchronize(c->arena.ev)); c->arena.pending = false; }
+    c->h_olm.resize((size_t)m); c->h_ohost.resize((size_t)m); c->h_otarget.resize((size_t)m); c->h_pts_i.resize(2 * (size_t)m);
+    if (!c->h_pts_j.resize_uninitialized(2 * (size_t)m)) return fail(c, VIO_ERR_HIP, "hipHostMalloc (observations)");
+    *lm = c->h_olm.data(); *host = c->h_ohost.data(); *target = c->h_otarget.data(); *pi = c->h_pts_i.data(); *pj = c->h_pts_j.p;
+    c->obs_mapped = true;           // the old list is gone, the new one is not there yet
+    c->raw_pts_valid = false;
+    c->topo_dirty = true;
+    c->dirty_inputs = true;
+    return VIO_OK;
+}
+
+vio_status vio_commit_observations(vio_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    if (!c->obs_mapped) return fail(c, VIO_ERR_BAD_ARG, "vio_commit_observations without vio_map_observations");
+    c->obs_mapped = false;
+    const int64_t m = (int64_t)c->h_olm.size();
+    const vio_status st = scan_observations(c, m, c->h_olm.data(), c->h_ohost.data(), c->h_otarget.data(), c->h_pts_i.data());
+    if (st != VIO_OK) { c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear(); }
+    return st;
 }
 
 vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {

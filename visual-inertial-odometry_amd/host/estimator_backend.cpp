@@ -176,15 +176,27 @@ bool EstimatorBackend::uploadWindow(bool graph_unchanged) {
         } else if (vio_set_prior(ctx_, 0, nullptr, nullptr, nullptr, nullptr) != VIO_OK) return false;
         return true;
     }
+    // the edges of the selected tracks, written straight into the library's own (pinned) arrays: vio_map_observations, one copy of the
+    // 44 bytes per edge instead of two (round 4).  The count first: the loop of estimator.cpp:975-1016 without its body
     size_t n_obs = 0;
-    for (const auto &it_per_id : feature) n_obs += it_per_id.feature_per_frame.size();
-    std::vector<int32_t> &lm = up_lm_, &host = up_host_, &target = up_target_;
-    std::vector<double> &pi = up_pi_, &pj = up_pj_;
-    lm.clear(); host.clear(); target.clear(); pi.clear(); pj.clear();
-    lm.reserve(n_obs); host.reserve(n_obs); target.reserve(n_obs); pi.reserve(2 * n_obs); pj.reserve(2 * n_obs);
-    int feature_index = -1;
-    for (auto &it_per_id : feature) {                                         // estimator.cpp:975-1016
+    int n_sel = 0;
+    for (auto &it_per_id : feature) {
         it_per_id.used_num = (int)it_per_id.feature_per_frame.size();
+        if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
+        ++n_sel;
+        n_obs += it_per_id.feature_per_frame.size() - 1;
+    }
+    if ((int)para_Feature.size() != n_sel) {                                  // para_Feature is vector2double's (:541-543), one per selected track
+        err_ = "para_Feature does not match the feature list: call vector2double() first";
+        return false;
+    }
+    if (vio_set_landmarks(ctx_, (int64_t)para_Feature.size(), para_Feature.data()) != VIO_OK) return false;
+    int32_t *lm = nullptr, *host = nullptr, *target = nullptr;
+    double *pi = nullptr, *pj = nullptr;
+    if (vio_map_observations(ctx_, (int64_t)n_obs, &lm, &host, &target, &pi, &pj) != VIO_OK) return false;
+    int feature_index = -1;
+    size_t e = 0;
+    for (auto &it_per_id : feature) {                                         // estimator.cpp:975-1016
         if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
         ++feature_index;
         const int imu_i = it_per_id.start_frame;
@@ -193,18 +205,13 @@ bool EstimatorBackend::uploadWindow(bool graph_unchanged) {
         for (const auto &it_per_frame : it_per_id.feature_per_frame) {
             imu_j++;
             if (imu_i == imu_j) continue;
-            lm.push_back(feature_index); host.push_back(imu_i); target.push_back(imu_j);
-            pi.push_back(pts_i[0]); pi.push_back(pts_i[1]);
-            pj.push_back(it_per_frame[0]); pj.push_back(it_per_frame[1]);
+            lm[e] = feature_index; host[e] = imu_i; target[e] = imu_j;
+            pi[2 * e] = pts_i[0]; pi[2 * e + 1] = pts_i[1];
+            pj[2 * e] = it_per_frame[0]; pj[2 * e + 1] = it_per_frame[1];
+            ++e;
         }
     }
-    if ((int)para_Feature.size() != feature_index + 1) {                      // para_Feature is vector2double's (:541-543), one per selected track
-        err_ = "para_Feature does not match the feature list: call vector2double() first";
-        return false;
-    }
-    if (vio_set_landmarks(ctx_, (int64_t)para_Feature.size(), para_Feature.data()) != VIO_OK) return false;
-    if (vio_set_observations(ctx_, (int64_t)lm.size(), lm.data(), host.data(), target.data(), pi.data(), pj.data()) != VIO_OK)
-        return false;
+    if (vio_commit_observations(ctx_) != VIO_OK) return false;
     for (int i = 0; i < WINDOW_SIZE; ++i) {                                   // estimator.cpp:956-970
         const vio_preint *p = pre_integrations[i + 1];
         if (vio_set_imu(ctx_, i, (p && p->sum_dt <= 10.0) ? p : nullptr) != VIO_OK) return false;

@@ -78,8 +78,6 @@ private:
     bool uploadWindow(bool graph_unchanged = false);
     bool marginalize(int kind);
     bool marg_pending_ = false;
-    std::vector<int32_t> up_lm_, up_host_, up_target_;      // uploadWindow's flat edge arrays, kept from frame to frame (3.5 MB of allocation and first touches per frame otherwise)
-    std::vector<double> up_pi_, up_pj_;
     bool graph_uploaded_ = false;                     // set by problemSolve inside backendOptimization, used by the Marg*Frame that follows
 public:
     vio_ctx *context() { return ctx_; }               // for FeatureManager::triangulate
