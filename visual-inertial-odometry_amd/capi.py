@@ -41,12 +41,15 @@ class VioPreint(C.Structure):
     @classmethod
     def from_dict(cls, d):
         p = cls()
-        p.sum_dt = float(d["sum_dt"])
+        v = np.frombuffer(p, dtype=np.float64)       # the struct is 467 contiguous doubles: filled through a view (a ctypes array
+        v[0] = float(d["sum_dt"])                    # assigned from a list costs 10 us per pre-integration, 0.1 ms per frame)
+        o = 1
         for name, n in (("delta_p", 3), ("delta_q", 4), ("delta_v", 3), ("linearized_ba", 3),
                         ("linearized_bg", 3), ("jacobian", 225), ("covariance", 225)):
-            arr = np.ascontiguousarray(d[name], dtype=np.float64).reshape(-1)
+            arr = np.asarray(d[name], dtype=np.float64).reshape(-1)
             assert arr.size == n, name
-            getattr(p, name)[:] = arr.tolist()
+            v[o:o + n] = arr
+            o += n
         return p
 
 
