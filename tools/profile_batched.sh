@@ -19,5 +19,6 @@ python3 tools/rocpd_summary.py stats $(db bk) > $O/${T}_batched_kernels.csv
 python3 tools/rocpd_summary.py traffic $O/${T}_batched_pmc_traffic.csv $O/traffic_batched.json $(db bf) $(db bw)
 python3 tools/rocpd_summary.py pmc $(db bsq) > $O/${T}_batched_sq_counters.csv
 python3 tools/rocpd_summary.py pmc $(db bm) > $O/${T}_batched_mfma.csv
+python3 tools/batched_counters_json.py $O/traffic_batched.json $O/${T}_batched_mfma.csv $B
 rm -rf $O/bk $O/bf $O/bw $O/bsq $O/bm
 head -8 $O/${T}_batched_kernels.csv; cat $O/${T}_batched_pmc_traffic.csv; cat $O/${T}_batched_sq_counters.csv; cat $O/${T}_batched_mfma.csv; tail -3 $O/${T}_batched_run.log
