@@ -173,31 +173,33 @@ bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout) {
     return ok;
 }
 
-static void move_to_bottom(std::vector<double> &H, std::vector<double> &b, int n, int idx, int dim) {
-    std::vector<int> order;
-    for (int i = 0; i < n; ++i)
-        if (i < idx || i >= idx + dim) order.push_back(i);
-    for (int i = idx; i < idx + dim; ++i) order.push_back(i);
-    std::vector<double> T((size_t)n * n), tb(n);
-    for (int i = 0; i < n; ++i) {
-        for (int j = 0; j < n; ++j) T[(size_t)i * n + j] = H[(size_t)order[i] * n + order[j]];
-        tb[i] = b[order[i]];
-    }
-    H.swap(T);
-    b.swap(tb);
+// The two moves of problem.cc:721-745 (speed-bias of the marginalised frame to the bottom, then its pose) as one index map:
+// entry (i, j) of the reordered matrix is H[order[i]][order[j]] of the matrix that came in.
+static void marg_order(int n, int frame, int *order) {
+    int o1[171], o2[171];
+    auto move = [n](int idx, int dim, int *o) {
+        int q = 0;
+        for (int i = 0; i < n; ++i) if (i < idx || i >= idx + dim) o[q++] = i;
+        for (int i = idx; i < idx + dim; ++i) o[q++] = i;
+    };
+    move(12 + 15 * frame, 9, o1);       // larger index first: speed-bias, then pose
+    move(6 + 15 * frame, 6, o2);
+    for (int i = 0; i < n; ++i) order[i] = o1[o2[i]];
 }
 
 __attribute__((target_clones("avx2", "default")))
 int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *bout, double *errout, double *jtout) {
-    const int n = 171, m2 = 15, n2 = n - m2;
-    std::vector<double> H(Hin, Hin + (size_t)n * n), b(bin, bin + n);
-    // larger index first: speed-bias, then pose (problem.cc:721-745)
-    move_to_bottom(H, b, n, 12 + 15 * frame, 9);
-    move_to_bottom(H, b, n, 6 + 15 * frame, 6);
+    constexpr int n = 171, m2 = 15, n2 = n - m2;
+    // Round 4: nothing of the 171 x 171 matrix is copied or permuted in memory (it was, twice: 0.14 of the tail's 0.44 ms on the build
+    // host); the reordered matrix is read through `order`, and everything below works on the rows that are not exactly zero.  The sums
+    // are the ones the full-size version formed for those rows, in the same order: the outputs are bit-identical.
+    int order[n];
+    marg_order(n, frame, order);
+    auto Hp_ = [&](int i, int j) -> double { return Hin[(size_t)order[i] * n + order[j]]; };
     const double eps = 1e-8;
     double Amm[m2 * m2], ev[m2], V[m2 * m2], Ainv[m2 * m2];
     for (int i = 0; i < m2; ++i)
-        for (int j = 0; j < m2; ++j) Amm[i * m2 + j] = 0.5 * (H[(size_t)(n2 + i) * n + n2 + j] + H[(size_t)(n2 + j) * n + n2 + i]);
+        for (int j = 0; j < m2; ++j) Amm[i * m2 + j] = 0.5 * (Hp_(n2 + i, n2 + j) + Hp_(n2 + j, n2 + i));
     symmetric_eigen(m2, Amm, ev, V);
     for (int i = 0; i < m2; ++i)
         for (int j = 0; j < m2; ++j) {
@@ -205,70 +207,73 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
             for (int k = 0; k < m2; ++k) s += V[i * m2 + k] * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V[j * m2 + k];
             Ainv[i * m2 + j] = s;
         }
-    std::vector<double> tempB((size_t)n2 * m2), Hp((size_t)n2 * n2), bp(n2);
-    for (int i = 0; i < n2; ++i)
+    // Arr - Arm Amm^+ Amr, brr - Arm Amm^+ bmm (problem.cc:758-762).  A row (column) of the kept block that is exactly zero all the way — a
+    // frame neither the marginalised frame's landmarks nor the old prior reach: 117 of the 156 at tracks of four frames — has a zero row
+    // of tempB and yields zeros whatever it is multiplied with: only the others are formed.
+    int rowlive[n2], nr = 0;
+    for (int i = 0; i < n2; ++i) {
+        bool any = false;
+        const double *hr = Hin + (size_t)order[i] * n;            // (the whole row, in whatever order: any non-zero?)
+        for (int j = 0; j < n && !any; ++j) any = hr[j] != 0.0;
+        for (int j = n2; j < n && !any; ++j) any = Hp_(j, i) != 0.0;      // the marginalised rows' entries in column i (Amr)
+        if (any) rowlive[nr++] = i;
+    }
+    std::vector<double> tempB((size_t)std::max(nr, 1) * m2), Hpc((size_t)std::max(nr, 1) * std::max(nr, 1)), Amr((size_t)m2 * std::max(nr, 1)), bp(n2);
+    for (int k = 0; k < m2; ++k)
+        for (int c = 0; c < nr; ++c) Amr[(size_t)k * nr + c] = Hp_(n2 + k, rowlive[c]);
+    for (int i = 0; i < n2; ++i) bp[i] = bin[order[i]] - 0.0;
+    for (int a = 0; a < nr; ++a) {
+        const int i = rowlive[a];
         for (int j = 0; j < m2; ++j) {
             double s = 0;
-            for (int k = 0; k < m2; ++k) s += H[(size_t)i * n + n2 + k] * Ainv[k * m2 + j];
-            tempB[(size_t)i * m2 + j] = s;
+            for (int k = 0; k < m2; ++k) s += Hp_(i, n2 + k) * Ainv[k * m2 + j];
+            tempB[(size_t)a * m2 + j] = s;
         }
-    for (int i = 0; i < n2; ++i) {
-        for (int j = 0; j < n2; ++j) {
+        for (int c = 0; c < nr; ++c) {
             double s = 0;
-            for (int k = 0; k < m2; ++k) s += tempB[(size_t)i * m2 + k] * H[(size_t)(n2 + k) * n + j];
-            Hp[(size_t)i * n2 + j] = H[(size_t)i * n + j] - s;
+            for (int k = 0; k < m2; ++k) s += tempB[(size_t)a * m2 + k] * Amr[(size_t)k * nr + c];
+            Hpc[(size_t)a * nr + c] = Hp_(i, rowlive[c]) - s;
         }
         double s = 0;
-        for (int k = 0; k < m2; ++k) s += tempB[(size_t)i * m2 + k] * b[n2 + k];
-        bp[i] = b[i] - s;
+        for (int k = 0; k < m2; ++k) s += tempB[(size_t)a * m2 + k] * bin[order[n2 + k]];
+        bp[i] = bin[order[i]] - s;
     }
     // Eigen-decomposition of the reduced system (problem.cc:766).  Rows and columns that are exactly zero — frames the
     // marginalised frame's landmarks and the old prior do not reach: 90 of the 156 in the steady state of a window with
     // tracks of 4 frames — are eigenvectors e_i of eigenvalue 0 already and fall under the 1e-8 cut whatever basis a solver
     // picks for them, so only the block they leave is decomposed (cost ~ n^3).
-    std::vector<int> live;
-    for (int i = 0; i < n2; ++i) {
+    int live[n2], lpos[n2], nl = 0;      // live: index in the 156-system; lpos: its place in rowlive
+    for (int a = 0; a < nr; ++a) {
         bool any = false;
-        for (int j = 0; j < n2 && !any; ++j) any = Hp[(size_t)i * n2 + j] != 0.0 || Hp[(size_t)j * n2 + i] != 0.0;
-        if (any) live.push_back(i);
+        for (int c = 0; c < nr && !any; ++c) any = Hpc[(size_t)a * nr + c] != 0.0 || Hpc[(size_t)c * nr + a] != 0.0;
+        if (any) { live[nl] = rowlive[a]; lpos[nl] = a; ++nl; }
     }
-    const int nl = (int)live.size(), nz = n2 - nl;
-    std::vector<double> ev2(n2, 0.0), V2((size_t)n2 * n2, 0.0);
-    {
-        std::vector<double> Hc((size_t)std::max(nl, 1) * std::max(nl, 1)), evc(std::max(nl, 1)), Vc((size_t)std::max(nl, 1) * std::max(nl, 1));
-        for (int a = 0; a < nl; ++a)
-            for (int c = 0; c < nl; ++c) Hc[(size_t)a * nl + c] = Hp[(size_t)live[a] * n2 + live[c]];
-        if (nl > 0) symmetric_eigen(nl, Hc.data(), evc.data(), Vc.data());
-        // columns 0 .. nz-1: the unit vectors of the dead indices (eigenvalue 0); then the live block's, ascending.  (A negative
-        // eigenvalue of the live block would sort before the zeros in the reference; both are below the cut.)
-        int col = 0;
-        std::vector<char> is_live(n2, 0);
-        for (int a = 0; a < nl; ++a) is_live[live[a]] = 1;
-        for (int i = 0; i < n2; ++i) if (!is_live[i]) V2[(size_t)i * n2 + col++] = 1.0;
-        for (int k = 0; k < nl; ++k) {
-            ev2[nz + k] = evc[k];
-            for (int a = 0; a < nl; ++a) V2[(size_t)live[a] * n2 + nz + k] = Vc[(size_t)a * nl + k];
-        }
-    }
-    std::vector<int> kept;      // eigenvalues above the cut: the only ones the three products below see
-    for (int k = 0; k < n2; ++k) if (ev2[k] > eps) kept.push_back(k);
+    const int nz = n2 - nl;
+    std::vector<double> Hc((size_t)std::max(nl, 1) * std::max(nl, 1)), evc(std::max(nl, 1)), Vc((size_t)std::max(nl, 1) * std::max(nl, 1));
+    for (int a = 0; a < nl; ++a)
+        for (int c = 0; c < nl; ++c) Hc[(size_t)a * nl + c] = Hpc[(size_t)lpos[a] * nr + lpos[c]];
+    if (nl > 0) symmetric_eigen(nl, Hc.data(), evc.data(), Vc.data());
+    // In the 156-system the eigenvalues are: nz zeros (the unit vectors of the dead indices), then the live block's, ascending: eigenpair
+    // k of the live block is number nz + k.  (A negative eigenvalue of the live block would sort before the zeros in the reference;
+    // both are below the cut.)  kept: the live block's eigenvalues above the cut, the only ones the three products below see.
+    int kept[n2], nk = 0;
+    for (int k = 0; k < nl; ++k) if (evc[k] > eps) kept[nk++] = k;
     std::fill(jtout, jtout + (size_t)n2 * n2, 0.0);
-    for (int i : kept) {
-        const double sinv = std::sqrt(1.0 / ev2[i]);
-        for (int j = 0; j < n2; ++j) jtout[(size_t)i * n2 + j] = sinv * V2[(size_t)j * n2 + i];
-    }
     std::fill(errout, errout + n2, 0.0);
-    for (int i : kept) {                                    // err_prior = -Jt_prior_inv b (problem.cc:774); the other rows of Jt are zero
-        double s = 0;
-        for (int j = 0; j < n2; ++j) s += -jtout[(size_t)i * n2 + j] * bp[j];
+    for (int q = 0; q < nk; ++q) {
+        const int k = kept[q], i = nz + k;
+        const double sinv = std::sqrt(1.0 / evc[k]);
+        double *row = jtout + (size_t)i * n2;
+        for (int a = 0; a < nl; ++a) row[live[a]] = sinv * Vc[(size_t)a * nl + k];
+        double s = 0;                                       // err_prior = -Jt_prior_inv b (problem.cc:774); the other rows of Jt are zero
+        for (int a = 0; a < nl; ++a) s += -row[live[a]] * bp[live[a]];
         errout[i] = s;
     }
     {   // H_prior = J^T J with J = sqrt(S) V^T (problem.cc:775-777): sum over the kept k of V_ik s_k V_jk, k ascending; the
         // kept eigenvectors live on the live indices only, every other entry of the product is an exact zero
-        const int nk = (int)kept.size();
         std::vector<double> VS((size_t)std::max(nl, 1) * std::max(nk, 1)), VK((size_t)std::max(nl, 1) * std::max(nk, 1));
         for (int a = 0; a < nl; ++a)
-            for (int q = 0; q < nk; ++q) { VK[(size_t)a * nk + q] = V2[(size_t)live[a] * n2 + kept[q]]; VS[(size_t)a * nk + q] = VK[(size_t)a * nk + q] * ev2[kept[q]]; }
+            for (int q = 0; q < nk; ++q) { VK[(size_t)a * nk + q] = Vc[(size_t)a * nl + kept[q]]; VS[(size_t)a * nk + q] = VK[(size_t)a * nk + q] * evc[kept[q]]; }
         std::fill(Hout, Hout + (size_t)n2 * n2, 0.0);
         for (int a = 0; a < nl; ++a)
             for (int c = 0; c < nl; ++c) {
