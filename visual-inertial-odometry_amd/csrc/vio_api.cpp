@@ -1352,11 +1352,13 @@ vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, co
 // edges of a landmark — neighbours in such a list — share host frame and host observation (edge_reprojection.cc:24: pts_i is the
 // landmark's)?  The landmark's host observation is noted by landmark on the way (h_pts_i_lm), for build_plan, which repeats the
 // consistency check per landmark only for the lists this pass does not vouch for (and names the offender).
-static vio_status scan_observations(vio_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi) {
+// *same_pi (optional): every landmark's host observation is the one h_pts_i_lm held before the call (meaningful when the list the context
+// holds was vouched for: then that is all there is to compare — the per-edge copies are not kept for such lists).
+static vio_status scan_observations(vio_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi, bool *same_pi = nullptr) {
     const int64_t N = (int64_t)c->h_invd.size();
-    unsigned bad = 0, unsorted = 0, incons = 0;
+    unsigned bad = 0, unsorted = 0, incons = 0, changed = 0;
     const uint32_t un = (uint32_t)std::min<int64_t>(N, INT32_MAX);
-    c->h_pts_i_lm.resize(2 * (size_t)N);
+    if (c->h_pts_i_lm.size() != 2 * (size_t)N) { c->h_pts_i_lm.assign(2 * (size_t)N, 0.0); changed = 1; }
     double *pl = c->h_pts_i_lm.data();
     int32_t prev = -1;
     for (int64_t e = 0; e < m; ++e) {
@@ -1365,9 +1367,13 @@ static vio_status scan_observations(vio_ctx *c, int64_t m, const int32_t *lm, co
                (unsigned)(host[e] == target[e]);
         unsorted |= (unsigned)(l < prev);
         if (l == prev) incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
-        else if ((uint32_t)l < un) { pl[2 * (size_t)l] = pi[2 * e]; pl[2 * (size_t)l + 1] = pi[2 * e + 1]; }
+        else if ((uint32_t)l < un) {
+            changed |= (unsigned)(pl[2 * (size_t)l] != pi[2 * e]) | (unsigned)(pl[2 * (size_t)l + 1] != pi[2 * e + 1]);
+            pl[2 * (size_t)l] = pi[2 * e]; pl[2 * (size_t)l + 1] = pi[2 * e + 1];
+        }
         prev = l;
     }
+    if (same_pi) *same_pi = !changed;
     if (bad)
         for (int64_t e = 0; e < m; ++e)
             if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
@@ -1382,15 +1388,22 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
     if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
     if (c->lm_dim == 3) return fail(c, VIO_ERR_BAD_ARG, "the context holds XYZ landmarks: use vio_set_observations_xyz");
     if (c->obs_mapped) return fail(c, VIO_ERR_BAD_ARG, "vio_map_observations without vio_commit_observations");
-    VIOCHK(scan_observations(c, m, lm, host, target, pi));
-    if ((int64_t)c->h_olm.size() == m && (m == 0 || (std::memcmp(c->h_olm.data(), lm, (size_t)m * 4) == 0 && std::memcmp(c->h_ohost.data(), host, (size_t)m * 4) == 0 &&
-                                                     std::memcmp(c->h_otarget.data(), target, (size_t)m * 4) == 0 && std::memcmp(c->h_pts_i.data(), pi, (size_t)m * 16) == 0 &&
-                                                     std::memcmp(c->h_pts_j.data(), pj, (size_t)m * 16) == 0)))
+    const bool was_vouched = c->obs_consistent && c->h_pts_i.empty();       // the list held so far: host observations by landmark only
+    bool same_pi = false;
+    VIOCHK(scan_observations(c, m, lm, host, target, pi, &same_pi));
+    const bool vouched = c->obs_consistent;
+    if (!was_vouched) same_pi = vouched == false && c->h_pts_i.size() == 2 * (size_t)m && (m == 0 || std::memcmp(c->h_pts_i.data(), pi, (size_t)m * 16) == 0);
+    else same_pi = same_pi && vouched;
+    if (same_pi && (int64_t)c->h_olm.size() == m &&
+        (m == 0 || (std::memcmp(c->h_olm.data(), lm, (size_t)m * 4) == 0 && std::memcmp(c->h_ohost.data(), host, (size_t)m * 4) == 0 &&
+                    std::memcmp(c->h_otarget.data(), target, (size_t)m * 4) == 0 && std::memcmp(c->h_pts_j.data(), pj, (size_t)m * 16) == 0)))
         return VIO_OK;               // the graph the context already holds: its plans stay
     enter_device(c);
     if (c->arena.pending) { HIPCHK(hipEventSynchronize(c->arena.ev)); c->arena.pending = false; }      // an upload out of h_pts_j still in flight (long done)
     c->h_olm.assign(lm, lm + m); c->h_ohost.assign(host, host + m); c->h_otarget.assign(target, target + m);
-    c->h_pts_i.assign(pi, pi + 2 * m);
+    // the per-edge copies of the host observation are kept only for lists whose landmarks' edges this pass could not vouch for (1.3 MB
+    // of the 3.5 MB a frame's list is: what a vouched list needs of them is in h_pts_i_lm)
+    if (vouched) c->h_pts_i.clear(); else c->h_pts_i.assign(pi, pi + 2 * m);
     if (!c->h_pts_j.assign(pj, pj + 2 * m)) return fail(c, VIO_ERR_HIP, "hipHostMalloc (observations)");
     c->raw_pts_valid = false;
     c->topo_dirty = true;
