@@ -387,3 +387,25 @@ def test_hip_headline_size_properties(vio, oracle_lib, hip_lib):
     np.testing.assert_array_equal(runs[0][0], runs[1][0])
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
     assert runs[0][2] == runs[1][2]
+
+
+@pytest.mark.gpu
+def test_xyz_observation_list_in_any_order(vio, hip_lib):
+    """A landmark-major list with ascending frames (what make_window_xyz and the reference's loops emit) takes build_plan_xyz's fast
+    path — the list is its own CSR, the observations are put into item order on the device —; any other order goes through the table
+    of observations by (landmark, frame).  An XYZ pattern is a SET of frames, so the items and every sum are the same: the shuffled
+    list gives the same bits, through Solve(10) and MargOldFrame."""
+    w = vio.synth.make_window_xyz(900, seed=77, ragged=True)
+    order = np.random.RandomState(5).permutation(w.n_observations)
+    v = w.copy()
+    v.lm, v.frame, v.pts = (np.ascontiguousarray(a[order]) for a in (w.lm, w.frame, w.pts))
+    out = []
+    for win in (w, v):
+        c = hip_lib.context()
+        c.load(win)
+        rep = c.solve(10)
+        pr = c.marginalize(vio.MARG_OLD, allow_nonfinite=True)
+        out.append((rep.final_chi2, rep.iterations, c.get_landmarks_xyz(), c.get_window()[0], pr["H"]))
+    a, b = out
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4], equal_nan=True)

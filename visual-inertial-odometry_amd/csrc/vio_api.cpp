@@ -371,19 +371,41 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
     const bool half = c->cfg.item_policy == VIO_ITEMS_THROUGHPUT && !std::getenv("VIO_NO_HALF_WIDTH");      // as build_plan: k_linearize_xyz_h
     pl.lin_threads = half ? lin_threads_half_host() : lin_threads_host();
     const int64_t N = (int64_t)c->h_invd.size() / 3, M = (int64_t)c->h_olm.size();
+    // A landmark-major list with ascending frames (what vio_set_observations_xyz's pass found) is its own CSR and observation k of a
+    // landmark is its pattern's k-th frame: no table of observations by (landmark, frame), and the observations go to the device as
+    // listed (k_gather_obs puts them into item order).  Any other list: the table, and the gather on the host.
+    const bool fast = c->obs_lm_major;
+    std::vector<int64_t> obs_off;
+    if (fast) {
+        if (M && !c->raw_pts_valid) {
+            HIPCHK(c->d_raw_pts_j.resize(2 * (size_t)M));
+            HIPCHK(hipMemcpyAsync(c->d_raw_pts_j.p, c->h_pts_j.data(), 2 * (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
+            c->raw_pts_valid = true;
+        }
+        obs_off.assign((size_t)N + 1, 0);
+        for (int64_t e = 0; e < M; ++e) ++obs_off[c->h_olm[e] + 1];
+        for (int64_t l = 0; l < N; ++l) obs_off[l + 1] += obs_off[l];
+    }
     // observation of landmark l in frame f: obs_at[l * NF + f] (or -1)
-    std::vector<int32_t> obs_at((size_t)std::max<int64_t>(N, 1) * NF, -1);
-    for (int64_t e = 0; e < M; ++e) {
-        if (marg && c->h_otarget[e] != 0) continue;
-        int32_t &slot = obs_at[(size_t)c->h_olm[e] * NF + c->h_otarget[e]];
-        if (slot >= 0) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
-        slot = (int32_t)e;
+    std::vector<int32_t> obs_at;
+    if (!fast) {
+        obs_at.assign((size_t)std::max<int64_t>(N, 1) * NF, -1);
+        for (int64_t e = 0; e < M; ++e) {
+            if (marg && c->h_otarget[e] != 0) continue;
+            int32_t &slot = obs_at[(size_t)c->h_olm[e] * NF + c->h_otarget[e]];
+            if (slot >= 0) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
+            slot = (int32_t)e;
+        }
     }
     std::vector<int32_t> mask(N, 0), pat_of_mask(1 << NF, -1), lm_pattern(N, -1);
     pl.patterns.clear();
     for (int64_t l = 0; l < N; ++l) {
         int m = 0;
-        for (int f = 0; f < NF; ++f) if (obs_at[(size_t)l * NF + f] >= 0) m |= 1 << f;
+        if (fast) {
+            for (int64_t e = obs_off[l]; e < obs_off[l + 1]; ++e) m |= 1 << c->h_otarget[e];
+            if (marg) m &= 1;              // Problem::Marginalize's graph: the observation frame 0 has of the landmark, nothing else
+        } else
+            for (int f = 0; f < NF; ++f) if (obs_at[(size_t)l * NF + f] >= 0) m |= 1 << f;
         if (m == 0) {
             if (marg) continue;
             return fail(c, VIO_ERR_UNSUPPORTED, "landmark without observations (its 3x3 Hessian block would be singular)");
@@ -448,8 +470,9 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
     pl.items.clear();
     // observations in item order, written straight into the pinned staging (every observation of the window has a place)
     const double *pts_i = nullptr;
-    double *pts_j = (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>((int64_t)c->h_olm.size(), 1) * 8);
-    if (!pts_j) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+    double *pts_j = fast ? nullptr : (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>((int64_t)c->h_olm.size(), 1) * 8);
+    int32_t *first = fast ? (int32_t *)c->arena.alloc((size_t)std::max<int64_t>(pl.Ns, 1) * 4) : nullptr;
+    if (fast ? !first : !pts_j) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
     pl.slab_doubles = 0; pl.lw_doubles = 0; pl.max_lds_doubles = IMU_ITEM_LDS_DOUBLES;
     int64_t s = 0, obs_base = 0;
     while (s < pl.Ns) {
@@ -473,6 +496,7 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
         pl.lw_doubles += (size_t)9 * it.G;            // H_ll (6), b_l (3): W is formed again where it is needed
         for (int g = 0; g < it.G; ++g) {
             const int32_t l = pl.sorted_to_orig[s + g];
+            if (fast) { first[s + g] = (int32_t)obs_off[l]; continue; }      // (marg: the frame-0 observation is the landmark's first)
             for (int k = 0; k < it.K; ++k) {
                 const int32_t oe = obs_at[(size_t)l * NF + (pt.cam_block[k] - 1)];
                 const int64_t o = obs_base + (int64_t)k * it.G + g;
@@ -483,7 +507,7 @@ vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
         s = e;
     }
     pl.Ms = obs_base;
-    return upload_plan(c, pl, pts_i, pts_j);
+    return fast ? upload_plan(c, pl, pts_i, nullptr, first, nullptr, 0) : upload_plan(c, pl, pts_i, pts_j);
 }
 
 vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
@@ -1330,9 +1354,24 @@ vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, co
     if (!c || m < 0 || (m > 0 && (!lm || !frame || !pts))) return VIO_ERR_BAD_ARG;
     if (c->lm_dim != 3) return fail(c, VIO_ERR_BAD_ARG, "vio_set_observations_xyz needs vio_set_landmarks_xyz first");
     const int64_t N = (int64_t)c->h_invd.size() / 3;
-    for (int64_t e = 0; e < m; ++e)
-        if (lm[e] < 0 || lm[e] >= N || frame[e] < 0 || frame[e] >= NF)
-            return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
+    {   // one pass: indices in range?  landmark-major with a landmark's frames ascending (then observation k of a landmark is the k-th
+        // frame of its pattern and the list is its own CSR: build_plan_xyz's fast path, the observations put into item order on the device)?
+        unsigned bad = 0, unordered = 0;
+        const uint32_t un = (uint32_t)std::min<int64_t>(N, INT32_MAX);
+        int32_t pl = -1, pf = -1;
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t l = lm[e], f = frame[e];
+            bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)f >= (uint32_t)NF);
+            unordered |= (unsigned)(l < pl) | ((unsigned)(l == pl) & (unsigned)(f <= pf));
+            pl = l; pf = f;
+        }
+        if (bad)
+            for (int64_t e = 0; e < m; ++e)
+                if (lm[e] < 0 || lm[e] >= N || frame[e] < 0 || frame[e] >= NF)
+                    return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
+        c->obs_lm_major = !unordered;
+        c->obs_consistent = false;
+    }
     // (what the device holds newer than the host mirrors stays there until activate() needs it: the old plan is alive till then)
     if ((int64_t)c->h_olm.size() == m && (m == 0 || (std::memcmp(c->h_olm.data(), lm, (size_t)m * 4) == 0 && std::memcmp(c->h_otarget.data(), frame, (size_t)m * 4) == 0 &&
                                                      std::memcmp(c->h_pts_j.data(), pts, (size_t)m * 16) == 0)))
