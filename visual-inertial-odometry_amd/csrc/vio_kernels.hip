@@ -456,6 +456,9 @@ __device__ __forceinline__ void d_bprior_rows(const DeviceTables &T, int from, i
 template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    // the item's descriptor is requested before the gate looks at LmState (vio_solve's loop): one round trip for both, not two
+    int32_t desc_word = 0;
+    if (b < T.n_items && tid < (int)(sizeof(ItemDesc) / 4)) desc_word = ((const int32_t *)(T.items + b))[tid];
     if (d_gated_off(T.lm, T.lm_gate)) return;
     // GN mode (gn_flags bit 1) with a prior: the previous step also owes b_prior' = b_prior - H_prior dx (problem.cc:473).
     // Row r belongs to workgroup r mod grid, to its last wave: idle in phase 1 of a landmark item, first thing in an IMU item.
@@ -472,7 +475,7 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
     __shared__ ItemDesc sIt;        // kept in LDS: its small arrays are indexed at run time
     const int cur = d_cur(T);      // requested together with the descriptor: both are cold after the kernel boundary
     const int64_t lw_r = d_set_r(T) * T.lw_set, lw_w = d_set_w(T) * T.lw_set;
-    if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = ((const int32_t *)(T.items + b))[tid];
+    if (tid < (int)(sizeof(ItemDesc) / 4)) ((int32_t *)&sIt)[tid] = desc_word;
     __syncthreads();
     const ItemDesc &it = sIt;
     STAMP(T, 0);
@@ -1076,6 +1079,8 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R, const Devic
     // is fixed by the list, not by timing.  Three dependent round trips (offsets, list, slab) whatever the list length.
     __shared__ double sV[56 * 18 + 8];
     const int b = blockIdx.x, tid = threadIdx.x;
+    // (the list bounds are requested before the gate looks at LmState: one round trip for both)
+    const int lo_pre = b < VIO_NPAIR + VIO_NCB + 1 ? R.list_off[b] : 0, hi_pre = b < VIO_NPAIR + VIO_NCB + 1 ? R.list_off[b + 1] : 0;
     if (d_gated_off(R.lm, R.gate)) return;
     const bool step_owed = !R.lm_loop || R.lm->pending != 0;
     if (FUSED && b >= VIO_NPAIR + VIO_NCB + 1 && b < VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS) {
@@ -1088,7 +1093,7 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R, const Devic
         if (row < VIO_PRD && step_owed) d_errprior_row(R.jtinv, R.bprior + copy * 176, R.errprior + copy * 160, row, tid & 63);
         return;
     }
-    const int lo = R.list_off[b], hi = R.list_off[b + 1];
+    const int lo = lo_pre, hi = hi_pre;
     if (b < VIO_NPAIR) {
         constexpr int W = 36, NS = RED_THREADS / W;           // 28 slots
         const int s = tid / W, t = tid - s * W;
