@@ -149,7 +149,8 @@ vio_status vio_set_landmarks(struct vio_ctx *ctx, int64_t n, const double *inv_d
 /* EdgeReprojection x M (estimator.cpp:996-1016): edge e connects landmark lm[e], host frame host[e],
  * target frame target[e] and the extrinsic; pts_i/pts_j are the normalised (x,y) of the two
  * observations (z == 1 is implied, feature_manager.h).  All edges of one landmark must share
- * host[e] and pts_i (they do in the reference: one host observation per feature). */
+ * host[e] and pts_i (they do in the reference: one host observation per feature).  A list that is refused (an index out
+ * of range) leaves the context without observations. */
 vio_status vio_set_observations(struct vio_ctx *ctx, int64_t m, const int32_t *lm,
                                 const int32_t *host, const int32_t *target,
                                 const double *pts_i_xy, const double *pts_j_xy);

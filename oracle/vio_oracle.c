@@ -1114,6 +1114,8 @@ vio_status vio_set_observations(struct vioo_ctx *c, int64_t m, const int32_t *lm
         if (lm[e] < 0 || lm[e] >= c->N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF ||
             host[e] == target[e]) {
             snprintf(c->err, sizeof(c->err), "observation %lld out of range", (long long)e);
+            c->M = 0;                  /* a refused list leaves the context without one (include/vio_backend.h) */
+            c->linearized = 0;
             return VIO_ERR_BAD_ARG;
         }
     }

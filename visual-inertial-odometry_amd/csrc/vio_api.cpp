@@ -1429,7 +1429,16 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
     if (c->obs_mapped) return fail(c, VIO_ERR_BAD_ARG, "vio_map_observations without vio_commit_observations");
     const bool was_vouched = c->obs_consistent && c->h_pts_i.empty();       // the list held so far: host observations by landmark only
     bool same_pi = false;
-    VIOCHK(scan_observations(c, m, lm, host, target, pi, &same_pi));
+    {
+        const vio_status st = scan_observations(c, m, lm, host, target, pi, &same_pi);
+        if (st != VIO_OK) {
+            // the pass has written into h_pts_i_lm, which the list held so far may rely on: a refused list leaves the context without one
+            c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear();
+            c->obs_lm_major = c->obs_consistent = false;
+            c->raw_pts_valid = false; c->topo_dirty = true; c->dirty_inputs = true;
+            return st;
+        }
+    }
     const bool vouched = c->obs_consistent;
     if (!was_vouched) same_pi = vouched == false && c->h_pts_i.size() == 2 * (size_t)m && (m == 0 || std::memcmp(c->h_pts_i.data(), pi, (size_t)m * 16) == 0);
     else same_pi = same_pi && vouched;
@@ -1472,7 +1481,7 @@ vio_status vio_commit_observations(vio_ctx *c) {
     c->obs_mapped = false;
     const int64_t m = (int64_t)c->h_olm.size();
     const vio_status st = scan_observations(c, m, c->h_olm.data(), c->h_ohost.data(), c->h_otarget.data(), c->h_pts_i.data());
-    if (st != VIO_OK) { c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear(); }
+    if (st != VIO_OK) { c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear(); c->obs_lm_major = c->obs_consistent = false; }
     return st;
 }
 
