@@ -94,6 +94,27 @@ def test_solve_trace_against_the_reference_iteration_by_iteration(vio, hip_lib):
         assert max(abs(t[2] - l) / l for t, l in zip(tr, rl)) <= 3e-4, name
 
 
+@pytest.mark.parametrize("path", [p for p in WINDOW_FILES if "window_noimu_" in p], ids=lambda p: os.path.basename(p)[:-4])
+def test_imu_less_windows_iteration_by_iteration(vio, hip_lib, path):
+    """Windows without IMU edges, generated by the compiled reference with nothing of the oracle in the graph (make_golden_noimu.py):
+    Solve(10) iteration by iteration — lambda_0 = O(10..100) walking down to O(1), the speed-bias blocks carrying lambda (and the
+    prior) alone — for both elimination orders of the pose solve and both item policies.  Same trial counts as the reference; state
+    within 1e-8 of the reference's after every outer iteration (measured: see profiles/r05_noimu_parity.json)."""
+    from test_oracle_golden import check_noimu_trace
+    z = dict(np.load(path))
+    for order in (vio.capi.ORDER_CHAIN, vio.capi.ORDER_EIGEN):
+        d = check_noimu_trace(vio, hip_lib, path, 1e-8, order=order)
+        print(os.path.basename(path), "order", order, "max |state - reference| per outer iteration:", ["%.1e" % v for v in d])
+    for policy in (vio.capi.ITEMS_THROUGHPUT,):
+        w, kw = tu.arrays_to_window(vio, z), {"ext_fixed": int(z["cfg_ext_fixed"]), "item_policy": policy}
+        c = hip_lib.context(**kw)
+        c.load(w)
+        sol, rep = tu.run_solve(c, 10)
+        assert int(sol["iterations"]) == int(z["solve_iterations"])
+        for k in ("posesF", "sbF", "extF", "invdF"):
+            assert np.abs(sol[k] - z["solve_" + k]).max() <= 1e-8, k
+
+
 def restart_states(vio, z, zr, name, k):
     """the window of fixture z with the reference's states (and prior vectors) after outer iteration k of its Solve(10); k = 0: the input"""
     w = tu.arrays_to_window(vio, z)

@@ -11,8 +11,12 @@ def window_to_arrays(w, prefix="in_"):
     for k in (("poses", "speed_bias", "ext", "xyz", "lm", "frame", "pts") if xyz else
               ("poses", "speed_bias", "ext", "inv_depth", "lm", "host", "target", "pts_i", "pts_j")):
         d[prefix + k] = np.asarray(getattr(w, k))
+    if any(p is None for p in w.preint):            # estimator.cpp:956-970: an IMU edge with sum_dt > 10 is not added
+        d[prefix + "pre_valid"] = np.array([p is not None for p in w.preint], dtype=np.int32)
+    size = {"sum_dt": 1, "delta_p": 3, "delta_q": 4, "delta_v": 3, "linearized_ba": 3, "linearized_bg": 3, "jacobian": 225, "covariance": 225}
     for f in PREINT_FIELDS:
-        d[prefix + "pre_" + f] = np.stack([np.asarray(p[f], dtype=np.float64).reshape(-1) for p in w.preint])
+        d[prefix + "pre_" + f] = np.stack([np.zeros(size[f]) if p is None else np.asarray(p[f], dtype=np.float64).reshape(-1)
+                                           for p in w.preint])
     if w.prior is not None:
         for f in PRIOR_FIELDS:
             d[prefix + "prior_" + f] = np.asarray(w.prior[f])
@@ -22,7 +26,11 @@ def window_to_arrays(w, prefix="in_"):
 def arrays_to_window(vio, z, prefix="in_"):
     pre = []
     n_edges = z[prefix + "pre_sum_dt"].shape[0]
+    valid = z[prefix + "pre_valid"] if prefix + "pre_valid" in z else np.ones(n_edges, dtype=np.int32)
     for k in range(n_edges):
+        if not valid[k]:
+            pre.append(None)
+            continue
         p = {}
         for f in PREINT_FIELDS:
             a = z[prefix + "pre_" + f][k]
