@@ -352,8 +352,28 @@ def main():
         except Exception:
             traffic = None
     it_bytes = (24 * m + 72 * n + 280000) if xyz else vio.synth.algorithmic_bytes(n, m)
-    roofline = {"bound": "hbm", "kernel": symbol, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
+    # Which roof?  k_pose_solve(_c) is ONE workgroup on one of the device's CUs walking a dependent chain of pivots: neither the HBM roof
+    # nor the device's fp64 roof binds it ("latency"); its arithmetic against ONE CU's fp64 rate is given beside the HBM fraction
+    # (171^3 / 3 flops, the dense LDL^T's count, as the upper bound of what the structured solve performs).  k_linearize: nearer the fp64
+    # matrix roof than the HBM one (14 % against 3.5 % for one window, 22 % against 5.5 % batched).
+    n_cus_dev = torch.cuda.get_device_properties(0 if one_device else local_rank).multi_processor_count
+    if dominant == "k_pose_solve":
+        bound = "latency"
+        flops = 171.0 ** 3 / 3.0
+        fp64 = {"flops_per_launch_upper_bound": flops, "one_cu_peak_GFLOPs": round(FP64_PEAK_TFLOPS * 1e3 / n_cus_dev, 1),
+                "achieved_GFLOPs": round(flops / dom_launch_s / 1e9, 2) if dom_launch_s > 0 else 0.0,
+                "frac_of_one_cu": (flops / dom_launch_s / 1e9) / (FP64_PEAK_TFLOPS * 1e3 / n_cus_dev) if dom_launch_s > 0 else 0.0,
+                "workgroups": 1, "cus_of_the_device": n_cus_dev}
+    elif dominant == "k_linearize":
+        bound = "mfma"
+        flops = algorithmic_flops(n, m)
+        fp64 = {"algorithmic_flops_per_launch": flops, "peak_TFLOPs": FP64_PEAK_TFLOPS,
+                "achieved_TFLOPs": round(flops / dom_launch_s / 1e12, 3) if dom_launch_s > 0 else 0.0,
+                "frac": (flops / dom_launch_s / 1e12) / FP64_PEAK_TFLOPS if dom_launch_s > 0 else 0.0}
+    else:
+        bound, fp64 = "latency", None
+    roofline = {"bound": bound, "kernel": symbol, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                "frac": achieved / 8000.0, "fp64": fp64, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_us": round(dom_launch_s * 1e6, 3),
                 "launch_us_method": "HIP event pairs on the library's stream around every %d-th launch of the timed steps " % stride +
                                     "(includes the event's own drain, ~8 % above rocprofv3's kernel duration)",

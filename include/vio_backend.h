@@ -37,6 +37,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is what it exports. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define VIO_WINDOW_SIZE 10                      /* VM/include/parameters.h:35 */
 #define VIO_NUM_FRAMES (VIO_WINDOW_SIZE + 1)    /* 11 poses + 11 speed-biases */
@@ -158,7 +162,10 @@ vio_status vio_set_observations(struct vio_ctx *ctx, int64_t m, const int32_t *l
  * ones its uploads leave from: pts_j_xy is pinned host memory) for the caller's loop over its tracks (estimator.cpp:975-1016) to fill,
  * vio_commit_observations checks and adopts what was written — one copy of the 44 bytes per edge instead of two.  The arrays are the
  * library's; they stay valid until the next vio_set_observations / vio_map_observations / vio_set_landmarks* / vio_destroy.  Between
- * map and commit the context holds no observation list (any call that needs one fails with VIO_ERR_BAD_ARG).  (VIO_ABI_VERSION 5.) */
+ * map and commit the context holds no observation list (any call that needs one fails with VIO_ERR_BAD_ARG).  The ways out of a
+ * mapping: vio_commit_observations; vio_map_observations again; vio_set_observations, which drops what was written in place and sets
+ * its own list.  vio_set_landmarks* with another landmark count invalidates the mapping (the indices would refer to another landmark
+ * set): the commit then fails with VIO_ERR_BAD_ARG and leaves the context without a list.  (VIO_ABI_VERSION 5.) */
 vio_status vio_map_observations(struct vio_ctx *ctx, int64_t m, int32_t **lm, int32_t **host, int32_t **target,
                                 double **pts_i_xy, double **pts_j_xy);
 vio_status vio_commit_observations(struct vio_ctx *ctx);
@@ -358,10 +365,17 @@ vio_status vio_get_host_timing(struct vio_ctx *ctx, double *out8);
  * Eigen's order whatever was asked for; vio_get_solve_order reports the order asked for and the one in effect. */
 vio_status vio_set_solve_order(struct vio_ctx *ctx, int32_t order);
 vio_status vio_get_solve_order(struct vio_ctx *ctx, int32_t *requested, int32_t *effective);
-/* Diagnostic: x = (H + lambda I)^-1 b by the chain-order kernel alone on a caller-supplied 171 x 171 row-major H (natural order of
+#ifdef VIO_DEBUG_ENTRY_POINTS
+/* Diagnostic, NOT part of the product ABI (exported only by a build with -DVIO_DEBUG_ENTRY_POINTS: csrc/diag/libvio_hip_debug.so, which
+ * the tests build): x = (H + lambda I)^-1 b by the chain-order kernel alone on a caller-supplied 171 x 171 row-major H (natural order of
  * H_pp_schur_; only its lower triangle is read).  lds_dump: NULL, or room for the factor as the kernel leaves it
  * (tools/chain_solve_model.py documents the layout). */
 vio_status vio_debug_chain_solve(struct vio_ctx *ctx, const double *H, const double *b, double lambda, double *x, double *lds_dump);
+#endif
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

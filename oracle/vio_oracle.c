@@ -1065,7 +1065,10 @@ vio_status vio_set_window(struct vioo_ctx *c, const double *poses, const double 
 static vio_status set_landmarks_dim(struct vioo_ctx *c, int64_t n, const double *val, int dim) {
     if (!c || n < 0 || (n > 0 && !val)) return VIO_ERR_BAD_ARG;
     free(c->invd); free(c->invd_bak); free(c->hll); free(c->bl); free(c->Hpl); free(c->dx_lm);
-    if (dim != c->lm_dim || n != c->N) c->M = 0;        /* the observation list refers to the other kind / other indices */
+    if (dim != c->lm_dim || n != c->N) {
+        c->M = 0;                                       /* the observation list refers to the other kind / other indices */
+        if (c->M_mapped >= 0) c->M_mapped = -2;         /* ... and so does a mapping: its commit is refused (as the HIP library does) */
+    }
     c->N = n;
     c->lm_dim = dim;
     size_t nn = (size_t)(n > 0 ? n : 1);
@@ -1087,6 +1090,7 @@ vio_status vio_set_landmarks_xyz(struct vioo_ctx *c, int64_t n, const double *xy
 vio_status vio_set_observations_xyz(struct vioo_ctx *c, int64_t m, const int32_t *lm, const int32_t *frame, const double *pts) {
     if (!c || m < 0 || (m > 0 && (!lm || !frame || !pts))) return VIO_ERR_BAD_ARG;
     if (c->lm_dim != 3) { snprintf(c->err, sizeof(c->err), "vio_set_observations_xyz needs vio_set_landmarks_xyz first"); return VIO_ERR_BAD_ARG; }
+    c->M_mapped = -1;
     for (int64_t e = 0; e < m; ++e)
         if (lm[e] < 0 || lm[e] >= c->N || frame[e] < 0 || frame[e] >= NF) {
             snprintf(c->err, sizeof(c->err), "observation %lld out of range", (long long)e);
@@ -1110,6 +1114,7 @@ vio_status vio_set_observations(struct vioo_ctx *c, int64_t m, const int32_t *lm
                                 const int32_t *target, const double *pi, const double *pj) {
     if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
     if (c->lm_dim == 3) { snprintf(c->err, sizeof(c->err), "the context holds XYZ landmarks: use vio_set_observations_xyz"); return VIO_ERR_BAD_ARG; }
+    if (c->M_mapped != -1) { c->M_mapped = -1; c->M = 0; }     /* vio_set_observations ends a mapping (include/vio_backend.h): what was written in place is dropped */
     for (int64_t e = 0; e < m; ++e) {
         if (lm[e] < 0 || lm[e] >= c->N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF ||
             host[e] == target[e]) {
@@ -1151,6 +1156,11 @@ vio_status vio_map_observations(struct vioo_ctx *c, int64_t m, int32_t **lm, int
 }
 vio_status vio_commit_observations(struct vioo_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
+    if (c->M_mapped == -2) {
+        c->M_mapped = -1;
+        snprintf(c->err, sizeof(c->err), "vio_commit_observations: the mapping was invalidated by vio_set_landmarks (another landmark count): map again");
+        return VIO_ERR_BAD_ARG;
+    }
     if (c->M_mapped < 0) { snprintf(c->err, sizeof(c->err), "vio_commit_observations without vio_map_observations"); return VIO_ERR_BAD_ARG; }
     const int64_t m = c->M_mapped;
     c->M_mapped = -1;
@@ -1502,7 +1512,7 @@ static int run_hook(struct vioo_ctx *c, int which) {
 
 /* SetOrdering + MakeHessian (problem.cc:256-285,303-389) + the lambda-free part of SolveLinearSystem (:412-429) */
 vio_status vio_linearize(struct vioo_ctx *c) {
-    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
+    if (c && c->M_mapped != -1) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;
     double t0 = now_ms();
     linearize_visual(c, 0);
@@ -1735,7 +1745,7 @@ vio_status vio_eval_step(struct vioo_ctx *c, int32_t *accepted, double *chi2, do
 
 /* Problem::Solve, problem.cc:169-250 */
 vio_status vio_solve(struct vioo_ctx *c, int32_t iterations, vio_solve_report *rep) {
-    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
+    if (c && c->M_mapped != -1) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;
     if (c->M == 0 && c->N == 0) {
         int any = 0;
@@ -1778,7 +1788,7 @@ vio_status vio_solve(struct vioo_ctx *c, int32_t iterations, vio_solve_report *r
 }
 
 vio_status vio_gn_iteration(struct vioo_ctx *c, double lambda) {
-    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
+    if (c && c->M_mapped != -1) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;
     vio_linearize(c);
     vio_solve_linear(c, lambda);
@@ -1847,7 +1857,7 @@ void vioo_schur_pinv(int n, int m2, const double *H, const double *b, double *Hp
 }
 
 vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, double *bout, double *errout, double *jtout) {
-    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
+    if (c && c->M_mapped != -1) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c || !Hout || !bout || !errout || !jtout) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
     const int n = PD;
@@ -1913,7 +1923,7 @@ vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, doubl
 
 /* the two halves of include/vio_backend.h (here: begin computes, end copies; nothing runs in the background) */
 vio_status vio_marginalize_begin(struct vioo_ctx *c, int32_t kind) {
-    if (c && c->M_mapped >= 0) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
+    if (c && c->M_mapped != -1) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;
     if (!c->mo_H) { c->mo_H = (double *)malloc(sizeof(double) * PRD * PRD); c->mo_jt = (double *)malloc(sizeof(double) * PRD * PRD); }
     c->mo_status = vio_marginalize(c, kind, c->mo_H, c->mo_b, c->mo_err, c->mo_jt);

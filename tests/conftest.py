@@ -59,3 +59,14 @@ def ref_lib(vio):
 def hip_lib(vio):
     """The product library.  No fallback: a missing build is a failure, not a skip."""
     return vio.load_hip()
+
+
+@pytest.fixture(scope="session")
+def hip_debug_lib(vio):
+    """The product's sources built with -DVIO_DEBUG_ENTRY_POINTS (vio_debug_chain_solve): not the product library."""
+    so = os.path.join(PKG_DIR, "csrc", "diag", "libvio_hip_debug.so")
+    if not os.path.exists(so):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as g
+        g.build_hip()
+    return vio.load_hip_debug()

@@ -7,12 +7,14 @@ import re
 import numpy as np
 import pytest
 
+import vio_testutil as tu
 from conftest import ROOT
 
 
 def header_functions():
     txt = open(os.path.join(ROOT, "include", "vio_backend.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"#ifdef VIO_DEBUG_ENTRY_POINTS.*?#endif", "", txt, flags=re.S)      # not part of the product ABI
     names = set(re.findall(r"\b(vio_[a-z0-9_]+)\s*\(", txt))
     names.discard("vio_exchange_fn")
     return sorted(names)
@@ -43,6 +45,18 @@ def test_hip_library_exports_every_declared_symbol(vio):
     assert not missing, missing
 
 
+def test_hip_library_exports_nothing_but_the_abi(vio):
+    """-fvisibility=hidden: the dynamic symbol table of the product library holds the functions include/vio_backend.h declares and nothing
+    else of the library's own (no vio_launch_* / vio_chain_* internals, no diagnostic entry points)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", vio.HIP_LIB], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-2] in ("T", "W", "B", "D", "V")}
+    ours = {n for n in exported if "vio" in n.lower() or n.startswith("k_") or "lin_" in n}
+    extra = sorted(ours - set(header_functions()))
+    assert not extra, extra
+    assert "vio_debug_chain_solve" not in exported
+
+
 def test_abi_version(vio):
     import ctypes as C
     f = vio.load_hip().dll.vio_abi_version
@@ -68,7 +82,7 @@ def test_oracle_exports_the_same_surface(vio, oracle_lib):
             continue
         if f in ("vio_profile_begin", "vio_profile_begin_sampled", "vio_profile_end", "vio_kernel_name",
                  "vio_comm_unique_id", "vio_comm_init", "vio_comm_destroy", "vio_get_stream", "vio_batch_gn_iteration", "vio_batch_solve",
-                 "vio_get_host_timing", "vio_set_solve_order", "vio_get_solve_order", "vio_debug_chain_solve", "vio_abi_version"):
+                 "vio_get_host_timing", "vio_set_solve_order", "vio_get_solve_order", "vio_abi_version"):
             continue        # measurement hooks, the native RCCL exchange, streams, batched launches and the choice of the GPU
                             # solver's elimination order exist on the HIP library only
         assert oracle_lib.has(f[len("vio_"):]), f
@@ -182,3 +196,7 @@ def test_observation_list_written_in_place(vio, oracle_lib):
     lm[:], host[:], target[:] = (0, 1, 500), (0, 0, 0), (1, 1, 1)
     with pytest.raises(vio.VioError):
         b.commit_observations()             # landmark index out of range
+
+
+def test_mapping_protocol_on_the_oracle(vio, oracle_lib):
+    tu.check_mapping_protocol(vio, oracle_lib, pytest)

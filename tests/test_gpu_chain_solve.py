@@ -24,10 +24,10 @@ def backward_error(H, b, lam, x):
     return float((np.abs(r[ok]) / den[ok]).max())
 
 
-def test_kernel_against_the_model_block_by_block(hip_lib):
+def test_kernel_against_the_model_block_by_block(hip_debug_lib):
     """every intermediate the kernel leaves in LDS (L tiles, M, pivots, forward-substituted right-hand side, solution) against
     the numpy model; random systems with the sparsity and the 1e16 scaling of a window's reduced system"""
-    ctx = hip_lib.context()
+    ctx = hip_debug_lib.context()
     rng = np.random.default_rng(7)
     for case in range(8):
         # cases 0..5: bias random walk of weight 1e16 beside entries of 1e4 (a window's scaling: the pivots of the chain are what
@@ -50,12 +50,12 @@ def test_kernel_against_the_model_block_by_block(hip_lib):
                 assert np.all(x[:6] == 0.0)
 
 
-def test_kernel_on_the_reference_system_against_exact_arithmetic(hip_lib):
+def test_kernel_on_the_reference_system_against_exact_arithmetic(hip_debug_lib):
     """tests/golden/ldlt.npz (the reference's H_pp_schur, its Eigen LDLT vectors) and ldlt_exact.npz (50-digit solutions): the chain
     order is closer to the exact solution than Eigen's own vectors are, at every lambda"""
     z = dict(np.load(os.path.join(GOLDEN_DIR, "ldlt.npz")))
     ze = dict(np.load(os.path.join(GOLDEN_DIR, "ldlt_exact.npz")))
-    ctx = hip_lib.context()
+    ctx = hip_debug_lib.context()
     for i in range(3):
         lam = float(z["lambda_%d" % i])
         x = ctx.debug_chain_solve(z["Hs"], z["bs"], lam)
@@ -68,7 +68,7 @@ def test_kernel_on_the_reference_system_against_exact_arithmetic(hip_lib):
         assert backward_error(z["Hs"], z["bs"], lam, x) <= 5e-15
 
 
-def test_kernel_below_lambda_1_on_the_reference_system(hip_lib):
+def test_kernel_below_lambda_1_on_the_reference_system(hip_debug_lib):
     """The unpivoted chain order has no pivot check where Eigen's LDLT pivots.  tests/golden/ldlt.npz's H_pp_schur at lambda = 1e-3
     and 1e-6 — far below anything Solve reaches on a window with IMU factors (lambda >= 8 on the goldens) — is INDEFINITE: the
     reduced system's smallest eigenvalues are -0.57 .. -0.02, rounding of the 1e16-sized terms the Schur complement cancels
@@ -77,7 +77,7 @@ def test_kernel_below_lambda_1_on_the_reference_system(hip_lib):
     measured backward error 3.3e-16 at both lambdas (profiles/r05b_noimu_and_low_lambda.txt) — the numpy model of the same order,
     with numpy's quotients instead of the kernel's correctly rounded ones and no FMA, reaches 4e-13 there, LU with pivoting 1e-15."""
     z = dict(np.load(os.path.join(GOLDEN_DIR, "ldlt.npz")))
-    ctx = hip_lib.context()
+    ctx = hip_debug_lib.context()
     for lam in (1e-3, 1e-6):
         x = ctx.debug_chain_solve(z["Hs"], z["bs"], lam)
         m = cm.ChainModel(z["Hs"], z["bs"], lam)

@@ -413,6 +413,10 @@ def test_observation_list_written_in_place_on_the_gpu(vio, hip_lib):
         b.commit_observations()
 
 
+def test_mapping_protocol_on_the_gpu(vio, hip_lib):
+    tu.check_mapping_protocol(vio, hip_lib, pytest)
+
+
 def test_rollback_restores_the_states(vio, hip_lib):
     w = vio.synth.make_window(120, seed=9)
     ctx = hip_lib.context()

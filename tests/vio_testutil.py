@@ -105,3 +105,48 @@ def run_solve(ctx, iterations=10):
     out["chi2_trace"] = np.array(list(rep.chi2_trace[:max(rep.iterations, 1)]))
     out["lambda_trace"] = np.array(list(rep.lambda_trace[:max(rep.iterations, 1)]))
     return out, rep
+
+
+def check_mapping_protocol(vio, lib, pytest):
+    """The ways out of a mapping (include/vio_backend.h), the same on the oracle and on the HIP library: vio_set_observations drops what
+    was written in place and sets its own list (map -> set -> solve gives the bits of set -> solve); vio_set_landmarks with another
+    count invalidates the mapping: the commit is refused, the context has no list, and a fresh map -> commit works again; an
+    invalid first edge (landmark -1) is refused without a look at the edge before it."""
+    import numpy as np
+    w = vio.synth.make_window(90, seed=15, ragged=True)
+    a, b = lib.context(), lib.context()
+    a.load(w)
+    b.set_window(w.poses, w.speed_bias, w.ext)
+    b.set_landmarks(w.inv_depth)
+    lm, host, target, pi, pj = b.map_observations(7)
+    lm[:] = 3                                   # rubbish that is never committed
+    b.set_observations(w.lm, w.host, w.target, w.pts_i, w.pts_j)
+    for k, p in enumerate(w.preint):
+        b.set_imu(k, p)
+    b.set_prior(None)
+    ra, rb = a.solve(10), b.solve(10)
+    assert ra.final_chi2 == rb.final_chi2 and ra.iterations == rb.iterations
+    assert np.array_equal(a.get_landmarks(), b.get_landmarks())
+    with pytest.raises(vio.VioError):
+        b.commit_observations()                 # the set ended the mapping
+    # another landmark count while mapped
+    w2 = vio.synth.make_window(40, seed=16)
+    lm, host, target, pi, pj = b.map_observations(w2.n_observations)
+    b.set_landmarks(w2.inv_depth)
+    with pytest.raises(vio.VioError) as e:
+        b.commit_observations()
+    assert e.value.status == -1 and "invalidated" in str(e.value)
+    with pytest.raises(vio.VioError):
+        b.solve(10)                             # no list (and no silent vision-less solve)
+    b.set_window(w2.poses, w2.speed_bias, w2.ext)
+    lm, host, target, pi, pj = b.map_observations(w2.n_observations)
+    lm[:], host[:], target[:], pi[:], pj[:] = w2.lm, w2.host, w2.target, w2.pts_i, w2.pts_j
+    b.commit_observations()
+    a.load(w2)
+    ra, rb = a.solve(10), b.solve(10)
+    assert ra.final_chi2 == rb.final_chi2 and np.array_equal(a.get_landmarks(), b.get_landmarks())
+    # an invalid FIRST edge
+    bad = w2.lm.copy()
+    bad[0] = -1
+    with pytest.raises(vio.VioError):
+        b.set_observations(bad, w2.host, w2.target, w2.pts_i, w2.pts_j)

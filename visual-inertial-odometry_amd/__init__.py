@@ -30,3 +30,18 @@ def load_hip():
             pass
         _hip = VioLib(HIP_LIB, "vio_")
     return _hip
+
+
+_hip_debug = None
+
+
+def load_hip_debug():
+    """The tests' build of the same sources with the diagnostic entry points (-DVIO_DEBUG_ENTRY_POINTS): csrc/diag/libvio_hip_debug.so."""
+    global _hip_debug
+    if _hip_debug is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        _hip_debug = VioLib(os.environ.get("VIO_HIP_DEBUG_LIB") or os.path.join(PKG_DIR, "csrc", "diag", "libvio_hip_debug.so"), "vio_")
+    return _hip_debug

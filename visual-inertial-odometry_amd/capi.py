@@ -101,7 +101,9 @@ class VioLib:
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
                 "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration", "batch_solve", "get_host_timing",
-                "set_solve_order", "get_solve_order", "debug_chain_solve"]
+                "set_solve_order", "get_solve_order"]
+    # diagnostic entry points: only in a build with -DVIO_DEBUG_ENTRY_POINTS (csrc/diag/libvio_hip_debug.so, the tests')
+    HIP_DEBUG = ["debug_chain_solve"]
     KERNELS = ["k_linearize", "k_reduce", "k_assemble", "k_pose_solve", "k_backsub", "k_lm_decide"]
 
     def __init__(self, path, prefix="vio_"):
@@ -123,6 +125,10 @@ class VioLib:
                 self.fn[s] = getattr(self.dll, prefix + s)
                 self.fn[s].restype = C.c_int
             self.fn["kernel_name"].restype = C.c_char_p
+            for s in self.HIP_DEBUG:
+                if hasattr(self.dll, prefix + s):
+                    self.fn[s] = getattr(self.dll, prefix + s)
+                    self.fn[s].restype = C.c_int
         self.fn["last_error"].restype = C.c_char_p
         self.fn["destroy"].restype = None
         self.fn["default_config"].restype = None

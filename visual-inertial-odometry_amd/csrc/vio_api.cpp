@@ -258,6 +258,7 @@ struct vio_ctx {
     unsigned ahead = 0;                        // what the device holds newer than the host mirrors: 1 states, 2 landmarks, 4 b_prior / err_prior
     bool topo_dirty = true;
     bool obs_mapped = false;                   // between vio_map_observations and vio_commit_observations: no list
+    bool obs_map_stale = false;                // ... and vio_set_landmarks has changed the landmark count meanwhile: the mapped arrays are gone
     bool obs_consistent = false;               // ... and vio_set_observations has seen that they share host frame and host observation
     bool obs_lm_major = false;                 // the observations of a landmark are consecutive and the landmarks ascend (vio_set_observations)
     bool linearized = false;
@@ -1341,6 +1342,8 @@ static vio_status set_landmarks_dim(vio_ctx *c, int64_t n, const double *val, in
     c->lm_dim = dim;
     if (resized) {      // the observation list refers to landmark indices (of this kind): it must be set again
         c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear();
+        c->obs_lm_major = c->obs_consistent = c->raw_pts_valid = false;
+        if (c->obs_mapped) c->obs_map_stale = true;       // the caller's pointers are gone: vio_commit_observations says so
         c->topo_dirty = true;
     }
     c->dirty_inputs = true;
@@ -1405,7 +1408,7 @@ static vio_status scan_observations(vio_ctx *c, int64_t m, const int32_t *lm, co
         bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)host[e] >= (uint32_t)NF) | (unsigned)((uint32_t)target[e] >= (uint32_t)NF) |
                (unsigned)(host[e] == target[e]);
         unsorted |= (unsigned)(l < prev);
-        if (l == prev) incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
+        if (e > 0 && l == prev) incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
         else if ((uint32_t)l < un) {
             changed |= (unsigned)(pl[2 * (size_t)l] != pi[2 * e]) | (unsigned)(pl[2 * (size_t)l + 1] != pi[2 * e + 1]);
             pl[2 * (size_t)l] = pi[2 * e]; pl[2 * (size_t)l + 1] = pi[2 * e + 1];
@@ -1426,7 +1429,11 @@ vio_status vio_set_observations(vio_ctx *c, int64_t m, const int32_t *lm, const 
                                 const double *pi, const double *pj) {
     if (!c || m < 0 || (m > 0 && (!lm || !host || !target || !pi || !pj))) return VIO_ERR_BAD_ARG;
     if (c->lm_dim == 3) return fail(c, VIO_ERR_BAD_ARG, "the context holds XYZ landmarks: use vio_set_observations_xyz");
-    if (c->obs_mapped) return fail(c, VIO_ERR_BAD_ARG, "vio_map_observations without vio_commit_observations");
+    if (c->obs_mapped) {            // vio_set_observations ends a mapping (include/vio_backend.h): what was written in place is dropped
+        c->obs_mapped = c->obs_map_stale = false;
+        c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear();
+        c->obs_lm_major = c->obs_consistent = false;
+    }
     const bool was_vouched = c->obs_consistent && c->h_pts_i.empty();       // the list held so far: host observations by landmark only
     bool same_pi = false;
     {
@@ -1469,6 +1476,8 @@ vio_status vio_map_observations(vio_ctx *c, int64_t m, int32_t **lm, int32_t **h
     if (!c->h_pts_j.resize_uninitialized(2 * (size_t)m)) return fail(c, VIO_ERR_HIP, "hipHostMalloc (observations)");
     *lm = c->h_olm.data(); *host = c->h_ohost.data(); *target = c->h_otarget.data(); *pi = c->h_pts_i.data(); *pj = c->h_pts_j.p;
     c->obs_mapped = true;           // the old list is gone, the new one is not there yet
+    c->obs_map_stale = false;
+    c->obs_lm_major = c->obs_consistent = false;
     c->raw_pts_valid = false;
     c->topo_dirty = true;
     c->dirty_inputs = true;
@@ -1479,6 +1488,11 @@ vio_status vio_commit_observations(vio_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
     if (!c->obs_mapped) return fail(c, VIO_ERR_BAD_ARG, "vio_commit_observations without vio_map_observations");
     c->obs_mapped = false;
+    if (c->obs_map_stale) {
+        c->obs_map_stale = false;
+        c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear();
+        return fail(c, VIO_ERR_BAD_ARG, "vio_commit_observations: the mapping was invalidated by vio_set_landmarks (another landmark count): map again");
+    }
     const int64_t m = (int64_t)c->h_olm.size();
     const vio_status st = scan_observations(c, m, c->h_olm.data(), c->h_ohost.data(), c->h_otarget.data(), c->h_pts_i.data());
     if (st != VIO_OK) { c->h_olm.clear(); c->h_ohost.clear(); c->h_otarget.clear(); c->h_pts_i.clear(); c->h_pts_j.clear(); c->obs_lm_major = c->obs_consistent = false; }
@@ -1570,6 +1584,7 @@ vio_status vio_get_solve_order(vio_ctx *c, int32_t *requested, int32_t *effectiv
     return VIO_OK;
 }
 
+#ifdef VIO_DEBUG_ENTRY_POINTS
 // Diagnostic: (H + lambda I) x = b by the chain-order kernel alone, on a matrix the caller supplies (171 x 171 row-major, natural
 // order of H_pp_schur_).  lds_dump (optional, vio_chain_lds_core_doubles() doubles): the factor as the kernel left it in LDS.
 vio_status vio_debug_chain_solve(vio_ctx *c, const double *H, const double *b, double lambda, double *x, double *lds_dump) {
@@ -1589,15 +1604,22 @@ vio_status vio_debug_chain_solve(vio_ctx *c, const double *H, const double *b, d
         }
     }
     DevBuf<double> d_img, d_x, d_dump;
-    HIPCHK(d_img.resize(img.size())); HIPCHK(d_x.resize(176)); HIPCHK(d_dump.resize((size_t)n_lds));
-    HIPCHK(hipMemcpyAsync(d_img.p, img.data(), img.size() * 8, hipMemcpyHostToDevice, c->stream));
-    vio_launch_chain_solve_test(d_img.p, lambda, d_x.p, lds_dump ? d_dump.p : nullptr, c->stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(x, d_x.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
-    if (lds_dump) HIPCHK(hipMemcpyAsync(lds_dump, d_dump.p, (size_t)n_lds * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return VIO_OK;
+    auto body = [&]() -> vio_status {
+        HIPCHK(d_img.resize(img.size())); HIPCHK(d_x.resize(176));
+        if (lds_dump) HIPCHK(d_dump.resize((size_t)n_lds));
+        HIPCHK(hipMemcpyAsync(d_img.p, img.data(), img.size() * 8, hipMemcpyHostToDevice, c->stream));
+        vio_launch_chain_solve_test(d_img.p, lambda, d_x.p, lds_dump ? d_dump.p : nullptr, c->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(x, d_x.p, PD * 8, hipMemcpyDeviceToHost, c->stream));
+        if (lds_dump) HIPCHK(hipMemcpyAsync(lds_dump, d_dump.p, (size_t)n_lds * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return VIO_OK;
+    };
+    const vio_status st = body();
+    d_img.release(); d_x.release(); d_dump.release();       // (DevBuf has no destructor: every way out passes here)
+    return st;
 }
+#endif
 
 vio_status vio_linearize(vio_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
@@ -1867,7 +1889,11 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
     // vio_profile_begin on the leader: an event pair around that kernel's batched launch (every prof_every-th iteration)
     int ev_kernel = -1;
     hipEvent_t ev[2] = {nullptr, nullptr};
-    if (c->prof_which >= 0 && c->prof_seen++ % c->prof_every == 0) {
+    // (a pair is taken only for a kernel this order launches: k_linearize, k_reduce, k_pose_solve in both, k_assemble in Eigen's order only;
+    // a pair consumed but never recorded would make vio_profile_end read events nobody recorded, or stale ones)
+    const bool prof_marks = c->prof_which == VIO_K_LINEARIZE || c->prof_which == VIO_K_REDUCE || c->prof_which == VIO_K_POSE_SOLVE ||
+                            (c->prof_which == VIO_K_ASSEMBLE && order == VIO_ORDER_EIGEN);
+    if (prof_marks && c->prof_seen++ % c->prof_every == 0) {
         bool ok = true;
         while (ok && c->prof_used + 2 > c->prof_events.size()) { hipEvent_t e; ok = hipEventCreate(&e) == hipSuccess; if (ok) c->prof_events.push_back(e); }
         if (ok) { ev[0] = c->prof_events[c->prof_used]; ev[1] = c->prof_events[c->prof_used + 1]; ev_kernel = c->prof_which; c->prof_used += 2; }
@@ -2392,7 +2418,7 @@ vio_status vio_bind_exchange_buffers(vio_ctx *c, void *reduced, void *scalars) {
 
 #ifdef VIO_STAMPS
 // diagnostic build: copy out the s_memtime stamps of the last k_linearize launch ([block][16])
-vio_status vio_debug_stamps(vio_ctx *c, unsigned long long *out, int64_t n_blocks) {
+__attribute__((visibility("default"))) vio_status vio_debug_stamps(vio_ctx *c, unsigned long long *out, int64_t n_blocks) {
     if (!c || !c->d_dbg.p) return VIO_ERR_BAD_ARG;
     enter_device(c);
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2432,15 +2458,16 @@ vio_status vio_profile_end(vio_ctx *c, double *total_ms, int64_t *launches) {
     enter_device(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     double tot = 0;
-    for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+    const size_t used = c->prof_used;
+    c->prof_which = -1;             // (the session ends whatever the events say)
+    c->prof_used = 0;
+    for (size_t i = 0; i + 1 < used; i += 2) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i], c->prof_events[i + 1]));
         tot += ms;
     }
     if (total_ms) *total_ms = tot;
-    if (launches) *launches = (int64_t)(c->prof_used / 2);
-    c->prof_which = -1;
-    c->prof_used = 0;
+    if (launches) *launches = (int64_t)(used / 2);
     return VIO_OK;
 }
 

@@ -2567,9 +2567,11 @@ void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t 
     else hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
 }
 // test entry of the chain solve: one image, one lambda (tests/test_gpu_chain_solve.py)
+#ifdef VIO_DEBUG_ENTRY_POINTS
 void vio_launch_chain_solve_test(const double *img, double lambda, double *x_nat, double *lds_dump, hipStream_t s) {
     hipLaunchKernelGGL(k_chain_solve_test, dim3(1), dim3(PS_THREADS), CH_LDS_CORE * sizeof(double), s, img, lambda, x_nat, lds_dump);
 }
+#endif
 int vio_chain_image_doubles() { return CH_PACKED; }
 int vio_chain_y_offset() { return CH_OFF_Y; }
 int vio_chain_lds_core_doubles() { return CH_LDS_CORE; }
@@ -2615,7 +2617,9 @@ int vio_set_kernel_attributes() {
     if (hipFuncSetAttribute((const void *)k_pose_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_pose_solve_c, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_pose_solve_cb, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+#ifdef VIO_DEBUG_ENTRY_POINTS
     if (hipFuncSetAttribute((const void *)k_chain_solve_test, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+#endif
     hipError_t e3 = hipFuncSetAttribute((const void *)k_linearize_xyz, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     if (e3 == hipSuccess) e3 = hipFuncSetAttribute((const void *)k_linearize_xyz_h, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);

@@ -567,6 +567,7 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
 __global__ __launch_bounds__(PS_THREADS) void k_pose_solve_c(DeviceTables T) { d_pose_solve_chain_body(T); }
 __global__ __launch_bounds__(PS_THREADS) void k_pose_solve_cb(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_pose_solve_chain_body(T); }
 
+#ifdef VIO_DEBUG_ENTRY_POINTS
 // Diagnostic / test entry: solve one image (CH_PACKED doubles, lambda NOT yet on its diagonal) and return x by natural index;
 // lds_dump (optional): the first CH_LDS_CORE doubles of LDS after the solve (L tiles, M, pivots, x) for tools/chain_solve_model.py
 __global__ __launch_bounds__(PS_THREADS) void k_chain_solve_test(const double *img, double lambda, double *x_nat, double *lds_dump) {
@@ -593,5 +594,6 @@ __global__ __launch_bounds__(PS_THREADS) void k_chain_solve_test(const double *i
     if (tid < PS_N) x_nat[tid] = P[CH_OFF_X + ch_dim(tid)];
     if (lds_dump) for (int i = tid; i < CH_LDS_CORE; i += PS_THREADS) lds_dump[i] = P[i];
 }
+#endif  // VIO_DEBUG_ENTRY_POINTS
 #endif  // __HIPCC__
 #endif
