@@ -53,7 +53,7 @@ def load_package():
     return mod
 
 
-CHAIN_IMAGE_BYTES = 15028 * 8        # CH_PACKED doubles (csrc/vio_pose_solve_chain.h): the tiles of the chain order + right-hand side
+CHAIN_IMAGE_BYTES = 16096 * 8        # CH_PACKED doubles (csrc/vio_pose_solve_chain.h): the tiles of the chain order + right-hand side
 PAIR_TABLE_BYTES = (121 * 40 + 16) * 8    # the reprojection chains k_pose_solve leaves for the next linearisation
 FP64_PEAK_TFLOPS = 78.6              # 1024 SIMDs x 32 FLOP/clk (v_mfma_f64_16x16x4_f64: 64 cycles; tools/microbench/mfma_lds_stream.hip) x 2.4 GHz = the vector fp64 rate
 

@@ -37,7 +37,7 @@ def test_two_ranks_launched_as_the_driver_would():
     # one window's iterations per second, not ranks x iterations
     assert abs(out["value"] * out["ms_per_step"] - 1e3) <= 1e-6 * 1e3
     assert out["single_gpu_same_window_ms"] > 0 and out["speedup_vs_single_gpu_same_window"] > 0
-    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["achieved"] > 0
+    assert out["roofline"]["bound"] in ("mfma", "latency") and out["roofline"]["achieved"] > 0 and out["roofline"]["fp64"] is not None
     assert out["final_chi2"] > 0 and out["final_chi2"] == out["final_chi2"]
     # the CPU port on the whole shared window, and the regime that scales with GPUs: independent batches, no collective
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0 and "200000" in out["cpu_baseline"]["sample"]

@@ -60,6 +60,12 @@ void vio_launch_batch_lm(const DeviceTables *tabs, int B, int lm_dim, int max_bl
                          int what, int max_iter, int order, hipStream_t s);
 void vio_launch_batch_gn(const DeviceTables *tabs, int B, int lm_dim, int max_blocks, size_t lin_lds, int lin_threads, int test_prev, int any_prior,
                          int parity, size_t ps_lds, int order, hipStream_t s, int ev_kernel, hipEvent_t *ev);
+void vio_launch_chain_pre(const DeviceTables &T, hipStream_t s);
+void vio_launch_prior_simg(const DeviceTables &T, hipStream_t s);
+int vio_chain_s_doubles();
+int vio_chain_pre_lds_doubles();
+int vio_chain_prior_flags();
+void vio_chain_imu_map(uint32_t *out);
 void vio_launch_chain_solve_test(const double *img, double lambda, double *x_nat, double *lds_dump, hipStream_t s);
 int vio_chain_image_doubles();
 int vio_chain_y_offset();
@@ -268,6 +274,7 @@ struct vio_ctx {
     int solve_order = VIO_ORDER_CHAIN;         // vio_set_solve_order (VIO_SOLVE_ORDER=eigen|chain overrides the default at creation)
     bool prior_chain_ok = true;                // H_prior couples no two speed-bias blocks that are not neighbours (the chain order's storage)
     bool test_in_solve = false;                // three-launch path: the step test owed by the last k_reduce_c goes to the next k_pose_solve_c
+    int gn_split = 0;                          // the GN iteration being enqueued has its speed-bias chain pre-eliminated: k_pose_solve_cs follows
     int pg_layout = -1;                        // which order's image d_Pg holds (the two layouts rely on different never-written zeros)
     bool want_natural_hs = false;              // set by vio_get_schur_system: re-run k_assemble with the natural-order copy
     bool natural_hs_valid = false;
@@ -279,8 +286,13 @@ struct vio_ctx {
     Plan *active = nullptr;
     // device buffers independent of the topology
     DevBuf<double> d_state, d_pairtab, d_vis, d_pre, d_imu_out, d_Hprior, d_bprior, d_errprior, d_Jtinv, d_Hs, d_bs,
-        d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi, d_gath, d_step_gath, d_sp_part;
+        d_bfull, d_diagfull, d_dx, d_step_tot, d_imu_chi, d_gath, d_step_gath, d_sp_part, d_cfi;
     DevBuf<int32_t> d_imu_valid, d_perm, d_rank, d_gather_map;
+    DevBuf<uint32_t> d_imu_map;                // static: where an IMU item's elements go in the chain image (d_chain_pre_item)
+    DevBuf<double> d_prior_simg;               // H_prior's speed-bias rows at their places in the chain image
+    DevBuf<int32_t> d_prior_flags, d_prior_list;     // ... which tiles / rows of it hold a non-zero, and its non-zero entries as a list
+    DevBuf<double> d_prior_cval;
+    bool prior_simg_valid = false;
     DevBuf<double> d_raw_pts_j;                // the target observations in the caller's order (k_gather_obs reads them)
     DevBuf<double> d_Pg;
     DevBuf<LmState> d_lm;
@@ -774,6 +786,17 @@ vio_status alloc_fixed(vio_ctx *c) {
     HIPCHK(c->d_imu_chi.resize(16)); HIPCHK(c->d_imu_valid.resize(16)); HIPCHK(c->d_lm.resize(1));
     HIPCHK(c->d_gath.resize((size_t)c->cfg.shard_count * VIS_SEND)); HIPCHK(c->d_step_gath.resize((size_t)c->cfg.shard_count * 2));
     HIPCHK(c->d_perm.resize(2 * 176)); HIPCHK(c->d_rank.resize(176)); HIPCHK(c->d_Pg.resize(2 * POSE_SOLVE_TILED));     // two sets (vio_solve's loop)
+    {
+        std::vector<uint32_t> map(10 * 63 * 9);
+        vio_chain_imu_map(map.data());
+        HIPCHK(c->d_imu_map.resize(map.size()));
+        HIPCHK(hipMemcpy(c->d_imu_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(c->d_prior_simg.resize((size_t)vio_chain_s_doubles()));
+        HIPCHK(c->d_prior_flags.resize((size_t)vio_chain_prior_flags()));
+        HIPCHK(c->d_prior_list.resize(128 + (size_t)vio_chain_s_doubles())); HIPCHK(c->d_prior_cval.resize((size_t)vio_chain_s_doubles()));
+    }
+    HIPCHK(c->d_cfi.resize((size_t)vio_chain_lds_core_doubles()));
+    HIPCHK(hipMemsetAsync(c->d_cfi.p, 0, (size_t)vio_chain_lds_core_doubles() * 8, c->stream));
     HIPCHK(hipMemset(c->d_Pg.p, 0, 2 * POSE_SOLVE_TILED * sizeof(double)));   // tile padding (17th column) is never written again (use_pg_layout)
     HIPCHK(hipMemsetAsync(c->d_vis.p, 0, VIS_COUNT * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_step_tot.p, 0, 8 * 8, c->stream));
@@ -821,10 +844,11 @@ DeviceTables make_tables_raw(vio_ctx *c, Plan &pl) {
     T.gath = c->ext_gath ? c->ext_gath : c->d_gath.p; T.step_gath = c->ext_step_gath ? c->ext_step_gath : c->d_step_gath.p;
     T.n_shards = (c->hook != nullptr || c->comm != nullptr) ? c->cfg.shard_count : 0;
     T.solve_order = effective_order(c);
+    T.cfi = c->d_cfi.p; T.prior_simg = c->d_prior_simg.p; T.prior_flags = c->d_prior_flags.p; T.prior_list = c->d_prior_list.p; T.prior_cval = c->d_prior_cval.p; T.imu_map = c->d_imu_map.p;
     use_pg_layout(c, T.solve_order);
     T.list_off = pl.d_list_off.p; T.list = pl.d_list.p;
 #ifdef VIO_STAMPS
-    (void)c->d_dbg.resize(16 * (size_t)(T.n_items + T.n_imu_items + 16));
+    (void)c->d_dbg.resize(16 * (size_t)(T.n_items + T.n_imu_items + 48));
     T.dbg = c->d_dbg.p;
 #endif
     return T;
@@ -950,6 +974,7 @@ vio_status push_to_device(vio_ctx *c, Plan &pl) {
         HIPCHK(hipMemcpyAsync(c->d_Hprior.p, s_H, PD * PD * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(c->d_Jtinv.p, s_J, PRD * PRD * 8, hipMemcpyHostToDevice, st));
         c->prior_dirty = false;
+        c->prior_simg_valid = false;
     }
     HIPCHK(hipMemcpyAsync(c->d_bprior.p, s_b, PD * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(c->d_errprior.p, s_e, PRD * 8, hipMemcpyHostToDevice, st));
@@ -1092,7 +1117,28 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     if (gn) T.cur_hint = c->cur_host;
     if (test_prev) T.gn_flags = 2;
     if (!c->pairtab_valid && pl.lm_dim == 1) { vio_launch_prepare(T, c->stream); c->pairtab_valid = true; }
-    { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(T, T.n_items + T.n_imu_items, (size_t)pl.max_lds_doubles * 8, pl.lin_threads, pl.use_ext, c->stream); }
+    // The GN loop's split solve (VIO_GN_SPLIT=1, off by default): lambda is the caller's, so the speed-bias chain of
+    // this iteration's system — IMU factors, prior and lambda, nothing of the landmarks — can be eliminated by one more workgroup of
+    // k_linearize's grid (it forms the IMU items itself: their workgroups are not launched) while k_pose_solve_cs starts at the camera block.
+    // Bit-identical, and measured as a wash at 20 000 landmarks: the solve loses 8.1 us (30.2 -> 22.1), the linearisation gains the 8.5 us
+    // by which the chain workgroup (IMU items 6 us, assembly 4 us, elimination 9 us, store) outlasts the items' 13.7 us.  2: diagnostic form.
+    static const int split_mode = std::getenv("VIO_GN_SPLIT") ? std::atoi(std::getenv("VIO_GN_SPLIT")) : 0;
+    c->gn_split = 0;
+    const bool split = split_mode == 1 && gn && three_launch(c, T) && pl.lm_dim == 1 && pl.lin_threads == lin_threads_host() && lin_threads_host() == 1024 &&
+                       T.n_items >= 1;
+    size_t lin_lds = (size_t)pl.max_lds_doubles * 8;
+    int lin_blocks = T.n_items + T.n_imu_items;
+    DeviceTables TL = T;
+    if (split) {
+        if (T.has_prior && !c->prior_simg_valid) { vio_launch_prior_simg(T, c->stream); c->prior_simg_valid = true; }
+        TL.gn_flags |= 16;
+        TL.n_imu_items = 0;
+        TL.n_step_blocks = T.n_items;          // (the rows of b_prior' are shared out over the item workgroups alone)
+        lin_blocks = 1 + T.n_items;
+        lin_lds = std::max(lin_lds, (size_t)vio_chain_pre_lds_doubles() * 8);
+        c->gn_split = 1;
+    }
+    { ProfScope ps(c, VIO_K_LINEARIZE); vio_launch_linearize(TL, lin_blocks, lin_lds, pl.lin_threads, pl.use_ext, c->stream); }
     // with a prior, the previous GN step left err_prior to this k_reduce (k_pose_solve wrote b_prior' only)
     const bool err_prev = test_prev && T.has_prior;
     // sharded + gated slot: the all-reduce below runs whether the slot is live or not (every rank enqueues the same
@@ -1107,6 +1153,8 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     c->test_in_solve = false;
     if (gn && three_launch(c, T)) {
         { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce_assemble(R, T, c->stream); }
+        // (VIO_GN_SPLIT=2, diagnostic: the chain eliminated in a launch of its own, from the assembled image)
+        if (split_mode == 2) { vio_launch_chain_pre(T, c->stream); c->gn_split = 2; }
         if (test_prev) { c->test_in_solve = true; c->decide_pending = false; }
         HIPCHK(hipGetLastError());
         c->linearized = true;
@@ -1137,6 +1185,7 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int ga
     T.gn_flags = 4;         // bit 2: k_pose_solve leaves the prior update to the kernels that follow (all paths now)
     if (gn) T.cur_hint = c->cur_host;      // GN: the update rides with the next k_linearize / k_reduce (or with flush_decide)
     if (gn && c->test_in_solve) { T.gn_flags |= 1; c->test_in_solve = false; }      // three-launch path: the previous step's test at this kernel's head
+    if (gn && c->gn_split) { T.gn_flags |= 16; c->gn_split = 0; }                   // ... and the chain of this system is eliminated already
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     if (gn) {
         // the step is accepted whatever chi2 turns out to be: the landmark back-substitution, the chi2 of the new state and
@@ -1286,6 +1335,7 @@ vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
     if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
     if (replan) c->topo_dirty = true;
     c->dirty_inputs = true;
+    c->prior_simg_valid = false;        // (ext_fixed decides which prior entries are masked)
     return VIO_OK;
 }
 
@@ -1303,7 +1353,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_state.release(); c->d_pairtab.release(); c->d_vis.release(); c->d_pre.release(); c->d_imu_out.release();
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release(); c->d_sp_part.release();
-    c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release();
+    c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release(); c->d_cfi.release(); c->d_imu_map.release(); c->d_prior_simg.release(); c->d_prior_flags.release(); c->d_prior_list.release(); c->d_prior_cval.release();
     c->d_batch_tabs.release(); c->d_rank.release(); c->d_gather_map.release(); c->d_gath.release(); c->d_step_gath.release();
     c->arena.release(c->own_stream);
     c->h_pts_j.release(); c->d_raw_pts_j.release();

@@ -287,7 +287,9 @@ __device__ __forceinline__ void ch_yc_tile(double *P, int e, int t, int lane) {
 }
 
 // what the workers (waves 2..15, wi = wave - 2) do after barrier LEV
-template <int LEV>
+// CAM = false (the pre-elimination of the GN loop, ch_chain_pre: the camera block and its right-hand side are not there yet): the terms
+// of CC and y_C are left to the kernel that has them (ch_camera_solve<true> applies them in the same order)
+template <int LEV, bool CAM = true>
 __device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int wi, int lane, unsigned long long eff) {
     constexpr int eA = LEV, eB = 10 - LEV;
     if (wi == 13) { ch_rhs_phase<LEV>(P, lane); return; }
@@ -328,12 +330,12 @@ __device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int 
         }
         first_cc = wi >= 5 ? wi - 5 : wi + 8;             // eight idle workers: tasks 0..7 and 8..14 after them
     }
-    if (LEV > 0 && wi < 5) {
+    if (CAM && LEV > 0 && wi < 5) {
         // the right-hand side rows of camera tile wi: the terms of the previous level's blocks (their w came out one phase ago)
         if (ch_bit(eff, LEV - 1, wi)) ch_yc_tile(P, LEV - 1, wi, lane);
         if (ch_bit(eff, 11 - LEV, wi)) ch_yc_tile(P, 11 - LEV, wi, lane);
     }
-    if (LEV > 0) {
+    if (CAM && LEV > 0) {
         // the camera-block terms of the previous level, for the six tiles step 0 consumes: two each on three waves without a fused task
         const int idle0 = (LEV < 4) ? 10 : 5;
         if (wi >= idle0 && wi < idle0 + 3) {
@@ -348,23 +350,27 @@ __device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int 
 // What follows the solve for the camera variables (trial poses, pair table) need not wait for the speed-bias part of the solution:
 // mid1(lane) is called by wave 13 once the camera part is out (sX[CH_YC ..]; phase Y: it has nothing else to do), mid2(index, lane) one
 // barrier later by the fourteen waves that do not walk the chains (phase Z), index 0..13.
-template <typename Mid1, typename Mid2>
-__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 mid1, Mid2 mid2, unsigned long long *dbg = nullptr) {
-#ifdef VIO_STAMPS
-    const unsigned long long t_start__ = __builtin_amdgcn_s_memtime();
-    if (tid == 0) { g_ch_dbg = dbg; g_ch_t0 = t_start__; }
-#endif
-    const int lane = tid & 63;
-    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+__device__ __forceinline__ ChLane ch_lane(int lane) {
     const int r16 = lane & 15, g = lane >> 4;
-    double *sD = P + CH_OFF_D, *sX = P + CH_OFF_X, *sY = P + CH_OFF_Y, *sMc = P + CH_OFF_MC;
-    const bool r9 = r16 < 9;
     ChLane L;
-    L.r16 = r16; L.g = g; L.r9 = r9;
+    L.r16 = r16; L.g = g; L.r9 = r16 < 9;
     L.oA0 = r16 * CH_TS + g; L.oA2 = r16 * CH_TS + (g == 0 ? 8 : 9);
     L.oM0 = g * CH_TS + r16; L.oM2 = (g == 0) ? 8 * CH_TS + r16 : 8 * CH_TS + 9;
+    return L;
+}
 
-    // ================= speed-bias chain =================
+// The speed-bias chain: six levels (all 16 waves; ends behind a barrier).  Returns the mask of the SC tiles that are non-zero when their
+// block is eliminated.  CAM: the camera block and the camera part of the right-hand side are in the image and take the chain's terms
+// level by level (the fused solve); without them (the pre-elimination of the GN loop) the chain leaves L_SC, L_SO, M_e, the pivots and
+// w_e = M_e^T y_e, and whoever has the camera block applies the terms (ch_camera_solve<true>: the same operations in the same order).
+template <bool CAM>
+__device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, const int tid, const ChLane &L, unsigned long long *dbg, unsigned long long t_start__) {
+    const int lane = tid & 63;
+    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = L.g;
+    const bool r9 = L.r9;
+    double *sD = P + CH_OFF_D;
+    (void)dbg; (void)t_start__;
     unsigned long long eff = 0ull;
     if (uwave < 2) {
         // the two chain waves: wave 0 blocks 0..4 and then 5, wave 1 blocks 10..6 (one copy of the code, the block a run-time value)
@@ -397,24 +403,61 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 m
         ch_scan_tiles(P, wi, lane);                                // (nothing else to do during level 0)
         __syncthreads();                                           // barrier 0: level 0 is out
         eff = ch_eff_mask(P, lane);
-        ch_worker_phase<0>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(112);
+        ch_worker_phase<0, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(112);
         __syncthreads();
-        ch_worker_phase<1>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(113);
+        ch_worker_phase<1, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(113);
         __syncthreads();
-        ch_worker_phase<2>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(114); CH_STAMP(140 + uwave);
+        ch_worker_phase<2, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(114); CH_STAMP(140 + uwave);
         __syncthreads();
-        ch_worker_phase<3>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(115);
+        ch_worker_phase<3, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(115);
         __syncthreads();
-        ch_worker_phase<4>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(116);
+        ch_worker_phase<4, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(116);
         __syncthreads();
-        ch_worker_phase<5>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(117);
+        ch_worker_phase<5, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(117);
         __syncthreads();
     }
     if (uwave == 0) CH_STAMP(87);
+    return eff;
+}
 
-    // ================= camera block: 5 tiles (16, 16, 16, 16, 8) =================
+// The camera block (5 tiles: 16, 16, 16, 16, 8) and the back-substitution.  SPLIT: the chain was eliminated by another workgroup
+// (ch_chain_pre: L_SC, L_SO, M_e, pivots and w_e are in the image, `eff` came with them): the terms the chain waves apply level by level
+// in the fused solve — to the six camera tiles step 0 consumes and to y_C — are applied here in one go, in the chain's order
+// (0, 10, 1, 9, ..., 4, 6, 5: the same accumulations, bit for bit).
+template <bool SPLIT, typename Mid1, typename Mid2>
+__device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const ChLane &L, const unsigned long long eff, Mid1 mid1, Mid2 mid2,
+                                                unsigned long long *dbg, unsigned long long t_start__) {
+    const int lane = tid & 63;
+    const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = L.r16, g = L.g;
+    const bool r9 = L.r9;
+    double *sD = P + CH_OFF_D, *sX = P + CH_OFF_X, *sY = P + CH_OFF_Y, *sMc = P + CH_OFF_MC;
+    (void)dbg; (void)t_start__;
     const int lofs = r16 * PS_TROW + g;      // A image of a 16 x 17 tile: row r16, k = g + 4q
     const int cofs = g * PS_TROW + r16;      // C / B image: row g + 4v, column r16
+    if (SPLIT) {
+        if (uwave <= 5) {
+            // the six tiles camera step 0 consumes — (0,0) (1,0) (1,1) (2,0) (3,0) (4,0) — take all eleven blocks' terms now
+            int I, J;
+            ch_tile_ij(ch_early_tile(uwave), I, J);
+            double *tc = P + ch_cc(I, J) + cofs;
+            ps_v4d acc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = tc[4 * PS_TROW * v];
+            ch_cc_deferred_terms(P, L, I, J, acc, eff);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tc[4 * PS_TROW * v] = acc[v];
+            if (uwave == 0) ch_factor_tile(P + ch_cc(0, 0), sMc, sD + CH_YC, 16, lane);
+        } else if (uwave >= 6 && uwave <= 10) {
+            // y_C -= L_SC[e] w_e for the rows of camera tile t, block after block in the chain's order
+            const int t = uwave - 6;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const int e = (i == 10) ? 5 : ((i & 1) ? 10 - (i >> 1) : (i >> 1));
+                if (ch_bit(eff, e, t)) ch_yc_tile(P, e, t, lane);
+            }
+        }
+    } else
     if (uwave == 0) {
         // CC(0,0) -= (L D) L^T of block 5 first: it is what F(0) waits for
         double *tc = P + ch_cc(0, 0) + cofs;
@@ -680,5 +723,18 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 m
         if (uwave == 0) CH_STAMP(63);
         __syncthreads();
     }
+}
+
+// the whole solve on one workgroup's image (k_pose_solve_c outside the GN loop's split form, the diagnostic entry)
+template <typename Mid1, typename Mid2>
+__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 mid1, Mid2 mid2, unsigned long long *dbg = nullptr) {
+    unsigned long long t_start__ = 0ull;
+#ifdef VIO_STAMPS
+    t_start__ = __builtin_amdgcn_s_memtime();
+    if (tid == 0) { g_ch_dbg = dbg; g_ch_t0 = t_start__; }
+#endif
+    const ChLane L = ch_lane(tid & 63);
+    const unsigned long long eff = ch_chain_elimination<true>(P, tid, L, dbg, t_start__);
+    ch_camera_solve<false>(P, tid, L, eff, mid1, mid2, dbg, t_start__);
 }
 #endif

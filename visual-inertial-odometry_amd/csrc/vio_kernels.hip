@@ -184,6 +184,50 @@ __global__ __launch_bounds__(128) void k_prepare(DeviceTables T) {
 #define O_BA 9
 #define O_BG 12
 
+// The IMU factor's residual and Jacobian blocks are evaluated with NO floating-point contraction: every product and every sum is the
+// IEEE operation the source states, in the order it states it (as the oracle's C is compiled).  With the compiler free to fuse a*b+c
+// the result of these expressions depended on what surrounded them after inlining (a product with a second use is not fused), and two
+// call sites of the same function — the IMU workgroups of d_imu_item, the chain workgroup of the GN loop — could differ in the last bit.
+// The helpers of vio_device_math.h they use are restated here under the same rule.
+#pragma clang fp contract(off)
+__device__ __forceinline__ void nc_quat_to_R(const double *q, double *R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void nc_m3_mul(const double *A, const double *B, double *C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+__device__ __forceinline__ dquat nc_qmul(dquat a, dquat b) {       // Eigen quaternion product
+    dquat r;
+    r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+    r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+    r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+    r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+    return r;
+}
+__device__ __forceinline__ dquat nc_qinv(dquat q) {                // Eigen::QuaternionBase::inverse
+    const double n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    dquat r = {0, 0, 0, 0};
+    if (n2 > 0) { r.x = -q.x / n2; r.y = -q.y / n2; r.z = -q.z / n2; r.w = q.w / n2; }
+    return r;
+}
+__device__ __forceinline__ void nc_qrot(dquat q, const double *v, double *o) {   // Eigen _transformVector
+    double ux = q.y * v[2] - q.z * v[1], uy = q.z * v[0] - q.x * v[2], uz = q.x * v[1] - q.y * v[0];
+    ux += ux; uy += uy; uz += uz;
+    o[0] = v[0] + q.w * ux + (q.y * uz - q.z * uy);
+    o[1] = v[1] + q.w * uy + (q.z * ux - q.x * uz);
+    o[2] = v[2] + q.w * uz + (q.x * uy - q.y * ux);
+}
 struct ImuCommon {
     dquat Qi, Qj, Qi_inv, dq, cdq;
     double sum_dt;
@@ -208,7 +252,7 @@ __device__ __forceinline__ void d_qright_br(dquat q, double *B) {     // Utility
 
 __device__ void d_imu_common(const double *pre, const double *pi, const double *si, const double *pj, ImuCommon &c) {
     c.Qi = d_qload(pi); c.Qj = d_qload(pj);
-    c.Qi_inv = d_qinv(c.Qi);
+    c.Qi_inv = nc_qinv(c.Qi);
     c.sum_dt = pre[PRE_SUMDT];
     c.dq.x = pre[PRE_DQ]; c.dq.y = pre[PRE_DQ + 1]; c.dq.z = pre[PRE_DQ + 2]; c.dq.w = pre[PRE_DQ + 3];
 #pragma unroll
@@ -219,7 +263,7 @@ __device__ void d_imu_common(const double *pre, const double *pi, const double *
     for (int i = 0; i < 3; ++i)
         th[i] = Jm[15 * (O_R + i) + O_BG] * c.dbg[0] + Jm[15 * (O_R + i) + O_BG + 1] * c.dbg[1] + Jm[15 * (O_R + i) + O_BG + 2] * c.dbg[2];
     dquat dth = {th[0] / 2.0, th[1] / 2.0, th[2] / 2.0, 1.0};      // Utility::deltaQ, not normalised
-    c.cdq = d_qmul(c.dq, dth);
+    c.cdq = nc_qmul(c.dq, dth);
 }
 
 // IntegrationBase::evaluate (integration_base.h:160-186)
@@ -244,14 +288,14 @@ __device__ void d_imu_residual(const double *pre, const double *G, const double 
     double t[3], u[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) t[k] = 0.5 * G[k] * sum_dt * sum_dt + pj[k] - pi[k] - si[k] * sum_dt;
-    d_qrot(c.Qi_inv, t, u);
+    nc_qrot(c.Qi_inv, t, u);
 #pragma unroll
     for (int k = 0; k < 3; ++k) res[O_P + k] = u[k] - cdp[k];
-    dquat qe = d_qmul(d_qinv(c.cdq), d_qmul(c.Qi_inv, c.Qj));
+    dquat qe = nc_qmul(nc_qinv(c.cdq), nc_qmul(c.Qi_inv, c.Qj));
     res[O_R] = 2 * qe.x; res[O_R + 1] = 2 * qe.y; res[O_R + 2] = 2 * qe.z;
 #pragma unroll
     for (int k = 0; k < 3; ++k) t[k] = G[k] * sum_dt + sj[k] - si[k];
-    d_qrot(c.Qi_inv, t, u);
+    nc_qrot(c.Qi_inv, t, u);
 #pragma unroll
     for (int k = 0; k < 3; ++k) res[O_V + k] = u[k] - cdv[k];
 #pragma unroll
@@ -260,15 +304,17 @@ __device__ void d_imu_residual(const double *pre, const double *G, const double 
 
 // One 3x3 block of the 15x30 Jacobian [J_pose_i | J_sb_i | J_pose_j | J_sb_j] (edge_imu.cc:74-153).
 // `blk` enumerates the 14 non-zero blocks; sJ is the 15x30 row-major LDS image (zero-initialised).
+// RiT = Qi.inverse().toRotationMatrix() (d_imu_rit)
+__device__ __forceinline__ void d_imu_rit(const ImuCommon &c, double *RiT) {
+    double qi[4] = {c.Qi_inv.x, c.Qi_inv.y, c.Qi_inv.z, c.Qi_inv.w};
+    nc_quat_to_R(qi, RiT);
+}
 __device__ void d_imu_jac_block(int blk, const double *pre, const double *G, const double *pi, const double *si,
-                                const double *pj, const double *sj, const ImuCommon &c, double *sJ) {
+                                const double *pj, const double *sj, const ImuCommon &c, const double *RiT, double *sJ) {
     const double *Jm = pre + PRE_JAC;
     const double sum_dt = c.sum_dt;
     double B[9];
     int r0 = 0, c0 = 0;
-    double RiT[9];
-    double qi[4] = {c.Qi_inv.x, c.Qi_inv.y, c.Qi_inv.z, c.Qi_inv.w};
-    d_quat_to_R(qi, RiT);                 // Qi.inverse().toRotationMatrix()
     switch (blk) {
     case 0: r0 = O_P; c0 = 0 + O_P;       // jacobian_pose_i(O_P,O_P) = -Ri^T
         for (int k = 0; k < 9; ++k) B[k] = -RiT[k];
@@ -276,19 +322,19 @@ __device__ void d_imu_jac_block(int blk, const double *pre, const double *G, con
     case 1: { r0 = O_P; c0 = 0 + O_R;     // skew(Qi^-1 (0.5 G dt^2 + Pj - Pi - Vi dt))
         double t[3], u[3];
         for (int k = 0; k < 3; ++k) t[k] = 0.5 * G[k] * sum_dt * sum_dt + pj[k] - pi[k] - si[k] * sum_dt;
-        d_qrot(c.Qi_inv, t, u); d_skew(u, B);
+        nc_qrot(c.Qi_inv, t, u); d_skew(u, B);
         break; }
     case 2: { r0 = O_R; c0 = 0 + O_R;     // -(Qleft(Qj^-1 Qi) Qright(corrected_delta_q)).bottomRight
-        dquat a = d_qmul(d_qinv(c.Qj), c.Qi), b = c.cdq;
+        dquat a = nc_qmul(nc_qinv(c.Qj), c.Qi), b = c.cdq;
         double La[9], Rb[9], P[9];
-        d_qleft_br(a, La); d_qright_br(b, Rb); d_m3_mul(La, Rb, P);
+        d_qleft_br(a, La); d_qright_br(b, Rb); nc_m3_mul(La, Rb, P);
         const double va[3] = {a.x, a.y, a.z}, vb[3] = {b.x, b.y, b.z};
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[3 * i + j] = -(va[i] * (-vb[j]) + P[3 * i + j]);
         break; }
     case 3: { r0 = O_V; c0 = 0 + O_R;     // skew(Qi^-1 (G dt + Vj - Vi))
         double t[3], u[3];
         for (int k = 0; k < 3; ++k) t[k] = G[k] * sum_dt + sj[k] - si[k];
-        d_qrot(c.Qi_inv, t, u); d_skew(u, B);
+        nc_qrot(c.Qi_inv, t, u); d_skew(u, B);
         break; }
     case 4: r0 = O_P; c0 = 6 + 0;         // speedbias_i(O_P, V) = -Ri^T dt
         for (int k = 0; k < 9; ++k) B[k] = -RiT[k] * sum_dt;
@@ -301,10 +347,10 @@ __device__ void d_imu_jac_block(int blk, const double *pre, const double *G, con
         break;
     case 7: { r0 = O_R; c0 = 6 + 6;       // -Qleft(Qj^-1 Qi delta_q).bottomRight * dq_dbg  (delta_q, not corrected: edge_imu.cc:107-109)
         double L[9], nL[9], D[9];
-        d_qleft_br(d_qmul(d_qmul(d_qinv(c.Qj), c.Qi), c.dq), L);
+        d_qleft_br(nc_qmul(nc_qmul(nc_qinv(c.Qj), c.Qi), c.dq), L);
         for (int k = 0; k < 9; ++k) nL[k] = -L[k];
         for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) D[3 * i + j] = Jm[15 * (O_R + i) + O_BG + j];
-        d_m3_mul(nL, D, B);
+        nc_m3_mul(nL, D, B);
         break; }
     case 8: r0 = O_V; c0 = 6 + 0;         // -Ri^T
         for (int k = 0; k < 9; ++k) B[k] = -RiT[k];
@@ -319,7 +365,7 @@ __device__ void d_imu_jac_block(int blk, const double *pre, const double *G, con
         for (int k = 0; k < 9; ++k) B[k] = RiT[k];
         break;
     case 12: { r0 = O_R; c0 = 15 + O_R;   // Qleft(corrected_dq^-1 Qi^-1 Qj).bottomRight
-        d_qleft_br(d_qmul(d_qmul(d_qinv(c.cdq), c.Qi_inv), c.Qj), B);
+        d_qleft_br(nc_qmul(nc_qmul(nc_qinv(c.cdq), c.Qi_inv), c.Qj), B);
         break; }
     case 13: r0 = O_V; c0 = 21 + 0;       // speedbias_j(O_V,V) = Ri^T
         for (int k = 0; k < 9; ++k) B[k] = RiT[k];
@@ -329,6 +375,7 @@ __device__ void d_imu_jac_block(int blk, const double *pre, const double *G, con
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) sJ[30 * (r0 + i) + c0 + j] = B[3 * i + j];
 }
 
+#pragma clang fp contract(fast)
 // T = J^T Info J (30x30), g = J^T Info r, chi = r^T Info r  for IMU edge k
 template <int NT> __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
     const int tid = threadIdx.x;
@@ -351,8 +398,10 @@ template <int NT> __device__ void d_imu_item(const DeviceTables &T, int k, doubl
     __syncthreads();
     if (tid < 16) {
         ImuCommon c;
+        double RiT[9];
         d_imu_common(pre, pi, si, pj, c);
-        if (tid < 14) d_imu_jac_block(tid, pre, T.gravity, pi, si, pj, sj, c, sJ);
+        d_imu_rit(c, RiT);
+        if (tid < 14) d_imu_jac_block(tid, pre, T.gravity, pi, si, pj, sj, c, RiT, sJ);
         else if (tid == 14) {
             double r[15];
             d_imu_residual(pre, T.gravity, pi, si, pj, sj, c, r);
@@ -368,29 +417,29 @@ template <int NT> __device__ void d_imu_item(const DeviceTables &T, int k, doubl
     for (int e = tid; e < 450; e += NT) {      // JtI[a][j] = sum_i J[i][a] * I[i][j]
         const int a = e / 15, j = e % 15;
         double s = 0;
-        for (int i = 0; i < 15; ++i) s += sJ[30 * i + a] * sI[15 * i + j];
+        for (int i = 0; i < 15; ++i) s = fma(sJ[30 * i + a], sI[15 * i + j], s);
         sJtI[e] = s;
     }
     if (tid < 15) {
         double s = 0;
-        for (int j = 0; j < 15; ++j) s += sI[15 * tid + j] * sr[j];
+        for (int j = 0; j < 15; ++j) s = fma(sI[15 * tid + j], sr[j], s);
         sIr[tid] = s;
     }
     __syncthreads();
     for (int e = tid; e < 900; e += NT) {
         const int a = e / 30, b = e % 30;
         double s = 0;
-        for (int j = 0; j < 15; ++j) s += sJtI[15 * a + j] * sJ[30 * j + b];
+        for (int j = 0; j < 15; ++j) s = fma(sJtI[15 * a + j], sJ[30 * j + b], s);
         out[IMU_T + e] = s;
     }
     if (tid < 30) {
         double s = 0;
-        for (int i = 0; i < 15; ++i) s += sJ[30 * i + tid] * sIr[i];
+        for (int i = 0; i < 15; ++i) s = fma(sJ[30 * i + tid], sIr[i], s);
         out[IMU_G + tid] = s;
     }
     if (tid == 32) {
         double s = 0;
-        for (int i = 0; i < 15; ++i) s += sr[i] * sIr[i];
+        for (int i = 0; i < 15; ++i) s = fma(sr[i], sIr[i], s);
         out[IMU_CHI] = s;
     }
 }
@@ -451,11 +500,18 @@ __device__ __forceinline__ void d_bprior_rows(const DeviceTables &T, int from, i
     }
 }
 
+// the chain workgroup of the GN loop's grid (vio_pose_solve_chain.h)
+__device__ __forceinline__ void d_chain_pre_item(const DeviceTables &T);
 // NT: threads of the workgroup.  UE = 0: the plan has no extrinsic block (vio_config.ext_fixed, the reference's ESTIMATE_EXTRINSIC = 0) —
 // row-record sizes and operand-stream strides are compile-time constants (phase 2: 7.3 k -> 6.8 k cycles); UE = 1: read from the item.
-template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
+// CH = 1 (the 1024-thread single-window kernels): with gn_flags bit 4 the grid's first workgroup is the chain workgroup, the items follow.
+template <int NT, int UE, int CH = 0> __device__ __forceinline__ void d_linearize_body(const DeviceTables &T) {
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    int b = blockIdx.x;
+    if (CH && (T.gn_flags & 16)) {
+        if (b == 0) { d_chain_pre_item(T); return; }
+        b -= 1;
+    }
     // the item's descriptor is requested before the gate looks at LmState (vio_solve's loop): one round trip for both, not two
     int32_t desc_word = 0;
     if (b < T.n_items && tid < (int)(sizeof(ItemDesc) / 4)) desc_word = ((const int32_t *)(T.items + b))[tid];
@@ -976,8 +1032,8 @@ template <int NT, int UE> __device__ __forceinline__ void d_linearize_body(const
     STAMP(T, 5);
     STAMP_FLUSH(T);
 }
-__global__ LIN_BOUNDS void k_linearize(DeviceTables T) { d_linearize_body<LIN_THREADS, 0>(T); }
-__global__ LIN_BOUNDS void k_linearize_g(DeviceTables T) { d_linearize_body<LIN_THREADS, 1>(T); }      // plans with an extrinsic block (free extrinsic, marginalisation)
+__global__ LIN_BOUNDS void k_linearize(DeviceTables T) { d_linearize_body<LIN_THREADS, 0, LIN_THREADS == 1024>(T); }
+__global__ LIN_BOUNDS void k_linearize_g(DeviceTables T) { d_linearize_body<LIN_THREADS, 1, LIN_THREADS == 1024>(T); }      // plans with an extrinsic block (free extrinsic, marginalisation)
 // The same kernel with half the threads and two workgroups to a CU (items of at most half the LDS): what the throughput policy's
 // plans run on (vio_config.item_policy = VIO_ITEMS_THROUGHPUT).  When every CU has workgroup after workgroup to run, a CU sits
 // idle for 1.7 us between two of them and a workgroup's head is two dependent round trips that overlap nothing
@@ -2563,7 +2619,8 @@ void vio_launch_assemble(const DeviceTables &T, hipStream_t s) {
 }
 // lds_bytes: what the Eigen-order kernel needs (the chain kernel's size is its own)
 void vio_launch_pose_solve(const DeviceTables &T, size_t lds_bytes, hipStream_t s) {
-    if (T.solve_order == 1) hipLaunchKernelGGL(k_pose_solve_c, dim3(1), dim3(PS_THREADS), CH_LDS_DOUBLES * sizeof(double), s, T);
+    if (T.solve_order == 1 && (T.gn_flags & 16)) hipLaunchKernelGGL(k_pose_solve_cs, dim3(1), dim3(PS_THREADS), CH_LDS_DOUBLES * sizeof(double), s, T);
+    else if (T.solve_order == 1) hipLaunchKernelGGL(k_pose_solve_c, dim3(1), dim3(PS_THREADS), CH_LDS_DOUBLES * sizeof(double), s, T);
     else hipLaunchKernelGGL(k_pose_solve, dim3(1), dim3(PS_THREADS), lds_bytes, s, T);
 }
 // test entry of the chain solve: one image, one lambda (tests/test_gpu_chain_solve.py)
@@ -2572,6 +2629,40 @@ void vio_launch_chain_solve_test(const double *img, double lambda, double *x_nat
     hipLaunchKernelGGL(k_chain_solve_test, dim3(1), dim3(PS_THREADS), CH_LDS_CORE * sizeof(double), s, img, lambda, x_nat, lds_dump);
 }
 #endif
+void vio_launch_prior_simg(const DeviceTables &T, hipStream_t s) {
+    (void)hipMemsetAsync(T.prior_simg, 0, (size_t)CH_OFF_CC * sizeof(double), s);
+    (void)hipMemsetAsync(T.prior_flags, 0, CPI_FLAGS * sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_prior_simg, dim3(99), dim3(192), 0, s, T);
+    hipLaunchKernelGGL(k_prior_compact, dim3(1), dim3(PS_THREADS), 0, s, T);
+}
+int vio_chain_s_doubles() { return CH_OFF_CC; }
+int vio_chain_pre_lds_doubles() { return CPI_END; }
+int vio_chain_prior_flags() { return CPI_FLAGS; }
+// where the elements of an IMU item's 3 x 3 tiles go in the chain image: [10][63][9] (p1 | p2 << 16; p2 0xffff: no mirror; p1 CH_OFF_X: nowhere).  An element (a, b) of
+// the vertex blocks on or above the diagonal feeds entry (max, min) of the pair; inside a diagonal vertex block only a >= b is read
+// (d_hs_rest: "upper vertex blocks are computed, lower ones mirrored", problem.cc:347-355)
+void vio_chain_imu_map(uint32_t *out) {
+    for (int k = 0; k < 10; ++k)
+        for (int tau = 0; tau < 63; ++tau) {
+            int ca, cb;
+            cpi_tile(tau, ca, cb);
+            for (int u = 0; u < 3; ++u)
+                for (int v = 0; v < 3; ++v) {
+                    const int a = 3 * ca + u, b = 3 * cb + v;
+                    uint32_t m = 0xffff0000u | (uint32_t)CH_OFF_X;      // nowhere: the dummy position (the solution's place, unused by the chain workgroup)
+                    const bool use = cpi_vb(ca) < cpi_vb(cb) || a >= b;
+                    if (use) {
+                        const int I = 6 + 15 * k + (a > b ? a : b), J = 6 + 15 * k + (a > b ? b : a);
+                        int p1, p2;
+                        ch_entry_pos(I, J, p1, p2);
+                        const bool s_row = (I - 6) % 15 >= 6 || (J - 6) % 15 >= 6;       // a speed-bias variable is involved: an entry of the chain's blocks
+                        if (s_row && p1 >= 0 && p1 < CH_OFF_CC) m = (uint32_t)p1 | ((p2 >= 0 ? (uint32_t)p2 : 0xffffu) << 16);
+                    }
+                    out[(k * 63 + tau) * 9 + 3 * u + v] = m;
+                }
+        }
+}
+void vio_launch_chain_pre(const DeviceTables &T, hipStream_t s) { hipLaunchKernelGGL(k_chain_pre, dim3(1), dim3(PS_THREADS), CH_LDS_CORE * sizeof(double), s, T); }
 int vio_chain_image_doubles() { return CH_PACKED; }
 int vio_chain_y_offset() { return CH_OFF_Y; }
 int vio_chain_lds_core_doubles() { return CH_LDS_CORE; }
@@ -2617,6 +2708,8 @@ int vio_set_kernel_attributes() {
     if (hipFuncSetAttribute((const void *)k_pose_solve_b, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_pose_solve_c, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_pose_solve_cb, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_pose_solve_cs, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_chain_pre, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
 #ifdef VIO_DEBUG_ENTRY_POINTS
     if (hipFuncSetAttribute((const void *)k_chain_solve_test, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
 #endif

@@ -34,10 +34,10 @@
 #define CH_SCSZ (16 * CH_TS)
 #define CH_S9SZ (9 * CH_TS)
 #define CH_OFF_SC 0
-#define CH_OFF_SO (CH_OFF_SC + CH_NS * 5 * CH_SCSZ)        // 8800
-#define CH_OFF_SD (CH_OFF_SO + 10 * CH_S9SZ)                // 9700
-#define CH_OFF_CC (CH_OFF_SD + CH_NS * CH_S9SZ)             // 10690
-#define CH_OFF_Y (CH_OFF_CC + 15 * PS_TS)                   // 14770
+#define CH_OFF_SO (CH_OFF_SC + CH_NS * 5 * CH_SCSZ)        // 9680
+#define CH_OFF_SD (CH_OFF_SO + 10 * CH_S9SZ)                // 10670
+#define CH_OFF_CC (CH_OFF_SD + CH_NS * CH_S9SZ)             // 11759
+#define CH_OFF_Y (CH_OFF_CC + 15 * PS_TS)                   // 15839
 #define CH_YC 176                                           // dimension index of camera variable 0
 #define CH_NDIM 256
 #define CH_PACKED ((CH_OFF_Y + CH_NDIM + 1) & ~1)             // what travels through HBM (an even count: copied as double2)
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(ASMC_THREADS) void k_assemble_cb(BatchArgs a) { con
 #define CH_OFF_B (CH_OFF_R + 112)                   // 176 trial b_prior
 #define CH_OFF_STATE (CH_OFF_B + 176)               // 184
 #define CH_LDS_DOUBLES (CH_OFF_STATE + 184)         // 17448
+template <bool SPLIT>
 __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     double *P = dyn_smem;
     double *sX = P + CH_OFF_X, *sDx = P + CH_OFF_DX, *sR = P + CH_OFF_R, *sB = P + CH_OFF_B, *sState = P + CH_OFF_STATE;
@@ -342,12 +343,26 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
 #define CH_OUT(slot) do { } while (0)
 #endif
     // the image k_assemble_c wrote (vio_solve's loop: the set of the trial state first; a rejected step solves the other set again)
+    // SPLIT (the GN loop, gn_flags bit 4): the speed-bias chain of this system was eliminated under the linearisation (d_chain_pre_item, a
+    // workgroup of k_linearize's grid: it depends on the IMU factors, the prior and lambda only); what it left — L_SC, L_SO, M_e, the pivots,
+    // w_e and the tile mask, at their LDS offsets in T.cfi — comes in with the camera block and the camera right-hand side of the image
     int set = lm_loop ? (lm->sys ^ lm->pending) : 0;
+    const double *cfi = SPLIT ? T.cfi : nullptr;
+    double xs0 = 0.0, xs1 = 0.0, xd = 0.0, xy = 0.0, xe = 0.0;
+    if (SPLIT) {
+        xs0 = cfi[CH_OFF_SM + tid];
+        if (tid < CH_NS * CH_S9SZ - PS_THREADS) xs1 = cfi[CH_OFF_SM + PS_THREADS + tid];
+        if (tid < CH_YC) { xd = cfi[CH_OFF_D + tid]; xy = cfi[CH_OFF_Y + tid]; }
+        if (tid < 2) xe = cfi[CH_OFF_NZ + tid];
+    }
     for (int pass = 0; pass < 2; ++pass) {
         const double2 *src = reinterpret_cast<const double2 *>(T.Pg + set * CH_SET_STRIDE);
+        const double2 *csrc = reinterpret_cast<const double2 *>(cfi);
         double2 *dst = reinterpret_cast<double2 *>(P);
         static_assert((CH_PACKED / 2 + PS_THREADS - 1) / PS_THREADS == 8, "copy below is written for 8 rounds");
-#define CH_LD(q) const double2 v##q = src[min(tid + q * PS_THREADS, CH_PACKED / 2 - 1)];
+        static_assert(CH_OFF_SD % 2 == 0, "the range that comes from cfi is whole double2s");
+#define CH_FROM_CFI(i2) (SPLIT && (i2) < CH_OFF_SD / 2)
+#define CH_LD(q) const double2 v##q = (CH_FROM_CFI(tid + q * PS_THREADS) ? csrc : src)[min(tid + q * PS_THREADS, CH_PACKED / 2 - 1)];
 #define CH_ST(q) dst[min(tid + q * PS_THREADS, CH_PACKED / 2 - 1)] = v##q;
         CH_LD(0) CH_LD(1) CH_LD(2) CH_LD(3) CH_LD(4) CH_LD(5) CH_LD(6) CH_LD(7)
         if (pass == 0) {
@@ -432,22 +447,30 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         }
 #undef CH_LD
 #undef CH_ST
+#undef CH_FROM_CFI
     }
     const int trial = cur ^ 1;
     // lambda on the 171 pivots (problem.cc:434-436); the 8 padding variables of the last camera tile are identity rows
     if (tid < n) {
         const int d = ch_dim(tid);
         if (d >= CH_YC) P[ch_cc_elem(d - CH_YC, d - CH_YC)] += lambda;
-        else P[ch_sd(d >> 4) + (d & 15) * (CH_TS + 1)] += lambda;
+        else if (!SPLIT) P[ch_sd(d >> 4) + (d & 15) * (CH_TS + 1)] += lambda;       // (SPLIT: the chain's pivots carry it already)
     } else if (tid < n + 8) {
         P[ch_cc_elem(72 + tid - n, 72 + tid - n)] = 1.0;
     } else if (tid >= 256 && tid < 256 + CH_S9SZ + PS_TS) {
         const int i = tid - 256;
         P[CH_OFF_I9 + i] = (i < CH_S9SZ) ? ((i / CH_TS == i % CH_TS) ? 1.0 : 0.0) : (((i - CH_S9SZ) / PS_TROW == (i - CH_S9SZ) % PS_TROW) ? 1.0 : 0.0);
     } else if (tid >= 640 && tid < 640 + CH_NDIM) {
-        P[CH_OFF_D + tid - 640] = 1.0;                  // pivots of padding dimensions
+        if (!SPLIT || tid - 640 >= CH_YC) P[CH_OFF_D + tid - 640] = 1.0;           // pivots of padding dimensions
     }
-    for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) P[CH_OFF_SM + i] = 0.0;      // (the padding column of every M_e must read as zero)
+    if (SPLIT) {
+        P[CH_OFF_SM + tid] = xs0;
+        if (tid < CH_NS * CH_S9SZ - PS_THREADS) P[CH_OFF_SM + PS_THREADS + tid] = xs1;
+        if (tid < CH_YC) { P[CH_OFF_D + tid] = xd; P[CH_OFF_Y + tid] = xy; }      // (the image's own speed-bias rows came in with the copy: replaced by w_e)
+        if (tid < 2) P[CH_OFF_NZ + tid] = xe;
+    } else {
+        for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) P[CH_OFF_SM + i] = 0.0;      // (the padding column of every M_e must read as zero)
+    }
     __syncthreads();
     CH_OUT(0);
     // The camera part of the step (poses, extrinsic) is known two phases before the speed-bias part: wave 13 forms the trial poses
@@ -479,7 +502,18 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         if (prior_here || lm_dim == 3) return;
         d_pair_rows(pw, pairtab_trial, pw + 96, ln + 64 * idx, 14 * 64);
     };
-    ch_factor_solve(P, tid, mid1, mid2, T.dbg);
+    if (SPLIT) {
+        unsigned long long t0__ = 0ull;
+#ifdef VIO_STAMPS
+        t0__ = __builtin_amdgcn_s_memtime();
+        if (tid == 0) { g_ch_dbg = T.dbg; g_ch_t0 = t0__; }
+#endif
+        const unsigned lo = (unsigned)P[CH_OFF_NZ], hi = (unsigned)P[CH_OFF_NZ + 1];
+        const unsigned long long eff = ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(lo);
+        ch_camera_solve<true>(P, tid, ch_lane(lane), eff, mid1, mid2, T.dbg, t0__);
+    } else {
+        ch_factor_solve(P, tid, mid1, mid2, T.dbg);
+    }
     CH_OUT(2);
     for (int i = tid; i < n; i += PS_THREADS) sDx[i] = sX[ch_dim(i)];
     if (tid < 192 && T.sp_part) {
@@ -564,8 +598,450 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     if (tid >= 384 && tid < 384 + STATE_STRIDE) T.state[trial * STATE_STRIDE + (tid - 384)] = sState[tid - 384];
     CH_OUT(3);
 }
-__global__ __launch_bounds__(PS_THREADS) void k_pose_solve_c(DeviceTables T) { d_pose_solve_chain_body(T); }
-__global__ __launch_bounds__(PS_THREADS) void k_pose_solve_cb(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_pose_solve_chain_body(T); }
+__global__ __launch_bounds__(PS_THREADS) void k_pose_solve_c(DeviceTables T) { d_pose_solve_chain_body<false>(T); }
+__global__ __launch_bounds__(PS_THREADS) void k_pose_solve_cb(BatchArgs a) { const DeviceTables T = d_batch_tables(a); d_pose_solve_chain_body<false>(T); }
+// the GN loop's form: the camera block and the back-substitution behind a chain that d_chain_pre_item eliminated under the linearisation
+__global__ __launch_bounds__(PS_THREADS) void k_pose_solve_cs(DeviceTables T) { d_pose_solve_chain_body<true>(T); }
+
+// ---------------------------------------------------------------------------------------------------------
+// The pre-elimination of the speed-bias chain (the GN loop, fixed lambda).  The chain's blocks — SD, SO, SC and the speed-bias rows of
+// the right-hand side — hold IMU and prior terms only (the landmark Schur complement reaches the camera block alone, problem.cc:427-429),
+// so with lambda known their elimination does not wait for the linearisation of the window's 80 000 observations: it runs beside it, on a
+// CU of its own, and k_pose_solve_cs starts at the camera block.  ch_chain_pre_store: what the elimination leaves, at its LDS offsets.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ch_chain_pre_store(const double *P, int tid, unsigned long long eff, double *cfi) {
+    {   // L_SC, L_SO: 5335 double2, every LDS read in flight before the first store
+        const double2 *s2 = reinterpret_cast<const double2 *>(P);
+        double2 *d2 = reinterpret_cast<double2 *>(cfi);
+        constexpr int N2 = CH_OFF_SD / 2;
+        static_assert(5 * PS_THREADS < N2 && N2 <= 6 * PS_THREADS, "six rounds");
+        const double2 v0 = s2[tid], v1 = s2[tid + PS_THREADS], v2 = s2[tid + 2 * PS_THREADS], v3 = s2[tid + 3 * PS_THREADS], v4 = s2[tid + 4 * PS_THREADS];
+        const int i5 = tid + 5 * PS_THREADS;
+        double2 v5 = make_double2(0.0, 0.0);
+        if (i5 < N2) v5 = s2[i5];
+        d2[tid] = v0; d2[tid + PS_THREADS] = v1; d2[tid + 2 * PS_THREADS] = v2; d2[tid + 3 * PS_THREADS] = v3; d2[tid + 4 * PS_THREADS] = v4;
+        if (i5 < N2) d2[i5] = v5;
+    }
+    for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) cfi[CH_OFF_SM + i] = P[CH_OFF_SM + i];               // M_e
+    if (tid < CH_YC) { cfi[CH_OFF_D + tid] = P[CH_OFF_D + tid]; cfi[CH_OFF_Y + tid] = P[CH_OFF_Y + tid]; }      // pivots, w_e
+    if (tid == 0) { cfi[CH_OFF_NZ] = (double)(unsigned)(eff & 0xffffffffull); cfi[CH_OFF_NZ + 1] = (double)(unsigned)(eff >> 32); }
+}
+// the chain image's constants around the S part (identity for F's second half-row, pivots of the padding dimensions, zero M tiles)
+__device__ __forceinline__ void ch_chain_pre_init(double *P, int tid) {
+    if (tid >= 256 && tid < 256 + CH_S9SZ) { const int i = tid - 256; P[CH_OFF_I9 + i] = (i / CH_TS == i % CH_TS) ? 1.0 : 0.0; }
+    else if (tid >= 640 && tid < 640 + CH_YC) P[CH_OFF_D + tid - 640] = 1.0;
+    for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) P[CH_OFF_SM + i] = 0.0;
+}
+// ---- the chain workgroup of k_linearize's grid (GN loop, gn_flags bit 4; blockIdx 0) ------------------------------------------------
+// It forms the ten IMU items itself (nobody to wait for: the IMU workgroups that follow the items in the other paths are not launched),
+// writes them to imu_out for k_reduce_c, assembles the chain's blocks from them and the prior, eliminates the chain, stores the factors.
+// Same arithmetic as d_imu_item + d_hs_rest / d_rhs_rest + the chain phase of k_pose_solve_c, operation for operation:
+//   * Jacobian blocks / residual: the same device functions, one WAVE per block kind (a uniform branch; d_imu_item runs the sixteen
+//     branches one after the other in one wave), lane = IMU edge; what all blocks share (d_imu_common, R_i^T) is formed once, by wave 15
+//     under the staging;
+//   * J^T Info J: the dense sums of d_imu_item are chains of FMAs over the 15 residual rows in ascending order; J is 18 non-zero 3 x 3 blocks
+//     of 50, and a term with an exactly zero factor leaves the sum as it is, so the chains run over the non-zero row blocks only (3 x 3
+//     register tiles, a wave per column group so that the row blocks are the same for all its lanes; only the vertex blocks on and above
+//     the diagonal, the ones Problem::MakeHessian computes, problem.cc:337-355);
+//   * an entry of the image is 0 + T_(f-1) + T_f + prior (d_hs_rest's order; the two IMU terms commute): the items of even edges are
+//     stored, those of odd edges added, then the prior's image (k_prior_simg: the masked H_prior entries at their places) is added.
+#define CPI_PRE 0                               // staged pre-integrations [10][PRE_STRIDE]   (the image's place, free until the scatter)
+#define CPI_J (CPI_PRE + 10 * PRE_STRIDE)       // J [10][15 x 30]
+#define CPI_ST (CPI_J + 10 * 450)               // states (184)
+#define CPI_CM (CPI_ST + 184)                   // per edge 40: ImuCommon (27) | R_i^T (9, at 28)
+#define CPI_JTI(k) ((k) < 9 ? CH_OFF_CC + 450 * (k) : CH_LDS_CORE)       // J^T Info [30 x 15] of edge k (the camera tiles' place; edge 9 behind the core)
+#define CPI_VEC (CH_LDS_CORE + 450)             // per edge 64: r (15) | Info r (15, at 16) | g (30, at 32)
+#define CPI_BP (CPI_VEC + 640)                  // b_prior of the linearisation state (176)
+#define CPI_PN (CPI_BP + 176)                   // the prior's list sizes (2 ints)
+#define CPI_END (CPI_PN + 2)
+#define CPI_NTILES (55 + 10 + 11)               // SC, SO, SD tiles of the chain image
+#define CPI_FLAGS (CPI_NTILES + 99)             // prior_flags: tiles, then speed-bias rows
+static_assert(CPI_CM + 400 <= CH_OFF_CC && CH_OFF_CC + 9 * 450 <= CH_OFF_Y, "staging fits the image's place");
+static_assert(sizeof(ImuCommon) == 27 * 8, "ImuCommon is staged as 27 doubles");
+__host__ __device__ inline int cpi_vb(int cg) { return cg < 2 ? 0 : (cg < 5 ? 1 : (cg < 7 ? 2 : 3)); }           // vertex of a column group of 3
+__host__ __device__ inline void cpi_tile(int tau, int &ca, int &cb) {      // the 63 tiles (ca, cb) with vertex(ca) <= vertex(cb), row-major
+    if (tau < 20) { ca = tau / 10; cb = tau % 10; }
+    else if (tau < 44) { const int q = tau - 20; ca = 2 + q / 8; cb = 2 + q % 8; }
+    else if (tau < 54) { const int q = tau - 44; ca = 5 + q / 5; cb = 5 + q % 5; }
+    else { const int q = tau - 54; ca = 7 + q / 3; cb = 7 + q % 3; }
+}
+__device__ __forceinline__ int cpi_tau(int ca, int cb) { return ca < 2 ? ca * 10 + cb : (ca < 5 ? 20 + (ca - 2) * 8 + (cb - 2) : (ca < 7 ? 44 + (ca - 5) * 5 + (cb - 5) : 54 + (ca - 7) * 3 + (cb - 7))); }
+// which of the five residual row blocks (P, R, V, BA, BG) of J are non-zero in column group cg (edge_imu.cc:74-153)
+// (bit rb; column groups: pose_i P, R | speed-bias_i v, ba, bg | pose_j P, R | speed-bias_j v, ba, bg)
+__device__ __forceinline__ unsigned cpi_rows(int cg) {
+    return cg == 0 ? 0x01u : cg == 1 ? 0x07u : cg == 2 ? 0x05u : cg == 3 ? 0x0du : cg == 4 ? 0x17u : cg == 5 ? 0x01u : cg == 6 ? 0x02u : cg == 7 ? 0x04u : cg == 8 ? 0x08u : 0x10u;
+}
+// tile index of an image position p < CH_OFF_CC: SC tiles 0..54, SO 55..64, SD 65..75
+__host__ __device__ inline int cpi_tile_of(int p) { return p < CH_OFF_SO ? p / CH_SCSZ : (p < CH_OFF_SD ? 55 + (p - CH_OFF_SO) / CH_S9SZ : 65 + (p - CH_OFF_SD) / CH_S9SZ); }
+__host__ __device__ inline int cpi_tile_base(int t) { return t < 55 ? t * CH_SCSZ : (t < 65 ? CH_OFF_SO + (t - 55) * CH_S9SZ : CH_OFF_SD + (t - 65) * CH_S9SZ); }
+__host__ __device__ inline int cpi_tile_size(int t) { return t < 55 ? CH_SCSZ : CH_S9SZ; }
+
+__device__ __forceinline__ void d_chain_pre_item(const DeviceTables &T) {
+    double *P = dyn_smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cur = d_cur(T);
+    const int valid = d_imu_mask(T);
+    const bool owe_prior = d_step_owed(T, 2) && T.has_prior;
+    const double lambda = T.lm->lambda;
+#ifdef VIO_STAMPS
+    // diagnostic build: phase stamps of this workgroup behind the items' and IMU workgroups' slots (tools/diag_chain_pre_stamps.py)
+    unsigned long long *cdbg = T.dbg ? T.dbg + 16 * (size_t)(T.n_items + 11) : nullptr;
+    const unsigned long long cp_t0 = __builtin_amdgcn_s_memtime();
+#define CP_STAMP(i) do { if (tid == 0 && cdbg) cdbg[i] = __builtin_amdgcn_s_memtime() - cp_t0; } while (0)
+#else
+    unsigned long long *cdbg = nullptr;
+    const unsigned long long cp_t0 = 0ull;
+#define CP_STAMP(i) do { } while (0)
+#endif
+    // ---- stage: pre-integrations, states; constants of the image; what the Jacobian blocks share; b_prior of this state ----
+    {
+        double pv[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int i = tid + q * PS_THREADS; pv[q] = i < 10 * PRE_STRIDE ? T.pre[i] : 0.0; }
+        const double sv = tid < STATE_STRIDE ? T.state[cur * STATE_STRIDE + tid] : 0.0;
+        // the prior's lists (k_prior_compact): n entries of the chain's blocks, m speed-bias rows of H_prior that hold anything
+        int pn = 0, pm = 0, prow = -1;
+        double bpv = 0.0;
+        bool bp_skip = false;
+        if (T.has_prior) {
+            pn = T.prior_list[0]; pm = T.prior_list[1];
+            // thread 128 + r: b_prior of speed-bias row r as it stands (replaced below by b_prior - H_prior dx where that is owed and the row
+            // of H_prior holds anything)
+            if (tid >= 128 && tid < 128 + 99) {
+                const int r = tid - 128;
+                bpv = T.bprior[(owe_prior ? cur ^ 1 : cur) * 176 + 12 + 15 * (r / 9) + r % 9];
+                bp_skip = owe_prior && T.prior_flags[CPI_NTILES + r] != 0;        // (a listed row: its dot product is the value)
+            }
+            if (owe_prior && wave < 15) prow = T.prior_list[2 + min(wave, 98)];         // (wave w: listed rows w, w + 15, ...: the first one now)
+        }
+        if (wave == 15 && lane < 10 && ((valid >> lane) & 1)) {
+            // (from global memory: the staged copies are not there yet; the same values)
+            const int k = lane;
+            const double *pre = T.pre + k * PRE_STRIDE, *st = T.state + cur * STATE_STRIDE;
+            ImuCommon c;
+            double RiT[9];
+            d_imu_common(pre, st + STATE_POSE + 7 * k, st + STATE_SB + 9 * k, st + STATE_POSE + 7 * k + 7, c);
+            d_imu_rit(c, RiT);
+            double *cm = P + CPI_CM + 40 * k;
+            const double *cc = reinterpret_cast<const double *>(&c);
+#pragma unroll
+            for (int q = 0; q < 27; ++q) cm[q] = cc[q];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) cm[28 + q] = RiT[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int i = tid + q * PS_THREADS; if (i < 10 * PRE_STRIDE) P[CPI_PRE + i] = pv[q]; }
+        if (tid < STATE_STRIDE) P[CPI_ST + tid] = sv;
+        double2 *zj = reinterpret_cast<double2 *>(P + CPI_J);
+        static_assert(CPI_J % 2 == 0, "J is zeroed as double2");
+        for (int i = tid; i < 10 * 450 / 2; i += PS_THREADS) zj[i] = make_double2(0.0, 0.0);
+        if (tid < CH_YC) P[CH_OFF_Y + tid] = 0.0;
+        ch_chain_pre_init(P, tid);
+        if (T.has_prior && tid >= 128 && tid < 128 + 99 && !bp_skip) { const int r = tid - 128; P[CPI_BP + 12 + 15 * (r / 9) + r % 9] = bpv; }
+        // b_prior - H_prior dx of the listed rows (d_bprior_dot: the sums the item workgroups that own those rows form in this launch)
+        if (owe_prior && wave < 15 && wave < pm) {
+            const bool in2 = lane + 128 < VIO_PD;
+            const double x0 = T.dx[lane], x1 = T.dx[lane + 64], x2 = in2 ? T.dx[lane + 128] : 0.0;
+            for (int q = wave; q < pm; q += 15) {
+                const int r = q == wave ? prow : T.prior_list[2 + q];
+                const int i = 12 + 15 * (r / 9) + r % 9;
+                const double *hr = T.Hprior + (size_t)i * VIO_PD;
+                const double v = d_bprior_dot(hr[lane], hr[lane + 64], in2 ? hr[lane + 128] : 0.0, x0, x1, x2, T.bprior[(cur ^ 1) * 176 + i]);
+                if (lane == 63) P[CPI_BP + i] = v;
+            }
+        }
+        if (tid == 0) { reinterpret_cast<int *>(P + CPI_PN)[0] = pn; reinterpret_cast<int *>(P + CPI_PN)[1] = pm; }
+    }
+    CP_STAMP(0);
+    __syncthreads();
+    CP_STAMP(1);
+    // ---- I1: the Jacobian blocks and the residual; wave = block kind, lane = edge ----
+    // (waves w, w + 4, w + 8, w + 12 share a SIMD: the residual (14) and the three blocks with quaternion products (2, 7, 12) go to four different ones)
+    const int task = __builtin_amdgcn_readfirstlane((int)((0xfa85d964b310c72eull >> (4 * wave)) & 15ull));
+    if (lane < 10 && ((valid >> lane) & 1)) {
+        const int k = lane;
+        const double *pre = P + CPI_PRE + k * PRE_STRIDE, *st = P + CPI_ST;
+        const double *pi = st + STATE_POSE + 7 * k, *pj = pi + 7, *si = st + STATE_SB + 9 * k, *sj = si + 9;
+        double *sJ = P + CPI_J + 450 * k, *sr = P + CPI_VEC + 64 * k;
+        const double *cm = P + CPI_CM + 40 * k;
+        if (task < 15) {
+            // (what the blocks share stays in LDS and is read where it is used: a copy in registers — 27 + 9 doubles — beside a block's own
+            // temporaries is what spilled in d_imu_item's sixteen-branch wave)
+            const ImuCommon &c = *reinterpret_cast<const ImuCommon *>(cm);
+            if (task < 14) {
+                d_imu_jac_block(task, pre, T.gravity, pi, si, pj, sj, c, cm + 28, sJ);
+            } else {
+                double r[15];
+                d_imu_residual(pre, T.gravity, pi, si, pj, sj, c, r);
+                for (int i = 0; i < 15; ++i) sr[i] = r[i];
+            }
+        } else {
+            for (int i = 0; i < 3; ++i) {       // identity blocks (edge_imu.cc:116-118,146-148)
+                sJ[30 * (O_BA + i) + 6 + 3 + i] = -1.0; sJ[30 * (O_BG + i) + 6 + 6 + i] = -1.0;
+                sJ[30 * (O_BA + i) + 21 + 3 + i] = 1.0; sJ[30 * (O_BG + i) + 21 + 6 + i] = 1.0;
+            }
+        }
+    }
+    CP_STAMP(2);
+#ifdef VIO_STAMPS
+    if (lane == 0 && cdbg) cdbg[32 + wave] = __builtin_amdgcn_s_memtime() - cp_t0;
+#endif
+    __syncthreads();
+    CP_STAMP(3);
+    // ---- I2: J^T Info (3 x 3 tiles; wave = column group of J, lanes = edge x 5 column groups of Info) and Info r ----
+    if (wave < 10) {
+        const int ca = wave, k = lane / 5, j0 = 3 * (lane % 5);
+        if (lane < 50 && ((valid >> k) & 1)) {
+            const double *sJ = P + CPI_J + 450 * k + 3 * ca, *sI = P + CPI_PRE + k * PRE_STRIDE + PRE_INFO + j0;
+            double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+            const unsigned rows = cpi_rows(ca);
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) {
+                if (!((rows >> rb) & 1)) continue;          // (wave-uniform)
+                double ja[3][3], ib[3][3];
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) { ja[ii][u] = sJ[30 * (3 * rb + ii) + u]; ib[ii][u] = sI[15 * (3 * rb + ii) + u]; }
+#pragma unroll
+                for (int ii = 0; ii < 3; ++ii)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) acc[u][v] = fma(ja[ii][u], ib[ii][v], acc[u][v]);
+            }
+            double *o = P + CPI_JTI(k) + 15 * 3 * ca + j0;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) o[15 * u + v] = acc[u][v];
+        }
+    } else if (wave < 13) {
+        const int t = (wave - 10) * 64 + lane;
+        const int k = t / 15, i = t % 15;
+        if (t < 150 && ((valid >> k) & 1)) {
+            const double *sI = P + CPI_PRE + k * PRE_STRIDE + PRE_INFO, *sr = P + CPI_VEC + 64 * k;
+            double sum = 0;
+            for (int j = 0; j < 15; ++j) sum = fma(sI[15 * i + j], sr[j], sum);
+            P[CPI_VEC + 64 * k + 16 + i] = sum;
+        }
+    }
+    CP_STAMP(4);
+    __syncthreads();
+    CP_STAMP(5);
+    // ---- I3: T = (J^T Info) J in 3 x 3 register tiles (kept for the scatter, written to imu_out now); g = J^T Info r; chi = r^T Info r.
+    //      Waves 0..14: one column group cb of J each (two waves for the groups with more than 64 tiles over the ten edges) ----
+    double tv[9];
+    unsigned tmap[9];
+    int t_edge = -1;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { tv[q] = 0.0; tmap[q] = 0xffff0000u | (unsigned)CH_OFF_X; }
+    if (wave < 15) {
+        // wave -> (cb, first task, tasks): cb 0..4 one wave each, cb 5..9 two
+        const int cb = wave < 5 ? wave : 5 + (wave - 5) / 2;
+        const int nca = cb < 2 ? 2 : (cb < 5 ? 5 : (cb < 7 ? 7 : 10));          // tiles (ca, cb) with vertex(ca) <= vertex(cb)
+        const int ntask = 10 * nca, half = (ntask + 1) / 2;
+        const int q0 = wave < 5 ? 0 : ((wave - 5) & 1) * half, q1 = wave < 5 ? ntask : (((wave - 5) & 1) ? ntask : half);
+        const int q = q0 + lane;
+        const int k = q / nca, ca = q % nca;
+        if (q < q1 && ((valid >> k) & 1)) {
+            t_edge = k;
+            const int tau = cpi_tau(ca, cb);
+#pragma unroll
+            for (int e = 0; e < 9; ++e) tmap[e] = T.imu_map[(k * 63 + tau) * 9 + e];
+            const double *sA = P + CPI_JTI(k) + 15 * 3 * ca, *sJ = P + CPI_J + 450 * k + 3 * cb;
+            double acc[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+            const unsigned rows = cpi_rows(cb);
+#pragma unroll
+            for (int rb = 0; rb < 5; ++rb) {
+                if (!((rows >> rb) & 1)) continue;          // (wave-uniform)
+                double aa[3][3], jb[3][3];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) { aa[jj][u] = sA[15 * u + 3 * rb + jj]; jb[jj][u] = sJ[30 * (3 * rb + jj) + u]; }
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+                    for (int u = 0; u < 3; ++u)
+#pragma unroll
+                        for (int v = 0; v < 3; ++v) acc[u][v] = fma(aa[jj][u], jb[jj][v], acc[u][v]);
+            }
+            double *out = T.imu_out + k * IMU_OUT + IMU_T + 30 * 3 * ca + 3 * cb;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int v = 0; v < 3; ++v) { tv[3 * u + v] = acc[u][v]; out[30 * u + v] = acc[u][v]; }
+        }
+    }
+    // g = J^T (Info r): 300 entries, twenty per wave of the fifteen above; chi = r^T Info r on wave 15
+    if (wave < 15 && lane < 20) {
+        const int t = wave * 20 + lane;
+        const int k = t / 30, a = t % 30;
+        if ((valid >> k) & 1) {
+            const double *sJ = P + CPI_J + 450 * k + a, *sIr = P + CPI_VEC + 64 * k + 16;
+            double ja[15], ir[15];
+#pragma unroll
+            for (int i = 0; i < 15; ++i) { ja[i] = sJ[30 * i]; ir[i] = sIr[i]; }
+            double sum = 0;
+#pragma unroll
+            for (int i = 0; i < 15; ++i) sum = fma(ja[i], ir[i], sum);
+            P[CPI_VEC + 64 * k + 32 + a] = sum;
+            T.imu_out[k * IMU_OUT + IMU_G + a] = sum;
+        }
+    } else if (wave == 15 && lane < 10) {
+        const int k = lane;
+        if ((valid >> k) & 1) {
+            const double *sr = P + CPI_VEC + 64 * k, *sIr = sr + 16;
+            double sum = 0;
+            for (int i = 0; i < 15; ++i) sum = fma(sr[i], sIr[i], sum);
+            T.imu_out[k * IMU_OUT + IMU_CHI] = sum;
+        }
+    }
+    // the prior's entries (the list of k_prior_compact): requested now, added behind the items
+    double pr[2] = {0.0, 0.0};
+    int pr_pos[2] = {-1, -1};
+    const int pn = T.has_prior ? reinterpret_cast<const int *>(P + CPI_PN)[0] : 0;
+    if (pn <= 2 * PS_THREADS) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) if (tid + h * PS_THREADS < pn) { pr_pos[h] = T.prior_list[128 + tid + h * PS_THREADS]; pr[h] = T.prior_cval[tid + h * PS_THREADS]; }
+    }
+    CP_STAMP(6);
+#ifdef VIO_STAMPS
+    if (lane == 0 && cdbg) cdbg[48 + wave] = __builtin_amdgcn_s_memtime() - cp_t0;
+#endif
+    __syncthreads();
+    CP_STAMP(7);
+    // ---- the image: zero, items of the even edges, items of the odd edges, prior, right-hand side, lambda ----
+    {
+        double2 *z = reinterpret_cast<double2 *>(P);
+        for (int i = tid; i < (CH_OFF_CC + 1) / 2; i += PS_THREADS) z[i] = make_double2(0.0, 0.0);      // (one double into the camera tiles' place: dead)
+    }
+    __syncthreads();
+    CP_STAMP(8);
+    // (an element without a place in the chain's blocks carries the dummy position CH_OFF_X in its low half; mirrors — the entries of a
+    // diagonal block of the chain — are rare: a wave without any skips them as a whole)
+    bool has_mirror = false;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) has_mirror = has_mirror || (tmap[q] >> 16) != 0xffffu;
+    has_mirror = has_mirror && t_edge >= 0;
+    const bool wave_mirror = __ballot(has_mirror) != 0ull;
+    if (t_edge >= 0 && (t_edge & 1) == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) P[tmap[q] & 0xffffu] = tv[q];            // (0 + v: the image is zero)
+        if (wave_mirror) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) if ((tmap[q] >> 16) != 0xffffu) P[tmap[q] >> 16] = tv[q];
+        }
+    }
+    CP_STAMP(14);
+    __syncthreads();
+    CP_STAMP(15);
+    if (t_edge >= 0 && (t_edge & 1) == 1) {
+        double old[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) old[q] = P[tmap[q] & 0xffffu];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) P[tmap[q] & 0xffffu] = old[q] + tv[q];
+        if (wave_mirror) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) if ((tmap[q] >> 16) != 0xffffu) P[tmap[q] >> 16] = old[q] + tv[q];
+        }
+    }
+    __syncthreads();
+    CP_STAMP(9);
+    if (T.has_prior) {
+        if (pn > 2 * PS_THREADS) { for (int i = tid; i < CH_OFF_CC; i += PS_THREADS) P[i] += T.prior_simg[i]; }     // (a prior that fills the chain's blocks)
+        else {
+            if (pr_pos[0] >= 0) P[pr_pos[0]] += pr[0];
+            if (pr_pos[1] >= 0) P[pr_pos[1]] += pr[1];
+        }
+    }
+    if (tid < 99) {
+        // row i of b for a speed-bias variable: d_rhs_rest's sum
+        const int f = tid / 9, i = 12 + 15 * f + tid % 9;
+        double extra = 0.0;
+        for (int k = f - 1; k <= f; ++k) {
+            if (k < 0 || k >= 10 || !((valid >> k) & 1)) continue;
+            const int a = i - (6 + 15 * k);
+            extra -= P[CPI_VEC + 64 * k + 32 + a];
+        }
+        if (T.has_prior) extra += P[CPI_BP + i];
+        P[CH_OFF_Y + ch_dim(i)] = extra;
+    }
+    __syncthreads();
+    CP_STAMP(10);
+    if (tid < CH_NS * 9) { const int e = tid / 9, k = tid % 9; P[ch_sd(e) + k * (CH_TS + 1)] += lambda; }
+    __syncthreads();
+    CP_STAMP(11);
+    const unsigned long long eff = ch_chain_elimination<false>(P, tid, ch_lane(lane), cdbg, cp_t0);
+    CP_STAMP(12);
+    ch_chain_pre_store(P, tid, eff, T.cfi);
+    CP_STAMP(13);
+#undef CP_STAMP
+}
+
+// H_prior's contribution to the chain's blocks at their places in the image (the entries of the 99 speed-bias rows, masked as d_hs_rest
+// masks them: problem.cc:372-381), and which tiles / rows hold a non-zero: built once per prior, used by d_chain_pre_item every iteration
+__global__ __launch_bounds__(192) void k_prior_simg(DeviceTables T) {
+    const int r = blockIdx.x, t = threadIdx.x;
+    if (r >= 99 || t >= VIO_PD) return;
+    const int i = 12 + 15 * (r / 9) + r % 9;
+    // (the whole row counts for b_prior' = b_prior - H_prior dx, which is not masked: problem.cc:473)
+    if (T.Hprior[i * VIO_PD + t] != 0.0) T.prior_flags[CPI_NTILES + r] = 1;
+    if (!(full_to_cam(t) >= 0 || t <= i)) return;
+    const int I = max(i, t), J = min(i, t);
+    const bool mask = T.ext_fixed && !T.marg_mode && (I < 6 || J < 6);
+    const double v = mask ? 0.0 : T.Hprior[I * VIO_PD + J];
+    int p1, p2;
+    ch_entry_pos(I, J, p1, p2);
+    if (p1 >= 0) { T.prior_simg[p1] = v; if (v != 0.0) T.prior_flags[cpi_tile_of(p1)] = 1; }
+    if (p2 >= 0) T.prior_simg[p2] = v;
+}
+
+// ... and the non-zero entries of that image as a list (position ascending), the speed-bias rows of H_prior that hold anything as another:
+// what d_chain_pre_item reads every iteration is a few hundred entries (Problem::Marginalize fills the rows of frame 0's speed-bias alone)
+__global__ __launch_bounds__(PS_THREADS) void k_prior_compact(DeviceTables T) {
+    __shared__ int sCnt[PS_THREADS + 1];
+    const int tid = threadIdx.x;
+    constexpr int PER = (CH_OFF_CC + PS_THREADS - 1) / PS_THREADS;
+    int c = 0;
+    for (int q = 0; q < PER; ++q) { const int p = tid * PER + q; if (p < CH_OFF_CC && T.prior_simg[p] != 0.0) ++c; }
+    sCnt[tid + 1] = c;
+    if (tid == 0) sCnt[0] = 0;
+    __syncthreads();
+    if (tid == 0) for (int i = 1; i <= PS_THREADS; ++i) sCnt[i] += sCnt[i - 1];
+    __syncthreads();
+    int o = sCnt[tid];
+    for (int q = 0; q < PER; ++q) {
+        const int p = tid * PER + q;
+        if (p < CH_OFF_CC) { const double v = T.prior_simg[p]; if (v != 0.0) { T.prior_list[128 + o] = p; T.prior_cval[o] = v; ++o; } }
+    }
+    if (tid == 0) {
+        T.prior_list[0] = sCnt[PS_THREADS];
+        int m = 0;
+        for (int r = 0; r < 99; ++r) if (T.prior_flags[CPI_NTILES + r]) T.prior_list[2 + m++] = r;
+        T.prior_list[1] = m;
+    }
+}
+
+// Stage-one form (diagnostic, VIO_GN_SPLIT=2): the chain of the image k_reduce_c wrote, in a launch of its own between k_reduce_c and
+// k_pose_solve_cs — the same arithmetic as the workgroup inside k_linearize's grid, fed from the assembled image instead of from the IMU items
+__global__ __launch_bounds__(PS_THREADS) void k_chain_pre(DeviceTables T) {
+    double *P = dyn_smem;
+    const int tid = threadIdx.x;
+    const double lambda = T.lm->lambda;
+    const double *img = T.Pg + d_set_w(T) * CH_SET_STRIDE;
+    for (int i = tid; i < CH_OFF_CC; i += PS_THREADS) P[i] = img[i];
+    if (tid < CH_YC) P[CH_OFF_Y + tid] = img[CH_OFF_Y + tid];
+    ch_chain_pre_init(P, tid);
+    __syncthreads();
+    if (tid < CH_NS * 9) { const int e = tid / 9, k = tid % 9; P[ch_sd(e) + k * (CH_TS + 1)] += lambda; }
+    __syncthreads();
+    const unsigned long long eff = ch_chain_elimination<false>(P, tid, ch_lane(tid & 63), T.dbg, 0ull);
+    ch_chain_pre_store(P, tid, eff, T.cfi);
+}
 
 #ifdef VIO_DEBUG_ENTRY_POINTS
 // Diagnostic / test entry: solve one image (CH_PACKED doubles, lambda NOT yet on its diagonal) and return x by natural index;

@@ -168,7 +168,8 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     int32_t gn_flags;            // GN mode, for the PREVIOUS step: bit 0: k_assemble runs its test (its chi2 is the one this linearisation
                                  // computed); bit 1: k_linearize applies its landmark back-substitution first; bit 2 (k_pose_solve):
                                  // this step's prior update is left to the next k_linearize (b_prior') and k_reduce (err_prior');
-                                 // bit 3 (k_backsub): flush of such a step, form b_prior' here
+                                 // bit 3 (k_backsub): flush of such a step, form b_prior' here; bit 4 (k_linearize, GN loop): the grid's first
+                                 // workgroup eliminates the speed-bias chain (and forms the IMU items: no IMU workgroups follow the items)
     int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur;
                                  // -2 (vio_solve's loop): the copy to linearise at is lm->cur ^ lm->pending, and bits 0 / 1 of gn_flags
                                  // count only while lm->pending
@@ -186,6 +187,14 @@ struct DeviceTables {            // everything a kernel needs, passed by value
     const double *step_gath;     // [n_shards][2]
     int32_t n_shards;
     int32_t solve_order;         // 0: Eigen's pivot order (k_assemble / k_pose_solve); 1: the static chain order (k_assemble_c / k_pose_solve_c, vio_pose_solve_chain.h)
+    double *cfi;                 // the GN loop's pre-eliminated speed-bias chain (vio_pose_solve_chain.h: d_chain_pre_item -> k_pose_solve_cs), laid out
+                                 // as the solve's LDS image
+    double *prior_simg;          // H_prior's entries of the speed-bias rows at their places in the chain image (k_prior_simg), CH_OFF_CC doubles
+    int32_t *prior_flags;        // [76 tiles of the chain image | 99 speed-bias rows]: H_prior has a non-zero entry there (k_prior_simg)
+    int32_t *prior_list;         // k_prior_compact: [0] n non-zero entries of prior_simg, [1] m speed-bias rows of H_prior with a non-zero, [2 .. 2 + m) those
+                                 // rows, [128 .. 128 + n) the entries' positions in the image; their values: prior_cval[0 .. n)
+    double *prior_cval;
+    const uint32_t *imu_map;     // [10][63][9] where an element of an IMU item's 3 x 3 tile goes in the chain image (p1 | p2 << 16; 0xffff: nowhere)
     LmState *lm;
     unsigned long long *dbg;     // diagnostic builds only (-DVIO_STAMPS): [block][16] s_memtime stamps
 };
