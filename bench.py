@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="windows of the batched block (vio_batch_gn_iteration); 0 skips it")
     ap.add_argument("--batch-full", type=int, default=256, help="windows of the batched block's full-device figure (one pose solve per CU); 0 skips it")
     ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame cost block (set / plan+upload / Solve(10) / marginalise)")
+    ap.add_argument("--no-small-regime", action="store_true", help="skip the per_frame_small block (N = 150 / 300 and the MH_05 real-IMU windows, four backends)")
     ap.add_argument("--cpu-baseline-steps", type=int, default=0, help="0 = sized for about 10-20 s")
     ap.add_argument("--replica-windows", type=int, default=16, help="N > 1: independent windows per GPU of the `replicas` block (0 skips it)")
     ap.add_argument("--replica-landmarks", type=int, default=20000)
@@ -396,7 +397,7 @@ def main():
             v = sorted(v)
             return {"median": round(v[len(v) // 2], 4), "min": round(v[0], 4), "max": round(v[-1], 4), "n": len(v)}
 
-        def frame_costs(lib, reps, warm=2, windows=None, pipelined=False):
+        def frame_costs(lib, reps, warm=2, windows=None, pipelined=False, ctx_kw=None):
             """`reps` timed frames after `warm` untimed ones (one per window: first touches, buffers reaching their size).
             A frame never repeats the one before (the library skips inputs it already holds).
             pipelined: MargOldFrame as vio_marginalize_begin; its dense host tail runs on the library's helper thread under the next
@@ -404,7 +405,7 @@ def main():
             wins = windows or stream_w
             chain = not xyz         # (XYZ graphs have no MargOldFrame caller: their windows keep the prior they came with)
             next_prior = wins[0].prior
-            c = lib.context(**({"device": local_rank} if lib is hip else {}))
+            c = lib.context(**dict({"device": local_rank} if lib is hip else {}, **(ctx_kw or {})))
             phases = ("set_ms", "plan_upload_linearize_ms", "solve10_ms", "marginalize_ms")
             acc = {k: [] for k in phases}
             acc["frame_ms"] = []
@@ -501,6 +502,74 @@ def main():
                                         "host_split_us_median": dense["host_split_us_median"],
                                         "marginalize_live_rows_of_156": dense["marginalize_live_rows_of_156"],
                                         "window": "a stream of windows of 2000 landmarks hosted in frame 0, each observed in frames 1..10; the first prior = the end of a chain of 11 such windows, each marginalised into the next, and every timed frame is set with the prior its predecessor returned"}
+
+    # ---- the reference's real regime: NUM_OF_F = 1000 and ~150 tracked features make N = 100 .. 300 the only sizes
+    #      Estimator can reach (VM/include/parameters.h:37).  Streams of ragged-track windows with chained priors at N = 150 and 300, and the
+    #      windows a stream on the reference's own EuRoC MH_05 IMU data produces (real inertial data, synthetic vision): one frame =
+    #      vio_set_*, first linearisation, Solve(10), MargOldFrame — through the HIP library (ctypes), through the C++ host mirror of
+    #      Estimator::backendOptimization, through the CPU port, and through the COMPILED REFERENCE's own Problem::Solve(10) + Marginalize
+    #      (oracle/_ref/libvio_ref.so, when the repo was built where /root/reference exists) on the same windows on this box's host.
+    per_frame_small = None
+    if per_frame is not None and not xyz and not args.no_small_regime:
+        import subprocess
+        per_frame_small = {"note": "host wall clock per frame, median of 20 frames (spread: min / max); the same windows for every backend; "
+                                   "reference_compiled = the reference's own backend sources compiled where they lie (oracle/Makefile), 1 thread"}
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+        orc_s = vio.VioLib(os.path.join(ROOT, "oracle", "liboracle.so"), "vioo_")
+        ref_path = os.path.join(ROOT, "oracle", "_ref", "libvio_ref.so")
+        ref_s = vio.VioLib(ref_path, "vior_") if os.path.exists(ref_path) else None
+        keys = ("set_ms", "plan_upload_linearize_ms", "solve10_ms", "marginalize_ms", "frame_ms", "spread", "solve10_iterations")
+
+        def three_ways(wins, ctx_kw=None, reps=20):
+            e = {"landmarks_median": int(np.median([w_.n_landmarks for w_ in wins])), "observations_median": int(np.median([w_.n_observations for w_ in wins]))}
+            g = frame_costs(hip, reps, windows=[w_.copy() for w_ in wins], ctx_kw=ctx_kw)
+            e["gpu_ctypes"] = {k: g[k] for k in keys}
+            gb = frame_costs(hip, reps, windows=[w_.copy() for w_ in wins], pipelined=True, ctx_kw=ctx_kw)
+            e["gpu_ctypes_tail_in_the_background"] = {k: gb[k] for k in ("frame_ms", "spread")}
+            o = frame_costs(orc_s, reps, warm=1, windows=[w_.copy() for w_ in wins], ctx_kw=ctx_kw)
+            e["cpu_port_1_thread"] = {k: o[k] for k in keys}
+            if ref_s is not None:
+                try:
+                    r_ = frame_costs(ref_s, reps, warm=1, windows=[w_.copy() for w_ in wins], ctx_kw=ctx_kw)
+                    e["reference_compiled_1_thread"] = {k: r_[k] for k in keys}
+                    e["frame_speedup_vs_reference_compiled"] = r_["frame_ms"] / g["frame_ms"]
+                except Exception as exc:
+                    e["reference_compiled_1_thread"] = {"error": str(exc)}
+            return e
+
+        for n_s in (150, 300):
+            wins = [vio.synth.make_window(n_s, seed=300 + r_, t0=1.0 + 0.1 * r_, ragged=True) for r_ in range(22)]
+            e = three_ways(wins)
+            # the C++ host mirror (host/estimator_backend.cpp over the C ABI; tests/cpp/adapter_main.cpp timed inside the C++ program)
+            try:
+                outc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_cpp_frame.py"), str(n_s), "20"], capture_output=True, text=True, timeout=300)
+                for ln in outc.stdout.splitlines():
+                    if ln.startswith("cpp_frame "):
+                        tok = ln.split()
+                        kv = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok) - 1, 2)}
+                        e.setdefault("gpu_cpp_mirror", {}).update(kv)
+                if "gpu_cpp_mirror" not in e:
+                    e["gpu_cpp_mirror"] = {"error": (outc.stderr or outc.stdout)[-300:]}
+            except Exception as exc:
+                e["gpu_cpp_mirror"] = {"error": str(exc)}
+            per_frame_small["n%d" % n_s] = e
+        # real inertial data: the windows a stream on the MH_05 stretch goes through (recorded from a run of the stream driver on the HIP library)
+        try:
+            zmh = dict(np.load(os.path.join(ROOT, "tests", "golden", "mh05_imu_stretch.npz")))
+            st_mh = vio.stream.RealImuStream(zmh, landmarks_per_frame=30, seed=7)
+            drv = vio.stream.StreamDriver(hip, st_mh, seed=2, ctx_kwargs={"device": local_rank})
+            rec = []
+            while True:
+                drv.ensure_depths()
+                rec.append(drv.window_arrays()[0])
+                if not drv.step():
+                    break
+            for w_ in rec:
+                w_.prior = None         # (every backend chains its own priors from frame to frame, as in the synthetic streams)
+            per_frame_small["mh05_real_imu"] = three_ways(rec, ctx_kw={"gravity": (0.0, 0.0, st_mh.g_norm)}, reps=min(20, len(rec) - 2))
+            per_frame_small["mh05_real_imu"]["frames_recorded"] = len(rec)
+        except Exception as exc:
+            per_frame_small["mh05_real_imu"] = {"error": str(exc)}
 
     # ---- B independent windows per launch (vio_batch_gn_iteration): the regime in which the device is full.  Same window
     #      size as the headline, different seeds; reported beside the single-window line, never instead of it
@@ -757,6 +826,7 @@ def main():
             "cpu_baseline": cpu_baseline,
             "replicas": replicas,
             "per_frame": per_frame,
+            "per_frame_small": per_frame_small,
             "batched": batched,
             "cpu_baseline_all_cores": cpu_baseline_all_cores,
             "cpu_reference": cpu_reference,

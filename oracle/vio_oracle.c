@@ -1921,6 +1921,29 @@ vio_status vio_marginalize(struct vioo_ctx *c, int32_t kind, double *Hout, doubl
     return VIO_OK;
 }
 
+/* Test infrastructure for the product's host code (tests/test_host_units.py): the dense 171 x 171 system Problem::Marginalize holds after
+ * the landmark Schur complement and the old prior (problem.cc:685-715) and BEFORE the marginalised frame moves to the bottom — what the
+ * HIP library's device half hands to its host tail (csrc/host_dense.cpp: marginalize_tail). */
+vio_status vioo_marg_dense_input(struct vioo_ctx *c, int32_t kind, double *H171, double *b171) {
+    if (!c || !H171 || !b171 || c->M_mapped != -1) return VIO_ERR_BAD_ARG;
+    const int n = PD;
+    memset(H171, 0, sizeof(double) * n * n);
+    memset(b171, 0, sizeof(double) * n);
+    if (kind == VIO_MARG_OLD) {
+        linearize_visual(c, 1);
+        for (int a = 0; a < CD; ++a) {
+            int fa = cam_to_full(a);
+            for (int b2 = 0; b2 < CD; ++b2) H171[fa * n + cam_to_full(b2)] = c->vis[VIS_H + a * CD + b2];
+            b171[fa] = c->vis[VIS_BRED + a];
+        }
+        add_imu_terms(c, 1, H171, b171, NULL, NULL);
+        c->linearized = 0;
+    }
+    for (int i = 0; i < n * n; ++i) H171[i] += c->Hprior[i];
+    for (int i = 0; i < n; ++i) b171[i] += c->bprior[i];
+    return VIO_OK;
+}
+
 /* the two halves of include/vio_backend.h (here: begin computes, end copies; nothing runs in the background) */
 vio_status vio_marginalize_begin(struct vioo_ctx *c, int32_t kind) {
     if (c && c->M_mapped != -1) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }

@@ -1,0 +1,103 @@
+// The planner's operations of the host-units driver (host_units_main.cpp): csrc/vio_plan.cpp, compiled with g++ alone.
+//   op 10 scan_observations      in: int64 N, m; lm[m] host[m] target[m] (int32), pi[2m]; int32 have_prev, [2N prev pts_i_lm]
+//                                out: int32 bad, int64 bad_index, int32 lm_major, consistent, changed; 2N pts_i_lm
+//   op 11 plan_invdepth          in: int32 marg, use_ext, throughput, n_cus, g_max, half; int64 N, M; lm, host, target, pi[2M]
+//                                out: int32 scan_bad, status; [error text length int32 + bytes] | int64 Ns, Ms, n_items, n_patterns, n_obs_idx, slab, lw;
+//                                     int32 max_lds; sorted_to_orig[Ns], first[Ns] (int32), pts_i[2Ns], items (raw ItemDesc), obs_idx, int64 n_list; list_off[92], list
+//   op 12 plan_xyz               in: int32 marg, throughput, n_cus, g_max, half; int64 N, M; lm, frame, pts[2M]
+//                                out: as op 11 without pts_i; + int32 fast; pts_j[2Ms] when not fast
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../visual-inertial-odometry_amd/csrc/vio_plan.h"
+
+template <typename T> static bool rd(FILE *f, T *p, size_t n) { return n == 0 || std::fread(p, sizeof(T), n, f) == n; }
+template <typename T> static bool wr(FILE *f, const T *p, size_t n) { return n == 0 || std::fwrite(p, sizeof(T), n, f) == n; }
+
+static std::vector<void *> g_allocs;
+static void *test_alloc(void *, size_t bytes) { void *p = std::malloc(bytes ? bytes : 1); g_allocs.push_back(p); return p; }
+static int lds_inv(int G, int K, int nb, int use_ext) { return lin_lds_doubles(G, K, nb, use_ext); }      // the kernel's own formula (vio_types.h)
+// (the XYZ kernels' formula lives with them in vio_kernels_xyz.h, HIP code; a stand-in of the same shape sizes the items here)
+static int lds_xyz(int G, int K) { return 400 + 24 * G * K + G * (18 * K + 29) + 2048; }
+
+static void write_common(FILE *o, const vio_plan::Output &out) {
+    const int64_t hdr[7] = {out.Ns, out.Ms, (int64_t)out.items.size(), (int64_t)out.patterns.size(), (int64_t)out.obs_idx.size(), (int64_t)out.slab_doubles, (int64_t)out.lw_doubles};
+    wr(o, hdr, 7);
+    const int32_t ml = out.max_lds_doubles;
+    wr(o, &ml, 1);
+    wr(o, out.sorted_to_orig.data(), out.sorted_to_orig.size());
+}
+
+int host_units_plan_op(int op, FILE *f, FILE *o) {
+    if (op == 10) {
+        int64_t N, m;
+        if (!rd(f, &N, 1) || !rd(f, &m, 1) || N < 0 || m < 0) return 4;
+        std::vector<int32_t> lm(m), host(m), target(m);
+        std::vector<double> pi(2 * (size_t)m);
+        int32_t have_prev = 0;
+        if (!rd(f, lm.data(), m) || !rd(f, host.data(), m) || !rd(f, target.data(), m) || !rd(f, pi.data(), pi.size()) || !rd(f, &have_prev, 1)) return 4;
+        std::vector<double> pl;
+        if (have_prev) { pl.resize(2 * (size_t)N); if (!rd(f, pl.data(), pl.size())) return 4; }
+        const vio_plan::ScanResult r = vio_plan::scan_observations(N, m, lm.data(), host.data(), target.data(), pi.data(), pl);
+        const int32_t a[3] = {r.lm_major, r.consistent, r.changed}, bad = r.bad;
+        wr(o, &bad, 1); wr(o, &r.bad_index, 1); wr(o, a, 3); wr(o, pl.data(), pl.size());
+        return 0;
+    }
+    if (op != 11 && op != 12) return 6;
+    const bool xyz = op == 12;
+    int32_t marg = 0, use_ext = 0, thr = 0, n_cus = 256, g_max = 0, half = 0;
+    if (!rd(f, &marg, 1)) return 4;
+    if (!xyz && !rd(f, &use_ext, 1)) return 4;
+    if (!rd(f, &thr, 1) || !rd(f, &n_cus, 1) || !rd(f, &g_max, 1) || !rd(f, &half, 1)) return 4;
+    int64_t N, M;
+    if (!rd(f, &N, 1) || !rd(f, &M, 1) || N < 0 || M < 0) return 4;
+    std::vector<int32_t> lm(M), host(M, 0), target(M);
+    std::vector<double> pi(2 * (size_t)M, 0.0), pj(2 * (size_t)M, 0.0), pts_i_lm;
+    if (!rd(f, lm.data(), M)) return 4;
+    if (!xyz && !rd(f, host.data(), M)) return 4;
+    if (!rd(f, target.data(), M)) return 4;
+    if (!rd(f, xyz ? pj.data() : pi.data(), 2 * (size_t)M)) return 4;
+    vio_plan::ScanResult r = xyz ? vio_plan::scan_observations_xyz(N, M, lm.data(), target.data())
+                                 : vio_plan::scan_observations(N, M, lm.data(), host.data(), target.data(), pi.data(), pts_i_lm);
+    const int32_t bad = r.bad;
+    wr(o, &bad, 1);
+    if (r.bad) return 0;            // (the library refuses such a list before any plan is built)
+    vio_plan::Input in;
+    in.N = N; in.M = M; in.olm = lm.data(); in.ohost = host.data(); in.otarget = target.data();
+    // a vouched list keeps the per-landmark host observations only, as the library does
+    in.pts_i = (!xyz && r.consistent) ? nullptr : pi.data();
+    in.pts_i_lm = pts_i_lm.empty() ? nullptr : pts_i_lm.data();
+    in.pts_j = pj.data();
+    in.lm_major = r.lm_major; in.vouched = r.consistent; in.marg = marg; in.use_ext = use_ext; in.throughput = thr;
+    in.g_max = g_max; in.g_min = g_max > 0 ? g_max : 8; in.n_cus = n_cus;
+    in.lin_threads_full = LIN_THREADS; in.lin_threads = half ? LIN_THREADS / 2 : LIN_THREADS;
+    in.lds_budget = half ? (80 * 1024 - 512) / 8 : (160 * 1024 - 512) / 8;
+    in.lds = lds_inv; in.lds_xyz = lds_xyz; in.imu_item_lds = 450 + 225 + 450 + 32;
+    vio_plan::Output out;
+    const bool ok = xyz ? vio_plan::plan_xyz(in, out, test_alloc, nullptr) : vio_plan::plan_invdepth(in, out, test_alloc, nullptr);
+    const int32_t st = out.status;
+    wr(o, &st, 1);
+    if (!ok) {
+        const int32_t n = (int32_t)out.err.size();
+        wr(o, &n, 1); wr(o, out.err.data(), out.err.size());
+    } else {
+        write_common(o, out);
+        const int32_t fast = in.lm_major;
+        if (xyz) wr(o, &fast, 1);
+        if (!xyz || fast) wr(o, out.first, (size_t)out.Ns);
+        if (!xyz) wr(o, out.pts_i, 2 * (size_t)out.Ns);
+        if (xyz && !fast) wr(o, out.pts_j, 2 * (size_t)out.Ms);
+        wr(o, out.items.data(), out.items.size());
+        wr(o, out.obs_idx.data(), out.obs_idx.size());
+        std::vector<int32_t> list_off, list;
+        vio_plan::build_reduce_lists(out.items, list_off, list);
+        const int64_t nl = (int64_t)list.size();
+        wr(o, &nl, 1); wr(o, list_off.data(), list_off.size()); wr(o, list.data(), list.size());
+    }
+    for (void *p : g_allocs) std::free(p);
+    g_allocs.clear();
+    return 0;
+}

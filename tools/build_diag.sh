@@ -9,4 +9,4 @@ name=${1:-stamps}; shift
 if [ "$name" = prev ]; then cp libvio_hip.so diag/libvio_hip_prev.so; exit $?; fi
 flags="$*"
 [ "$name" = stamps ] && flags="-DVIO_STAMPS $flags"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $flags vio_kernels.hip vio_api.cpp host_dense.cpp -o diag/libvio_hip_$name.so -ldl -lpthread
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value $flags vio_kernels.hip vio_api.cpp host_dense.cpp vio_plan.cpp -o diag/libvio_hip_$name.so -ldl -lpthread

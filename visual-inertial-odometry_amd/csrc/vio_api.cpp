@@ -23,6 +23,7 @@
 
 #include "../../include/vio_backend.h"
 #include "host_dense.h"
+#include "vio_plan.h"
 #include "vio_types.h"
 
 struct ReduceTables {
@@ -196,12 +197,7 @@ struct PinnedVec {
     void release() { if (p) hipHostFree(p); p = nullptr; n = cap = 0; }
 };
 
-struct Pattern {
-    int use_ext, host, K, nb, host_slot, G;
-    int btype_i[VIO_MAXNB], bk_i[VIO_MAXNB];
-    int8_t target[VIO_MAXK], tslot[VIO_MAXK], cam_block[VIO_MAXNB];
-    int n_rows, lds_doubles;
-};
+using vio_plan::Pattern;
 
 // Everything that depends on the graph topology (which landmark is seen from where).
 struct Plan {
@@ -353,395 +349,69 @@ vio_status fail(vio_ctx *c, vio_status s, const std::string &msg) {
 }
 
 // ---- topology preprocessing ----------------------------------------------------------------------------
-// Block types of a pattern, its slab size and the largest G that fits the LDS budget.  The slab of an item holds,
-// in this order: the 6x6 blocks of the pattern-local pairs (p <= q, p-major), then per block the direct b, the Schur
-// correction of b and the direct diagonal, then chi2 and max h_ll (k_linearize writes it, k_reduce's lists index it).
-void build_pattern_tables(Pattern &pt, int g_max, int threads, int lds_budget) {
-    const int nb = pt.nb, K = pt.K;
-    int *type = pt.btype_i, *kof = pt.bk_i;
-    for (int p = 0; p < nb; ++p) {
-        type[p] = (pt.use_ext && p == 0) ? 0 : (p == pt.host_slot ? 1 : 2);
-        kof[p] = 15;
-    }
-    for (int k = 0; k < K; ++k) kof[pt.tslot[k]] = k;
-    pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
-    int G = std::max(1, std::min(g_max, threads / K));                     // one thread per observation in k_linearize's phase 1
-    while (G > 1 && lin_lds_doubles_host(G, K, nb, pt.use_ext) > lds_budget) --G;
-    while (G > 1 && (6 * nb + 2) * G > 7 * threads) --G;                   // k_linearize stages the item's Schur rows with 7 loads per thread
-    pt.G = G;
-    pt.lds_doubles = lin_lds_doubles_host(G, K, nb, pt.use_ext);
-}
-
+// The planner itself is host-only code (csrc/vio_plan.cpp: patterns, counting sort, item sizing, items; CPU-tier tests and sanitizers
+// reach it without a device); here: its inputs out of the context, its staging out of the pinned arena, its outputs uploaded.
 vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j, const int32_t *first = nullptr, const int32_t *obs_idx = nullptr, int64_t n_obs_idx = 0);
 
-// The plan of a window of XYZ landmarks (vio_kernels_xyz.h): a pattern is the set of frames a landmark is seen from,
-// one pattern block per frame, no host frame and no extrinsic block.
-// marg: Problem::Marginalize's graph (problem.cc:617-637): the edges connected to the pose of frame 0 and the landmarks they touch —
-// a landmark seen from frame 0 enters with that one observation, whatever else observes it.
-vio_status build_plan_xyz(vio_ctx *c, Plan &pl, int marg) {
-    pl.valid = false;
-    pl.marg = marg; pl.use_ext = 0; pl.lm_dim = 3;
-    const bool half = c->cfg.item_policy == VIO_ITEMS_THROUGHPUT && !std::getenv("VIO_NO_HALF_WIDTH");      // as build_plan: k_linearize_xyz_h
-    pl.lin_threads = half ? lin_threads_half_host() : lin_threads_host();
-    const int64_t N = (int64_t)c->h_invd.size() / 3, M = (int64_t)c->h_olm.size();
-    // A landmark-major list with ascending frames (what vio_set_observations_xyz's pass found) is its own CSR and observation k of a
-    // landmark is its pattern's k-th frame: no table of observations by (landmark, frame), and the observations go to the device as
-    // listed (k_gather_obs puts them into item order).  Any other list: the table, and the gather on the host.
-    const bool fast = c->obs_lm_major;
-    std::vector<int64_t> obs_off;
-    if (fast) {
-        if (M && !c->raw_pts_valid) {
-            HIPCHK(c->d_raw_pts_j.resize(2 * (size_t)M));
-            HIPCHK(hipMemcpyAsync(c->d_raw_pts_j.p, c->h_pts_j.data(), 2 * (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
-            c->raw_pts_valid = true;
-        }
-        obs_off.assign((size_t)N + 1, 0);
-        for (int64_t e = 0; e < M; ++e) ++obs_off[c->h_olm[e] + 1];
-        for (int64_t l = 0; l < N; ++l) obs_off[l + 1] += obs_off[l];
-    }
-    // observation of landmark l in frame f: obs_at[l * NF + f] (or -1)
-    std::vector<int32_t> obs_at;
-    if (!fast) {
-        obs_at.assign((size_t)std::max<int64_t>(N, 1) * NF, -1);
-        for (int64_t e = 0; e < M; ++e) {
-            if (marg && c->h_otarget[e] != 0) continue;
-            int32_t &slot = obs_at[(size_t)c->h_olm[e] * NF + c->h_otarget[e]];
-            if (slot >= 0) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
-            slot = (int32_t)e;
-        }
-    }
-    std::vector<int32_t> mask(N, 0), pat_of_mask(1 << NF, -1), lm_pattern(N, -1);
-    pl.patterns.clear();
-    for (int64_t l = 0; l < N; ++l) {
-        int m = 0;
-        if (fast) {
-            for (int64_t e = obs_off[l]; e < obs_off[l + 1]; ++e) m |= 1 << c->h_otarget[e];
-            if (marg) m &= 1;              // Problem::Marginalize's graph: the observation frame 0 has of the landmark, nothing else
-        } else
-            for (int f = 0; f < NF; ++f) if (obs_at[(size_t)l * NF + f] >= 0) m |= 1 << f;
-        if (m == 0) {
-            if (marg) continue;
-            return fail(c, VIO_ERR_UNSUPPORTED, "landmark without observations (its 3x3 Hessian block would be singular)");
-        }
-        mask[l] = m;
-        if (pat_of_mask[m] < 0) {
-            pat_of_mask[m] = (int)pl.patterns.size();
-            Pattern pt;
-            std::memset(&pt, 0, sizeof(pt));
-            pt.host = -1; pt.host_slot = -1;
-            int p = 0;
-            for (int f = 0; f < NF; ++f) if ((m >> f) & 1) {
-                pt.cam_block[p] = (int8_t)(1 + f);
-                if (p < VIO_MAXK) { pt.target[p] = (int8_t)f; pt.tslot[p] = (int8_t)p; }
-                pt.btype_i[p] = 2; pt.bk_i[p] = p;
-                ++p;
-            }
-            pt.K = pt.nb = p;
-            pt.n_rows = item_nbp(pt.nb) * 6 + 3 * pt.nb;
-            int G = std::max(1, std::min(c->g_max > 0 ? c->g_max : 128, lin_threads_host() / pt.K));
-            while (G > 1 && xyz_lds_doubles_host(G, pt.K) > (half ? LDS_BUDGET_HALF_DOUBLES : LDS_BUDGET_DOUBLES)) --G;
-            pt.G = G;
-            pt.lds_doubles = xyz_lds_doubles_host(G, pt.K);
-            pl.patterns.push_back(pt);
-        }
-        lm_pattern[l] = pat_of_mask[m];
-    }
-    {   // counting sort: pattern-major, original index inside a pattern
-        std::vector<int64_t> start(pl.patterns.size() + 1, 0);
-        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) ++start[lm_pattern[l] + 1];
-        for (size_t q = 0; q < pl.patterns.size(); ++q) start[q + 1] += start[q];
-        pl.sorted_to_orig.assign((size_t)start[pl.patterns.size()], 0);
-        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) pl.sorted_to_orig[start[lm_pattern[l]]++] = (int32_t)l;
-    }
-    pl.Ns = (int64_t)pl.sorted_to_orig.size();
-    {   // landmarks per item: whole rounds of the device's CUs, as build_plan does, within what the LDS holds per pattern
-        std::vector<int64_t> n_of(pl.patterns.size(), 0);
-        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) ++n_of[lm_pattern[l]];
-        const int cus = std::max(1, c->n_cus);
-        int best_g = 0;
-        double best_cost = 0.0;
-        for (int g = (c->cfg.item_policy == VIO_ITEMS_THROUGHPUT ? 128 : c->g_min); g <= 128; ++g) {      // (throughput: the largest items the LDS holds)
-            int64_t blocks = VIO_WINDOW_SIZE;
-            int g_eff = 1;
-            for (size_t q = 0; q < pl.patterns.size(); ++q) {
-                const int gp = std::min(g, pl.patterns[q].G);
-                const int64_t ni = (n_of[q] + gp - 1) / gp;
-                blocks += ni;
-                if (ni) g_eff = std::max<int>(g_eff, (int)((n_of[q] + ni - 1) / ni));
-            }
-            const double cost = (double)((blocks + cus - 1) / cus) * (70.0 + g_eff);
-            if (best_g == 0 || cost < best_cost) { best_g = g; best_cost = cost; }
-        }
-        for (size_t q = 0; q < pl.patterns.size(); ++q) {
-            Pattern &pt = pl.patterns[q];
-            const int gp = std::min(best_g, pt.G);
-            const int64_t ni = std::max<int64_t>(1, (n_of[q] + gp - 1) / gp);
-            pt.G = (int)std::max<int64_t>(1, (n_of[q] + ni - 1) / ni);
-            pt.lds_doubles = xyz_lds_doubles_host(pt.G, pt.K);
-        }
-    }
-    pl.items.clear();
-    // observations in item order, written straight into the pinned staging (every observation of the window has a place)
-    const double *pts_i = nullptr;
-    double *pts_j = fast ? nullptr : (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>((int64_t)c->h_olm.size(), 1) * 8);
-    int32_t *first = fast ? (int32_t *)c->arena.alloc((size_t)std::max<int64_t>(pl.Ns, 1) * 4) : nullptr;
-    if (fast ? !first : !pts_j) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
-    pl.slab_doubles = 0; pl.lw_doubles = 0; pl.max_lds_doubles = IMU_ITEM_LDS_DOUBLES;
-    int64_t s = 0, obs_base = 0;
-    while (s < pl.Ns) {
-        const int id = lm_pattern[pl.sorted_to_orig[s]];
-        const Pattern &pt = pl.patterns[id];
-        int64_t e = s;
-        while (e < pl.Ns && e - s < pt.G && lm_pattern[pl.sorted_to_orig[e]] == id) ++e;
-        ItemDesc it;
-        std::memset(&it, 0, sizeof(it));
-        it.lm_base = (int32_t)s; it.G = (int32_t)(e - s); it.K = pt.K; it.nb = pt.nb; it.host = -1;
-        it.host_slot = -1; it.use_ext = 0; it.obs_base = (int32_t)obs_base;
-        it.out_base = (int32_t)pl.slab_doubles; it.lw_base = (int32_t)pl.lw_doubles;
-        std::memcpy(it.target, pt.target, sizeof(it.target)); std::memcpy(it.tslot, pt.tslot, sizeof(it.tslot));
-        std::memcpy(it.cam_block, pt.cam_block, sizeof(it.cam_block));
-        for (int p = 0; p < pt.nb; ++p) { it.btype[p] = 2; it.bk[p] = (int8_t)p; }
-        it.n_rows = pt.n_rows; it.lds_doubles = pt.lds_doubles;
-        pl.items.push_back(it);
-        pl.max_lds_doubles = std::max(pl.max_lds_doubles, pt.lds_doubles);
-        pl.slab_doubles += (size_t)item_out_count(pt.nb);
-        pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
-        pl.lw_doubles += (size_t)9 * it.G;            // H_ll (6), b_l (3): W is formed again where it is needed
-        for (int g = 0; g < it.G; ++g) {
-            const int32_t l = pl.sorted_to_orig[s + g];
-            if (fast) { first[s + g] = (int32_t)obs_off[l]; continue; }      // (marg: the frame-0 observation is the landmark's first)
-            for (int k = 0; k < it.K; ++k) {
-                const int32_t oe = obs_at[(size_t)l * NF + (pt.cam_block[k] - 1)];
-                const int64_t o = obs_base + (int64_t)k * it.G + g;
-                pts_j[2 * o] = c->h_pts_j[2 * oe]; pts_j[2 * o + 1] = c->h_pts_j[2 * oe + 1];
-            }
-        }
-        obs_base += (int64_t)it.G * it.K;
-        s = e;
-    }
-    pl.Ms = obs_base;
-    return fast ? upload_plan(c, pl, pts_i, nullptr, first, nullptr, 0) : upload_plan(c, pl, pts_i, pts_j);
-}
+static void *arena_alloc(void *user, size_t bytes) { return ((HostArena *)user)->alloc(bytes); }
+static int lds_fn(int G, int K, int nb, int use_ext) { return lin_lds_doubles_host(G, K, nb, use_ext); }
+static int lds_xyz_fn(int G, int K) { return xyz_lds_doubles_host(G, K); }
 
 vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     c->marg_map_valid = false;
-    if (c->lm_dim == 3) return build_plan_xyz(c, pl, marg);
     pl.valid = false;
-    pl.marg = marg; pl.lm_dim = 1;
-    pl.use_ext = marg ? 1 : (c->cfg.ext_fixed ? 0 : 1);
-    // the throughput policy's plans run on k_linearize_h: half the threads, half the LDS, two workgroups to a CU
+    pl.marg = marg; pl.lm_dim = c->lm_dim;
+    const bool xyz = c->lm_dim == 3;
+    pl.use_ext = xyz ? 0 : (marg ? 1 : (c->cfg.ext_fixed ? 0 : 1));
+    // the throughput policy's plans run on k_linearize_h (k_linearize_xyz_h): half the threads, half the LDS, two workgroups to a CU
     const bool half = c->cfg.item_policy == VIO_ITEMS_THROUGHPUT && !std::getenv("VIO_NO_HALF_WIDTH");
     pl.lin_threads = half ? lin_threads_half_host() : lin_threads_host();
-    const int64_t N = (int64_t)c->h_invd.size(), M = (int64_t)c->h_olm.size();
+    const int64_t M = (int64_t)c->h_olm.size();
     static const bool timing = std::getenv("VIO_HOST_TIMING") != nullptr;
-    auto tnow = [] { return std::chrono::steady_clock::now(); };
-    auto tus = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    const auto tp0 = tnow();
     // the observations leave for the device as the caller listed them, now: the copy runs under the host work below
-    if (M && !c->raw_pts_valid) {
+    if (M && !c->raw_pts_valid && (!xyz || c->obs_lm_major)) {
         HIPCHK(c->d_raw_pts_j.resize(2 * (size_t)M));
         HIPCHK(hipMemcpyAsync(c->d_raw_pts_j.p, c->h_pts_j.data(), 2 * (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
         c->raw_pts_valid = true;
     }
-    // observations of each landmark, in the caller's order (CSR; this runs once per frame on the host, so no
-    // per-landmark allocations and no tree lookups: 20 000 landmarks take well under a millisecond)
-    // (a landmark-major list — what the reference's loop emits — is its own CSR: observation k of landmark l is obs_off[l] + k)
-    struct ObsRange { const int32_t *p; size_t n; int32_t base; size_t size() const { return n; } bool empty() const { return n == 0; }
-                      int32_t operator[](size_t i) const { return p ? p[i] : base + (int32_t)i; } };
-    std::vector<int64_t> obs_off(N + 1, 0);
-    for (int64_t e = 0; e < M; ++e) ++obs_off[c->h_olm[e] + 1];
-    for (int64_t l = 0; l < N; ++l) obs_off[l + 1] += obs_off[l];
-    const bool lm_major = c->obs_lm_major;
-    std::vector<int32_t> obs_idx;
-    if (!lm_major) {
-        obs_idx.resize(std::max<int64_t>(M, 1));
-        std::vector<int64_t> fill(obs_off.begin(), obs_off.end() - 1);
-        for (int64_t e = 0; e < M; ++e) obs_idx[fill[c->h_olm[e]]++] = (int32_t)e;
+    vio_plan::Input in;
+    in.N = (int64_t)c->h_invd.size() / c->lm_dim; in.M = M;
+    in.olm = c->h_olm.data(); in.ohost = c->h_ohost.data(); in.otarget = c->h_otarget.data();
+    in.pts_i = c->h_pts_i.empty() ? nullptr : c->h_pts_i.data();
+    in.pts_i_lm = c->h_pts_i_lm.empty() ? nullptr : c->h_pts_i_lm.data();
+    in.pts_j = c->h_pts_j.data();
+    in.lm_major = c->obs_lm_major; in.vouched = c->obs_consistent;
+    in.marg = marg; in.use_ext = pl.use_ext;
+    in.throughput = c->cfg.item_policy == VIO_ITEMS_THROUGHPUT;
+    in.g_max = c->g_max; in.g_min = c->g_min; in.n_cus = c->n_cus;
+    in.lin_threads = pl.lin_threads; in.lin_threads_full = lin_threads_host();
+    in.lds_budget = half ? LDS_BUDGET_HALF_DOUBLES : LDS_BUDGET_DOUBLES;
+    in.lds = lds_fn; in.lds_xyz = lds_xyz_fn;
+    in.imu_item_lds = IMU_ITEM_LDS_DOUBLES;
+    vio_plan::Output out;
+    const bool ok = xyz ? vio_plan::plan_xyz(in, out, arena_alloc, &c->arena) : vio_plan::plan_invdepth(in, out, arena_alloc, &c->arena);
+    if (!ok) return fail(c, (vio_status)out.status, out.status == VIO_ERR_HIP ? "hipHostMalloc (staging)" : out.err);
+    pl.patterns.swap(out.patterns); pl.items.swap(out.items); pl.sorted_to_orig.swap(out.sorted_to_orig);
+    pl.Ns = out.Ns; pl.Ms = out.Ms; pl.slab_doubles = out.slab_doubles; pl.lw_doubles = out.lw_doubles; pl.max_lds_doubles = out.max_lds_doubles;
+    if (timing) std::fprintf(stderr, "[vio host timing] build_plan: obs lists %.0f us, patterns %.0f us, sort + sizing %.0f us, items + gather %.0f us\n",
+                             out.t_us[0], out.t_us[1], out.t_us[2], out.t_us[3]);
+    const auto tb = std::chrono::steady_clock::now();
+    vio_status st;
+    if (xyz && !in.lm_major) st = upload_plan(c, pl, nullptr, out.pts_j);
+    else {
+        const int32_t *s_idx = out.obs_idx.empty() || in.lm_major ? nullptr : c->arena.put(out.obs_idx.data(), out.obs_idx.size());
+        if (!in.lm_major && !xyz && !s_idx) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+        st = upload_plan(c, pl, out.pts_i, nullptr, out.first, s_idx, (int64_t)out.obs_idx.size());
     }
-    auto obs_of = [&](int64_t l) { return ObsRange{lm_major ? nullptr : obs_idx.data() + obs_off[l], (size_t)(obs_off[l + 1] - obs_off[l]), (int32_t)obs_off[l]}; };
-    const auto tp1 = tnow();
-    // pattern of each landmark: (host, targets in observation order) packed 4 bits a frame
-    std::unordered_map<uint64_t, int> pattern_id;
-    uint64_t pat_cache_key[256];
-    int pat_cache_id[256];
-    for (int q = 0; q < 256; ++q) pat_cache_id[q] = -1;
-    pl.patterns.clear();
-    std::vector<int32_t> lm_pattern(N, -1);
-    const bool vouched = lm_major && c->obs_consistent;
-    for (int64_t l = 0; l < N; ++l) {
-        const ObsRange ob = obs_of(l);
-        if (ob.empty()) {
-            if (marg) continue;
-            return fail(c, VIO_ERR_UNSUPPORTED, "landmark without observations (its 1x1 Hessian block would be singular)");
-        }
-        const int h = c->h_ohost[ob[0]];
-        if (marg && h != 0) continue;          // MargOldFrame keeps landmarks hosted in frame 0 only (estimator.cpp:762-764)
-        if ((int)ob.size() > VIO_MAXK) return fail(c, VIO_ERR_UNSUPPORTED, "more than 10 observations of one landmark");
-        int8_t key[1 + VIO_MAXK];
-        int nkey = 0;
-        key[nkey++] = (int8_t)h;
-        uint64_t packed = (uint64_t)ob.size() | ((uint64_t)h << 4);
-        bool seen[NF] = {false};
-        seen[h] = true;
-        for (size_t oi = 0; oi < ob.size(); ++oi) {
-            const int32_t e = ob[oi];
-            if (!vouched && (c->h_ohost[e] != h || c->h_pts_i[2 * e] != c->h_pts_i[2 * ob[0]] || c->h_pts_i[2 * e + 1] != c->h_pts_i[2 * ob[0] + 1]))
-                return fail(c, VIO_ERR_UNSUPPORTED, "edges of one landmark must share host frame and host observation");
-            const int t = c->h_otarget[e];
-            if (seen[t]) return fail(c, VIO_ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
-            seen[t] = true;
-            packed |= (uint64_t)t << (4 * (nkey + 1));
-            key[nkey++] = (int8_t)t;
-        }
-        int id = -1;
-        const unsigned hslot = (unsigned)((packed * 0x9E3779B97F4A7C15ull) >> 56);      // 256 slots in front of the map
-        if (pat_cache_id[hslot] >= 0 && pat_cache_key[hslot] == packed) id = pat_cache_id[hslot];
-        else {
-            auto itp = pattern_id.find(packed);
-            if (itp != pattern_id.end()) { id = itp->second; pat_cache_key[hslot] = packed; pat_cache_id[hslot] = id; }
-        }
-        if (id < 0) {
-            id = (int)pl.patterns.size();
-            pattern_id[packed] = id;
-            pat_cache_key[hslot] = packed; pat_cache_id[hslot] = id;
-            Pattern pt;
-            std::memset(&pt, 0, sizeof(pt));
-            pt.use_ext = pl.use_ext; pt.host = h; pt.K = (int)ob.size();
-            std::vector<int> frames;
-            for (int f = 0; f < NF; ++f) if (seen[f]) frames.push_back(f);
-            pt.nb = (int)frames.size() + pt.use_ext;
-            int p = 0;
-            if (pt.use_ext) pt.cam_block[p++] = 0;
-            for (int f : frames) { if (f == h) pt.host_slot = p; pt.cam_block[p++] = (int8_t)(1 + f); }
-            for (int k = 0; k < pt.K; ++k) {
-                pt.target[k] = key[1 + k];
-                for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + key[1 + k]) pt.tslot[k] = (int8_t)q;
-            }
-            build_pattern_tables(pt, c->g_max > 0 ? c->g_max : 128, pl.lin_threads, half ? LDS_BUDGET_HALF_DOUBLES : LDS_BUDGET_DOUBLES);      // pt.G = the most landmarks the LDS holds
-            pl.patterns.push_back(pt);
-        }
-        lm_pattern[l] = id;
-    }
-    const auto tp2 = tnow();
-    // sort landmarks by pattern (stable in the original index)
-    {   // counting sort: pattern-major, original index inside a pattern
-        std::vector<int64_t> start(pl.patterns.size() + 1, 0);
-        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) ++start[lm_pattern[l] + 1];
-        for (size_t q = 0; q < pl.patterns.size(); ++q) start[q + 1] += start[q];
-        pl.sorted_to_orig.assign((size_t)start[pl.patterns.size()], 0);
-        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) pl.sorted_to_orig[start[lm_pattern[l]]++] = (int32_t)l;
-    }
-    pl.Ns = (int64_t)pl.sorted_to_orig.size();
-    // Landmarks per item.  One k_linearize workgroup per item, one workgroup per CU (LDS), so the kernel takes
-    // rounds x (time of a workgroup), rounds = ceil((items + IMU workgroups) / CUs), and a workgroup of g landmarks takes
-    // ~ (70 + g) x 170 cycles (measured 48..80, tools/diag_wg_timeline.py).  A workgroup too many doubles the kernel:
-    // 20 000 landmarks in 7 patterns are 252 + 10 workgroups at 80 landmarks per item and 245 + 10 at 82 — one round on
-    // the 256 CUs of an MI355X instead of two (20 -> 12 us).  Items of a pattern are then evened out.
-    {
-        std::vector<int64_t> n_of(pl.patterns.size(), 0);
-        for (int64_t l = 0; l < N; ++l) if (lm_pattern[l] >= 0) ++n_of[lm_pattern[l]];
-        const int cus = std::max(1, c->n_cus);
-        int best_g = 0;
-        double best_cost = 0.0;
-        for (int g = (c->cfg.item_policy == VIO_ITEMS_THROUGHPUT ? 128 : c->g_min); g <= 128; ++g) {      // (throughput: the largest items the LDS holds)
-            int64_t blocks = VIO_WINDOW_SIZE;
-            int g_eff = 1;
-            for (size_t q = 0; q < pl.patterns.size(); ++q) {
-                const int gp = std::min(g, pl.patterns[q].G);
-                const int64_t ni = (n_of[q] + gp - 1) / gp;
-                blocks += ni;
-                if (ni) g_eff = std::max<int>(g_eff, (int)((n_of[q] + ni - 1) / ni));
-            }
-            const double cost = (double)((blocks + cus - 1) / cus) * (70.0 + g_eff);
-            if (best_g == 0 || cost < best_cost) { best_g = g; best_cost = cost; }
-        }
-        for (size_t q = 0; q < pl.patterns.size(); ++q) {
-            Pattern &pt = pl.patterns[q];
-            const int gp = std::min(best_g, pt.G);
-            const int64_t ni = std::max<int64_t>(1, (n_of[q] + gp - 1) / gp);
-            pt.G = (int)std::max<int64_t>(1, (n_of[q] + ni - 1) / ni);
-            pt.lds_doubles = lin_lds_doubles_host(pt.G, pt.K, pt.nb, pt.use_ext);
-        }
-    }
-    // items
-    const auto tp3 = tnow();
-    pl.items.clear();
-    // host observations / observations in item order, written straight into the pinned staging
-    double *pts_i = (double *)c->arena.alloc(2 * (size_t)std::max<int64_t>(pl.Ns, 1) * 8);
-    int32_t *first = (int32_t *)c->arena.alloc((size_t)std::max<int64_t>(pl.Ns, 1) * 4);
-    if (!pts_i || !first) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
-    pl.slab_doubles = 0; pl.lw_doubles = 0; pl.max_lds_doubles = IMU_ITEM_LDS_DOUBLES;
-    int64_t s = 0, obs_base = 0;
-    while (s < pl.Ns) {
-        const int id = lm_pattern[pl.sorted_to_orig[s]];
-        const Pattern &pt = pl.patterns[id];
-        int64_t e = s;
-        while (e < pl.Ns && e - s < pt.G && lm_pattern[pl.sorted_to_orig[e]] == id) ++e;
-        ItemDesc it;
-        std::memset(&it, 0, sizeof(it));
-        it.lm_base = (int32_t)s; it.G = (int32_t)(e - s); it.K = pt.K; it.nb = pt.nb; it.host = pt.host;
-        it.host_slot = pt.host_slot; it.use_ext = pt.use_ext; it.obs_base = (int32_t)obs_base;
-        it.out_base = (int32_t)pl.slab_doubles; it.lw_base = (int32_t)pl.lw_doubles;
-        std::memcpy(it.target, pt.target, sizeof(it.target)); std::memcpy(it.tslot, pt.tslot, sizeof(it.tslot));
-        std::memcpy(it.cam_block, pt.cam_block, sizeof(it.cam_block));
-        for (int p = 0; p < pt.nb; ++p) { it.btype[p] = (int8_t)pt.btype_i[p]; it.bk[p] = (int8_t)pt.bk_i[p]; }
-        it.n_rows = pt.n_rows; it.lds_doubles = pt.lds_doubles;
-        pl.items.push_back(it);
-        pl.max_lds_doubles = std::max(pl.max_lds_doubles, pt.lds_doubles);
-        pl.slab_doubles += (size_t)item_out_count(pt.nb);
-        pl.slab_doubles = (pl.slab_doubles + 1) & ~(size_t)1;
-        pl.lw_doubles += (size_t)item_lw_fields(pt.nb) * it.G;
-        for (int g = 0; g < it.G; ++g) {
-            const int32_t l = pl.sorted_to_orig[s + g];
-            const ObsRange ob = obs_of(l);
-            const double *hp = vouched ? &c->h_pts_i_lm[2 * (size_t)l] : &c->h_pts_i[2 * (size_t)ob[0]];
-            pts_i[2 * (s + g)] = hp[0]; pts_i[2 * (s + g) + 1] = hp[1];
-            first[s + g] = (int32_t)obs_off[l];          // (the target observations follow on the device: k_gather_obs)
-        }
-        obs_base += (int64_t)it.G * it.K;
-        s = e;
-    }
-    pl.Ms = obs_base;
-    if (timing) {
-        const auto tb = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[vio host timing] build_plan: obs lists %.0f us, patterns %.0f us, sort + sizing %.0f us, items + gather %.0f us\n", tus(tp0, tp1), tus(tp1, tp2), tus(tp2, tp3), tus(tp3, tb));
-        const int32_t *s_idx0 = lm_major ? nullptr : c->arena.put(obs_idx.data(), obs_idx.size());
-        if (!lm_major && !s_idx0) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
-        const vio_status st = upload_plan(c, pl, pts_i, nullptr, first, s_idx0, (int64_t)obs_idx.size());
-        std::fprintf(stderr, "[vio host timing] build_plan: upload_plan %.0f us of it\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count());
-        return st;
-    }
-    const int32_t *s_idx = lm_major ? nullptr : c->arena.put(obs_idx.data(), obs_idx.size());
-    if (!lm_major && !s_idx) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
-    return upload_plan(c, pl, pts_i, nullptr, first, s_idx, (int64_t)obs_idx.size());
+    if (timing) std::fprintf(stderr, "[vio host timing] build_plan: upload_plan %.0f us of it\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count());
+    return st;
 }
 
 // inverted lists for k_reduce, device buffers, upload: common to both kinds of landmark
 // pts_j == nullptr: the observations are on the device in the caller's order (d_raw_pts_j) and k_gather_obs puts them into item order:
 // first[s] = place of sorted landmark s's first observation in that list (landmark-major lists), or in obs_idx (the CSR of any other list)
 vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *pts_j, const int32_t *first, const int32_t *obs_idx, int64_t n_obs_idx) {
-    const int n_lists = VIO_NPAIR + VIO_NCB + 1;
-    std::vector<std::vector<int32_t>> lists(n_lists);
-    for (const ItemDesc &it : pl.items) {
-        for (int p = 0; p < it.nb; ++p) {
-            const int P = it.cam_block[p];
-            for (int q = p; q < it.nb; ++q) {
-                const int Q = it.cam_block[q];
-                const int bidx = P * VIO_NCB - P * (P - 1) / 2 + (Q - P);
-                lists[bidx].push_back(it.out_base + item_pair_index(it.nb, p, q) * 36);
-            }
-            lists[VIO_NPAIR + P].push_back(it.out_base + item_nbp(it.nb) * 36 + p * 6);
-            lists[VIO_NPAIR + P].push_back(it.nb * 6);
-        }
-        lists[n_lists - 1].push_back(it.out_base + it.n_rows * 6);
-    }
-    pl.list_off.assign(n_lists + 1, 0);
-    pl.list.clear();
-    for (int b = 0; b < n_lists; ++b) {
-        pl.list_off[b] = (int32_t)pl.list.size();
-        pl.list.insert(pl.list.end(), lists[b].begin(), lists[b].end());
-    }
-    pl.list_off[n_lists] = (int32_t)pl.list.size();
+    vio_plan::build_reduce_lists(pl.items, pl.list_off, pl.list);
     // upload
     const size_t ni = pl.items.size();
     HIPCHK(pl.d_items.resize(ni));
@@ -1408,21 +1078,10 @@ vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, co
     if (c->lm_dim != 3) return fail(c, VIO_ERR_BAD_ARG, "vio_set_observations_xyz needs vio_set_landmarks_xyz first");
     const int64_t N = (int64_t)c->h_invd.size() / 3;
     {   // one pass: indices in range?  landmark-major with a landmark's frames ascending (then observation k of a landmark is the k-th
-        // frame of its pattern and the list is its own CSR: build_plan_xyz's fast path, the observations put into item order on the device)?
-        unsigned bad = 0, unordered = 0;
-        const uint32_t un = (uint32_t)std::min<int64_t>(N, INT32_MAX);
-        int32_t pl = -1, pf = -1;
-        for (int64_t e = 0; e < m; ++e) {
-            const int32_t l = lm[e], f = frame[e];
-            bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)f >= (uint32_t)NF);
-            unordered |= (unsigned)(l < pl) | ((unsigned)(l == pl) & (unsigned)(f <= pf));
-            pl = l; pf = f;
-        }
-        if (bad)
-            for (int64_t e = 0; e < m; ++e)
-                if (lm[e] < 0 || lm[e] >= N || frame[e] < 0 || frame[e] >= NF)
-                    return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
-        c->obs_lm_major = !unordered;
+        // frame of its pattern and the list is its own CSR: plan_xyz's fast path, the observations put into item order on the device)?
+        const vio_plan::ScanResult r = vio_plan::scan_observations_xyz(N, m, lm, frame);
+        if (r.bad) return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(r.bad_index) + " out of range");
+        c->obs_lm_major = r.lm_major;
         c->obs_consistent = false;
     }
     // (what the device holds newer than the host mirrors stays there until activate() needs it: the old plan is alive till then)
@@ -1440,38 +1099,17 @@ vio_status vio_set_observations_xyz(vio_ctx *c, int64_t m, const int32_t *lm, co
     return VIO_OK;
 }
 
-// One pass over an observation list: any index out of range?  is it landmark-major, as estimator.cpp:975-1016 emits it?  and if so: do the
-// edges of a landmark — neighbours in such a list — share host frame and host observation (edge_reprojection.cc:24: pts_i is the
-// landmark's)?  The landmark's host observation is noted by landmark on the way (h_pts_i_lm), for build_plan, which repeats the
+// One pass over an observation list (vio_plan::scan_observations): range, landmark-major?, do a landmark's edges share host frame and host
+// observation?; the landmark's host observation is noted by landmark on the way (h_pts_i_lm), for the planner, which repeats the
 // consistency check per landmark only for the lists this pass does not vouch for (and names the offender).
 // *same_pi (optional): every landmark's host observation is the one h_pts_i_lm held before the call (meaningful when the list the context
 // holds was vouched for: then that is all there is to compare — the per-edge copies are not kept for such lists).
 static vio_status scan_observations(vio_ctx *c, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi, bool *same_pi = nullptr) {
-    const int64_t N = (int64_t)c->h_invd.size();
-    unsigned bad = 0, unsorted = 0, incons = 0, changed = 0;
-    const uint32_t un = (uint32_t)std::min<int64_t>(N, INT32_MAX);
-    if (c->h_pts_i_lm.size() != 2 * (size_t)N) { c->h_pts_i_lm.assign(2 * (size_t)N, 0.0); changed = 1; }
-    double *pl = c->h_pts_i_lm.data();
-    int32_t prev = -1;
-    for (int64_t e = 0; e < m; ++e) {
-        const int32_t l = lm[e];
-        bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)host[e] >= (uint32_t)NF) | (unsigned)((uint32_t)target[e] >= (uint32_t)NF) |
-               (unsigned)(host[e] == target[e]);
-        unsorted |= (unsigned)(l < prev);
-        if (e > 0 && l == prev) incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
-        else if ((uint32_t)l < un) {
-            changed |= (unsigned)(pl[2 * (size_t)l] != pi[2 * e]) | (unsigned)(pl[2 * (size_t)l + 1] != pi[2 * e + 1]);
-            pl[2 * (size_t)l] = pi[2 * e]; pl[2 * (size_t)l + 1] = pi[2 * e + 1];
-        }
-        prev = l;
-    }
-    if (same_pi) *same_pi = !changed;
-    if (bad)
-        for (int64_t e = 0; e < m; ++e)
-            if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e])
-                return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(e) + " out of range");
-    c->obs_lm_major = !unsorted;
-    c->obs_consistent = !unsorted && !incons;
+    const vio_plan::ScanResult r = vio_plan::scan_observations((int64_t)c->h_invd.size(), m, lm, host, target, pi, c->h_pts_i_lm);
+    if (same_pi) *same_pi = !r.changed;
+    if (r.bad) return fail(c, VIO_ERR_BAD_ARG, "observation " + std::to_string(r.bad_index) + " out of range");
+    c->obs_lm_major = r.lm_major;
+    c->obs_consistent = r.consistent;
     return VIO_OK;
 }
 

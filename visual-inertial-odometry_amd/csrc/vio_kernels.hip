@@ -28,15 +28,27 @@
 
 // threads of a k_linearize / k_linearize_xyz workgroup.  One workgroup holds a CU (its LDS), so the register budget of a thread is
 // 512 / (LIN_THREADS / 256): 128 at 1024 threads (16 waves, 4 per SIMD), 170 at 768 (12 waves, 3 per SIMD).
-#ifndef LIN_THREADS
-#define LIN_THREADS 1024
-#endif
+// (LIN_THREADS: vio_types.h)
 #ifdef LIN_MIN_WAVES            // (experiments with smaller workgroups, several to a CU: waves per SIMD the register allocation must leave room for)
 #define LIN_BOUNDS __launch_bounds__(LIN_THREADS, LIN_MIN_WAVES)
 #else
 #define LIN_BOUNDS __launch_bounds__(LIN_THREADS)
 #endif
 
+// LIN_EARLY_LW: k_linearize stores the landmarks' Schur rows right behind phase 1.5 instead of at its end (see there): 0 (default) in the
+// 1024-thread kernels only, 1 everywhere, -1 nowhere
+#ifndef LIN_EARLY_LW
+#define LIN_EARLY_LW 0
+#endif
+// a workgroup barrier that orders LDS accesses only: outstanding global stores are not waited for (__syncthreads() carries a fence that is)
+__device__ __forceinline__ void d_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Diagnostic builds for the per-phase attribution of the counters (tools/profile_phases.sh): -DLIN_EXIT_AFTER=p makes every item workgroup
+// of k_linearize* leave behind phase p (0 head, 1 phase 1, 2 phase 1.5, 3 phase 2); the differences between consecutive builds are the phases
+#ifdef LIN_EXIT_AFTER
+#define LIN_EXIT(p) do { if (LIN_EXIT_AFTER == (p)) return; } while (0)
+#else
+#define LIN_EXIT(p) do { } while (0)
+#endif
 // In-kernel stamps exist only in the diagnostic build (-DVIO_STAMPS -> libvio_hip_stamps.so, never shipped or timed)
 #ifdef VIO_STAMPS
 // Stamps go to LDS and are flushed once at the end: a global store in front of a barrier would add its own round
@@ -460,26 +472,7 @@ template <int NT> __device__ void d_imu_item(const DeviceTables &T, int k, doubl
 extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
 typedef double ps_v4d __attribute__((ext_vector_type(4)));      // accumulator of v_mfma_f64_16x16x4_f64
 
-__host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles): 2 x 6 per block + (z0, z1)
-__host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 15 : 9; }       // per-observation partials (odd stride)
-__host__ __device__ inline int lin_plane(int G, int use_ext) { return G * lin_rrow(use_ext) + 6; }
-__host__ __device__ inline int lin_lrec(int nb) { return 6 * nb + 7; }                  // landmark record stride (odd): w, 1/h, b_l, h, lambda, GN terms
-#define LIN_VS 8            // landmark splits of the vector sums of phase 2
-// tiles of phase 2: K direct products (1 tile of 16x16, 3 with the extrinsic) + the lower tiles of the 6nb x 6nb Schur term
-__host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
-    const int ts = (6 * nb + 16) >> 4;         // (one row past the 6 nb columns: the Schur correction of b rides there)
-    return K * (use_ext ? 3 : 1) + ts * (ts + 1) / 2;
-}
-// total dynamic LDS of an item (doubles); must match the carve-up in k_linearize
-__host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext) {
-    int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256;
-    int shared = aux > part ? aux : part;
-    const int stage = (6 * nb + 2) * G;         // the GN / LM head stages the item's Schur rows here (more than the per-observation
-    if (stage > shared) shared = stage;         // records of K <= 2 observations hold)
-    shared = (shared + 1) & ~1;
-    return VIO_MAXK * PAIR_STRIDE + 16 + 3 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
-}
-
+// (lin_rrow .. lin_lds_doubles, the LDS layout of an item: vio_types.h — the host-only planner sizes items with the same formulas)
 // b_prior'[i] = b_prior[i] - (H_prior dx)[i]  (problem.cc:473), one wave per row; the same sum whoever calls it
 __device__ __forceinline__ double d_bprior_dot(double h0, double h1, double h2, double x0, double x1, double x2, double b) {
     double s = 0;
@@ -625,6 +618,7 @@ template <int NT, int UE, int CH = 0> __device__ __forceinline__ void d_lineariz
     const double *ric = sCam, *tic = sCam + CAMTAB_TIC;
 
     // ---------------- phase 1 ----------------
+    LIN_EXIT(0);
     STAMP(T, 1);
     if (owe_prior && (tid >> 6) == NT / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, b, T.n_step_blocks, tid & 63);
     double chi_acc = 0.0;
@@ -755,6 +749,7 @@ template <int NT, int UE, int CH = 0> __device__ __forceinline__ void d_lineariz
     __syncthreads();
 
     // ---------------- phase 1.5: thread per (landmark, quantity): sum the K partials ----------------
+    LIN_EXIT(1);
     STAMP(T, 2);
     double maxh = 0.0;
     {
@@ -797,6 +792,21 @@ template <int NT, int UE, int CH = 0> __device__ __forceinline__ void d_lineariz
     }
     __syncthreads();
 
+    // The 1024-thread kernels (one window alone, one round of workgroups): w, h, b_l of the item's landmarks for the back-substitution (the
+    // next head, k_backsub) leave for HBM NOW — they are final, and nothing below writes the landmark records — so that their 256 bytes
+    // per landmark drain under phase 2 and the combine phase instead of behind the kernel's last instruction; the barrier that follows
+    // is LDS-only (d_lds_barrier: __syncthreads() would wait for these stores).  49.75 -> 49.41 us per GN iteration; under the batched
+    // loop, where the device's HBM pipe is busy all the time, it costs 1.4 % (10.81 -> 10.96 us per window-iteration,
+    // profiles/r05f_*): the half-width kernels keep the stores at the end.
+    constexpr bool EARLY_LW = LIN_EARLY_LW >= 0 ? (LIN_EARLY_LW > 0 || NT == 1024) : false;
+    if (EARLY_LW) {
+        double *lw = T.lw + lw_w + it.lw_base;
+        for (int e = tid; e < (6 * nb + 2) * G; e += NT) {
+            const int r = e / G, g = e - r * G;
+            const double *L = sL + (size_t)g * LREC;
+            lw[e] = (r < 6 * nb) ? L[r] : (r == 6 * nb ? L[lH] : L[lBl]);
+        }
+    }
     // ---------------- phase 2: the item's contribution as 16x16 products on the matrix cores ----------------
     // Streaming the LDS rows through VALU strips was bound by LDS bandwidth (9 bytes per FMA).  v_mfma_f64_16x16x4
     // takes one operand element per lane, so the same sums cost two LDS reads per 1024 FMAs:
@@ -804,6 +814,7 @@ template <int NT, int UE, int CH = 0> __device__ __forceinline__ void d_lineariz
     //           observations with columns [host 6 | target 6 | extrinsic 6]  (one tile; three with the extrinsic)
     //   Schur   S = - sum_g w_g w_g^T / h_g over the 6nb pattern columns (lower tiles)
     // One wave per product; the b vectors are plain sums over the landmarks (LIN_VS partials each).
+    LIN_EXIT(2);
     STAMP(T, 3);
     const int D = 6 * nb;
     const int ntd = use_ext ? 3 : 1;
@@ -949,9 +960,11 @@ template <int NT, int UE, int CH = 0> __device__ __forceinline__ void d_lineariz
         // (the b vectors need no sums of their own: row Dk of the direct products, row D of the Schur term)
         STAMP(T, 7);
     }
-    __syncthreads();
+    if (EARLY_LW) d_lds_barrier();
+    else __syncthreads();
 
     // ---------------- combine: thread per slab element ----------------
+    LIN_EXIT(3);
     STAMP(T, 4);
     {
         double *out = T.slab + it.out_base;
@@ -1021,12 +1034,14 @@ template <int NT, int UE, int CH = 0> __device__ __forceinline__ void d_lineariz
             T.dxl[li] = L[lDl];
             T.invd[(size_t)cur * T.Ns + li] = L[lLam];
         }
-        // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
-        double *lw = T.lw + lw_w + it.lw_base;
-        for (int e = tid; e < (6 * nb + 2) * G; e += NT) {
-            const int r = e / G, g = e - r * G;
-            const double *L = sL + (size_t)g * LREC;
-            lw[e] = (r < 6 * nb) ? L[r] : (r == 6 * nb ? L[lH] : L[lBl]);
+        if (!EARLY_LW) {
+            // w, h, b_l of the item's landmarks for the back-substitution (k_backsub), from the LDS records
+            double *lw = T.lw + lw_w + it.lw_base;
+            for (int e = tid; e < (6 * nb + 2) * G; e += NT) {
+                const int r = e / G, g = e - r * G;
+                const double *L = sL + (size_t)g * LREC;
+                lw[e] = (r < 6 * nb) ? L[r] : (r == 6 * nb ? L[lH] : L[lBl]);
+            }
         }
     }
     STAMP(T, 5);

@@ -1,0 +1,88 @@
+// vio_plan.h — the part of the library's host side that needs no device: the pass over a caller's observation list and the planner
+// that cuts a window's landmarks into workgroup items (Estimator::problemSolve's graph build, VM/src/estimator.cpp:909-1034, restated as
+// flat tables).  Plain C++ (no HIP): vio_api.cpp calls it with the context's mirrors and uploads what it returns; tests/test_host_units.py
+// compiles it with g++ alone — under AddressSanitizer / UBSan in the VIO_TEST_SANITIZE=1 tier — and drives it with refused, shuffled and
+// ragged lists.
+#ifndef VIO_PLAN_H
+#define VIO_PLAN_H
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "vio_types.h"
+
+namespace vio_plan {
+
+constexpr int NF = VIO_NF;
+
+struct Pattern {
+    int use_ext, host, K, nb, host_slot, G;
+    int btype_i[VIO_MAXNB], bk_i[VIO_MAXNB];
+    int8_t target[VIO_MAXK], tslot[VIO_MAXK], cam_block[VIO_MAXNB];
+    int n_rows, lds_doubles;
+};
+
+// One pass over an inverse-depth observation list (vio_set_observations / vio_commit_observations): any index out of range?  is it
+// landmark-major, as estimator.cpp:975-1016 emits it?  and if so: do the edges of a landmark — neighbours in such a list — share host
+// frame and host observation (edge_reprojection.cc:24: pts_i is the landmark's)?  pts_i_lm ([2 N], resized when it is not): the host
+// observation by landmark, noted on the way; `changed`: some landmark's differs from what pts_i_lm held before the call.
+struct ScanResult {
+    bool bad = false;               // an index out of range (bad_index: the first such edge)
+    int64_t bad_index = -1;
+    bool lm_major = false;
+    bool consistent = false;
+    bool changed = false;
+};
+ScanResult scan_observations(int64_t N, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi,
+                             std::vector<double> &pts_i_lm);
+// the same for an XYZ list (landmark, observing frame): range, and landmark-major with a landmark's frames ascending
+ScanResult scan_observations_xyz(int64_t N, int64_t m, const int32_t *lm, const int32_t *frame);
+
+// LDS a workgroup item needs, in doubles (the kernels' own formulas: lin_lds_doubles / xyz_lds_doubles of vio_kernels.hip)
+typedef int (*LdsFn)(int G, int K, int nb, int use_ext);
+typedef int (*LdsXyzFn)(int G, int K);
+// staging memory for the arrays that go to the device as they are (the HIP library hands out its pinned arena)
+typedef void *(*AllocFn)(void *user, size_t bytes);
+
+struct Input {
+    int64_t N = 0, M = 0;
+    const int32_t *olm = nullptr, *ohost = nullptr, *otarget = nullptr;       // observation -> landmark / host frame / target (XYZ: observing) frame
+    const double *pts_i = nullptr;         // [M][2] host observation per edge (lists the scan did not vouch for), or null
+    const double *pts_i_lm = nullptr;      // [N][2] host observation per landmark (vouched lists)
+    const double *pts_j = nullptr;         // [M][2] (XYZ, lists that are not landmark-major: gathered into item order here)
+    bool lm_major = false, vouched = false;
+    int marg = 0, use_ext = 0;
+    int throughput = 0;                    // VIO_ITEMS_THROUGHPUT: the largest items the LDS budget holds
+    int g_max = 0, g_min = 8, n_cus = 256;
+    int lin_threads = 1024, lin_threads_full = 1024, lds_budget = 0;
+    LdsFn lds = nullptr;
+    LdsXyzFn lds_xyz = nullptr;
+    int imu_item_lds = 0;                  // floor of max_lds_doubles (the IMU workgroups' need)
+};
+
+struct Output {
+    int status = 0;                        // 0, or a vio_status value (VIO_ERR_UNSUPPORTED = -5, VIO_ERR_HIP = -2 for a failed allocation)
+    std::string err;
+    std::vector<Pattern> patterns;
+    std::vector<ItemDesc> items;
+    std::vector<int32_t> sorted_to_orig;
+    std::vector<int32_t> obs_idx;          // the list's CSR by landmark (lists that are not landmark-major), else empty
+    int64_t Ns = 0, Ms = 0;
+    size_t slab_doubles = 0, lw_doubles = 0;
+    int max_lds_doubles = 0;
+    double *pts_i = nullptr;               // [Ns][2] host observations in sorted landmark order            (AllocFn memory)
+    int32_t *first = nullptr;              // [Ns] where sorted landmark s's observations start in the list / its CSR     (AllocFn memory)
+    double *pts_j = nullptr;               // XYZ slow path: [Ms][2] in item order                                  (AllocFn memory)
+    double t_us[4] = {0, 0, 0, 0};         // observation lists, pattern keys, sort + sizing, items (diagnostic)
+};
+
+void build_pattern_tables(Pattern &pt, int g_max, int threads, int lds_budget, LdsFn lds);
+bool plan_invdepth(const Input &in, Output &out, AllocFn alloc, void *user);
+bool plan_xyz(const Input &in, Output &out, AllocFn alloc, void *user);
+// k_reduce's inverted lists: list b < 78 = camera block pair (P, Q), 78 + P = block P's vectors, 90 = chi2 / max h_ll (vio_kernels.hip)
+void build_reduce_lists(const std::vector<ItemDesc> &items, std::vector<int32_t> &list_off, std::vector<int32_t> &list);
+
+}  // namespace vio_plan
+#endif

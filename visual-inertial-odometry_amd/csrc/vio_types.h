@@ -19,6 +19,15 @@
 
 #include <stdint.h>
 
+#ifndef __HIPCC__       /* (the host-only translation units — vio_plan.cpp, the tests' drivers — are plain C++) */
+#ifndef __host__
+#define __host__
+#endif
+#ifndef __device__
+#define __device__
+#endif
+#endif
+
 #define VIO_NF 11
 #define VIO_PD 171
 #define VIO_PRD 156
@@ -90,6 +99,33 @@ __host__ __device__ inline int item_pair_index(int nb, int p, int q) { return p 
 __host__ __device__ inline int item_out_count(int nb) { return item_nbp(nb) * 36 + 18 * nb + 2; }
 // per-landmark storage (doubles) kept for back-substitution: w[6nb] | hinv | bl ; field-major inside an item: [field][g]
 __host__ __device__ inline int item_lw_fields(int nb) { return 6 * nb + 2; }
+
+// ---- LDS layout of a k_linearize item (doubles): shared by the kernel's carve-up and the host's item sizing (vio_plan.cpp) ----
+// threads of a k_linearize / k_linearize_xyz workgroup.  One workgroup holds a CU (its LDS), so the register budget of a thread is
+// 512 / (LIN_THREADS / 256): 128 at 1024 threads (16 waves, 4 per SIMD), 170 at 768 (12 waves, 3 per SIMD).
+#ifndef LIN_THREADS
+#define LIN_THREADS 1024
+#endif
+__host__ __device__ inline int lin_rrow(int use_ext) { return use_ext ? 38 : 26; }      // row record stride (doubles): 2 x 6 per block + (z0, z1)
+__host__ __device__ inline int lin_raux(int use_ext) { return use_ext ? 15 : 9; }       // per-observation partials (odd stride)
+__host__ __device__ inline int lin_plane(int G, int use_ext) { return G * lin_rrow(use_ext) + 6; }
+__host__ __device__ inline int lin_lrec(int nb) { return 6 * nb + 7; }                  // landmark record stride (odd): w, 1/h, b_l, h, lambda, GN terms
+#define LIN_VS 8            // landmark splits of the vector sums of phase 2
+// tiles of phase 2: K direct products (1 tile of 16x16, 3 with the extrinsic) + the lower tiles of the 6nb x 6nb Schur term
+__host__ __device__ inline int lin_tiles(int K, int nb, int use_ext) {
+    const int ts = (6 * nb + 16) >> 4;         // (one row past the 6 nb columns: the Schur correction of b rides there)
+    return K * (use_ext ? 3 : 1) + ts * (ts + 1) / 2;
+}
+// total dynamic LDS of an item (doubles); must match the carve-up in k_linearize
+__host__ __device__ inline int lin_lds_doubles(int G, int K, int nb, int use_ext) {
+    int aux = G * K * lin_raux(use_ext), part = lin_tiles(K, nb, use_ext) * 256;
+    int shared = aux > part ? aux : part;
+    const int stage = (6 * nb + 2) * G;         // the GN / LM head stages the item's Schur rows here (more than the per-observation
+    if (stage > shared) shared = stage;         // records of K <= 2 observations hold)
+    shared = (shared + 1) & ~1;
+    return VIO_MAXK * PAIR_STRIDE + 16 + 3 * (LIN_THREADS / 64) + K * lin_plane(G, use_ext) + G * lin_lrec(nb) + shared;
+}
+
 
 struct LmState {
     double lambda;               // currentLambda_
