@@ -403,6 +403,8 @@ def main():
             pipelined: MargOldFrame as vio_marginalize_begin; its dense host tail runs on the library's helper thread under the next
             frame's vio_set_window / landmarks / observations / imu and is collected (vio_marginalize_end) in front of vio_set_prior."""
             wins = windows or stream_w
+            for w_ in wins:         # (a caller holds its pre-integrations as vio_preint structs: the dict -> struct conversion of the generator is not a frame's cost)
+                w_.preint = [p_ if (p_ is None or isinstance(p_, vio.VioPreint)) else vio.VioPreint.from_dict(p_) for p_ in w_.preint]
             chain = not xyz         # (XYZ graphs have no MargOldFrame caller: their windows keep the prior they came with)
             next_prior = wins[0].prior
             c = lib.context(**dict({"device": local_rank} if lib is hip else {}, **(ctx_kw or {})))
@@ -418,8 +420,7 @@ def main():
                     c.set_window(wr.poses, wr.speed_bias, wr.ext)
                     c.set_landmarks(wr.inv_depth)
                     c.set_observations(wr.lm, wr.host, wr.target, wr.pts_i, wr.pts_j)
-                    for k_, pre_ in enumerate(wr.preint):
-                        c.set_imu(k_, pre_)
+                    c.set_imu_all(wr.preint)
                     if r > 0:
                         next_prior = c.marginalize_end()
                     c.set_prior(next_prior if chain else wr.prior)

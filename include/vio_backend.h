@@ -80,8 +80,8 @@ typedef enum { VIO_ITEMS_LATENCY = 0, VIO_ITEMS_THROUGHPUT = 1 } vio_item_policy
 typedef enum { VIO_ORDER_EIGEN = 0, VIO_ORDER_CHAIN = 1 } vio_solve_order;
 
 /* Version of this interface: 3 = the sharded exchange is an all-gather (round 3); 4 = vio_set_solve_order (round 4);
- * 5 = vio_map_observations / vio_commit_observations. */
-#define VIO_ABI_VERSION 5
+ * 5 = vio_map_observations / vio_commit_observations; 6 = vio_set_imu_all. */
+#define VIO_ABI_VERSION 6
 
 typedef enum {
     VIO_MARG_OLD = 0,          /* Estimator::MargOldFrame  estimator.cpp:693-829 */
@@ -196,6 +196,9 @@ vio_status vio_get_landmarks_xyz(struct vio_ctx *ctx, int64_t n, double *xyz);
 /* EdgeImu between frames k and k+1, k in [0,10) (estimator.cpp:956-970).  pre == NULL removes the
  * edge (the reference skips it when sum_dt > 10). */
 vio_status vio_set_imu(struct vio_ctx *ctx, int32_t k, const vio_preint *pre);
+/* All ten edges in one call: pre[k] is the pre-integration between frames k and k + 1, or NULL for no edge — the loop of
+ * estimator.cpp:956-970 as one crossing of the boundary.  (VIO_ABI_VERSION 6.) */
+vio_status vio_set_imu_all(struct vio_ctx *ctx, const vio_preint *const *pre);
 /* SetHessianPrior/SetbPrior/SetErrPrior/SetJtPrior + ExtendHessiansPriorSize(15)
  * (estimator.cpp:1023-1034, problem.cc:82-91).  dim is 0 (no prior yet) or VIO_PRIOR_DIM;
  * H is dim x dim, b and err have dim entries, jt_inv is dim x dim. */

@@ -58,6 +58,7 @@
 #undef vio_set_landmarks
 #undef vio_set_observations
 #undef vio_set_imu
+#undef vio_set_imu_all
 #undef vio_set_prior
 #undef vio_solve
 #undef vio_linearize

@@ -1185,6 +1185,12 @@ vio_status vio_set_imu(struct vioo_ctx *c, int32_t k, const vio_preint *pre) {
     return VIO_OK;
 }
 
+vio_status vio_set_imu_all(struct vioo_ctx *c, const vio_preint *const *pre) {
+    if (!c || !pre) return VIO_ERR_BAD_ARG;
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) { vio_status s = vio_set_imu(c, k, pre[k]); if (s != VIO_OK) return s; }
+    return VIO_OK;
+}
+
 vio_status vio_set_prior(struct vioo_ctx *c, int32_t dim, const double *H, const double *b, const double *err,
                          const double *jt) {
     if (!c || (dim != 0 && dim != PRD)) return VIO_ERR_BAD_ARG;

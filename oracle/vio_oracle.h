@@ -19,6 +19,7 @@
 #define vio_set_landmarks vioo_set_landmarks
 #define vio_set_observations vioo_set_observations
 #define vio_set_imu vioo_set_imu
+#define vio_set_imu_all vioo_set_imu_all
 #define vio_set_prior vioo_set_prior
 #define vio_solve vioo_solve
 #define vio_linearize vioo_linearize

@@ -95,8 +95,9 @@ class VioLib:
     # ... nor the receive side of the sharded exchange (it never shards)
     # ... nor the two-halves marginalisation (vio_marginalize_begin / _end)
     # ... nor the in-place observation list (vio_map_observations / vio_commit_observations)
+    # ... nor the ten IMU edges in one call (vio_set_imu_all)
     OPTIONAL = ["triangulate", "gather_buffers", "bind_gather_buffers", "marginalize_begin", "marginalize_end",
-                "map_observations", "commit_observations"]
+                "map_observations", "commit_observations", "set_imu_all"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
@@ -296,6 +297,16 @@ class VioContext:
             p = pre if isinstance(pre, VioPreint) else VioPreint.from_dict(pre)
             self._ck(self.lib.fn["set_imu"](self.h, C.c_int32(k), C.byref(p)), "set_imu")
 
+    def set_imu_all(self, pres):
+        """vio_set_imu_all: the ten edges (dicts, VioPreint or None) in one crossing of the boundary; libraries without it: ten calls."""
+        if "set_imu_all" not in self.lib.fn:
+            for k, pre in enumerate(pres):
+                self.set_imu(k, pre)
+            return
+        keep = [None if p is None else (p if isinstance(p, VioPreint) else VioPreint.from_dict(p)) for p in pres]
+        arr = (C.POINTER(VioPreint) * WINDOW_SIZE)(*[C.pointer(p) if p is not None else C.POINTER(VioPreint)() for p in keep])
+        self._ck(self.lib.fn["set_imu_all"](self.h, arr), "set_imu_all")
+
     def set_prior(self, prior):
         if prior is None:
             self._ck(self.lib.fn["set_prior"](self.h, C.c_int32(0), None, None, None, None), "set_prior")
@@ -316,8 +327,12 @@ class VioContext:
         else:
             self.set_landmarks(g("inv_depth"))
             self.set_observations(g("lm"), g("host"), g("target"), g("pts_i"), g("pts_j"))
-        for k, pre in enumerate(g("preint")):
-            self.set_imu(k, pre)
+        pres = list(g("preint"))
+        if len(pres) == WINDOW_SIZE:
+            self.set_imu_all(pres)
+        else:
+            for k, pre in enumerate(pres):
+                self.set_imu(k, pre)
         self.set_prior(g("prior"))
 
     # ---- solve ----------------------------------------------------------------------------

@@ -1187,9 +1187,7 @@ vio_status vio_commit_observations(vio_ctx *c) {
     return st;
 }
 
-vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
-    if (!c || k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
-    enter_device(c);
+static vio_status set_imu_one(vio_ctx *c, int32_t k, const vio_preint *pre) {
     double blk[PRE_STRIDE];
     double *o = blk;
     std::memcpy(blk, c->h_pre.data() + (size_t)k * PRE_STRIDE, sizeof(blk));
@@ -1205,6 +1203,19 @@ vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
     std::memcpy(c->h_pre.data() + (size_t)k * PRE_STRIDE, blk, sizeof(blk));
     c->imu_dirty = true;
     c->dirty_inputs = true;
+    return VIO_OK;
+}
+
+vio_status vio_set_imu(vio_ctx *c, int32_t k, const vio_preint *pre) {
+    if (!c || k < 0 || k >= VIO_WINDOW_SIZE) return VIO_ERR_BAD_ARG;
+    enter_device(c);
+    return set_imu_one(c, k, pre);
+}
+
+vio_status vio_set_imu_all(vio_ctx *c, const vio_preint *const *pre) {
+    if (!c || !pre) return VIO_ERR_BAD_ARG;
+    enter_device(c);
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) VIOCHK(set_imu_one(c, k, pre[k]));
     return VIO_OK;
 }
 

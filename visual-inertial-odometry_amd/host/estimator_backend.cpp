@@ -212,9 +212,13 @@ bool EstimatorBackend::uploadWindow(bool graph_unchanged) {
         }
     }
     if (vio_commit_observations(ctx_) != VIO_OK) return false;
-    for (int i = 0; i < WINDOW_SIZE; ++i) {                                   // estimator.cpp:956-970
-        const vio_preint *p = pre_integrations[i + 1];
-        if (vio_set_imu(ctx_, i, (p && p->sum_dt <= 10.0) ? p : nullptr) != VIO_OK) return false;
+    {                                                                         // estimator.cpp:956-970: the ten edges, one call
+        const vio_preint *edges[WINDOW_SIZE];
+        for (int i = 0; i < WINDOW_SIZE; ++i) {
+            const vio_preint *p = pre_integrations[i + 1];
+            edges[i] = (p && p->sum_dt <= 10.0) ? p : nullptr;
+        }
+        if (vio_set_imu_all(ctx_, edges) != VIO_OK) return false;
     }
     // (the prior of the marginalisation the frame before left running — async_marginalization — is needed from here on: its dense
     // tail has had slideWindow, the front-end and the uploads above to finish under)
