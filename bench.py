@@ -819,6 +819,7 @@ def main():
             "config": {"workload": workload, "landmark_type": args.landmark_type,
                        "landmarks_per_gpu": n, "observations_per_gpu": m, "landmarks_total": n_total,
                        "lambda": lam, "parallelism": parallelism, "exchange": sb.exchange,
+                       "rccl_ranks_seen": sb.ctx.comm_info()[0] if sb.exchange == "native" else 0,       # ncclCommCount of the library's communicator
                        "all_ranks_on_one_device": bool(one_device)},
             "final_chi2": chi2,
             "single_gpu_same_window_ms": single_gpu,

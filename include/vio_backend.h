@@ -332,6 +332,8 @@ int32_t vio_abi_version(void);
 vio_status vio_comm_unique_id(void *id128);
 vio_status vio_comm_init(struct vio_ctx *ctx, const void *id128, int32_t rank, int32_t nranks);
 vio_status vio_comm_destroy(struct vio_ctx *ctx);
+/* The communicator as RCCL reports it: ranks it spans (ncclCommCount) and this rank's index (ncclCommUserRank); 0 / -1 without one. */
+vio_status vio_comm_info(struct vio_ctx *ctx, int32_t *nranks_seen, int32_t *rank_seen);
 
 /* Optional: make the library use caller-owned device memory for the exchange buffers (e.g. torch tensors, so that
  * torch.distributed can gather them in place).  reduced must hold >= the count reported by vio_exchange_buffers + 8

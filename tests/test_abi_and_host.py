@@ -81,7 +81,7 @@ def test_oracle_exports_the_same_surface(vio, oracle_lib):
             assert oracle_lib.has("preintegrate_abi")
             continue
         if f in ("vio_profile_begin", "vio_profile_begin_sampled", "vio_profile_end", "vio_kernel_name",
-                 "vio_comm_unique_id", "vio_comm_init", "vio_comm_destroy", "vio_get_stream", "vio_batch_gn_iteration", "vio_batch_solve",
+                 "vio_comm_unique_id", "vio_comm_init", "vio_comm_destroy", "vio_comm_info", "vio_get_stream", "vio_batch_gn_iteration", "vio_batch_solve",
                  "vio_get_host_timing", "vio_set_solve_order", "vio_get_solve_order", "vio_abi_version"):
             continue        # measurement hooks, the native RCCL exchange, streams, batched launches and the choice of the GPU
                             # solver's elimination order exist on the HIP library only

@@ -43,6 +43,12 @@ def test_two_ranks_launched_as_the_driver_would():
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0 and "200000" in out["cpu_baseline"]["sample"]
     rep = out["replicas"]
     assert rep["windows_per_gpu"] == 3 and rep["scaling"] == "weak" and rep["window_iterations_per_s"] > 0
+    assert cfg["rccl_ranks_seen"] == 0                  # (the host-staged exchange of the one-device form: no RCCL communicator)
+    # the same window's single-GPU time measured inside the N > 1 run against a `--gpus 1 --landmarks 200000` run of its own
+    # (two processes share the GPU in the first: the figure is taken by rank 0 behind a barrier, the other rank idle)
+    p1, one = run_bench(["--gpus", "1", "--landmarks", "200000", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--batch", "0", "--no-per-frame"])
+    assert p1.returncode == 0 and one["config"]["landmarks_total"] == 200000, p1.stderr[-2000:]
+    assert abs(out["single_gpu_same_window_ms"] - one["ms_per_step"]) <= 0.25 * one["ms_per_step"], (out["single_gpu_same_window_ms"], one["ms_per_step"])
 
 
 def test_a_rank_that_dies_ends_the_whole_run():

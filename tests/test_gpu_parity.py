@@ -638,6 +638,8 @@ def test_native_rccl_exchange_on_one_rank(vio, hip_lib):
     w = vio.synth.make_window(700, seed=29, ragged=True)
     sb = vio.sharded.ShardedBackend(hip_lib, w, 0, 1, dist=None, torch_device="cuda", force_hook=True, exchange="native")
     assert sb.exchange == "native"
+    assert sb.ctx.comm_info() == (1, 0)                 # ncclCommCount / ncclCommUserRank of the library's communicator
+    assert hip_lib.context().comm_info() == (0, -1)     # no communicator: nothing to report
     rep = sb.solve(10)
     ps, ss, _ = sb.ctx.get_window()
     ref = hip_lib.context()

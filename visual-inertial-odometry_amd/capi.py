@@ -101,7 +101,7 @@ class VioLib:
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
-                "comm_unique_id", "comm_init", "comm_destroy", "get_stream", "batch_gn_iteration", "batch_solve", "get_host_timing",
+                "comm_unique_id", "comm_init", "comm_destroy", "comm_info", "get_stream", "batch_gn_iteration", "batch_solve", "get_host_timing",
                 "set_solve_order", "get_solve_order"]
     # diagnostic entry points: only in a build with -DVIO_DEBUG_ENTRY_POINTS (csrc/diag/libvio_hip_debug.so, the tests')
     HIP_DEBUG = ["debug_chain_solve"]
@@ -486,6 +486,12 @@ class VioContext:
         """Native RCCL exchange: id128 = the 128 bytes of rank 0's VioLib.comm_unique_id(), same on every rank."""
         buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
         self._ck(self.lib.fn["comm_init"](self.h, buf, C.c_int32(rank), C.c_int32(nranks)), "comm_init")
+
+    def comm_info(self):
+        """(ranks RCCL's communicator spans, this rank's index in it); (0, -1) without a native communicator"""
+        n, r = C.c_int32(), C.c_int32()
+        self._ck(self.lib.fn["comm_info"](self.h, C.byref(n), C.byref(r)), "comm_info")
+        return n.value, r.value
 
     def comm_destroy(self):
         self._ck(self.lib.fn["comm_destroy"](self.h), "comm_destroy")

@@ -714,6 +714,8 @@ struct RcclApi {
     int (*CommInitRank)(void **comm, int nranks, RcclId128 id, int rank) = nullptr;
     int (*CommDestroy)(void *comm) = nullptr;
     int (*AllGather)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, hipStream_t s) = nullptr;
+    int (*CommCount)(void *comm, int *count) = nullptr;
+    int (*CommUserRank)(void *comm, int *rank) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 
@@ -732,6 +734,8 @@ RcclApi *rccl_api(std::string &err) {
     *(void **)&api.CommDestroy = dlsym(api.lib, "ncclCommDestroy");
     *(void **)&api.AllGather = dlsym(api.lib, "ncclAllGather");
     *(void **)&api.GetErrorString = dlsym(api.lib, "ncclGetErrorString");
+    *(void **)&api.CommCount = dlsym(api.lib, "ncclCommCount");
+    *(void **)&api.CommUserRank = dlsym(api.lib, "ncclCommUserRank");
     if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
         err = "librccl.so lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather";
         dlclose(api.lib); api.lib = nullptr;
@@ -2075,6 +2079,23 @@ vio_status vio_comm_init(vio_ctx *c, const void *id128, int32_t rank, int32_t nr
     const int rc = api->CommInitRank(&c->comm, nranks, id, rank);
     if (rc != 0) { c->comm = nullptr; return fail(c, VIO_ERR_HIP, std::string("ncclCommInitRank: ") + (api->GetErrorString ? api->GetErrorString(rc) : "error")); }
     c->linearized = false;
+    return VIO_OK;
+}
+
+// What RCCL itself says about the communicator of the native exchange: the number of ranks it spans and this rank's place in it
+// (ncclCommCount / ncclCommUserRank) — the N > 1 bench line records them, so that a scaling record shows how many ranks the collective
+// really ran over.  No communicator (unsharded, or the hook exchange): 0 ranks.
+vio_status vio_comm_info(vio_ctx *c, int32_t *nranks_seen, int32_t *rank_seen) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    int n = 0, r = -1;
+    if (c->comm) {
+        std::string err;
+        RcclApi *api = rccl_api(err);
+        if (!api || !api->CommCount || !api->CommUserRank) return fail(c, VIO_ERR_HIP, "librccl.so lacks ncclCommCount / ncclCommUserRank");
+        if (api->CommCount(c->comm, &n) != 0 || api->CommUserRank(c->comm, &r) != 0) return fail(c, VIO_ERR_HIP, "ncclCommCount failed");
+    }
+    if (nranks_seen) *nranks_seen = n;
+    if (rank_seen) *rank_seen = r;
     return VIO_OK;
 }
 
