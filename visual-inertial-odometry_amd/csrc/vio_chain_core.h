@@ -148,16 +148,17 @@ __device__ __forceinline__ void ch_cc_term(const double *P, const ChLane &L, int
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * p1, -b1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * p2, -b2, acc, 0, 0, 0);
 }
-// Which camera tiles take the chain's terms level by level, and which later.  A tile (I,J) is first CONSUMED at the S phase of
-// camera step K = J (I > J: multiplied by M_J) or K = J - 1 (I == J: wave 0 updates it from registers and factors it); until then
-// additions to it commute.  Only the six tiles consumed by step 0 — column 0 and (1,1) — take the speed-bias chain's terms during
-// the chain (ch_cc_early: tasks 0..5); the other nine take all eleven blocks' terms in one go in the U phase before their
-// consumption (ch_cc_deferred), when fourteen waves have nothing else to do while wave 0 factors a 16 x 16 tile.
-__device__ __forceinline__ int ch_early_tile(int q) { return q == 0 ? 0 : (q == 1 ? 1 : (q == 2 ? 2 : (q == 3 ? 3 : (q == 4 ? 6 : 10)))); }    // (0,0) (1,0) (1,1) (2,0) (3,0) (4,0)
+// The camera tiles take the chain's terms LEVEL BY LEVEL, all fifteen of them (round 5; until then only the six tiles camera step 0
+// consumes did, the other nine took all eleven blocks' terms "in one go in the U phase before their consumption, when fourteen waves have
+// nothing to do while wave 0 factors a tile" — but those U phases then lasted as long as F, 3.3 - 4.3 k ticks of 33 chained products per tile,
+// and slowed F, which shares their matrix cores: tools/diag_chain_stamps.py).  During the chain the workers finish a phase in 2.1 k ticks of
+// the 3.3 k a level takes: the terms of the previous level's two blocks — two tiles a worker at most, and only those whose L tiles are both
+// non-zero — fit in what is left.  A tile is first CONSUMED at the S phase of camera step K = J (I > J) or K = J - 1 (I == J); until then
+// additions to it commute, and every tile's accumulation order is: chain blocks 0, 10, 1, 9, ..., 4, 6, 5, then the camera steps.
 __device__ __forceinline__ void ch_tile_ij(int task, int &I, int &J) { I = (task >= 1) + (task >= 3) + (task >= 6) + (task >= 10); J = task - I * (I + 1) / 2; }
-// early tile q: the terms of level pl (blocks pl and 10 - pl; pl == 5: block 5 alone), those whose two L tiles are non-zero
-__device__ __forceinline__ void ch_cc_early(double *P, const ChLane &L, int q, int pl, unsigned long long eff) {
-    const int task = ch_early_tile(q);
+// camera tile `task` (0..14, row-major in the lower triangle): the terms of level pl (blocks pl and 10 - pl; pl == 5: block 5 alone), those
+// whose two L tiles are non-zero
+__device__ __forceinline__ void ch_cc_early(double *P, const ChLane &L, int task, int pl, unsigned long long eff) {
     int I, J;
     ch_tile_ij(task, I, J);
     const bool ta = ch_bit(eff, pl, I) && ch_bit(eff, pl, J), tb = pl < 5 && ch_bit(eff, 10 - pl, I) && ch_bit(eff, 10 - pl, J);
@@ -336,11 +337,14 @@ __device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int 
         if (ch_bit(eff, 11 - LEV, wi)) ch_yc_tile(P, 11 - LEV, wi, lane);
     }
     if (CAM && LEV > 0) {
-        // the camera-block terms of the previous level, for the six tiles step 0 consumes: two each on three waves without a fused task
-        const int idle0 = (LEV < 4) ? 10 : 5;
-        if (wi >= idle0 && wi < idle0 + 3) {
-            ch_cc_early(P, L, 2 * (wi - idle0), LEV - 1, eff);
-            ch_cc_early(P, L, 2 * (wi - idle0) + 1, LEV - 1, eff);
+        // the camera-block terms of the previous level, all fifteen tiles: the workers without a fused task take two or three each, the
+        // busy ones one each behind their task
+        if (LEV < 4) {
+            if (wi >= 10 && wi < 13) { for (int q = 0; q < 3; ++q) ch_cc_early(P, L, 3 * (wi - 10) + q, LEV - 1, eff); }      // tiles 0..8
+            else if (wi < 6) ch_cc_early(P, L, 9 + wi, LEV - 1, eff);                                                        // tiles 9..14
+        } else if (wi >= 5 && wi < 13) {
+            ch_cc_early(P, L, 2 * (wi - 5), LEV - 1, eff);                                                                   // tiles 0..14, two each
+            if (2 * (wi - 5) + 1 < 15) ch_cc_early(P, L, 2 * (wi - 5) + 1, LEV - 1, eff);
         }
     }
     (void)first_cc;
@@ -436,10 +440,10 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
     const int lofs = r16 * PS_TROW + g;      // A image of a 16 x 17 tile: row r16, k = g + 4q
     const int cofs = g * PS_TROW + r16;      // C / B image: row g + 4v, column r16
     if (SPLIT) {
-        if (uwave <= 5) {
-            // the six tiles camera step 0 consumes — (0,0) (1,0) (1,1) (2,0) (3,0) (4,0) — take all eleven blocks' terms now
+        if (uwave < 15) {
+            // every camera tile takes all eleven blocks' terms now, tile (0,0) on the wave that factors it next
             int I, J;
-            ch_tile_ij(ch_early_tile(uwave), I, J);
+            ch_tile_ij(uwave, I, J);
             double *tc = P + ch_cc(I, J) + cofs;
             ps_v4d acc;
 #pragma unroll
@@ -448,13 +452,15 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
 #pragma unroll
             for (int v = 0; v < 4; ++v) tc[4 * PS_TROW * v] = acc[v];
             if (uwave == 0) ch_factor_tile(P + ch_cc(0, 0), sMc, sD + CH_YC, 16, lane);
-        } else if (uwave >= 6 && uwave <= 10) {
-            // y_C -= L_SC[e] w_e for the rows of camera tile t, block after block in the chain's order
-            const int t = uwave - 6;
+            else if (uwave >= 10) {
+                // y_C -= L_SC[e] w_e for the rows of camera tile t, block after block in the chain's order (the waves of the last tile row:
+                // their tiles couple to few blocks)
+                const int t = uwave - 10;
 #pragma unroll
-            for (int i = 0; i < 11; ++i) {
-                const int e = (i == 10) ? 5 : ((i & 1) ? 10 - (i >> 1) : (i >> 1));
-                if (ch_bit(eff, e, t)) ch_yc_tile(P, e, t, lane);
+                for (int i = 0; i < 11; ++i) {
+                    const int e = (i == 10) ? 5 : ((i & 1) ? 10 - (i >> 1) : (i >> 1));
+                    if (ch_bit(eff, e, t)) ch_yc_tile(P, e, t, lane);
+                }
             }
         }
     } else
@@ -470,8 +476,8 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
         ch_factor_tile(P + ch_cc(0, 0), sMc, sD + CH_YC, 16, lane);
     } else if (uwave == 15) {
         ch_yc_term<5>(P, lane);
-    } else if (uwave >= 1 && uwave <= 5) {
-        ch_cc_early(P, L, uwave, 5, eff);      // (1,0) (1,1) (2,0) (3,0) (4,0)
+    } else {
+        ch_cc_early(P, L, uwave, 5, eff);      // tiles 1..14: block 5's term
     }
     if (uwave == 0) CH_STAMP(88);
     __syncthreads();
@@ -548,7 +554,11 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
         } else {
             const int ntile = nk * (nk + 1) / 2;
             const int nitem = ntile + 1;
-            for (int t = uwave; t < nitem; t += 15) {
+            // (waves 4, 8 and 12 share wave 0's SIMD — its vector ALU and its matrix core: they sit the phase out, F(K+1) is the critical path
+            // and the ten tasks of the widest step fit the other twelve waves in one round)
+            const bool same_simd = (uwave & 3) == 0;
+            const int widx = uwave - 1 - (uwave > 4) - (uwave > 8) - (uwave > 12);          // 0..11 over waves 1,2,3,5,6,7,9,10,11,13,14,15
+            for (int t = same_simd ? nitem : 1 + widx; t < nitem; t += 12) {
                 if (t < ntile) {
                     const int ii = (t >= 1) + (t >= 3) + (t >= 6), jj = t - ii * (ii + 1) / 2;
                     const int ti = K + 1 + ii, tj = K + 1 + jj;
@@ -558,8 +568,6 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
                     ps_v4d acc;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { av[q] = ta[4 * q]; bv[q] = tb[4 * q]; acc[q] = tc[4 * PS_TROW * q]; dk[q] = sD[d0 + g + 4 * q]; }
-                    // the speed-bias chain's terms, if this tile is consumed next (off-diagonal: at step tj; diagonal: at step tj - 1)
-                    if (tj >= 1 && !(ti == 1 && tj == 1) && K == (ti == tj ? tj - 2 : tj - 1)) ch_cc_deferred_terms(P, L, ti, tj, acc, eff);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q] * dk[q], -bv[q], acc, 0, 0, 0);
