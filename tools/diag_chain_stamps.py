@@ -37,6 +37,9 @@ for lev in range(6):
     print("  level %d: wave 0 done %6d (+%5d) | past the barrier %6d (+%5d)      worker: phase %d done at %6d" % (lev, a[0], a[0] - prev, a[1], a[1] - a[0], lev, s[112 + lev]))
     prev = a[1]
 print("  phase 2, every worker (waves 2..15) done at:", [int(v) for v in s[142:156]])
+print("  phase 4, every worker done at:", [int(v) for v in s[182:196]])
+print("  phase 5a: wave 0: eff mask %d, fused %d | wave 1: CC(0,0) level-4 terms %d" % tuple(int(v) for v in s[233:236]))
+print("  phase 5, every worker done at:", [int(v) for v in s[202:216]])
 print("  phase 5 + barrier: %6d (+%5d)" % (s[87], s[87] - prev))
 prev = s[87]
 print("camera block:")

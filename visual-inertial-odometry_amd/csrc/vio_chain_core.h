@@ -67,34 +67,27 @@ __device__ __forceinline__ unsigned long long ch_eff_mask(const double *P, int l
 }
 __device__ __forceinline__ bool ch_bit(unsigned long long eff, int e, int t) { return (eff >> (5 * e + t)) & 1ull; }
 
-// the chain wave's work of one level: F(e), pivots, L_SO[e] = (SO[e] M_e) / d formed transposed — the accumulator is the operand
-// image of the update that follows — and (upd) SD[n] -= (L D) L^T from registers.  e == 5: F only.
-__device__ __forceinline__ void ch_chain_level(double *P, const ChLane &L, int e, int n, bool upd, int lane) {
+// the chain wave's work of one level: F(e) with the rows of SO[e] riding (they come out as L_SO[e] = SO[e] L_ee^-T D_e^-1), the pivots, and
+// (upd) SD[n] -= (L D) L^T.  e == 5: F only.  `scr`: 64 doubles of scratch of this wave's own.
+// (Until round 5 L_SO was formed behind F as the product (SO M_e) / d on the matrix core and the update followed from registers: three
+// products, three reciprocals and a store more on the chain's critical path, 0.7 k ticks a level.)
+__device__ __forceinline__ void ch_chain_level(double *P, const ChLane &L, int e, int n, bool upd, int lane, double *scr) {
     double *sD = P + CH_OFF_D;
-    ch_factor<9, CH_TS, CH_TS>((lds_double *)(P + ch_sd(e)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(e)), lane);
+    if (e == 5) ch_factor<9, CH_TS, CH_TS>((lds_double *)(P + ch_sd(e)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(e)), lane);
+    else ch_factor<9, CH_TS, CH_TS, true>((lds_double *)(P + ch_sd(e)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(e)), lane,
+                                          (lds_double *)(P + ch_so(e)), (lds_double *)scr);
     if (lane < 9) sD[e * 16 + lane] = P[ch_sd(e) + lane * (CH_TS + 1)];
-    if (e == 5) return;
-    double *tt = P + ch_so(e);
-    const double *mm = P + ch_sm(e);
+    if (e == 5 || !upd) return;
+    const double *tt = P + ch_so(e);
     double *td = P + ch_sd(n);
     const double a0 = tt[L.oA0], a1 = tt[L.oA0 + 4], a2 = tt[L.oA2];
-    const double b0 = mm[L.oM0], b1 = mm[L.oM0 + 4 * CH_TS], b2 = mm[L.oM2];
     const double p0 = sD[e * 16 + L.g], p1 = sD[e * 16 + L.g + 4], p2 = sD[e * 16 + L.g + 8];
-    ps_v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {td[L.oM0], td[L.oM0 + 4 * CH_TS], td[L.oM0 + 8 * CH_TS], 0.0};
+    ps_v4d acc2 = {td[L.oM0], td[L.oM0 + 4 * CH_TS], td[L.oM0 + 8 * CH_TS], 0.0};
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, a0, acc, 0, 0, 0);       // (A M)^T: [k = g + 4v][row r16]
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, a1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(b2, a2, acc, 0, 0, 0);
-    const double q0 = d_fast_rcp(p0), q1 = d_fast_rcp(p1), q2 = d_fast_rcp(p2);
-    const double l0 = d_div(acc[0], p0, q0), l1 = d_div(acc[1], p1, q1);
-    const double l2 = (L.g == 0) ? d_div(acc[2], p2, q2) : 0.0, u2 = (L.g == 0) ? acc[2] : 0.0;
-    if (L.r9) { tt[L.oA0] = l0; tt[L.oA0 + 4] = l1; tt[L.oA2] = l2; }
-    if (upd) {
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[0], -l0, acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(acc[1], -l1, acc2, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(u2, -l2, acc2, 0, 0, 0);
-        if (L.r9) { td[L.oM0] = acc2[0]; td[L.oM0 + 4 * CH_TS] = acc2[1]; if (L.g == 0) td[L.oM0 + 8 * CH_TS] = acc2[2]; }
-    }
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * p0, -a0, acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * p1, -a1, acc2, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * p2, -a2, acc2, 0, 0, 0);
+    if (L.r9) { td[L.oM0] = acc2[0]; td[L.oM0 + 4 * CH_TS] = acc2[1]; if (L.g == 0) td[L.oM0 + 8 * CH_TS] = acc2[2]; }
 }
 // F on a camera tile (np = 16, or 8 for the last one): M to sM, the pivots to sDp[0 .. np)
 __device__ __forceinline__ void ch_factor_tile(double *tile, double *sM, double *sDp, int np, int lane) {
@@ -170,6 +163,20 @@ __device__ __forceinline__ void ch_cc_early(double *P, const ChLane &L, int task
     if (tb) ch_cc_term(P, L, 10 - pl, I, J, acc);
     tc[0] = acc[0]; tc[4 * PS_TROW] = acc[1]; tc[8 * PS_TROW] = acc[2]; tc[12 * PS_TROW] = acc[3];
 }
+// camera tile `task`: the last three blocks' terms in one go — level 4 (blocks 4, 6), then block 5 (the start of the camera block, below)
+__device__ __forceinline__ void ch_cc_last3(double *P, const ChLane &L, int task, unsigned long long eff) {
+    int I, J;
+    ch_tile_ij(task, I, J);
+    const bool t4 = ch_bit(eff, 4, I) && ch_bit(eff, 4, J), t6 = ch_bit(eff, 6, I) && ch_bit(eff, 6, J), t5 = ch_bit(eff, 5, I) && ch_bit(eff, 5, J);
+    if (!t4 && !t6 && !t5) return;
+    double *tc = P + ch_cc(0, 0) + task * PS_TS + L.g * PS_TROW + L.r16;
+    ps_v4d acc;
+    acc[0] = tc[0]; acc[1] = tc[4 * PS_TROW]; acc[2] = tc[8 * PS_TROW]; acc[3] = tc[12 * PS_TROW];
+    if (t4) ch_cc_term(P, L, 4, I, J, acc);
+    if (t6) ch_cc_term(P, L, 6, I, J, acc);
+    if (t5) ch_cc_term(P, L, 5, I, J, acc);
+    tc[0] = acc[0]; tc[4 * PS_TROW] = acc[1]; tc[8 * PS_TROW] = acc[2]; tc[12 * PS_TROW] = acc[3];
+}
 // acc (C image of tile (I,J)) -= the terms of the speed-bias blocks whose L tiles I and J are both non-zero, in elimination order
 // (0, 10, 1, 9, ..., 4, 6, 5).  The blocks are compacted into a list (4 bits each, scalar); the operands of block i + 2 are requested
 // before the products of block i are issued (three register sets: an LDS round trip takes longer than one block's three products).
@@ -229,9 +236,12 @@ __device__ __forceinline__ void ch_yc_term(double *P, int lane) {
         const int i = pass * 64 + lane;
         if (i < 80) {
             const double *l = P + ch_sc(E, 0) + (i >> 4) * CH_SCSZ + (i & 15) * CH_TS;
-            double y = sY[CH_YC + i];
+            double y = sY[CH_YC + i], lv[9];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) y = fma(-l[k], w[k], y);
+            for (int k = 0; k < 9; ++k) lv[k] = l[k];
+            __builtin_amdgcn_sched_barrier(0);       // (every operand requested before the chain starts: left alone, each step waits for its own load)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) y = fma(-lv[k], w[k], y);
             sY[CH_YC + i] = y;
         }
     }
@@ -248,8 +258,12 @@ __device__ __forceinline__ void ch_rhs_phase(double *P, int lane) {
     double w = 0.0;
     if (on) {
         const double *m = P + ch_sm(e) + k;
+        double yv[9], mv[9];
 #pragma unroll
-        for (int j = 0; j < 9; ++j) w = fma(sY[e * 16 + j], m[j * CH_TS], w);        // column k of M_e (zero below its diagonal)
+        for (int j = 0; j < 9; ++j) { yv[j] = sY[e * 16 + j]; mv[j] = m[j * CH_TS]; }
+        __builtin_amdgcn_sched_barrier(0);           // (operands first, then the chain — see ch_yc_term)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) w = fma(yv[j], mv[j], w);        // column k of M_e (zero below its diagonal)
     }
     __builtin_amdgcn_wave_barrier();
     if (on) sY[e * 16 + k] = w;
@@ -259,18 +273,22 @@ __device__ __forceinline__ void ch_rhs_phase(double *P, int lane) {
             const int n = half == 0 ? eA + 1 : eB - 1;
             if (on) {
                 const double *l = P + ch_so(e) + k * CH_TS;
-                double y = sY[n * 16 + k];
+                double y = sY[n * 16 + k], lv[9], wv[9];
 #pragma unroll
-                for (int j = 0; j < 9; ++j) y = fma(-l[j], sY[e * 16 + j], y);
+                for (int j = 0; j < 9; ++j) { lv[j] = l[j]; wv[j] = sY[e * 16 + j]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 9; ++j) y = fma(-lv[j], wv[j], y);
                 sY[n * 16 + k] = y;
             }
         } else if (lane < 9) {          // both chains end in block 5
             const double *la = P + ch_so(4) + k * CH_TS, *lb = P + ch_so(6) + k * CH_TS;
-            double y = sY[5 * 16 + k];
+            double y = sY[5 * 16 + k], lv[18], wv[18];
 #pragma unroll
-            for (int j = 0; j < 9; ++j) y = fma(-la[j], sY[4 * 16 + j], y);
+            for (int j = 0; j < 9; ++j) { lv[j] = la[j]; wv[j] = sY[4 * 16 + j]; lv[9 + j] = lb[j]; wv[9 + j] = sY[6 * 16 + j]; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 9; ++j) y = fma(-lb[j], sY[6 * 16 + j], y);
+            for (int j = 0; j < 18; ++j) y = fma(-lv[j], wv[j], y);
             sY[5 * 16 + k] = y;
         }
     }
@@ -280,9 +298,12 @@ __device__ __forceinline__ void ch_yc_tile(double *P, int e, int t, int lane) {
     if (lane < 16) {
         double *sY = P + CH_OFF_Y;
         const double *l = P + ch_sc(e, 0) + t * CH_SCSZ + lane * CH_TS;
-        double y = sY[CH_YC + 16 * t + lane];
+        double y = sY[CH_YC + 16 * t + lane], lv[9], wv[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) y = fma(-l[k], sY[e * 16 + k], y);
+        for (int k = 0; k < 9; ++k) { lv[k] = l[k]; wv[k] = sY[e * 16 + k]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) y = fma(-lv[k], wv[k], y);
         sY[CH_YC + 16 * t + lane] = y;
     }
 }
@@ -293,6 +314,9 @@ __device__ __forceinline__ void ch_yc_tile(double *P, int e, int t, int lane) {
 template <int LEV, bool CAM = true>
 __device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int wi, int lane, unsigned long long eff) {
     constexpr int eA = LEV, eB = 10 - LEV;
+#ifdef CH_DIAG_IDLE_SIMDS
+    if ((((wi + 2) & 3) == 0) || (CH_DIAG_IDLE_SIMDS > 1 && ((wi + 2) & 3) == 1)) return;      // timing experiment only: wrong results
+#endif
     if (wi == 13) { ch_rhs_phase<LEV>(P, lane); return; }
     int first_cc, busy;
     if (LEV < 4) {
@@ -337,14 +361,16 @@ __device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int 
         if (ch_bit(eff, 11 - LEV, wi)) ch_yc_tile(P, 11 - LEV, wi, lane);
     }
     if (CAM && LEV > 0) {
-        // the camera-block terms of the previous level, all fifteen tiles: the workers without a fused task take two or three each, the
-        // busy ones one each behind their task
+        // the camera-block terms of the previous level, all fifteen tiles: the workers without a fused task take two each, the busy ones
+        // one each behind their task
         if (LEV < 4) {
-            if (wi >= 10 && wi < 13) { for (int q = 0; q < 3; ++q) ch_cc_early(P, L, 3 * (wi - 10) + q, LEV - 1, eff); }      // tiles 0..8
-            else if (wi < 6) ch_cc_early(P, L, 9 + wi, LEV - 1, eff);                                                        // tiles 9..14
-        } else if (wi >= 5 && wi < 13) {
-            ch_cc_early(P, L, 2 * (wi - 5), LEV - 1, eff);                                                                   // tiles 0..14, two each
-            if (2 * (wi - 5) + 1 < 15) ch_cc_early(P, L, 2 * (wi - 5) + 1, LEV - 1, eff);
+            if (wi >= 10 && wi < 13) { ch_cc_early(P, L, 2 * (wi - 10), LEV - 1, eff); ch_cc_early(P, L, 2 * (wi - 10) + 1, LEV - 1, eff); }   // tiles 0..5
+            else if (wi < 9) ch_cc_early(P, L, 6 + wi, LEV - 1, eff);                                                                         // tiles 6..14
+        } else if (wi < 5) {
+            ch_cc_early(P, L, 10 + wi, LEV - 1, eff);                                                                        // tiles 10..14
+        } else if (wi < 13) {
+            ch_cc_early(P, L, wi - 5, LEV - 1, eff);                                                                         // tiles 0..7
+            if (wi < 7) ch_cc_early(P, L, wi + 3, LEV - 1, eff);                                                             // tiles 8, 9
         }
     }
     (void)first_cc;
@@ -376,6 +402,12 @@ __device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, co
     double *sD = P + CH_OFF_D;
     (void)dbg; (void)t_start__;
     unsigned long long eff = 0ull;
+#ifndef CH_NO_PRIO
+    // the waves on the critical path ask the instruction arbiter for priority over the waves of their SIMD: the chain waves (F, the
+    // level's products) and the right-hand-side wave, whose dependent fp64 chains otherwise queue behind the workers' matrix-core streams
+    if (uwave < 2) __builtin_amdgcn_s_setprio(3);
+    else if (uwave == 15) __builtin_amdgcn_s_setprio(2);
+#endif
     if (uwave < 2) {
         // the two chain waves: wave 0 blocks 0..4 and then 5, wave 1 blocks 10..6 (one copy of the code, the block a run-time value)
         const int dir = uwave == 0 ? 1 : -1;
@@ -394,13 +426,22 @@ __device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, co
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * p2, -a2, acc, 0, 0, 0);
                     if (r9) { td[L.oM0] = acc[0]; td[L.oM0 + 4 * CH_TS] = acc[1]; if (g == 0) td[L.oM0 + 8 * CH_TS] = acc[2]; }
                 }
-                ch_chain_level(P, L, e, e + dir, !(uwave == 1 && lev == 4), lane);
+                ch_chain_level(P, L, e, e + dir, !(uwave == 1 && lev == 4), lane, P + CH_OFF_X + 64 * uwave);
                 if (uwave == 0) CH_STAMP(64 + 4 * lev);
             }
             __syncthreads();
             if (uwave == 0) CH_STAMP(65 + 4 * lev);
         }
         eff = ch_eff_mask(P, lane);
+        if (uwave == 0) CH_STAMP(233);
+        if (CAM) {
+            // phase 5a (see the workers'): wave 0 forms L_SC[5][0] itself — the tile its CC(0,0) waits for —, wave 1 gives CC(0,0) the terms
+            // of level 4
+            if (uwave == 0) { if (ch_bit(eff, 5, 0)) { ps_v4d dummy = {0.0, 0.0, 0.0, 0.0}; ch_fused<5, false>(P, L, 0, dummy); } }
+            else ch_cc_early(P, L, 0, 4, eff);
+            if (uwave == 0) CH_STAMP(234);
+            if (uwave == 1) CH_STAMP(235);
+        }
         __syncthreads();
     } else {
         const int wi = uwave - 2;
@@ -415,9 +456,23 @@ __device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, co
         __syncthreads();
         ch_worker_phase<3, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(115);
         __syncthreads();
-        ch_worker_phase<4, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(116);
+        ch_worker_phase<4, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(116); CH_STAMP(180 + uwave);
         __syncthreads();
-        ch_worker_phase<5, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(117);
+        if (CAM) {
+            // Phase 5a, a short one: the five L_SC[5][t] (t = 0 on wave 0), w_5, and the right-hand side's terms of level 4.  Everything else
+            // that used to sit between the last level and the camera block — the camera tiles' terms of level 4 and of block 5, 3.7 k ticks of
+            // matrix-core work in front of F(0) — runs beside F(0) (ch_camera_solve's first phase): every wave one tile, three terms.
+            if (wi >= 1 && wi < 5) { if (ch_bit(eff, 5, wi)) { ps_v4d dummy = {0.0, 0.0, 0.0, 0.0}; ch_fused<5, false>(P, L, wi, dummy); } }
+            else if (wi == 13) ch_rhs_phase<5>(P, lane);
+            else if (wi == 0 || (wi >= 5 && wi < 9)) {
+                const int t = wi == 0 ? 0 : wi - 4;
+                if (ch_bit(eff, 4, t)) ch_yc_tile(P, 4, t, lane);
+                if (ch_bit(eff, 6, t)) ch_yc_tile(P, 6, t, lane);
+            }
+        } else {
+            ch_worker_phase<5, CAM>(P, L, wi, lane, eff);
+        }
+        if (uwave == 2) CH_STAMP(117); CH_STAMP(200 + uwave);
         __syncthreads();
     }
     if (uwave == 0) CH_STAMP(87);
@@ -440,6 +495,10 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
     const int lofs = r16 * PS_TROW + g;      // A image of a 16 x 17 tile: row r16, k = g + 4q
     const int cofs = g * PS_TROW + r16;      // C / B image: row g + 4v, column r16
     if (SPLIT) {
+#ifndef CH_NO_PRIO
+        if (uwave == 0) __builtin_amdgcn_s_setprio(3);
+        else if (uwave == 15) __builtin_amdgcn_s_setprio(2);
+#endif
         if (uwave < 15) {
             // every camera tile takes all eleven blocks' terms now, tile (0,0) on the wave that factors it next
             int I, J;
@@ -477,7 +536,16 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
     } else if (uwave == 15) {
         ch_yc_term<5>(P, lane);
     } else {
-        ch_cc_early(P, L, uwave, 5, eff);      // tiles 1..14: block 5's term
+        // tiles 1..14: the terms of level 4 and of block 5.  Waves 4, 8 and 12 share wave 0's SIMD: they sit it out (F(0) is the critical
+        // path), their tiles go to waves 1, 2, 3 as a second one
+#ifndef CH_PREAMBLE_ALL_WAVES
+        if ((uwave & 3) != 0) {
+            ch_cc_last3(P, L, uwave, eff);
+            if (uwave <= 3) ch_cc_last3(P, L, 4 * uwave, eff);
+        }
+#else
+        ch_cc_last3(P, L, uwave, eff);
+#endif
     }
     if (uwave == 0) CH_STAMP(88);
     __syncthreads();
@@ -531,8 +599,12 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
         } else if (uwave == 15) {
             double y = 0.0;
             if (lane < 16) {
+                double yv[16], mv[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) y = fma(sY[d0 + j], sMc[j * PS_TROW + lane], y);
+                for (int j = 0; j < 16; ++j) { yv[j] = sY[d0 + j]; mv[j] = sMc[j * PS_TROW + lane]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) y = fma(yv[j], mv[j], y);
             }
             __builtin_amdgcn_wave_barrier();
             if (lane < 16) sY[d0 + lane] = y;
@@ -578,9 +650,12 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
                     const int c = 16 * (K + 1) + lane;
                     if (c < 80) {
                         const double *l = P + ch_cc(c >> 4, K) + (c & 15) * PS_TROW;
-                        double y = sY[CH_YC + c];
+                        double y = sY[CH_YC + c], lv[16], wv[16];
 #pragma unroll
-                        for (int kk = 0; kk < 16; ++kk) y = fma(-l[kk], sY[d0 + kk], y);
+                        for (int kk = 0; kk < 16; ++kk) { lv[kk] = l[kk]; wv[kk] = sY[d0 + kk]; }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) y = fma(-lv[kk], wv[kk], y);
                         sY[CH_YC + c] = y;
                     }
                 }
@@ -602,7 +677,10 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
     //   phase Y   the owners: v_e = w_e / d_e - sum_t L_SC[e][t]^T x_C[t] (lane = (k, rows q mod 4), the quarters added in a fixed order),
     //             g_e = M_e v_e (x_5 = g_5); waves 11 / 12 request the rows of G of their chain.
     //   phase Z   waves 11 / 12 walk the two chains x_e = g_e - G_e x_succ(e) (e = 4..0, 6..10) out of registers, no barriers.
-    {
+ {
+#ifndef CH_NO_PRIO
+        if (uwave >= 11 && uwave <= 13) __builtin_amdgcn_s_setprio(2);      // the chain walkers and the wave of the trial poses
+#endif
         const int k9 = min(r16, 8);
         if (uwave == 15) {
             const int K = g;                                                         // the tile of this 16-lane row (0..3)
@@ -646,13 +724,21 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
         } else if (uwave < 11 && uwave != 5) {
             const int e = uwave;
             const double *m = P + ch_sm(e) + k9 * CH_TS, *so = P + ch_so(e);
-            double gk[3];
+            double gk[3], mv[9], sv[3][9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) mv[i] = m[i];
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
                 const int j = min(g + 4 * v, 8);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) sv[v][i] = so[j * CH_TS + i];
+            }
+            __builtin_amdgcn_sched_barrier(0);       // (operands first: left alone, every step of a chain waits for its own load)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
                 double sum = 0.0;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) sum = fma(m[i], so[j * CH_TS + i], sum);
+                for (int i = 0; i < 9; ++i) sum = fma(mv[i], sv[v][i], sum);
                 gk[v] = sum;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -697,14 +783,22 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
                 CH_STAMP(171);
             } else if (uwave < 11) {
                 const int e = uwave;
-                double sacc = 0.0;
+                double sacc = 0.0, lv[5][4], xv[5][4];
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
                     if (ch_bit(eff, e, t)) {
                         const double *src = P + ch_sc(e, t) + g * CH_TS + k9;
                         const double *xj = sX + CH_YC + 16 * t + g;
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) sacc = fma(src[4 * v * CH_TS], xj[4 * v], sacc);
+                        for (int v = 0; v < 4; ++v) { lv[t][v] = src[4 * v * CH_TS]; xv[t][v] = xj[4 * v]; }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    if (ch_bit(eff, e, t)) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) sacc = fma(lv[t][v], xv[t][v], sacc);
                     }
                 }
                 double *scr = P + CH_OFF_SD;           // (the diagonal blocks of the chain are dead by now)
@@ -729,7 +823,7 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
             if (uwave == 0) CH_STAMP(174);
         }
         if (uwave == 0) CH_STAMP(63);
-        __syncthreads();
+        d_lds_barrier();              // (mid2's stores — the pair table of the trial states — drain under what follows: nobody reads them in this kernel)
     }
 }
 

@@ -116,17 +116,24 @@ __device__ __forceinline__ double d_div(double a, double d, double r) {
 // divisions and a pivot count: lanes 16..31 carry the rows of the identity (read from sI, row stride TS) and end up with M = L^-T
 // (written to M, row stride MS, entries [r][c] for r, c < NP only).  After it: tile[TS j + c] = U(c, j) = L(c, j) d_j for c >= j
 // (the pivots on the diagonal).
-template <int NP, int TS, int MS>
-__device__ __noinline__ void ch_factor(lds_double *tile, lds_double *sI, lds_double *M, int lane) {
+// RIDE: the third 16-lane row carries the rows of ANOTHER tile through the same column operations — `rtile` (row stride TS), a block
+// of rows below the diagonal block in the same block column — and leaves l = a / d of every pivot in place of the entry: the tile
+// comes out as L (what (A M) / d gives) without a product, a reciprocal or a second pass; `scratch` = 64 doubles nobody reads (the
+// stores a lane has no use for go there: one instruction stream for all four rows of lanes).
+template <int NP, int TS, int MS, bool RIDE = false>
+__device__ __noinline__ void ch_factor(lds_double *tile, lds_double *sI, lds_double *M, int lane, lds_double *rtile = nullptr, lds_double *scratch = nullptr) {
     asm volatile("" : "+v"(tile));
     const bool ident = (lane >> 4) == 1;
+    const bool ride = RIDE && (lane >> 4) == 2;
     const int row = min(lane & 15, NP - 1);           // lanes past the block repeat its last row (identical stores)
-    lds_double *p0 = (ident ? sI : tile) + row * TS;
+    lds_double *p0 = (ident ? sI : (ride ? rtile : tile)) + row * TS;
     double a0[NP], u[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) a0[j] = p0[j];
-    lds_double *wp = ident ? M + row * MS : tile + row;
-    const int ws = ident ? 1 : TS;
+    lds_double *wp = ident ? M + row * MS : (ride ? scratch + lane : tile + row);
+    const int ws = ident ? 1 : (ride ? 0 : TS);
+    lds_double *lp = ride ? rtile + row * TS : scratch + lane;
+    const int ls = ride ? 1 : 0;
     __builtin_amdgcn_sched_barrier(0);   // every row is in registers before the first publish overwrites the tile
     wp[0] = a0[0];
     double d = d_readlane(a0[0], 0);
@@ -144,6 +151,7 @@ __device__ __noinline__ void ch_factor(lds_double *tile, lds_double *sI, lds_dou
             wp[0] = a0[j + 1];
             d = d_readlane(a0[j + 1], j + 1);
         }
+        if (RIDE) { lp[0] = l0; lp += ls; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = j + 2; c < NP; ++c) {
@@ -527,7 +535,7 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         // the trial states: poses from wave 13's copy, speed-bias = current + dx
         if (tid >= 128 && tid < 128 + 84) sState[tid - 128] = P[CH_OFF_CC + tid - 128];
         else if (tid >= 256 && tid < 256 + 99) { const int e = tid - 256; sState[STATE_SB + e] += sX[(e / 9) * 16 + (e % 9 < 3 ? 6 + e % 9 : (e % 9 < 6 ? e % 9 : e % 9 - 6))]; }
-        __syncthreads();
+        d_lds_barrier();
         if (tid >= 192 && tid < 192 + n) T.dx[tid - 192] = sDx[tid - 192];
         if (tid >= 384 && tid < 384 + STATE_STRIDE) T.state[trial * STATE_STRIDE + (tid - 384)] = sState[tid - 384];
         CH_OUT(3);
