@@ -13,6 +13,9 @@
 // lanes with k > 8 read the tile's padding column (column 9, zero in the image and never written), so no load is predicated.
 #ifndef VIO_CHAIN_CORE_H
 #define VIO_CHAIN_CORE_H
+#ifndef CH_DIAG_SKIP
+#define CH_DIAG_SKIP 0          // timing experiments only (tools/build_diag.sh <name> -DCH_DIAG_SKIP=n): the named part is left out, the results are wrong
+#endif
 
 #ifdef VIO_STAMPS
 #define CH_STAMP(slot) do { if (dbg && (tid & 63) == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[slot] = __builtin_amdgcn_s_memtime() - t_start__; } } while (0)
@@ -90,10 +93,14 @@ __device__ __forceinline__ void ch_chain_level(double *P, const ChLane &L, int e
     if (L.r9) { td[L.oM0] = acc2[0]; td[L.oM0 + 4 * CH_TS] = acc2[1]; if (L.g == 0) td[L.oM0 + 8 * CH_TS] = acc2[2]; }
 }
 // F on a camera tile (np = 16, or 8 for the last one): M to sM, the pivots to sDp[0 .. np)
+// np == 2: the last tile when the extrinsic is fixed (vio_config.ext_fixed, the reference's ESTIMATE_EXTRINSIC = 0): its variables 2..7
+// are the extrinsic's — rows without an entry off the diagonal (no extrinsic block in the plan, the prior's masked: d_hs_rest), lambda
+// on it — so their six pivots are the diagonal as it stands and their rows of L and M the identity's: two pivots instead of eight.
 __device__ __forceinline__ void ch_factor_tile(double *tile, double *sM, double *sDp, int np, int lane) {
     if (np == 16) ch_factor<16, PS_TROW, PS_TROW>((lds_double *)tile, (lds_double *)(dyn_smem + CH_OFF_I16), (lds_double *)sM, lane);
-    else ch_factor<8, PS_TROW, PS_TROW>((lds_double *)tile, (lds_double *)(dyn_smem + CH_OFF_I16), (lds_double *)sM, lane);
-    if (lane < np) sDp[lane] = tile[lane * (PS_TROW + 1)];
+    else if (np == 8) ch_factor<8, PS_TROW, PS_TROW>((lds_double *)tile, (lds_double *)(dyn_smem + CH_OFF_I16), (lds_double *)sM, lane);
+    else ch_factor<2, PS_TROW, PS_TROW>((lds_double *)tile, (lds_double *)(dyn_smem + CH_OFF_I16), (lds_double *)sM, lane);
+    if (lane < (np == 2 ? 8 : np)) sDp[lane] = tile[lane * (PS_TROW + 1)];
 }
 
 // a worker's fused task: L_SC[E][t] = (SC[E][t] M_E) / d (transposed product), stored; with FILL, acc2 (the C image of SC[N][t],
@@ -485,7 +492,7 @@ __device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, co
 // (0, 10, 1, 9, ..., 4, 6, 5: the same accumulations, bit for bit).
 template <bool SPLIT, typename Mid1, typename Mid2>
 __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const ChLane &L, const unsigned long long eff, Mid1 mid1, Mid2 mid2,
-                                                unsigned long long *dbg, unsigned long long t_start__) {
+                                                unsigned long long *dbg, unsigned long long t_start__, const bool ext_trivial = false) {
     const int lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = L.r16, g = L.g;
@@ -619,11 +626,11 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
             if (K + 1 == 4) {
                 // the last tile has 8 variables: M starts as the identity, rows / columns 8..15 stay that way
                 for (int i = lane; i < PS_TS; i += 64) sMc[i] = (i / PS_TROW == i % PS_TROW) ? 1.0 : 0.0;
-                ch_factor_tile(P + ch_cc(4, 4), sMc, sD + CH_YC + 64, 8, lane);
+                ch_factor_tile(P + ch_cc(4, 4), sMc, sD + CH_YC + 64, ext_trivial ? 2 : 8, lane);
             } else {
                 ch_factor_tile(P + ch_cc(K + 1, K + 1), sMc, sD + d0 + 16, 16, lane);
             }
-        } else {
+        } else if (CH_DIAG_SKIP != 5) {
             const int ntile = nk * (nk + 1) / 2;
             const int nitem = ntile + 1;
             // (waves 4, 8 and 12 share wave 0's SIMD — its vector ALU and its matrix core: they sit the phase out, F(K+1) is the critical path
@@ -682,7 +689,7 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
         if (uwave >= 11 && uwave <= 13) __builtin_amdgcn_s_setprio(2);      // the chain walkers and the wave of the trial poses
 #endif
         const int k9 = min(r16, 8);
-        if (uwave == 15) {
+        if (uwave == 15 && CH_DIAG_SKIP != 3) {
             const int K = g;                                                         // the tile of this 16-lane row (0..3)
             double mw[16], ucol[16];
             const double dd = sD[CH_YC + 16 * K + r16];
@@ -721,7 +728,7 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
                     asm volatile("" ::: "memory");
                 }
             }
-        } else if (uwave < 11 && uwave != 5) {
+        } else if (uwave < 11 && uwave != 5 && CH_DIAG_SKIP != 4) {
             const int e = uwave;
             const double *m = P + ch_sm(e) + k9 * CH_TS, *so = P + ch_so(e);
             double gk[3], mv[9], sv[3][9];
@@ -752,7 +759,7 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
         if (uwave == 15) CH_STAMP(170);
         __syncthreads();
         // ---- phases Y and Z (the two chain waves apart: their registers hold the rows of G) ----
-        if (uwave == 11 || uwave == 12) {
+        if ((uwave == 11 || uwave == 12) && CH_DIAG_SKIP != 4) {
             double gc[5][9], vc[5];
 #pragma unroll
             for (int s2 = 0; s2 < 5; ++s2) {
@@ -781,7 +788,7 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
             if (uwave == 13) {
                 mid1(lane);
                 CH_STAMP(171);
-            } else if (uwave < 11) {
+            } else if (uwave < 11 && CH_DIAG_SKIP != 4) {
                 const int e = uwave;
                 double sacc = 0.0, lv[5][4], xv[5][4];
 #pragma unroll
@@ -829,7 +836,7 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
 
 // the whole solve on one workgroup's image (k_pose_solve_c outside the GN loop's split form, the diagnostic entry)
 template <typename Mid1, typename Mid2>
-__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 mid1, Mid2 mid2, unsigned long long *dbg = nullptr) {
+__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 mid1, Mid2 mid2, unsigned long long *dbg = nullptr, const bool ext_trivial = false) {
     unsigned long long t_start__ = 0ull;
 #ifdef VIO_STAMPS
     t_start__ = __builtin_amdgcn_s_memtime();
@@ -837,6 +844,6 @@ __device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 m
 #endif
     const ChLane L = ch_lane(tid & 63);
     const unsigned long long eff = ch_chain_elimination<true>(P, tid, L, dbg, t_start__);
-    ch_camera_solve<false>(P, tid, L, eff, mid1, mid2, dbg, t_start__);
+    ch_camera_solve<false>(P, tid, L, eff, mid1, mid2, dbg, t_start__, ext_trivial);
 }
 #endif

@@ -142,35 +142,45 @@ __device__ __forceinline__ void d_pair_rotations(const double *st, double *sR, i
 __device__ __forceinline__ void d_pair_rows(const double *st, double *tab, const double *sR, int tid, int nt) {
     const double *ric = sR;
     const double *tic = st + STATE_EXT;
-    for (int task = tid; task < 121 * 3; task += nt) {
-        const int pr = task / 3, r = task - 3 * pr;
+    // one task per (part, pair, row): part 0 = row r of A, B, C and d[r], part 1 = row r of El (its 27-product R_t^T R_h is as long as
+    // the rest of the row together: as one task of 363 a row kept six waves of k_pose_solve_c's tail busy for 2.9 k ticks while eight idled)
+    for (int task = tid; task < 2 * 121 * 3; task += nt) {
+        const int part = task >= 121 * 3;
+        const int tk = task - part * 121 * 3;
+        const int pr = tk / 3, r = tk - 3 * pr;
         const int h = pr / 11, t = pr % 11;
         if (h == t) continue;
         const double *Rh = sR + 9 * (1 + h), *Rt = sR + 9 * (1 + t);
-        const double *Ph = st + STATE_POSE + 7 * h, *Pt = st + STATE_POSE + 7 * t;
         const double c0 = ric[r], c1 = ric[3 + r], c2 = ric[6 + r];          // column r of ric
-        double Ar[3], Br[3], Cr[3], Elr[3], u[3], w[3], RtRh[9];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Ar[j] = Rt[3 * j] * c0 + Rt[3 * j + 1] * c1 + Rt[3 * j + 2] * c2;      // A = ric^T Rt^T = (Rt ric)^T
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Br[j] = Ar[0] * Rh[j] + Ar[1] * Rh[3 + j] + Ar[2] * Rh[6 + j];         // B = A Rh
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Cr[j] = Br[0] * ric[j] + Br[1] * ric[3 + j] + Br[2] * ric[6 + j];      // C = B ric
-        d_m3_vec(Rh, tic, u);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) u[k] = u[k] + Ph[k] - Pt[k];
-        d_m3_tvec(Rt, u, w);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) w[k] -= tic[k];
-        const double dr = c0 * w[0] + c1 * w[1] + c2 * w[2];                                               // d = ric^T (Rt^T (Rh tic + Ph - Pt) - tic)
-        d_m3_tmul(Rt, Rh, RtRh);
-        RtRh[0] -= 1; RtRh[4] -= 1; RtRh[8] -= 1;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) Elr[j] = c0 * RtRh[j] + c1 * RtRh[3 + j] + c2 * RtRh[6 + j];           // El = ric^T (Rt^T Rh - I)
         double *o = tab + pr * PAIR_STRIDE;
+        if (part == 0) {
+            const double *Ph = st + STATE_POSE + 7 * h, *Pt = st + STATE_POSE + 7 * t;
+            double Ar[3], Br[3], Cr[3], u[3], w[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { o[PAIR_A + 3 * r + j] = Ar[j]; o[PAIR_B + 3 * r + j] = Br[j]; o[PAIR_C + 3 * r + j] = Cr[j]; o[PAIR_EL + 3 * r + j] = Elr[j]; }
-        o[PAIR_D + r] = dr;
+            for (int j = 0; j < 3; ++j) Ar[j] = Rt[3 * j] * c0 + Rt[3 * j + 1] * c1 + Rt[3 * j + 2] * c2;      // A = ric^T Rt^T = (Rt ric)^T
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Br[j] = Ar[0] * Rh[j] + Ar[1] * Rh[3 + j] + Ar[2] * Rh[6 + j];         // B = A Rh
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Cr[j] = Br[0] * ric[j] + Br[1] * ric[3 + j] + Br[2] * ric[6 + j];      // C = B ric
+            d_m3_vec(Rh, tic, u);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u[k] = u[k] + Ph[k] - Pt[k];
+            d_m3_tvec(Rt, u, w);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[k] -= tic[k];
+            const double dr = c0 * w[0] + c1 * w[1] + c2 * w[2];                                               // d = ric^T (Rt^T (Rh tic + Ph - Pt) - tic)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { o[PAIR_A + 3 * r + j] = Ar[j]; o[PAIR_B + 3 * r + j] = Br[j]; o[PAIR_C + 3 * r + j] = Cr[j]; }
+            o[PAIR_D + r] = dr;
+        } else {
+            double Elr[3], RtRh[9];
+            d_m3_tmul(Rt, Rh, RtRh);
+            RtRh[0] -= 1; RtRh[4] -= 1; RtRh[8] -= 1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Elr[j] = c0 * RtRh[j] + c1 * RtRh[3 + j] + c2 * RtRh[6 + j];           // El = ric^T (Rt^T Rh - I)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) o[PAIR_EL + 3 * r + j] = Elr[j];
+        }
     }
     if (tid < 9) tab[121 * PAIR_STRIDE + CAMTAB_RIC + tid] = ric[tid];
     if (tid < 3) tab[121 * PAIR_STRIDE + CAMTAB_TIC + tid] = tic[tid];

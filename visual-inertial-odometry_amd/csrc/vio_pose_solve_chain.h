@@ -490,7 +490,7 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     double *pairtab_trial = T.pairtab + trial * PAIRTAB_STRIDE;
     double *pw = P + CH_OFF_CC;                                 // trial ext + poses at [0, 84), rotations at [96, 204)
     auto mid1 = [&](int ln) {
-        if (prior_here) return;
+        if (prior_here || CH_DIAG_SKIP == 2) return;
         if (ln < 12) {
             const double *p = (ln == 0) ? sState + STATE_EXT : sState + STATE_POSE + 7 * (ln - 1);
             const double *d = (ln == 0) ? sX + CH_YC + 66 : sX + CH_YC + 6 * (ln - 1);
@@ -507,9 +507,10 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         if (lm_dim != 3) d_pair_rotations(pw, pw + 96, ln);
     };
     auto mid2 = [&](int idx, int ln) {
-        if (prior_here || lm_dim == 3) return;
+        if (prior_here || lm_dim == 3 || CH_DIAG_SKIP == 1 || CH_DIAG_SKIP == 2) return;
         d_pair_rows(pw, pairtab_trial, pw + 96, ln + 64 * idx, 14 * 64);
     };
+    const bool ext_trivial = T.ext_fixed && !T.marg_mode;       // (the extrinsic's rows of this system: lambda on the diagonal, nothing beside it)
     if (SPLIT) {
         unsigned long long t0__ = 0ull;
 #ifdef VIO_STAMPS
@@ -518,9 +519,9 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
 #endif
         const unsigned lo = (unsigned)P[CH_OFF_NZ], hi = (unsigned)P[CH_OFF_NZ + 1];
         const unsigned long long eff = ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(lo);
-        ch_camera_solve<true>(P, tid, ch_lane(lane), eff, mid1, mid2, T.dbg, t0__);
+        ch_camera_solve<true>(P, tid, ch_lane(lane), eff, mid1, mid2, T.dbg, t0__, ext_trivial);
     } else {
-        ch_factor_solve(P, tid, mid1, mid2, T.dbg);
+        ch_factor_solve(P, tid, mid1, mid2, T.dbg, ext_trivial);
     }
     CH_OUT(2);
     for (int i = tid; i < n; i += PS_THREADS) sDx[i] = sX[ch_dim(i)];
