@@ -38,6 +38,7 @@ for lev in range(6):
     prev = a[1]
 print("  phase 2, every worker (waves 2..15) done at:", [int(v) for v in s[142:156]])
 print("  phase 4, every worker done at:", [int(v) for v in s[182:196]])
+print("  level 2 on wave 0: enters %d | F(9) + ride done %d | SD[next] stored %d" % tuple(int(v) for v in s[224:227]))
 print("  phase 5a: wave 0: eff mask %d, fused %d | wave 1: CC(0,0) level-4 terms %d" % tuple(int(v) for v in s[233:236]))
 print("  phase 5, every worker done at:", [int(v) for v in s[202:216]])
 print("  phase 5 + barrier: %6d (+%5d)" % (s[87], s[87] - prev))

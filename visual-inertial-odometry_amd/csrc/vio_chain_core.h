@@ -76,9 +76,15 @@ __device__ __forceinline__ bool ch_bit(unsigned long long eff, int e, int t) { r
 // products, three reciprocals and a store more on the chain's critical path, 0.7 k ticks a level.)
 __device__ __forceinline__ void ch_chain_level(double *P, const ChLane &L, int e, int n, bool upd, int lane, double *scr) {
     double *sD = P + CH_OFF_D;
+#ifdef VIO_STAMPS
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
     if (e == 5) ch_factor<9, CH_TS, CH_TS>((lds_double *)(P + ch_sd(e)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(e)), lane);
     else ch_factor<9, CH_TS, CH_TS, true>((lds_double *)(P + ch_sd(e)), (lds_double *)(P + CH_OFF_I9), (lds_double *)(P + ch_sm(e)), lane,
                                           (lds_double *)(P + ch_so(e)), (lds_double *)scr);
+#ifdef VIO_STAMPS
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
     if (lane < 9) sD[e * 16 + lane] = P[ch_sd(e) + lane * (CH_TS + 1)];
     if (e == 5 || !upd) return;
     const double *tt = P + ch_so(e);
@@ -91,6 +97,13 @@ __device__ __forceinline__ void ch_chain_level(double *P, const ChLane &L, int e
     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * p1, -a1, acc2, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * p2, -a2, acc2, 0, 0, 0);
     if (L.r9) { td[L.oM0] = acc2[0]; td[L.oM0 + 4 * CH_TS] = acc2[1]; if (L.g == 0) td[L.oM0 + 8 * CH_TS] = acc2[2]; }
+#ifdef VIO_STAMPS
+    if (e == 2 && g_ch_dbg && lane == 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+        g_ch_dbg[224] = ts0 - g_ch_t0; g_ch_dbg[225] = ts1 - g_ch_t0; g_ch_dbg[226] = ts2 - g_ch_t0;
+    }
+#endif
 }
 // F on a camera tile (np = 16, or 8 for the last one): M to sM, the pivots to sDp[0 .. np)
 // np == 2: the last tile when the extrinsic is fixed (vio_config.ext_fixed, the reference's ESTIMATE_EXTRINSIC = 0): its variables 2..7
@@ -322,7 +335,7 @@ template <int LEV, bool CAM = true>
 __device__ __forceinline__ void ch_worker_phase(double *P, const ChLane &L, int wi, int lane, unsigned long long eff) {
     constexpr int eA = LEV, eB = 10 - LEV;
 #ifdef CH_DIAG_IDLE_SIMDS
-    if ((((wi + 2) & 3) == 0) || (CH_DIAG_IDLE_SIMDS > 1 && ((wi + 2) & 3) == 1)) return;      // timing experiment only: wrong results
+    if ((((wi + 2) & 3) == 0) || (CH_DIAG_IDLE_SIMDS > 1 && ((wi + 2) & 3) == 1) || CH_DIAG_IDLE_SIMDS > 3) return;      // timing experiment only: wrong results
 #endif
     if (wi == 13) { ch_rhs_phase<LEV>(P, lane); return; }
     int first_cc, busy;
@@ -401,7 +414,8 @@ __device__ __forceinline__ ChLane ch_lane(int lane) {
 // level by level (the fused solve); without them (the pre-elimination of the GN loop) the chain leaves L_SC, L_SO, M_e, the pivots and
 // w_e = M_e^T y_e, and whoever has the camera block applies the terms (ch_camera_solve<true>: the same operations in the same order).
 template <bool CAM>
-__device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, const int tid, const ChLane &L, unsigned long long *dbg, unsigned long long t_start__) {
+__device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, const int tid, const ChLane &L, unsigned long long *dbg, unsigned long long t_start__,
+                                                                   const bool scanned = false) {
     const int lane = tid & 63;
     const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = L.g;
@@ -452,7 +466,7 @@ __device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, co
         __syncthreads();
     } else {
         const int wi = uwave - 2;
-        ch_scan_tiles(P, wi, lane);                                // (nothing else to do during level 0)
+        if (!scanned) ch_scan_tiles(P, wi, lane);                  // (nothing else to do during level 0; `scanned`: the copy-in noted the flags)
         __syncthreads();                                           // barrier 0: level 0 is out
         eff = ch_eff_mask(P, lane);
         ch_worker_phase<0, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(112);
@@ -836,14 +850,15 @@ __device__ __forceinline__ void ch_camera_solve(double *P, const int tid, const 
 
 // the whole solve on one workgroup's image (k_pose_solve_c outside the GN loop's split form, the diagnostic entry)
 template <typename Mid1, typename Mid2>
-__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 mid1, Mid2 mid2, unsigned long long *dbg = nullptr, const bool ext_trivial = false) {
+__device__ __forceinline__ void ch_factor_solve(double *P, const int tid, Mid1 mid1, Mid2 mid2, unsigned long long *dbg = nullptr, const bool ext_trivial = false,
+                                                const bool scanned = false) {
     unsigned long long t_start__ = 0ull;
 #ifdef VIO_STAMPS
     t_start__ = __builtin_amdgcn_s_memtime();
     if (tid == 0) { g_ch_dbg = dbg; g_ch_t0 = t_start__; }
 #endif
     const ChLane L = ch_lane(tid & 63);
-    const unsigned long long eff = ch_chain_elimination<true>(P, tid, L, dbg, t_start__);
+    const unsigned long long eff = ch_chain_elimination<true>(P, tid, L, dbg, t_start__, scanned);
     ch_camera_solve<false>(P, tid, L, eff, mid1, mid2, dbg, t_start__, ext_trivial);
 }
 #endif

@@ -132,8 +132,6 @@ __device__ __noinline__ void ch_factor(lds_double *tile, lds_double *sI, lds_dou
     for (int j = 0; j < NP; ++j) a0[j] = p0[j];
     lds_double *wp = ident ? M + row * MS : (ride ? scratch + lane : tile + row);
     const int ws = ident ? 1 : (ride ? 0 : TS);
-    lds_double *lp = ride ? rtile + row * TS : scratch + lane;
-    const int ls = ride ? 1 : 0;
     __builtin_amdgcn_sched_barrier(0);   // every row is in registers before the first publish overwrites the tile
     wp[0] = a0[0];
     double d = d_readlane(a0[0], 0);
@@ -151,7 +149,7 @@ __device__ __noinline__ void ch_factor(lds_double *tile, lds_double *sI, lds_dou
             wp[0] = a0[j + 1];
             d = d_readlane(a0[j + 1], j + 1);
         }
-        if (RIDE) { lp[0] = l0; lp += ls; }
+        if (RIDE) a0[j] = l0;                   // (the entry is dead in every lane: published, or — the riding rows — replaced by its quotient)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = j + 2; c < NP; ++c) {
@@ -162,6 +160,12 @@ __device__ __noinline__ void ch_factor(lds_double *tile, lds_double *sI, lds_dou
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    }
+    if (RIDE && ride) {
+        // the riding rows leave as L, in place (kept in registers until here: a store per pivot cost 40 ticks a pivot, tools/microbench/factor_tile.hip)
+        lds_double *lp = rtile + row * TS;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) lp[j] = a0[j];
     }
 }
 
@@ -357,6 +361,134 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     int set = lm_loop ? (lm->sys ^ lm->pending) : 0;
     const double *cfi = SPLIT ? T.cfi : nullptr;
     double xs0 = 0.0, xs1 = 0.0, xd = 0.0, xy = 0.0, xe = 0.0;
+#ifndef CH_NO_EARLY_START
+    const bool early = !SPLIT && !lm_loop;
+#else
+    const bool early = false;
+#endif
+    if (early) {
+        // The GN loop and the stepwise solves (lambda and the set are known at entry): NO BARRIER IN FRONT OF THE CHAIN'S FIRST LEVEL.  The
+        // two chain waves fetch their own chain's tiles — SO and SD of blocks 0..5 resp. 6..10, 8 KB each — put lambda on them and start;
+        // the other fourteen waves bring in the rest of the image (110 KB: one CU's load path needs 2 k ticks for it on top of the latency)
+        // and meet them at barrier 0.  Level 0, 3 k ticks, used to begin when the whole copy was through (4.7 k).
+        const double *img = T.Pg;
+        if (uwave < 2) {
+            const int so0 = CH_OFF_SO + (uwave ? 5 * CH_S9SZ : 0), sd0 = CH_OFF_SD + (uwave ? 6 * CH_S9SZ : 0);
+            const int nsd = uwave ? 5 * CH_S9SZ : 6 * CH_S9SZ, e0 = uwave ? 6 : 0, ne = uwave ? 5 : 6;
+            double vo[8], vd[10];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vo[q] = img[so0 + min(lane + 64 * q, 5 * CH_S9SZ - 1)];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) vd[q] = img[sd0 + min(lane + 64 * q, nsd - 1)];
+            // under the latency: the identity F starts its second row of lanes from, M_e = 0 (its padding column must read as zero), pivots 1
+            for (int i = lane; i < CH_S9SZ; i += 64) P[CH_OFF_I9 + i] = (i / CH_TS == i % CH_TS) ? 1.0 : 0.0;
+            for (int i = lane; i < ne * CH_S9SZ; i += 64) P[CH_OFF_SM + e0 * CH_S9SZ + i] = 0.0;
+            for (int i = lane; i < ne * 16; i += 64) P[CH_OFF_D + e0 * 16 + i] = 1.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) P[so0 + min(lane + 64 * q, 5 * CH_S9SZ - 1)] = vo[q];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) P[sd0 + min(lane + 64 * q, nsd - 1)] = vd[q];
+            // lambda on the chain's pivots (problem.cc:434-436)
+            if (lane < ne * 9) P[ch_sd(e0 + lane / 9) + (lane % 9) * (CH_TS + 1)] += lambda;
+        } else {
+            const int wt = tid - 128;                                   // 0..895
+            // the speed-bias / camera coupling: a wave owns whole tiles (88 double2 each: lanes 0..63, then 0..23) and notes which of them hold
+            // a non-zero (ch_scan_tiles' flags, without its pass over the image)
+            const double2 *src2 = reinterpret_cast<const double2 *>(img);
+            double2 *dst2 = reinterpret_cast<double2 *>(P);
+            double2 va[4], vb[4], vc[3];
+            static_assert(CH_OFF_CC % 2 == 1 && CH_PACKED % 2 == 0 && (CH_PACKED - CH_OFF_CC - 1) / 2 <= 3 * 896, "the copy of the camera block below");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = min(uwave - 2 + 14 * k, 54);
+                va[k] = src2[t * (CH_SCSZ / 2) + lane];
+                vb[k] = src2[t * (CH_SCSZ / 2) + 64 + min(lane, CH_SCSZ / 2 - 65)];
+            }
+            // the camera block and the right-hand side
+#pragma unroll
+            for (int q = 0; q < 3; ++q) vc[q] = src2[min((CH_OFF_CC + 1) / 2 + wt + 896 * q, CH_PACKED / 2 - 1)];
+            const double vc0 = img[CH_OFF_CC];                          // (the block starts at an odd offset: its first element apart)
+            double st[3] = {0.0, 0.0, 0.0}, er[3] = {0.0, 0.0, 0.0};
+            const bool test_here = uwave == 2 && d_step_owed(T, 1);
+            double tv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, ichi = 0.0;
+            if (test_here) {
+                // everything the test reads, requested with the image — the IMU edges' chi2 as ONE load (lane = edge): one at a time behind
+                // its valid bit they are ten dependent round trips
+                tv[0] = T.vis[VIS_CHI]; tv[1] = T.vis[VIS_STEP + 1]; tv[2] = lm->chi; tv[3] = T.sp_part[0]; tv[4] = T.sp_part[1]; tv[5] = T.sp_part[2];
+                ichi = T.imu_out[min(lane, 9) * IMU_OUT + IMU_CHI];
+            }
+            if (uwave == 2) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) st[k] = T.state[cur * STATE_STRIDE + min(lane + 64 * k, STATE_STRIDE - 1)];
+                if (test_here && T.has_prior) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) if (lane + 64 * k < VIO_PRD) er[k] = T.errprior[cur * 160 + lane + 64 * k];
+                }
+            }
+            // under the latency: the 16 x 16 identity, the camera part's pivots = 1
+            for (int i = wt; i < PS_TS; i += 896) P[CH_OFF_I16 + i] = (i / PS_TROW == i % PS_TROW) ? 1.0 : 0.0;
+            if (wt < CH_NDIM - CH_YC) P[CH_OFF_D + CH_YC + wt] = 1.0;
+            int *sNZ = (int *)(P + CH_OFF_NZ);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = uwave - 2 + 14 * k;
+                if (t < 55) {
+                    dst2[t * (CH_SCSZ / 2) + lane] = va[k];
+                    if (lane < CH_SCSZ / 2 - 64) dst2[t * (CH_SCSZ / 2) + 64 + lane] = vb[k];
+                    const bool nz = va[k].x != 0.0 || va[k].y != 0.0 || (lane < CH_SCSZ / 2 - 64 && (vb[k].x != 0.0 || vb[k].y != 0.0));
+                    const unsigned long long any = __ballot(nz);
+                    if (lane == 0) sNZ[t] = any != 0ull ? 1 : 0;
+                }
+            }
+            // lambda on the camera block's pivots as they pass; the 8 padding variables of the last tile are identity rows
+            auto cam_value = [&](int o, double v) {
+                if (o < CH_OFF_Y) {
+                    const int ti = (o - CH_OFF_CC) / PS_TS, w = (o - CH_OFF_CC) % PS_TS, r = w / PS_TROW, c = w % PS_TROW;
+                    const bool dtile = ti == 0 || ti == 2 || ti == 5 || ti == 9 || ti == 14;
+                    if (dtile && r == c && c < 16) v = (ti == 14 && r >= 8) ? 1.0 : v + lambda;
+                }
+                return v;
+            };
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int i2 = (CH_OFF_CC + 1) / 2 + wt + 896 * q;
+                if (i2 < CH_PACKED / 2) { double2 v = vc[q]; v.x = cam_value(2 * i2, v.x); v.y = cam_value(2 * i2 + 1, v.y); dst2[i2] = v; }
+            }
+            if (wt == 0) P[CH_OFF_CC] = cam_value(CH_OFF_CC, vc0);
+            if (uwave == 2) {
+                // the state, and the test of the previous step (see the other prologue: the same sums — three wave partials added in wave
+                // order — by one wave, nobody waits for anybody)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) if (lane + 64 * k < STATE_STRIDE) sState[lane + 64 * k] = st[k];
+                if (test_here) {
+                    double w[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) w[k] = d_wave_sum_to_lane63(er[k] * er[k]);
+                    const int valid = d_imu_mask(T);
+                    double t_imu = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) { const double c = d_readlane(ichi, k); if ((valid >> k) & 1) t_imu += c; }
+                    if (lane == 63) {
+                        double total = tv[0] + t_imu;
+                        if (T.has_prior) total += sqrt((w[0] + w[1]) + w[2]);          // err_prior_.norm(), not squared (problem.cc:554-556)
+                        const double tempChi = 0.5 * total;
+                        const double scale = 0.5 * (tv[1] + ((tv[3] + tv[4]) + tv[5])) + 1e-6;
+                        lm->chi_try = tempChi;
+                        lm->scale = scale;
+                        lm->rho = (tv[2] - tempChi) / scale;
+                        lm->trials += 1;
+                        lm->chi = tempChi;
+                        lm->cur = cur;
+                        lm->accepted = 1;
+                        lm->naccepted += 1;
+                        lm->need_linearize = 1;
+                        lm->false_cnt = 0;
+                        if (!isfinite(tempChi)) lm->finite = 0;
+                    }
+                }
+            }
+        }
+    } else {
     if (SPLIT) {
         xs0 = cfi[CH_OFF_SM + tid];
         if (tid < CH_NS * CH_S9SZ - PS_THREADS) xs1 = cfi[CH_OFF_SM + PS_THREADS + tid];
@@ -387,12 +519,14 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
                 double e2 = 0.0;
                 if (T.has_prior && tid < VIO_PRD) { const double er = T.errprior[lc * 160 + tid]; e2 = er * er; }
                 if (tid < 192) { const double w = d_wave_sum_to_lane63(e2); if (lane == 63) sB[tid >> 6] = w; }
-                if (tid == 0) {
+                if (uwave == 0) {
+                    // (the IMU edges' chi2 as ONE load, lane = edge: one at a time behind its valid bit they are ten dependent round trips)
                     const int valid = d_imu_mask(T);
+                    const double ichi = T.imu_out[min(lane, 9) * IMU_OUT + IMU_CHI];
                     t_chi = T.vis[VIS_CHI]; t_step = T.vis[VIS_STEP + 1]; t_lmchi = lm->chi;
-#pragma unroll
-                    for (int k = 0; k < 10; ++k) if ((valid >> k) & 1) t_imu += T.imu_out[k * IMU_OUT + IMU_CHI];
                     t_sp = (T.sp_part[0] + T.sp_part[1]) + T.sp_part[2];
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) { const double c = d_readlane(ichi, k); if ((valid >> k) & 1) t_imu += c; }
                 }
             }
             if (lm_loop && tid == 0 && !test_here) {
@@ -457,7 +591,6 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
 #undef CH_ST
 #undef CH_FROM_CFI
     }
-    const int trial = cur ^ 1;
     // lambda on the 171 pivots (problem.cc:434-436); the 8 padding variables of the last camera tile are identity rows
     if (tid < n) {
         const int d = ch_dim(tid);
@@ -480,7 +613,9 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         for (int i = tid; i < CH_NS * CH_S9SZ; i += PS_THREADS) P[CH_OFF_SM + i] = 0.0;      // (the padding column of every M_e must read as zero)
     }
     __syncthreads();
+    }
     CH_OUT(0);
+    const int trial = cur ^ 1;
     // The camera part of the step (poses, extrinsic) is known two phases before the speed-bias part: wave 13 forms the trial poses
     // (UpdateStates, problem.cc:456-463; vertex_pose.cc:7-19) and their rotations while the speed-bias owners finish their sums, and the
     // fourteen waves that do not walk the chains form the pair table of the trial states meanwhile (in the camera tiles' space, free once
@@ -521,7 +656,7 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
         const unsigned long long eff = ((unsigned long long)__builtin_amdgcn_readfirstlane(hi) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(lo);
         ch_camera_solve<true>(P, tid, ch_lane(lane), eff, mid1, mid2, T.dbg, t0__, ext_trivial);
     } else {
-        ch_factor_solve(P, tid, mid1, mid2, T.dbg, ext_trivial);
+        ch_factor_solve(P, tid, mid1, mid2, T.dbg, ext_trivial, early);
     }
     CH_OUT(2);
     for (int i = tid; i < n; i += PS_THREADS) sDx[i] = sX[ch_dim(i)];
