@@ -1149,8 +1149,12 @@ __device__ __forceinline__ void d_errprior_row(const double *jt, const double *b
 // FUSED (the three-launch path of the chain order, vio_pose_solve_chain.h): the workgroup that has summed a block also adds the IMU and
 // prior terms and writes the entries straight into the image of the pose system — k_assemble_c's work without its launch; 20 more
 // workgroups write the 99 rows of the speed-bias variables (no visual part).  The hooks are defined with the chain layout.
-__device__ void d_fused_pair(const DeviceTables &T, int b, int tid, double tot);
-__device__ void d_fused_vec(const DeviceTables &T, int P, int tid, double bd, double bc, double dg);
+// (the *_pre hooks fetch what the entry takes besides the sum — IMU and prior terms, which depend on the indices only — at the top of the
+//  workgroup, with the list bounds: behind the sum they were two more dependent round trips at the kernel's end)
+__device__ double d_fused_pair_pre(const DeviceTables &T, int b, int tid);
+__device__ void d_fused_vec_pre(const DeviceTables &T, int P, int tid, double &extra, double &dgrest);
+__device__ void d_fused_pair(const DeviceTables &T, int b, int tid, double tot, double rest);
+__device__ void d_fused_vec(const DeviceTables &T, int P, int tid, double bd, double bc, double dg, double extra, double dgrest);
 __device__ void d_fused_sb_row(const DeviceTables &T, int r, int tid);
 #define RED_SB_BLOCKS 20          // five rows of speed-bias variables per workgroup (5 x 171 threads)
 template <bool FUSED>
@@ -1162,6 +1166,11 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R, const Devic
     const int b = blockIdx.x, tid = threadIdx.x;
     // (the list bounds are requested before the gate looks at LmState: one round trip for both)
     const int lo_pre = b < VIO_NPAIR + VIO_NCB + 1 ? R.list_off[b] : 0, hi_pre = b < VIO_NPAIR + VIO_NCB + 1 ? R.list_off[b + 1] : 0;
+    double pre0 = 0.0, pre1 = 0.0;
+    if (FUSED) {
+        if (b < VIO_NPAIR) { if (tid < 36) pre0 = d_fused_pair_pre(*Tp, b, tid); }
+        else if (b < VIO_NPAIR + VIO_NCB) { if (tid < 6) d_fused_vec_pre(*Tp, b - VIO_NPAIR, tid, pre0, pre1); }
+    }
     if (d_gated_off(R.lm, R.gate)) return;
     const bool step_owed = !R.lm_loop || R.lm->pending != 0;
     if (FUSED && b >= VIO_NPAIR + VIO_NCB + 1 && b < VIO_NPAIR + VIO_NCB + 1 + RED_SB_BLOCKS) {
@@ -1210,7 +1219,7 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R, const Devic
 #pragma unroll
             for (int q = 0; q < NS; ++q) tot += sV[q * W + tid];
             R.vis[VIS_H + b * 36 + tid] = tot;         // block b = VIS_PAIR(P, Q), entry (i, j) = tid: the mirror image is not stored
-            if (FUSED) d_fused_pair(*Tp, b, tid, tot);
+            if (FUSED) d_fused_pair(*Tp, b, tid, tot, pre0);
         }
     } else if (b < VIO_NPAIR + VIO_NCB) {
         constexpr int W = 18, NS = RED_THREADS / W;           // 56 slots
@@ -1244,35 +1253,32 @@ __device__ __forceinline__ void d_reduce_body(const ReduceTables &R, const Devic
             R.vis[VIS_BDIR + 6 * P + tid] = bd;
             R.vis[VIS_BRED + 6 * P + tid] = bd - bc;     // bpp - (Hpm*Hmm^-1)*bmm (problem.cc:429)
             R.vis[VIS_DIAG + 6 * P + tid] = dg;
-            if (FUSED) d_fused_vec(*Tp, P, tid, bd, bc, dg);
+            if (FUSED) d_fused_vec(*Tp, P, tid, bd, bc, dg, pre0, pre1);
         }
     } else {
-        // chi2 and max|h_ll| over the items: threads stride the list, then a fixed tree
-        __shared__ double sC[RED_THREADS], sM[RED_THREADS];
-        double chi = 0.0, mh = 0.0;
+        // chi2 and max|h_ll| over the items, and the landmark part of the previous step's gain-ratio denominator (summed here so that it is
+        // in the exchange buffer when the shards gather it): threads stride the lists, then the waves' sums (DPP, a fixed tree) and the
+        // sixteen wave partials in wave order.  (Until round 5 two ten-level trees through LDS, twenty barriers: this workgroup was the
+        // kernel's long pole.)
+        __shared__ double sC[3 * (RED_THREADS / 64)];
+        const bool with_step = R.step_part && step_owed;
+        double chi = 0.0, mh = 0.0, sc = 0.0;
+        if (with_step) for (int e = tid; e < R.n_step; e += RED_THREADS) sc += R.step_part[2 * e + STEP_SCALE];
         for (int e = lo + tid; e < hi; e += RED_THREADS) {
             const size_t o = (size_t)R.list[e];
             chi += R.slab[o];
             mh = fmax(mh, R.slab[o + 1]);
         }
-        sC[tid] = chi; sM[tid] = mh;
+        const double wc = d_wave_sum_to_lane63(chi), wm = d_wave_max_to_lane63(mh), ws = d_wave_sum_to_lane63(sc);
+        if ((tid & 63) == 63) { sC[tid >> 6] = wc; sC[RED_THREADS / 64 + (tid >> 6)] = wm; sC[2 * (RED_THREADS / 64) + (tid >> 6)] = ws; }
         __syncthreads();
-        for (int s2 = RED_THREADS / 2; s2 > 0; s2 >>= 1) {
-            if (tid < s2) { sC[tid] += sC[tid + s2]; sM[tid] = fmax(sM[tid], sM[tid + s2]); }
-            __syncthreads();
-        }
-        if (tid == 0) { R.vis[VIS_CHI] = sC[0]; R.vis[VIS_MAXH] = sM[0]; R.vis[VIS_STEP] = 0.0; if (!R.step_part) R.vis[VIS_STEP + 1] = 0.0; }
-        if (R.step_part && step_owed) {      // landmark part of the previous step's gain-ratio denominator: summed here so that it is in the
-            double sc = 0.0;    // exchange buffer when the shards all-reduce it (fixed order: strided partials, then the tree)
-            for (int e = tid; e < R.n_step; e += RED_THREADS) sc += R.step_part[2 * e + STEP_SCALE];
-            __syncthreads();
-            sC[tid] = sc;
-            __syncthreads();
-            for (int s2 = RED_THREADS / 2; s2 > 0; s2 >>= 1) {
-                if (tid < s2) sC[tid] += sC[tid + s2];
-                __syncthreads();
-            }
-            if (tid == 0) R.vis[VIS_STEP + 1] = sC[0];
+        if (tid == 0) {
+            double c = 0.0, m = 0.0, t = 0.0;
+#pragma unroll
+            for (int w = 0; w < RED_THREADS / 64; ++w) { c += sC[w]; m = fmax(m, sC[RED_THREADS / 64 + w]); t += sC[2 * (RED_THREADS / 64) + w]; }
+            R.vis[VIS_CHI] = c; R.vis[VIS_MAXH] = m; R.vis[VIS_STEP] = 0.0;
+            if (!R.step_part) R.vis[VIS_STEP + 1] = 0.0;
+            else if (with_step) R.vis[VIS_STEP + 1] = t;
         }
     }
 }

@@ -272,26 +272,38 @@ __device__ __forceinline__ void d_fused_store(const DeviceTables &T, int i, int 
     if (p1 >= 0) Pg[p1] = v;
     if (p2 >= 0) Pg[p2] = v;
 }
-__device__ void d_fused_pair(const DeviceTables &T, int b, int tid, double tot) {
+__device__ __forceinline__ bool d_fused_pair_ij(int b, int tid, int &I, int &J) {
     // block b = VIS_PAIR(P, Q), P <= Q; thread = entry (a, bq) of the 6 x 6 block.  A diagonal block holds both halves: the lower one is
     // what d_hs_entry reads
     int P = 0;
     while (VIS_PAIR(P + 1, P + 1) <= b) ++P;
     const int Q = P + (b - VIS_PAIR(P, P));
     const int a = tid / 6, bq = tid - 6 * a;
-    if (P == Q && a < bq) return;
+    if (P == Q && a < bq) return false;
     const int i = cam_to_full(6 * P + a), j = cam_to_full(6 * Q + bq);
-    const int I = max(i, j), J = min(i, j);
-    d_fused_store(T, I, J, tot + d_hs_rest(T, d_imu_mask(T), I, J));
+    I = max(i, j); J = min(i, j);
+    return true;
 }
-__device__ void d_fused_vec(const DeviceTables &T, int P, int tid, double bd, double bc, double dg) {
-    const int valid = d_imu_mask(T), cur = d_cur(T), wset = d_set_w(T);
+__device__ double d_fused_pair_pre(const DeviceTables &T, int b, int tid) {
+    int I, J;
+    return d_fused_pair_ij(b, tid, I, J) ? d_hs_rest(T, d_imu_mask(T), I, J) : 0.0;
+}
+__device__ void d_fused_pair(const DeviceTables &T, int b, int tid, double tot, double rest) {
+    int I, J;
+    if (d_fused_pair_ij(b, tid, I, J)) d_fused_store(T, I, J, tot + rest);
+}
+__device__ void d_fused_vec_pre(const DeviceTables &T, int P, int tid, double &extra, double &dgrest) {
+    const int valid = d_imu_mask(T), i = cam_to_full(6 * P + tid);
+    extra = d_rhs_rest(T, valid, i, d_cur(T));
+    dgrest = d_hs_rest(T, valid, i, i);
+}
+__device__ void d_fused_vec(const DeviceTables &T, int P, int tid, double bd, double bc, double dg, double extra, double dgrest) {
+    const int wset = d_set_w(T);
     const int i = cam_to_full(6 * P + tid);
-    const double extra = d_rhs_rest(T, valid, i, cur);
     const double bred = bd - bc;
     T.bs[i] = bred + extra;
     T.bfull[wset * 176 + i] = bd + extra;
-    T.diagfull[i] = dg + d_hs_rest(T, valid, i, i);
+    T.diagfull[i] = dg + dgrest;
     T.Pg[wset * CH_SET_STRIDE + CH_OFF_Y + ch_dim(i)] = bred + extra;
 }
 __device__ void d_fused_sb_row(const DeviceTables &T, int blk, int tid) {
@@ -366,6 +378,8 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
 #else
     const bool early = false;
 #endif
+    // (the pose part of b_ for the gain ratio's denominator, read in the kernel's last lines: requested here, a memory latency earlier)
+    const double bf_early = (early && tid >= 192 && tid < 192 + n) ? T.bfull[tid - 192] : 0.0;
     if (early) {
         // The GN loop and the stepwise solves (lambda and the set are known at entry): NO BARRIER IN FRONT OF THE CHAIN'S FIRST LEVEL.  The
         // two chain waves fetch their own chain's tiles — SO and SD of blocks 0..5 resp. 6..10, 8 KB each — put lambda on them and start;
@@ -660,12 +674,13 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     }
     CH_OUT(2);
     for (int i = tid; i < n; i += PS_THREADS) sDx[i] = sX[ch_dim(i)];
-    if (tid < 192 && T.sp_part) {
+    if (tid >= 192 && tid < 384 && T.sp_part) {
         // sum_i dx_i (lambda dx_i + b_i), b_ of the system just solved: three wave partials, as k_assemble's step test sums them
-        const double dxi = (tid < n) ? sX[ch_dim(min(tid, n - 1))] : 0.0;
-        const double bi = (tid < n) ? T.bfull[set * 176 + tid] : 0.0;
-        const double w = d_wave_sum_to_lane63((tid < n) ? dxi * (lambda * dxi + bi) : 0.0);
-        if (lane == 63) T.sp_part[tid >> 6] = w;
+        const int i = tid - 192;
+        const double dxi = (i < n) ? sX[ch_dim(min(i, n - 1))] : 0.0;
+        const double bi = early ? bf_early : ((i < n) ? T.bfull[set * 176 + i] : 0.0);
+        const double w = d_wave_sum_to_lane63((i < n) ? dxi * (lambda * dxi + bi) : 0.0);
+        if (lane == 63) T.sp_part[i >> 6] = w;
     }
     if (!prior_here) {
         // the trial states: poses from wave 13's copy, speed-bias = current + dx
