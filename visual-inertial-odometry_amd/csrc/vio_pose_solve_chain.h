@@ -543,6 +543,9 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
                     for (int k = 0; k < 10; ++k) { const double c = d_readlane(ichi, k); if ((valid >> k) & 1) t_imu += c; }
                 }
             }
+            // (LmState for the verdict below is requested here, with the image: behind the barrier it was one more round trip per slot)
+            int pend0 = 0, sys0 = 0;
+            if (lm_loop && tid == 0 && test_here) { d_lm_load(lm, sLm); pend0 = lm->pending; sys0 = lm->sys; }
             if (lm_loop && tid == 0 && !test_here) {
                 int go = 1, rej = 0, sys = lm->sys;
                 d_lm_load(lm, sLm);
@@ -574,9 +577,8 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
                         lm->false_cnt = 0;
                         if (!isfinite(tempChi)) lm->finite = 0;
                     } else {
-                        int go = 1, rej = 0, sys = lm->sys;
-                        d_lm_load(lm, sLm);
-                        if (lm->pending) {
+                        int go = 1, rej = 0, sys = sys0;
+                        if (pend0) {
                             d_lm_verdict(sLm, lm, 0, tempChi, scale, sLm.cur);
                             if (sLm.accepted) sys ^= 1; else rej = 1;
                             go = !sLm.stop;
