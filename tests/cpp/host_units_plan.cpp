@@ -1,6 +1,8 @@
 // The planner's operations of the host-units driver (host_units_main.cpp): csrc/vio_plan.cpp, compiled with g++ alone.
 //   op 10 scan_observations      in: int64 N, m; lm[m] host[m] target[m] (int32), pi[2m]; int32 have_prev, [2N prev pts_i_lm]
 //                                out: int32 bad, int64 bad_index, int32 lm_major, consistent, changed; 2N pts_i_lm
+//   op 13 the same pass in `pieces` pieces on a pool of helper threads (scan_range / scan_finish / pool_run: what vio_set_observations does)
+//                                in: int32 pieces, then as op 10; out: as op 10
 //   op 11 plan_invdepth          in: int32 marg, use_ext, throughput, n_cus, g_max, half; int64 N, M; lm, host, target, pi[2M]
 //                                out: int32 scan_bad, status; [error text length int32 + bytes] | int64 Ns, Ms, n_items, n_patterns, n_obs_idx, slab, lw;
 //                                     int32 max_lds; sorted_to_orig[Ns], first[Ns] (int32), pts_i[2Ns], items (raw ItemDesc), obs_idx, int64 n_list; list_off[92], list
@@ -44,6 +46,36 @@ int host_units_plan_op(int op, FILE *f, FILE *o) {
         const vio_plan::ScanResult r = vio_plan::scan_observations(N, m, lm.data(), host.data(), target.data(), pi.data(), pl);
         const int32_t a[3] = {r.lm_major, r.consistent, r.changed}, bad = r.bad;
         wr(o, &bad, 1); wr(o, &r.bad_index, 1); wr(o, a, 3); wr(o, pl.data(), pl.size());
+        return 0;
+    }
+    if (op == 13) {
+        int32_t pieces = 1;
+        int64_t N, m;
+        if (!rd(f, &pieces, 1) || !rd(f, &N, 1) || !rd(f, &m, 1) || N < 0 || m < 0 || pieces < 1 || pieces > 8) return 4;
+        std::vector<int32_t> lm(m), host(m), target(m);
+        std::vector<double> pi(2 * (size_t)m);
+        int32_t have_prev = 0;
+        if (!rd(f, lm.data(), m) || !rd(f, host.data(), m) || !rd(f, target.data(), m) || !rd(f, pi.data(), pi.size()) || !rd(f, &have_prev, 1)) return 4;
+        std::vector<double> pl;
+        if (have_prev) { pl.resize(2 * (size_t)N); if (!rd(f, pl.data(), pl.size())) return 4; }
+        bool resized = false;
+        if (pl.size() != 2 * (size_t)N) { pl.assign(2 * (size_t)N, 0.0); resized = true; }
+        struct Job { int64_t N, m; const int32_t *lm, *host, *target; const double *pi; double *pl; int pieces; vio_plan::ScanFlags fl[8]; } job;
+        job.N = N; job.m = m; job.lm = lm.data(); job.host = host.data(); job.target = target.data(); job.pi = pi.data(); job.pl = pl.data(); job.pieces = pieces;
+        vio_plan::HostPool *pool = vio_plan::pool_create(pieces - 1);
+        if (vio_plan::pool_width(pool) != pieces && pool) return 5;
+        for (int rep = 0; rep < 3; ++rep)           // (the pool is reused: a second and third run must find the helpers parked again)
+            vio_plan::pool_run(pool, pieces, [](void *a, int i) {
+                Job &j = *(Job *)a;
+                j.fl[i] = vio_plan::scan_range(j.N, j.m * i / j.pieces, j.m * (i + 1) / j.pieces, j.lm, j.host, j.target, j.pi, j.pl);
+            }, &job);
+        vio_plan::pool_destroy(pool);
+        vio_plan::ScanFlags fl;
+        for (int i = 0; i < pieces; ++i) { fl.bad |= job.fl[i].bad; fl.unsorted |= job.fl[i].unsorted; fl.incons |= job.fl[i].incons; fl.changed |= job.fl[i].changed; }
+        (void)resized;
+        const vio_plan::ScanResult r = vio_plan::scan_finish(fl, N, m, lm.data(), host.data(), target.data());
+        const int32_t a3[3] = {r.lm_major, r.consistent, r.changed}, bad = r.bad;
+        wr(o, &bad, 1); wr(o, &r.bad_index, 1); wr(o, a3, 3); wr(o, pl.data(), pl.size());
         return 0;
     }
     if (op != 11 && op != 12) return 6;

@@ -34,7 +34,7 @@ LDS_BUDGET = (160 * 1024 - 512) // 8
 def driver(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("host_units") / "host_units")
     cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", os.path.join(ROOT, "tests", "cpp", "host_units_main.cpp"),
-           os.path.join(ROOT, "tests", "cpp", "host_units_plan.cpp"), os.path.join(CSRC, "host_dense.cpp"), os.path.join(CSRC, "vio_plan.cpp")]
+           os.path.join(ROOT, "tests", "cpp", "host_units_plan.cpp"), os.path.join(CSRC, "host_dense.cpp"), os.path.join(CSRC, "vio_plan.cpp"), "-pthread"]
     if os.environ.get("VIO_TEST_SANITIZE") == "1":
         cmd += ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
     subprocess.check_call(cmd + ["-o", exe])
@@ -183,6 +183,17 @@ def scan(driver, N, lm, host, target, pi, prev=None):
                 pts_i_lm=np.frombuffer(b, dtype=np.float64, offset=24).reshape(-1, 2))
 
 
+def scan_pieces(driver, pieces, N, lm, host, target, pi, prev=None):
+    m = len(lm)
+    payload = struct.pack("<iiqq", 13, pieces, N, m) + i32(lm) + i32(host) + i32(target) + f64(pi) + struct.pack("<i", 0 if prev is None else 1)
+    if prev is not None:
+        payload += f64(prev)
+    b = driver(payload)
+    bad, bad_index, lm_major, consistent, changed = struct.unpack_from("<iqiii", b, 0)
+    return dict(bad=bad, bad_index=bad_index, lm_major=lm_major, consistent=consistent, changed=changed,
+                pts_i_lm=np.frombuffer(b, dtype=np.float64, offset=24).reshape(-1, 2))
+
+
 def plan(driver, w, marg=0, use_ext=0, throughput=0, n_cus=256, g_max=0, half=0, order=None):
     lm, host, target, pi = w.lm, w.host, w.target, w.pts_i
     if order is not None:
@@ -286,6 +297,31 @@ def test_scan_observations(vio, driver):
     l2 = int(np.argmax(np.bincount(w.lm, minlength=w.n_landmarks) >= 2))
     b[first[l2] + 1, 0] += 1e-9
     assert scan(driver, w.n_landmarks, w.lm, w.host, w.target, b)["consistent"] == 0
+
+
+def test_scan_in_pieces_on_helper_threads(vio, driver):
+    """vio_set_observations' pass as the library runs it on a long landmark-major list — pieces of the list on parked helper threads
+    (vio_plan::scan_range / scan_finish / pool_run) — gives what the one-thread pass gives: flags, the first refused edge, the host
+    observations noted by landmark; a landmark's run may straddle two pieces."""
+    for n, seed, ragged in ((3000, 3, True), (20000, 42, False), (17, 9, True)):
+        w = vio.synth.make_window(n, seed=seed, ragged=ragged)
+        ref = scan(driver, w.n_landmarks, w.lm, w.host, w.target, w.pts_i)
+        for pieces in (1, 2, 4, 7):
+            r = scan_pieces(driver, pieces, w.n_landmarks, w.lm, w.host, w.target, w.pts_i)
+            assert (r["bad"], r["lm_major"], r["consistent"]) == (ref["bad"], ref["lm_major"], ref["consistent"]) == (0, 1, 1)
+            assert np.array_equal(r["pts_i_lm"], ref["pts_i_lm"])
+            assert scan_pieces(driver, pieces, w.n_landmarks, w.lm, w.host, w.target, w.pts_i, prev=ref["pts_i_lm"])["changed"] == 0
+        # an inconsistent host observation exactly at a piece boundary, a refused edge in the last piece
+        b = w.pts_i.copy()
+        e = len(w.lm) // 2
+        while e > 0 and w.lm[e] != w.lm[e - 1]:
+            e += 1
+        b[e, 1] += 1e-9
+        assert scan_pieces(driver, 2, w.n_landmarks, w.lm, w.host, w.target, b)["consistent"] == 0
+        a = w.target.copy()
+        a[-1] = 11
+        rb = scan_pieces(driver, 4, w.n_landmarks, w.lm, w.host, a, w.pts_i)
+        assert rb["bad"] == 1 and rb["bad_index"] == len(w.lm) - 1
 
 
 @pytest.mark.parametrize("n,seed,ragged,use_ext,throughput,half", [(1, 1, False, 0, 0, 0), (9, 2, True, 0, 0, 0), (300, 5, True, 1, 0, 0), (2000, 6, True, 0, 0, 0),

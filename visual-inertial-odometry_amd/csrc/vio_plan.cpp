@@ -1,6 +1,11 @@
 // vio_plan.cpp — see vio_plan.h.  No HIP in this file.
 #include "vio_plan.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -42,36 +47,110 @@ int best_item_size(const Input &in, const std::vector<Pattern> &patterns, const 
 }
 }  // namespace
 
-ScanResult scan_observations(int64_t N, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi,
-                             std::vector<double> &pts_i_lm) {
-    ScanResult r;
-    unsigned bad = 0, unsorted = 0, incons = 0, changed = 0;
+ScanFlags scan_range(int64_t N, int64_t e0, int64_t e1, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi, double *pl) {
+    ScanFlags f;
     const uint32_t un = (uint32_t)std::min<int64_t>(N, INT32_MAX);
-    if (pts_i_lm.size() != 2 * (size_t)N) { pts_i_lm.assign(2 * (size_t)N, 0.0); changed = 1; }
-    double *pl = pts_i_lm.data();
-    int32_t prev = -1;
-    for (int64_t e = 0; e < m; ++e) {
+    int32_t prev = e0 > 0 ? lm[e0 - 1] : -1;
+    for (int64_t e = e0; e < e1; ++e) {
         const int32_t l = lm[e];
-        bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)host[e] >= (uint32_t)NF) | (unsigned)((uint32_t)target[e] >= (uint32_t)NF) |
-               (unsigned)(host[e] == target[e]);
-        unsorted |= (unsigned)(l < prev);
-        if (e > 0 && l == prev) incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
+        f.bad |= (unsigned)((uint32_t)l >= un) | (unsigned)((uint32_t)host[e] >= (uint32_t)NF) | (unsigned)((uint32_t)target[e] >= (uint32_t)NF) |
+                 (unsigned)(host[e] == target[e]);
+        f.unsorted |= (unsigned)(l < prev);
+        if (e > 0 && l == prev) f.incons |= (unsigned)(host[e] != host[e - 1]) | (unsigned)(pi[2 * e] != pi[2 * e - 2]) | (unsigned)(pi[2 * e + 1] != pi[2 * e - 1]);
         else if ((uint32_t)l < un) {
-            changed |= (unsigned)(pl[2 * (size_t)l] != pi[2 * e]) | (unsigned)(pl[2 * (size_t)l + 1] != pi[2 * e + 1]);
+            f.changed |= (unsigned)(pl[2 * (size_t)l] != pi[2 * e]) | (unsigned)(pl[2 * (size_t)l + 1] != pi[2 * e + 1]);
             pl[2 * (size_t)l] = pi[2 * e]; pl[2 * (size_t)l + 1] = pi[2 * e + 1];
         }
         prev = l;
     }
-    r.changed = changed != 0;
-    if (bad)
+    return f;
+}
+ScanResult scan_finish(const ScanFlags &f, int64_t N, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target) {
+    ScanResult r;
+    r.changed = f.changed != 0;
+    if (f.bad)
         for (int64_t e = 0; e < m; ++e)
             if (lm[e] < 0 || lm[e] >= N || host[e] < 0 || host[e] >= NF || target[e] < 0 || target[e] >= NF || host[e] == target[e]) {
                 r.bad = true; r.bad_index = e;
                 return r;
             }
-    r.lm_major = !unsorted;
-    r.consistent = !unsorted && !incons;
+    r.lm_major = !f.unsorted;
+    r.consistent = !f.unsorted && !f.incons;
     return r;
+}
+ScanResult scan_observations(int64_t N, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi,
+                             std::vector<double> &pts_i_lm) {
+    unsigned resized = 0;
+    if (pts_i_lm.size() != 2 * (size_t)N) { pts_i_lm.assign(2 * (size_t)N, 0.0); resized = 1; }
+    ScanFlags f = scan_range(N, 0, m, lm, host, target, pi, pts_i_lm.data());
+    f.changed |= resized;
+    return scan_finish(f, N, m, lm, host, target);
+}
+
+// ---- helper threads ----
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    uint64_t gen = 0;                       // bumped by every pool_run
+    int n = 0;                              // tasks of the current run (task i >= 1 belongs to helper i - 1)
+    void (*fn)(void *, int) = nullptr;
+    void *arg = nullptr;
+    std::atomic<int> remaining{0};
+    bool quit = false;
+};
+static void pool_loop(HostPool *p, int me) {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(p->mu);
+    for (;;) {
+        p->cv.wait(lk, [&] { return p->gen != seen || p->quit; });
+        if (p->quit) return;
+        seen = p->gen;
+        if (me + 1 < p->n) {
+            void (*fn)(void *, int) = p->fn;
+            void *arg = p->arg;
+            lk.unlock();
+            fn(arg, me + 1);
+            lk.lock();
+            if (p->remaining.fetch_sub(1) == 1) p->cv_done.notify_all();
+        }
+    }
+}
+HostPool *pool_create(int helpers) {
+    HostPool *p = nullptr;
+    try {
+        p = new HostPool;
+        for (int i = 0; i < helpers; ++i) p->th.emplace_back(pool_loop, p, i);
+    } catch (...) {
+        if (p) pool_destroy(p);
+        return nullptr;
+    }
+    return p;
+}
+void pool_destroy(HostPool *p) {
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(p->mu); p->quit = true; }
+    p->cv.notify_all();
+    for (auto &t : p->th) if (t.joinable()) t.join();
+    delete p;
+}
+int pool_width(const HostPool *p) { return p ? (int)p->th.size() + 1 : 1; }
+void pool_run(HostPool *p, int n, void (*fn)(void *arg, int i), void *arg) {
+    if (!p || n <= 1) { for (int i = 0; i < n; ++i) fn(arg, i); return; }
+    n = std::min(n, pool_width(p));
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->n = n; p->fn = fn; p->arg = arg;
+        p->remaining.store(n - 1);
+        ++p->gen;
+    }
+    p->cv.notify_all();
+    fn(arg, 0);
+    for (int spin = 0; spin < 2000 && p->remaining.load() != 0; ++spin) { }      // (a helper is usually a few microseconds behind)
+    if (p->remaining.load() != 0) {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->cv_done.wait(lk, [&] { return p->remaining.load() == 0; });
+    }
 }
 
 ScanResult scan_observations_xyz(int64_t N, int64_t m, const int32_t *lm, const int32_t *frame) {

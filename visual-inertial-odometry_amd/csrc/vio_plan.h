@@ -37,6 +37,24 @@ struct ScanResult {
 };
 ScanResult scan_observations(int64_t N, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi,
                              std::vector<double> &pts_i_lm);
+// The pass in pieces, for callers that run it on several threads (vio_set_observations: 80 000 edges are 2.2 MB to read, DRAM-bound on one
+// core): scan_range over [e0, e1) — the edge before e0 is looked at, not written — gives the flags of that piece; the pieces' flags are
+// OR-ed and handed to scan_finish.  Valid for landmark-major lists (a landmark's run starts in exactly one piece, which notes its host
+// observation); when the OR-ed `unsorted` is set the caller runs scan_observations itself (the serial pass's last-writer semantics).
+// pts_i_lm must have its size (2 N) before the pieces run.
+struct ScanFlags { unsigned bad = 0, unsorted = 0, incons = 0, changed = 0; };
+ScanFlags scan_range(int64_t N, int64_t e0, int64_t e1, const int32_t *lm, const int32_t *host, const int32_t *target, const double *pi, double *pts_i_lm);
+ScanResult scan_finish(const ScanFlags &f, int64_t N, int64_t m, const int32_t *lm, const int32_t *host, const int32_t *target);
+
+// A few parked helper threads for such passes (host memory bandwidth, not compute).  pool_create: nullptr when no thread can be created —
+// pool_run then runs everything on the caller.  pool_run: fn(arg, i) for i = 0 .. n - 1 (n <= helpers + 1), i = 0 on the caller; returns
+// when all are done.  One pool_run at a time per pool.
+struct HostPool;
+HostPool *pool_create(int helpers);
+void pool_destroy(HostPool *p);
+int pool_width(const HostPool *p);          // helpers + 1 (1 for nullptr)
+void pool_run(HostPool *p, int n, void (*fn)(void *arg, int i), void *arg);
+
 // the same for an XYZ list (landmark, observing frame): range, and landmark-major with a landmark's frames ascending
 ScanResult scan_observations_xyz(int64_t N, int64_t m, const int32_t *lm, const int32_t *frame);
 
