@@ -109,7 +109,11 @@ int host_units_plan_op(int op, FILE *f, FILE *o) {
     in.lds_budget = half ? (80 * 1024 - 512) / 8 : (160 * 1024 - 512) / 8;
     in.lds = lds_inv; in.lds_xyz = lds_xyz; in.imu_item_lds = 450 + 225 + 450 + 32;
     vio_plan::Output out;
+    // (the per-landmark pass of plan_invdepth runs in pieces on helper threads when the caller has any: the driver has three, as the library)
+    vio_plan::HostPool *pool = std::getenv("HOST_UNITS_NO_POOL") ? nullptr : vio_plan::pool_create(3);
+    in.pool = pool;
     const bool ok = xyz ? vio_plan::plan_xyz(in, out, test_alloc, nullptr) : vio_plan::plan_invdepth(in, out, test_alloc, nullptr);
+    vio_plan::pool_destroy(pool);
     const int32_t st = out.status;
     wr(o, &st, 1);
     if (!ok) {

@@ -392,6 +392,22 @@ def test_plan_refusals(vio, driver):
     assert plan(driver, oob).get("scan_bad") == 1
 
 
+def test_plan_refusals_in_pieces(vio, driver):
+    """at 20 000 landmarks the per-landmark pass runs in pieces on helper threads: the FIRST refused landmark of the list names the error,
+    whichever piece it falls into, as one pass would"""
+    w = vio.synth.make_window(20000, seed=42)
+    first = np.concatenate([[0], np.cumsum(np.bincount(w.lm, minlength=w.n_landmarks))[:-1]])
+    assert plan(driver, w)["status"] == 0
+    for l_dup, l_hole in ((19000, 300), (300, 19000), (9999, 10001)):
+        bad = w.copy()
+        bad.target = bad.target.copy()
+        bad.target[first[l_dup] + 1] = bad.target[first[l_dup]]           # two observations of landmark l_dup in one frame
+        keep = w.lm != l_hole                                            # landmark l_hole without observations
+        bad.lm, bad.host, bad.target, bad.pts_i = bad.lm[keep], bad.host[keep], bad.target[keep], bad.pts_i[keep]
+        r = plan(driver, bad)
+        assert r["status"] == -5 and (("same frame" in r["err"]) if l_dup < l_hole else ("without observations" in r["err"])), (l_dup, l_hole, r["err"])
+
+
 def test_plan_fuzz(vio, driver):
     """random windows, random orders of the list (a landmark's edges in another order = another pattern): a valid plan or a refusal, never a crash"""
     rng = np.random.RandomState(11)

@@ -378,6 +378,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     }
     vio_plan::Input in;
     in.N = (int64_t)c->h_invd.size() / c->lm_dim; in.M = M;
+    in.pool = c->host_pool;                // (the helpers vio_set_observations parked, if the list was long enough to create them)
     in.olm = c->h_olm.data(); in.ohost = c->h_ohost.data(); in.otarget = c->h_otarget.data();
     in.pts_i = c->h_pts_i.empty() ? nullptr : c->h_pts_i.data();
     in.pts_i_lm = c->h_pts_i_lm.empty() ? nullptr : c->h_pts_i_lm.data();

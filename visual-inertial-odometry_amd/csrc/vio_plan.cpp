@@ -190,6 +190,55 @@ void build_pattern_tables(Pattern &pt, int g_max, int threads, int lds_budget, L
     pt.lds_doubles = lds(G, K, nb, pt.use_ext);
 }
 
+// The pattern key of every landmark — (count, host, targets in observation order), 4 bits a field — and the per-landmark checks, over a range
+// of landmarks: the part of the planner's pattern pass that needs nothing but the landmark's own edges (pieces of it run on helper threads,
+// Input::pool).  packed[l] = 0: the landmark is not part of this graph (MargOldFrame: not hosted in frame 0, or without observations).
+namespace {
+enum { PK_OK = 0, PK_NO_OBS, PK_TOO_MANY, PK_HOST, PK_TWICE };
+struct PatKeys {
+    const Input *in;
+    const int64_t *obs_off;
+    const int32_t *obs_idx;          // null: landmark-major (the list is its own CSR)
+    bool vouched;
+    uint64_t *packed;
+    int pieces;
+    int64_t N;
+    int err[8];
+    int64_t err_l[8];
+};
+void pat_keys_piece(void *arg, int i) {
+    PatKeys &j = *(PatKeys *)arg;
+    const Input &in = *j.in;
+    j.err[i] = PK_OK; j.err_l[i] = -1;
+    const int64_t l0 = j.N * i / j.pieces, l1 = j.N * (i + 1) / j.pieces;
+    for (int64_t l = l0; l < l1; ++l) {
+        const int64_t o0 = j.obs_off[l], n = j.obs_off[l + 1] - o0;
+        const int32_t *ix = j.obs_idx ? j.obs_idx + o0 : nullptr;
+        auto edge = [&](int64_t k) { return ix ? (int64_t)ix[k] : o0 + k; };
+        j.packed[l] = 0;
+        if (n == 0) {
+            if (in.marg) continue;
+            j.err[i] = PK_NO_OBS; j.err_l[i] = l; return;
+        }
+        const int64_t e0 = edge(0);
+        const int h = in.ohost[e0];
+        if (in.marg && h != 0) continue;          // MargOldFrame keeps landmarks hosted in frame 0 only (estimator.cpp:762-764)
+        if (n > VIO_MAXK) { j.err[i] = PK_TOO_MANY; j.err_l[i] = l; return; }
+        uint64_t packed = (uint64_t)n | ((uint64_t)h << 4);
+        unsigned seen = 1u << h;
+        for (int64_t k = 0; k < n; ++k) {
+            const int64_t e = edge(k);
+            if (!j.vouched && (in.ohost[e] != h || in.pts_i[2 * e] != in.pts_i[2 * e0] || in.pts_i[2 * e + 1] != in.pts_i[2 * e0 + 1])) { j.err[i] = PK_HOST; j.err_l[i] = l; return; }
+            const int t = in.otarget[e];
+            if (seen & (1u << t)) { j.err[i] = PK_TWICE; j.err_l[i] = l; return; }
+            seen |= 1u << t;
+            packed |= (uint64_t)t << (4 * (k + 2));
+        }
+        j.packed[l] = packed;
+    }
+}
+}  // namespace
+
 bool plan_invdepth(const Input &in, Output &out, AllocFn alloc, void *user) {
     const int64_t N = in.N, M = in.M;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -222,31 +271,24 @@ bool plan_invdepth(const Input &in, Output &out, AllocFn alloc, void *user) {
     std::vector<int32_t> lm_pattern(N, -1);
     const bool vouched = lm_major && in.vouched;
     if (!vouched && M > 0 && !in.pts_i) return fail(out, ERR_UNSUPPORTED, "the per-edge host observations are needed for a list the scan did not vouch for");
+    std::vector<uint64_t> packed_of((size_t)std::max<int64_t>(N, 1));
+    {
+        PatKeys pk;
+        pk.in = &in; pk.obs_off = obs_off.data(); pk.obs_idx = lm_major ? nullptr : obs_idx.data(); pk.vouched = vouched; pk.packed = packed_of.data(); pk.N = N;
+        pk.pieces = (in.pool && N >= 4096) ? std::min(pool_width(in.pool), 8) : 1;
+        pool_run(pk.pieces > 1 ? in.pool : nullptr, pk.pieces, pat_keys_piece, &pk);
+        // the first landmark (in list order) that was refused names the error, as one pass over the landmarks would
+        int code = PK_OK;
+        int64_t at = -1;
+        for (int i = 0; i < pk.pieces; ++i) if (pk.err[i] != PK_OK && (at < 0 || pk.err_l[i] < at)) { code = pk.err[i]; at = pk.err_l[i]; }
+        if (code == PK_NO_OBS) return fail(out, ERR_UNSUPPORTED, "landmark without observations (its 1x1 Hessian block would be singular)");
+        if (code == PK_TOO_MANY) return fail(out, ERR_UNSUPPORTED, "more than 10 observations of one landmark");
+        if (code == PK_HOST) return fail(out, ERR_UNSUPPORTED, "edges of one landmark must share host frame and host observation");
+        if (code == PK_TWICE) return fail(out, ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
+    }
     for (int64_t l = 0; l < N; ++l) {
-        const ObsRange ob = obs_of(l);
-        if (ob.empty()) {
-            if (in.marg) continue;
-            return fail(out, ERR_UNSUPPORTED, "landmark without observations (its 1x1 Hessian block would be singular)");
-        }
-        const int h = in.ohost[ob[0]];
-        if (in.marg && h != 0) continue;          // MargOldFrame keeps landmarks hosted in frame 0 only (estimator.cpp:762-764)
-        if ((int)ob.size() > VIO_MAXK) return fail(out, ERR_UNSUPPORTED, "more than 10 observations of one landmark");
-        int8_t key[1 + VIO_MAXK];
-        int nkey = 0;
-        key[nkey++] = (int8_t)h;
-        uint64_t packed = (uint64_t)ob.size() | ((uint64_t)h << 4);
-        bool seen[NF] = {false};
-        seen[h] = true;
-        for (size_t oi = 0; oi < ob.size(); ++oi) {
-            const int32_t e = ob[oi];
-            if (!vouched && (in.ohost[e] != h || in.pts_i[2 * e] != in.pts_i[2 * ob[0]] || in.pts_i[2 * e + 1] != in.pts_i[2 * ob[0] + 1]))
-                return fail(out, ERR_UNSUPPORTED, "edges of one landmark must share host frame and host observation");
-            const int t = in.otarget[e];
-            if (seen[t]) return fail(out, ERR_UNSUPPORTED, "two observations of one landmark in the same frame");
-            seen[t] = true;
-            packed |= (uint64_t)t << (4 * (nkey + 1));
-            key[nkey++] = (int8_t)t;
-        }
+        const uint64_t packed = packed_of[l];
+        if (packed == 0) continue;
         int id = -1;
         const unsigned hslot = (unsigned)((packed * 0x9E3779B97F4A7C15ull) >> 56);      // 256 slots in front of the map
         if (pat_cache_id[hslot] >= 0 && pat_cache_key[hslot] == packed) id = pat_cache_id[hslot];
@@ -260,16 +302,21 @@ bool plan_invdepth(const Input &in, Output &out, AllocFn alloc, void *user) {
             pat_cache_key[hslot] = packed; pat_cache_id[hslot] = id;
             Pattern pt;
             std::memset(&pt, 0, sizeof(pt));
-            pt.use_ext = in.use_ext; pt.host = h; pt.K = (int)ob.size();
+            const int K = (int)(packed & 15), h = (int)((packed >> 4) & 15);
+            pt.use_ext = in.use_ext; pt.host = h; pt.K = K;
+            bool seen[NF] = {false};
+            seen[h] = true;
+            for (int k = 0; k < K; ++k) seen[(packed >> (4 * (k + 2))) & 15] = true;
             int frames[NF], nfr = 0;
             for (int f = 0; f < NF; ++f) if (seen[f]) frames[nfr++] = f;
             pt.nb = nfr + pt.use_ext;
             int p = 0;
             if (pt.use_ext) pt.cam_block[p++] = 0;
             for (int q = 0; q < nfr; ++q) { const int f = frames[q]; if (f == h) pt.host_slot = p; pt.cam_block[p++] = (int8_t)(1 + f); }
-            for (int k = 0; k < pt.K; ++k) {
-                pt.target[k] = key[1 + k];
-                for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + key[1 + k]) pt.tslot[k] = (int8_t)q;
+            for (int k = 0; k < K; ++k) {
+                const int t = (int)((packed >> (4 * (k + 2))) & 15);
+                pt.target[k] = (int8_t)t;
+                for (int q = 0; q < pt.nb; ++q) if (pt.cam_block[q] == 1 + t) pt.tslot[k] = (int8_t)q;
             }
             build_pattern_tables(pt, in.g_max > 0 ? in.g_max : 128, in.lin_threads, in.lds_budget, in.lds);      // pt.G = the most landmarks the LDS holds
             out.patterns.push_back(pt);

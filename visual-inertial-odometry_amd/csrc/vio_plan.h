@@ -64,8 +64,10 @@ typedef int (*LdsXyzFn)(int G, int K);
 // staging memory for the arrays that go to the device as they are (the HIP library hands out its pinned arena)
 typedef void *(*AllocFn)(void *user, size_t bytes);
 
+struct HostPool;
 struct Input {
     int64_t N = 0, M = 0;
+    HostPool *pool = nullptr;              // helper threads for the per-landmark pass (or null: the caller's thread does it all)
     const int32_t *olm = nullptr, *ohost = nullptr, *otarget = nullptr;       // observation -> landmark / host frame / target (XYZ: observing) frame
     const double *pts_i = nullptr;         // [M][2] host observation per edge (lists the scan did not vouch for), or null
     const double *pts_i_lm = nullptr;      // [N][2] host observation per landmark (vouched lists)
