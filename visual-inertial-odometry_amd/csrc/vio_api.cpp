@@ -863,6 +863,8 @@ vio_status enqueue_trial(vio_ctx *c, Plan &pl, int mode, bool gn = false, int ga
     if (gn) T.cur_hint = c->cur_host;      // GN: the update rides with the next k_linearize / k_reduce (or with flush_decide)
     if (gn && c->test_in_solve) { T.gn_flags |= 1; c->test_in_solve = false; }      // three-launch path: the previous step's test at this kernel's head
     if (gn && c->gn_split) { T.gn_flags |= 16; c->gn_split = 0; }                   // ... and the chain of this system is eliminated already
+    static const bool no_early = std::getenv("VIO_NO_EARLY_START") != nullptr;      // diagnostic / tests: k_pose_solve_c's prologue with its barriers (bit 5)
+    if (no_early) T.gn_flags |= 32;
     { ProfScope ps(c, VIO_K_POSE_SOLVE); vio_launch_pose_solve(T, POSE_SOLVE_LDS, c->stream); }
     if (gn) {
         // the step is accepted whatever chi2 turns out to be: the landmark back-substitution, the chi2 of the new state and

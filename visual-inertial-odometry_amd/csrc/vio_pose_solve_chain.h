@@ -374,7 +374,7 @@ __device__ __forceinline__ void d_pose_solve_chain_body(const DeviceTables &T) {
     const double *cfi = SPLIT ? T.cfi : nullptr;
     double xs0 = 0.0, xs1 = 0.0, xd = 0.0, xy = 0.0, xe = 0.0;
 #ifndef CH_NO_EARLY_START
-    const bool early = !SPLIT && !lm_loop;
+    const bool early = !SPLIT && !lm_loop && !(T.gn_flags & 32);
 #else
     const bool early = false;
 #endif

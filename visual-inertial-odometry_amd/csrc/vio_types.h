@@ -206,6 +206,7 @@ struct DeviceTables {            // everything a kernel needs, passed by value
                                  // this step's prior update is left to the next k_linearize (b_prior') and k_reduce (err_prior');
                                  // bit 3 (k_backsub): flush of such a step, form b_prior' here; bit 4 (k_linearize, GN loop): the grid's first
                                  // workgroup eliminates the speed-bias chain (and forms the IMU items: no IMU workgroups follow the items)
+                                 // bit 5 (k_pose_solve_c, diagnostic: VIO_NO_EARLY_START): the prologue with its barriers instead of the early start
     int32_t cur_hint;            // >= 0: LmState.cur as the host tracks it through GN iterations (kernels skip the dependent load); -1: read lm->cur;
                                  // -2 (vio_solve's loop): the copy to linearise at is lm->cur ^ lm->pending, and bits 0 / 1 of gn_flags
                                  // count only while lm->pending
