@@ -2,14 +2,16 @@
 // (included by vio_pose_solve_chain.h, which documents the layout).
 //
 // Schedule (16 waves; "level" l = 0..5 of the speed-bias chain, blocks eA = l on wave 0 and eB = 10 - l on wave 1):
-//   waves 0, 1   F(e) -> pivots -> L_SO[e] = (SO[e] M_e) / d formed transposed, SD[succ] -= (L D) L^T from registers -> barrier l.
-//                They never wait for anybody: what they read (SD, SO) nobody else writes.
-//   waves 2..15  after barrier l ("phase l"): one fused task per (chain, camera tile t): L_SC[e][t] = (SC[e][t] M_e) / d, again
+//   waves 0, 1   F(e) with the rows of SO[e] riding (they leave as L_SO[e]) -> pivots -> SD[succ] -= (L D) L^T on the matrix core -> barrier l.
+//                They never wait for anybody: what they read (SD, SO) nobody else writes.  They run at instruction priority 3.
+//   waves 2..15  after barrier l ("phase l"): one fused task per (chain, camera tile t): L_SC[e][t] = (SC[e][t] M_e) / d, formed
 //                transposed, and the fill SC[succ][t] -= (L D) L_SO[e]^T from registers — no cross-wave dependency inside a phase;
 //                the camera-block updates CC(I,J) -= (L_SC[e][I] D) L_SC[e][J]^T of the PREVIOUS level (they need two waves' tiles:
-//                one barrier later) fill the rest of the phase; wave 15 carries the right-hand side.
+//                one barrier later), all fifteen tiles, fill the rest of the phase; wave 15 carries the right-hand side (priority 2).
+//   behind barrier 5 a short phase 5a (the five L_SC[5][t]: wave 0 its own tile's), one barrier, then F(0) on wave 0 while the other waves
+//                — not 4, 8, 12: they share wave 0's SIMD — give the camera tiles the terms of blocks 4, 6 and 5;
 //   then the camera block (5 tiles, F on wave 0 with look-ahead, two barriers per tile) and the back-substitution.
-// Operand images of a 9-column tile (row stride 10): the k index of the matrix core runs 0..11 in three steps; the third step's
+// Operand images of a 9-column tile (row stride 11): the k index of the matrix core runs 0..11 in three steps; the third step's
 // lanes with k > 8 read the tile's padding column (column 9, zero in the image and never written), so no load is predicated.
 #ifndef VIO_CHAIN_CORE_H
 #define VIO_CHAIN_CORE_H
