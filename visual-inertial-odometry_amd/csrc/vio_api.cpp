@@ -92,6 +92,8 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool view = false;          // a piece of another allocation (alloc_fixed's frame block): never freed, never grown
+    void view_of(void *base, size_t count) { p = (T *)base; n = count; view = true; }
     hipError_t resize(size_t count) {
         if (count == 0) count = 1;
         if (count <= n) return hipSuccess;
@@ -103,7 +105,7 @@ struct DevBuf {
         if (e == hipSuccess) n = count;
         return e;
     }
-    void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+    void release() { if (p && !view) hipFree(p); p = nullptr; n = 0; view = false; }
 };
 
 // Pinned staging for the uploads of a frame (plan tables, observations, states, prior): the copies out of it are truly
@@ -306,6 +308,7 @@ struct vio_ctx {
     std::vector<uint64_t> batch_gens;
     std::vector<int> batch_cur0;                       // every member's LmState.cur when the array was built
     DevBuf<DeviceTables> d_batch_tabs;
+    DevBuf<char> d_frame_block;                // d_state, d_bprior, d_errprior, d_lm, d_imu_valid are views of it (alloc_fixed)
     int batch_iters = 0;                               // iterations since the array was built (its parity flips every window's cur)
     vio_status flush_status = VIO_OK;                  // what the flush_decide inside the last make_tables returned
     bool decide_pending = false;                       // GN mode: the last step's test has not run yet (k_assemble of the next iteration does it)
@@ -449,7 +452,18 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *
 }
 
 // ---- device state management ---------------------------------------------------------------------------
+// The small per-frame inputs — states, b_prior, err_prior (two copies each), LmState, the IMU edges' valid flags — are pieces of ONE device
+// block in this order, so that a frame uploads them with one copy instead of five (a hipMemcpyAsync costs the host 5 us whatever its size).
+constexpr size_t FB_STATE = 0, FB_BPRIOR = FB_STATE + 2 * STATE_STRIDE * 8, FB_ERRPRIOR = FB_BPRIOR + 2 * 176 * 8, FB_LM = FB_ERRPRIOR + 2 * 160 * 8,
+                 FB_IV = (FB_LM + sizeof(LmState) + 15) / 16 * 16, FB_BYTES = FB_IV + 16 * 4;
 vio_status alloc_fixed(vio_ctx *c) {
+    if (!c->d_frame_block.p) {
+        HIPCHK(c->d_frame_block.resize(FB_BYTES));
+        HIPCHK(hipMemsetAsync(c->d_frame_block.p, 0, FB_BYTES, c->stream));
+        c->d_state.view_of(c->d_frame_block.p + FB_STATE, 2 * STATE_STRIDE); c->d_bprior.view_of(c->d_frame_block.p + FB_BPRIOR, 2 * 176);
+        c->d_errprior.view_of(c->d_frame_block.p + FB_ERRPRIOR, 2 * 160); c->d_lm.view_of(c->d_frame_block.p + FB_LM, 1);
+        c->d_imu_valid.view_of(c->d_frame_block.p + FB_IV, 16);
+    }
     HIPCHK(c->d_state.resize(2 * STATE_STRIDE)); HIPCHK(c->d_pairtab.resize(2 * PAIRTAB_STRIDE));
     HIPCHK(c->d_vis.resize(VIS_COUNT)); HIPCHK(c->d_pre.resize(VIO_WINDOW_SIZE * PRE_STRIDE));
     HIPCHK(c->d_imu_out.resize(VIO_WINDOW_SIZE * IMU_OUT)); HIPCHK(c->d_Hprior.resize(PD * PD));
@@ -619,17 +633,23 @@ vio_status push_to_device(vio_ctx *c, Plan &pl) {
     hipStream_t st = c->stream;
     HostArena &A = c->arena;
     const size_t ld = (size_t)pl.lm_dim;
-    double *s_state = A.put(c->h_state, (size_t)STATE_STRIDE);
+    // states, b_prior, err_prior, LmState and the IMU flags: an image of the device's frame block (its second copies — trial state, trial
+    // b_prior / err_prior: written by the kernels before anybody reads them — go out as zeros), one copy
+    char *s_fb = (char *)A.alloc(FB_BYTES);
     double *s_invd = (double *)A.alloc(ld * (size_t)std::max<int64_t>(pl.Ns, 1) * 8);
-    double *s_b = A.put(c->h_bprior.data(), (size_t)PD), *s_e = A.put(c->h_errprior.data(), (size_t)PRD);
-    int32_t iv[16] = {0};
-    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) iv[k] = c->imu_valid[k] ? 1 : 0;
-    int32_t *s_iv = A.put(iv, (size_t)16);
+    if (!s_fb || !s_invd) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+    std::memset(s_fb, 0, FB_BYTES);
+    std::memcpy(s_fb + FB_STATE, c->h_state, (size_t)STATE_STRIDE * 8);
+    std::memcpy(s_fb + FB_BPRIOR, c->h_bprior.data(), (size_t)PD * 8);
+    std::memcpy(s_fb + FB_ERRPRIOR, c->h_errprior.data(), (size_t)PRD * 8);
     std::memset(&c->h_lm, 0, sizeof(LmState));
     c->h_lm.ni = 2; c->h_lm.lambda = -1; c->h_lm.finite = 1; c->h_lm.last_chi = 1e20;
-    LmState *s_lm = A.put(&c->h_lm, (size_t)1);
-    if (!s_state || !s_invd || !s_b || !s_e || !s_iv || !s_lm) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
-    HIPCHK(hipMemcpyAsync(c->d_state.p, s_state, STATE_STRIDE * 8, hipMemcpyHostToDevice, st));
+    std::memcpy(s_fb + FB_LM, &c->h_lm, sizeof(LmState));
+    {
+        int32_t *iv = (int32_t *)(s_fb + FB_IV);
+        for (int k = 0; k < VIO_WINDOW_SIZE; ++k) iv[k] = c->imu_valid[k] ? 1 : 0;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_frame_block.p, s_fb, FB_BYTES, hipMemcpyHostToDevice, st));
     for (int64_t s = 0; s < pl.Ns; ++s)
         for (size_t k = 0; k < ld; ++k) s_invd[k * pl.Ns + s] = c->h_invd[ld * pl.sorted_to_orig[s] + k];
     if (pl.Ns) HIPCHK(hipMemcpyAsync(pl.d_invd.p, s_invd, ld * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
@@ -640,7 +660,6 @@ vio_status push_to_device(vio_ctx *c, Plan &pl) {
         HIPCHK(hipMemcpyAsync(c->d_pre.p, s_pre, VIO_WINDOW_SIZE * PRE_STRIDE * 8, hipMemcpyHostToDevice, st));
         c->imu_dirty = false;
     }
-    HIPCHK(hipMemcpyAsync(c->d_imu_valid.p, s_iv, sizeof(iv), hipMemcpyHostToDevice, st));
     if (c->prior_dirty) {
         double *s_H = A.put(c->h_Hprior.data(), (size_t)PD * PD), *s_J = A.put(c->h_Jtinv.data(), (size_t)PRD * PRD);
         if (!s_H || !s_J) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
@@ -649,9 +668,6 @@ vio_status push_to_device(vio_ctx *c, Plan &pl) {
         c->prior_dirty = false;
         c->prior_simg_valid = false;
     }
-    HIPCHK(hipMemcpyAsync(c->d_bprior.p, s_b, PD * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_errprior.p, s_e, PRD * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_lm.p, s_lm, sizeof(LmState), hipMemcpyHostToDevice, st));
     c->decide_pending = false; c->cur_host = 0;      // a fresh LmState: nothing of the old one is owed
     return VIO_OK;
 }
@@ -1034,7 +1050,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_Hprior.release(); c->d_bprior.release(); c->d_errprior.release(); c->d_Jtinv.release(); c->d_Hs.release();
     c->d_bs.release(); c->d_bfull.release(); c->d_diagfull.release(); c->d_dx.release(); c->d_step_tot.release(); c->d_sp_part.release();
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release(); c->d_cfi.release(); c->d_imu_map.release(); c->d_prior_simg.release(); c->d_prior_flags.release(); c->d_prior_list.release(); c->d_prior_cval.release();
-    c->d_batch_tabs.release(); c->d_rank.release(); c->d_gather_map.release(); c->d_gath.release(); c->d_step_gath.release();
+    c->d_batch_tabs.release(); c->d_frame_block.release(); c->d_rank.release(); c->d_gather_map.release(); c->d_gath.release(); c->d_step_gath.release();
     c->arena.release(c->own_stream);
     c->h_pts_j.release(); c->d_raw_pts_j.release();
     if (c->pull_stage) hipHostFree(c->pull_stage);
