@@ -215,9 +215,10 @@ struct Plan {
     int lin_threads = 0;                       // k_linearize's workgroup width for this plan: lin_threads_host(), or lin_threads_half_host() (two workgroups to a CU)
     DevBuf<ItemDesc> d_items;
     DevBuf<int32_t> d_list_off, d_list, d_first, d_obs_idx;      // d_first / d_obs_idx: k_gather_obs's view of the caller's observation list
+    DevBuf<char> d_tables;      // d_items, d_list_off, d_list, d_first and (inverse depth) d_pts_i are views of it: one upload per plan (upload_plan)
     DevBuf<double> d_pts_i, d_pts_j, d_invd, d_slab, d_lw, d_dxl, d_step_part;
     void release() {
-        d_items.release(); d_list_off.release(); d_list.release(); d_first.release(); d_obs_idx.release();
+        d_items.release(); d_list_off.release(); d_list.release(); d_first.release(); d_obs_idx.release(); d_tables.release();
         d_pts_i.release(); d_pts_j.release(); d_invd.release(); d_slab.release(); d_lw.release(); d_dxl.release();
         d_step_part.release();
         valid = false;
@@ -420,26 +421,37 @@ vio_status upload_plan(vio_ctx *c, Plan &pl, const double *pts_i, const double *
     vio_plan::build_reduce_lists(pl.items, pl.list_off, pl.list);
     // upload
     const size_t ni = pl.items.size();
-    HIPCHK(pl.d_items.resize(ni));
-    HIPCHK(pl.d_list_off.resize(pl.list_off.size())); HIPCHK(pl.d_list.resize(pl.list.size()));
     const size_t ld = (size_t)pl.lm_dim;
-    HIPCHK(pl.d_pts_i.resize(2 * (size_t)pl.Ns)); HIPCHK(pl.d_pts_j.resize(2 * (size_t)pl.Ms));
+    // The plan's tables — item descriptors, k_reduce's lists, the gather's `first`, the landmarks' host observations — are pieces of one
+    // device block and leave the staging with one copy (five before: a hipMemcpyAsync costs the host 5 us whatever its size).
+    const bool with_first = pl.Ms && !pts_j, with_pi = pl.Ns && pl.lm_dim == 1;
+    auto up16 = [](size_t b) { return (b + 15) / 16 * 16; };
+    const size_t o_items = 0, o_off = up16(o_items + std::max<size_t>(ni, 1) * sizeof(ItemDesc)), o_list = up16(o_off + pl.list_off.size() * 4),
+                 o_first = up16(o_list + std::max<size_t>(pl.list.size(), 1) * 4), o_pi = up16(o_first + (with_first ? (size_t)pl.Ns * 4 : 0)),
+                 tb_bytes = up16(o_pi + (with_pi ? 2 * (size_t)pl.Ns * 8 : 0));
+    pl.d_items.release(); pl.d_list_off.release(); pl.d_list.release(); pl.d_first.release();      // (views: nothing is freed)
+    if (with_pi || pl.d_pts_i.view) pl.d_pts_i.release();       // (an allocation of its own only where the plan's landmarks were XYZ before)
+    HIPCHK(pl.d_tables.resize(tb_bytes));
+    pl.d_items.view_of(pl.d_tables.p + o_items, std::max<size_t>(ni, 1)); pl.d_list_off.view_of(pl.d_tables.p + o_off, pl.list_off.size());
+    pl.d_list.view_of(pl.d_tables.p + o_list, std::max<size_t>(pl.list.size(), 1));
+    if (with_first) pl.d_first.view_of(pl.d_tables.p + o_first, (size_t)pl.Ns);
+    if (with_pi) pl.d_pts_i.view_of(pl.d_tables.p + o_pi, 2 * (size_t)pl.Ns); else HIPCHK(pl.d_pts_i.resize(2 * (size_t)pl.Ns));
+    HIPCHK(pl.d_pts_j.resize(2 * (size_t)pl.Ms));
     HIPCHK(pl.d_invd.resize(2 * ld * (size_t)std::max<int64_t>(pl.Ns, 1))); HIPCHK(pl.d_slab.resize(pl.slab_doubles));
     HIPCHK(pl.d_lw.resize(2 * pl.lw_doubles)); HIPCHK(pl.d_dxl.resize(ld * (size_t)pl.Ns));      // lw: two sets, see DeviceTables.lw_set
     HIPCHK(pl.d_step_part.resize(4 * (ni + VIO_WINDOW_SIZE)));
     hipStream_t st = c->stream;
     // everything leaves from the pinned staging: no wait here (activate() marks the staging busy until these copies are done)
-    const ItemDesc *s_items = c->arena.put(pl.items.data(), ni);
-    const int32_t *s_off = c->arena.put(pl.list_off.data(), pl.list_off.size()), *s_list = c->arena.put(pl.list.data(), pl.list.size());
-    if (!s_items || !s_off || !s_list) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
-    if (ni) HIPCHK(hipMemcpyAsync(pl.d_items.p, s_items, ni * sizeof(ItemDesc), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(pl.d_list_off.p, s_off, pl.list_off.size() * 4, hipMemcpyHostToDevice, st));
-    if (!pl.list.empty()) HIPCHK(hipMemcpyAsync(pl.d_list.p, s_list, pl.list.size() * 4, hipMemcpyHostToDevice, st));
-    if (pl.Ns && pl.lm_dim == 1) HIPCHK(hipMemcpyAsync(pl.d_pts_i.p, pts_i, 2 * (size_t)pl.Ns * 8, hipMemcpyHostToDevice, st));
+    char *s_tb = (char *)c->arena.alloc(tb_bytes);
+    if (!s_tb) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
+    if (ni) std::memcpy(s_tb + o_items, pl.items.data(), ni * sizeof(ItemDesc));
+    std::memcpy(s_tb + o_off, pl.list_off.data(), pl.list_off.size() * 4);
+    if (!pl.list.empty()) std::memcpy(s_tb + o_list, pl.list.data(), pl.list.size() * 4);
+    if (with_first) std::memcpy(s_tb + o_first, first, (size_t)pl.Ns * 4);
+    if (with_pi) std::memcpy(s_tb + o_pi, pts_i, 2 * (size_t)pl.Ns * 8);
+    HIPCHK(hipMemcpyAsync(pl.d_tables.p, s_tb, tb_bytes, hipMemcpyHostToDevice, st));
     if (pl.Ms && pts_j) HIPCHK(hipMemcpyAsync(pl.d_pts_j.p, pts_j, 2 * (size_t)pl.Ms * 8, hipMemcpyHostToDevice, st));
     else if (pl.Ms) {
-        HIPCHK(pl.d_first.resize((size_t)pl.Ns));
-        HIPCHK(hipMemcpyAsync(pl.d_first.p, first, (size_t)pl.Ns * 4, hipMemcpyHostToDevice, st));
         if (obs_idx) {
             HIPCHK(pl.d_obs_idx.resize((size_t)n_obs_idx));
             HIPCHK(hipMemcpyAsync(pl.d_obs_idx.p, obs_idx, (size_t)n_obs_idx * 4, hipMemcpyHostToDevice, st));
