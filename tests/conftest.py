@@ -64,9 +64,13 @@ def hip_lib(vio):
 @pytest.fixture(scope="session")
 def hip_debug_lib(vio):
     """The product's sources built with -DVIO_DEBUG_ENTRY_POINTS (vio_debug_chain_solve): not the product library."""
-    so = os.path.join(PKG_DIR, "csrc", "diag", "libvio_hip_debug.so")
-    if not os.path.exists(so):
-        sys.path.insert(0, ROOT)
-        import __graft_entry__ as g
+    # (build_hip is a no-op unless a source is newer than the library: a stale debug build must not test an old kernel against new sources;
+    #  on a box without hipcc the library that travelled with the snapshot is used as it is)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    try:
         g.build_hip()
+    except RuntimeError as exc:
+        if "hipcc not found" not in str(exc):
+            raise
     return vio.load_hip_debug()

@@ -86,7 +86,6 @@ constexpr int LDS_BUDGET_DOUBLES = (160 * 1024 - 512) / 8;   // per linearize wo
 constexpr int LDS_BUDGET_HALF_DOUBLES = (80 * 1024 - 512) / 8;   // two workgroups to a CU (k_linearize_h: plans of the throughput policy)
 constexpr int POSE_SOLVE_TILED = 66 * 272 + 192;   // PS_PACKED of vio_kernels.hip: 66 tiles of 16x17 + the rhs row
 constexpr int POSE_SOLVE_LDS = (POSE_SOLVE_TILED + 176 + 272 + 272 + 192 + 176 + 112 + 176 + 184) * 8 + 176 * 4 + 64;
-constexpr int IMU_ITEM_LDS_DOUBLES = 450 + 225 + 450 + 32;
 
 template <typename T>
 struct DevBuf {
@@ -269,6 +268,9 @@ struct vio_ctx {
     bool obs_consistent = false;               // ... and vio_set_observations has seen that they share host frame and host observation
     bool obs_lm_major = false;                 // the observations of a landmark are consecutive and the landmarks ascend (vio_set_observations)
     bool linearized = false;
+    bool lin_fresh = false;                    // vio_linearize was the last call that touched the device state: vio_solve starts from its system
+    hipEvent_t lin_ev[2] = {nullptr, nullptr}; // vio_solve's timing of the first linearisation (vio_solve_report.hessian_ms)
+    float last_lin_ms = 0;                     // ... the last such timing: reported when the linearisation is already there
     bool pairtab_valid = false;
     bool stepwise_updated = false;
     double gn_lambda = -1.0;
@@ -344,9 +346,11 @@ namespace {
 
 // every entry point: the context's device, and whatever error an earlier call of anybody's left on this thread forgotten (the
 // launch checks below ask hipGetLastError(), which would report it as theirs)
-static inline void enter_device(const vio_ctx *c) {
+// keep_fresh: entry points that leave the device's state and system as they are (vio_synchronize, the profiling calls)
+static inline void enter_device(const vio_ctx *c, bool keep_fresh = false) {
     (void)hipSetDevice(c->cfg.device);
     (void)hipGetLastError();
+    if (!keep_fresh) const_cast<vio_ctx *>(c)->lin_fresh = false;
 }
 
 vio_status fail(vio_ctx *c, vio_status s, const std::string &msg) {
@@ -856,10 +860,13 @@ vio_status enqueue_linearize(vio_ctx *c, Plan &pl, bool gn = false, int gate = 0
     // chain order, nobody waiting for the natural-order matrix.  k_reduce_c writes the image; the step test moves to the head of the
     // k_pose_solve_c that follows (enqueue_trial).
     c->test_in_solve = false;
-    if (gn && three_launch(c, T)) {
+    // (round 6: also the linearisation that opens vio_solve / vio_linearize — nothing of the loops' flags is needed for the fused sums;
+    //  VIO_FIRST_FOUR_LAUNCHES=1 keeps k_reduce + k_assemble_c there, for A/B)
+    static const bool first_four = std::getenv("VIO_FIRST_FOUR_LAUNCHES") != nullptr;
+    if (three_launch(c, T) && (gn || (gate == 0 && !first_four))) {
         { ProfScope ps(c, VIO_K_REDUCE); vio_launch_reduce_assemble(R, T, c->stream); }
         // (VIO_GN_SPLIT=2, diagnostic: the chain eliminated in a launch of its own, from the assembled image)
-        if (split_mode == 2) { vio_launch_chain_pre(T, c->stream); c->gn_split = 2; }
+        if (gn && split_mode == 2) { vio_launch_chain_pre(T, c->stream); c->gn_split = 2; }
         if (test_prev) { c->test_in_solve = true; c->decide_pending = false; }
         HIPCHK(hipGetLastError());
         c->linearized = true;
@@ -1069,6 +1076,7 @@ void vio_destroy(vio_ctx *c) {
     if (c->marg_stage) hipHostFree(c->marg_stage);
     if (c->h_lm_pin) hipHostFree(c->h_lm_pin);
     if (c->lm_event) hipEventDestroy(c->lm_event);
+    for (hipEvent_t e : c->lin_ev) if (e) hipEventDestroy(e);
     for (hipEvent_t e : c->prof_events) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
     (void)hipGetLastError();         // (an event of a borrowed stream that is gone may have complained: not the next caller's business)
@@ -1428,6 +1436,7 @@ vio_status vio_linearize(vio_ctx *c) {
     VIOCHK(activate(c, c->solve_plan, 0));
     if (c->stepwise_updated) c->stepwise_updated = false;     // a new linearisation commits the step
     VIOCHK(enqueue_linearize(c, c->solve_plan));
+    c->lin_fresh = true;
     return VIO_OK;
 }
 
@@ -1510,6 +1519,7 @@ vio_status vio_eval_step(vio_ctx *c, int32_t *accepted, double *chi2, double *la
 
 vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
     if (!c) return VIO_ERR_BAD_ARG;
+    const bool fresh = c->lin_fresh;
     enter_device(c);
     bool any_imu = false;
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) any_imu |= c->imu_valid[k];
@@ -1517,15 +1527,18 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
     const auto t0 = std::chrono::steady_clock::now();
     VIOCHK(activate(c, c->solve_plan, 0));
     Plan &pl = c->solve_plan;
-    float first_lin_ms = 0;
-    struct EventPair {      // destroyed on every way out
-        hipEvent_t a = nullptr, b = nullptr;
-        ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
-    } ev;
-    HIPCHK(hipEventCreate(&ev.a)); HIPCHK(hipEventCreate(&ev.b));
-    HIPCHK(hipEventRecord(ev.a, c->stream));
-    VIOCHK(enqueue_linearize(c, pl));
-    HIPCHK(hipEventRecord(ev.b, c->stream));
+    // Problem::Solve opens with MakeHessian (problem.cc:178-183).  When the caller's last call was vio_linearize on this very state and
+    // graph, that system is on the device already — the same kernels on the same inputs would write the same bits again — and the solve
+    // starts from it (`fresh`, read before enter_device cleared it; VIO_SOLVE_RELINEARIZE=1: always linearise, for A/B).
+    static const bool always_lin = std::getenv("VIO_SOLVE_RELINEARIZE") != nullptr;
+    const bool reuse = fresh && !always_lin && c->linearized && c->active == &pl;
+    float first_lin_ms = c->last_lin_ms;
+    if (!reuse) {
+        if (!c->lin_ev[0]) { HIPCHK(hipEventCreate(&c->lin_ev[0])); HIPCHK(hipEventCreate(&c->lin_ev[1])); }
+        HIPCHK(hipEventRecord(c->lin_ev[0], c->stream));
+        VIOCHK(enqueue_linearize(c, pl));
+        HIPCHK(hipEventRecord(c->lin_ev[1], c->stream));
+    }
     {
         MAKE_TABLES(T, c, pl);
         VIOCHK(enqueue_init_lm(c, T, iterations));
@@ -1570,7 +1583,7 @@ vio_status vio_solve(vio_ctx *c, int32_t iterations, vio_solve_report *rep) {
         if (status == VIO_OK && iterations <= 0) status = read_lm(c);
     }
     if (status != VIO_OK) return status;
-    hipEventElapsedTime(&first_lin_ms, ev.a, ev.b);
+    if (!reuse && hipEventElapsedTime(&first_lin_ms, c->lin_ev[0], c->lin_ev[1]) == hipSuccess) c->last_lin_ms = first_lin_ms;
     vio_solve_report r;
     std::memset(&r, 0, sizeof(r));
     r.initial_chi2 = c->h_lm.init_chi;
@@ -1627,6 +1640,7 @@ vio_status vio_batch_gn_iteration(vio_ctx *const *ctxs, int32_t count, double la
     for (int i = 0; i < count; ++i) {
         vio_ctx *m = ctxs[i];
         if (!m) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_gn_iteration: null context");
+        m->lin_fresh = false;
         if (m->cfg.device != c->cfg.device || m->stream != c->stream)
             return fail(c, VIO_ERR_BAD_ARG, "vio_batch_gn_iteration: the contexts must share one device and one stream (vio_config.stream; vio_get_stream)");
         if (sharded(m)) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_gn_iteration: sharded contexts cannot be batched");
@@ -1726,6 +1740,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
     for (int i = 0; i < count; ++i) {
         vio_ctx *m = ctxs[i];
         if (!m) return fail(c, VIO_ERR_BAD_ARG, "vio_batch_solve: null context");
+        m->lin_fresh = false;
         if (m->cfg.device != c->cfg.device || m->stream != c->stream)
             return fail(c, VIO_ERR_BAD_ARG, "vio_batch_solve: the contexts must share one device and one stream (vio_config.stream; vio_get_stream)");
         if (sharded(m)) return fail(c, VIO_ERR_UNSUPPORTED, "vio_batch_solve: sharded contexts cannot be batched");
@@ -1826,7 +1841,7 @@ vio_status vio_batch_solve(vio_ctx *const *ctxs, int32_t count, int32_t iteratio
 
 vio_status vio_synchronize(vio_ctx *c) {
     if (!c) return VIO_ERR_BAD_ARG;
-    enter_device(c);
+    enter_device(c, true);
     HIPCHK(hipStreamSynchronize(c->stream));
     return VIO_OK;
 }
@@ -2273,7 +2288,7 @@ vio_status vio_profile_begin(vio_ctx *c, int32_t which) {
 
 vio_status vio_profile_end(vio_ctx *c, double *total_ms, int64_t *launches) {
     if (!c) return VIO_ERR_BAD_ARG;
-    enter_device(c);
+    enter_device(c, true);
     HIPCHK(hipStreamSynchronize(c->stream));
     double tot = 0;
     const size_t used = c->prof_used;
