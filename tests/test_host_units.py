@@ -1,5 +1,5 @@
 """CPU-tier tests of the product library's own HOST code — the part of libvio_hip.so that needs no device — compiled with g++ alone into a
-driver (tests/cpp/host_units_main.cpp) and, with VIO_TEST_SANITIZE=1, under AddressSanitizer + UBSan:
+driver (tests/cpp/host_units_main.cpp) and, with VIO_TEST_SANITIZE=1, under AddressSanitizer + UBSan (VIO_TEST_SANITIZE=thread: ThreadSanitizer):
 
   csrc/host_dense.cpp   symmetric_eigen (SelfAdjointEigenSolver's role, problem.cc:747-773), inverse15 (covariance.inverse(), edge_imu.cc:35),
                         marginalize_tail (problem.cc:717-779), preintegrate (integration_base.h:54-158) — against the fixtures of the COMPILED
@@ -37,6 +37,11 @@ def driver(tmp_path_factory):
            os.path.join(ROOT, "tests", "cpp", "host_units_plan.cpp"), os.path.join(CSRC, "host_dense.cpp"), os.path.join(CSRC, "vio_plan.cpp"), "-pthread"]
     if os.environ.get("VIO_TEST_SANITIZE") == "1":
         cmd += ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    elif os.environ.get("VIO_TEST_SANITIZE") == "thread":
+        # ThreadSanitizer tier (round 6: the library's host side is multi-threaded — the shared helper pool, the background worker, the
+        # eigen-solver's pipeline).  VIO_NO_TARGET_CLONES: the AVX2 / baseline clones are dispatched by ifunc resolvers, which run before
+        # TSan's runtime is initialised.  TSAN_OPTIONS is left to the caller; a report fails the run (exit code 66).
+        cmd += ["-O1", "-g", "-fsanitize=thread", "-fno-omit-frame-pointer", "-DVIO_NO_TARGET_CLONES"]
     subprocess.check_call(cmd + ["-o", exe])
     assert ITEM_DTYPE.itemsize == 104
 
@@ -147,6 +152,56 @@ def test_marginalize_tail_on_degenerate_systems(driver):
     Hn = a[:156 * 156].reshape(156, 156)
     keep = [i for i in range(171) if not 6 <= i < 21]
     assert np.abs(Hn - H[np.ix_(keep, keep)]).max() <= 1e-9 * np.abs(H).max()      # eigenvalues below the cut are zeroed: the rest is untouched
+
+
+def test_eigen_solver_on_helper_threads_returns_the_legacy_bits(driver):
+    """Round 6: the QL iteration records its plane rotations and they are applied to the eigenvector matrix by row blocks, on 1 .. 7 threads,
+    while the iteration still runs.  Whatever the thread count, the result must be, bit for bit, what the routine it replaced returns
+    (symmetric_eigen_legacy: the rotations applied inside the loop) — the priors of every earlier round depend on it."""
+    rng = np.random.RandomState(11)
+    z = np.load(os.path.join(GOLDEN_DIR, "symmetric_eigen.npz"))
+    mats = [np.ascontiguousarray(z["A_small"]), np.ascontiguousarray(z["A_prior"])]
+    for n in (1, 2, 31, 32, 33, 75, 101):
+        J = rng.normal(size=(n + 2 if n % 2 else max(n // 2, 1), n)) * 10.0 ** rng.uniform(-2, 4)
+        mats.append(J.T @ J)                   # (full rank, and rank-deficient: eigenvalues at the rounding level)
+    Z = mats[-2].copy()
+    Z[::3, :] = 0.0
+    Z[:, ::3] = 0.0
+    mats.append(Z)                             # exactly-zero rows and columns, as a prior's dead frames leave them
+    for A in mats:
+        n = A.shape[0]
+        for width in (1, 2, 4, 7):
+            out = driver(struct.pack("<iii", 5, n, width) + f64(A))
+            same, ok = struct.unpack("<ii", out)
+            assert same == 1 and ok == 1, (n, width)
+
+
+def test_marginalize_tail_does_not_depend_on_the_thread_count(driver):
+    """The tail on the process's shared pool (what vio_marginalize runs) against the same call on the caller's thread alone: identical bytes."""
+    rng = np.random.RandomState(5)
+    live = list(range(6)) + list(range(6, 21)) + [6 + 15 * f + i for f in range(1, 11) for i in range(6)] + list(range(27, 36))
+    J = np.zeros((300, 171))
+    J[:, live] = rng.normal(size=(300, len(live))) * 30.0
+    H, b = J.T @ J, J.T @ rng.normal(size=300)
+    base = driver(struct.pack("<iii", 6, 1, 0) + f64(H) + f64(b))
+    assert struct.unpack_from("<i", base, 0)[0] == 75               # the most rows a window's graph can keep live (DESIGN.md section 5)
+    for width in (2, 4, 7):
+        assert driver(struct.pack("<iii", 6, width, 0) + f64(H) + f64(b)) == base, width
+
+
+def test_the_process_has_one_set_of_helper_threads_whatever_the_number_of_contexts(driver):
+    """Round 6: one pool of helpers and one background worker per process, reference-counted by the contexts — a batch of
+    256 contexts parked 1 024 threads before.  256 owners on 4 caller threads come and go, submit background jobs (vio_marginalize_begin's
+    hand-over), wait for them in any order (vio_marginalize_end, vio_destroy) and run parallel passes that find the pool busy or free:
+    every job runs exactly once, every pass's tasks run exactly once, at most SHARED_POOL_HELPERS + 1 = 7 threads ever exist, and none is
+    left when the last owner has gone.  Under VIO_TEST_SANITIZE=thread this is the race check of the hand-overs."""
+    for contexts, callers, rounds, seed in ((1, 1, 3, 1), (256, 4, 2, 2), (16, 8, 4, 3)):
+        out = driver(struct.pack("<iiiii", 7, contexts, callers, rounds, seed))
+        ran, expected, max_alive, passes_ok, after = struct.unpack("<iiiii", out)
+        assert ran == expected and expected > 0
+        assert passes_ok == 1
+        assert 0 < max_alive <= 7
+        assert after == 0
 
 
 def test_preintegrate_on_the_mh05_sensor_data(vio, oracle_lib, driver):

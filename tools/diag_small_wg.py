@@ -21,10 +21,13 @@ for r in range(3):
     if r < 2:
         prior = ctx.marginalize(vio.MARG_OLD)
 ctx.synchronize()
-nb = 400
-buf = np.zeros((nb, 16), dtype=np.uint64)
 f = lib.dll.vio_debug_stamps; f.restype = C.c_int
-assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(nb)) == 0
+for nb in range(400, 10, -2):          # (the buffer holds items + IMU workgroups + 48 blocks: the largest read that fits)
+    buf = np.zeros((nb, 16), dtype=np.uint64)
+    if f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(nb)) == 0:
+        break
+nb -= 46
+buf = buf[:nb]
 st = buf.astype(np.int64)
 v = (st[:, 9] > st[:, 8]) & (st[:, 8] > 0) & (st[:, 9] - st[:, 8] < 10_000_000)
 idx = np.nonzero(v)[0]

@@ -2,9 +2,15 @@
 #include "host_dense.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <vector>
+#ifdef VIO_TAIL_TIMING
+#include <chrono>
+#include <cstdio>
+#endif
 
 namespace vio_host {
 
@@ -46,9 +52,170 @@ void inverse15(const double *cov, double *info) {
 
 // Householder tridiagonalisation followed by the implicit-shift QL iteration.  The work matrix is kept column-major
 // (at(i, j) = V[j n + i]): every inner loop of the two phases walks down a column.
+// (compiled twice, AVX2 and baseline, dispatched at load time: same operations in the same order, wider vectors;
+//  -DVIO_NO_TARGET_CLONES: one plain copy — ifunc resolvers run before ThreadSanitizer's runtime is up)
+#if defined(VIO_NO_TARGET_CLONES) || defined(__HIP_DEVICE_COMPILE__)     // (hipcc's device pass of this host-only file knows no multiversioning)
+#define VIO_CLONES
+#else
+#define VIO_CLONES __attribute__((target_clones("avx2", "default")))
+#endif
+
+namespace {
+struct Rot { int i; double c, s; };
+struct QlJob {
+    double *V = nullptr;
+    int n = 0;
+    Rot *rots = nullptr;
+    size_t cap = 0;
+    double *d = nullptr, *e = nullptr;
+    std::atomic<size_t> avail{0};           // rotations recorded so far (release-published by the producer)
+    std::atomic<bool> done{false}, overflow{false};
+    bool ok = true;
+};
+constexpr int QL_MAXB = 96;                 // rows of a block (the carried column lives on the stack)
+
+// rotations [from, to) applied to rows [r0, r1) of V.  A sweep's rotations walk down the column pairs (i, i + 1), (i - 1, i), ...: the column a
+// rotation leaves as `at(k, i)` is the next one's `at(k, i + 1)` and stays in `carry` (carry_col: which column it is, -1: none).
+VIO_CLONES
+void ql_apply(double *V, int n, int r0, int r1, const Rot *__restrict rots, size_t from, size_t to, double *__restrict carry_io, int &carry_col) {
+    const int nb = r1 - r0;
+    double carry[QL_MAXB];
+    int cc = carry_col;
+    for (int k = 0; k < nb; ++k) carry[k] = carry_io[k];
+    for (size_t q = from; q < to; ++q) {
+        const int i = rots[q].i;
+        const double c = rots[q].c, s = rots[q].s;
+        double *__restrict ci = V + (size_t)i * n + r0;
+        double *__restrict ci1 = V + (size_t)(i + 1) * n + r0;
+        if (cc != i + 1) {
+            if (cc >= 0) { double *__restrict pc = V + (size_t)cc * n + r0; for (int k = 0; k < nb; ++k) pc[k] = carry[k]; }
+            for (int k = 0; k < nb; ++k) carry[k] = ci1[k];
+        }
+        for (int k = 0; k < nb; ++k) {
+            const double h = carry[k], a = ci[k];
+            ci1[k] = s * a + c * h;
+            carry[k] = c * a - s * h;
+        }
+        cc = i;
+    }
+    for (int k = 0; k < nb; ++k) carry_io[k] = carry[k];
+    carry_col = cc;
+}
+void ql_flush(double *V, int n, int r0, int r1, const double *carry, int &carry_col) {
+    if (carry_col >= 0) { double *cc = V + (size_t)carry_col * n + r0; for (int k = 0; k < r1 - r0; ++k) cc[k] = carry[k]; }
+    carry_col = -1;
+}
+// tql2 on (d, e) alone, recording its rotations (the statements of the loop this replaces, in their order, minus the update of V)
+void ql_generate(QlJob &J) {
+    const int n = J.n;
+    double *d = J.d, *e = J.e;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = std::ldexp(1.0, -52);
+    size_t nr = 0;
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }
+        if (m == n) m = n - 1;
+        if (m > l) {
+            int iter = 0;
+            do {
+                if (++iter > 200) { J.ok = false; break; }
+                if (nr + (size_t)(m - l) > J.cap) { J.overflow.store(true); J.avail.store(nr, std::memory_order_release); J.done.store(true, std::memory_order_release); return; }
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    J.rots[nr].i = i; J.rots[nr].c = c; J.rots[nr].s = s;
+                    ++nr;
+                }
+                J.avail.store(nr, std::memory_order_release);
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    J.avail.store(nr, std::memory_order_release);
+    J.done.store(true, std::memory_order_release);
+}
+// participant i of nt: 0 generates, then applies to its (small) block; the others apply to theirs as the rotations arrive
+void ql_participant(void *arg, int i, int nt) {
+    QlJob &J = *(QlJob *)arg;
+    const int n = J.n;
+    if (nt <= 1) {
+        // (one thread: the whole iteration first, then the rotations block by block — on the round's host 125 + 85 us for 75 rows where the
+        //  routine replaced, which applied every rotation where it was generated, took 260; generating and applying in ONE loop with the
+        //  carried column, so that the core could overlap the dependent hypot / division chain with the vector work, measured 337: dropped)
+        ql_generate(J);
+        if (J.overflow.load()) return;
+        const size_t total = J.avail.load(std::memory_order_acquire);
+        double carry[QL_MAXB];
+        for (int r0 = 0; r0 < n; r0 += QL_MAXB) {
+            int cc = -1;
+            const int r1 = std::min(n, r0 + QL_MAXB);
+            for (int k = 0; k < r1 - r0; ++k) carry[k] = 0.0;
+            ql_apply(J.V, n, r0, r1, J.rots, 0, total, carry, cc);
+            ql_flush(J.V, n, r0, r1, carry, cc);
+        }
+        return;
+    }
+    // rows: the producer keeps a quarter of a consumer's share (it starts applying when the iteration is over)
+    const int units = 4 * (nt - 1) + 1;
+    auto cut = [&](int t) { return t <= 0 ? 0 : (t >= nt ? n : (int)(((int64_t)n * (1 + 4 * (t - 1)) / units + 3) & ~3)); };
+    int r0 = std::min(n, cut(i)), r1 = std::min(n, cut(i + 1));
+    if (i == nt - 1) r1 = n;
+    if (i == 0) ql_generate(J);
+    if (r1 <= r0) return;
+    double carry[QL_MAXB];
+    size_t seen = 0;
+    std::vector<int> bcc((size_t)(r1 - r0 + QL_MAXB - 1) / QL_MAXB, -1);
+    std::vector<double> bcarry((size_t)bcc.size() * QL_MAXB);
+    for (;;) {
+        const bool fin = J.done.load(std::memory_order_acquire);
+        const size_t av = J.avail.load(std::memory_order_acquire);
+        if (J.overflow.load(std::memory_order_relaxed)) return;
+        if (av > seen) {
+            int bi = 0;
+            for (int b0 = r0; b0 < r1; b0 += QL_MAXB, ++bi) {
+                const int b1 = std::min(r1, b0 + QL_MAXB);
+                ql_apply(J.V, n, b0, b1, J.rots, seen, av, bcarry.data() + (size_t)bi * QL_MAXB, bcc[bi]);
+            }
+            seen = av;
+        } else if (fin) break;
+    }
+    int bi = 0;
+    for (int b0 = r0; b0 < r1; b0 += QL_MAXB, ++bi) ql_flush(J.V, n, b0, std::min(r1, b0 + QL_MAXB), bcarry.data() + (size_t)bi * QL_MAXB, bcc[bi]);
+    (void)carry;
+}
+}  // namespace
+
+// Householder tridiagonalisation followed by the implicit-shift QL iteration.  The work matrix is kept column-major
+// (at(i, j) = V[j n + i]): every inner loop of the two phases walks down a column.
 // (compiled twice, AVX2 and baseline, dispatched at load time: same operations in the same order, wider vectors)
-__attribute__((target_clones("avx2", "default")))
-bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout) {
+VIO_CLONES
+bool symmetric_eigen_legacy(int n, const double *Ain, double *d, double *Vout) {
     std::vector<double> Vv((size_t)n * n), ev(n);
     double *V = Vv.data(), *e = ev.data();
     auto at = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
@@ -173,6 +340,184 @@ bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout) {
     return ok;
 }
 
+VIO_CLONES
+bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout, const Par *par) {
+#ifdef VIO_TAIL_TIMING
+    static double et[6] = {0}; static int ecalls = 0;
+    auto enow = [] { return std::chrono::steady_clock::now(); };
+    auto E0 = enow();
+#define ET(k) do { auto E1 = enow(); if (n >= 32) et[k] += std::chrono::duration<double, std::micro>(E1 - E0).count(); E0 = E1; } while (0)
+#else
+#define ET(k) do { } while (0)
+#endif
+    std::vector<double> Vv((size_t)n * n), ev(n);
+    double *V = Vv.data(), *e = ev.data();
+    auto at = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) { at(i, j) = Ain[(size_t)i * n + j]; at(j, i) = at(i, j); }
+    for (int j = 0; j < n; ++j) d[j] = at(n - 1, j);
+    ET(0);
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) { d[j] = at(i - 1, j); at(i, j) = 0.0; at(j, i) = 0.0; }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h -= f * g;
+            d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            // (the symmetric product p = A v, one column at a time in the routine this replaces: a dependent chain of i - j additions per
+            //  column.  Two columns side by side — column j + 1 starts from e[j + 1], which column j's first step has just completed —:
+            //  every sum takes its terms in the order it always did, two chains are in flight instead of one)
+            {
+                int j = 0;
+                for (; j + 1 < i; j += 2) {
+                    const double f0 = d[j], f1 = d[j + 1];
+                    const double *c0 = &at(0, j), *c1 = &at(0, j + 1);
+                    at(j, i) = f0;
+                    at(j + 1, i) = f1;
+                    double g0 = e[j] + c0[j] * f0;
+                    g0 += c0[j + 1] * d[j + 1];
+                    e[j + 1] += c0[j + 1] * f0;
+                    double g1 = e[j + 1] + c1[j + 1] * f1;
+                    for (int k = j + 2; k <= i - 1; ++k) {
+                        const double a0 = c0[k], a1 = c1[k], dk = d[k];
+                        g0 += a0 * dk;
+                        g1 += a1 * dk;
+                        double ek = e[k];
+                        ek += a0 * f0;
+                        ek += a1 * f1;
+                        e[k] = ek;
+                    }
+                    e[j] = g0;
+                    e[j + 1] = g1;
+                }
+                for (; j < i; ++j) {
+                    f = d[j];
+                    at(j, i) = f;
+                    g = e[j] + at(j, j) * f;
+                    for (int k = j + 1; k <= i - 1; ++k) { g += at(k, j) * d[k]; e[k] += at(k, j) * f; }
+                    e[j] = g;
+                }
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; g = e[j];
+                for (int k = j; k <= i - 1; ++k) at(k, j) -= (f * e[k] + g * d[k]);
+                d[j] = at(i - 1, j);
+                at(i, j) = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+    ET(1);
+    for (int i = 0; i < n - 1; ++i) {
+        at(n - 1, i) = at(i, i);
+        at(i, i) = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) d[k] = at(k, i + 1) / h;
+            // (the columns are independent of each other: four dot products side by side, each over k ascending as before)
+            {
+                const double *u = &at(0, i + 1);
+                int j = 0;
+                for (; j + 3 <= i; j += 4) {
+                    double *c0 = &at(0, j), *c1 = &at(0, j + 1), *c2 = &at(0, j + 2), *c3 = &at(0, j + 3);
+                    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+                    for (int k = 0; k <= i; ++k) { const double uk = u[k]; g0 += uk * c0[k]; g1 += uk * c1[k]; g2 += uk * c2[k]; g3 += uk * c3[k]; }
+                    for (int k = 0; k <= i; ++k) { const double dk = d[k]; c0[k] -= g0 * dk; c1[k] -= g1 * dk; c2[k] -= g2 * dk; c3[k] -= g3 * dk; }
+                }
+                for (; j <= i; ++j) {
+                    double g = 0.0;
+                    for (int k = 0; k <= i; ++k) g += at(k, i + 1) * at(k, j);
+                    for (int k = 0; k <= i; ++k) at(k, j) -= g * d[k];
+                }
+            }
+        }
+        for (int k = 0; k <= i; ++k) at(k, i + 1) = 0.0;
+    }
+    for (int j = 0; j < n; ++j) { d[j] = at(n - 1, j); at(n - 1, j) = 0.0; }
+    at(n - 1, n - 1) = 1.0;
+    e[0] = 0.0;
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    // The QL iteration on (d, e) does not read the eigenvector matrix: thread 0 runs it and RECORDS the plane rotations (column pair, c, s) in
+    // the order it generates them; the rotations are applied to V by row blocks — a row sees the same rotations in the same order whoever
+    // applies them, so the result does not depend on the number of threads — while the iteration is still running (pipeline: `avail`).
+    ET(2);
+    const size_t cap = (size_t)8 * n * n + 64;
+    std::vector<Rot> rots(cap);
+    QlJob job;
+    job.V = V; job.n = n; job.rots = rots.data(); job.cap = cap; job.d = d; job.e = e;
+    const int want = (par && par->run_n && n >= 32) ? std::min(par->width, (n + 15) / 16 + 1) : 1;
+    if (want > 1) par->run_n(par->ctx, want, ql_participant, &job);
+    else ql_participant(&job, 0, 1);
+    if (job.overflow.load()) return symmetric_eigen_legacy(n, Ain, d, Vout);      // (more than 8 n^2 rotations: not a matrix this library meets)
+    bool ok = job.ok;
+    ET(3);
+    for (int i = 0; i < n - 1; ++i) {
+        int k = i;
+        double p = d[i];
+        for (int j = i + 1; j < n; ++j)
+            if (d[j] < p) { k = j; p = d[j]; }
+        if (k != i) {
+            d[k] = d[i]; d[i] = p;
+            for (int j = 0; j < n; ++j) std::swap(at(j, i), at(j, k));
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) Vout[(size_t)i * n + j] = at(i, j);
+    ET(4);
+#ifdef VIO_TAIL_TIMING
+    if (n >= 32 && ++ecalls % 50 == 0) std::fprintf(stderr, "[eigen timing n=%d, avg us] copy-in %.1f | tred2 reduce %.1f | accumulate %.1f | ql (generate + apply) %.1f | sort, copy-out %.1f | generate alone %.1f\n", n, et[0] / ecalls, et[1] / ecalls, et[2] / ecalls, et[3] / ecalls, et[4] / ecalls, 0.0);
+#endif
+    return ok;
+}
+
+// rows [0, count) in contiguous pieces of at least `grain` on the helper threads of `par` (all of them on the caller without any)
+namespace {
+template <typename F> struct RowsJob { F *f; int count; };
+template <typename F> void rows_piece(void *arg, int i, int n) {
+    RowsJob<F> &j = *(RowsJob<F> *)arg;
+    const int a0 = (int)((int64_t)j.count * i / n), a1 = (int)((int64_t)j.count * (i + 1) / n);
+    if (a1 > a0) (*j.f)(a0, a1);
+}
+template <typename F> void par_rows(const Par *par, int count, int grain, F &f) {
+    const int want = (par && par->run_n) ? std::min(par->width, count / std::max(grain, 1)) : 1;
+    if (want <= 1) { if (count > 0) f(0, count); return; }
+    RowsJob<F> j{&f, count};
+    par->run_n(par->ctx, want, rows_piece<F>, &j);
+}
+}  // namespace
+
+// rows [a0, a1) of H_prior = (V S) V^T over the kept eigenpairs (problem.cc:775-778): entry (a, c) = sum over q ascending of VS[a][q] VKt[q][c], a
+// whole row of c at a time with q outside — every entry's additions in the order of the dot product they replace, nl independent chains
+// instead of one dependent one (a function of its own so that it exists in the AVX2 clone: a lambda inside marginalize_tail does not)
+VIO_CLONES
+void prior_product_rows(int a0, int a1, const double *__restrict VS, const double *__restrict VKt, int nk, int nl, const int *__restrict live,
+                        double *__restrict Hout, int n2, double *__restrict acc) {
+    for (int a = a0; a < a1; ++a) {
+        for (int c = 0; c < nl; ++c) acc[c] = 0.0;
+        const double *__restrict x = VS + (size_t)a * nk;
+        for (int q = 0; q < nk; ++q) {
+            const double xq = x[q];
+            const double *__restrict y = VKt + (size_t)q * nl;
+            for (int c = 0; c < nl; ++c) acc[c] += xq * y[c];
+        }
+        double *__restrict ho = Hout + (size_t)live[a] * n2;
+        for (int c = 0; c < nl; ++c) ho[live[c]] = std::fabs(acc[c]) > 1e-9 ? acc[c] : 0.0;     // problem.cc:778
+    }
+}
+
 // The two moves of problem.cc:721-745 (speed-bias of the marginalised frame to the bottom, then its pose) as one index map:
 // entry (i, j) of the reordered matrix is H[order[i]][order[j]] of the matrix that came in.
 static void marg_order(int n, int frame, int *order) {
@@ -187,12 +532,21 @@ static void marg_order(int n, int frame, int *order) {
     for (int i = 0; i < n; ++i) order[i] = o1[o2[i]];
 }
 
-__attribute__((target_clones("avx2", "default")))
-int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *bout, double *errout, double *jtout) {
+VIO_CLONES
+int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *bout, double *errout, double *jtout, const Par *par) {
     constexpr int n = 171, m2 = 15, n2 = n - m2;
     // Round 4: nothing of the 171 x 171 matrix is copied or permuted in memory (it was, twice: 0.14 of the tail's 0.44 ms on the build
     // host); the reordered matrix is read through `order`, and everything below works on the rows that are not exactly zero.  The sums
     // are the ones the full-size version formed for those rows, in the same order: the outputs are bit-identical.
+#ifdef VIO_TAIL_TIMING
+    static double tt[8] = {0}; static int tcalls = 0;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tus = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    auto T0 = tnow();
+#define TT(k) do { auto T1 = tnow(); tt[k] += tus(T0, T1); T0 = T1; } while (0)
+#else
+#define TT(k) do { } while (0)
+#endif
     int order[n];
     marg_order(n, frame, order);
     auto Hp_ = [&](int i, int j) -> double { return Hin[(size_t)order[i] * n + order[j]]; };
@@ -207,6 +561,7 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
             for (int k = 0; k < m2; ++k) s += V[i * m2 + k] * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V[j * m2 + k];
             Ainv[i * m2 + j] = s;
         }
+    TT(0);
     // Arr - Arm Amm^+ Amr, brr - Arm Amm^+ bmm (problem.cc:758-762).  A row (column) of the kept block that is exactly zero all the way — a
     // frame neither the marginalised frame's landmarks nor the old prior reach: 117 of the 156 at tracks of four frames — has a zero row
     // of tempB and yields zeros whatever it is multiplied with: only the others are formed.
@@ -218,26 +573,37 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
         for (int j = n2; j < n && !any; ++j) any = Hp_(j, i) != 0.0;      // the marginalised rows' entries in column i (Amr)
         if (any) rowlive[nr++] = i;
     }
+    TT(1);
     std::vector<double> tempB((size_t)std::max(nr, 1) * m2), Hpc((size_t)std::max(nr, 1) * std::max(nr, 1)), Amr((size_t)m2 * std::max(nr, 1)), bp(n2);
     for (int k = 0; k < m2; ++k)
         for (int c = 0; c < nr; ++c) Amr[(size_t)k * nr + c] = Hp_(n2 + k, rowlive[c]);
     for (int i = 0; i < n2; ++i) bp[i] = bin[order[i]] - 0.0;
-    for (int a = 0; a < nr; ++a) {
-        const int i = rowlive[a];
-        for (int j = 0; j < m2; ++j) {
+    // (rows of the kept block are independent of each other: shared out over the helper threads when there are any)
+    auto schur_rows = [&](int a0, int a1) {
+        for (int a = a0; a < a1; ++a) {
+            const int i = rowlive[a];
+            for (int j = 0; j < m2; ++j) {
+                double s = 0;
+                for (int k = 0; k < m2; ++k) s += Hp_(i, n2 + k) * Ainv[k * m2 + j];
+                tempB[(size_t)a * m2 + j] = s;
+            }
+            {   // (the 15-term sums of a row's entries side by side, k outside: the same additions per entry)
+                double *hrow = &Hpc[(size_t)a * nr];
+                for (int c = 0; c < nr; ++c) hrow[c] = 0.0;
+                for (int k = 0; k < m2; ++k) {
+                    const double tb = tempB[(size_t)a * m2 + k];
+                    const double *am = &Amr[(size_t)k * nr];
+                    for (int c = 0; c < nr; ++c) hrow[c] += tb * am[c];
+                }
+                for (int c = 0; c < nr; ++c) hrow[c] = Hp_(i, rowlive[c]) - hrow[c];
+            }
             double s = 0;
-            for (int k = 0; k < m2; ++k) s += Hp_(i, n2 + k) * Ainv[k * m2 + j];
-            tempB[(size_t)a * m2 + j] = s;
+            for (int k = 0; k < m2; ++k) s += tempB[(size_t)a * m2 + k] * bin[order[n2 + k]];
+            bp[i] = bin[order[i]] - s;
         }
-        for (int c = 0; c < nr; ++c) {
-            double s = 0;
-            for (int k = 0; k < m2; ++k) s += tempB[(size_t)a * m2 + k] * Amr[(size_t)k * nr + c];
-            Hpc[(size_t)a * nr + c] = Hp_(i, rowlive[c]) - s;
-        }
-        double s = 0;
-        for (int k = 0; k < m2; ++k) s += tempB[(size_t)a * m2 + k] * bin[order[n2 + k]];
-        bp[i] = bin[order[i]] - s;
-    }
+    };
+    par_rows(par, nr, 24, schur_rows);
+    TT(2);
     // Eigen-decomposition of the reduced system (problem.cc:766).  Rows and columns that are exactly zero — frames the
     // marginalised frame's landmarks and the old prior do not reach: 90 of the 156 in the steady state of a window with
     // tracks of 4 frames — are eigenvectors e_i of eigenvalue 0 already and fall under the 1e-8 cut whatever basis a solver
@@ -252,7 +618,9 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
     std::vector<double> Hc((size_t)std::max(nl, 1) * std::max(nl, 1)), evc(std::max(nl, 1)), Vc((size_t)std::max(nl, 1) * std::max(nl, 1));
     for (int a = 0; a < nl; ++a)
         for (int c = 0; c < nl; ++c) Hc[(size_t)a * nl + c] = Hpc[(size_t)lpos[a] * nr + lpos[c]];
-    if (nl > 0) symmetric_eigen(nl, Hc.data(), evc.data(), Vc.data());
+    TT(3);
+    if (nl > 0) symmetric_eigen(nl, Hc.data(), evc.data(), Vc.data(), par);
+    TT(4);
     // In the 156-system the eigenvalues are: nz zeros (the unit vectors of the dead indices), then the live block's, ascending: eigenpair
     // k of the live block is number nz + k.  (A negative eigenvalue of the live block would sort before the zeros in the reference;
     // both are below the cut.)  kept: the live block's eigenvalues above the cut, the only ones the three products below see.
@@ -269,21 +637,29 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
         for (int a = 0; a < nl; ++a) s += -row[live[a]] * bp[live[a]];
         errout[i] = s;
     }
+    TT(5);
     {   // H_prior = J^T J with J = sqrt(S) V^T (problem.cc:775-777): sum over the kept k of V_ik s_k V_jk, k ascending; the
         // kept eigenvectors live on the live indices only, every other entry of the product is an exact zero
         std::vector<double> VS((size_t)std::max(nl, 1) * std::max(nk, 1)), VK((size_t)std::max(nl, 1) * std::max(nk, 1));
         for (int a = 0; a < nl; ++a)
             for (int q = 0; q < nk; ++q) { VK[(size_t)a * nk + q] = Vc[(size_t)a * nl + kept[q]]; VS[(size_t)a * nk + q] = VK[(size_t)a * nk + q] * evc[kept[q]]; }
         std::fill(Hout, Hout + (size_t)n2 * n2, 0.0);
-        for (int a = 0; a < nl; ++a)
-            for (int c = 0; c < nl; ++c) {
-                const double *x = &VS[(size_t)a * nk], *y = &VK[(size_t)c * nk];
-                double s = 0;
-                for (int q = 0; q < nk; ++q) s += x[q] * y[q];
-                Hout[(size_t)live[a] * n2 + live[c]] = std::fabs(s) > 1e-9 ? s : 0.0;     // problem.cc:778
-            }
+        // (entry (a, c) = sum over q ascending of VS[a][q] VK[c][q]: formed for a whole row of c at once, the q loop outside — every entry's
+        //  additions in the same order as the dot product they replace, but 75 independent chains instead of one dependent one)
+        std::vector<double> VKt((size_t)std::max(nk, 1) * std::max(nl, 1));
+        for (int c = 0; c < nl; ++c)
+            for (int q = 0; q < nk; ++q) VKt[(size_t)q * nl + c] = VK[(size_t)c * nk + q];
+        auto prior_rows = [&](int a0, int a1) {
+            std::vector<double> accv((size_t)std::max(nl, 1));
+            prior_product_rows(a0, a1, VS.data(), VKt.data(), nk, nl, live, Hout, n2, accv.data());
+        };
+        par_rows(par, nl, 16, prior_rows);
     }
     std::memcpy(bout, bp.data(), sizeof(double) * n2);
+    TT(6);
+#ifdef VIO_TAIL_TIMING
+    if (++tcalls % 50 == 0) { std::fprintf(stderr, "[tail timing, avg us] Amm eigen %.1f | live-row scan %.1f | Schur rows %.1f | live block %.1f | eigen %.1f | Jt, err %.1f | H_prior %.1f\n", tt[0] / tcalls, tt[1] / tcalls, tt[2] / tcalls, tt[3] / tcalls, tt[4] / tcalls, tt[5] / tcalls, tt[6] / tcalls); }
+#endif
     return nl;
 }
 

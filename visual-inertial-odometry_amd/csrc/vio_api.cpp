@@ -251,9 +251,9 @@ struct vio_ctx {
     std::vector<double> h_Hprior, h_bprior, h_errprior, h_Jtinv;
     HostArena arena;                           // pinned staging of the uploads
     double *marg_stage = nullptr;              // pinned: H_marg (171 x 171) and b_marg for the host tail of vio_marginalize
-    struct MargWorker *marg_worker = nullptr;  // parked helper thread for the dense tail of a marginalisation (vio_marginalize_begin / _end)
-    vio_plan::HostPool *host_pool = nullptr;   // parked helper threads for the pass over a frame's observation list (vio_set_observations)
-    bool host_pool_tried = false;
+    vio_plan::BgTicket marg_ticket;            // the dense tail of a marginalisation on the process's background worker (vio_marginalize_begin / _end)
+    int marg_job_frame = 0;
+    bool shared_ref = false;                   // this context holds a reference on the process's helper threads (vio_plan::shared_acquire)
     bool marg_pending = false;
     MargResult marg_out;
     double *pull_stage = nullptr;              // pinned staging of the landmark read-back (pull_from_device)
@@ -386,7 +386,7 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     }
     vio_plan::Input in;
     in.N = (int64_t)c->h_invd.size() / c->lm_dim; in.M = M;
-    in.pool = c->host_pool;                // (the helpers vio_set_observations parked, if the list was long enough to create them)
+    in.pool = in.M >= 16384 ? vio_plan::shared_pool() : nullptr;      // (the process's helper threads: windows long enough for pieces to pay)
     in.olm = c->h_olm.data(); in.ohost = c->h_ohost.data(); in.otarget = c->h_otarget.data();
     in.pts_i = c->h_pts_i.empty() ? nullptr : c->h_pts_i.data();
     in.pts_i_lm = c->h_pts_i_lm.empty() ? nullptr : c->h_pts_i_lm.data();
@@ -1010,11 +1010,12 @@ vio_status vio_create(const vio_config *cfg, vio_ctx **out) {
     if (cfg->device < 0 || cfg->device >= ndev) return VIO_ERR_BAD_ARG;
     if (hipSetDevice(cfg->device) != hipSuccess) return VIO_ERR_HIP;
     vio_ctx *c = new vio_ctx();
+    vio_plan::shared_acquire(); c->shared_ref = true;       // (the process's helper threads live as long as any context does)
     c->cfg = *cfg;
     if (c->cfg.shard_count < 1) c->cfg.shard_count = 1;
     if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
     else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VIO_ERR_HIP; }
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { vio_plan::shared_release(); delete c; return VIO_ERR_HIP; }
         c->own_stream = true;
     }
     std::memset(c->h_state, 0, sizeof(c->h_state));
@@ -1053,11 +1054,11 @@ vio_status vio_set_config(vio_ctx *c, const vio_config *cfg) {
     return VIO_OK;
 }
 
-static void marg_worker_stop(vio_ctx *c);
+static void marg_join(vio_ctx *c);
 void vio_destroy(vio_ctx *c) {
     if (!c) return;
-    marg_worker_stop(c);
-    vio_plan::pool_destroy(c->host_pool); c->host_pool = nullptr;
+    marg_join(c);
+    if (c->shared_ref) { vio_plan::shared_release(); c->shared_ref = false; }
     enter_device(c);
     // A stream the caller supplied (vio_config.stream, e.g. the leader's of a batch) may be gone already when this context
     // goes: it is not touched here.  hipFree waits for the device itself, so nothing in flight loses its buffers.
@@ -1186,17 +1187,18 @@ static void run_obs_pass(vio_ctx *c, ObsPass &o, vio_plan::ScanResult *r, bool *
     if (c->h_pts_i_lm.size() != 2 * (size_t)o.N) { c->h_pts_i_lm.assign(2 * (size_t)o.N, 0.0); resized = true; }
     o.pl = c->h_pts_i_lm.data();
     o.pieces = 1;
+    vio_plan::HostPool *hp = nullptr;
     if (o.m >= 16384) {
         // pieces only for landmark-major lists (then no two of them note the same landmark's host observation): one look at the landmark
         // indices alone, 0.3 MB, tells
         unsigned unsorted = 0;
         for (int64_t e = 1; e < o.m; ++e) unsorted |= (unsigned)(o.lm[e] < o.lm[e - 1]);
         if (!unsorted) {
-            if (!c->host_pool && !c->host_pool_tried) { c->host_pool = vio_plan::pool_create(3); c->host_pool_tried = true; }
-            o.pieces = std::min(vio_plan::pool_width(c->host_pool), 8);
+            hp = vio_plan::shared_pool();
+            o.pieces = std::min(vio_plan::pool_width(hp), 4);          // (four pieces: the pass is bound by one core's memory bandwidth, not by arithmetic)
         }
     }
-    vio_plan::pool_run(o.pieces > 1 ? c->host_pool : nullptr, o.pieces, obs_pass_piece, &o);
+    vio_plan::pool_run(o.pieces > 1 ? hp : nullptr, o.pieces, obs_pass_piece, &o);
     vio_plan::ScanFlags f;
     bool same = o.comparable;
     for (int i = 0; i < o.pieces; ++i) { f.bad |= o.flags[i].bad; f.unsorted |= o.flags[i].unsorted; f.incons |= o.flags[i].incons; f.changed |= o.flags[i].changed; same = same && o.same[i]; }
@@ -1860,7 +1862,17 @@ static void marg_tail_job(vio_ctx *c, int frame) {
     bool finite_in = true;
     for (size_t i = 0; i < (size_t)PD * PD + PD && finite_in; ++i) finite_in = std::isfinite(Hm[i]);
     r.live_rows = 0;
-    if (finite_in) r.live_rows = vio_host::marginalize_tail(Hm, bm, frame, r.H.data(), r.b.data(), r.err.data(), r.jt.data());
+    if (finite_in) {
+        // The tail's row-parallel parts and the eigen-solver's pipeline can use the process's helper threads (the same bits whatever their
+        // number: tests/test_host_units.py) — measured on the round's host, a two-socket EPYC 9575F, and left OFF: one thread 290 us for
+        // the 75-row eigen-problem, two 250, three and more 650 .. 1 000 (profiles/r06d_host_tail_threads.txt: the rotation stream and the
+        // eigenvector matrix travel between cores that share no cache).  VIO_MARG_THREADS=n turns them on.
+        static const int marg_threads = std::getenv("VIO_MARG_THREADS") ? std::atoi(std::getenv("VIO_MARG_THREADS")) : 1;
+        vio_plan::HostPool *hp = marg_threads > 1 ? vio_plan::shared_pool() : nullptr;
+        vio_host::Par par{hp, [](void *ctx, int want, void (*fn)(void *, int, int), void *arg) { vio_plan::pool_run_n((vio_plan::HostPool *)ctx, want, fn, arg); },
+                          std::min(marg_threads, vio_plan::pool_width(hp))};
+        r.live_rows = vio_host::marginalize_tail(Hm, bm, frame, r.H.data(), r.b.data(), r.err.data(), r.jt.data(), hp ? &par : nullptr);
+    }
     else {
         const double nan = std::nan("");
         std::fill(r.H.begin(), r.H.end(), 0.0); std::fill(r.jt.begin(), r.jt.end(), nan);
@@ -1870,66 +1882,25 @@ static void marg_tail_job(vio_ctx *c, int frame) {
     r.tail_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
 }
 
-// One helper thread per context, created with the first marginalisation and parked on a condition variable between jobs (a thread
-// per frame cost 30-60 us of the 0.14 ms the caller spends in vio_marginalize_begin).  If it cannot be created the tail
-// runs on the caller's thread: no exception crosses the C boundary.
-struct MargWorker {
-    std::thread th;
-    std::mutex mu;
-    std::condition_variable cv, cv_done;
-    int job = -1;               // frame of the job waiting to be taken, -1: none
-    bool busy = false, quit = false;
-};
-static void marg_worker_loop(vio_ctx *c, MargWorker *w) {
-    std::unique_lock<std::mutex> lk(w->mu);
-    for (;;) {
-        w->cv.wait(lk, [&] { return w->job >= 0 || w->quit; });
-        if (w->quit) return;
-        const int frame = w->job;
-        w->job = -1;
-        lk.unlock();
-        marg_tail_job(c, frame);
-        lk.lock();
-        w->busy = false;
-        w->cv_done.notify_all();
-    }
+// The tail runs on the process's ONE background worker (vio_plan::bg_submit: created with the first job, parked between jobs, joined when the
+// last context goes; round 6 — until then every context had a worker thread of its own) or, for the synchronous vio_marginalize, on the
+// caller's thread; either way its row-parallel parts use the process's helper threads when they are free.  Without threads everything runs on
+// the caller: no exception crosses the C boundary.
+static void marg_job_fn(void *arg) {
+    vio_ctx *c = (vio_ctx *)arg;
+    marg_tail_job(c, c->marg_job_frame);
 }
-static void marg_join(vio_ctx *c) {
-    MargWorker *w = c->marg_worker;
-    if (!w) return;
-    std::unique_lock<std::mutex> lk(w->mu);
-    w->cv_done.wait(lk, [&] { return !w->busy; });
-}
-static void marg_submit(vio_ctx *c, int frame) {
-    if (!c->marg_worker) {
-        MargWorker *w = nullptr;
-        try {
-            w = new MargWorker;
-            w->th = std::thread(marg_worker_loop, c, w);
-            c->marg_worker = w;
-        } catch (...) {
-            delete w;
-            c->marg_worker = nullptr;
-        }
-    }
-    MargWorker *w = c->marg_worker;
-    if (!w) { marg_tail_job(c, frame); return; }            // (the result is ready when vio_marginalize_begin returns)
-    std::lock_guard<std::mutex> lk(w->mu);
-    w->job = frame;
-    w->busy = true;
-    w->cv.notify_one();
-}
-static void marg_worker_stop(vio_ctx *c) {
-    MargWorker *w = c->marg_worker;
-    if (!w) return;
-    marg_join(c);
-    { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; w->cv.notify_one(); }
-    if (w->th.joinable()) w->th.join();
-    delete w;
-    c->marg_worker = nullptr;
+static void marg_join(vio_ctx *c) { vio_plan::bg_wait(&c->marg_ticket); }
+static void marg_submit(vio_ctx *c, int frame, bool inline_tail) {
+    c->marg_job_frame = frame;
+    if (inline_tail) { marg_tail_job(c, frame); return; }
+    vio_plan::bg_submit(&c->marg_ticket, marg_job_fn, c);
 }
 
-vio_status vio_marginalize_begin(vio_ctx *c, int32_t kind) {
+static vio_status marginalize_begin_impl(vio_ctx *c, int32_t kind, bool inline_tail);
+vio_status vio_marginalize_begin(vio_ctx *c, int32_t kind) { return marginalize_begin_impl(c, kind, false); }
+static vio_status marginalize_begin_impl(vio_ctx *c, int32_t kind, bool inline_tail) {
+
     if (!c) return VIO_ERR_BAD_ARG;
     if (kind != VIO_MARG_OLD && kind != VIO_MARG_SECOND_NEW) return VIO_ERR_BAD_ARG;
     enter_device(c);
@@ -1973,7 +1944,7 @@ vio_status vio_marginalize_begin(vio_ctx *c, int32_t kind) {
     r.kind = kind;
     c->timing[3] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     c->marg_pending = true;
-    marg_submit(c, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1);
+    marg_submit(c, kind == VIO_MARG_OLD ? 0 : VIO_WINDOW_SIZE - 1, inline_tail);
     return VIO_OK;
 }
 
@@ -1995,7 +1966,7 @@ vio_status vio_marginalize_end(vio_ctx *c, double *H, double *b, double *err, do
 
 vio_status vio_marginalize(vio_ctx *c, int32_t kind, double *H, double *b, double *err, double *jt) {
     if (!c || !H || !b || !err || !jt) return VIO_ERR_BAD_ARG;
-    VIOCHK(vio_marginalize_begin(c, kind));
+    VIOCHK(marginalize_begin_impl(c, kind, true));         // (the caller waits for the prior anyway: its thread runs the tail, no hand-over)
     return vio_marginalize_end(c, H, b, err, jt);
 }
 

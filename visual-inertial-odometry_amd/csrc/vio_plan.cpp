@@ -88,6 +88,8 @@ ScanResult scan_observations(int64_t N, int64_t m, const int32_t *lm, const int3
 }
 
 // ---- helper threads ----
+// A pool is a few parked threads and ONE run at a time: a caller that finds it busy (another context's pass, the marginalisation's
+// background tail) runs its tasks itself, in order — the same results, nobody waits for anybody.
 struct HostPool {
     std::vector<std::thread> th;
     std::mutex mu;
@@ -95,22 +97,34 @@ struct HostPool {
     uint64_t gen = 0;                       // bumped by every pool_run
     int n = 0;                              // tasks of the current run (task i >= 1 belongs to helper i - 1)
     void (*fn)(void *, int) = nullptr;
+    void (*fn_n)(void *, int, int) = nullptr;
     void *arg = nullptr;
     std::atomic<int> remaining{0};
+    std::atomic<uint64_t> gen_hint{0};
+    std::atomic<bool> busy{false};          // a run is in flight (try-lock of the callers)
     bool quit = false;
 };
 static void pool_loop(HostPool *p, int me) {
     uint64_t seen = 0;
     std::unique_lock<std::mutex> lk(p->mu);
     for (;;) {
+        if (p->gen == seen && !p->quit) {
+            // (a pass is often followed by another within microseconds — the stages of the marginalisation's tail —: look for it a little
+            //  while before parking; gen_hint mirrors gen for readers without the mutex)
+            lk.unlock();
+            for (int spin = 0; spin < 4000 && p->gen_hint.load(std::memory_order_acquire) == seen; ++spin) { }
+            lk.lock();
+        }
         p->cv.wait(lk, [&] { return p->gen != seen || p->quit; });
         if (p->quit) return;
         seen = p->gen;
         if (me + 1 < p->n) {
             void (*fn)(void *, int) = p->fn;
+            void (*fn_n)(void *, int, int) = p->fn_n;
             void *arg = p->arg;
+            const int n = p->n;
             lk.unlock();
-            fn(arg, me + 1);
+            if (fn_n) fn_n(arg, me + 1, n); else fn(arg, me + 1);
             lk.lock();
             if (p->remaining.fetch_sub(1) == 1) p->cv_done.notify_all();
         }
@@ -135,22 +149,144 @@ void pool_destroy(HostPool *p) {
     delete p;
 }
 int pool_width(const HostPool *p) { return p ? (int)p->th.size() + 1 : 1; }
-void pool_run(HostPool *p, int n, void (*fn)(void *arg, int i), void *arg) {
-    if (!p || n <= 1) { for (int i = 0; i < n; ++i) fn(arg, i); return; }
-    n = std::min(n, pool_width(p));
+static void pool_dispatch(HostPool *p, int n, void (*fn)(void *, int), void (*fn_n)(void *, int, int), void *arg) {
     {
         std::lock_guard<std::mutex> lk(p->mu);
-        p->n = n; p->fn = fn; p->arg = arg;
+        p->n = n; p->fn = fn; p->fn_n = fn_n; p->arg = arg;
         p->remaining.store(n - 1);
         ++p->gen;
+        p->gen_hint.store(p->gen, std::memory_order_release);
     }
     p->cv.notify_all();
-    fn(arg, 0);
+    if (fn_n) fn_n(arg, 0, n); else fn(arg, 0);
     for (int spin = 0; spin < 2000 && p->remaining.load() != 0; ++spin) { }      // (a helper is usually a few microseconds behind)
     if (p->remaining.load() != 0) {
         std::unique_lock<std::mutex> lk(p->mu);
         p->cv_done.wait(lk, [&] { return p->remaining.load() == 0; });
     }
+    p->busy.store(false, std::memory_order_release);
+}
+void pool_run(HostPool *p, int n, void (*fn)(void *arg, int i), void *arg) {
+    if (p && n > 1) {
+        bool expected = false;
+        if (p->busy.compare_exchange_strong(expected, true, std::memory_order_acquire)) { pool_dispatch(p, std::min(n, pool_width(p)), fn, nullptr, arg); return; }
+    }
+    for (int i = 0; i < n; ++i) fn(arg, i);
+}
+void pool_run_n(HostPool *p, int want, void (*fn)(void *arg, int i, int n), void *arg) {
+    if (p && want > 1 && pool_width(p) > 1) {
+        bool expected = false;
+        if (p->busy.compare_exchange_strong(expected, true, std::memory_order_acquire)) { pool_dispatch(p, std::min(want, pool_width(p)), nullptr, fn, arg); return; }
+    }
+    fn(arg, 0, 1);
+}
+
+// ---- the process's shared pool and its background worker ----
+namespace {
+std::mutex g_shared_mu;
+HostPool *g_shared = nullptr;
+int g_shared_refs = 0;
+bool g_shared_tried = false;
+
+struct BgWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<BgTicket *> queue;
+    bool quit = false;
+};
+BgWorker *g_bg = nullptr;
+bool g_bg_tried = false;
+std::atomic<int> g_threads_alive{0};
+
+void bg_loop(BgWorker *w) {
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return !w->queue.empty() || w->quit; });
+        if (w->queue.empty() && w->quit) return;
+        BgTicket *t = w->queue.front();
+        w->queue.erase(w->queue.begin());
+        lk.unlock();
+        t->fn(t->arg);
+        {
+            // (notified under the ticket's mutex: the waiter cannot leave bg_wait — and, say, destroy the ticket — before this thread is
+            //  done with it; found by the ThreadSanitizer tier)
+            std::lock_guard<std::mutex> tl(t->mu);
+            t->pending = false;
+            t->cv.notify_all();
+        }
+        lk.lock();
+    }
+}
+}  // namespace
+
+void shared_acquire() {
+    std::lock_guard<std::mutex> lk(g_shared_mu);
+    ++g_shared_refs;
+}
+void shared_release() {
+    HostPool *dead = nullptr;
+    BgWorker *bg = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_shared_mu);
+        if (g_shared_refs > 0 && --g_shared_refs == 0) {
+            dead = g_shared; g_shared = nullptr; g_shared_tried = false;
+            bg = g_bg; g_bg = nullptr; g_bg_tried = false;
+        }
+    }
+    if (dead) { g_threads_alive.fetch_sub((int)dead->th.size()); pool_destroy(dead); }
+    if (bg) {
+        { std::lock_guard<std::mutex> lk(bg->mu); bg->quit = true; }
+        bg->cv.notify_all();
+        if (bg->th.joinable()) bg->th.join();
+        g_threads_alive.fetch_sub(1);
+        delete bg;
+    }
+}
+HostPool *shared_pool() {
+    std::lock_guard<std::mutex> lk(g_shared_mu);
+    if (!g_shared && !g_shared_tried && g_shared_refs > 0) {
+        g_shared_tried = true;
+        unsigned hw = std::thread::hardware_concurrency();
+        int helpers = SHARED_POOL_HELPERS;
+        if (hw > 0 && (int)hw - 1 < helpers) helpers = (int)hw - 1;
+        if (helpers > 0) g_shared = pool_create(helpers);
+        if (g_shared) g_threads_alive.fetch_add((int)g_shared->th.size());
+    }
+    return g_shared;
+}
+int shared_threads_alive() { return g_threads_alive.load(); }
+
+void bg_submit(BgTicket *t, void (*fn)(void *), void *arg) {
+    t->fn = fn; t->arg = arg;
+    BgWorker *w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_shared_mu);
+        if (!g_bg && !g_bg_tried && g_shared_refs > 0) {
+            g_bg_tried = true;
+            try {
+                g_bg = new BgWorker;
+                g_bg->th = std::thread(bg_loop, g_bg);
+                g_threads_alive.fetch_add(1);
+            } catch (...) {
+                delete g_bg;
+                g_bg = nullptr;
+            }
+        }
+        w = g_bg;
+        if (w) {
+            // (queued under g_shared_mu: shared_release cannot take the worker away between the look and the push)
+            { std::lock_guard<std::mutex> tl(t->mu); t->pending = true; }
+            std::lock_guard<std::mutex> wl(w->mu);
+            w->queue.push_back(t);
+        }
+    }
+    if (!w) { fn(arg); return; }            // (no worker: the job is done when the call returns)
+    w->cv.notify_one();
+}
+void bg_wait(BgTicket *t) {
+    std::unique_lock<std::mutex> lk(t->mu);
+    t->cv.wait(lk, [&] { return !t->pending; });
 }
 
 ScanResult scan_observations_xyz(int64_t N, int64_t m, const int32_t *lm, const int32_t *frame) {

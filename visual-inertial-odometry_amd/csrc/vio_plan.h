@@ -6,8 +6,10 @@
 #ifndef VIO_PLAN_H
 #define VIO_PLAN_H
 
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -54,6 +56,28 @@ HostPool *pool_create(int helpers);
 void pool_destroy(HostPool *p);
 int pool_width(const HostPool *p);          // helpers + 1 (1 for nullptr)
 void pool_run(HostPool *p, int n, void (*fn)(void *arg, int i), void *arg);
+// the same for passes that coordinate among themselves (the eigen-solver's pipeline): fn(arg, i, n) with the number of participants the run
+// really has — `want` at most, 1 (everything on the caller) when the pool is busy or absent
+void pool_run_n(HostPool *p, int want, void (*fn)(void *arg, int i, int n), void *arg);
+
+// The process's host threads (round 6: until then every context created its own — pool_create(3) with its first long observation list and a
+// worker for its marginalisation tails: a batch of 256 contexts parked 1 024 threads).  ONE pool of SHARED_POOL_HELPERS helpers and ONE
+// background worker per process, created when first wanted, reference-counted by the contexts (vio_create / vio_destroy): the last
+// shared_release joins them.  A run that finds the pool busy runs on its caller (pool_run); background jobs queue in order.
+constexpr int SHARED_POOL_HELPERS = 6;
+void shared_acquire();
+void shared_release();
+HostPool *shared_pool();                    // nullptr while no context holds a reference or when no thread could be created
+int shared_threads_alive();                 // helpers + background worker (tests: <= SHARED_POOL_HELPERS + 1 whatever the number of contexts)
+struct BgTicket {                           // one per submitter (a context): at most one job in flight per ticket
+    std::mutex mu;
+    std::condition_variable cv;
+    bool pending = false;
+    void (*fn)(void *) = nullptr;
+    void *arg = nullptr;
+};
+void bg_submit(BgTicket *t, void (*fn)(void *), void *arg);      // runs fn(arg) on the background worker (on the caller if there is none)
+void bg_wait(BgTicket *t);                                        // returns when the ticket's job is done (at once if none is pending)
 
 // the same for an XYZ list (landmark, observing frame): range, and landmark-major with a landmark's frames ascending
 ScanResult scan_observations_xyz(int64_t N, int64_t m, const int32_t *lm, const int32_t *frame);
