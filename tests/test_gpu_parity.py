@@ -197,6 +197,22 @@ def test_full_solve_against_oracle(vio, oracle_lib, hip_lib, n, seed, ragged, ex
     assert rh.solve_ms > 0 and rh.hessian_ms > 0
 
 
+@pytest.mark.parametrize("n,seed,ragged,ext_fixed", [(300, 12, True, 1), (400, 13, False, 0), (150, 300, True, 1)])
+def test_lambda_sequence_against_the_oracle(vio, oracle_lib, hip_lib, n, seed, ragged, ext_fixed):
+    """IsGoodStepInLM's factor 1 - (2 rho - 1)^3 (problem.cc:561) is formed on the device as 1 - (t t) t, two products, where the oracle (and
+    the reference) call pow: at most an ulp apart per step, and the step feeds lambda.  Over the ten outer iterations of
+    Solve(10) the lambda sequence must stay within 1e-6 of the oracle's (measured: 0 on most windows, 3e-8 at worst,
+    tools/diag_lambda_deviation.py) — the looser 2e-3 of the full-solve tests covers windows whose chi2 has stopped changing."""
+    w = vio.synth.make_window(n, seed=seed, ragged=ragged)
+    ch, co = hip_lib.context(ext_fixed=ext_fixed), oracle_lib.context(ext_fixed=ext_fixed)
+    ch.load(w)
+    co.load(w)
+    sh, rh = tu.run_solve(ch)
+    so, ro = tu.run_solve(co)
+    assert rh.iterations == ro.iterations == 10 and rh.trials == ro.trials
+    np.testing.assert_allclose(sh["lambda_trace"], so["lambda_trace"], rtol=1e-6)
+
+
 def test_solve_with_prior_and_marginalisation_chain(vio, oracle_lib, hip_lib):
     """Three consecutive windows: solve, MargOldFrame, shift, solve with the prior, MargNewFrame — the sequence of
     Estimator::backendOptimization (estimator.cpp:1075-1141), HIP and oracle side by side."""

@@ -299,6 +299,9 @@ class VioContext:
 
     def set_imu_all(self, pres):
         """vio_set_imu_all: the ten edges (dicts, VioPreint or None) in one crossing of the boundary; libraries without it: ten calls."""
+        pres = list(pres)
+        if len(pres) != WINDOW_SIZE:           # (a shorter list would silently pass NULL — "no edge" — for the missing ones: ADVICE r05)
+            raise ValueError("set_imu_all takes the window's %d IMU edges (None for a missing one), got %d" % (WINDOW_SIZE, len(pres)))
         if "set_imu_all" not in self.lib.fn:
             for k, pre in enumerate(pres):
                 self.set_imu(k, pre)
