@@ -50,4 +50,19 @@ for n, seed, with_prior, ragged, ext_fixed in ((500, 17, False, False, 1), (700,
     rep = c.solve(6)
     p, s, e = c.get_window()
     feed(p, s, e, c.get_landmarks(), [rep.final_chi2, rep.final_lambda, rep.iterations, rep.trials])
+# vio_solve's loop in the reference's real regime: ragged tracks, chained priors — windows on which trials are rejected (a rejected step makes
+# k_pose_solve_c solve the other set again: the second copy of either prologue)
+cs = hip.context()
+pr, trials = None, []
+for r in range(6):
+    w = vio.synth.make_window(150, seed=300 + r, t0=1.0 + 0.1 * r, ragged=True)
+    w.prior = pr
+    cs.load(w)
+    rep = cs.solve(10)
+    trials.append(rep.trials)
+    p, s, e = cs.get_window()
+    feed(p, s, e, cs.get_landmarks(), [rep.final_chi2, rep.final_lambda, rep.iterations, rep.trials], rep.chi2_trace[:rep.iterations + 1], rep.lambda_trace[:rep.iterations + 1])
+    pr = cs.marginalize(vio.MARG_OLD)
+    feed(pr["H"], pr["b"], pr["err"], pr["jt_inv"])
+assert max(trials) > 10, trials        # (some step was rejected: the case is exercised)
 print("digest", h.hexdigest())

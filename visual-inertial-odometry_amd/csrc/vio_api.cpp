@@ -601,6 +601,7 @@ vio_status read_lm_begin(vio_ctx *c) {
     return VIO_OK;
 }
 vio_status read_lm_end(vio_ctx *c) {
+    // (polling the event with hipEventQuery instead: measured, no difference — 0.5205 / 0.5196 against 0.5212 / 0.5232 ms per Solve(10))
     HIPCHK(hipEventSynchronize(c->lm_event));
     c->h_lm = *c->h_lm_pin;
     c->cur_host = c->h_lm.cur;
