@@ -422,6 +422,7 @@ def main():
                     c.set_landmarks(wr.inv_depth)
                     c.set_observations(wr.lm, wr.host, wr.target, wr.pts_i, wr.pts_j)
                     c.set_imu_all(wr.preint)
+                    c.prepare()             # (vio_prepare: the plan of the new graph built and uploaded while the tail still runs)
                     if r > 0:
                         next_prior = c.marginalize_end()
                     c.set_prior(next_prior if chain else wr.prior)

@@ -81,7 +81,7 @@ typedef enum { VIO_ORDER_EIGEN = 0, VIO_ORDER_CHAIN = 1 } vio_solve_order;
 
 /* Version of this interface: 3 = the sharded exchange is an all-gather (round 3); 4 = vio_set_solve_order (round 4);
  * 5 = vio_map_observations / vio_commit_observations; 6 = vio_set_imu_all. */
-#define VIO_ABI_VERSION 6
+#define VIO_ABI_VERSION 7
 
 typedef enum {
     VIO_MARG_OLD = 0,          /* Estimator::MargOldFrame  estimator.cpp:693-829 */
@@ -282,6 +282,13 @@ vio_status vio_marginalize(struct vio_ctx *ctx, int32_t kind, double *H, double 
  * (estimator.cpp:1023-1034).  A second begin, or vio_destroy, waits for an unfinished tail itself. */
 vio_status vio_marginalize_begin(struct vio_ctx *ctx, int32_t kind);
 vio_status vio_marginalize_end(struct vio_ctx *ctx, double *H, double *b, double *err, double *jt_inv);
+/* What the next solve needs of the graph set so far — the grouping of the landmarks into workgroup items, its tables and the
+ * observations on the device (the host side of Problem's AddVertex / AddEdge / SetOrdering, estimator.cpp:909-1016, problem.cc:256-285) —
+ * built and uploaded NOW instead of inside the next vio_linearize / vio_solve.  Optional: a frame loop that runs its marginalisation in
+ * the background calls it between the vio_set_window / landmarks / observations / imu of the new frame and vio_marginalize_end, so that
+ * the planner's 0.06 - 0.2 ms run under the dense tail too; vio_set_prior afterwards only sends the prior.  Results are the same with and
+ * without it.  (VIO_ABI_VERSION 7.) */
+vio_status vio_prepare(struct vio_ctx *ctx);
 
 /* ---- read back ------------------------------------------------------------------------------ */
 vio_status vio_get_window(struct vio_ctx *ctx, double *poses, double *speed_bias, double *ext);

@@ -1517,6 +1517,8 @@ static int run_hook(struct vioo_ctx *c, int which) {
 }
 
 /* SetOrdering + MakeHessian (problem.cc:256-285,303-389) + the lambda-free part of SolveLinearSystem (:412-429) */
+vio_status vio_prepare(struct vioo_ctx *c) { return c ? VIO_OK : VIO_ERR_BAD_ARG; }      /* (the port builds nothing ahead of its solve) */
+
 vio_status vio_linearize(struct vioo_ctx *c) {
     if (c && c->M_mapped != -1) { snprintf(c->err, sizeof(c->err), "vio_map_observations without vio_commit_observations"); return VIO_ERR_BAD_ARG; }
     if (!c) return VIO_ERR_BAD_ARG;

@@ -23,6 +23,7 @@
 #define vio_set_prior vioo_set_prior
 #define vio_solve vioo_solve
 #define vio_linearize vioo_linearize
+#define vio_prepare vioo_prepare
 #define vio_init_lm vioo_init_lm
 #define vio_solve_linear vioo_solve_linear
 #define vio_update_states vioo_update_states

@@ -24,6 +24,8 @@ for r in range(reps + 3):
     if pipelined:
         c.set_window(w.poses, w.speed_bias, w.ext); c.set_landmarks(w.inv_depth)
         c.set_observations(w.lm, w.host, w.target, w.pts_i, w.pts_j); c.set_imu_all(w.preint)
+        if os.environ.get("VIO_DIAG_NO_PREPARE") is None:
+            c.prepare()
         if r > 0:
             prior = c.marginalize_end()
         c.set_prior(prior)

@@ -96,8 +96,9 @@ class VioLib:
     # ... nor the two-halves marginalisation (vio_marginalize_begin / _end)
     # ... nor the in-place observation list (vio_map_observations / vio_commit_observations)
     # ... nor the ten IMU edges in one call (vio_set_imu_all)
+    # ... nor the plan built ahead of the solve (vio_prepare)
     OPTIONAL = ["triangulate", "gather_buffers", "bind_gather_buffers", "marginalize_begin", "marginalize_end",
-                "map_observations", "commit_observations", "set_imu_all"]
+                "map_observations", "commit_observations", "set_imu_all", "prepare"]
 
     # exported by the HIP library only (measurement, caller-owned exchange buffers)
     HIP_ONLY = ["profile_begin", "profile_begin_sampled", "profile_end", "kernel_name", "preintegrate",
@@ -343,6 +344,11 @@ class VioContext:
         rep = VioSolveReport()
         self._ck(self.lib.fn["solve"](self.h, C.c_int32(iterations), C.byref(rep)), "solve")
         return rep
+
+    def prepare(self):
+        """vio_prepare: the graph's plan built and uploaded now (a no-op for libraries without it)."""
+        if "prepare" in self.lib.fn:
+            self._ck(self.lib.fn["prepare"](self.h), "prepare")
 
     def linearize(self):
         self._ck(self.lib.fn["linearize"](self.h), "linearize")

@@ -1459,6 +1459,15 @@ vio_status vio_linearize(vio_ctx *c) {
     return VIO_OK;
 }
 
+vio_status vio_prepare(vio_ctx *c) {
+    if (!c) return VIO_ERR_BAD_ARG;
+    enter_device(c);
+    bool any_imu = false;
+    for (int k = 0; k < VIO_WINDOW_SIZE; ++k) any_imu |= c->imu_valid[k];
+    if (c->h_olm.empty() && !any_imu) return VIO_OK;        // nothing to prepare (vio_solve will say what it thinks of an empty graph)
+    return activate(c, c->solve_plan, 0);
+}
+
 vio_status vio_init_lm(vio_ctx *c, double *chi2, double *lambda) {
     if (!c || !c->linearized) return VIO_ERR_BAD_ARG;
     enter_device(c);

@@ -221,7 +221,8 @@ bool EstimatorBackend::uploadWindow(bool graph_unchanged) {
         if (vio_set_imu_all(ctx_, edges) != VIO_OK) return false;
     }
     // (the prior of the marginalisation the frame before left running — async_marginalization — is needed from here on: its dense
-    // tail has had slideWindow, the front-end and the uploads above to finish under)
+    // tail has had slideWindow, the front-end and the uploads above to finish under, and the planner's pass over the new graph too)
+    if (async_marginalization && vio_prepare(ctx_) != VIO_OK) return false;
     if (!waitMarginalization()) return false;
     if (!Hprior_.empty()) {                                                   // estimator.cpp:1023-1034
         if (vio_set_prior(ctx_, VIO_PRIOR_DIM, Hprior_.data(), bprior_.data(), errprior_.data(), Jprior_inv_.data()) != VIO_OK)
