@@ -168,6 +168,13 @@ def main():
     import numpy as np
     import torch
 
+    # The contract is ONE JSON line on stdout.  Libraries talk there too (RCCL prints its version banner on the C stdout when a communicator
+    # is created, gloo its connections): from here to the final print file descriptor 1 is stderr, and the real stdout comes back — with the C
+    # library's buffer flushed first — for that one line.
+    sys.stdout.flush()
+    real_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     one_device = os.environ.get("VIO_BENCH_ONE_DEVICE") == "1"      # all ranks on device 0: the N > 1 path on a one-GPU box
@@ -890,6 +897,13 @@ def main():
         }
         import ctypes
         ctypes.CDLL(None).fflush(None)      # RCCL's version banner sits in C stdio's buffer: keep the JSON line last
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(real_stdout_fd, 1)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

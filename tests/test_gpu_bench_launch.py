@@ -76,6 +76,9 @@ def test_single_gpu_line_carries_the_measured_scale_projection():
     one-rank communicator, against the unsharded window in the same run (VERDICT r05 next #3)."""
     p, out = run_bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--batch", "0", "--no-per-frame"])
     assert p.returncode == 0, p.stderr[-3000:]
+    # the contract: ONE JSON line on stdout — RCCL's version banner (a communicator is created for the projection) and anything else a library
+    # prints there must not be on it
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == [ln for ln in p.stdout.splitlines() if ln.startswith("{")] and p.stdout.count("\n") == 1, p.stdout[:600]
     sp = out["scale_projection"]
     assert "error" not in sp, sp
     assert sp["unsharded_ms_per_iteration"] > 0

@@ -15,7 +15,18 @@ from conftest import load_package  # noqa: E402
 vio = load_package()
 lib = vio.VioLib(os.path.join(ROOT, "visual-inertial-odometry_amd", "csrc", "diag", os.environ.get("VIO_DIAG_LIB", "libvio_hip_stamps.so")), "vio_")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-w = vio.synth.make_window(n, seed=42)
+w = vio.synth.make_window(n, seed=42, ragged=os.environ.get("VIO_DIAG_RAGGED") == "1")
+if os.environ.get("VIO_DIAG_DENSE_PRIOR") == "1":
+    # the prior a stream reaches after a few frames: the speed-bias block of frame 0 coupled with every camera tile (75 live rows)
+    cp, pr = lib.context(), None
+    for r in range(8):
+        wq = vio.synth.make_window(150, seed=300 + r, t0=1.0 + 0.1 * r, ragged=True)
+        wq.prior = pr
+        cp.load(wq)
+        cp.solve(10)
+        pr = cp.marginalize(vio.MARG_OLD)
+    w.prior = pr
+    del cp
 ctx = lib.context()
 ctx.load(w)
 ctx.linearize()

@@ -399,76 +399,37 @@ __device__ void d_imu_jac_block(int blk, const double *pre, const double *G, con
 
 #pragma clang fp contract(fast)
 // T = J^T Info J (30x30), g = J^T Info r, chi = r^T Info r  for IMU edge k
-// Round 6: the edge's inputs (its pre-integration, the two frames' states, gravity) are staged in LDS by the whole workgroup — one round
-// trip — what the Jacobian blocks share (d_imu_common, R_i^T) is formed once and kept in LDS, and the sixteen tasks (14 Jacobian blocks,
-// the residual, the identity blocks) run ONE PER WAVE on uniform branches.  Until then sixteen lanes of one wave ran the sixteen branches
-// one after the other, each with its own loads from global memory: 8 us per workgroup — the long pole of k_linearize for the windows the
-// Estimator really produces (N = 100 .. 300: their items take 5.5 us).  The same device functions on the same values (no contraction in
-// them: see above): the same bits, as d_chain_pre_item's wave-per-block form has shown since round 5.
-// owe_rows: the rows of b_prior' this workgroup owes (the GN / LM loops, see d_linearize_body) are formed by its last wave between the
-// staging loads and their stores, under their latency.
-__device__ __forceinline__ void d_bprior_rows(const DeviceTables &T, int from, int to, int first, int step, int lane);
-#define IMU_LDS_J 0
-#define IMU_LDS_PRE (IMU_LDS_J + 450)                   // the pre-integration as uploaded (PRE_STRIDE); its information at PRE_INFO
-#define IMU_LDS_JTI (IMU_LDS_PRE + PRE_STRIDE)          // 30 x 15
-#define IMU_LDS_R (IMU_LDS_JTI + 450)                   // 15 (16)
-#define IMU_LDS_IR (IMU_LDS_R + 16)                     // 15 (16)
-#define IMU_LDS_ST (IMU_LDS_IR + 16)                    // pose_i, pose_j (14) | sb_i, sb_j (18)
-#define IMU_LDS_CM (IMU_LDS_ST + 32)                    // ImuCommon (27) | R_i^T (9, at 28)
-#define IMU_LDS_G (IMU_LDS_CM + 40)                     // gravity (3)
-#define IMU_LDS_END (IMU_LDS_G + 4)
-static_assert(IMU_LDS_END <= IMU_ITEM_LDS_DOUBLES, "vio_types.h: the LDS floor of a k_linearize workgroup");
-template <int NT> __device__ void d_imu_item(const DeviceTables &T, int k, double *smem, bool owe_rows = false, int row_first = 0) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double *sJ = smem + IMU_LDS_J, *sPre = smem + IMU_LDS_PRE, *sI = sPre + PRE_INFO, *sJtI = smem + IMU_LDS_JTI;
-    double *sr = smem + IMU_LDS_R, *sIr = smem + IMU_LDS_IR, *sSt = smem + IMU_LDS_ST, *sCm = smem + IMU_LDS_CM, *sG = smem + IMU_LDS_G;
+// (Round 6 tried the inputs staged in LDS and the sixteen tasks one per wave on uniform branches: bit-identical, the IMU workgroup 19-20 k ->
+//  16.4 k cycles — and k_linearize at 20 000 landmarks 13.5 -> 14.2 us, the GN iteration 45.7 -> 46.4 us (tools/ab.py, profiles/r06n_imu_item_ab.txt):
+//  the item workgroups, which share the kernel's register allocation, lost more than the IMU workgroups — never the long pole — gained.  Reverted.)
+template <int NT> __device__ void d_imu_item(const DeviceTables &T, int k, double *smem) {
+    const int tid = threadIdx.x;
+    double *sJ = smem;               // 450
+    double *sI = sJ + 450;           // 225 information
+    double *sJtI = sI + 225;         // 30x15
+    double *sr = sJtI + 450;         // 15
+    double *sIr = sr + 16;           // 15
     double *out = T.imu_out + k * IMU_OUT;
-    const int cur = d_cur(T);
     if (!T.imu_valid[k]) {
-        if (owe_rows && wave == NT / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, row_first, T.n_step_blocks, lane);
         for (int e = tid; e < IMU_OUT; e += NT) out[e] = 0.0;
         return;
     }
-    {
-        const double *st = T.state + cur * STATE_STRIDE;
-        const double *pre = T.pre + k * PRE_STRIDE;
-        static_assert(PRE_STRIDE <= 1024 && PRE_STRIDE > 256, "staged in one or two rounds");
-        const double pv0 = tid < PRE_STRIDE ? pre[tid] : 0.0;
-        const double pv1 = (NT < PRE_STRIDE && tid + NT < PRE_STRIDE) ? pre[tid + NT] : 0.0;
-        double sv = 0.0;
-        if (tid >= 64 && tid < 64 + 14) sv = st[STATE_POSE + 7 * k + (tid - 64)];
-        else if (tid >= 128 && tid < 128 + 18) sv = st[STATE_SB + 9 * k + (tid - 128)];
-        else if (tid >= 192 && tid < 192 + 3) sv = T.gravity[tid - 192];
-        if (owe_rows && wave == NT / 64 - 1) d_bprior_rows(T, cur ^ 1, cur, row_first, T.n_step_blocks, lane);
-        if (tid < PRE_STRIDE) sPre[tid] = pv0;
-        if (NT < PRE_STRIDE && tid + NT < PRE_STRIDE) sPre[tid + NT] = pv1;
-        if (tid >= 64 && tid < 64 + 14) sSt[tid - 64] = sv;
-        else if (tid >= 128 && tid < 128 + 18) sSt[14 + tid - 128] = sv;
-        else if (tid >= 192 && tid < 192 + 3) sG[tid - 192] = sv;
-        for (int e = tid; e < 450; e += NT) sJ[e] = 0.0;
-    }
+    const int cur = d_cur(T);
+    const double *st = T.state + cur * STATE_STRIDE;
+    const double *pre = T.pre + k * PRE_STRIDE;
+    const double *pi = st + STATE_POSE + 7 * k, *pj = pi + 7, *si = st + STATE_SB + 9 * k, *sj = si + 9;
+    for (int e = tid; e < 450; e += NT) sJ[e] = 0.0;
+    for (int e = tid; e < 225; e += NT) sI[e] = pre[PRE_INFO + e];
     __syncthreads();
-    const double *pi = sSt, *pj = sSt + 7, *si = sSt + 14, *sj = sSt + 23;
-    if (wave == 0 && lane == 0) {
+    if (tid < 16) {
         ImuCommon c;
         double RiT[9];
-        d_imu_common(sPre, pi, si, pj, c);
+        d_imu_common(pre, pi, si, pj, c);
         d_imu_rit(c, RiT);
-        const double *cc = reinterpret_cast<const double *>(&c);
-#pragma unroll
-        for (int q = 0; q < 27; ++q) sCm[q] = cc[q];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) sCm[28 + q] = RiT[q];
-    }
-    __syncthreads();
-    for (int task = wave; task < 16; task += NT / 64) {
-        if (lane != 0) continue;
-        const ImuCommon &c = *reinterpret_cast<const ImuCommon *>(sCm);
-        if (task < 14) d_imu_jac_block(task, sPre, sG, pi, si, pj, sj, c, sCm + 28, sJ);
-        else if (task == 14) {
+        if (tid < 14) d_imu_jac_block(tid, pre, T.gravity, pi, si, pj, sj, c, RiT, sJ);
+        else if (tid == 14) {
             double r[15];
-            d_imu_residual(sPre, sG, pi, si, pj, sj, c, r);
+            d_imu_residual(pre, T.gravity, pi, si, pj, sj, c, r);
             for (int i = 0; i < 15; ++i) sr[i] = r[i];
         } else {
             for (int i = 0; i < 3; ++i) {       // identity blocks (edge_imu.cc:116-118,146-148)
@@ -484,10 +445,10 @@ template <int NT> __device__ void d_imu_item(const DeviceTables &T, int k, doubl
         for (int i = 0; i < 15; ++i) s = fma(sJ[30 * i + a], sI[15 * i + j], s);
         sJtI[e] = s;
     }
-    if (tid >= NT - 64 && lane < 15) {
+    if (tid < 15) {
         double s = 0;
-        for (int j = 0; j < 15; ++j) s = fma(sI[15 * lane + j], sr[j], s);
-        sIr[lane] = s;
+        for (int j = 0; j < 15; ++j) s = fma(sI[15 * tid + j], sr[j], s);
+        sIr[tid] = s;
     }
     __syncthreads();
     for (int e = tid; e < 900; e += NT) {
@@ -567,8 +528,9 @@ template <int NT, int UE, int CH = 0> __device__ __forceinline__ void d_lineariz
     const bool owe_prior = owe && T.has_prior;
     if (b >= T.n_items) {
         STAMP(T, 0);
+        if (owe_prior && (tid >> 6) == NT / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
 #ifndef LIN_DIAG_NO_IMU
-        d_imu_item<NT>(T, b - T.n_items, dyn_smem, owe_prior, b);
+        d_imu_item<NT>(T, b - T.n_items, dyn_smem);
 #endif
         STAMP(T, 5);
         STAMP_FLUSH(T);

@@ -249,7 +249,8 @@ template <int NT> __device__ __forceinline__ void d_linearize_xyz_body(const Dev
     // GN mode (gn_flags bit 1), as in k_linearize: the previous step's b_prior' rows and landmark back-substitution come first
     const bool owe = d_step_owed(T, 2), owe_prior = owe && T.has_prior;
     if (b >= T.n_items) {
-        d_imu_item<NT>(T, b - T.n_items, dyn_smem, owe_prior, b);
+        if (owe_prior && (tid >> 6) == NT / 64 - 1) { const int c = d_cur(T); d_bprior_rows(T, c ^ 1, c, b, T.n_step_blocks, tid & 63); }
+        d_imu_item<NT>(T, b - T.n_items, dyn_smem);
         return;
     }
     __shared__ ItemDesc sIt;

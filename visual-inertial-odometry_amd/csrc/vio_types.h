@@ -257,8 +257,8 @@ struct TriTables {               // k_triangulate (FeatureManager::triangulate)
 #define PRE_JAC 17               // 15x15
 #define PRE_INFO (17 + 225)      // 15x15 information = covariance^-1 (computed on the host at upload)
 #define PRE_STRIDE (17 + 450 + 5)
-// LDS of an IMU workgroup of k_linearize* (d_imu_item: J, the staged pre-integration, J^T Info, r, Info r, states, the blocks' common part,
-// gravity), in doubles: the floor of a plan's max_lds_doubles
-#define IMU_ITEM_LDS_DOUBLES (450 + PRE_STRIDE + 450 + 16 + 16 + 32 + 40 + 4)
+// LDS of an IMU workgroup of k_linearize* (d_imu_item: J 450, information 225, J^T Info 450, r and Info r 32), in doubles: the floor of a
+// plan's max_lds_doubles
+#define IMU_ITEM_LDS_DOUBLES (450 + 225 + 450 + 32)
 
 #endif
