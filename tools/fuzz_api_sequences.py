@@ -120,7 +120,12 @@ for seq in range(n_seq):
         if not state["ok"] or state.get("stop"):
             break
         op = rng.choice(["solve", "gn", "get", "chi2", "set_window", "set_landmarks", "set_prior", "reload_same", "load_other", "marg_old", "marg_new",
-                         "stepwise", "set_imu", "set_config"], p=[.15, .1, .1, .08, .08, .07, .07, .05, .06, .08, .05, .05, .03, .03])
+                         "stepwise", "set_imu", "set_config", "linearize"], p=[.15, .1, .08, .08, .08, .07, .07, .05, .06, .08, .05, .05, .03, .03, .02])
+        if op == "linearize":
+            # (round 6: a vio_solve that follows a vio_linearize on the same state and graph starts from that system — and must not when anything
+            #  came in between: whatever follows in this sequence is compared with a fresh context as always)
+            run("linearize", lambda c: c.linearize())
+            continue
         if op in ("solve", "marg_old", "marg_new", "chi2", "stepwise"):
             if (op == "marg_new" and model["prior"] is None) or (op == "marg_old" and xyz):
                 continue
