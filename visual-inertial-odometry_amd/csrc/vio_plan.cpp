@@ -42,6 +42,9 @@ int best_item_size(const Input &in, const std::vector<Pattern> &patterns, const 
         }
         const double cost = (double)((blocks + cus - 1) / cus) * (70.0 + g_eff);
         if (best_g == 0 || cost < best_cost) { best_g = g; best_cost = cost; }
+        // (one round already at the smallest size: a larger g keeps the one round and only lengthens its workgroups — g_eff does not fall
+        //  as g grows — so the search would end where it started: the windows an Estimator produces, a few hundred landmarks, leave here)
+        if (g == in.g_min && !in.throughput && blocks <= cus) break;
     }
     return best_g;
 }
