@@ -2352,6 +2352,11 @@ __device__ __forceinline__ void d_init_lm_body(const DeviceTables &T, int max_it
     __shared__ double s0[256];
     const int tid = threadIdx.x;
     LmState *lm = T.lm;
+    // (everything thread 0 adds up at the end is requested here, with LmState: the ten IMU edges' chi2 as ONE load, lane = edge — one after the other
+    //  behind their valid flags they were twenty dependent round trips at the kernel's end, half of its 7.7 us; round 6.  The same sums in the same order.)
+    const int valid = d_imu_mask(T);
+    const double ichi = (tid < 10) ? T.imu_out[tid * IMU_OUT + IMU_CHI] : 0.0;
+    const double vchi = (tid == 0) ? d_vis(T, VIS_CHI) : 0.0, vmaxh = (tid == 0) ? d_vis_maxh(T) : 0.0;
     const int cur = lm->cur;
     double e = 0.0, md = 0.0;
     if (T.has_prior)
@@ -2359,12 +2364,14 @@ __device__ __forceinline__ void d_init_lm_body(const DeviceTables &T, int max_it
     for (int i = tid; i < VIO_PD; i += 256) md = fmax(md, fabs(T.diagfull[i]));
     const double en2 = d_block_sum<256>(e, s0, tid);
     const double maxd = d_block_max<256>(md, s0, tid);
+    if (tid >= 64) return;
+    double total = vchi;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { const double c = d_readlane(ichi, k); if ((valid >> k) & 1) total += c; }
     if (tid != 0) return;
-    double total = d_vis(T, VIS_CHI);
-    for (int k = 0; k < 10; ++k) if (T.imu_valid[k]) total += T.imu_out[k * IMU_OUT + IMU_CHI];
     if (T.has_prior) total += sqrt(en2);
     const double chi = 0.5 * total;
-    double maxDiagonal = fmax(maxd, d_vis_maxh(T));     // max |h_ll| over all shards
+    double maxDiagonal = fmax(maxd, vmaxh);             // max |h_ll| over all shards
     maxDiagonal = fmin(5e10, maxDiagonal);
     lm->ni = 2.;
     lm->chi = chi;
