@@ -466,14 +466,17 @@ bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout, const Pa
     // the order it generates them; the rotations are applied to V by row blocks — a row sees the same rotations in the same order whoever
     // applies them, so the result does not depend on the number of threads — while the iteration is still running (pipeline: `avail`).
     ET(2);
-    const size_t cap = (size_t)8 * n * n + 64;
-    std::vector<Rot> rots(cap);
+    // (the record: 3 n^2 rotations — an iteration takes about 0.85 n^2 — in a buffer the thread keeps from call to call: a fresh, zeroed
+    //  megabyte per call cost the tail tens of microseconds in page faults)
+    const size_t cap = (size_t)3 * n * n + 64;
+    static thread_local std::vector<Rot> rots;
+    if (rots.size() < cap) rots.resize(cap);
     QlJob job;
     job.V = V; job.n = n; job.rots = rots.data(); job.cap = cap; job.d = d; job.e = e;
     const int want = (par && par->run_n && n >= 32) ? std::min(par->width, (n + 15) / 16 + 1) : 1;
     if (want > 1) par->run_n(par->ctx, want, ql_participant, &job);
     else ql_participant(&job, 0, 1);
-    if (job.overflow.load()) return symmetric_eigen_legacy(n, Ain, d, Vout);      // (more than 8 n^2 rotations: not a matrix this library meets)
+    if (job.overflow.load()) return symmetric_eigen_legacy(n, Ain, d, Vout);      // (more than 3 n^2 rotations: the routine as it was takes over)
     bool ok = job.ok;
     ET(3);
     for (int i = 0; i < n - 1; ++i) {
