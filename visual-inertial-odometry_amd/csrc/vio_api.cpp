@@ -249,7 +249,8 @@ struct vio_ctx {
     bool imu_valid[VIO_WINDOW_SIZE];
     std::vector<double> h_pre;                 // [10][PRE_STRIDE]
     int has_prior = 0;
-    std::vector<double> h_Hprior, h_bprior, h_errprior, h_Jtinv;
+    std::vector<double> h_bprior, h_errprior;
+    PinnedVec h_Hprior, h_Jtinv;               // pinned: the two matrices of the prior (430 KB) go up as they lie here (round 6: they were copied into the staging arena first)
     HostArena arena;                           // pinned staging of the uploads
     double *marg_stage = nullptr;              // pinned: H_marg (171 x 171) and b_marg for the host tail of vio_marginalize
     vio_plan::BgTicket marg_ticket;            // the dense tail of a marginalisation on the process's background worker (vio_marginalize_begin / _end)
@@ -679,10 +680,9 @@ vio_status push_to_device(vio_ctx *c, Plan &pl) {
         c->imu_dirty = false;
     }
     if (c->prior_dirty) {
-        double *s_H = A.put(c->h_Hprior.data(), (size_t)PD * PD), *s_J = A.put(c->h_Jtinv.data(), (size_t)PRD * PRD);
-        if (!s_H || !s_J) return fail(c, VIO_ERR_HIP, "hipHostMalloc (staging)");
-        HIPCHK(hipMemcpyAsync(c->d_Hprior.p, s_H, PD * PD * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(c->d_Jtinv.p, s_J, PRD * PRD * 8, hipMemcpyHostToDevice, st));
+        // (straight out of the pinned mirrors; vio_set_prior waits for the arena's event — recorded behind these copies — before it writes them again)
+        HIPCHK(hipMemcpyAsync(c->d_Hprior.p, c->h_Hprior.p, PD * PD * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(c->d_Jtinv.p, c->h_Jtinv.p, PRD * PRD * 8, hipMemcpyHostToDevice, st));
         c->prior_dirty = false;
         c->prior_simg_valid = false;
     }
@@ -1025,7 +1025,9 @@ vio_status vio_create(const vio_config *cfg, vio_ctx **out) {
     for (int i = 0; i < NF; ++i) c->h_state[STATE_POSE + 7 * i + 6] = 1.0;
     for (int k = 0; k < VIO_WINDOW_SIZE; ++k) c->imu_valid[k] = false;
     c->h_pre.assign(VIO_WINDOW_SIZE * PRE_STRIDE, 0.0);
-    c->h_Hprior.assign(PD * PD, 0.0); c->h_bprior.assign(PD, 0.0); c->h_errprior.assign(PRD, 0.0); c->h_Jtinv.assign(PRD * PRD, 0.0);
+    c->h_bprior.assign(PD, 0.0); c->h_errprior.assign(PRD, 0.0);
+    if (!c->h_Hprior.resize_uninitialized((size_t)PD * PD) || !c->h_Jtinv.resize_uninitialized((size_t)PRD * PRD)) { vio_plan::shared_release(); c->h_Hprior.release(); c->h_Jtinv.release(); if (c->own_stream) hipStreamDestroy(c->stream); delete c; return VIO_ERR_HIP; }
+    std::memset(c->h_Hprior.p, 0, (size_t)PD * PD * 8); std::memset(c->h_Jtinv.p, 0, (size_t)PRD * PRD * 8);
     if (const char *e = std::getenv("VIO_G_MAX")) { int v = std::atoi(e); if (v >= 1 && v <= 128) c->g_max = v; }
     if (const char *e = std::getenv("VIO_G_MIN")) { int v = std::atoi(e); if (v >= 1 && v <= 128) c->g_min = v; }
     if (c->g_max > 0) c->g_min = c->g_max;     // a forced size is exactly that size (LDS permitting)
@@ -1074,7 +1076,7 @@ void vio_destroy(vio_ctx *c) {
     c->d_imu_chi.release(); c->d_imu_valid.release(); c->d_lm.release(); c->d_perm.release(); c->d_Pg.release(); c->d_cfi.release(); c->d_imu_map.release(); c->d_prior_simg.release(); c->d_prior_flags.release(); c->d_prior_list.release(); c->d_prior_cval.release();
     c->d_batch_tabs.release(); c->d_frame_block.release(); c->d_rank.release(); c->d_gather_map.release(); c->d_gath.release(); c->d_step_gath.release();
     c->arena.release(c->own_stream);
-    c->h_pts_j.release(); c->d_raw_pts_j.release();
+    c->h_pts_j.release(); c->d_raw_pts_j.release(); c->h_Hprior.release(); c->h_Jtinv.release();
     if (c->pull_stage) hipHostFree(c->pull_stage);
     if (c->marg_stage) hipHostFree(c->marg_stage);
     if (c->h_lm_pin) hipHostFree(c->h_lm_pin);
@@ -1357,7 +1359,7 @@ vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double 
     bool same_mats = c->has_prior == (dim ? 1 : 0);
     if (same_mats && dim) {
         same_mats = std::memcmp(c->h_Jtinv.data(), jt, (size_t)PRD * PRD * 8) == 0;
-        for (int i = 0; same_mats && i < PRD; ++i) same_mats = std::memcmp(&c->h_Hprior[(size_t)i * PD], &H[(size_t)i * PRD], PRD * 8) == 0;
+        for (int i = 0; same_mats && i < PRD; ++i) same_mats = std::memcmp(c->h_Hprior.p + (size_t)i * PD, &H[(size_t)i * PRD], PRD * 8) == 0;
     }
     const bool same_vecs = same_mats && !(c->ahead & 4u) &&
                            (dim == 0 || (std::memcmp(c->h_bprior.data(), b, PRD * 8) == 0 && std::memcmp(c->h_errprior.data(), err, PRD * 8) == 0));
@@ -1365,16 +1367,20 @@ vio_status vio_set_prior(vio_ctx *c, int32_t dim, const double *H, const double 
     c->ahead &= ~4u;                 // b_prior and err_prior are replaced whole
     std::fill(c->h_bprior.begin(), c->h_bprior.end(), 0.0); std::fill(c->h_errprior.begin(), c->h_errprior.end(), 0.0);
     if (!same_mats) {
-        std::fill(c->h_Hprior.begin(), c->h_Hprior.end(), 0.0); std::fill(c->h_Jtinv.begin(), c->h_Jtinv.end(), 0.0);
+        // (the pinned mirrors may still be the source of the previous activation's upload: long done in practice)
+        if (c->arena.pending) { HIPCHK(hipEventSynchronize(c->arena.ev)); c->arena.pending = false; }
+        // a prior that goes away leaves zeros; one that comes overwrites its 156 x 156 corner, and the 15 rows / columns of
+        // ExtendHessiansPriorSize(15) (problem.cc:82-91) are zero and stay zero: nobody writes them (430 KB of memset per frame before)
+        if (!dim) { std::memset(c->h_Hprior.p, 0, (size_t)PD * PD * 8); std::memset(c->h_Jtinv.p, 0, (size_t)PRD * PRD * 8); }
         c->has_prior = dim ? 1 : 0;
         c->prior_dirty = true;
     }
-    if (dim) {      // ExtendHessiansPriorSize(15): 15 zero rows/cols appended (problem.cc:82-91)
+    if (dim) {
         for (int i = 0; i < PRD; ++i) c->h_bprior[i] = b[i];
         std::memcpy(c->h_errprior.data(), err, PRD * 8);
         if (!same_mats) {
-            for (int i = 0; i < PRD; ++i) std::memcpy(&c->h_Hprior[(size_t)i * PD], &H[(size_t)i * PRD], PRD * 8);
-            std::memcpy(c->h_Jtinv.data(), jt, (size_t)PRD * PRD * 8);
+            for (int i = 0; i < PRD; ++i) std::memcpy(c->h_Hprior.p + (size_t)i * PD, &H[(size_t)i * PRD], PRD * 8);
+            std::memcpy(c->h_Jtinv.p, jt, (size_t)PRD * PRD * 8);
         }
     }
     if (!same_mats) {
