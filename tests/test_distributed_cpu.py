@@ -1,4 +1,4 @@
-"""The N > 1 path on CPU: world_size 2 and 3 over gloo.  Each process runs the sharded LM loop of
+"""The N > 1 path on CPU: world_size 2, 3 and 8 over gloo.  Each process runs the sharded LM loop of
 visual-inertial-odometry_amd/sharded.py with the CPU oracle standing in for the GPU library (same C ABI, same
 exchange hooks), and the result must equal the unsharded solve."""
 import os
@@ -41,9 +41,10 @@ def _worker(rank, world, port, out_dir, n, ragged):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,ragged,world", [(90, False, 2), (61, True, 2), (100, True, 3)])
+@pytest.mark.parametrize("n,ragged,world", [(90, False, 2), (61, True, 2), (100, True, 3), (96, True, 8)])
 def test_sharded_solve_equals_unsharded(vio, oracle_lib, tmp_path, n, ragged, world):
-    """(world 3: uneven shards, and a rank-ordered sum of more than two terms: (a + b) + c on every rank)"""
+    """(world 3: uneven shards, and a rank-ordered sum of more than two terms: (a + b) + c on every rank; world 8: the rank count of
+    BASELINE.json configs[3], twelve landmarks a shard)"""
     import torch.multiprocessing as mp
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path), n, ragged), nprocs=world, join=True)
