@@ -34,10 +34,10 @@ _, lam = ctx.init_lm()
 for _ in range(3):
     ctx.solve_linear(lam)
 ctx.synchronize()
-buf = np.zeros((16, 16), dtype=np.uint64)
+buf = np.zeros((24, 16), dtype=np.uint64)
 f = lib.dll.vio_debug_stamps
 f.restype = C.c_int
-assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(16)) == 0
+assert f(ctx.h, buf.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int64(24)) == 0
 s = buf.astype(np.int64).ravel()
 print("copy-in + lambda done %d | factor + solve done %d | end %d" % (s[0], s[2], s[3]))
 base = s[0]
@@ -54,6 +54,11 @@ print("  phase 5a: wave 0: eff mask %d, fused %d | wave 1: CC(0,0) level-4 terms
 print("  phase 5, every worker done at:", [int(v) for v in s[202:216]])
 print("  phase 5 + barrier: %6d (+%5d)" % (s[87], s[87] - prev))
 prev = s[87]
+print("arrival of every wave at the chain's barriers (ticks; wave 0, 1 = chain waves, 15 = right-hand side):")
+for B in range(6):
+    a = s[256 + 16 * B:256 + 16 * B + 16]
+    late = int(np.argmax(a))
+    print("  barrier %d: %s   last: wave %d (+%d behind the median)" % (B, [int(v) for v in a], late, int(a.max() - np.median(a))))
 print("camera block:")
 print("  CC(0,0) update + F(0) done %6d (+%5d) | past barrier %6d" % (s[88], s[88] - prev, s[89]))
 prev = s[89]
