@@ -452,6 +452,7 @@ __device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, co
                 ch_chain_level(P, L, e, e + dir, !(uwave == 1 && lev == 4), lane, P + CH_OFF_X + 64 * uwave);
                 if (uwave == 0) CH_STAMP(64 + 4 * lev);
             }
+            CH_STAMP(256 + 16 * lev + uwave);              // (diagnostic build: when each wave reaches barrier `lev`: tools/diag_chain_stamps.py)
             __syncthreads();
             if (uwave == 0) CH_STAMP(65 + 4 * lev);
         }
@@ -469,17 +470,23 @@ __device__ __forceinline__ unsigned long long ch_chain_elimination(double *P, co
     } else {
         const int wi = uwave - 2;
         if (!scanned) ch_scan_tiles(P, wi, lane);                  // (nothing else to do during level 0; `scanned`: the copy-in noted the flags)
+        CH_STAMP(256 + uwave);
         __syncthreads();                                           // barrier 0: level 0 is out
         eff = ch_eff_mask(P, lane);
         ch_worker_phase<0, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(112);
+        CH_STAMP(256 + 16 + uwave);
         __syncthreads();
         ch_worker_phase<1, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(113);
+        CH_STAMP(256 + 32 + uwave);
         __syncthreads();
         ch_worker_phase<2, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(114); CH_STAMP(140 + uwave);
+        CH_STAMP(256 + 48 + uwave);
         __syncthreads();
         ch_worker_phase<3, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(115);
+        CH_STAMP(256 + 64 + uwave);
         __syncthreads();
         ch_worker_phase<4, CAM>(P, L, wi, lane, eff); if (uwave == 2) CH_STAMP(116); CH_STAMP(180 + uwave);
+        CH_STAMP(256 + 80 + uwave);
         __syncthreads();
         if (CAM) {
             // Phase 5a, a short one: the five L_SC[5][t] (t = 0 on wave 0), w_5, and the right-hand side's terms of level 4.  Everything else
