@@ -45,12 +45,12 @@ def driver(tmp_path_factory):
     subprocess.check_call(cmd + ["-o", exe])
     assert ITEM_DTYPE.itemsize == 104
 
-    def run(payload):
+    def run(payload, env=None):
         d = os.path.dirname(exe)
         inp, out = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
         with open(inp, "wb") as f:
             f.write(payload)
-        r = subprocess.run([exe, inp, out], capture_output=True, text=True)
+        r = subprocess.run([exe, inp, out], capture_output=True, text=True, env=None if env is None else dict(os.environ, **env))
         assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
         return open(out, "rb").read()
     return run
@@ -174,6 +174,11 @@ def test_eigen_solver_on_helper_threads_returns_the_legacy_bits(driver):
             out = driver(struct.pack("<iii", 5, n, width) + f64(A))
             same, ok = struct.unpack("<ii", out)
             assert same == 1 and ok == 1, (n, width)
+        # (on a host with AVX-512 the rotations are applied with the carried column in vector registers, ql_apply_512: the run above took
+        # that path there; VIO_NO_AVX512 forces the 256-bit / baseline clones — the same bits either way)
+        out = driver(struct.pack("<iii", 5, n, 1) + f64(A), env={"VIO_NO_AVX512": "1"})
+        same, ok = struct.unpack("<ii", out)
+        assert same == 1 and ok == 1, (n, "VIO_NO_AVX512")
 
 
 def test_marginalize_tail_does_not_depend_on_the_thread_count(driver):
@@ -187,6 +192,9 @@ def test_marginalize_tail_does_not_depend_on_the_thread_count(driver):
     assert struct.unpack_from("<i", base, 0)[0] == 75               # the most rows a window's graph can keep live
     for width in (2, 4, 7):
         assert driver(struct.pack("<iii", 6, width, 0) + f64(H) + f64(b)) == base, width
+    # (a host with AVX-512 runs the rotations, the Schur rows and the H_prior product with their accumulators in vector registers:
+    # the 256-bit / baseline clones, forced by VIO_NO_AVX512, return the same bytes)
+    assert driver(struct.pack("<iii", 6, 1, 0) + f64(H) + f64(b), env={"VIO_NO_AVX512": "1"}) == base
 
 
 def test_the_process_has_one_set_of_helper_threads_whatever_the_number_of_contexts(driver):

@@ -72,6 +72,10 @@ static inline double vio_hypot(double a, double b) {
 #define VIO_CLONES __attribute__((target_clones("avx2", "default")))
 #endif
 
+#if !defined(VIO_NO_TARGET_CLONES) && !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 namespace {
 struct Rot { int i; double c, s; };
 struct QlJob {
@@ -86,10 +90,73 @@ struct QlJob {
 };
 constexpr int QL_MAXB = 96;                 // rows of a block (the carried column lives on the stack)
 
+#if !defined(VIO_NO_TARGET_CLONES) && !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#define VIO_QL_AVX512 1
+// The same loop on a host with AVX-512 (the MI355X boxes' EPYC 9575F): the carried column — up to 96 rows — stays in NV of the 32 vector
+// registers instead of on the stack, so a rotation is one load and one store per eight rows where the 256-bit form has two of each per four.
+// The same operations on every element in the same order (two products and a sum, two products and a difference: no contraction), so the
+// eigenvectors are the bits the other clones give.  The last vector is masked: a column's tail must not touch the next column.
+#if defined(__clang__)
+#define VIO_512_ATTR __attribute__((target("avx512f")))
+#else
+#define VIO_512_ATTR __attribute__((target("avx512f"), optimize("fp-contract=off")))
+#endif
+template <int NV>
+VIO_512_ATTR void ql_apply_512(double *V, int n, int r0, int nb, const Rot *rots, size_t from, size_t to, double *carry_io, int &carry_col) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const __mmask8 tail = (nb & 7) ? (__mmask8)((1u << (nb & 7)) - 1u) : (__mmask8)0xff;
+    __m512d cr[NV];
+#pragma GCC unroll 16
+    for (int v = 0; v < NV; ++v) cr[v] = _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, carry_io + 8 * v);
+    int cc = carry_col;
+    for (size_t q = from; q < to; ++q) {
+        const int i = rots[q].i;
+        const __m512d vc = _mm512_set1_pd(rots[q].c), vs = _mm512_set1_pd(rots[q].s);
+        const double *ci = V + (size_t)i * n + r0;
+        double *ci1 = V + (size_t)(i + 1) * n + r0;
+        if (cc != i + 1) {
+            if (cc >= 0) {
+                double *pc = V + (size_t)cc * n + r0;
+#pragma GCC unroll 16
+                for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(pc + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, cr[v]);
+            }
+#pragma GCC unroll 16
+            for (int v = 0; v < NV; ++v) cr[v] = _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, ci1 + 8 * v);
+        }
+#pragma GCC unroll 16
+        for (int v = 0; v < NV; ++v) {
+            const __mmask8 mk = v == NV - 1 ? tail : (__mmask8)0xff;
+            const __m512d a = _mm512_maskz_loadu_pd(mk, ci + 8 * v), h = cr[v];
+            const __m512d o = _mm512_add_pd(_mm512_mul_pd(vs, a), _mm512_mul_pd(vc, h));       // ci1[k] = s * a + c * h
+            cr[v] = _mm512_sub_pd(_mm512_mul_pd(vc, a), _mm512_mul_pd(vs, h));                // carry[k] = c * a - s * h
+            _mm512_mask_storeu_pd(ci1 + 8 * v, mk, o);
+        }
+        cc = i;
+    }
+#pragma GCC unroll 16
+    for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(carry_io + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, cr[v]);
+    carry_col = cc;
+}
+static bool ql_apply_wide(double *V, int n, int r0, int r1, const Rot *rots, size_t from, size_t to, double *carry_io, int &carry_col) {
+    static const bool have = __builtin_cpu_supports("avx512f") && std::getenv("VIO_NO_AVX512") == nullptr;
+    if (!have) return false;
+    const int nb = r1 - r0;
+    switch ((nb + 7) / 8) {
+#define VIO_QL_CASE(NV) case NV: ql_apply_512<NV>(V, n, r0, nb, rots, from, to, carry_io, carry_col); return true;
+        VIO_QL_CASE(1) VIO_QL_CASE(2) VIO_QL_CASE(3) VIO_QL_CASE(4) VIO_QL_CASE(5) VIO_QL_CASE(6)
+        VIO_QL_CASE(7) VIO_QL_CASE(8) VIO_QL_CASE(9) VIO_QL_CASE(10) VIO_QL_CASE(11) VIO_QL_CASE(12)
+#undef VIO_QL_CASE
+        default: return false;
+    }
+}
+#endif
+
 // rotations [from, to) applied to rows [r0, r1) of V.  A sweep's rotations walk down the column pairs (i, i + 1), (i - 1, i), ...: the column a
 // rotation leaves as `at(k, i)` is the next one's `at(k, i + 1)` and stays in `carry` (carry_col: which column it is, -1: none).
 VIO_CLONES
-void ql_apply(double *V, int n, int r0, int r1, const Rot *__restrict rots, size_t from, size_t to, double *__restrict carry_io, int &carry_col) {
+void ql_apply_narrow(double *V, int n, int r0, int r1, const Rot *__restrict rots, size_t from, size_t to, double *__restrict carry_io, int &carry_col) {
     const int nb = r1 - r0;
     double carry[QL_MAXB];
     int cc = carry_col;
@@ -112,6 +179,12 @@ void ql_apply(double *V, int n, int r0, int r1, const Rot *__restrict rots, size
     }
     for (int k = 0; k < nb; ++k) carry_io[k] = carry[k];
     carry_col = cc;
+}
+void ql_apply(double *V, int n, int r0, int r1, const Rot *rots, size_t from, size_t to, double *carry_io, int &carry_col) {
+#ifdef VIO_QL_AVX512
+    if (r1 - r0 > 0 && ql_apply_wide(V, n, r0, r1, rots, from, to, carry_io, carry_col)) return;
+#endif
+    ql_apply_narrow(V, n, r0, r1, rots, from, to, carry_io, carry_col);
 }
 void ql_flush(double *V, int n, int r0, int r1, const double *carry, int &carry_col) {
     if (carry_col >= 0) { double *cc = V + (size_t)carry_col * n + r0; for (int k = 0; k < r1 - r0; ++k) cc[k] = carry[k]; }
@@ -221,6 +294,134 @@ void ql_participant(void *arg, int i, int nt) {
     for (int b0 = r0; b0 < r1; b0 += QL_MAXB, ++bi) ql_flush(J.V, n, b0, std::min(r1, b0 + QL_MAXB), bcarry.data() + (size_t)bi * QL_MAXB, bcc[bi]);
     (void)carry;
 }
+#ifdef VIO_QL_AVX512
+// acc[c0 .. c0 + ncols) = sum over q ascending of x[q] Y[q][c] (Y: rows of ld doubles), the accumulators in NV vector registers for the
+// whole sum: the additions of every entry in the order of the scalar loops this stands in for, one load per eight products instead of an
+// accumulator round trip per term (AVX-512 hosts: see ql_apply_512)
+template <int NV>
+VIO_512_ATTR void axpy_rows_512(const double *x, const double *Y, int nq, int ld, int c0, int ncols, double *acc) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const __mmask8 tail = (ncols & 7) ? (__mmask8)((1u << (ncols & 7)) - 1u) : (__mmask8)0xff;
+    __m512d a[NV];
+#pragma GCC unroll 16
+    for (int v = 0; v < NV; ++v) a[v] = _mm512_setzero_pd();
+    for (int q = 0; q < nq; ++q) {
+        const __m512d xq = _mm512_set1_pd(x[q]);
+        const double *y = Y + (size_t)q * ld + c0;
+#pragma GCC unroll 16
+        for (int v = 0; v < NV; ++v) a[v] = _mm512_add_pd(a[v], _mm512_mul_pd(xq, _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, y + 8 * v)));
+    }
+#pragma GCC unroll 16
+    for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(acc + c0 + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, a[v]);
+}
+bool have_avx512() {
+    static const bool have = __builtin_cpu_supports("avx512f") && std::getenv("VIO_NO_AVX512") == nullptr;
+    return have;
+}
+// acc[0 .. n) = sum over q ascending of x[q] Y[q][.]; false: no AVX-512 here
+bool axpy_rows_wide(const double *x, const double *Y, int nq, int ld, int n, double *acc) {
+    if (!have_avx512()) return false;
+    for (int c0 = 0; c0 < n; c0 += 96) {
+        const int ncols = std::min(96, n - c0);
+        switch ((ncols + 7) / 8) {
+#define VIO_AX_CASE(NV) case NV: axpy_rows_512<NV>(x, Y, nq, ld, c0, ncols, acc); break;
+            VIO_AX_CASE(1) VIO_AX_CASE(2) VIO_AX_CASE(3) VIO_AX_CASE(4) VIO_AX_CASE(5) VIO_AX_CASE(6)
+            VIO_AX_CASE(7) VIO_AX_CASE(8) VIO_AX_CASE(9) VIO_AX_CASE(10) VIO_AX_CASE(11) VIO_AX_CASE(12)
+#undef VIO_AX_CASE
+        }
+    }
+    return true;
+}
+// r[0 .. len) -= g[.] * s   (a product, then a difference)
+VIO_512_ATTR void sub_scaled_512(double *r, const double *g, double s, int len) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const __m512d sv = _mm512_set1_pd(s);
+    int j = 0;
+    for (; j + 8 <= len; j += 8) _mm512_storeu_pd(r + j, _mm512_sub_pd(_mm512_loadu_pd(r + j), _mm512_mul_pd(_mm512_loadu_pd(g + j), sv)));
+    if (j < len) {
+        const __mmask8 mk = (__mmask8)((1u << (len - j)) - 1u);
+        _mm512_mask_storeu_pd(r + j, mk, _mm512_sub_pd(_mm512_maskz_loadu_pd(mk, r + j), _mm512_mul_pd(_mm512_maskz_loadu_pd(mk, g + j), sv)));
+    }
+}
+// r[0 .. len) -= D[.] * er + E[.] * dr   (two products, their sum, a difference: tred2's rank-2 update of one row)
+VIO_512_ATTR void rank2_row_512(double *r, const double *D, const double *E, double er, double dr, int len) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const __m512d ev = _mm512_set1_pd(er), dv = _mm512_set1_pd(dr);
+    int j = 0;
+    for (; j + 8 <= len; j += 8) {
+        const __m512d t = _mm512_add_pd(_mm512_mul_pd(_mm512_loadu_pd(D + j), ev), _mm512_mul_pd(_mm512_loadu_pd(E + j), dv));
+        _mm512_storeu_pd(r + j, _mm512_sub_pd(_mm512_loadu_pd(r + j), t));
+    }
+    if (j < len) {
+        const __mmask8 mk = (__mmask8)((1u << (len - j)) - 1u);
+        const __m512d t = _mm512_add_pd(_mm512_mul_pd(_mm512_maskz_loadu_pd(mk, D + j), ev), _mm512_mul_pd(_mm512_maskz_loadu_pd(mk, E + j), dv));
+        _mm512_mask_storeu_pd(r + j, mk, _mm512_sub_pd(_mm512_maskz_loadu_pd(mk, r + j), t));
+    }
+}
+// tred2 — both phases — with the work matrix ROW-major and FULL (both triangles kept: the rank-2 update of entry (k, j) and of (j, k) are sums of
+// the same two products, so the two stay bit for bit equal) on a host with AVX-512:
+//   * the symmetric product p = A v is the sum over the rows k ascending of d[k] A[k][.], eight columns a register — every p_j takes its terms in
+//     the order the column-wise loops of symmetric_eigen give it (row part j' < j ascending, the diagonal, the column part k > j ascending);
+//   * the rank-2 update and the accumulation's update go a row at a time; the accumulation's dot products of column i + 1 with the columns
+//     j <= i are one sum over the rows, every column's additions over k ascending.
+// The same value in every entry as the loops in symmetric_eigen; leaves V column-major as they do.  false: not on this host.
+bool tred2_wide(int n, const double *Ain, double *d, double *e, double *V) {
+    if (!have_avx512() || n < 24) return false;
+    static thread_local std::vector<double> Rv, uv, gv;
+    if (Rv.size() < (size_t)n * n) Rv.resize((size_t)n * n);
+    if (uv.size() < (size_t)n + 8) { uv.resize((size_t)n + 8); gv.resize((size_t)n + 8); }
+    double *R = Rv.data(), *u = uv.data(), *G = gv.data();
+    auto at = [&](int i, int j) -> double & { return R[(size_t)i * n + j]; };
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) { at(i, j) = Ain[(size_t)i * n + j]; at(j, i) = at(i, j); }
+    for (int j = 0; j < n; ++j) d[j] = at(n - 1, j);
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) { d[j] = at(i - 1, j); at(i, j) = 0.0; at(j, i) = 0.0; }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1];
+            double g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g;
+            h -= f * g;
+            d[i - 1] = f - g;
+            axpy_rows_wide(d, R, i, n, i, e);                               // e = A d over the active block
+            for (int j = 0; j < i; ++j) at(j, i) = d[j];                    // (the Householder vector, for the second phase)
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int r = 0; r < i; ++r) rank2_row_512(R + (size_t)r * n, d, e, e[r], d[r], i);
+            for (int j = 0; j < i; ++j) { d[j] = at(i - 1, j); at(i, j) = 0.0; }
+        }
+        d[i] = h;
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        at(n - 1, i) = at(i, i);
+        at(i, i) = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) { u[k] = at(k, i + 1); d[k] = u[k] / h; }
+            axpy_rows_wide(u, R, i + 1, n, i + 1, G);
+            for (int k = 0; k <= i; ++k) sub_scaled_512(R + (size_t)k * n, G, d[k], i + 1);
+        }
+        for (int k = 0; k <= i; ++k) at(k, i + 1) = 0.0;
+    }
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) V[(size_t)j * n + i] = R[(size_t)i * n + j];
+    return true;
+}
+#endif
 }  // namespace
 
 // Householder tridiagonalisation followed by the implicit-shift QL iteration.  The work matrix is kept column-major
@@ -365,11 +566,18 @@ bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout, const Pa
     std::vector<double> Vv((size_t)n * n), ev(n);
     double *V = Vv.data(), *e = ev.data();
     auto at = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
+#ifdef VIO_QL_AVX512
+    const bool accumulated = tred2_wide(n, Ain, d, e, V);          // (both phases, row-major, on an AVX-512 host: the same values)
+#else
+    const bool accumulated = false;
+#endif
+    if (!accumulated) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) { at(i, j) = Ain[(size_t)i * n + j]; at(j, i) = at(i, j); }
     for (int j = 0; j < n; ++j) d[j] = at(n - 1, j);
+    }
     ET(0);
-    for (int i = n - 1; i > 0; --i) {
+    for (int i = n - 1; i > 0 && !accumulated; --i) {
         double scale = 0.0, h = 0.0;
         for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
         if (scale == 0.0) {
@@ -432,7 +640,7 @@ bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout, const Pa
         d[i] = h;
     }
     ET(1);
-    for (int i = 0; i < n - 1; ++i) {
+    for (int i = 0; i < n - 1 && !accumulated; ++i) {
         at(n - 1, i) = at(i, i);
         at(i, i) = 1.0;
         const double h = d[i + 1];
@@ -521,6 +729,13 @@ VIO_CLONES
 void prior_product_rows(int a0, int a1, const double *__restrict VS, const double *__restrict VKt, int nk, int nl, const int *__restrict live,
                         double *__restrict Hout, int n2, double *__restrict acc) {
     for (int a = a0; a < a1; ++a) {
+#ifdef VIO_QL_AVX512
+        if (axpy_rows_wide(VS + (size_t)a * nk, VKt, nk, nl, nl, acc)) {
+            double *__restrict ho = Hout + (size_t)live[a] * n2;
+            for (int c = 0; c < nl; ++c) ho[live[c]] = std::fabs(acc[c]) > 1e-9 ? acc[c] : 0.0;     // problem.cc:778
+            continue;
+        }
+#endif
         for (int c = 0; c < nl; ++c) acc[c] = 0.0;
         const double *__restrict x = VS + (size_t)a * nk;
         int q = 0;
@@ -617,11 +832,16 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
             }
             {   // (the 15-term sums of a row's entries side by side, k outside: the same additions per entry)
                 double *hrow = &Hpc[(size_t)a * nr];
-                for (int c = 0; c < nr; ++c) hrow[c] = 0.0;
-                for (int k = 0; k < m2; ++k) {
-                    const double tb = tempB[(size_t)a * m2 + k];
-                    const double *am = &Amr[(size_t)k * nr];
-                    for (int c = 0; c < nr; ++c) hrow[c] += tb * am[c];
+#ifdef VIO_QL_AVX512
+                if (!axpy_rows_wide(&tempB[(size_t)a * m2], Amr.data(), m2, nr, nr, hrow))
+#endif
+                {
+                    for (int c = 0; c < nr; ++c) hrow[c] = 0.0;
+                    for (int k = 0; k < m2; ++k) {
+                        const double tb = tempB[(size_t)a * m2 + k];
+                        const double *am = &Amr[(size_t)k * nr];
+                        for (int c = 0; c < nr; ++c) hrow[c] += tb * am[c];
+                    }
                 }
                 for (int c = 0; c < nr; ++c) hrow[c] = Hp_(i, rowlive[c]) - hrow[c];
             }
