@@ -57,6 +57,19 @@ def test_hip_library_exports_nothing_but_the_abi(vio):
     assert "vio_debug_chain_solve" not in exported
 
 
+def test_host_code_of_the_product_library_has_no_fused_multiply_add(vio):
+    """csrc/host_dense.cpp promises the same bits from its baseline, AVX2 and AVX-512 paths (the priors of a stream must not depend on the
+    host they were computed on): none of them may contract a product with the sum behind it.  hipcc compiles the file with -ffp-contract=fast,
+    so the promise is checked where it can break — in the library's x86 code: no vfmadd / vfmsub / vfnmadd instruction at all."""
+    import shutil
+    import subprocess
+    if shutil.which("objdump") is None:
+        pytest.skip("no objdump here")
+    out = subprocess.run(["objdump", "-d", "--no-show-raw-insn", vio.HIP_LIB], capture_output=True, text=True, check=True).stdout
+    fused = [l for l in out.splitlines() if "\tvfmadd" in l or "\tvfmsub" in l or "\tvfnmadd" in l or "\tvfnmsub" in l]
+    assert not fused, fused[:5]
+
+
 def test_abi_version(vio):
     import ctypes as C
     f = vio.load_hip().dll.vio_abi_version

@@ -96,11 +96,21 @@ constexpr int QL_MAXB = 96;                 // rows of a block (the carried colu
 // registers instead of on the stack, so a rotation is one load and one store per eight rows where the 256-bit form has two of each per four.
 // The same operations on every element in the same order (two products and a sum, two products and a difference: no contraction), so the
 // eigenvectors are the bits the other clones give.  The last vector is masked: a column's tail must not touch the next column.
+// (no contraction of a product with the sum that follows it: the other clones have no fused instruction to contract into.  hipcc compiles
+//  this file with -ffp-contract=fast, and the intrinsics' operations carry the flags of the header they come from — a pragma in the caller does
+//  not reach them, and __arithmetic_fence does not hold the backend's contraction back either —, so every product passes through an empty
+//  asm that pins it in a register: no instruction, and nothing to fuse with)
 #if defined(__clang__)
 #define VIO_512_ATTR __attribute__((target("avx512f")))
 #else
 #define VIO_512_ATTR __attribute__((target("avx512f"), optimize("fp-contract=off")))
 #endif
+VIO_512_ATTR static inline __m512d vio_mul512(__m512d a, __m512d b) {
+    __m512d p = _mm512_mul_pd(a, b);
+    asm("" : "+v"(p));
+    return p;
+}
+#define VIO_MUL512(a, b) vio_mul512((a), (b))
 template <int NV>
 VIO_512_ATTR void ql_apply_512(double *V, int n, int r0, int nb, const Rot *rots, size_t from, size_t to, double *carry_io, int &carry_col) {
 #if defined(__clang__)
@@ -129,8 +139,8 @@ VIO_512_ATTR void ql_apply_512(double *V, int n, int r0, int nb, const Rot *rots
         for (int v = 0; v < NV; ++v) {
             const __mmask8 mk = v == NV - 1 ? tail : (__mmask8)0xff;
             const __m512d a = _mm512_maskz_loadu_pd(mk, ci + 8 * v), h = cr[v];
-            const __m512d o = _mm512_add_pd(_mm512_mul_pd(vs, a), _mm512_mul_pd(vc, h));       // ci1[k] = s * a + c * h
-            cr[v] = _mm512_sub_pd(_mm512_mul_pd(vc, a), _mm512_mul_pd(vs, h));                // carry[k] = c * a - s * h
+            const __m512d o = _mm512_add_pd(VIO_MUL512(vs, a), VIO_MUL512(vc, h));       // ci1[k] = s * a + c * h
+            cr[v] = _mm512_sub_pd(VIO_MUL512(vc, a), VIO_MUL512(vs, h));                // carry[k] = c * a - s * h
             _mm512_mask_storeu_pd(ci1 + 8 * v, mk, o);
         }
         cc = i;
@@ -311,7 +321,7 @@ VIO_512_ATTR void axpy_rows_512(const double *x, const double *Y, int nq, int ld
         const __m512d xq = _mm512_set1_pd(x[q]);
         const double *y = Y + (size_t)q * ld + c0;
 #pragma GCC unroll 16
-        for (int v = 0; v < NV; ++v) a[v] = _mm512_add_pd(a[v], _mm512_mul_pd(xq, _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, y + 8 * v)));
+        for (int v = 0; v < NV; ++v) a[v] = _mm512_add_pd(a[v], VIO_MUL512(xq, _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, y + 8 * v)));
     }
 #pragma GCC unroll 16
     for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(acc + c0 + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, a[v]);
@@ -341,10 +351,10 @@ VIO_512_ATTR void sub_scaled_512(double *r, const double *g, double s, int len) 
 #endif
     const __m512d sv = _mm512_set1_pd(s);
     int j = 0;
-    for (; j + 8 <= len; j += 8) _mm512_storeu_pd(r + j, _mm512_sub_pd(_mm512_loadu_pd(r + j), _mm512_mul_pd(_mm512_loadu_pd(g + j), sv)));
+    for (; j + 8 <= len; j += 8) _mm512_storeu_pd(r + j, _mm512_sub_pd(_mm512_loadu_pd(r + j), VIO_MUL512(_mm512_loadu_pd(g + j), sv)));
     if (j < len) {
         const __mmask8 mk = (__mmask8)((1u << (len - j)) - 1u);
-        _mm512_mask_storeu_pd(r + j, mk, _mm512_sub_pd(_mm512_maskz_loadu_pd(mk, r + j), _mm512_mul_pd(_mm512_maskz_loadu_pd(mk, g + j), sv)));
+        _mm512_mask_storeu_pd(r + j, mk, _mm512_sub_pd(_mm512_maskz_loadu_pd(mk, r + j), VIO_MUL512(_mm512_maskz_loadu_pd(mk, g + j), sv)));
     }
 }
 // r[0 .. len) -= D[.] * er + E[.] * dr   (two products, their sum, a difference: tred2's rank-2 update of one row)
@@ -355,12 +365,12 @@ VIO_512_ATTR void rank2_row_512(double *r, const double *D, const double *E, dou
     const __m512d ev = _mm512_set1_pd(er), dv = _mm512_set1_pd(dr);
     int j = 0;
     for (; j + 8 <= len; j += 8) {
-        const __m512d t = _mm512_add_pd(_mm512_mul_pd(_mm512_loadu_pd(D + j), ev), _mm512_mul_pd(_mm512_loadu_pd(E + j), dv));
+        const __m512d t = _mm512_add_pd(VIO_MUL512(_mm512_loadu_pd(D + j), ev), VIO_MUL512(_mm512_loadu_pd(E + j), dv));
         _mm512_storeu_pd(r + j, _mm512_sub_pd(_mm512_loadu_pd(r + j), t));
     }
     if (j < len) {
         const __mmask8 mk = (__mmask8)((1u << (len - j)) - 1u);
-        const __m512d t = _mm512_add_pd(_mm512_mul_pd(_mm512_maskz_loadu_pd(mk, D + j), ev), _mm512_mul_pd(_mm512_maskz_loadu_pd(mk, E + j), dv));
+        const __m512d t = _mm512_add_pd(VIO_MUL512(_mm512_maskz_loadu_pd(mk, D + j), ev), VIO_MUL512(_mm512_maskz_loadu_pd(mk, E + j), dv));
         _mm512_mask_storeu_pd(r + j, mk, _mm512_sub_pd(_mm512_maskz_loadu_pd(mk, r + j), t));
     }
 }
