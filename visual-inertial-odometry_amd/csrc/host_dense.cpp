@@ -56,6 +56,9 @@ void inverse15(const double *cov, double *info) {
 // whenever both arguments are in [1e-150, 1e150] (and zero), std::hypot otherwise (non-finite input included).  Round 6; it moves the last
 // bits of the eigenpairs against earlier rounds — the tolerances to the reference's own solver (another algorithm altogether) are unchanged.
 static inline double vio_hypot(double a, double b) {
+#if defined(__clang__)
+#pragma clang fp contract(off)      // (inlined into routines built for AVX-512 hosts too: a * a + b * b stays a product and a sum everywhere)
+#endif
     const double aa = std::fabs(a), bb = std::fabs(b);
     const double mx = aa > bb ? aa : bb, mn = aa > bb ? bb : aa;
     if (mx < 1e150 && (mn > 1e-150 || mn == 0.0) && mx > 1e-150) return std::sqrt(a * a + b * b);
@@ -111,6 +114,10 @@ VIO_512_ATTR static inline __m512d vio_mul512(__m512d a, __m512d b) {
     return p;
 }
 #define VIO_MUL512(a, b) vio_mul512((a), (b))
+bool have_avx512() {
+    static const bool have = __builtin_cpu_supports("avx512f") && std::getenv("VIO_NO_AVX512") == nullptr;
+    return have;
+}
 template <int NV>
 VIO_512_ATTR void ql_apply_512(double *V, int n, int r0, int nb, const Rot *rots, size_t from, size_t to, double *carry_io, int &carry_col) {
 #if defined(__clang__)
@@ -255,6 +262,106 @@ void ql_generate(QlJob &J) {
     J.avail.store(nr, std::memory_order_release);
     J.done.store(true, std::memory_order_release);
 }
+#ifdef VIO_QL_AVX512
+// One thread, an AVX-512 host, at most 96 rows: ql_generate's loop with every rotation applied where it is generated, the carried column in NV
+// vector registers.  The iteration's scalar chain — a square root and two divisions a rotation, each waiting for the one before — leaves the
+// vector pipes idle and the rotation's 6 n flops need nothing of the chain but (c, s): the core runs the two side by side (generation alone
+// 57 us, application alone 50 at 75 rows on the EPYC 9575F; together, here, the longer of the two).  The 256-bit form of this fusion, with the
+// carried column on the stack, lost (337 against 210 us, round 6); with the column in registers it wins.  The statements of ql_generate in
+// their order, the element operations of ql_apply_512: the same bits.
+template <int NV>
+VIO_512_ATTR void ql_fused_512(QlJob &J) {
+#if defined(__clang__)
+#pragma clang fp contract(off)      // (the scalar chain: this function may use fused instructions, ql_generate's build may not)
+#endif
+    const int n = J.n;
+    double *d = J.d, *e = J.e, *V = J.V;
+    const __mmask8 tail = (n & 7) ? (__mmask8)((1u << (n & 7)) - 1u) : (__mmask8)0xff;
+    __m512d cr[NV];
+#pragma GCC unroll 16
+    for (int v = 0; v < NV; ++v) cr[v] = _mm512_setzero_pd();
+    int cc = -1;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = std::ldexp(1.0, -52);
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }
+        if (m == n) m = n - 1;
+        if (m > l) {
+            int iter = 0;
+            do {
+                if (++iter > 200) { J.ok = false; break; }
+                double g = d[l];
+                double p = (d[l + 1] - g) / (2.0 * e[l]);
+                double r = vio_hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r);
+                d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i];
+                    h = c * p;
+                    r = vio_hypot(p, e[i]);
+                    e[i + 1] = s * r;
+                    s = e[i] / r;
+                    c = p / r;
+                    p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    // the rotation (i, c, s) on the columns i, i + 1 of V (ql_apply_512's element operations)
+                    const double *ci = V + (size_t)i * n;
+                    double *ci1 = V + (size_t)(i + 1) * n;
+                    if (cc != i + 1) {
+                        if (cc >= 0) {
+                            double *pc = V + (size_t)cc * n;
+#pragma GCC unroll 16
+                            for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(pc + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, cr[v]);
+                        }
+#pragma GCC unroll 16
+                        for (int v = 0; v < NV; ++v) cr[v] = _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, ci1 + 8 * v);
+                    }
+                    const __m512d vc = _mm512_set1_pd(c), vs = _mm512_set1_pd(s);
+#pragma GCC unroll 16
+                    for (int v = 0; v < NV; ++v) {
+                        const __mmask8 mk = v == NV - 1 ? tail : (__mmask8)0xff;
+                        const __m512d a = _mm512_maskz_loadu_pd(mk, ci + 8 * v), hh = cr[v];
+                        const __m512d o = _mm512_add_pd(VIO_MUL512(vs, a), VIO_MUL512(vc, hh));
+                        cr[v] = _mm512_sub_pd(VIO_MUL512(vc, a), VIO_MUL512(vs, hh));
+                        _mm512_mask_storeu_pd(ci1 + 8 * v, mk, o);
+                    }
+                    cc = i;
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p;
+                d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1);
+        }
+        d[l] += f;
+        e[l] = 0.0;
+    }
+    if (cc >= 0) {
+        double *pc = V + (size_t)cc * n;
+#pragma GCC unroll 16
+        for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(pc + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, cr[v]);
+    }
+}
+bool ql_fused_wide(QlJob &J) {
+    if (!have_avx512() || J.n < 24 || J.n > 96 || std::getenv("VIO_NO_QL_FUSION") != nullptr) return false;
+    switch ((J.n + 7) / 8) {
+#define VIO_QF_CASE(NV) case NV: ql_fused_512<NV>(J); return true;
+        VIO_QF_CASE(3) VIO_QF_CASE(4) VIO_QF_CASE(5) VIO_QF_CASE(6) VIO_QF_CASE(7) VIO_QF_CASE(8) VIO_QF_CASE(9) VIO_QF_CASE(10) VIO_QF_CASE(11) VIO_QF_CASE(12)
+#undef VIO_QF_CASE
+        default: return false;
+    }
+}
+#endif
 // participant i of nt: 0 generates, then applies to its (small) block; the others apply to theirs as the rotations arrive
 void ql_participant(void *arg, int i, int nt) {
     QlJob &J = *(QlJob *)arg;
@@ -263,6 +370,9 @@ void ql_participant(void *arg, int i, int nt) {
         // (one thread: the whole iteration first, then the rotations block by block — on the round's host 125 + 85 us for 75 rows where the
         //  routine replaced, which applied every rotation where it was generated, took 260; generating and applying in ONE loop with the
         //  carried column, so that the core could overlap the dependent hypot / division chain with the vector work, measured 337: dropped)
+#ifdef VIO_QL_AVX512
+        if (ql_fused_wide(J)) return;
+#endif
         ql_generate(J);
         if (J.overflow.load()) return;
         const size_t total = J.avail.load(std::memory_order_acquire);
@@ -325,10 +435,6 @@ VIO_512_ATTR void axpy_rows_512(const double *x, const double *Y, int nq, int ld
     }
 #pragma GCC unroll 16
     for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(acc + c0 + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, a[v]);
-}
-bool have_avx512() {
-    static const bool have = __builtin_cpu_supports("avx512f") && std::getenv("VIO_NO_AVX512") == nullptr;
-    return have;
 }
 // acc[0 .. n) = sum over q ascending of x[q] Y[q][.]; false: no AVX-512 here
 bool axpy_rows_wide(const double *x, const double *Y, int nq, int ld, int n, double *acc) {
