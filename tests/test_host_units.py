@@ -161,7 +161,7 @@ def test_eigen_solver_on_helper_threads_returns_the_legacy_bits(driver):
     rng = np.random.RandomState(11)
     z = np.load(os.path.join(GOLDEN_DIR, "symmetric_eigen.npz"))
     mats = [np.ascontiguousarray(z["A_small"]), np.ascontiguousarray(z["A_prior"])]
-    for n in (1, 2, 31, 32, 33, 75, 101):
+    for n in (1, 2, 23, 24, 31, 32, 33, 75, 96, 97, 101, 156):      # (24 .. 96: the fused AVX-512 iteration; 97 and up: row blocks of 96)
         J = rng.normal(size=(n + 2 if n % 2 else max(n // 2, 1), n)) * 10.0 ** rng.uniform(-2, 4)
         mats.append(J.T @ J)                   # (full rank, and rank-deficient: eigenvalues at the rounding level)
     Z = mats[-2].copy()
