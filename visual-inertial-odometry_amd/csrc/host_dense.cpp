@@ -281,6 +281,8 @@ VIO_512_ATTR void ql_fused_512(QlJob &J) {
 #pragma GCC unroll 16
     for (int v = 0; v < NV; ++v) cr[v] = _mm512_setzero_pd();
     int cc = -1;
+    int pi = -1;                    // the rotation that still waits for its columns: (pi, pcs, psn)
+    double pcs = 1.0, psn = 0.0;
     double f = 0.0, tst1 = 0.0;
     const double eps = std::ldexp(1.0, -52);
     for (int l = 0; l < n; ++l) {
@@ -315,28 +317,36 @@ VIO_512_ATTR void ql_fused_512(QlJob &J) {
                     c = p / r;
                     p = c * d[i] - s * g;
                     d[i + 1] = h + s * (c * g + s * d[i]);
-                    // the rotation (i, c, s) on the columns i, i + 1 of V (ql_apply_512's element operations)
-                    const double *ci = V + (size_t)i * n;
-                    double *ci1 = V + (size_t)(i + 1) * n;
-                    if (cc != i + 1) {
-                        if (cc >= 0) {
-                            double *pc = V + (size_t)cc * n;
+                    // The rotation generated one step ago goes on the columns now (ql_apply_512's element operations), BEHIND this step's scalar
+                    // chain in program order: the core's schedulers serve the oldest ready instruction first, so the chain — a square root and two
+                    // divisions waiting for each other — keeps its pace and the 6 n vector flops of the previous rotation fill the pipes under
+                    // its latencies (with the rotation applied in front of the next step's chain the two added up: 97 us at 75 rows against
+                    // 57 + 50 apart).  The rotations reach V in the order they are generated, one step late.
+                    asm volatile("" ::: "memory");           // (the compiler keeps the order too: the chain's statements above, the columns below)
+                    if (pi >= 0) {
+                        const double *ci = V + (size_t)pi * n;
+                        double *ci1 = V + (size_t)(pi + 1) * n;
+                        if (cc != pi + 1) {
+                            if (cc >= 0) {
+                                double *pc = V + (size_t)cc * n;
 #pragma GCC unroll 16
-                            for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(pc + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, cr[v]);
+                                for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(pc + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, cr[v]);
+                            }
+#pragma GCC unroll 16
+                            for (int v = 0; v < NV; ++v) cr[v] = _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, ci1 + 8 * v);
                         }
+                        const __m512d vc = _mm512_set1_pd(pcs), vs = _mm512_set1_pd(psn);
 #pragma GCC unroll 16
-                        for (int v = 0; v < NV; ++v) cr[v] = _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, ci1 + 8 * v);
+                        for (int v = 0; v < NV; ++v) {
+                            const __mmask8 mk = v == NV - 1 ? tail : (__mmask8)0xff;
+                            const __m512d a = _mm512_maskz_loadu_pd(mk, ci + 8 * v), hh = cr[v];
+                            const __m512d o = _mm512_add_pd(VIO_MUL512(vs, a), VIO_MUL512(vc, hh));
+                            cr[v] = _mm512_sub_pd(VIO_MUL512(vc, a), VIO_MUL512(vs, hh));
+                            _mm512_mask_storeu_pd(ci1 + 8 * v, mk, o);
+                        }
+                        cc = pi;
                     }
-                    const __m512d vc = _mm512_set1_pd(c), vs = _mm512_set1_pd(s);
-#pragma GCC unroll 16
-                    for (int v = 0; v < NV; ++v) {
-                        const __mmask8 mk = v == NV - 1 ? tail : (__mmask8)0xff;
-                        const __m512d a = _mm512_maskz_loadu_pd(mk, ci + 8 * v), hh = cr[v];
-                        const __m512d o = _mm512_add_pd(VIO_MUL512(vs, a), VIO_MUL512(vc, hh));
-                        cr[v] = _mm512_sub_pd(VIO_MUL512(vc, a), VIO_MUL512(vs, hh));
-                        _mm512_mask_storeu_pd(ci1 + 8 * v, mk, o);
-                    }
-                    cc = i;
+                    pi = i; pcs = c; psn = s;
                 }
                 p = -s * s2 * c3 * el1 * e[l] / dl1;
                 e[l] = s * p;
@@ -345,6 +355,29 @@ VIO_512_ATTR void ql_fused_512(QlJob &J) {
         }
         d[l] += f;
         e[l] = 0.0;
+    }
+    if (pi >= 0) {                  // the last rotation
+        const double *ci = V + (size_t)pi * n;
+        double *ci1 = V + (size_t)(pi + 1) * n;
+        if (cc != pi + 1) {
+            if (cc >= 0) {
+                double *pc = V + (size_t)cc * n;
+#pragma GCC unroll 16
+                for (int v = 0; v < NV; ++v) _mm512_mask_storeu_pd(pc + 8 * v, v == NV - 1 ? tail : (__mmask8)0xff, cr[v]);
+            }
+#pragma GCC unroll 16
+            for (int v = 0; v < NV; ++v) cr[v] = _mm512_maskz_loadu_pd(v == NV - 1 ? tail : (__mmask8)0xff, ci1 + 8 * v);
+        }
+        const __m512d vc = _mm512_set1_pd(pcs), vs = _mm512_set1_pd(psn);
+#pragma GCC unroll 16
+        for (int v = 0; v < NV; ++v) {
+            const __mmask8 mk = v == NV - 1 ? tail : (__mmask8)0xff;
+            const __m512d a = _mm512_maskz_loadu_pd(mk, ci + 8 * v), hh = cr[v];
+            const __m512d o = _mm512_add_pd(VIO_MUL512(vs, a), VIO_MUL512(vc, hh));
+            cr[v] = _mm512_sub_pd(VIO_MUL512(vc, a), VIO_MUL512(vs, hh));
+            _mm512_mask_storeu_pd(ci1 + 8 * v, mk, o);
+        }
+        cc = pi;
     }
     if (cc >= 0) {
         double *pc = V + (size_t)cc * n;
