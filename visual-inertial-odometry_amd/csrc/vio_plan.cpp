@@ -323,8 +323,16 @@ void build_pattern_tables(Pattern &pt, int g_max, int threads, int lds_budget, L
     for (int k = 0; k < K; ++k) kof[pt.tslot[k]] = k;
     pt.n_rows = item_nbp(nb) * 6 + 3 * nb;
     int G = std::max(1, std::min(g_max, threads / K));                     // one thread per observation in k_linearize's phase 1
-    while (G > 1 && lds(G, K, nb, pt.use_ext) > lds_budget) --G;
-    while (G > 1 && (6 * nb + 2) * G > 7 * threads) --G;                   // k_linearize stages the item's Schur rows with 7 loads per thread
+    G = std::max(1, std::min(G, 7 * threads / (6 * nb + 2)));              // k_linearize stages the item's Schur rows with 7 loads per thread
+    if (G > 1 && lds(G, K, nb, pt.use_ext) > lds_budget) {
+        // the largest G the LDS holds (the size grows with G: by bisection — one G at a time this loop was most of a small window's pattern pass)
+        int lo = 1, hi = G;                                                // lo fits (or is 1), hi does not
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) / 2;
+            if (lds(mid, K, nb, pt.use_ext) > lds_budget) hi = mid; else lo = mid;
+        }
+        G = lo;
+    }
     pt.G = G;
     pt.lds_doubles = lds(G, K, nb, pt.use_ext);
 }
