@@ -1027,10 +1027,12 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
     for (int i = 0; i < m2; ++i)
         for (int j = 0; j < m2; ++j) Amm[i * m2 + j] = 0.5 * (Hp_(n2 + i, n2 + j) + Hp_(n2 + j, n2 + i));
     symmetric_eigen(m2, Amm, ev, V);
+    double evinv[m2];                                             // (the quotient once per eigenvalue, not once per term: 3 375 divisions before)
+    for (int k = 0; k < m2; ++k) evinv[k] = ev[k] > eps ? 1.0 / ev[k] : 0.0;
     for (int i = 0; i < m2; ++i)
         for (int j = 0; j < m2; ++j) {
             double s = 0;
-            for (int k = 0; k < m2; ++k) s += V[i * m2 + k] * (ev[k] > eps ? 1.0 / ev[k] : 0.0) * V[j * m2 + k];
+            for (int k = 0; k < m2; ++k) s += V[i * m2 + k] * evinv[k] * V[j * m2 + k];
             Ainv[i * m2 + j] = s;
         }
     TT(0);
@@ -1039,9 +1041,10 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
     // of tempB and yields zeros whatever it is multiplied with: only the others are formed.
     int rowlive[n2], nr = 0;
     for (int i = 0; i < n2; ++i) {
-        bool any = false;
         const double *hr = Hin + (size_t)order[i] * n;            // (the whole row, in whatever order: any non-zero?)
-        for (int j = 0; j < n && !any; ++j) any = hr[j] != 0.0;
+        int anyi = 0;                                             // (no early exit: a dead row is read to its end anyway, and the plain loop vectorises)
+        for (int j = 0; j < n; ++j) anyi |= (hr[j] != 0.0);
+        bool any = anyi != 0;
         for (int j = n2; j < n && !any; ++j) any = Hp_(j, i) != 0.0;      // the marginalised rows' entries in column i (Amr)
         if (any) rowlive[nr++] = i;
     }
