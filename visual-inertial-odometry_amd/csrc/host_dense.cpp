@@ -951,6 +951,15 @@ template <typename F> void par_rows(const Par *par, int count, int grain, F &f) 
 }
 }  // namespace
 
+// A scratch array of the calling thread that keeps its storage from call to call (every user writes what it reads: nothing relies on zeros; a
+// fresh std::vector per call is an allocation and 45 KB of zero fill each, eight of them in one marginalize_tail)
+namespace {
+struct Scratch {
+    std::vector<double> v;
+    double *get(size_t n) { if (v.size() < n) v.resize(n); return v.data(); }
+};
+}  // namespace
+
 // rows [a0, a1) of H_prior = (V S) V^T over the kept eigenpairs (problem.cc:775-778): entry (a, c) = sum over q ascending of VS[a][q] VKt[q][c], a
 // whole row of c at a time with q outside — every entry's additions in the order of the dot product they replace, nl independent chains
 // instead of one dependent one (a function of its own so that it exists in the AVX2 clone: a lambda inside marginalize_tail does not)
@@ -1049,7 +1058,9 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
         if (any) rowlive[nr++] = i;
     }
     TT(1);
-    std::vector<double> tempB((size_t)std::max(nr, 1) * m2), Hpc((size_t)std::max(nr, 1) * std::max(nr, 1)), Amr((size_t)m2 * std::max(nr, 1)), bp(n2);
+    static thread_local Scratch s_tempB, s_Hpc, s_Amr, s_Hc, s_Vc, s_VS, s_VK, s_VKt;
+    double *tempB = s_tempB.get((size_t)std::max(nr, 1) * m2), *Hpc = s_Hpc.get((size_t)std::max(nr, 1) * std::max(nr, 1)), *Amr = s_Amr.get((size_t)m2 * std::max(nr, 1));
+    std::vector<double> bp(n2);
     for (int k = 0; k < m2; ++k)
         for (int c = 0; c < nr; ++c) Amr[(size_t)k * nr + c] = Hp_(n2 + k, rowlive[c]);
     for (int i = 0; i < n2; ++i) bp[i] = bin[order[i]] - 0.0;
@@ -1065,7 +1076,7 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
             {   // (the 15-term sums of a row's entries side by side, k outside: the same additions per entry)
                 double *hrow = &Hpc[(size_t)a * nr];
 #ifdef VIO_QL_AVX512
-                if (!axpy_rows_wide(&tempB[(size_t)a * m2], Amr.data(), m2, nr, nr, hrow))
+                if (!axpy_rows_wide(&tempB[(size_t)a * m2], Amr, m2, nr, nr, hrow))
 #endif
                 {
                     for (int c = 0; c < nr; ++c) hrow[c] = 0.0;
@@ -1095,11 +1106,12 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
         if (any) { live[nl] = rowlive[a]; lpos[nl] = a; ++nl; }
     }
     const int nz = n2 - nl;
-    std::vector<double> Hc((size_t)std::max(nl, 1) * std::max(nl, 1)), evc(std::max(nl, 1)), Vc((size_t)std::max(nl, 1) * std::max(nl, 1));
+    double *Hc = s_Hc.get((size_t)std::max(nl, 1) * std::max(nl, 1)), *Vc = s_Vc.get((size_t)std::max(nl, 1) * std::max(nl, 1));
+    std::vector<double> evc(std::max(nl, 1));
     for (int a = 0; a < nl; ++a)
         for (int c = 0; c < nl; ++c) Hc[(size_t)a * nl + c] = Hpc[(size_t)lpos[a] * nr + lpos[c]];
     TT(3);
-    if (nl > 0) symmetric_eigen(nl, Hc.data(), evc.data(), Vc.data(), par);
+    if (nl > 0) symmetric_eigen(nl, Hc, evc.data(), Vc, par);
     TT(4);
     // In the 156-system the eigenvalues are: nz zeros (the unit vectors of the dead indices), then the live block's, ascending: eigenpair
     // k of the live block is number nz + k.  (A negative eigenvalue of the live block would sort before the zeros in the reference;
@@ -1120,18 +1132,18 @@ int marginalize_tail(double *Hin, double *bin, int frame, double *Hout, double *
     TT(5);
     {   // H_prior = J^T J with J = sqrt(S) V^T (problem.cc:775-777): sum over the kept k of V_ik s_k V_jk, k ascending; the
         // kept eigenvectors live on the live indices only, every other entry of the product is an exact zero
-        std::vector<double> VS((size_t)std::max(nl, 1) * std::max(nk, 1)), VK((size_t)std::max(nl, 1) * std::max(nk, 1));
+        double *VS = s_VS.get((size_t)std::max(nl, 1) * std::max(nk, 1)), *VK = s_VK.get((size_t)std::max(nl, 1) * std::max(nk, 1));
         for (int a = 0; a < nl; ++a)
             for (int q = 0; q < nk; ++q) { VK[(size_t)a * nk + q] = Vc[(size_t)a * nl + kept[q]]; VS[(size_t)a * nk + q] = VK[(size_t)a * nk + q] * evc[kept[q]]; }
         std::fill(Hout, Hout + (size_t)n2 * n2, 0.0);
         // (entry (a, c) = sum over q ascending of VS[a][q] VK[c][q]: formed for a whole row of c at once, the q loop outside — every entry's
         //  additions in the same order as the dot product they replace, but 75 independent chains instead of one dependent one)
-        std::vector<double> VKt((size_t)std::max(nk, 1) * std::max(nl, 1));
+        double *VKt = s_VKt.get((size_t)std::max(nk, 1) * std::max(nl, 1));
         for (int c = 0; c < nl; ++c)
             for (int q = 0; q < nk; ++q) VKt[(size_t)q * nl + c] = VK[(size_t)c * nk + q];
         auto prior_rows = [&](int a0, int a1) {
             std::vector<double> accv((size_t)std::max(nl, 1));
-            prior_product_rows(a0, a1, VS.data(), VKt.data(), nk, nl, live, Hout, n2, accv.data());
+            prior_product_rows(a0, a1, VS, VKt, nk, nl, live, Hout, n2, accv.data());
         };
         par_rows(par, nl, 16, prior_rows);
     }
