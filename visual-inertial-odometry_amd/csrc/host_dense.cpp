@@ -712,7 +712,10 @@ bool symmetric_eigen(int n, const double *Ain, double *d, double *Vout, const Pa
 #else
 #define ET(k) do { } while (0)
 #endif
-    std::vector<double> Vv((size_t)n * n), ev(n);
+    // (the work matrix: scratch of the calling thread, every entry written before it is read — a fresh vector was an allocation and n^2 zeros a call)
+    static thread_local std::vector<double> Vv, ev;
+    if (Vv.size() < (size_t)n * n) Vv.resize((size_t)n * n);
+    if (ev.size() < (size_t)n) ev.resize((size_t)n);
     double *V = Vv.data(), *e = ev.data();
     auto at = [&](int i, int j) -> double & { return V[(size_t)j * n + i]; };
 #ifdef VIO_QL_AVX512
