@@ -402,7 +402,6 @@ vio_status build_plan(vio_ctx *c, Plan &pl, int marg) {
     in.lds = lds_fn; in.lds_xyz = lds_xyz_fn;
     in.imu_item_lds = IMU_ITEM_LDS_DOUBLES;
     vio_plan::Output out;
-    out.patterns.swap(pl.patterns); out.items.swap(pl.items); out.sorted_to_orig.swap(pl.sorted_to_orig);      // (their storage is used again)
     const bool ok = xyz ? vio_plan::plan_xyz(in, out, arena_alloc, &c->arena) : vio_plan::plan_invdepth(in, out, arena_alloc, &c->arena);
     if (!ok) return fail(c, (vio_status)out.status, out.status == VIO_ERR_HIP ? "hipHostMalloc (staging)" : out.err);
     pl.patterns.swap(out.patterns); pl.items.swap(out.items); pl.sorted_to_orig.swap(out.sorted_to_orig);

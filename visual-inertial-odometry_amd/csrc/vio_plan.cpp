@@ -396,12 +396,7 @@ bool plan_invdepth(const Input &in, Output &out, AllocFn alloc, void *user) {
     // (a landmark-major list — what the reference's loop emits — is its own CSR: observation k of landmark l is obs_off[l] + k)
     struct ObsRange { const int32_t *p; size_t n; int32_t base; size_t size() const { return n; } bool empty() const { return n == 0; }
                       int32_t operator[](size_t i) const { return p ? p[i] : base + (int32_t)i; } };
-    // (the pass's work arrays are scratch of the calling thread: at 20 000 landmarks they are 600 KB, and fresh vectors of that size come from mmap —
-    //  a page fault per 4 KB, every frame)
-    static thread_local std::vector<int64_t> obs_off, fill;
-    static thread_local std::vector<int32_t> lm_pattern;
-    static thread_local std::vector<uint64_t> packed_of;
-    obs_off.assign((size_t)N + 1, 0);
+    std::vector<int64_t> obs_off(N + 1, 0);
     for (int64_t e = 0; e < M; ++e) ++obs_off[in.olm[e] + 1];
     for (int64_t l = 0; l < N; ++l) obs_off[l + 1] += obs_off[l];
     const bool lm_major = in.lm_major;
@@ -409,7 +404,7 @@ bool plan_invdepth(const Input &in, Output &out, AllocFn alloc, void *user) {
     obs_idx.clear();
     if (!lm_major) {
         obs_idx.resize(std::max<int64_t>(M, 1));
-        fill.assign(obs_off.begin(), obs_off.end() - 1);
+        std::vector<int64_t> fill(obs_off.begin(), obs_off.end() - 1);
         for (int64_t e = 0; e < M; ++e) obs_idx[fill[in.olm[e]]++] = (int32_t)e;
     }
     auto obs_of = [&](int64_t l) { return ObsRange{lm_major ? nullptr : obs_idx.data() + obs_off[l], (size_t)(obs_off[l + 1] - obs_off[l]), (int32_t)obs_off[l]}; };
@@ -420,10 +415,10 @@ bool plan_invdepth(const Input &in, Output &out, AllocFn alloc, void *user) {
     int pat_cache_id[256];
     for (int q = 0; q < 256; ++q) pat_cache_id[q] = -1;
     out.patterns.clear();
-    lm_pattern.assign((size_t)N, -1);
+    std::vector<int32_t> lm_pattern(N, -1);
     const bool vouched = lm_major && in.vouched;
     if (!vouched && M > 0 && !in.pts_i) return fail(out, ERR_UNSUPPORTED, "the per-edge host observations are needed for a list the scan did not vouch for");
-    if (packed_of.size() < (size_t)std::max<int64_t>(N, 1)) packed_of.resize((size_t)std::max<int64_t>(N, 1));
+    std::vector<uint64_t> packed_of((size_t)std::max<int64_t>(N, 1));
     {
         PatKeys pk;
         pk.in = &in; pk.obs_off = obs_off.data(); pk.obs_idx = lm_major ? nullptr : obs_idx.data(); pk.vouched = vouched; pk.packed = packed_of.data(); pk.N = N;
